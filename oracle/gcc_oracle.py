@@ -1,0 +1,694 @@
+"""CPU oracle for the GCC Pix2Pix hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+This file is a from-scratch, *functional* restatement (plain PyTorch-CPU fp32, parameters held in a
+flat ``dict`` keyed by the reference's ``state_dict`` names) of what one iteration of the
+reference's ``Pix2PixModel`` computes.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it; the product (``gcc_amd``) never does and fails
+loudly when its HIP library is missing.
+
+Parity status: PINNED.  ``tests/golden/make_fixtures.py`` imports the real reference
+(``/root/reference``, stub-imported as SURVEY.md Appendix B describes) in the authoring container
+and stores its outputs (eval images, hooked features, every loss scalar, post-step weights / BN
+running statistics / alpha, prune cfgs) under ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``
+checks every function here against those vectors.
+
+Reference anchors (all relative to /root/reference):
+  unet_forward ............ models/Pix2Pix.py:20-130   (UnetSkipConnectionBlock / UnetGenertor)
+  patchgan_forward ........ models/Pix2Pix.py:267-348  (NLayerDiscriminator / MaskNLayerDiscriminator)
+  gate_mask / gate ........ models/DifferentiableOp.py:22-59
+  gan_loss ................ models/GANLoss.py:38-59
+  gram .................... models/Pix2Pix.py:733-740
+  Pix2PixOracle.optimize_parameters  models/Pix2Pix.py:464-583
+  Pix2PixOracle.optimizer_netD_arch  models/Pix2Pix.py:479-511, 585-593
+  adam_step ............... torch.optim.Adam as configured at models/Pix2Pix.py:382,415,430-431
+  lr_lambda_linear ........ utils/util.py:288-303
+  scale_prune_cfg / norm_prune_cfg / max_min_* ... models/Pix2Pix.py:754-902
+
+The in-place aliasing of the reference (SURVEY.md hazard H1) is restated *explicitly*: the skip
+concatenation and the hooked tensors are written as the post-activation values the reference ends
+up reading, instead of relying on in-place mutation.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+LRELU = 0.2
+
+
+# ----------------------------------------------------------------------------------------------
+# names
+# ----------------------------------------------------------------------------------------------
+def unet_block_prefix(d: int) -> str:
+    """state_dict prefix of the U-Net block at depth d (0 = outermost). models/Pix2Pix.py:85-127."""
+    if d == 0:
+        return 'model'
+    return 'model.model.1' + '.model.3' * (d - 1)
+
+
+def unet_dropout_depths(num_downs: int) -> List[int]:
+    """Depths whose up path ends in Dropout(0.5): the ``num_downs-5`` blocks built by the loop at
+    models/Pix2Pix.py:95-102 (they sit directly above the innermost block)."""
+    return [num_downs - 2 - i for i in range(num_downs - 5)]
+
+
+def unet_hook_names(num_downs: int = 8) -> List[str]:
+    """models/Pix2Pix.py:366-369"""
+    return ['model.model.1.model.2',
+            'model.model.1.model.3.model.3.model.2',
+            'model.model.1.model.3.model.3.model.4',
+            'model.model.1.model.4']
+
+
+# ----------------------------------------------------------------------------------------------
+# small ops
+# ----------------------------------------------------------------------------------------------
+def batch_norm(sd: SD, prefix: str, x: Tensor, train: bool) -> Tensor:
+    """nn.BatchNorm2d(affine, track_running_stats), momentum .1, eps 1e-5.  In train mode the
+    running statistics in ``sd`` are updated in place (unbiased variance), like the module."""
+    w, b = sd[prefix + '.weight'], sd[prefix + '.bias']
+    rm, rv = sd[prefix + '.running_mean'], sd[prefix + '.running_var']
+    if train:
+        n = x.numel() // x.shape[1]
+        mean = x.mean(dim=(0, 2, 3))
+        var = x.var(dim=(0, 2, 3), unbiased=False)
+        with torch.no_grad():
+            rm.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean.detach())
+            rv.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * var.detach() * (n / max(n - 1, 1)))
+            key = prefix + '.num_batches_tracked'
+            if key in sd:
+                sd[key] += 1
+    else:
+        mean, var = rm, rv
+    xhat = (x - mean[None, :, None, None]) * torch.rsqrt(var[None, :, None, None] + BN_EPS)
+    return xhat * w[None, :, None, None] + b[None, :, None, None]
+
+
+def gate_mask(alpha: Tensor, threshold: float) -> Tensor:
+    """(sign(alpha - tau) + 1) / 2  --  alpha == tau gives 0.5.  models/DifferentiableOp.py:25-26"""
+    return (torch.sign(alpha - threshold) + 1) / 2
+
+
+class _MaskSTE(torch.autograd.Function):
+    """Straight-through: d mask / d alpha := 1.  models/DifferentiableOp.py:22-32"""
+
+    @staticmethod
+    def forward(ctx, alpha, threshold):
+        return gate_mask(alpha, threshold)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.clone(), None
+
+
+def gate(x: Tensor, alpha: Tensor, threshold: float) -> Tensor:
+    """y = x * m[c]; dalpha[c] = sum_{n,h,w} dy*x (no mask factor), dx = dy*m."""
+    m = _MaskSTE.apply(alpha, threshold)
+    return x * m[None, :, None, None]
+
+
+def gan_loss(mode: str, pred: Tensor, target_is_real: bool, for_discriminator: bool = True) -> Tensor:
+    """models/GANLoss.py:38-59"""
+    if mode == 'lsgan':
+        t = torch.ones_like(pred) if target_is_real else torch.zeros_like(pred)
+        return F.mse_loss(pred, t)
+    if mode == 'vanilla':
+        t = torch.ones_like(pred) if target_is_real else torch.zeros_like(pred)
+        return F.binary_cross_entropy_with_logits(pred, t)
+    if mode == 'wgangp':
+        return -pred.mean() if target_is_real else pred.mean()
+    if mode == 'hinge':
+        if for_discriminator:
+            z = (pred - 1) if target_is_real else (-pred - 1)
+            return -torch.clamp(z, max=0.0).mean()
+        assert target_is_real
+        return -pred.mean()
+    raise NotImplementedError('gan mode %s not implemented' % mode)
+
+
+def gram(x: Tensor) -> Tensor:
+    """G = F F^T / (c h w), F = x.view(b, c, hw).  models/Pix2Pix.py:733-740"""
+    b, c, h, w = x.shape
+    f = x.reshape(b, c, h * w)
+    return torch.bmm(f, f.transpose(1, 2)) / (c * h * w)
+
+
+def rmse(a: Tensor, b: Tensor) -> Tensor:
+    return torch.sqrt(F.mse_loss(a, b))
+
+
+# ----------------------------------------------------------------------------------------------
+# U-Net generator
+# ----------------------------------------------------------------------------------------------
+def unet_forward(sd: SD, x: Tensor, num_downs: int = 8, train: bool = True,
+                 dropout: bool = False, dropout_masks: Optional[Dict[int, Tensor]] = None,
+                 features: Optional[OrderedDict] = None) -> Tensor:
+    """8-down / 8-up U-Net with forced BatchNorm (models/Pix2Pix.py:26), written depth by depth.
+
+    e[d]  : pre-activation output of the down conv (+BN for 0<d<D-1) at depth d
+    u     : output of the up conv + BN at a depth
+    skip  : because the reference's LeakyReLU is in-place, the tensor concatenated at depth d is
+            leaky_relu(e[d-1]), and the tensor a hook on the down-BN sees is leaky_relu(e[d]).
+    ``features`` (if given) receives the four hooked tensors under the reference's module names.
+    ``dropout_masks[d]`` optionally injects the (already 1/(1-p)-scaled) mask for depth d.
+    """
+    D = num_downs
+    hook = unet_hook_names(D)
+    drop_depths = unet_dropout_depths(D) if dropout else []
+
+    def conv(t, key):
+        return F.conv2d(t, sd[key + '.weight'], sd.get(key + '.bias'), stride=2, padding=1)
+
+    def convT(t, key):
+        return F.conv_transpose2d(t, sd[key + '.weight'], sd.get(key + '.bias'), stride=2, padding=1)
+
+    e: List[Tensor] = [None] * D
+    e[0] = conv(x, 'model.model.0')
+    for d in range(1, D):
+        p = unet_block_prefix(d)
+        z = conv(F.leaky_relu(e[d - 1], LRELU), p + '.model.1')
+        if d < D - 1:
+            z = batch_norm(sd, p + '.model.2', z, train)
+            if features is not None and (p + '.model.2') in hook:
+                features[p + '.model.2'] = F.leaky_relu(z, LRELU)       # hazard H1
+        e[d] = z
+
+    p = unet_block_prefix(D - 1)
+    u = batch_norm(sd, p + '.model.4', convT(F.relu(e[D - 1]), p + '.model.3'), train)
+    cat = torch.cat([F.leaky_relu(e[D - 2], LRELU), u], 1)
+    for d in range(D - 2, 0, -1):
+        p = unet_block_prefix(d)
+        r = F.relu(cat)
+        if features is not None and (p + '.model.4') in hook:
+            features[p + '.model.4'] = r
+        u = batch_norm(sd, p + '.model.6', convT(r, p + '.model.5'), train)
+        if d in drop_depths and train:
+            if dropout_masks is not None and d in dropout_masks:
+                u = u * dropout_masks[d]
+            else:
+                u = F.dropout(u, 0.5, True)
+        cat = torch.cat([F.leaky_relu(e[d - 1], LRELU), u], 1)
+    out = torch.tanh(convT(F.relu(cat), 'model.model.3'))
+    if features is not None:       # keep the reference's hook-firing order
+        for k in hook:
+            if k in features:
+                features.move_to_end(k)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# PatchGAN discriminators
+# ----------------------------------------------------------------------------------------------
+def patchgan_layout(masked: bool, n_layers: int = 3):
+    """Sequential indices of (conv, bn, gate) per layer.  models/Pix2Pix.py:280-300 / 320-343"""
+    L = []
+    if not masked:
+        L.append((0, None, None))
+        i = 2
+        for _ in range(n_layers):
+            L.append((i, i + 1, None))
+            i += 3
+        L.append((i, None, None))
+    else:
+        L.append((0, None, 2))
+        i = 3
+        for _ in range(n_layers):
+            L.append((i, i + 1, i + 2))
+            i += 4
+        L.append((i, None, None))
+    return L
+
+
+def patchgan_forward(sd: SD, x: Tensor, masked: bool = False, threshold: float = 0.5,
+                     train: bool = True, features: Optional[OrderedDict] = None,
+                     hook_names: Sequence[str] = ()) -> Tensor:
+    """conv(k4 s2)+LReLU [+gate]; 2x conv(k4 s2)+BN[+gate]+LReLU; conv(k4 s1)+BN[+gate]+LReLU;
+    conv(k4 s1)->1.  Plain D: a hook on a BN sees the post-LeakyReLU tensor (in-place, H1).
+    Masked D: the gate multiplies out-of-place, so a hook on a BN sees the raw BN output."""
+    lay = patchgan_layout(masked)
+    h = x
+    n = len(lay)
+    for li, (ci, bi, gi) in enumerate(lay):
+        stride = 2 if li < n - 2 else 1
+        h = F.conv2d(h, sd['model.%d.weight' % ci], sd.get('model.%d.bias' % ci), stride=stride, padding=1)
+        if li == n - 1:
+            break
+        if bi is not None:
+            h = batch_norm(sd, 'model.%d' % bi, h, train)
+            raw_bn = h
+        if li == 0:
+            h = F.leaky_relu(h, LRELU)
+            if gi is not None:
+                h = gate(h, sd['model.%d.alpha' % gi], threshold)
+        else:
+            if gi is not None:
+                h = gate(h, sd['model.%d.alpha' % gi], threshold)
+            h = F.leaky_relu(h, LRELU)
+        if features is not None and bi is not None and ('model.%d' % bi) in hook_names:
+            features['model.%d' % bi] = raw_bn if masked else h
+    return h
+
+
+# ----------------------------------------------------------------------------------------------
+# init / optimizer / schedule
+# ----------------------------------------------------------------------------------------------
+@torch.no_grad()
+def adam_step(params: List[Tensor], grads: List[Tensor], state: dict, lr: float,
+              betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+    """torch.optim.Adam (no weight decay, no amsgrad): one step, in place on ``params``."""
+    state['step'] = state.get('step', 0) + 1
+    t = state['step']
+    b1, b2 = betas
+    if 'm' not in state:
+        state['m'] = [torch.zeros_like(p) for p in params]
+        state['v'] = [torch.zeros_like(p) for p in params]
+    bc1 = 1 - b1 ** t
+    bc2 = 1 - b2 ** t
+    for p, g, m, v in zip(params, grads, state['m'], state['v']):
+        if g is None:
+            continue
+        m.lerp_(g, 1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def lr_lambda_linear(epoch: int, epoch_count: int, n_epochs: int, n_epochs_decay: int) -> float:
+    """utils/util.py:291-293"""
+    return 1.0 - max(0, epoch + epoch_count - n_epochs) / float(n_epochs_decay + 1)
+
+
+def init_state_dict(shapes: Dict[str, Tuple[int, ...]], gen: torch.Generator) -> SD:
+    """utils/util.py:261-286 semantics on a name->shape table (conv W~N(0,.02), conv b=0,
+    BN gamma~N(1,.02), BN beta~N(0,1), running stats 0/1, alpha=1)."""
+    sd: SD = {}
+    for k, shp in shapes.items():
+        if k.endswith('running_mean'):
+            sd[k] = torch.zeros(shp)
+        elif k.endswith('running_var'):
+            sd[k] = torch.ones(shp)
+        elif k.endswith('num_batches_tracked'):
+            sd[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith('alpha'):
+            sd[k] = torch.ones(shp)
+        elif len(shp) == 4:
+            sd[k] = torch.randn(shp, generator=gen) * 0.02
+        elif k.endswith('.weight'):
+            sd[k] = 1.0 + torch.randn(shp, generator=gen) * 0.02
+        elif k.endswith('.bias'):
+            # conv bias -> 0 ; BN bias -> N(0,1).  A conv bias belongs to a module whose weight is 4-d.
+            wk = k[:-5] + '.weight'
+            if wk in shapes and len(shapes[wk]) == 4:
+                sd[k] = torch.zeros(shp)
+            else:
+                sd[k] = torch.randn(shp, generator=gen)
+    return sd
+
+
+def unet_shapes(ngf: int, num_downs: int = 8, in_nc: int = 3, out_nc: int = 3) -> Dict[str, Tuple[int, ...]]:
+    """Parameter/buffer shapes of UnetGenertor(filter_cfgs=None).  models/Pix2Pix.py:85-127"""
+    D = num_downs
+    width = [min(ngf * 2 ** d, ngf * 8) for d in range(D)]       # e[d] channels
+    shp: Dict[str, Tuple[int, ...]] = OrderedDict()
+
+    def bn(key, c):
+        shp[key + '.weight'] = (c,)
+        shp[key + '.bias'] = (c,)
+        shp[key + '.running_mean'] = (c,)
+        shp[key + '.running_var'] = (c,)
+        shp[key + '.num_batches_tracked'] = ()
+
+    shp['model.model.0.weight'] = (width[0], in_nc, 4, 4)
+    for d in range(1, D):
+        p = unet_block_prefix(d)
+        shp[p + '.model.1.weight'] = (width[d], width[d - 1], 4, 4)
+        if d < D - 1:
+            bn(p + '.model.2', width[d])
+    # up path: depth d up-conv maps (cat of depth d+1 | e[D-1]) -> width[d-1]
+    p = unet_block_prefix(D - 1)
+    shp[p + '.model.3.weight'] = (width[D - 1], width[D - 2], 4, 4)
+    bn(p + '.model.4', width[D - 2])
+    for d in range(D - 2, 0, -1):
+        p = unet_block_prefix(d)
+        shp[p + '.model.5.weight'] = (2 * width[d], width[d - 1], 4, 4)
+        bn(p + '.model.6', width[d - 1])
+    shp['model.model.3.weight'] = (2 * width[0], out_nc, 4, 4)
+    shp['model.model.3.bias'] = (out_nc,)
+    return shp
+
+
+def patchgan_shapes(ndf: int, in_nc: int = 6, masked: bool = False, n_layers: int = 3):
+    shp: Dict[str, Tuple[int, ...]] = OrderedDict()
+    lay = patchgan_layout(masked, n_layers)
+    chans = [ndf * min(2 ** i, 8) for i in range(n_layers + 1)]
+    cin = in_nc
+    for li, (ci, bi, gi) in enumerate(lay):
+        cout = chans[li] if li < len(lay) - 1 else 1
+        shp['model.%d.weight' % ci] = (cout, cin, 4, 4)
+        if bi is None:
+            shp['model.%d.bias' % ci] = (cout,)
+        else:
+            for s, v in (('weight', (cout,)), ('bias', (cout,)), ('running_mean', (cout,)),
+                         ('running_var', (cout,)), ('num_batches_tracked', ())):
+                shp['model.%d.%s' % (bi, s)] = v
+        if gi is not None:
+            shp['model.%d.alpha' % gi] = (cout,)
+        cin = cout
+    return shp
+
+
+# ----------------------------------------------------------------------------------------------
+# the model step
+# ----------------------------------------------------------------------------------------------
+class Opt:
+    """Just the flags the step reads (options/options.py)."""
+
+    def __init__(self, **kw):
+        self.ngf = 32
+        self.ndf = 128
+        self.teacher_ngf = 64
+        self.teacher_ndf = 128
+        self.num_downs = 8
+        self.no_dropout = True
+        self.gan_mode = 'hinge'
+        self.lambda_L1 = 100.0
+        self.lambda_gram = 1e4
+        self.lambda_content = 50.0
+        self.lambda_weight = 0.0
+        self.lambda_scale = 0.0
+        self.lr = 2e-4
+        self.arch_lr = 1e-4
+        self.ema_beta = 1.0
+        self.threshold = 0.5
+        self.darts_discriminator = True
+        self.online_distillation = True
+        self.direction = 'AtoB'
+        self.__dict__.update(kw)
+
+
+def _is_float_param(k: str) -> bool:
+    return k.endswith('.weight') or k.endswith('.bias') or k.endswith('.alpha')
+
+
+class Pix2PixOracle:
+    """One replica of the reference Pix2PixModel reduced to its arithmetic.
+
+    ``G``/``D`` are state-dict-keyed dicts of fp32 tensors (requires_grad toggled per phase);
+    ``T`` are the student's 1x1 transform convs (models/Pix2Pix.py:407-409).
+    """
+
+    def __init__(self, opt: Opt, G: SD, D: SD, T: Optional[List[Tensor]] = None, masked: bool = False,
+                 teacher: Optional['Pix2PixOracle'] = None):
+        self.opt = opt
+        self.G, self.D, self.T = G, D, (T or [])
+        self.masked = masked
+        self.teacher = teacher
+        self.g_hooks = unet_hook_names(opt.num_downs)
+        self.d_hooks = ['model.4', 'model.12'] if masked else ['model.3', 'model.9']
+        self.g_feats: OrderedDict = OrderedDict()
+        self.d_feats: OrderedDict = OrderedDict()
+        self.train = True
+        self.current_D_arch_diff_loss = 0.0
+        self.losses: Dict[str, float] = {}
+        self.lr_G = self.lr_D = opt.lr
+        self.lr_arch = opt.arch_lr
+        self.dropout_masks = None
+        # parameter groups, in the reference's optimizer order
+        self.G_keys = [k for k in G if _is_float_param(k)]
+        self.D_w_keys = [k for k in D if (k.endswith('.weight') or k.endswith('.bias'))]
+        self.D_a_keys = [k for k in D if k.endswith('.alpha')]
+        self.st_G, self.st_D, self.st_A = {}, {}, {}
+
+    # -- forward pieces ------------------------------------------------------------------
+    def netG(self, x):
+        return unet_forward(self.G, x, self.opt.num_downs, self.train, dropout=not self.opt.no_dropout,
+                            dropout_masks=self.dropout_masks, features=self.g_feats)
+
+    def netD(self, x):
+        return patchgan_forward(self.D, x, self.masked, self.opt.threshold, self.train,
+                                features=self.d_feats, hook_names=self.d_hooks)
+
+    def set_input(self, A: Tensor, B: Tensor):
+        """A, B as in the batch dict; direction picks the roles (models/Pix2Pix.py:453-458)."""
+        self.in_A, self.in_B = A, B
+        self.real_A, self.real_B = (A, B) if self.opt.direction == 'AtoB' else (B, A)
+
+    def forward(self):
+        self.fake_B = self.netG(self.real_A)
+
+    def features(self) -> List[Tensor]:
+        return list(self.g_feats.values()) + list(self.d_feats.values())
+
+    def _req(self, sd: SD, keys: Sequence[str], flag: bool):
+        for k in keys:
+            sd[k].requires_grad_(flag)
+            if flag:
+                sd[k].grad = None
+
+    # -- one iteration (models/Pix2Pix.py:565-583) -----------------------------------------
+    def optimize_parameters(self):
+        o = self.opt
+        if self.teacher is not None:
+            self.teacher.set_input(self.in_A, self.in_B)
+            self.teacher.optimize_parameters()
+            self.targets = [f.detach().clone() for f in self.teacher.features()]
+
+        Gp = self.G_keys
+        self._req(self.G, Gp, True)
+        for t in self.T:
+            t.requires_grad_(True)
+            t.grad = None
+        self.forward()
+
+        # ---- D step (:464-477) ----
+        self._req(self.D, self.D_w_keys, True)
+        self._req(self.D, self.D_a_keys, False)
+        pred_fake = self.netD(torch.cat((self.real_A, self.fake_B), 1).detach())
+        loss_D_fake = gan_loss(o.gan_mode, pred_fake, False, True)
+        pred_real = self.netD(torch.cat((self.real_A, self.real_B), 1))
+        loss_D_real = gan_loss(o.gan_mode, pred_real, True, True)
+        loss_D = (loss_D_fake + loss_D_real) * 0.5
+        loss_D.backward()
+        adam_step([self.D[k] for k in self.D_w_keys], [self.D[k].grad for k in self.D_w_keys],
+                  self.st_D, self.lr_D, (0.5, 0.999))
+        self._req(self.D, self.D_w_keys, False)
+
+        # ---- G step (:513-552) ----
+        pred_fake = self.netD(torch.cat((self.real_A, self.fake_B), 1))
+        loss_G_GAN = gan_loss(o.gan_mode, pred_fake, True, False)
+        loss_G_L1 = F.l1_loss(self.fake_B, self.real_B) * o.lambda_L1
+        loss_G = loss_G_GAN + loss_G_L1
+        self.losses.update(G_GAN=float(loss_G_GAN.detach()), G_L1=float(loss_G_L1.detach()), D_real=float(loss_D_real.detach()),
+                           D_fake=float(loss_D_fake.detach()))
+        if self.teacher is not None:
+            feats = list(self.g_feats.values())
+            # teacher D (train mode, weights frozen) on the student's fake: hazard H2
+            self.teacher.netD(torch.cat((self.real_A, self.fake_B), 1))
+            feats = feats + list(self.teacher.d_feats.values())
+            loss_gram = 0.0
+            loss_content = 0.0
+            for i, f in enumerate(feats):
+                if i < 4:
+                    f = F.conv2d(f, self.T[i])
+                t = self.targets[i]
+                loss_gram = loss_gram + rmse(gram(f), gram(t))
+                loss_content = loss_content + rmse(f, t)
+            loss_gram = o.lambda_gram * loss_gram
+            loss_content = o.lambda_content * loss_content
+            loss_G = loss_G + loss_gram + loss_content
+            self.losses.update(gram=float(loss_gram.detach()), content=float(loss_content.detach()))
+            self.dist_feats = [f.detach() for f in feats]
+        loss_G.backward()
+        # L1 sparsity sub-gradient (:554-563)
+        if o.lambda_weight > 0.0:
+            for k in Gp:
+                if self.G[k].dim() == 4:
+                    self.G[k].grad.add_(o.lambda_weight * torch.sign(self.G[k].detach()))
+        elif o.lambda_scale > 0.0:
+            for k in Gp:
+                if k.endswith('.weight') and self.G[k].dim() == 1:
+                    self.G[k].grad.add_(o.lambda_scale * torch.sign(self.G[k].detach()))
+        params = [self.G[k] for k in Gp] + list(self.T)
+        with torch.no_grad():
+            adam_step([p for p in params], [p.grad for p in params], self.st_G, self.lr_G, (0.5, 0.999))
+        self.fake_B = self.fake_B.detach()
+        self._req(self.G, Gp, False)
+        for t in self.T:
+            t.requires_grad_(False)
+
+    # -- arch step (models/Pix2Pix.py:479-511, 585-593) --------------------------------------
+    def _arch_diff(self, is_teacher: bool):
+        o = self.opt
+        pred_fake = self.netD(torch.cat((self.real_A, self.fake_B), 1).detach())
+        self.loss_D_arch_fake = gan_loss(o.gan_mode, pred_fake, False, True)
+        fake_real = gan_loss(o.gan_mode, pred_fake, True, False)
+        pred_real = self.netD(torch.cat((self.real_A, self.real_B), 1))
+        self.loss_D_arch_real = gan_loss(o.gan_mode, pred_real, True, True)
+        cur = (fake_real - self.loss_D_arch_fake).abs()
+        if is_teacher and float(self.current_D_arch_diff_loss) != 0.0:
+            cur = o.ema_beta * cur + (1.0 - o.ema_beta) * self.current_D_arch_diff_loss
+        self.current_D_arch_diff_loss = cur
+        return cur
+
+    def clipping_mask_alpha(self):
+        with torch.no_grad():
+            for k in self.D_a_keys:
+                self.D[k].clamp_(0, 1)
+
+    def optimizer_netD_arch(self):
+        T = self.teacher
+        with torch.no_grad():
+            self.forward()
+            T.set_input(self.in_A, self.in_B)
+            T.forward()
+        self._req(self.D, self.D_w_keys, False)
+        self._req(self.D, self.D_a_keys, True)
+        with torch.no_grad():
+            t_diff = T._arch_diff(True)
+        s_diff = self._arch_diff(False)
+        loss = (s_diff - t_diff).abs() + (self.loss_D_arch_real + self.loss_D_arch_fake) * 0.5
+        loss.backward()
+        with torch.no_grad():
+            adam_step([self.D[k] for k in self.D_a_keys], [self.D[k].grad for k in self.D_a_keys],
+                      self.st_A, self.lr_arch, (0.9, 0.999))
+        self._req(self.D, self.D_a_keys, False)
+        self.losses.update(D_arch_diff=float(s_diff.detach()), D_arch=float(loss.detach()), teacher_D_arch_diff=float(t_diff.detach()))
+
+
+def build_gcc_pair(opt: Opt, seed: int = 0) -> Pix2PixOracle:
+    """Student (masked D, transform convs) + online teacher, initialised with the reference's
+    init rule from one seeded generator (not the reference's RNG stream: parity tests load the
+    reference's own state_dicts from the golden fixtures instead)."""
+    g = torch.Generator().manual_seed(seed)
+    tG = init_state_dict(unet_shapes(opt.teacher_ngf, opt.num_downs), g)
+    tD = init_state_dict(patchgan_shapes(opt.teacher_ndf, 6, False), g)
+    sG = init_state_dict(unet_shapes(opt.ngf, opt.num_downs), g)
+    sD = init_state_dict(patchgan_shapes(opt.ndf, 6, opt.darts_discriminator), g)
+    s_w = [opt.ngf * 2, opt.ngf * 8, opt.ngf * 16, opt.ngf * 4]
+    t_w = [opt.teacher_ngf * 2, opt.teacher_ngf * 8, opt.teacher_ngf * 16, opt.teacher_ngf * 4]
+    # nn.Conv2d default init (kaiming_uniform a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+    T = [(torch.rand((t, s, 1, 1), generator=g) * 2 - 1) / math.sqrt(s) for s, t in zip(s_w, t_w)]
+    teacher = Pix2PixOracle(opt, tG, tD, masked=False)
+    return Pix2PixOracle(opt, sG, sD, T, masked=opt.darts_discriminator, teacher=teacher)
+
+
+# ----------------------------------------------------------------------------------------------
+# prune cfgs (integer contract)
+# ----------------------------------------------------------------------------------------------
+def _unet_bn_names(num_downs: int = 8) -> List[str]:
+    """BatchNorm2d modules of the U-Net in named_modules() order: down norms d=1..D-2 on the way in,
+    then up norms from the innermost block outwards."""
+    D = num_downs
+    names = [unet_block_prefix(d) + '.model.2' for d in range(1, D - 1)]
+    names.append(unet_block_prefix(D - 1) + '.model.4')
+    names += [unet_block_prefix(d) + '.model.6' for d in range(D - 2, 0, -1)]
+    return names
+
+
+def scale_prune_cfg(G: SD, threshold: float, ngf: int, num_downs: int = 8):
+    """models/Pix2Pix.py:823-860  ->  (filter_cfgs, channel_cfgs), both length 15 for D=8."""
+    D = num_downs
+    f, c = [ngf], [ngf]
+    inner_up = unet_block_prefix(D - 1) + '.model.4'
+    last_down = unet_block_prefix(D - 2) + '.model.2'
+    up_flag, up_num = False, 0
+    for name in _unet_bn_names(D):
+        cnt = int((G[name + '.weight'] > threshold).sum())
+        f.append(cnt)
+        if name == inner_up:
+            up_flag = True
+            if cnt == 0:
+                f[-2] = 0
+        if up_flag:
+            up_num += 1
+            if f[-2 * up_num] == 0:
+                f[-1] = 0
+                cnt = 0
+            c.append(cnt + f[-1 - 2 * up_num])
+        else:
+            c.append(cnt)
+        if name == last_down:
+            if f[-1] == 0:
+                f.append(0)
+                c.append(0)
+            else:
+                f.append(ngf * 8)
+                c.append(ngf * 8)
+    return f, c
+
+
+def _unet_conv_names(num_downs: int = 8) -> List[Tuple[str, bool]]:
+    """(name, is_transposed) of every Conv2d / ConvTranspose2d in named_modules() order."""
+    D = num_downs
+    out = [('model.model.0', False)]
+    out += [(unet_block_prefix(d) + '.model.1', False) for d in range(1, D)]
+    out.append((unet_block_prefix(D - 1) + '.model.3', True))
+    out += [(unet_block_prefix(d) + '.model.5', True) for d in range(D - 2, 0, -1)]
+    out.append(('model.model.3', True))
+    return out
+
+
+def filter_norms(w: Tensor, transposed: bool) -> Tensor:
+    """sum |w| over (1,2,3) for Conv2d, (0,2,3) for ConvTranspose2d.  models/Pix2Pix.py:877-880"""
+    return w.abs().sum((0, 2, 3) if transposed else (1, 2, 3))
+
+
+def norm_prune_cfg(G: SD, threshold: float, ngf: int, num_downs: int = 8):
+    """models/Pix2Pix.py:866-898  ->  len(f)=16, len(c)=15 for D=8."""
+    f, c = [], []
+    up_num = 0
+    for name, tr in _unet_conv_names(num_downs):
+        cnt = int((filter_norms(G[name + '.weight'], tr) > threshold).sum())
+        f.append(cnt)
+        if tr:
+            up_num += 1
+            if name != 'model.model.3':
+                c.append(cnt + f[-1 - 2 * up_num])
+        else:
+            c.append(cnt)
+    if f[0] == 0:
+        f[0] = ngf
+        c[0] = ngf
+        c[-1] += ngf
+    return f, c
+
+
+def max_min_bn_scale(G: SD, num_downs: int = 8):
+    """models/Pix2Pix.py:754-776 (the 'prunable' list is hard-coded for D=8)."""
+    p3 = 'model.model.1.model.3.model.3.model.3.model.3'
+    prunable = [p3 + '.model.2', p3 + '.model.3.model.2', p3 + '.model.3.model.3.model.4',
+                p3 + '.model.3.model.6', p3 + '.model.6']
+    un_max, pr_max, mn = float('inf'), -float('inf'), float('inf')
+    for name in _unet_bn_names(num_downs):
+        w = G[name + '.weight']
+        if name in prunable:
+            pr_max = max(float(w.max()), pr_max)
+        else:
+            un_max = min(float(w.max()), un_max)
+        mn = min(float(w.min()), mn)
+    return min(pr_max, un_max), mn
+
+
+def max_min_conv_norm(G: SD, num_downs: int = 8):
+    """models/Pix2Pix.py:778-818 (unet branch)."""
+    p3 = 'model.model.1.model.3.model.3.model.3.model.3'
+    prunable = [p3 + '.model.1', p3 + '.model.3.model.1', p3 + '.model.3.model.3.model.1',
+                p3 + '.model.3.model.3.model.3', p3 + '.model.3.model.5', p3 + '.model.5']
+    un_max, pr_max, mn = float('inf'), -float('inf'), float('inf')
+    for name, tr in _unet_conv_names(num_downs):
+        nrm = filter_norms(G[name + '.weight'], tr)
+        if name in prunable:
+            pr_max = max(float(nrm.max()), pr_max)
+        else:
+            un_max = min(float(nrm.max()), un_max)
+        mn = min(float(nrm.min()), mn)
+    return min(pr_max, un_max), mn

@@ -1,0 +1,316 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REAL REFERENCE.
+
+Runs only in the authoring container (needs /root/reference; never runs on the GPU box, never
+imported by tests).  The reference's Python is imported unmodified with empty stand-ins for the
+packages this image lacks (torchvision / cv2 / thop / skimage -- SURVEY.md Appendix B); nothing from
+the reference is copied: the outputs are data (inputs + expected outputs).
+
+    python tests/golden/make_fixtures.py            # rewrites tests/golden/*.npz
+
+Fixtures
+  pix2pix_eval_d8.npz   eval-mode U-Net (num_downs 8, ngf 4, 256x256): weights, input, fake_B
+  pix2pix_gcc_d6.npz    student(ngf4,ndf4,masked D)+teacher(ngf8,ndf8), num_downs 6, 64x64, N=2,
+                        --no_dropout, direction BtoA: 2 x (optimize_parameters + arch step):
+                        initial state_dicts, inputs, per-iteration losses, iteration-1 hooked
+                        features / targets / fake_B, final state_dicts (incl. BN running stats, alpha)
+  pix2pix_pretrain_d6.npz  plain Pix2Pix (no teacher, plain D, lambda_scale 1e-2): 2 iterations
+  ops.npz               DifferentiableOP fwd/bwd (alpha <,==,> tau), GANLoss x4 modes, gram,
+                        LambdaLR values, init_weights statistics
+  prune_d8.npz          scale_prune / norm_prune cfgs + max_min_* at several thresholds (ngf 8)
+"""
+import copy
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference'
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    m.__path__ = []
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    tv = _stub('torchvision')
+    tv.transforms = _stub('torchvision.transforms')
+    _stub('torchvision.transforms.functional')
+    _stub('torchvision.utils', make_grid=None)
+    _stub('torchvision.models')
+    _stub('torchvision.datasets')
+    _stub('torchvision.models.vgg', vgg19=None)
+    _stub('cv2', INTER_AREA=3)
+    _stub('thop', profile=None)
+    _stub('skimage')
+    _stub('skimage.metrics', peak_signal_noise_ratio=None, structural_similarity=None)
+    sys.path.insert(0, REF)
+
+
+def parse(argv):
+    from options import options
+    sys.argv = ['train.py'] + argv
+    opt = options.parse()
+    opt.isTrain = True
+    return opt
+
+
+def sd_np(prefix, sd, out):
+    for k, v in sd.items():
+        out[prefix + k] = v.detach().cpu().numpy().copy()
+
+
+def build_gcc(opt):
+    """train.py:84-105"""
+    from models import get_model_class
+    cls = get_model_class(opt)
+    model = cls(opt)
+    topt = copy.deepcopy(opt)
+    topt.ngf = opt.teacher_ngf
+    topt.ndf = opt.teacher_ndf
+    topt.darts_discriminator = False
+    topt.online_distillation = False
+    topt.generator_only = False
+    teacher = cls(topt)
+    teacher.model_train()
+    setattr(model, 'teacher_model', teacher)
+    model.init_distillation()
+    teacher.init_distillation()
+    return model, teacher
+
+
+def fixture_eval_d8():
+    torch.manual_seed(11)
+    opt = parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '-1',
+                 '--ngf', '4', '--ndf', '4', '--no_dropout'])
+    from models import get_model_class
+    model = get_model_class(opt)(opt)
+    # make the running statistics non-trivial: a few train-mode passes first
+    model.model_train()
+    g = torch.Generator().manual_seed(5)
+    for _ in range(3):
+        with torch.no_grad():
+            model.netG(torch.rand(2, 3, 256, 256, generator=g) * 2 - 1)
+    model.model_eval()
+    out = {}
+    sd_np('G.', model.netG.state_dict(), out)
+    A = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    B = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    model.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
+    with torch.no_grad():
+        model.forward()
+    out['A'] = A.numpy()
+    out['B'] = B.numpy()
+    out['direction'] = np.array(opt.direction)
+    out['fake_B'] = model.get_current_visuals()['fake_B'].numpy()
+    np.savez_compressed(os.path.join(HERE, 'pix2pix_eval_d8.npz'), **out)
+    print('pix2pix_eval_d8: fake_B', out['fake_B'].shape, 'direction', opt.direction)
+
+
+def fixture_gcc_d6():
+    torch.manual_seed(7)
+    opt = parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '-1',
+                 '--ngf', '4', '--ndf', '4', '--teacher_ngf', '8', '--num_downs', '6', '--no_dropout',
+                 '--online_distillation', '--darts_discriminator', '--lambda_content', '50',
+                 '--lambda_gram', '1e4', '--arch_lr', '1e-4', '--arch_lr_step'])
+    opt.teacher_ndf = 8            # parse() forces 128; shrunk so the fixture stays small
+    opt.batch_size = 2
+    model, teacher = build_gcc(opt)
+    model.model_train()
+    out = {'direction': np.array(opt.direction), 'threshold': np.array(opt.threshold),
+           'flags': np.array(' '.join(sys.argv[1:]) + ' (teacher_ndf=8)')}
+    # nudge two alphas so that the gate has <, == and > tau channels
+    with torch.no_grad():
+        a = model.netD.model[2].alpha
+        a[0] = 0.2
+        a[1] = 0.5
+    sd_np('init.sG.', model.netG.state_dict(), out)
+    sd_np('init.sD.', model.netD.state_dict(), out)
+    sd_np('init.tG.', teacher.netG.state_dict(), out)
+    sd_np('init.tD.', teacher.netD.state_dict(), out)
+    for i, t in enumerate(model.transform_convs):
+        out['init.T.%d' % i] = t.weight.detach().numpy().copy()
+    g = torch.Generator().manual_seed(99)
+    n_iter = 2
+    for it in range(n_iter):
+        A = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+        B = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+        vA = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+        vB = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+        out['it%d.A' % it], out['it%d.B' % it] = A.numpy(), B.numpy()
+        out['it%d.vA' % it], out['it%d.vB' % it] = vA.numpy(), vB.numpy()
+        model.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
+        model.optimize_parameters()
+        if it == 0:
+            out['it0.fake_B'] = model.fake_B.detach().numpy().copy()
+            out['it0.Tfake_B'] = teacher.fake_B.detach().numpy().copy()
+            for j, f in enumerate(model.target_distillation_features):
+                out['it0.target.%d' % j] = f.detach().numpy().copy()
+            for j, f in enumerate(model.get_distillation_features()):
+                out['it0.sfeat.%d' % j] = f.detach().numpy().copy()
+            for j, f in enumerate(teacher.total_discriminator_features.values()):
+                out['it0.tDfeat_on_sfake.%d' % j] = f.detach().numpy().copy()
+            sd_np('it0.afterstep.sG.', model.netG.state_dict(), out)
+            sd_np('it0.afterstep.sD.', model.netD.state_dict(), out)
+        model.set_input({'A': vA, 'B': vB, 'A_paths': ['a'], 'B_paths': ['b']})
+        model.clipping_mask_alpha()
+        model.optimizer_netD_arch()
+        for k, v in model.get_current_losses().items():
+            out['it%d.loss.%s' % (it, k)] = np.array(v, dtype=np.float64)
+        for k in ('G_GAN', 'G_L1', 'D_real', 'D_fake'):
+            out['it%d.tloss.%s' % (it, k)] = np.array(float(getattr(teacher, 'loss_' + k)), dtype=np.float64)
+    sd_np('final.sG.', model.netG.state_dict(), out)
+    sd_np('final.sD.', model.netD.state_dict(), out)
+    sd_np('final.tG.', teacher.netG.state_dict(), out)
+    sd_np('final.tD.', teacher.netD.state_dict(), out)
+    for i, t in enumerate(model.transform_convs):
+        out['final.T.%d' % i] = t.weight.detach().numpy().copy()
+    out['threads'] = np.array(torch.get_num_threads())
+    np.savez_compressed(os.path.join(HERE, 'pix2pix_gcc_d6.npz'), **out)
+    print('pix2pix_gcc_d6:', {k: float(out[k]) for k in out if k.startswith('it1.loss')})
+
+
+def fixture_pretrain_d6():
+    torch.manual_seed(21)
+    opt = parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '-1',
+                 '--ngf', '4', '--ndf', '4', '--num_downs', '6', '--no_dropout', '--lambda_scale', '1e-2'])
+    from models import get_model_class
+    model = get_model_class(opt)(opt)
+    model.model_train()
+    out = {'direction': np.array(opt.direction)}
+    sd_np('init.G.', model.netG.state_dict(), out)
+    sd_np('init.D.', model.netD.state_dict(), out)
+    g = torch.Generator().manual_seed(3)
+    for it in range(2):
+        A = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+        B = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+        out['it%d.A' % it], out['it%d.B' % it] = A.numpy(), B.numpy()
+        model.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
+        model.optimize_parameters()
+        for k, v in model.get_current_losses().items():
+            out['it%d.loss.%s' % (it, k)] = np.array(v, dtype=np.float64)
+    sd_np('final.G.', model.netG.state_dict(), out)
+    sd_np('final.D.', model.netD.state_dict(), out)
+    # LR schedule values as the reference's scheduler produces them (n_epochs 10, decay 15 here)
+    lrs = []
+    for ep in range(1, opt.n_epochs + opt.n_epochs_decay + 1):
+        model.update_learning_rate(ep)
+        lrs.append(model.optimizers[0].param_groups[0]['lr'])
+    out['lr_after_epoch'] = np.array(lrs, dtype=np.float64)
+    out['sched'] = np.array([opt.epoch_count, opt.n_epochs, opt.n_epochs_decay, opt.lr], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, 'pix2pix_pretrain_d6.npz'), **out)
+    print('pix2pix_pretrain_d6 ok; n_epochs', opt.n_epochs, opt.n_epochs_decay)
+
+
+def fixture_ops():
+    from models.DifferentiableOp import DifferentiableOP
+    from models.GANLoss import GANLoss
+    from models import get_model_class
+    import utils.util as util
+    out = {}
+    g = torch.Generator().manual_seed(17)
+    # gate
+    op = DifferentiableOP(6, 0.5)
+    with torch.no_grad():
+        op.alpha.copy_(torch.tensor([0.1, 0.5, 0.9, 0.5000001, 0.4999999, 1.0]))
+    x = torch.randn(3, 6, 5, 4, generator=g, requires_grad=True)
+    dy = torch.randn(3, 6, 5, 4, generator=g)
+    y = op(x)
+    y.backward(dy)
+    out['gate.x'], out['gate.dy'], out['gate.alpha'] = x.detach().numpy(), dy.numpy(), op.alpha.detach().numpy()
+    out['gate.y'], out['gate.dx'], out['gate.dalpha'] = y.detach().numpy(), x.grad.numpy(), op.alpha.grad.numpy()
+    out['gate.mask'] = op.get_current_mask().detach().numpy()
+    # gan losses
+    pred = torch.randn(2, 1, 6, 6, generator=g) * 1.5
+    out['gan.pred'] = pred.numpy()
+    for mode in ('hinge', 'lsgan', 'vanilla', 'wgangp'):
+        crit = GANLoss(mode)
+        for real in (True, False):
+            for ford in (True, False):
+                if mode == 'hinge' and not ford and not real:
+                    continue
+                p = pred.clone().requires_grad_(True)
+                l = crit(p, real, for_discriminator=ford)
+                l.backward()
+                key = 'gan.%s.%d.%d' % (mode, int(real), int(ford))
+                out[key] = np.array(float(l), dtype=np.float64)
+                out[key + '.grad'] = p.grad.numpy()
+    # gram (method of the model; build a tiny one)
+    opt = parse(['--dataroot', './database/x/', '--model', 'pix2pix', '--gpu_ids', '-1', '--ngf', '4',
+                 '--ndf', '4', '--num_downs', '6'])
+    torch.manual_seed(1)
+    model = get_model_class(opt)(opt)
+    f = torch.randn(2, 5, 7, 3, generator=g)
+    out['gram.x'] = f.numpy()
+    out['gram.y'] = model.gram(f).numpy()
+    # init_weights statistics (seeded; compared statistically)
+    w = []
+    bn_w, bn_b = [], []
+    for m in model.netG.modules():
+        cn = m.__class__.__name__
+        if cn.find('Conv') != -1:
+            w.append(m.weight.detach().flatten())
+        elif cn.find('BatchNorm2d') != -1:
+            bn_w.append(m.weight.detach().flatten())
+            bn_b.append(m.bias.detach().flatten())
+    w, bn_w, bn_b = torch.cat(w), torch.cat(bn_w), torch.cat(bn_b)
+    out['init.stats'] = np.array([float(w.mean()), float(w.std()), float(bn_w.mean()), float(bn_w.std()),
+                                  float(bn_b.mean()), float(bn_b.std())])
+    out['init.G_keys'] = np.array(list(model.netG.state_dict().keys()))
+    out['init.D_keys'] = np.array(list(model.netD.state_dict().keys()))
+    np.savez_compressed(os.path.join(HERE, 'ops.npz'), **out)
+    print('ops ok')
+
+
+def fixture_prune_d8():
+    torch.manual_seed(0)
+    opt = parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '-1',
+                 '--ngf', '8', '--ndf', '4', '--scale_prune'])
+    from models import get_model_class
+    model = get_model_class(opt)(opt)
+    out = {}
+    G = model.netG.state_dict()
+    for k, v in G.items():
+        if k.endswith('.weight'):
+            out['G.' + k] = v.numpy().copy()
+    mx, mn = model.max_min_bn_scale()
+    out['bn.max_min'] = np.array([float(mx), float(mn)], dtype=np.float64)
+    ths = [float(mn) - 0.01, 0.97, 0.99, 1.0, 1.01, 1.03, float(mx)]
+    out['bn.thresholds'] = np.array(ths, dtype=np.float64)
+    for i, t in enumerate(ths):
+        pm = model.scale_prune(t)
+        f, c = pm.get_cfg()
+        out['bn.f.%d' % i], out['bn.c.%d' % i] = np.array(f), np.array(c)
+    opt2 = copy.deepcopy(opt)
+    opt2.scale_prune, opt2.norm_prune = False, True
+    model.opt = opt2
+    mx, mn = model.max_min_conv_norm()
+    out['norm.max_min'] = np.array([float(mx), float(mn)], dtype=np.float64)
+    ths = [float(mn) * 0.5, float(mn) + 0.3 * (float(mx) - float(mn)), float(mn) + 0.6 * (float(mx) - float(mn)),
+           float(mx) * 0.999]
+    out['norm.thresholds'] = np.array(ths, dtype=np.float64)
+    for i, t in enumerate(ths):
+        pm = model.norm_prune(t)
+        f, c = pm.get_cfg()
+        out['norm.f.%d' % i], out['norm.c.%d' % i] = np.array(f), np.array(c)
+    np.savez_compressed(os.path.join(HERE, 'prune_d8.npz'), **out)
+    print('prune_d8 ok: bn cfg@1.0 =', list(out['bn.f.3']))
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    import_reference()
+    fixture_ops()
+    fixture_eval_d8()
+    fixture_gcc_d6()
+    fixture_pretrain_d6()
+    fixture_prune_d8()
