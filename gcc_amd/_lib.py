@@ -1,0 +1,114 @@
+"""ctypes binding of libgcc_hip.so (include/gcc_hip.h).  There is NO fallback: if the library is
+missing or a call fails, this raises -- the product never routes through PyTorch eager or the
+CPU oracle."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgcc_hip.so')
+
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+
+
+class GccError(RuntimeError):
+    pass
+
+
+class conv_t(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('N', 'H', 'W', 'Ci', 'Co', 'KH', 'KW', 'stride', 'pad',
+                                       'ldx', 'xoff', 'ldy', 'yoff')]
+
+
+class epilogue_t(C.Structure):
+    _fields_ = [('bias', C.c_void_p), ('act', C.c_int), ('slope', C.c_float), ('stats_partial', C.c_void_p)]
+
+
+class bnact_t(C.Structure):
+    _fields_ = [('scale', C.c_void_p), ('shift', C.c_void_p), ('gate', C.c_void_p), ('gate_after_act', C.c_int),
+                ('act', C.c_int), ('slope', C.c_float), ('act2', C.c_int), ('drop_p', C.c_float),
+                ('seed', C.c_uint64)]
+
+
+class bnact_bwd_t(C.Structure):
+    _fields_ = [('bn', C.c_int), ('bn_eval', C.c_int), ('mean', C.c_void_p), ('rstd', C.c_void_p),
+                ('gamma', C.c_void_p), ('beta', C.c_void_p), ('gate', C.c_void_p), ('gate_after_act', C.c_int),
+                ('act', C.c_int), ('slope', C.c_float), ('act2', C.c_int), ('drop_p', C.c_float),
+                ('seed', C.c_uint64), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('dalpha', C.c_void_p)]
+
+
+class adam_tensor_t(C.Structure):
+    _fields_ = [('p', C.c_void_p), ('g', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p),
+                ('numel', C.c_int64), ('l1', C.c_float), ('grad_scale', C.c_float)]
+
+
+class adam_chunk_t(C.Structure):
+    _fields_ = [('tensor', C.c_int), ('pad_', C.c_int), ('offset', C.c_int64)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_Z = C.c_size_t
+
+# name -> (restype, argtypes): every symbol include/gcc_hip.h declares
+PROTOTYPES = {
+    'gcc_strerror': (C.c_char_p, [_I]),
+    'gcc_version': (_I, []),
+    'gcc_conv_stat_tiles': (_I, [C.POINTER(conv_t), _I]),
+    'gcc_conv_fprop': (_I, [C.POINTER(conv_t), _P, _P, _P, C.POINTER(epilogue_t), _P]),
+    'gcc_conv_dgrad': (_I, [C.POINTER(conv_t), _P, _P, _P, C.POINTER(epilogue_t), _P]),
+    'gcc_conv_wgrad_workspace': (_Z, [C.POINTER(conv_t)]),
+    'gcc_conv_wgrad': (_I, [C.POINTER(conv_t), _P, _P, _P, _I, _P, _Z, _P]),
+    'gcc_pack_weights': (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    'gcc_nchw_f32_to_nhwc_bf16': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'gcc_nhwc_bf16_to_nchw_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'gcc_nhwc_copy': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _Z, _P]),
+    'gcc_nhwc_add': (_I, [_P, _I, _I, _P, _I, _I, _I, _Z, _P]),
+    'gcc_bn_finalize': (_I, [_P, _I, _I, C.c_double, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    'gcc_bn_eval_coeffs': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    'gcc_bnact_fwd': (_I, [C.POINTER(bnact_t), _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _Z, _P]),
+    'gcc_bnact_bwd_workspace': (_Z, [_I, _Z]),
+    'gcc_bnact_bwd': (_I, [C.POINTER(bnact_bwd_t), _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I,
+                           _I, _Z, _P, _Z, _P]),
+    'gcc_bnact_bwd_ex': (_I, [C.POINTER(bnact_bwd_t), _I, _F, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P,
+                              _I, _I, _I, _Z, _P, _Z, _P]),
+    'gcc_channel_sum': (_I, [_P, _I, _I, _I, _Z, _P, _I, _P, _Z, _P]),
+    'gcc_channel_sum_workspace': (_Z, [_I, _Z]),
+    'gcc_gate_mask': (_I, [_P, _F, _P, _I, _P]),
+    'gcc_gan_loss': (_I, [_I, _I, _I, _P, _I, _I, _Z, _F, _P, _I, _P, _P, _Z, _P]),
+    'gcc_l1_loss': (_I, [_P, _I, _I, _P, _I, _I, _I, _Z, _F, _P, _I, _P, _I, _I, _P, _Z, _P]),
+    'gcc_loss_workspace': (_Z, [_Z, _I]),
+    'gcc_distill_workspace': (_Z, [_I, _I, _I]),
+    'gcc_distill_fwd': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
+    'gcc_distill_bwd': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _F, _P, _I, _I, _P, _Z, _P]),
+    'gcc_adam_step': (_I, [_P, _P, _I, _I, _F, _F, _F, _F, _I, _P]),
+    'gcc_fill_f32': (_I, [_P, _F, _Z, _P]),
+    'gcc_clamp_f32': (_I, [_P, _F, _F, _Z, _P]),
+    'gcc_scalar_op': (_I, [_I, _P, _P, _P, _F, _F, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the in-tree library; raises GccError when it has not been built (run
+    ``python -c 'import __graft_entry__ as g; g.build()'`` or gcc_amd/csrc/build.sh)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GccError('libgcc_hip.so is not built (%s missing): the HIP kernels are the only '
+                       'implementation of this path -- build them with gcc_amd/csrc/build.sh' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)      # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().gcc_strerror(rc).decode()
+        raise GccError('%s failed: %s (%d)' % (what or 'gcc call', msg, rc))

@@ -1,0 +1,90 @@
+// Shared device helpers for the gfx950 kernels of libgcc_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gcc_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, NaN preserved by the hardware convert (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const i32x4& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t u = (uint32_t)v[i];
+        f[2 * i] = __uint_as_float(u << 16);
+        f[2 * i + 1] = __uint_as_float(u & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ i32x4 pack8(const float* f) {
+    i32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = (int)pack2bf(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    switch (act) {
+        case GCC_ACT_LRELU: return v > 0.f ? v : v * slope;
+        case GCC_ACT_RELU: return v > 0.f ? v : 0.f;
+        case GCC_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+// derivative of the activation evaluated on its OUTPUT y (the reference's in-place activations
+// differentiate through the result: leaky_relu_backward(self_is_result), threshold_backward).
+__device__ __forceinline__ float act_grad_from_out(float y, int act, float slope) {
+    switch (act) {
+        case GCC_ACT_LRELU: return y > 0.f ? 1.f : slope;
+        case GCC_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case GCC_ACT_TANH: return 1.f - y * y;
+        default: return 1.f;
+    }
+}
+
+// counter-based RNG for dropout: splitmix64 of (seed, index) -> uniform [0,1)
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__host__ __device__ static inline int ceil8(int v) { return (v + 7) & ~7; }
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+#define GCC_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return GCC_ERR_LAUNCH; \
+    } while (0)
+
+// XCD-aware remap of a linear workgroup id (8 XCDs, round-robin dispatch): logical tiles that are
+// adjacent end up on the same XCD (shared L2).  Bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

@@ -1,0 +1,272 @@
+// Weight gradient of a convolution on MFMA for gfx950:
+//     dW[co][tap][ci] = sum over output pixels m of dY[m][co] * X[pixel(m, tap)][ci]
+// The contraction runs over pixels, which is the slow (strided) dimension of both NHWC operands, so
+// both LDS tiles are [64 pixels][128 channels] images (filled by 16-byte buffer loads, zero padding
+// by the hardware range check) and the MFMA fragments are fetched with the CDNA4 transposing read
+// ds_read_b64_tr_b16.  Rows are padded to 288 B so that the 8 pixel rows one half-wave touches per
+// transposed read land on 8 distinct 32-B bank groups (conflict-free), and ds_write_b128 stays on
+// whole 128-B bank rows.
+//
+// Tile: 128 (tap,ci) columns x 128 output channels, 64 pixels per step, 256 threads = 2x2 waves.
+// Split-K over pixels: every split writes an fp32 slab, gcc_wgrad_reduce folds the slabs into the
+// fp32 master-layout gradient (deterministic; no float atomics).
+#include "common.hpp"
+
+namespace {
+
+struct FastDiv {
+    uint32_t mul, shr;
+    int d;
+};
+static FastDiv make_fastdiv(int d) {
+    FastDiv f; f.d = d;
+    if (d == 1) { f.mul = 0; f.shr = 0; return f; }
+    int lg = 0;
+    while ((1ll << lg) < d) lg++;
+    const int p = 31 + lg;
+    f.mul = (uint32_t)((((unsigned long long)1 << p) + d - 1) / d);
+    f.shr = p - 32;
+    return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
+    return f.d == 1 ? n : (int)(__umulhi((uint32_t)n, f.mul) >> f.shr);
+}
+
+struct WgradParams {
+    const bf16_t* x;
+    const bf16_t* dy;
+    float* out;          // slabs [splits][Co][ncols] (ncols = taps*Cip) or direct dW when splits==1 && direct
+    int N, H, W, ldx, xoff, Cip, Ci;
+    int Ho, Wo, ldy, yoff, Co;
+    int KH, KW, stride, pad;
+    int ncols;           // taps * Cip
+    int M;               // N*Ho*Wo
+    int ksteps_per_split;
+    int col_tiles, co_tiles;
+    uint32_t x_bytes, dy_bytes;
+    FastDiv dHW, dW, dCip, dKW;
+    int batch;                       // independent problems on blockIdx.y (gram matrices per image)
+    long x_bstride, dy_bstride;      // elements
+};
+
+constexpr int TP = 64;          // pixels per step
+constexpr int TCOL = 128;
+constexpr int TCO = 128;
+constexpr int RS = 288;         // LDS row stride (bytes)
+constexpr int TILE_BYTES = TP * RS;
+constexpr uint32_t OOB = 0x7FFFFFF0u;
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int ks, int colbase, int lane) {
+    // 16x16x32 operand from a [pixel][channel] image: lane (g = lane>>4, i = lane&15) ends up with
+    // channel colbase+i and the 8 pixel rows {ks*32 + 4g + 0..3, ks*32 + 16 + 4g + 0..3}.
+    const int g = lane >> 4, i = lane & 15;
+    const char* a = tile + (ks * 32 + 4 * g + (i >> 2)) * RS + (colbase + 4 * (i & 3)) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a + 16 * RS));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sX = smem;                       // [2][64][288]
+    char* sY = smem + 2 * TILE_BYTES;      // [2][64][288]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave & 1, wb = wave >> 1;
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = tile % p.col_tiles;     // column tile fastest: neighbours share the dY panel
+    const int ot = tile / p.col_tiles;
+    const int col0 = ct * TCOL, co0 = ot * TCO;
+    const int split = blockIdx.z;
+    const int k_begin = split * p.ksteps_per_split;
+    int k_end = k_begin + p.ksteps_per_split;
+    const int ksteps_total = (p.M + TP - 1) / TP;
+    if (k_end > ksteps_total) k_end = ksteps_total;
+
+    const int bidx = blockIdx.y;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)bidx * p.x_bstride), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + (size_t)bidx * p.dy_bstride), 0, p.dy_bytes, 0x00020000);
+
+    // this thread's 16-B column chunk of the X panel: fixed (tap, channel) for the whole K loop
+    const int chunk = tid & 15;
+    const int q = col0 + chunk * 8;
+    const bool col_ok = q < p.ncols;
+    const int tap = fdiv(q, p.dCip);
+    const int cx = q - tap * p.Cip;
+    const int kh = fdiv(tap, p.dKW);
+    const int kw = tap - kh * p.KW;
+    const int dyo = kh - p.pad, dxo = kw - p.pad;
+    const int coy = co0 + chunk * 8;
+    const bool co_ok = coy < ((p.Co + 7) & ~7);
+
+    i32x4 rx[4], ry[4];
+    auto issue_loads = [&](int kstep) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int m = kstep * TP + (tid >> 4) + 16 * i;
+            const bool mv = m < p.M;
+            const int n = fdiv(m, p.dHW);
+            const int r = m - n * (p.Ho * p.Wo);
+            const int oy = fdiv(r, p.dW);
+            const int ox = r - oy * p.Wo;
+            const int iy = oy * p.stride + dyo, ix = ox * p.stride + dxo;
+            const bool okx = mv && col_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const uint32_t offx = okx ? (uint32_t)((((n * p.H + iy) * p.W + ix) * p.ldx + p.xoff + cx) * 2) : OOB;
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, offx, 0, 0);
+            const bool oky = mv && co_ok;
+            const uint32_t offy = oky ? (uint32_t)((m * p.ldy + p.yoff + coy) * 2) : OOB;
+            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, offy, 0, 0);
+        }
+    };
+    auto write_lds = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = (tid >> 4) + 16 * i;
+            *(i32x4*)(sX + stage * TILE_BYTES + row * RS + chunk * 16) = rx[i];
+            *(i32x4*)(sY + stage * TILE_BYTES + row * RS + chunk * 16) = ry[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = k_end - k_begin;
+    if (nk > 0) {
+        issue_loads(k_begin);
+        write_lds(0);
+        if (nk > 1) issue_loads(k_begin + 1);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt++) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) {
+                write_lds(cur ^ 1);
+                if (kt + 2 < nk) issue_loads(k_begin + kt + 2);
+            }
+            const char* tx = sX + cur * TILE_BYTES;
+            const char* ty = sY + cur * TILE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                bf16x8 fx[4], fy[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) fx[i] = tr_frag(tx, ks, wa * 64 + i * 16, lane);
+#pragma unroll
+                for (int j = 0; j < 4; j++) fy[j] = tr_frag(ty, ks, wb * 64 + j * 16, lane);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[i], fy[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+
+    // acc[i][j][r] = dW[co = co0 + wb*64 + j*16 + (lane&15)][col = col0 + wa*64 + i*16 + 4*(lane>>4) + r]
+    float* slab = p.out + ((size_t)split * p.batch + bidx) * p.Co * p.ncols;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int co = co0 + wb * 64 + j * 16 + (lane & 15);
+        if (co < p.Co) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int col = col0 + wa * 64 + i * 16 + 4 * (lane >> 4);
+                if (col < p.ncols) *(f32x4*)(slab + (size_t)co * p.ncols + col) = acc[i][j];
+            }
+        }
+    }
+}
+
+// dW[co][tap][ci] (+)= sum_z slab[z][co][tap][cip]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splits, int Co,
+                                    int taps, int Ci, int Cip, int accumulate) {
+    const size_t total = (size_t)Co * taps * Ci;
+    const size_t slab = (size_t)Co * taps * Cip;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Ci);
+        const size_t rt = i / Ci;   // co*taps + tap
+        const size_t src = rt * Cip + c;
+        float s = 0.f;
+        for (int z = 0; z < splits; z++) s += slabs[z * slab + src];
+        dw[i] = accumulate ? dw[i] + s : s;
+    }
+}
+
+int plan_splits(const gcc_conv_t* c, int batch, int* ksteps_per_split) {
+    const int Ho = gcc_conv_out(c->H, c->KH, c->stride, c->pad), Wo = gcc_conv_out(c->W, c->KW, c->stride, c->pad);
+    const long M = (long)c->N * Ho * Wo;
+    const int ksteps = (int)((M + TP - 1) / TP);
+    const int ncols = c->KH * c->KW * ceil8(c->Ci);
+    const int tiles = cdiv(ncols, TCOL) * cdiv(c->Co, TCO) * batch;
+    int splits = cdiv(1024, tiles);
+    const int max_splits = ksteps / 4 > 0 ? ksteps / 4 : 1;   // at least 4 k-steps (256 pixels) per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const int per = cdiv(ksteps, splits);
+    splits = cdiv(ksteps, per);
+    *ksteps_per_split = per;
+    return splits;
+}
+
+}  // namespace
+
+size_t gcc_internal_wgrad_workspace(const gcc_conv_t* c, int batch) {
+    if (!c || c->Ci <= 0 || c->Co <= 0 || batch < 1) return 0;
+    int per;
+    const int splits = plan_splits(c, batch, &per);
+    return (size_t)splits * batch * c->Co * c->KH * c->KW * ceil8(c->Ci) * sizeof(float);
+}
+
+extern "C" size_t gcc_conv_wgrad_workspace(const gcc_conv_t* c) { return gcc_internal_wgrad_workspace(c, 1); }
+
+// batched form: problem b reads x + b*x_bstride, dy + b*dy_bstride (elements; c->N images each) and
+// writes dw + b*Co*taps*Ci
+int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float* dw, int accumulate, void* ws,
+                       size_t ws_bytes, int batch, long x_bstride, long dy_bstride, hipStream_t st) {
+    if (!c || !x || !dy || !dw || !ws) return GCC_ERR_BAD_ARG;
+    if (c->N <= 0 || c->H <= 0 || c->W <= 0 || c->Ci <= 0 || c->Co <= 0 || c->KH <= 0 || c->KW <= 0 ||
+        c->stride <= 0 || c->pad < 0)
+        return GCC_ERR_BAD_ARG;
+    if ((c->ldx & 7) || (c->xoff & 7) || (c->ldy & 7) || (c->yoff & 7)) return GCC_ERR_BAD_ARG;
+    const int Ho = gcc_conv_out(c->H, c->KH, c->stride, c->pad), Wo = gcc_conv_out(c->W, c->KW, c->stride, c->pad);
+    if (Ho <= 0 || Wo <= 0) return GCC_ERR_BAD_ARG;
+    if (batch < 1 || ws_bytes < gcc_internal_wgrad_workspace(c, batch)) return GCC_ERR_WORKSPACE;
+    WgradParams p;
+    p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.out = (float*)ws;
+    p.N = c->N; p.H = c->H; p.W = c->W; p.ldx = c->ldx; p.xoff = c->xoff; p.Ci = c->Ci; p.Cip = ceil8(c->Ci);
+    p.Ho = Ho; p.Wo = Wo; p.ldy = c->ldy; p.yoff = c->yoff; p.Co = c->Co;
+    p.KH = c->KH; p.KW = c->KW; p.stride = c->stride; p.pad = c->pad;
+    p.ncols = c->KH * c->KW * p.Cip;
+    const size_t M = (size_t)c->N * Ho * Wo;
+    const size_t xb = (size_t)c->N * c->H * c->W * c->ldx * 2, yb = M * c->ldy * 2;
+    if (xb >= OOB || yb >= OOB || M >= (1u << 30)) return GCC_ERR_UNSUPPORTED;
+    p.M = (int)M; p.x_bytes = (uint32_t)xb; p.dy_bytes = (uint32_t)yb;
+    const int splits = plan_splits(c, batch, &p.ksteps_per_split);
+    p.batch = batch; p.x_bstride = x_bstride; p.dy_bstride = dy_bstride;
+    p.col_tiles = cdiv(p.ncols, TCOL); p.co_tiles = cdiv(c->Co, TCO);
+    p.dHW = make_fastdiv(Ho * Wo); p.dW = make_fastdiv(Wo); p.dCip = make_fastdiv(p.Cip); p.dKW = make_fastdiv(c->KW);
+    static bool attr_set = false;
+    const int lds = 4 * TILE_BYTES;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_kernel, dim3(p.col_tiles * p.co_tiles, batch, splits), dim3(256), lds, st, p);
+    GCC_CHECK_LAUNCH();
+    const size_t total = (size_t)batch * c->Co * c->KH * c->KW * c->Ci;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits,
+                       batch * c->Co, c->KH * c->KW, c->Ci, p.Cip, accumulate);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+extern "C" int gcc_conv_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float* dw, int accumulate,
+                              void* ws, size_t ws_bytes, gcc_stream_t stream) {
+    return gcc_internal_wgrad(c, x, dy, dw, accumulate, ws, ws_bytes, 1, 0, 0, (hipStream_t)stream);
+}

@@ -1,0 +1,487 @@
+// Layout packing, weight packing, losses, distillation loss glue and multi-tensor Adam.
+#include "common.hpp"
+
+int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const void* w, void* dst, const gcc_epilogue_t* ep,
+                       int batch, long src_bstride, long wgt_bstride, long dst_bstride, hipStream_t st);
+size_t gcc_internal_wgrad_workspace(const gcc_conv_t* c, int batch);
+int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float* dw, int accumulate, void* ws,
+                       size_t ws_bytes, int batch, long x_bstride, long dy_bstride, hipStream_t st);
+
+namespace {
+
+static int grid_for(size_t n, int per_block = 256, int cap = 4096) {
+    size_t b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > (size_t)cap) b = cap;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int N, int C, int HW, int ld,
+                                    int off, int Cfill) {
+    const size_t total = (size_t)N * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / HW, r = i - n * HW;
+        bf16_t* d = dst + i * ld + off;
+        for (int c = 0; c < C; c++) d[c] = f2bf(src[(n * C + c) * HW + r]);
+        for (int c = C; c < Cfill; c++) d[c] = 0;
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int N, int C, int HW, int ld,
+                                    int off) {
+    const size_t total = (size_t)N * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / HW, r = i - n * HW;
+        const bf16_t* s = src + i * ld + off;
+        for (int c = 0; c < C; c++) dst[(n * C + c) * HW + r] = bf2f(s[c]);
+    }
+}
+// vector path (everything a multiple of 8) and scalar path
+__global__ void nhwc_copy_vec_kernel(const bf16_t* __restrict__ src, int lds, int soff, bf16_t* __restrict__ dst, int ldd,
+                                     int doff, int CH, size_t pixels, int add) {
+    const size_t total = pixels * CH;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / CH;
+        const int ch = (int)(i - pix * CH);
+        const i32x4 v = *(const i32x4*)(src + pix * lds + soff + ch * 8);
+        i32x4* d = (i32x4*)(dst + pix * ldd + doff + ch * 8);
+        if (add) {
+            float a[8], b[8];
+            unpack8(v, a); unpack8(*d, b);
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] += b[j];
+            *d = pack8(a);
+        } else {
+            *d = v;
+        }
+    }
+}
+__global__ void nhwc_copy_scalar_kernel(const bf16_t* __restrict__ src, int lds, int soff, bf16_t* __restrict__ dst, int ldd,
+                                        int doff, int C, int Cfill, size_t pixels, int add) {
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < pixels; pix += (size_t)gridDim.x * blockDim.x) {
+        const bf16_t* s = src + pix * lds + soff;
+        bf16_t* d = dst + pix * ldd + doff;
+        for (int c = 0; c < C; c++) d[c] = add ? f2bf(bf2f(d[c]) + bf2f(s[c])) : s[c];
+        if (!add)
+            for (int c = C; c < Cfill; c++) d[c] = 0;
+    }
+}
+
+// fp32 master [rows][taps][cols] -> W [rows][taps][colsp] , Wt [cols][taps][rowsp]
+__global__ void pack_w_kernel(const float* __restrict__ m, int rows, int taps, int cols, int colsp, bf16_t* __restrict__ w) {
+    const size_t total = (size_t)rows * taps * colsp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % colsp);
+        const size_t rt = i / colsp;
+        w[i] = c < cols ? f2bf(m[rt * cols + c]) : (bf16_t)0;
+    }
+}
+__global__ void pack_wt_kernel(const float* __restrict__ m, int rows, int taps, int cols, int rowsp, bf16_t* __restrict__ wt) {
+    // tile transpose through LDS: block = (32 rows x 32 cols) of one tap
+    __shared__ float t[32][33];
+    const int tap = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        t[k][tx] = (r < rows && c < cols) ? m[((size_t)r * taps + tap) * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < cols && r < rowsp) wt[((size_t)c * taps + tap) * rowsp + r] = f2bf(t[tx][k]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// block-wide sum (256 threads) -> thread 0
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    const int nw = blockDim.x >> 6;
+    for (int i = 0; i < nw; i++) t += sh[i];
+    return t;
+}
+
+// GANLoss over a 1-channel PatchGAN map; single block (the map is a few 10^4 values)
+__global__ __launch_bounds__(1024) void gan_loss_kernel(int mode, int real, int ford, const bf16_t* __restrict__ pred, int ld,
+                                                        int off, size_t pixels, float weight, float* loss, int accumulate,
+                                                        bf16_t* dpred) {
+    __shared__ float sh[16];
+    const float inv = 1.f / (float)pixels;
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i < pixels; i += blockDim.x) {
+        const float x = bf2f(pred[i * ld + off]);
+        float l, d;
+        if (mode == 0) {          // hinge
+            if (ford) {
+                const float z = real ? x - 1.f : -x - 1.f;
+                l = -(z < 0.f ? z : 0.f);
+                const float dz = z < 0.f ? -1.f : (z == 0.f ? -0.5f : 0.f);
+                d = real ? dz : -dz;
+            } else { l = -x; d = -1.f; }
+        } else if (mode == 1) {   // lsgan
+            const float t = real ? 1.f : 0.f;
+            l = (x - t) * (x - t); d = 2.f * (x - t);
+        } else if (mode == 2) {   // vanilla: BCE with logits
+            const float t = real ? 1.f : 0.f;
+            l = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+            d = 1.f / (1.f + expf(-x)) - t;
+        } else {                  // wgangp
+            l = real ? -x : x; d = real ? -1.f : 1.f;
+        }
+        acc += l;
+        if (dpred) {
+            float o[8] = {weight * d * inv, 0, 0, 0, 0, 0, 0, 0};
+            *(i32x4*)(dpred + i * ld + off) = pack8(o);
+        }
+    }
+    const float t = block_sum256(acc, sh);
+    if (threadIdx.x == 0) loss[0] = (accumulate ? loss[0] : 0.f) + weight * t * inv;
+}
+
+// stage 1 of L1 / squared-difference reductions over C channels of NHWC tensors
+struct DiffArgs {
+    const bf16_t* a; int lda, aoff; const bf16_t* b; int ldb, boff; int C, CH; size_t pixels;
+    float* partial; bf16_t* da; int ldda, daoff; float gscale; int mode;   // mode 0: |a-b| ; 1: (a-b)^2
+};
+__global__ __launch_bounds__(256) void diff_reduce_kernel(const DiffArgs g) {
+    __shared__ float sh[4];
+    const size_t total = g.pixels * g.CH;
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t pix = i / g.CH;
+        const int c0 = (int)(i - pix * g.CH) * 8;
+        float av[8], bv[8], dv[8];
+        unpack8(*(const i32x4*)(g.a + pix * g.lda + g.aoff + c0), av);
+        unpack8(*(const i32x4*)(g.b + pix * g.ldb + g.boff + c0), bv);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float d = (c0 + j < g.C) ? av[j] - bv[j] : 0.f;
+            if (g.mode == 0) { acc += fabsf(d); dv[j] = d > 0.f ? g.gscale : (d < 0.f ? -g.gscale : 0.f); }
+            else { acc += d * d; dv[j] = 0.f; }
+        }
+        if (g.da) *(i32x4*)(g.da + pix * g.ldda + g.daoff + c0) = pack8(dv);
+    }
+    const float t = block_sum256(acc, sh);
+    if (threadIdx.x == 0) g.partial[blockIdx.x] = t;
+}
+// stage 2: out = f(sum partial): mode 0: (+)= weight*sum/count ; mode 1: sqrt(sum/count)
+__global__ __launch_bounds__(256) void scalar_finalize_kernel(const float* partial, int n, double count, float weight,
+                                                              float* out, int accumulate, int mode) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    const float t = block_sum256(acc, sh);
+    if (threadIdx.x == 0) {
+        if (mode == 0) out[0] = (accumulate ? out[0] : 0.f) + weight * (float)((double)t / count);
+        else out[0] = sqrtf((float)((double)t / count));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// distillation: D = (Gf - Gt)/(C*HW) -> bf16 weights S, partial sums of D^2
+__global__ __launch_bounds__(256) void gram_diff_kernel(const float* __restrict__ gf, const float* __restrict__ gt, size_t n,
+                                                        float inv_chw, bf16_t* __restrict__ s, float* partial) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float d = (gf[i] - gt[i]) * inv_chw;
+        acc += d * d;
+        s[i] = f2bf(d);
+    }
+    const float t = block_sum256(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+// df = kg * dfg + kc * (f - t),  kg = wg*2/(N*C*C*Lg*C*HW),  kc = wc/(N*C*HW*Lc)
+__global__ __launch_bounds__(256) void distill_combine_kernel(const bf16_t* __restrict__ f, int ldf, int foff,
+                                                              const bf16_t* __restrict__ t, int ldt, int toff,
+                                                              const bf16_t* __restrict__ dfg, int CH, size_t pixels,
+                                                              const float* scal, float kg0, float kc0, bf16_t* __restrict__ df,
+                                                              int lddf, int dfoff) {
+    const float kg = kg0 / scal[0], kc = kc0 / scal[1];
+    const size_t total = pixels * CH;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t pix = i / CH;
+        const int c0 = (int)(i - pix * CH) * 8;
+        float fv[8], tv[8], gv[8], o[8];
+        unpack8(*(const i32x4*)(f + pix * ldf + foff + c0), fv);
+        unpack8(*(const i32x4*)(t + pix * ldt + toff + c0), tv);
+        unpack8(*(const i32x4*)(dfg + (pix * CH) * 8 + c0), gv);
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = kg * gv[j] + kc * (fv[j] - tv[j]);
+        *(i32x4*)(df + pix * lddf + dfoff + c0) = pack8(o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(const gcc_adam_tensor_t* __restrict__ tensors,
+                                                   const gcc_adam_chunk_t* __restrict__ chunks, int chunk_elems, float lr,
+                                                   float b1, float b2, float eps, float bc1, float sqrt_bc2) {
+    const gcc_adam_chunk_t ck = chunks[blockIdx.x];
+    const gcc_adam_tensor_t t = tensors[ck.tensor];
+    const int64_t end = ck.offset + chunk_elems < t.numel ? ck.offset + chunk_elems : t.numel;
+    const float step_size = lr / bc1;
+    for (int64_t i = ck.offset + threadIdx.x; i < end; i += 256) {
+        float p = t.p[i];
+        float g = t.g[i] * t.grad_scale;
+        if (t.l1 != 0.f) g += t.l1 * (p > 0.f ? 1.f : (p < 0.f ? -1.f : 0.f));
+        const float m = t.m[i] + (g - t.m[i]) * (1.f - b1);         // lerp_, as torch
+        const float v = t.v[i] * b2 + (1.f - b2) * g * g;
+        const float denom = sqrtf(v) / sqrt_bc2 + eps;
+        p -= step_size * (m / denom);
+        t.p[i] = p; t.m[i] = m; t.v[i] = v;
+    }
+}
+
+__global__ void fill_kernel(float* p, float v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void clamp_kernel(float* p, float lo, float hi, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = fminf(fmaxf(p[i], lo), hi);
+}
+// out[0] = |a - b| (+ extra terms): the arch-step scalar algebra of models/Pix2Pix.py:484-486, 505-511
+__global__ void scalar_ops_kernel(int op, const float* a, const float* b, const float* c, float k0, float k1, float* out) {
+    if (threadIdx.x || blockIdx.x) return;
+    if (op == 0) out[0] = fabsf(a[0] - b[0]);                               // L1 of two scalars
+    else if (op == 1) out[0] = k0 * fabsf(a[0] - b[0]) + k1 * c[0];         // EMA: beta*|a-b| + (1-beta)*prev
+    else if (op == 2) out[0] = a[0] + k0 * b[0];
+}
+
+constexpr int RED_BLOCKS = 1024;
+
+}  // namespace
+
+// =================================================================================================
+extern "C" const char* gcc_strerror(int code) {
+    switch (code) {
+        case GCC_OK: return "ok";
+        case GCC_ERR_BAD_ARG: return "bad argument (null pointer, non-positive size or misaligned ld/offset)";
+        case GCC_ERR_UNSUPPORTED: return "geometry not supported by the gfx950 kernels";
+        case GCC_ERR_WORKSPACE: return "workspace too small";
+        case GCC_ERR_LAUNCH: return "kernel launch failed";
+        default: return "unknown error";
+    }
+}
+extern "C" int gcc_version(void) { return 100; }
+
+extern "C" int gcc_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int N, int C, int H, int W, int ld, int off, int Cfill,
+                                         gcc_stream_t stream) {
+    if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0 || off + (Cfill > C ? Cfill : C) > ld) return GCC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, src,
+                       (bf16_t*)dst, N, C, H * W, ld, off, Cfill);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+extern "C" int gcc_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int N, int C, int H, int W, int ld, int off,
+                                         gcc_stream_t stream) {
+    if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0 || off + C > ld) return GCC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, dst, N, C, H * W, ld, off);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+static int nhwc_copy_impl(const void* src, int lds, int soff, void* dst, int ldd, int doff, int C, int Cfill, size_t pixels,
+                          int add, gcc_stream_t stream) {
+    if (!src || !dst || C <= 0 || pixels == 0 || soff + C > lds || doff + (Cfill > C ? Cfill : C) > ldd) return GCC_ERR_BAD_ARG;
+    const bool vec = !((lds | soff | ldd | doff | C) & 7) && Cfill <= C;
+    if (vec)
+        hipLaunchKernelGGL(nhwc_copy_vec_kernel, dim3(grid_for(pixels * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)src, lds, soff, (bf16_t*)dst, ldd, doff, C / 8, pixels, add);
+    else
+        hipLaunchKernelGGL(nhwc_copy_scalar_kernel, dim3(grid_for(pixels)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)src, lds, soff, (bf16_t*)dst, ldd, doff, C, Cfill, pixels, add);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+extern "C" int gcc_nhwc_copy(const void* src, int lds, int soff, void* dst, int ldd, int doff, int C, int Cfill, size_t pixels,
+                             gcc_stream_t stream) {
+    return nhwc_copy_impl(src, lds, soff, dst, ldd, doff, C, Cfill, pixels, 0, stream);
+}
+extern "C" int gcc_nhwc_add(const void* src, int lds, int soff, void* dst, int ldd, int doff, int C, size_t pixels,
+                            gcc_stream_t stream) {
+    return nhwc_copy_impl(src, lds, soff, dst, ldd, doff, C, C, pixels, 1, stream);
+}
+
+extern "C" int gcc_pack_weights(const float* master, int rows, int taps, int cols, void* w, void* wt, gcc_stream_t stream) {
+    if (!master || rows <= 0 || taps <= 0 || cols <= 0 || (!w && !wt)) return GCC_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (w) {
+        const int colsp = ceil8(cols);
+        hipLaunchKernelGGL(pack_w_kernel, dim3(grid_for((size_t)rows * taps * colsp)), dim3(256), 0, st, master, rows, taps,
+                           cols, colsp, (bf16_t*)w);
+        GCC_CHECK_LAUNCH();
+    }
+    if (wt) {
+        const int rowsp = ceil8(rows);
+        hipLaunchKernelGGL(pack_wt_kernel, dim3(cdiv(cols, 32), cdiv(rowsp, 32), taps), dim3(256), 0, st, master, rows, taps,
+                           cols, rowsp, (bf16_t*)wt);
+        GCC_CHECK_LAUNCH();
+    }
+    return GCC_OK;
+}
+
+extern "C" size_t gcc_loss_workspace(size_t pixels, int C) {
+    (void)pixels; (void)C;
+    return RED_BLOCKS * sizeof(float);
+}
+
+extern "C" int gcc_gan_loss(int mode, int target_is_real, int for_discriminator, const void* pred, int ld, int off,
+                            size_t pixels, float weight, float* loss, int accumulate, void* dpred, void* ws, size_t ws_bytes,
+                            gcc_stream_t stream) {
+    (void)ws; (void)ws_bytes;
+    if (!pred || !loss || pixels == 0 || (ld & 7) || (off & 7) || mode < 0 || mode > 3) return GCC_ERR_BAD_ARG;
+    if (mode == 0 && !for_discriminator && !target_is_real) return GCC_ERR_BAD_ARG;   // reference asserts
+    hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mode, target_is_real, for_discriminator,
+                       (const bf16_t*)pred, ld, off, pixels, weight, loss, accumulate, (bf16_t*)dpred);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+extern "C" int gcc_l1_loss(const void* a, int lda, int aoff, const void* b, int ldb, int boff, int C, size_t pixels,
+                           float weight, float* loss, int accumulate, void* da, int ldda, int daoff, void* ws,
+                           size_t ws_bytes, gcc_stream_t stream) {
+    if (!a || !b || !loss || !ws || C <= 0 || pixels == 0) return GCC_ERR_BAD_ARG;
+    if ((lda | aoff | ldb | boff) & 7 || (da && ((ldda | daoff) & 7))) return GCC_ERR_BAD_ARG;
+    if (ws_bytes < RED_BLOCKS * sizeof(float)) return GCC_ERR_WORKSPACE;
+    DiffArgs g;
+    g.a = (const bf16_t*)a; g.lda = lda; g.aoff = aoff; g.b = (const bf16_t*)b; g.ldb = ldb; g.boff = boff;
+    g.C = C; g.CH = (C + 7) / 8; g.pixels = pixels; g.partial = (float*)ws;
+    g.da = (bf16_t*)da; g.ldda = ldda; g.daoff = daoff;
+    const double count = (double)pixels * C;
+    g.gscale = (float)(weight / count); g.mode = 0;
+    const int blocks = grid_for(pixels * g.CH, 256 * 4, RED_BLOCKS);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(diff_reduce_kernel, dim3(blocks), dim3(256), 0, st, g);
+    GCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, blocks, count, weight, loss,
+                       accumulate, 0);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+// workspace layout of one feature pair:
+//   [0]   scal[4]  (Lg, Lc, -, -)            fp32
+//   [64]  partial[2][RED_BLOCKS]             fp32
+//   Gf [N][C][C] fp32 | Gt [N][C][C] fp32 | S [N][C][C] bf16 | dfg [N][HW][C] bf16 | wgrad slabs
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+struct DistillWs { size_t scal, partial, gf, gt, s, dfg, slabs, total; };
+static DistillWs distill_layout(int N, int C, int HW) {
+    DistillWs w;
+    gcc_conv_t c = {1, 1, HW, C, C, 1, 1, 1, 0, C, 0, C, 0};
+    size_t o = 0;
+    w.scal = o; o = al256(o + 16 * sizeof(float));
+    w.partial = o; o = al256(o + 2 * RED_BLOCKS * sizeof(float));
+    w.gf = o; o = al256(o + (size_t)N * C * C * 4);
+    w.gt = o; o = al256(o + (size_t)N * C * C * 4);
+    w.s = o; o = al256(o + (size_t)N * C * C * 2);
+    w.dfg = o; o = al256(o + (size_t)N * HW * C * 2);
+    w.slabs = o; o = al256(o + gcc_internal_wgrad_workspace(&c, N));
+    w.total = o;
+    return w;
+}
+
+extern "C" size_t gcc_distill_workspace(int N, int C, int HW) {
+    if (N <= 0 || C <= 0 || HW <= 0 || (C & 7)) return 0;
+    return distill_layout(N, C, HW).total;
+}
+
+extern "C" int gcc_distill_fwd(const void* f, int ldf, int foff, const void* t, int ldt, int toff, int N, int C, int HW,
+                               float* out2, void* ws, size_t ws_bytes, gcc_stream_t stream) {
+    if (!f || !t || !out2 || !ws || N <= 0 || C <= 0 || HW <= 0 || (C & 7)) return GCC_ERR_BAD_ARG;
+    if ((ldf | foff | ldt | toff) & 7) return GCC_ERR_BAD_ARG;
+    const DistillWs L = distill_layout(N, C, HW);
+    if (ws_bytes < L.total) return GCC_ERR_WORKSPACE;
+    char* base = (char*)ws;
+    hipStream_t st = (hipStream_t)stream;
+    float* scal = (float*)(base + L.scal);
+    float* partial = (float*)(base + L.partial);
+    // raw gram matrices: per image, G = F^T F over the HW pixels  (a 1x1 weight-gradient product)
+    gcc_conv_t cf = {1, 1, HW, C, C, 1, 1, 1, 0, ldf, foff, ldf, foff};
+    gcc_conv_t ct = {1, 1, HW, C, C, 1, 1, 1, 0, ldt, toff, ldt, toff};
+    const size_t slab_bytes = L.total - L.slabs;
+    int rc = gcc_internal_wgrad(&cf, f, f, (float*)(base + L.gf), 0, base + L.slabs, slab_bytes, N, (long)HW * ldf,
+                                (long)HW * ldf, st);
+    if (rc) return rc;
+    rc = gcc_internal_wgrad(&ct, t, t, (float*)(base + L.gt), 0, base + L.slabs, slab_bytes, N, (long)HW * ldt, (long)HW * ldt, st);
+    if (rc) return rc;
+    const size_t ng = (size_t)N * C * C;
+    const int b1 = grid_for(ng, 256 * 4, RED_BLOCKS);
+    hipLaunchKernelGGL(gram_diff_kernel, dim3(b1), dim3(256), 0, st, (const float*)(base + L.gf), (const float*)(base + L.gt),
+                       ng, 1.f / ((float)C * (float)HW), (bf16_t*)(base + L.s), partial);
+    GCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)partial, b1, (double)ng, 1.f,
+                       scal + 0, 0, 1);
+    GCC_CHECK_LAUNCH();
+    DiffArgs g;
+    g.a = (const bf16_t*)f; g.lda = ldf; g.aoff = foff; g.b = (const bf16_t*)t; g.ldb = ldt; g.boff = toff;
+    g.C = C; g.CH = C / 8; g.pixels = (size_t)N * HW; g.partial = partial + RED_BLOCKS;
+    g.da = nullptr; g.ldda = 0; g.daoff = 0; g.gscale = 0.f; g.mode = 1;
+    const int b2 = grid_for(g.pixels * g.CH, 256 * 4, RED_BLOCKS);
+    hipLaunchKernelGGL(diff_reduce_kernel, dim3(b2), dim3(256), 0, st, g);
+    GCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)(partial + RED_BLOCKS), b2,
+                       (double)N * HW * C, 1.f, scal + 1, 0, 1);
+    GCC_CHECK_LAUNCH();
+    if (hipMemcpyAsync(out2, scal, 2 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return GCC_ERR_LAUNCH;
+    return GCC_OK;
+}
+
+extern "C" int gcc_distill_bwd(const void* f, int ldf, int foff, const void* t, int ldt, int toff, int N, int C, int HW,
+                               float wg, float wc, void* df, int lddf, int dfoff, void* ws, size_t ws_bytes,
+                               gcc_stream_t stream) {
+    if (!f || !t || !df || !ws || N <= 0 || C <= 0 || HW <= 0 || (C & 7)) return GCC_ERR_BAD_ARG;
+    if ((ldf | foff | ldt | toff | lddf | dfoff) & 7) return GCC_ERR_BAD_ARG;
+    const DistillWs L = distill_layout(N, C, HW);
+    if (ws_bytes < L.total) return GCC_ERR_WORKSPACE;
+    char* base = (char*)ws;
+    hipStream_t st = (hipStream_t)stream;
+    // dfg[pix][c] = sum_c' f[pix][c'] * D[c'][c]   (D symmetric): per-image 1x1 product
+    gcc_conv_t c1 = {1, 1, HW, C, C, 1, 1, 1, 0, ldf, foff, C, 0};
+    int rc = gcc_internal_igemm(&c1, 0, f, base + L.s, base + L.dfg, nullptr, N, (long)HW * ldf, (long)C * C, (long)HW * C, st);
+    if (rc) return rc;
+    const double kg0 = (double)wg * 2.0 / ((double)N * C * C * (double)C * HW);
+    const double kc0 = (double)wc / ((double)N * C * HW);
+    const size_t pixels = (size_t)N * HW;
+    hipLaunchKernelGGL(distill_combine_kernel, dim3(grid_for(pixels * (C / 8), 256 * 2, 4096)), dim3(256), 0, st,
+                       (const bf16_t*)f, ldf, foff, (const bf16_t*)t, ldt, toff, (const bf16_t*)(base + L.dfg), C / 8, pixels,
+                       (const float*)(base + L.scal), (float)kg0, (float)kc0, (bf16_t*)df, lddf, dfoff);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+extern "C" int gcc_adam_step(const gcc_adam_tensor_t* tensors, const gcc_adam_chunk_t* chunks, int nchunks, int chunk_elems,
+                             float lr, float beta1, float beta2, float eps, int step, gcc_stream_t stream) {
+    if (!tensors || !chunks || nchunks <= 0 || chunk_elems <= 0 || step < 1) return GCC_ERR_BAD_ARG;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, tensors, chunks, chunk_elems, lr, beta1,
+                       beta2, eps, (float)bc1, (float)sqrt(bc2));
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+extern "C" int gcc_fill_f32(float* p, float v, size_t n, gcc_stream_t stream) {
+    if (!p || n == 0) return GCC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, v, n);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+extern "C" int gcc_clamp_f32(float* p, float lo, float hi, size_t n, gcc_stream_t stream) {
+    if (!p || n == 0) return GCC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(clamp_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, lo, hi, n);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+extern "C" int gcc_scalar_op(int op, const float* a, const float* b, const float* c, float k0, float k1, float* out,
+                             gcc_stream_t stream) {
+    if (!a || !b || !out || op < 0 || op > 2) return GCC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(scalar_ops_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, op, a, b, c, k0, k1, out);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}

@@ -1,0 +1,461 @@
+// BatchNorm2d (train/eval) + activation + DifferentiableOP gate + dropout, forward and backward,
+// on NHWC bf16 tensors.  All of these are HBM-bound streaming kernels: 16-byte (8-channel) accesses,
+// one thread per 8-channel chunk, per-channel reductions kept in registers across a grid-stride
+// loop, folded through LDS once per block and finished by a tiny second kernel (deterministic, no
+// float atomics).
+#include "common.hpp"
+
+namespace {
+
+// thread layout shared by the streaming kernels: CHP = chunks per pixel rounded up to a power of
+// two (<= 256); a 256-thread block covers 256/CHP pixels per sweep.
+struct Layout {
+    int CH;      // 16-B chunks per pixel = ceil8(C)/8
+    int CHP;     // power of two >= CH
+    int sh;      // log2(CHP)
+    int PPB;     // pixels per block sweep
+};
+static bool make_layout(int C, Layout* L) {
+    L->CH = (C + 7) / 8;
+    if (L->CH > 256) return false;
+    L->CHP = 1; L->sh = 0;
+    while (L->CHP < L->CH) { L->CHP <<= 1; L->sh++; }
+    L->PPB = 256 / L->CHP;
+    return true;
+}
+static int stream_blocks(size_t pixels, const Layout& L, int sweeps_per_block) {
+    size_t b = (pixels + (size_t)L.PPB * sweeps_per_block - 1) / ((size_t)L.PPB * sweeps_per_block);
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int tiles, int C, double count,
+                                                           const float* gamma, const float* beta, float eps, float momentum,
+                                                           float* rmean, float* rvar, float* mean, float* rstd,
+                                                           float* scale, float* shift) {
+    __shared__ double sh[2][32][33];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, ss = 0.0;
+    if (c < C) {
+        for (int t = pl; t < tiles; t += 32) {
+            s += (double)part[((size_t)t * 2 + 0) * C + c];
+            ss += (double)part[((size_t)t * 2 + 1) * C + c];
+        }
+    }
+    sh[0][pl][cl] = s; sh[1][pl][cl] = ss;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        for (int q = 1; q < 32; q++) { s += sh[0][q][cl]; ss += sh[1][q][cl]; }
+        const double m = s / count;
+        double var = ss / count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float r = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        if (mean) mean[c] = (float)m;
+        if (rstd) rstd[c] = r;
+        scale[c] = g * r;
+        shift[c] = b - (float)m * g * r;
+        if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+        if (rvar) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float r = 1.f / sqrtf(rv[c] + eps);
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        scale[c] = g * r;
+        shift[c] = b - rm[c] * g * r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct FwdArgs {
+    gcc_bnact_t p;
+    const bf16_t* x; int ldx, xoff;
+    bf16_t* y; int ldy, yoff;
+    bf16_t* y2; int ldy2, y2off;
+    int C; size_t pixels; Layout L;
+};
+
+__global__ __launch_bounds__(256) void bnact_fwd_kernel(const FwdArgs a) {
+    const int ch = threadIdx.x & (a.L.CHP - 1);
+    const int pl = threadIdx.x >> a.L.sh;
+    if (ch >= a.L.CH) return;
+    const int c0 = ch * 8;
+    float sc[8], sf[8], gm[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int c = c0 + j;
+        const bool v = c < a.C;
+        sc[j] = (v && a.p.scale) ? a.p.scale[c] : 1.f;
+        sf[j] = (v && a.p.shift) ? a.p.shift[c] : 0.f;
+        gm[j] = v ? (a.p.gate ? a.p.gate[c] : 1.f) : 0.f;   // pad channels come out as exact zeros
+    }
+    const float keep_scale = a.p.drop_p > 0.f ? 1.f / (1.f - a.p.drop_p) : 1.f;
+    for (size_t pix = (size_t)blockIdx.x * a.L.PPB + pl; pix < a.pixels; pix += (size_t)gridDim.x * a.L.PPB) {
+        const i32x4 raw = *(const i32x4*)(a.x + pix * a.ldx + a.xoff + c0);
+        float v[8], o1[8], o2[8];
+        unpack8(raw, v);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float z = v[j] * sc[j] + sf[j];
+            if (a.p.drop_p > 0.f) {
+                const float u = rng_uniform(a.p.seed, pix * (size_t)a.C + c0 + j);
+                z = u >= a.p.drop_p ? z * keep_scale : 0.f;
+            }
+            if (!a.p.gate_after_act) {
+                z *= gm[j];
+                o1[j] = apply_act(z, a.p.act, a.p.slope);
+            } else {
+                o1[j] = apply_act(z, a.p.act, a.p.slope) * gm[j];
+                z *= gm[j];
+            }
+            o2[j] = apply_act(z, a.p.act2, a.p.slope);
+        }
+        if (a.y) *(i32x4*)(a.y + pix * a.ldy + a.yoff + c0) = pack8(o1);
+        if (a.y2) *(i32x4*)(a.y2 + pix * a.ldy2 + a.y2off + c0) = pack8(o2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct BwdArgs {
+    gcc_bnact_bwd_t p;
+    const bf16_t* x; int ldx, xoff;
+    const bf16_t* y; int ldy, yoff;
+    const bf16_t* g1; int ldg1, g1off;
+    const bf16_t* g2; int ldg2, g2off;
+    bf16_t* dx; int lddx, dxoff;
+    int C, C8; size_t pixels; Layout L;
+    float* partial;   // [blocks][3][C8]
+    float* totals;    // [3][C8]
+    int in_act;       // activation already applied to x by the producer (conv epilogue): dx *= act'(x)
+    float in_slope;
+};
+
+// pass 1: dz (-> dx buffer) and per-block partial sums {sum dz, sum dz*xhat, sum g*zd}
+__global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(const BwdArgs a) {
+    __shared__ float red[3][256][9];
+    const int ch = threadIdx.x & (a.L.CHP - 1);
+    const int pl = threadIdx.x >> a.L.sh;
+    const int c0 = ch * 8;
+    const bool active = ch < a.L.CH;
+    float mu[8], rs[8], sc[8], sf[8], gm[8];
+    float s0[8], s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int c = c0 + j;
+        const bool v = active && c < a.C;
+        mu[j] = (v && a.p.bn) ? a.p.mean[c] : 0.f;
+        rs[j] = (v && a.p.bn) ? a.p.rstd[c] : 1.f;
+        const float g = (v && a.p.bn && a.p.gamma) ? a.p.gamma[c] : 1.f;
+        const float b = (v && a.p.bn && a.p.beta) ? a.p.beta[c] : 0.f;
+        sc[j] = g * rs[j];
+        sf[j] = b - mu[j] * sc[j];
+        gm[j] = v ? (a.p.gate ? a.p.gate[c] : 1.f) : 0.f;
+        s0[j] = s1[j] = s2[j] = 0.f;
+    }
+    const float keep_scale = a.p.drop_p > 0.f ? 1.f / (1.f - a.p.drop_p) : 1.f;
+    if (active) {
+        for (size_t pix = (size_t)blockIdx.x * a.L.PPB + pl; pix < a.pixels; pix += (size_t)gridDim.x * a.L.PPB) {
+            float xv[8], yv[8], g1v[8], g2v[8], dz[8];
+            unpack8(*(const i32x4*)(a.x + pix * a.ldx + a.xoff + c0), xv);
+            if (a.y) unpack8(*(const i32x4*)(a.y + pix * a.ldy + a.yoff + c0), yv);
+            unpack8(*(const i32x4*)(a.g1 + pix * a.ldg1 + a.g1off + c0), g1v);
+            if (a.g2) unpack8(*(const i32x4*)(a.g2 + pix * a.ldg2 + a.g2off + c0), g2v);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float z = xv[j] * sc[j] + sf[j];
+                float df = 1.f;
+                if (a.p.drop_p > 0.f) {
+                    const float u = rng_uniform(a.p.seed, pix * (size_t)a.C + c0 + j);
+                    df = u >= a.p.drop_p ? keep_scale : 0.f;
+                }
+                const float zd = z * df;
+                float g, ga;   // g: gradient at the gate output side ; ga: factor for dalpha
+                if (!a.p.gate_after_act) {
+                    const float yo = a.y ? yv[j] : apply_act(zd * gm[j], a.p.act, a.p.slope);
+                    g = g1v[j] * act_grad_from_out(yo, a.p.act, a.p.slope);
+                    if (a.g2) g += g2v[j] * act_grad_from_out(yo, a.p.act2, a.p.slope);
+                    ga = g * zd;
+                    g *= gm[j];
+                } else {
+                    const float ao = apply_act(zd, a.p.act, a.p.slope);
+                    ga = g1v[j] * ao;
+                    g = g1v[j] * gm[j] * act_grad_from_out(ao, a.p.act, a.p.slope);
+                }
+                float d = g * df;
+                if (!a.p.bn) d *= act_grad_from_out(xv[j], a.in_act, a.in_slope);
+                if (a.p.bn_eval) d *= sc[j];
+                dz[j] = d;
+                s0[j] += d;
+                s1[j] += d * (xv[j] - mu[j]) * rs[j];
+                s2[j] += ga;
+            }
+            *(i32x4*)(a.dx + pix * a.lddx + a.dxoff + c0) = pack8(dz);
+        }
+    }
+    // fold the pixel lanes of this block
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        red[0][threadIdx.x][j] = s0[j]; red[1][threadIdx.x][j] = s1[j]; red[2][threadIdx.x][j] = s2[j];
+    }
+    __syncthreads();
+    if (pl == 0 && active) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+            for (int q = 0; q < a.L.PPB; q++) {
+                const int t = q * a.L.CHP + ch;
+                t0 += red[0][t][j]; t1 += red[1][t][j]; t2 += red[2][t][j];
+            }
+            float* o = a.partial + (size_t)blockIdx.x * 3 * a.C8;
+            o[0 * a.C8 + c0 + j] = t0; o[1 * a.C8 + c0 + j] = t1; o[2 * a.C8 + c0 + j] = t2;
+        }
+    }
+}
+
+// pass 2: totals over blocks; parameter gradients (+=)
+__global__ __launch_bounds__(1024) void bnact_bwd_finalize_kernel(const BwdArgs a, int blocks) {
+    __shared__ double sh[3][32][33];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double t[3] = {0.0, 0.0, 0.0};
+    if (c < a.C8) {
+        for (int b = pl; b < blocks; b += 32) {
+            const float* o = a.partial + (size_t)b * 3 * a.C8;
+            t[0] += o[c]; t[1] += o[a.C8 + c]; t[2] += o[2 * a.C8 + c];
+        }
+    }
+    for (int k = 0; k < 3; k++) sh[k][pl][cl] = t[k];
+    __syncthreads();
+    if (pl == 0 && c < a.C8) {
+        for (int q = 1; q < 32; q++)
+            for (int k = 0; k < 3; k++) t[k] += sh[k][q][cl];
+        a.totals[c] = (float)t[0]; a.totals[a.C8 + c] = (float)t[1]; a.totals[2 * a.C8 + c] = (float)t[2];
+        if (c < a.C) {
+            if (a.p.dbeta) a.p.dbeta[c] += (float)t[0];
+            if (a.p.dgamma) a.p.dgamma[c] += (float)t[1];
+            if (a.p.dalpha) a.p.dalpha[c] += (float)t[2];
+        }
+    }
+}
+
+// pass 3 (training BN only): dx = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)), in place over dz
+__global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(const BwdArgs a) {
+    const int ch = threadIdx.x & (a.L.CHP - 1);
+    const int pl = threadIdx.x >> a.L.sh;
+    if (ch >= a.L.CH) return;
+    const int c0 = ch * 8;
+    float mu[8], rs[8], k0[8], k1[8], gr[8];
+    const float inv = 1.f / (float)a.pixels;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int c = c0 + j;
+        const bool v = c < a.C;
+        mu[j] = v ? a.p.mean[c] : 0.f;
+        rs[j] = v ? a.p.rstd[c] : 0.f;
+        gr[j] = v ? (a.p.gamma ? a.p.gamma[c] : 1.f) * rs[j] : 0.f;
+        k0[j] = a.totals[c] * inv;
+        k1[j] = a.totals[a.C8 + c] * inv;
+    }
+    for (size_t pix = (size_t)blockIdx.x * a.L.PPB + pl; pix < a.pixels; pix += (size_t)gridDim.x * a.L.PPB) {
+        float xv[8], dz[8], o[8];
+        unpack8(*(const i32x4*)(a.x + pix * a.ldx + a.xoff + c0), xv);
+        bf16_t* dp = a.dx + pix * a.lddx + a.dxoff + c0;
+        unpack8(*(const i32x4*)dp, dz);
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = gr[j] * (dz[j] - k0[j] - (xv[j] - mu[j]) * rs[j] * k1[j]);
+        *(i32x4*)dp = pack8(o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct SumArgs {
+    const bf16_t* x; int ld, off; int C, C8; size_t pixels; Layout L; float* partial;
+};
+__global__ __launch_bounds__(256) void channel_sum_kernel(const SumArgs a) {
+    __shared__ float red[256][9];
+    const int ch = threadIdx.x & (a.L.CHP - 1);
+    const int pl = threadIdx.x >> a.L.sh;
+    const int c0 = ch * 8;
+    const bool active = ch < a.L.CH;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) {
+        for (size_t pix = (size_t)blockIdx.x * a.L.PPB + pl; pix < a.pixels; pix += (size_t)gridDim.x * a.L.PPB) {
+            float v[8];
+            unpack8(*(const i32x4*)(a.x + pix * a.ld + a.off + c0), v);
+#pragma unroll
+            for (int j = 0; j < 8; j++) s[j] += v[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) red[threadIdx.x][j] = s[j];
+    __syncthreads();
+    if (pl == 0 && active) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float t = 0.f;
+            for (int q = 0; q < a.L.PPB; q++) t += red[q * a.L.CHP + ch][j];
+            a.partial[(size_t)blockIdx.x * a.C8 + c0 + j] = t;
+        }
+    }
+}
+__global__ __launch_bounds__(1024) void channel_sum_finalize_kernel(const float* partial, int blocks, int C, int C8, float* out,
+                                                                    int accumulate) {
+    __shared__ double sh[32][33];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double t = 0.0;
+    if (c < C)
+        for (int b = pl; b < blocks; b += 32) t += partial[(size_t)b * C8 + c];
+    sh[pl][cl] = t;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        for (int q = 1; q < 32; q++) t += sh[q][cl];
+        out[c] = accumulate ? out[c] + (float)t : (float)t;
+    }
+}
+
+__global__ void gate_mask_kernel(const float* alpha, float tau, float* mask, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float d = alpha[c] - tau;
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        mask[c] = (sgn + 1.f) * 0.5f;
+    }
+}
+
+bool aligned8(int a, int b) { return !((a & 7) || (b & 7)); }
+
+}  // namespace
+
+extern "C" int gcc_bn_finalize(const float* stats_partial, int tiles, int C, double count, const float* gamma,
+                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                               float* mean, float* rstd, float* scale, float* shift, gcc_stream_t stream) {
+    if (!stats_partial || tiles <= 0 || C <= 0 || count <= 0 || !scale || !shift) return GCC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, stats_partial, tiles, C,
+                       count, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+extern "C" int gcc_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, int C, float* scale, float* shift,
+                                  gcc_stream_t stream) {
+    if (!running_mean || !running_var || !scale || !shift || C <= 0) return GCC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, C, scale, shift);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+extern "C" int gcc_bnact_fwd(const gcc_bnact_t* p, const void* x, int ldx, int xoff, void* y, int ldy, int yoff,
+                             void* y2, int ldy2, int y2off, int C, size_t pixels, gcc_stream_t stream) {
+    if (!p || !x || (!y && !y2) || C <= 0 || pixels == 0) return GCC_ERR_BAD_ARG;
+    if (!aligned8(ldx, xoff) || (y && !aligned8(ldy, yoff)) || (y2 && !aligned8(ldy2, y2off))) return GCC_ERR_BAD_ARG;
+    FwdArgs a;
+    a.p = *p; a.x = (const bf16_t*)x; a.ldx = ldx; a.xoff = xoff;
+    a.y = (bf16_t*)y; a.ldy = ldy; a.yoff = yoff; a.y2 = (bf16_t*)y2; a.ldy2 = ldy2; a.y2off = y2off;
+    a.C = C; a.pixels = pixels;
+    if (!make_layout(C, &a.L)) return GCC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bnact_fwd_kernel, dim3(stream_blocks(pixels, a.L, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+static int bwd_blocks(size_t pixels, const Layout& L) {
+    size_t b = (pixels + (size_t)L.PPB * 16 - 1) / ((size_t)L.PPB * 16);
+    if (b < 1) b = 1;
+    if (b > 1024) b = 1024;
+    return (int)b;
+}
+
+extern "C" size_t gcc_bnact_bwd_workspace(int C, size_t pixels) {
+    Layout L;
+    if (C <= 0 || !make_layout(C, &L)) return 0;
+    const int C8 = (C + 7) & ~7;
+    return ((size_t)bwd_blocks(pixels, L) + 1) * 3 * C8 * sizeof(float);
+}
+
+// extended entry used by the library itself and by the python shim: `in_act` = activation the
+// producer already applied to x (plain conv+act layers, bn == 0)
+extern "C" int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_slope, const void* x, int ldx, int xoff,
+                                const void* y, int ldy, int yoff, const void* g1, int ldg1, int g1off, const void* g2,
+                                int ldg2, int g2off, void* dx, int lddx, int dxoff, int C, size_t pixels, void* ws,
+                                size_t ws_bytes, gcc_stream_t stream) {
+    if (!p || !x || !g1 || !dx || !ws || C <= 0 || pixels == 0) return GCC_ERR_BAD_ARG;
+    if (!aligned8(ldx, xoff) || !aligned8(ldg1, g1off) || !aligned8(lddx, dxoff)) return GCC_ERR_BAD_ARG;
+    if ((y && !aligned8(ldy, yoff)) || (g2 && !aligned8(ldg2, g2off))) return GCC_ERR_BAD_ARG;
+    if (p->bn && !p->bn_eval && (!p->mean || !p->rstd)) return GCC_ERR_BAD_ARG;
+    if (ws_bytes < gcc_bnact_bwd_workspace(C, pixels)) return GCC_ERR_WORKSPACE;
+    BwdArgs a;
+    a.p = *p;
+    a.x = (const bf16_t*)x; a.ldx = ldx; a.xoff = xoff;
+    a.y = (const bf16_t*)y; a.ldy = ldy; a.yoff = yoff;
+    a.g1 = (const bf16_t*)g1; a.ldg1 = ldg1; a.g1off = g1off;
+    a.g2 = (const bf16_t*)g2; a.ldg2 = ldg2; a.g2off = g2off;
+    a.dx = (bf16_t*)dx; a.lddx = lddx; a.dxoff = dxoff;
+    a.C = C; a.C8 = (C + 7) & ~7; a.pixels = pixels;
+    a.in_act = in_act; a.in_slope = in_slope;
+    if (!make_layout(C, &a.L)) return GCC_ERR_UNSUPPORTED;
+    const int blocks = bwd_blocks(pixels, a.L);
+    a.partial = (float*)ws;
+    a.totals = a.partial + (size_t)blocks * 3 * a.C8;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bnact_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+    GCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3((a.C8 + 31) / 32), dim3(1024), 0, st, a, blocks);
+    GCC_CHECK_LAUNCH();
+    if (p->bn && !p->bn_eval) {
+        hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(stream_blocks(pixels, a.L, 4)), dim3(256), 0, st, a);
+        GCC_CHECK_LAUNCH();
+    }
+    return GCC_OK;
+}
+
+extern "C" int gcc_bnact_bwd(const gcc_bnact_bwd_t* p, const void* x, int ldx, int xoff, const void* y, int ldy, int yoff,
+                             const void* g1, int ldg1, int g1off, const void* g2, int ldg2, int g2off, void* dx, int lddx,
+                             int dxoff, int C, size_t pixels, void* ws, size_t ws_bytes, gcc_stream_t stream) {
+    return gcc_bnact_bwd_ex(p, GCC_ACT_NONE, 0.f, x, ldx, xoff, y, ldy, yoff, g1, ldg1, g1off, g2, ldg2, g2off, dx, lddx,
+                            dxoff, C, pixels, ws, ws_bytes, stream);
+}
+
+extern "C" size_t gcc_channel_sum_workspace(int C, size_t pixels) {
+    Layout L;
+    if (C <= 0 || !make_layout(C, &L)) return 0;
+    return (size_t)bwd_blocks(pixels, L) * ((C + 7) & ~7) * sizeof(float);
+}
+
+extern "C" int gcc_channel_sum(const void* x, int ld, int off, int C, size_t pixels, float* out, int accumulate,
+                               void* ws, size_t ws_bytes, gcc_stream_t stream) {
+    if (!x || !out || !ws || C <= 0 || pixels == 0 || !aligned8(ld, off)) return GCC_ERR_BAD_ARG;
+    if (ws_bytes < gcc_channel_sum_workspace(C, pixels)) return GCC_ERR_WORKSPACE;
+    SumArgs a;
+    a.x = (const bf16_t*)x; a.ld = ld; a.off = off; a.C = C; a.C8 = (C + 7) & ~7; a.pixels = pixels;
+    a.partial = (float*)ws;
+    if (!make_layout(C, &a.L)) return GCC_ERR_UNSUPPORTED;
+    const int blocks = bwd_blocks(pixels, a.L);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(blocks), dim3(256), 0, st, a);
+    GCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, (const float*)ws, blocks, C,
+                       a.C8, out, accumulate);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+extern "C" int gcc_gate_mask(const float* alpha, float tau, float* mask, int C, gcc_stream_t stream) {
+    if (!alpha || !mask || C <= 0) return GCC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gate_mask_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, alpha, tau, mask, C);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}

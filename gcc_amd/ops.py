@@ -1,0 +1,346 @@
+"""Thin Python wrappers over the C ABI (include/gcc_hip.h) on torch device tensors.
+
+Activations are ``torch.bfloat16`` tensors of logical shape [N, C, H, W] in channels_last memory
+(NHWC), possibly channel-slices of a wider buffer; PyTorch only provides the memory, the current
+HIP stream and (elsewhere) torch.distributed -- every computation below is a libgcc_hip.so kernel.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, check  # noqa: F401
+
+_ws_cache = {}
+
+
+def lib():
+    return _lib.load()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ceil8(v):
+    return (v + 7) & ~7
+
+
+def workspace(nbytes, device, slot='default'):
+    """Grow-only scratch buffer per (device, slot); all users are ordered on one stream."""
+    key = (str(device), slot)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def new_act(N, Cc, H, W, device, ld=None):
+    """Zero-initialised NHWC bf16 activation [N, Cc, H, W] with pixel stride ld >= ceil8(Cc)."""
+    ld = ld or ceil8(Cc)
+    base = torch.zeros((N, H, W, ld), dtype=torch.bfloat16, device=device)
+    return base.permute(0, 3, 1, 2)[:, :Cc]
+
+
+def cslice(t, off, Cc):
+    """Channel slice [off, off+Cc) of an NHWC activation (off % 8 == 0)."""
+    assert off % 8 == 0
+    return t[:, off:off + Cc]
+
+
+def geom(t):
+    """(ptr, N, C, H, W, ld) of an NHWC bf16 activation view."""
+    assert t.dtype == torch.bfloat16 and t.dim() == 4, (t.dtype, t.shape)
+    N, Cc, H, W = t.shape
+    ld = t.stride(3)
+    assert t.stride(1) == 1 or Cc == 1, t.stride()
+    if H > 1:
+        assert t.stride(2) == W * ld, (t.stride(), t.shape)
+    if N > 1:
+        assert t.stride(0) == H * W * ld, (t.stride(), t.shape)
+    assert ld % 8 == 0 and t.data_ptr() % 16 == 0
+    return t.data_ptr(), N, Cc, H, W, ld
+
+
+def conv_desc(N, H, W, Ci, Co, k, stride, pad, ldx, ldy):
+    return _lib.conv_t(N, H, W, Ci, Co, k, k, stride, pad, ldx, 0, ldy, 0)
+
+
+def pack_weights(master, want_w=True, want_wt=True):
+    """master: fp32 [rows, cols, KH, KW] channels_last parameter (physical [rows][taps][cols])."""
+    rows, cols, KH, KW = master.shape
+    m = master.detach()
+    assert m.dtype == torch.float32
+    if not m.is_contiguous(memory_format=torch.channels_last) and KH * KW > 1:
+        raise _lib.GccError('conv master weights must be channels_last')
+    taps = KH * KW
+    w = torch.empty((rows, taps, ceil8(cols)), dtype=torch.bfloat16, device=m.device) if want_w else None
+    wt = torch.empty((cols, taps, ceil8(rows)), dtype=torch.bfloat16, device=m.device) if want_wt else None
+    check(lib().gcc_pack_weights(m.data_ptr(), rows, taps, cols, w.data_ptr() if want_w else None,
+                                 wt.data_ptr() if want_wt else None, stream()), 'gcc_pack_weights')
+    return w, wt
+
+
+def pack_weights_into(master, w, wt):
+    rows, cols, KH, KW = master.shape
+    check(lib().gcc_pack_weights(master.data_ptr(), rows, KH * KW, cols, w.data_ptr() if w is not None else None,
+                                 wt.data_ptr() if wt is not None else None, stream()), 'gcc_pack_weights')
+
+
+def _epilogue(bias, act, slope, stats):
+    return _lib.epilogue_t(bias.data_ptr() if bias is not None else None, act, slope,
+                           stats.data_ptr() if stats is not None else None)
+
+
+def conv_fprop(x, w, Co, k, stride, pad, out=None, bias=None, act=ACT_NONE, slope=0.2, want_stats=False):
+    xp, N, Ci, H, W, ldx = geom(x)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if out is None:
+        out = new_act(N, Co, Ho, Wo, x.device)
+    yp, _, _, _, _, ldy = geom(out)
+    d = conv_desc(N, H, W, Ci, Co, k, stride, pad, ldx, ldy)
+    stats = None
+    if want_stats:
+        tiles = lib().gcc_conv_stat_tiles(C.byref(d), 0)
+        stats = torch.empty((tiles, 2, Co), dtype=torch.float32, device=x.device)
+    ep = _epilogue(bias, act, slope, stats)
+    check(lib().gcc_conv_fprop(C.byref(d), xp, w.data_ptr(), yp, C.byref(ep), stream()), 'gcc_conv_fprop')
+    return (out, stats) if want_stats else out
+
+
+def conv_dgrad(dy, wt, Ci, H, W, k, stride, pad, out=None, bias=None, act=ACT_NONE, slope=0.2, want_stats=False):
+    """dx [N,Ci,H,W] = conv_backward_data(dy) == ConvTranspose2d forward."""
+    yp, N, Co, Ho, Wo, ldy = geom(dy)
+    assert Ho == (H + 2 * pad - k) // stride + 1 and Wo == (W + 2 * pad - k) // stride + 1
+    if out is None:
+        out = new_act(N, Ci, H, W, dy.device)
+    xp, _, _, _, _, ldx = geom(out)
+    d = conv_desc(N, H, W, Ci, Co, k, stride, pad, ldx, ldy)
+    stats = None
+    if want_stats:
+        tiles = lib().gcc_conv_stat_tiles(C.byref(d), 1)
+        stats = torch.empty((tiles, 2, Ci), dtype=torch.float32, device=dy.device)
+    ep = _epilogue(bias, act, slope, stats)
+    check(lib().gcc_conv_dgrad(C.byref(d), yp, wt.data_ptr(), xp, C.byref(ep), stream()), 'gcc_conv_dgrad')
+    return (out, stats) if want_stats else out
+
+
+def conv_wgrad(x, dy, dw, k, stride, pad, accumulate=False):
+    """dw: fp32 [Co, Ci, k, k] channels_last gradient buffer (physical [Co][taps][Ci])."""
+    xp, N, Ci, H, W, ldx = geom(x)
+    yp, _, Co, Ho, Wo, ldy = geom(dy)
+    assert tuple(dw.shape) == (Co, Ci, k, k) and dw.dtype == torch.float32
+    assert k == 1 or dw.is_contiguous(memory_format=torch.channels_last)
+    d = conv_desc(N, H, W, Ci, Co, k, stride, pad, ldx, ldy)
+    need = lib().gcc_conv_wgrad_workspace(C.byref(d))
+    ws = workspace(need, x.device, 'wgrad')
+    check(lib().gcc_conv_wgrad(C.byref(d), xp, yp, dw.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel(),
+                               stream()), 'gcc_conv_wgrad')
+    return dw
+
+
+def nchw_to_nhwc(src, dst, off=0, cfill=None):
+    """src fp32 [N,C,H,W] contiguous -> dst NHWC bf16 channels [off, off+C) (+ zero fill to cfill)."""
+    N, Cc, H, W = src.shape
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    dp, _, _, _, _, ld = geom(dst)
+    check(lib().gcc_nchw_f32_to_nhwc_bf16(src.data_ptr(), dp, N, Cc, H, W, ld, off, cfill if cfill else Cc, stream()),
+          'gcc_nchw_f32_to_nhwc_bf16')
+    return dst
+
+
+def nhwc_to_nchw(src, Cc=None):
+    sp, N, C0, H, W, ld = geom(src)
+    Cc = Cc or C0
+    out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=src.device)
+    check(lib().gcc_nhwc_bf16_to_nchw_f32(sp, out.data_ptr(), N, Cc, H, W, ld, 0, stream()), 'gcc_nhwc_bf16_to_nchw_f32')
+    return out
+
+
+def nhwc_copy(src, soff, dst, doff, Cc, cfill=None):
+    sp, N, _, H, W, lds = geom(src)
+    dp, _, _, _, _, ldd = geom(dst)
+    check(lib().gcc_nhwc_copy(sp, lds, soff, dp, ldd, doff, Cc, cfill if cfill else Cc, N * H * W, stream()), 'gcc_nhwc_copy')
+
+
+def nhwc_add(src, soff, dst, doff, Cc):
+    sp, N, _, H, W, lds = geom(src)
+    dp, _, _, _, _, ldd = geom(dst)
+    check(lib().gcc_nhwc_add(sp, lds, soff, dp, ldd, doff, Cc, N * H * W, stream()), 'gcc_nhwc_add')
+
+
+class BNState:
+    """Per-application saved statistics of one BatchNorm layer (fp32 [C] each)."""
+
+    def __init__(self, Cc, device):
+        z = torch.zeros((4, Cc), dtype=torch.float32, device=device)
+        self.mean, self.rstd, self.scale, self.shift = z[0], z[1], z[2], z[3]
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, st, eps=1e-5, momentum=0.1):
+    tiles, _, Cc = stats.shape
+    check(lib().gcc_bn_finalize(stats.data_ptr(), tiles, Cc, float(count), gamma.data_ptr(), beta.data_ptr(), eps,
+                                momentum, running_mean.data_ptr() if running_mean is not None else None,
+                                running_var.data_ptr() if running_var is not None else None, st.mean.data_ptr(),
+                                st.rstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), stream()), 'gcc_bn_finalize')
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, st, eps=1e-5):
+    check(lib().gcc_bn_eval_coeffs(gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
+                                   eps, gamma.numel(), st.scale.data_ptr(), st.shift.data_ptr(), stream()),
+          'gcc_bn_eval_coeffs')
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def bnact_fwd(x, y, y2=None, scale=None, shift=None, gate=None, gate_after_act=False, act=ACT_NONE, slope=0.2,
+              act2=ACT_NONE, drop_p=0.0, seed=0):
+    xp, N, Cc, H, W, ldx = geom(x)
+    yp, ldy = (None, 0)
+    if y is not None:
+        yp, _, _, _, _, ldy = geom(y)
+    y2p, ldy2 = (None, 0)
+    if y2 is not None:
+        y2p, _, _, _, _, ldy2 = geom(y2)
+    p = _lib.bnact_t(_p(scale), _p(shift), _p(gate), int(gate_after_act), act, slope, act2, drop_p, seed)
+    check(lib().gcc_bnact_fwd(C.byref(p), xp, ldx, 0, yp, ldy, 0, y2p, ldy2, 0, Cc, N * H * W, stream()), 'gcc_bnact_fwd')
+
+
+def bnact_bwd(x, y, g1, dx, g2=None, bn=None, gamma=None, beta=None, bn_eval=False, gate=None, gate_after_act=False,
+              act=ACT_NONE, slope=0.2, act2=ACT_NONE, drop_p=0.0, seed=0, dgamma=None, dbeta=None, dalpha=None,
+              in_act=ACT_NONE):
+    """bn: BNState (training statistics) or None."""
+    xp, N, Cc, H, W, ldx = geom(x)
+    yp, ldy = (None, 0)
+    if y is not None:
+        yp, _, _, _, _, ldy = geom(y)
+    g1p, _, _, _, _, ldg1 = geom(g1)
+    g2p, ldg2 = (None, 0)
+    if g2 is not None:
+        g2p, _, _, _, _, ldg2 = geom(g2)
+    dxp, _, _, _, _, lddx = geom(dx)
+    pixels = N * H * W
+    p = _lib.bnact_bwd_t(1 if bn is not None else 0, int(bn_eval), _p(bn.mean) if bn is not None else None,
+                         _p(bn.rstd) if bn is not None else None, _p(gamma), _p(beta), _p(gate), int(gate_after_act),
+                         act, slope, act2, drop_p, seed, _p(dgamma), _p(dbeta), _p(dalpha))
+    need = lib().gcc_bnact_bwd_workspace(Cc, pixels)
+    ws = workspace(need, x.device, 'bnbwd')
+    check(lib().gcc_bnact_bwd_ex(C.byref(p), in_act, slope, xp, ldx, 0, yp, ldy, 0, g1p, ldg1, 0, g2p, ldg2, 0, dxp, lddx,
+                                 0, Cc, pixels, ws.data_ptr(), ws.numel(), stream()), 'gcc_bnact_bwd')
+
+
+def channel_sum(x, out, accumulate=False):
+    xp, N, Cc, H, W, ld = geom(x)
+    need = lib().gcc_channel_sum_workspace(Cc, N * H * W)
+    ws = workspace(need, x.device, 'bnbwd')
+    check(lib().gcc_channel_sum(xp, ld, 0, Cc, N * H * W, out.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel(),
+                                stream()), 'gcc_channel_sum')
+
+
+def gate_mask(alpha, tau, mask):
+    check(lib().gcc_gate_mask(alpha.data_ptr(), float(tau), mask.data_ptr(), alpha.numel(), stream()), 'gcc_gate_mask')
+
+
+GAN_MODES = {'hinge': 0, 'lsgan': 1, 'vanilla': 2, 'wgangp': 3}
+
+
+def gan_loss(mode, pred, target_is_real, for_discriminator, loss, weight=1.0, accumulate=False, dpred=None):
+    pp, N, Cc, H, W, ld = geom(pred)
+    assert Cc == 1
+    dp = None
+    if dpred is not None:
+        dp, _, _, _, _, ldd = geom(dpred)
+        assert ldd == ld
+    check(lib().gcc_gan_loss(GAN_MODES[mode], int(target_is_real), int(for_discriminator), pp, ld, 0, N * H * W,
+                             float(weight), loss.data_ptr(), int(accumulate), dp, None, 0, stream()), 'gcc_gan_loss')
+
+
+def l1_loss(a, b, loss, weight=1.0, accumulate=False, da=None):
+    ap, N, Cc, H, W, lda = geom(a)
+    bp, _, _, _, _, ldb = geom(b)
+    dap, ldda = (None, 0)
+    if da is not None:
+        dap, _, _, _, _, ldda = geom(da)
+    ws = workspace(lib().gcc_loss_workspace(N * H * W, Cc), a.device, 'loss')
+    check(lib().gcc_l1_loss(ap, lda, 0, bp, ldb, 0, Cc, N * H * W, float(weight), loss.data_ptr(), int(accumulate), dap,
+                            ldda, 0, ws.data_ptr(), ws.numel(), stream()), 'gcc_l1_loss')
+
+
+def distill_workspace_bytes(N, Cc, HW):
+    return lib().gcc_distill_workspace(N, Cc, HW)
+
+
+def distill_fwd(f, t, out2, ws):
+    fp, N, Cc, H, W, ldf = geom(f)
+    tp, _, _, _, _, ldt = geom(t)
+    check(lib().gcc_distill_fwd(fp, ldf, 0, tp, ldt, 0, N, Cc, H * W, out2.data_ptr(), ws.data_ptr(), ws.numel(),
+                                stream()), 'gcc_distill_fwd')
+
+
+def distill_bwd(f, t, wg, wc, df, ws):
+    fp, N, Cc, H, W, ldf = geom(f)
+    tp, _, _, _, _, ldt = geom(t)
+    dp, _, _, _, _, ldd = geom(df)
+    check(lib().gcc_distill_bwd(fp, ldf, 0, tp, ldt, 0, N, Cc, H * W, float(wg), float(wc), dp, ldd, 0, ws.data_ptr(),
+                                ws.numel(), stream()), 'gcc_distill_bwd')
+
+
+class AdamPlan:
+    """Device-side descriptor/work lists of one optimizer (built once; pointers must stay valid)."""
+    CHUNK = 1 << 16
+
+    def __init__(self, params, grads, device, l1=None):
+        self.params = list(params)
+        self.grads = list(grads)
+        self.m = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in self.params]
+        self.v = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in self.params]
+        self.step_count = 0
+        self.device = device
+        self.l1 = list(l1) if l1 is not None else [0.0] * len(self.params)
+        self.grad_scale = 1.0
+        self._build()
+
+    def _build(self):
+        n = len(self.params)
+        T = (_lib.adam_tensor_t * n)()
+        chunks = []
+        for i, (p, g, m, v) in enumerate(zip(self.params, self.grads, self.m, self.v)):
+            assert p.dtype == torch.float32 and g.dtype == torch.float32
+            assert p.stride() == g.stride() == m.stride() == v.stride(), 'p/g/m/v must share a layout'
+            T[i] = _lib.adam_tensor_t(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                      float(self.l1[i]), float(self.grad_scale))
+            for o in range(0, p.numel(), self.CHUNK):
+                chunks.append((i, o))
+        K = (_lib.adam_chunk_t * len(chunks))()
+        for j, (i, o) in enumerate(chunks):
+            K[j] = _lib.adam_chunk_t(i, 0, o)
+        self.nchunks = len(chunks)
+        self.d_tensors = torch.frombuffer(bytearray(bytes(T)), dtype=torch.uint8).to(self.device)
+        self.d_chunks = torch.frombuffer(bytearray(bytes(K)), dtype=torch.uint8).to(self.device)
+
+    def set_grad_scale(self, s):
+        if s != self.grad_scale:
+            self.grad_scale = s
+            self._build()
+
+    def step(self, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.step_count += 1
+        check(lib().gcc_adam_step(self.d_tensors.data_ptr(), self.d_chunks.data_ptr(), self.nchunks, self.CHUNK,
+                                  float(lr), float(betas[0]), float(betas[1]), float(eps), self.step_count, stream()),
+              'gcc_adam_step')
+
+
+def fill(t, v):
+    check(lib().gcc_fill_f32(t.data_ptr(), float(v), t.numel(), stream()), 'gcc_fill_f32')
+
+
+def clamp_(t, lo, hi):
+    check(lib().gcc_clamp_f32(t.data_ptr(), float(lo), float(hi), t.numel(), stream()), 'gcc_clamp_f32')
+
+
+def scalar_op(op, a, b, out, c=None, k0=0.0, k1=0.0):
+    check(lib().gcc_scalar_op(op, a.data_ptr(), b.data_ptr(), _p(c), float(k0), float(k1), out.data_ptr(), stream()),
+          'gcc_scalar_op')

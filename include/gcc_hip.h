@@ -1,0 +1,244 @@
+/*
+ * gcc_hip.h -- C ABI of libgcc_hip.so: the MI355X (gfx950) kernels under the GCC training step.
+ *
+ * The reference (SJLeo/GCC) has no FFI layer: its hot path dispatches torch/ATen operators from
+ * models/Pix2Pix.py.  Each entry point below names the reference call site(s) whose ATen operator
+ * it replaces (paths relative to the reference root).  Conventions:
+ *   - plain C, no torch types; every pointer is a DEVICE pointer owned by the caller (activations,
+ *     weights, workspaces); the library allocates nothing and keeps no global state;
+ *   - every kernel is enqueued on the caller's `stream` and never synchronises;
+ *   - return value: 0 = GCC_OK, negative = error (see gcc_strerror); no exceptions, no abort;
+ *   - activations are NHWC bf16 (a PyTorch channels_last tensor): element (n,h,w,c) lives at
+ *     ((n*H+h)*W+w)*ld + off + c, `ld` (pixel stride, elements) and `off` multiples of 8, and the
+ *     bytes up to the next multiple of 8 channels are readable and zero;
+ *   - conv weights are bf16 in two packings made by gcc_pack_weights from the fp32 master
+ *     (a channels_last nn.Parameter, physical [Co][KH][KW][Ci]):  W  = [Co][KH*KW][Cip]  (fprop)
+ *     and Wt = [Ci][KH*KW][Cop] (dgrad), Cip/Cop = channels rounded up to 8, zero filled;
+ *   - fp32 everywhere else (statistics, losses, gradients of parameters, optimizer state).
+ */
+#ifndef GCC_HIP_H
+#define GCC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gcc_stream_t; /* hipStream_t */
+
+enum {
+    GCC_OK = 0,
+    GCC_ERR_BAD_ARG = -1,      /* null pointer / non-positive size / misaligned ld or offset */
+    GCC_ERR_UNSUPPORTED = -2,  /* geometry outside what the kernels implement */
+    GCC_ERR_WORKSPACE = -3,    /* workspace too small */
+    GCC_ERR_LAUNCH = -4        /* hipGetLastError() after launch was not hipSuccess */
+};
+
+enum { GCC_ACT_NONE = 0, GCC_ACT_LRELU = 1, GCC_ACT_RELU = 2, GCC_ACT_TANH = 3 };
+
+const char* gcc_strerror(int code);
+int gcc_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution geometry.  One descriptor serves Conv2d and ConvTranspose2d: a ConvTranspose2d
+ * (models/Pix2Pix.py:40-56) is described by the Conv2d it is the adjoint of (big image = conv
+ * input, small image = conv output) and run "backwards" (its forward = gcc_conv_dgrad, its
+ * input-gradient = gcc_conv_fprop, its weight-gradient = gcc_conv_wgrad with x := grad of its
+ * output and dy := its input).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int N;            /* batch */
+    int H, W;         /* conv INPUT spatial size */
+    int Ci, Co;       /* logical channels */
+    int KH, KW, stride, pad;
+    int ldx, xoff;    /* conv-input tensor pixel stride / channel offset (elements) */
+    int ldy, yoff;    /* conv-output tensor pixel stride / channel offset */
+} gcc_conv_t;
+
+static inline int gcc_conv_out(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
+
+/* fused epilogue of fprop / dgrad: out = act(acc + bias[c]); optional per-tile BatchNorm partial
+ * statistics (sum, sum of squares of the bf16-rounded outputs) for gcc_bn_finalize. */
+typedef struct {
+    const float* bias;    /* [channels] or NULL */
+    int act;              /* GCC_ACT_* */
+    float slope;          /* LeakyReLU slope */
+    float* stats_partial; /* NULL, or [gcc_conv_stat_tiles()][2][channels] fp32 */
+} gcc_epilogue_t;
+
+/* number of partial-statistics rows a fprop/dgrad launch writes (one per 128-pixel tile) */
+int gcc_conv_stat_tiles(const gcc_conv_t* c, int dgrad);
+
+/* y = conv(x, W) (+bias, act).  Replaces aten::convolution at models/Pix2Pix.py:31-32, 280-300,
+ * 320-343, 407-409 (F.conv2d / nn.Conv2d.forward).  x: [N,H,W,ldx]  w: W packing  y: [N,Ho,Wo,ldy] */
+int gcc_conv_fprop(const gcc_conv_t* c, const void* x, const void* w, void* y,
+                   const gcc_epilogue_t* ep, gcc_stream_t stream);
+
+/* dx = conv_backward_data(dy, Wt) (+bias, act) -- also ConvTranspose2d.forward.  Replaces
+ * aten::convolution_backward (grad_input) for the layers above and aten::convolution(transposed)
+ * at models/Pix2Pix.py:40-56.  dy: [N,Ho,Wo,ldy]  wt: Wt packing  dx: [N,H,W,ldx] */
+int gcc_conv_dgrad(const gcc_conv_t* c, const void* dy, const void* wt, void* dx,
+                   const gcc_epilogue_t* ep, gcc_stream_t stream);
+
+/* dW (+)= conv_backward_weight(x, dy) into the fp32 master layout [Co][KH*KW][Ci].  Replaces
+ * aten::convolution_backward (grad_weight).  ws: workspace of gcc_conv_wgrad_workspace() bytes
+ * (split-K slabs); accumulate != 0 adds into dw (PyTorch .grad accumulation semantics). */
+size_t gcc_conv_wgrad_workspace(const gcc_conv_t* c);
+int gcc_conv_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float* dw, int accumulate,
+                   void* ws, size_t ws_bytes, gcc_stream_t stream);
+
+/* fp32 master [rows][taps][cols] -> bf16 W [rows][taps][ceil8(cols)] and Wt [cols][taps][ceil8(rows)].
+ * Either output may be NULL. */
+int gcc_pack_weights(const float* master, int rows, int taps, int cols, void* w, void* wt,
+                     gcc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tensor packing between the public NCHW fp32 surface and NHWC bf16.
+ * Replaces torch.cat((real_A, fake_B), 1) at models/Pix2Pix.py:467,471,494,499,516 and the
+ * host->device staging of set_input (:456-457).
+ * ------------------------------------------------------------------------------------------- */
+/* dst[n,h,w,dstoff + c] = bf16(src[n,c,h,w]) for c < C ; channels [C, Cfill) zero-filled. */
+int gcc_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int N, int C, int H, int W, int ld, int off,
+                              int Cfill, gcc_stream_t stream);
+int gcc_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int N, int C, int H, int W, int ld, int off,
+                              gcc_stream_t stream);
+/* channel-slice copy between NHWC bf16 tensors: dst[.., doff+c] = src[.., soff+c], c < C (C%8==0 not
+ * required; [C, Cfill) zero-filled in dst). */
+int gcc_nhwc_copy(const void* src, int lds, int soff, void* dst, int ldd, int doff, int C, int Cfill,
+                  size_t pixels, gcc_stream_t stream);
+/* dst[.., doff+c] += src[.., soff+c]  (gradient fan-in of fake_B: models/Pix2Pix.py:516-550) */
+int gcc_nhwc_add(const void* src, int lds, int soff, void* dst, int ldd, int doff, int C, size_t pixels,
+                 gcc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm2d (training / eval) fused with activation, DifferentiableOP gate and dropout.
+ * Replaces aten::native_batch_norm(+_backward), leaky_relu_, relu_, bernoulli_/mul (Dropout) and
+ * the mask multiply of models/DifferentiableOp.py:44-49 at models/Pix2Pix.py:33-36, 57-64, 286-298,
+ * 320-341.
+ * ------------------------------------------------------------------------------------------- */
+/* Reduce the per-tile partial sums over `count` pixels into batch statistics; writes
+ * mean/rstd (saved for backward), scale = gamma*rstd, shift = beta - mean*scale and updates
+ * running_mean/var (momentum, unbiased variance) when they are non-NULL. */
+int gcc_bn_finalize(const float* stats_partial, int tiles, int C, double count, const float* gamma,
+                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                    float* mean, float* rstd, float* scale, float* shift, gcc_stream_t stream);
+/* eval mode: scale/shift from running statistics */
+int gcc_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, int C, float* scale, float* shift,
+                       gcc_stream_t stream);
+
+typedef struct {
+    const float* scale;   /* [C] or NULL (identity) */
+    const float* shift;   /* [C] or NULL */
+    const float* gate;    /* [C] gate mask m (0, .5, 1) or NULL */
+    int gate_after_act;   /* 0: act(gate(bn(x)))  (models/Pix2Pix.py:327-332) ; 1: gate(act(x)) (:320-322) */
+    int act;              /* activation written to y */
+    float slope;
+    int act2;             /* activation written to y2 (if y2 != NULL): y2 = act2(gate(bn(x))) */
+    float drop_p;         /* dropout probability (0 = off); applied after bn, before act (U-Net up path) */
+    uint64_t seed;        /* counter-based RNG: keep = hash(seed, element index) >= p */
+} gcc_bnact_t;
+
+/* y[.., yoff+c] = act(...) ; optional second output y2 (e.g. the ReLU'd copy that lands in the
+ * concat buffer).  x/y/y2 are NHWC bf16 with their own ld/off. */
+int gcc_bnact_fwd(const gcc_bnact_t* p, const void* x, int ldx, int xoff, void* y, int ldy, int yoff,
+                  void* y2, int ldy2, int y2off, int C, size_t pixels, gcc_stream_t stream);
+
+/* Backward of y = act(gate(bn(x))) [dropout] given up to two upstream gradients:
+ *   g  = g1 * act'(y)  +  g2 * act2'(y)     (g2 from the skip/concat path, may be NULL)
+ *   dz = g * m[c]  (gate)       dalpha[c] = sum g * z   (z = bn(x), STE, no mask factor)
+ *   dgamma[c] = sum dz*xhat, dbeta[c] = sum dz, dx = scale*(dz - mean(dz) - xhat*mean(dz*xhat))
+ * Two launches: reduce (writes dz into `dz` and per-block partials into ws) then apply (dx over dz).
+ * bn == 0 : no normalisation (plain act backward: dx = g*m, no statistics). */
+typedef struct {
+    int bn;                  /* 1: through BatchNorm (training statistics) */
+    int bn_eval;             /* 1: BN used running stats (dx = dz*scale) */
+    const float* mean;       /* saved mean [C] */
+    const float* rstd;       /* saved rstd [C] */
+    const float* gamma;      /* [C] */
+    const float* beta;       /* [C] */
+    const float* gate;       /* mask [C] or NULL */
+    int gate_after_act;
+    int act; float slope;    /* activation of y  (y is what act' is evaluated on, in-place semantics) */
+    int act2;                /* activation of the second consumer (g2) */
+    float drop_p; uint64_t seed;
+    float* dgamma; float* dbeta; float* dalpha;  /* [C] fp32, accumulated into (+=) ; any may be NULL */
+} gcc_bnact_bwd_t;
+
+size_t gcc_bnact_bwd_workspace(int C, size_t pixels);
+int gcc_bnact_bwd(const gcc_bnact_bwd_t* p, const void* x, int ldx, int xoff, const void* y, int ldy, int yoff,
+                  const void* g1, int ldg1, int g1off, const void* g2, int ldg2, int g2off,
+                  void* dx, int lddx, int dxoff, int C, size_t pixels, void* ws, size_t ws_bytes,
+                  gcc_stream_t stream);
+
+/* same, for a layer whose producer already applied `in_act` to x (conv epilogue): dx *= in_act'(x) */
+int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_slope, const void* x, int ldx, int xoff,
+                     const void* y, int ldy, int yoff, const void* g1, int ldg1, int g1off, const void* g2,
+                     int ldg2, int g2off, void* dx, int lddx, int dxoff, int C, size_t pixels, void* ws,
+                     size_t ws_bytes, gcc_stream_t stream);
+
+/* per-channel sum over pixels of an NHWC bf16 tensor (bias gradients): out[c] (+)= sum x[..,c] */
+int gcc_channel_sum(const void* x, int ld, int off, int C, size_t pixels, float* out, int accumulate,
+                    void* ws, size_t ws_bytes, gcc_stream_t stream);
+size_t gcc_channel_sum_workspace(int C, size_t pixels);
+
+/* gate mask m = (sign(alpha - tau) + 1) / 2.  models/DifferentiableOp.py:25-26,58-59 */
+int gcc_gate_mask(const float* alpha, float tau, float* mask, int C, gcc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Losses (forward value + gradient in one pass; scalars are fp32 device words).
+ * ------------------------------------------------------------------------------------------- */
+/* GANLoss.__call__, models/GANLoss.py:38-59.  mode 0 hinge, 1 lsgan, 2 vanilla(BCE logits), 3 wgangp.
+ * pred: NHWC bf16 [pixels][ld] channel `off` (PatchGAN map, 1 channel).  loss (+)= weight * L ;
+ * dpred (may be NULL) = weight * dL/dpred written as bf16 with the same layout. */
+int gcc_gan_loss(int mode, int target_is_real, int for_discriminator, const void* pred, int ld, int off,
+                 size_t pixels, float weight, float* loss, int accumulate, void* dpred,
+                 void* ws, size_t ws_bytes, gcc_stream_t stream);
+/* mean |a-b| * weight (nn.L1Loss, models/Pix2Pix.py:520) over C channels; da = weight*sign(a-b)/count */
+int gcc_l1_loss(const void* a, int lda, int aoff, const void* b, int ldb, int boff, int C, size_t pixels,
+                float weight, float* loss, int accumulate, void* da, int ldda, int daoff,
+                void* ws, size_t ws_bytes, gcc_stream_t stream);
+size_t gcc_loss_workspace(size_t pixels, int C);
+
+/* Feature distillation, models/Pix2Pix.py:537-548 + :733-740, for one feature pair:
+ *   gram(f) = F F^T /(c h w) per image (F = [C][HW]);  Lg = sqrt(mse(gram(f), gram(t))) ;
+ *   Lc = sqrt(mse(f, t)).   f,t: NHWC bf16 [N][HW][ld].
+ * gcc_distill_fwd writes the two scalars (unweighted) into out[0..1] and keeps what backward needs
+ * in ws; gcc_distill_bwd writes df = wg*dLg/df + wc*dLc/df (bf16, same layout as f). */
+size_t gcc_distill_workspace(int N, int C, int HW);
+int gcc_distill_fwd(const void* f, int ldf, int foff, const void* t, int ldt, int toff, int N, int C, int HW,
+                    float* out2, void* ws, size_t ws_bytes, gcc_stream_t stream);
+int gcc_distill_bwd(const void* f, int ldf, int foff, const void* t, int ldt, int toff, int N, int C, int HW,
+                    float wg, float wc, void* df, int lddf, int dfoff, void* ws, size_t ws_bytes,
+                    gcc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer: multi-tensor Adam (torch.optim.Adam, no weight decay; models/Pix2Pix.py:382,415,
+ * 430-431) with the L1-sparsity sub-gradient of L1_sparsity() (:554-563) fused in.
+ * `tensors` / `chunks` are DEVICE arrays built once per optimizer; step is the 1-based step count.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    float* p; const float* g; float* m; float* v;
+    int64_t numel;
+    float l1;        /* grad += l1 * sign(p) before the update (lambda_weight / lambda_scale) */
+    float grad_scale;/* grad *= grad_scale first (1/world_size after a sum all-reduce) */
+} gcc_adam_tensor_t;
+/* work list: one 256-thread workgroup per chunk of `chunk_elems` consecutive elements of one tensor */
+typedef struct { int tensor; int pad_; int64_t offset; } gcc_adam_chunk_t;
+int gcc_adam_step(const gcc_adam_tensor_t* tensors, const gcc_adam_chunk_t* chunks, int nchunks, int chunk_elems,
+                  float lr, float beta1, float beta2, float eps, int step, gcc_stream_t stream);
+
+/* misc fp32 helpers */
+/* device-side scalar algebra of the arch step (models/Pix2Pix.py:484-486, 505-511):
+ * op 0: out = |a-b| ; op 1: out = k0*|a-b| + k1*c ; op 2: out = a + k0*b */
+int gcc_scalar_op(int op, const float* a, const float* b, const float* c, float k0, float k1, float* out,
+                  gcc_stream_t stream);
+int gcc_fill_f32(float* p, float v, size_t n, gcc_stream_t stream);
+int gcc_clamp_f32(float* p, float lo, float hi, size_t n, gcc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCC_HIP_H */
