@@ -129,7 +129,7 @@ def gan_loss(mode: str, pred: Tensor, target_is_real: bool, for_discriminator: b
     if mode == 'hinge':
         if for_discriminator:
             z = (pred - 1) if target_is_real else (-pred - 1)
-            return -torch.clamp(z, max=0.0).mean()
+            return -torch.min(z, torch.zeros_like(z)).mean()     # binary min: ties get half the gradient
         assert target_is_real
         return -pred.mean()
     raise NotImplementedError('gan mode %s not implemented' % mode)
