@@ -9,11 +9,14 @@ the reference is copied: the outputs are data (inputs + expected outputs).
     python tests/golden/make_fixtures.py            # rewrites tests/golden/*.npz
 
 Fixtures
-  pix2pix_eval_d8.npz   eval-mode U-Net (num_downs 8, ngf 4, 256x256): weights, input, fake_B
-  pix2pix_gcc_d6.npz    student(ngf4,ndf4,masked D)+teacher(ngf8,ndf8), num_downs 6, 64x64, N=2,
-                        --no_dropout, direction BtoA: 2 x (optimize_parameters + arch step):
-                        initial state_dicts, inputs, per-iteration losses, iteration-1 hooked
-                        features / targets / fake_B, final state_dicts (incl. BN running stats, alpha)
+  (weights marked "recipe" are NOT stored: tests/golden/recipe.py regenerates them; the script
+   loads the recipe values into the reference's modules before running them)
+  pix2pix_eval_d8.npz   eval-mode U-Net (num_downs 8, ngf 8, 256x256), recipe weights: input, fake_B
+  pix2pix_gcc_d6.npz    student(ngf8,ndf8,masked D)+teacher(ngf16,ndf16), num_downs 6, 64x64, N=2,
+                        --no_dropout, direction BtoA, recipe weights: 2 x (optimize_parameters +
+                        arch step): inputs, per-iteration losses, iteration-1 hooked features /
+                        targets / fake_B, final state (small tensors whole, large ones subsampled
+                        at recipe.sample_idx positions; BN running stats, alpha included)
   pix2pix_pretrain_d6.npz  plain Pix2Pix (no teacher, plain D, lambda_scale 1e-2): 2 iterations
   ops.npz               DifferentiableOP fwd/bwd (alpha <,==,> tau), GANLoss x4 modes, gram,
                         LambdaLR values, init_weights statistics
@@ -29,6 +32,8 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from recipe import recipe_state_dict, recipe_transform, sample_idx  # noqa: E402
 REF = '/root/reference'
 
 
@@ -88,21 +93,27 @@ def build_gcc(opt):
     return model, teacher
 
 
+def load_recipe(module, seed):
+    sd = module.state_dict()
+    rec = recipe_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed)
+    module.load_state_dict(rec)
+
+
+def sd_np_sampled(prefix, sd, out):
+    for k, v in sd.items():
+        v = v.detach().cpu().reshape(-1)
+        out[prefix + k] = v[sample_idx(v.numel())].numpy().copy()
+
+
 def fixture_eval_d8():
-    torch.manual_seed(11)
     opt = parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '-1',
-                 '--ngf', '4', '--ndf', '4', '--no_dropout'])
+                 '--ngf', '8', '--ndf', '8', '--no_dropout'])
     from models import get_model_class
     model = get_model_class(opt)(opt)
-    # make the running statistics non-trivial: a few train-mode passes first
-    model.model_train()
-    g = torch.Generator().manual_seed(5)
-    for _ in range(3):
-        with torch.no_grad():
-            model.netG(torch.rand(2, 3, 256, 256, generator=g) * 2 - 1)
+    load_recipe(model.netG, 31)
     model.model_eval()
     out = {}
-    sd_np('G.', model.netG.state_dict(), out)
+    g = torch.Generator().manual_seed(5)
     A = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
     B = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
     model.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
@@ -111,6 +122,7 @@ def fixture_eval_d8():
     out['A'] = A.numpy()
     out['B'] = B.numpy()
     out['direction'] = np.array(opt.direction)
+    out['seed_G'] = np.array(31)
     out['fake_B'] = model.get_current_visuals()['fake_B'].numpy()
     np.savez_compressed(os.path.join(HERE, 'pix2pix_eval_d8.npz'), **out)
     print('pix2pix_eval_d8: fake_B', out['fake_B'].shape, 'direction', opt.direction)
@@ -119,26 +131,31 @@ def fixture_eval_d8():
 def fixture_gcc_d6():
     torch.manual_seed(7)
     opt = parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '-1',
-                 '--ngf', '4', '--ndf', '4', '--teacher_ngf', '8', '--num_downs', '6', '--no_dropout',
+                 '--ngf', '8', '--ndf', '8', '--teacher_ngf', '16', '--num_downs', '6', '--no_dropout',
                  '--online_distillation', '--darts_discriminator', '--lambda_content', '50',
                  '--lambda_gram', '1e4', '--arch_lr', '1e-4', '--arch_lr_step'])
-    opt.teacher_ndf = 8            # parse() forces 128; shrunk so the fixture stays small
+    opt.teacher_ndf = 16           # parse() forces 128; shrunk so the fixture stays small
     opt.batch_size = 2
     model, teacher = build_gcc(opt)
     model.model_train()
     out = {'direction': np.array(opt.direction), 'threshold': np.array(opt.threshold),
-           'flags': np.array(' '.join(sys.argv[1:]) + ' (teacher_ndf=8)')}
-    # nudge two alphas so that the gate has <, == and > tau channels
+           'flags': np.array(' '.join(sys.argv[1:]) + ' (teacher_ndf=16)'),
+           'seeds': np.array([101, 102, 103, 104, 105])}     # sG sD tG tD T
+    load_recipe(model.netG, 101)
+    load_recipe(model.netD, 102)
+    load_recipe(teacher.netG, 103)
+    load_recipe(teacher.netD, 104)
     with torch.no_grad():
+        for i, t in enumerate(model.transform_convs):
+            t.weight.copy_(recipe_transform(t.weight.shape[0], t.weight.shape[1], 105 + i))
+        # nudge alphas so that the gates have <, == and > tau channels
         a = model.netD.model[2].alpha
         a[0] = 0.2
         a[1] = 0.5
-    sd_np('init.sG.', model.netG.state_dict(), out)
-    sd_np('init.sD.', model.netD.state_dict(), out)
-    sd_np('init.tG.', teacher.netG.state_dict(), out)
-    sd_np('init.tD.', teacher.netD.state_dict(), out)
-    for i, t in enumerate(model.transform_convs):
-        out['init.T.%d' % i] = t.weight.detach().numpy().copy()
+        model.netD.model[5].alpha[3] = 0.1
+    for k, v in model.netD.state_dict().items():
+        if k.endswith('alpha'):
+            out['init.sD.' + k] = v.numpy().copy()
     g = torch.Generator().manual_seed(99)
     n_iter = 2
     for it in range(n_iter):
@@ -159,8 +176,8 @@ def fixture_gcc_d6():
                 out['it0.sfeat.%d' % j] = f.detach().numpy().copy()
             for j, f in enumerate(teacher.total_discriminator_features.values()):
                 out['it0.tDfeat_on_sfake.%d' % j] = f.detach().numpy().copy()
-            sd_np('it0.afterstep.sG.', model.netG.state_dict(), out)
-            sd_np('it0.afterstep.sD.', model.netD.state_dict(), out)
+            sd_np_sampled('it0.afterstep.sG.', model.netG.state_dict(), out)
+            sd_np_sampled('it0.afterstep.sD.', model.netD.state_dict(), out)
         model.set_input({'A': vA, 'B': vB, 'A_paths': ['a'], 'B_paths': ['b']})
         model.clipping_mask_alpha()
         model.optimizer_netD_arch()
@@ -168,10 +185,10 @@ def fixture_gcc_d6():
             out['it%d.loss.%s' % (it, k)] = np.array(v, dtype=np.float64)
         for k in ('G_GAN', 'G_L1', 'D_real', 'D_fake'):
             out['it%d.tloss.%s' % (it, k)] = np.array(float(getattr(teacher, 'loss_' + k)), dtype=np.float64)
-    sd_np('final.sG.', model.netG.state_dict(), out)
-    sd_np('final.sD.', model.netD.state_dict(), out)
-    sd_np('final.tG.', teacher.netG.state_dict(), out)
-    sd_np('final.tD.', teacher.netD.state_dict(), out)
+    sd_np_sampled('final.sG.', model.netG.state_dict(), out)
+    sd_np_sampled('final.sD.', model.netD.state_dict(), out)
+    sd_np_sampled('final.tG.', teacher.netG.state_dict(), out)
+    sd_np_sampled('final.tD.', teacher.netD.state_dict(), out)
     for i, t in enumerate(model.transform_convs):
         out['final.T.%d' % i] = t.weight.detach().numpy().copy()
     out['threads'] = np.array(torch.get_num_threads())
@@ -182,13 +199,13 @@ def fixture_gcc_d6():
 def fixture_pretrain_d6():
     torch.manual_seed(21)
     opt = parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '-1',
-                 '--ngf', '4', '--ndf', '4', '--num_downs', '6', '--no_dropout', '--lambda_scale', '1e-2'])
+                 '--ngf', '8', '--ndf', '8', '--num_downs', '6', '--no_dropout', '--lambda_scale', '1e-2'])
     from models import get_model_class
     model = get_model_class(opt)(opt)
     model.model_train()
-    out = {'direction': np.array(opt.direction)}
-    sd_np('init.G.', model.netG.state_dict(), out)
-    sd_np('init.D.', model.netD.state_dict(), out)
+    out = {'direction': np.array(opt.direction), 'seeds': np.array([201, 202])}
+    load_recipe(model.netG, 201)
+    load_recipe(model.netD, 202)
     g = torch.Generator().manual_seed(3)
     for it in range(2):
         A = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
@@ -198,8 +215,8 @@ def fixture_pretrain_d6():
         model.optimize_parameters()
         for k, v in model.get_current_losses().items():
             out['it%d.loss.%s' % (it, k)] = np.array(v, dtype=np.float64)
-    sd_np('final.G.', model.netG.state_dict(), out)
-    sd_np('final.D.', model.netD.state_dict(), out)
+    sd_np_sampled('final.G.', model.netG.state_dict(), out)
+    sd_np_sampled('final.D.', model.netD.state_dict(), out)
     # LR schedule values as the reference's scheduler produces them (n_epochs 10, decay 15 here)
     lrs = []
     for ep in range(1, opt.n_epochs + opt.n_epochs_decay + 1):
@@ -277,11 +294,13 @@ def fixture_prune_d8():
                  '--ngf', '8', '--ndf', '4', '--scale_prune'])
     from models import get_model_class
     model = get_model_class(opt)(opt)
-    out = {}
-    G = model.netG.state_dict()
-    for k, v in G.items():
-        if k.endswith('.weight'):
-            out['G.' + k] = v.numpy().copy()
+    out = {'seed_G': np.array(301)}
+    load_recipe(model.netG, 301)
+    with torch.no_grad():      # spread the BN scales so that thresholds prune different amounts
+        gsp = torch.Generator().manual_seed(302)
+        for m in model.netG.modules():
+            if m.__class__.__name__ == 'BatchNorm2d':
+                m.weight.copy_(1.0 + 0.02 * torch.randn(m.weight.shape, generator=gsp))
     mx, mn = model.max_min_bn_scale()
     out['bn.max_min'] = np.array([float(mx), float(mn)], dtype=np.float64)
     ths = [float(mn) - 0.01, 0.97, 0.99, 1.0, 1.01, 1.03, float(mx)]

@@ -1,0 +1,45 @@
+"""Deterministic weight recipe shared by tests/golden/make_fixtures.py (which loads these values
+INTO the real reference models before running them) and by the tests (which rebuild the same
+values instead of storing megabytes of random weights).  Pure torch-CPU; imports nothing from the
+reference."""
+import zlib
+
+import torch
+
+
+def recipe_state_dict(shapes, seed):
+    """name -> tensor following the reference's init rule (utils/util.py:261-286) with one seeded
+    generator per tensor: conv W ~ N(0,.02), conv bias 0, BN gamma ~ N(1,.02), BN beta ~ N(0,1),
+    running_mean ~ N(0,.1), running_var ~ U(.5,1.5), alpha = 1, num_batches_tracked = 0."""
+    sd = {}
+    for k, shp in shapes.items():
+        g = torch.Generator().manual_seed(seed * 1000003 + zlib.crc32(k.encode()) % 1000003)
+        shp = tuple(shp)
+        if k.endswith('num_batches_tracked'):
+            sd[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith('running_mean'):
+            sd[k] = torch.randn(shp, generator=g) * 0.1
+        elif k.endswith('running_var'):
+            sd[k] = torch.rand(shp, generator=g) + 0.5
+        elif k.endswith('alpha'):
+            sd[k] = torch.ones(shp)
+        elif len(shp) == 4:
+            sd[k] = torch.randn(shp, generator=g) * 0.02
+        elif k.endswith('.weight'):
+            sd[k] = 1.0 + torch.randn(shp, generator=g) * 0.02
+        else:  # bias: conv bias (its module has a 4-d weight) -> 0 ; BN beta -> N(0,1)
+            wk = k[:-len('bias')] + 'weight'
+            sd[k] = torch.zeros(shp) if (wk in shapes and len(shapes[wk]) == 4) else torch.randn(shp, generator=g)
+    return sd
+
+
+def recipe_transform(cout, cin, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand((cout, cin, 1, 1), generator=g) * 2 - 1) / (cin ** 0.5)
+
+
+def sample_idx(n, k=2048):
+    """fixed subsample positions used to store large final tensors compactly"""
+    if n <= k:
+        return torch.arange(n)
+    return (torch.arange(k, dtype=torch.float64) * (n - 1) / (k - 1)).round().long()

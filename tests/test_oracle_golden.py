@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from oracle import gcc_oracle as O
+from tests.golden.recipe import recipe_state_dict, recipe_transform, sample_idx
 
 torch.set_num_threads(8)
 
@@ -27,7 +28,7 @@ def sd_from(z, prefix):
 
 def test_eval_generated_images(golden_dir):
     z = load(golden_dir, 'pix2pix_eval_d8.npz')
-    G = sd_from(z, 'G.')
+    G = recipe_state_dict(O.unet_shapes(8, 8), int(z['seed_G']))
     A, B = torch.from_numpy(z['A']), torch.from_numpy(z['B'])
     real_A = A if str(z['direction']) == 'AtoB' else B
     with torch.no_grad():
@@ -42,10 +43,14 @@ def test_state_dict_key_parity(golden_dir):
     assert list(O.unet_shapes(4, 6).keys()) == [str(k) for k in z['init.G_keys']]
     assert list(O.patchgan_shapes(4, 6, False).keys()) == [str(k) for k in z['init.D_keys']]
     g = load(golden_dir, 'pix2pix_gcc_d6.npz')
-    masked_keys = [k[len('init.sD.'):] for k in g.files if k.startswith('init.sD.')]
-    assert list(O.patchgan_shapes(4, 6, True).keys()) == masked_keys
-    for k, shp in O.unet_shapes(8, 6).items():
-        assert tuple(g['init.tG.' + k].shape) == tuple(shp), k
+    masked_keys = [k[len('final.sD.'):] for k in g.files if k.startswith('final.sD.')]
+    assert list(O.patchgan_shapes(8, 6, True).keys()) == masked_keys
+    shp = O.unet_shapes(16, 6)
+    for k in [k[len('final.tG.'):] for k in g.files if k.startswith('final.tG.')]:
+        n = 1
+        for d in shp[k]:
+            n *= d
+        assert g['final.tG.' + k].size == min(n, 2048), k
 
 
 def test_gate_fwd_bwd(golden_dir):
@@ -106,9 +111,10 @@ def _compare_sd(got, z, prefix, atol, rtol=1e-4):
             continue
         name = k[len(prefix):]
         ref = z[k]
-        g = got[name].detach().numpy()
+        g = got[name].detach().reshape(-1)
+        g = g[sample_idx(g.numel())].numpy()
         if ref.dtype.kind in 'iu':
-            assert int(g) == int(ref), name
+            assert int(g[0]) == int(ref.reshape(-1)[0]), name
             continue
         err = np.abs(g - ref).max()
         tol = atol + rtol * np.abs(ref).max()
@@ -119,9 +125,11 @@ def _compare_sd(got, z, prefix, atol, rtol=1e-4):
 
 def test_pretrain_two_iterations(golden_dir):
     z = load(golden_dir, 'pix2pix_pretrain_d6.npz')
-    opt = O.Opt(ngf=4, ndf=4, num_downs=6, no_dropout=True, lambda_scale=1e-2, darts_discriminator=False,
+    opt = O.Opt(ngf=8, ndf=8, num_downs=6, no_dropout=True, lambda_scale=1e-2, darts_discriminator=False,
                 online_distillation=False, direction=str(z['direction']))
-    m = O.Pix2PixOracle(opt, sd_from(z, 'init.G.'), sd_from(z, 'init.D.'), masked=False)
+    sG, sD = [int(v) for v in z['seeds']]
+    m = O.Pix2PixOracle(opt, recipe_state_dict(O.unet_shapes(8, 6), sG),
+                        recipe_state_dict(O.patchgan_shapes(8, 6, False), sD), masked=False)
     for it in range(2):
         m.set_input(torch.from_numpy(z['it%d.A' % it]), torch.from_numpy(z['it%d.B' % it]))
         m.optimize_parameters()
@@ -131,13 +139,26 @@ def test_pretrain_two_iterations(golden_dir):
     _compare_sd(m.D, z, 'final.D.', atol=2e-5)
 
 
+def build_gcc_oracle(z):
+    """student+teacher oracle with the recipe weights the fixture was generated from"""
+    opt = O.Opt(ngf=8, ndf=8, teacher_ngf=16, teacher_ndf=16, num_downs=6, no_dropout=True,
+                direction=str(z['direction']), threshold=float(z['threshold']))
+    s_sG, s_sD, s_tG, s_tD, s_T = [int(v) for v in z['seeds']]
+    teacher = O.Pix2PixOracle(opt, recipe_state_dict(O.unet_shapes(16, 6), s_tG),
+                              recipe_state_dict(O.patchgan_shapes(16, 6, False), s_tD), masked=False)
+    sD = recipe_state_dict(O.patchgan_shapes(8, 6, True), s_sD)
+    for k in z.files:
+        if k.startswith('init.sD.'):
+            sD[k[len('init.sD.'):]] = torch.from_numpy(np.array(z[k]))
+    sw, tw = [16, 64, 128, 32], [32, 128, 256, 64]
+    T = [recipe_transform(t, s, s_T + i) for i, (s, t) in enumerate(zip(sw, tw))]
+    m = O.Pix2PixOracle(opt, recipe_state_dict(O.unet_shapes(8, 6), s_sG), sD, T, masked=True, teacher=teacher)
+    return m, teacher, opt
+
+
 def test_gcc_two_iterations(golden_dir):
     z = load(golden_dir, 'pix2pix_gcc_d6.npz')
-    opt = O.Opt(ngf=4, ndf=4, teacher_ngf=8, teacher_ndf=8, num_downs=6, no_dropout=True,
-                direction=str(z['direction']), threshold=float(z['threshold']))
-    teacher = O.Pix2PixOracle(opt, sd_from(z, 'init.tG.'), sd_from(z, 'init.tD.'), masked=False)
-    T = [torch.from_numpy(z['init.T.%d' % i]) for i in range(4)]
-    m = O.Pix2PixOracle(opt, sd_from(z, 'init.sG.'), sd_from(z, 'init.sD.'), T, masked=True, teacher=teacher)
+    m, teacher, opt = build_gcc_oracle(z)
     for it in range(2):
         m.set_input(torch.from_numpy(z['it%d.A' % it]), torch.from_numpy(z['it%d.B' % it]))
         m.optimize_parameters()
@@ -178,7 +199,11 @@ def test_gcc_two_iterations(golden_dir):
 
 def test_prune_cfgs_bit_exact(golden_dir):
     z = load(golden_dir, 'prune_d8.npz')
-    G = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('G.')}
+    G = recipe_state_dict(O.unet_shapes(8, 8), int(z['seed_G']))
+    gsp = torch.Generator().manual_seed(302)
+    # same BN-scale spread the fixture script applied, in the reference's modules() order
+    for name in O._unet_bn_names(8):
+        G[name + '.weight'] = 1.0 + 0.02 * torch.randn(G[name + '.weight'].shape, generator=gsp)
     mx, mn = O.max_min_bn_scale(G)
     assert [mx, mn] == [float(v) for v in z['bn.max_min']]
     for i, t in enumerate(z['bn.thresholds']):
