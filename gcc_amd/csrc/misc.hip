@@ -110,9 +110,11 @@ __device__ __forceinline__ float block_sum256(float v, float* sh) {
 // GANLoss over a 1-channel PatchGAN map; single block (the map is a few 10^4 values)
 __global__ __launch_bounds__(1024) void gan_loss_kernel(int mode, int real, int ford, const bf16_t* __restrict__ pred, int ld,
                                                         int off, size_t pixels, float weight, float* loss, int accumulate,
-                                                        bf16_t* dpred) {
+                                                        bf16_t* dpred, float gweight, const float* gweight_dev,
+                                                        int dpred_accumulate) {
     __shared__ float sh[16];
     const float inv = 1.f / (float)pixels;
+    const float gw = gweight * (gweight_dev ? gweight_dev[0] : 1.f);
     float acc = 0.f;
     for (size_t i = threadIdx.x; i < pixels; i += blockDim.x) {
         const float x = bf2f(pred[i * ld + off]);
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(1024) void gan_loss_kernel(int mode, int real, int 
         }
         acc += l;
         if (dpred) {
-            float o[8] = {weight * d * inv, 0, 0, 0, 0, 0, 0, 0};
+            float o[8] = {gw * d * inv, 0, 0, 0, 0, 0, 0, 0};
+            if (dpred_accumulate) o[0] += bf2f(dpred[i * ld + off]);
             *(i32x4*)(dpred + i * ld + off) = pack8(o);
         }
     }
@@ -338,7 +341,41 @@ extern "C" int gcc_gan_loss(int mode, int target_is_real, int for_discriminator,
     if (!pred || !loss || pixels == 0 || (ld & 7) || (off & 7) || mode < 0 || mode > 3) return GCC_ERR_BAD_ARG;
     if (mode == 0 && !for_discriminator && !target_is_real) return GCC_ERR_BAD_ARG;   // reference asserts
     hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mode, target_is_real, for_discriminator,
-                       (const bf16_t*)pred, ld, off, pixels, weight, loss, accumulate, (bf16_t*)dpred);
+                       (const bf16_t*)pred, ld, off, pixels, weight, loss, accumulate, (bf16_t*)dpred, weight, (const float*)nullptr, 0);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+extern "C" int gcc_gan_loss_ex(int mode, int target_is_real, int for_discriminator, const void* pred, int ld, int off,
+                               size_t pixels, float* loss, void* dpred, float grad_weight, const float* grad_weight_dev,
+                               int dpred_accumulate, gcc_stream_t stream) {
+    if (!pred || !loss || pixels == 0 || (ld & 7) || (off & 7) || mode < 0 || mode > 3) return GCC_ERR_BAD_ARG;
+    if (mode == 0 && !for_discriminator && !target_is_real) return GCC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mode, target_is_real, for_discriminator,
+                       (const bf16_t*)pred, ld, off, pixels, 1.f, loss, 0, (bf16_t*)dpred, grad_weight, grad_weight_dev,
+                       dpred_accumulate);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+// arch step scalars (models/Pix2Pix.py:479-487): dS = |Lfr - Lf| ;
+// loss = |dS - dT| + (Lr + Lf)/2 ; c_fr = dloss/dLfr ; c_f = dloss/dLf   (dloss/dLr = 1/2)
+__global__ void arch_coeffs_kernel(const float* Lfr, const float* Lf, const float* Lr, const float* dT, float* loss,
+                                   float* c_fr, float* c_f) {
+    if (threadIdx.x || blockIdx.x) return;
+    const float a = Lfr[0] - Lf[0];
+    const float dS = fabsf(a);
+    const float s1 = a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
+    const float b = dS - dT[0];
+    const float s2 = b > 0.f ? 1.f : (b < 0.f ? -1.f : 0.f);
+    loss[0] = fabsf(b) + 0.5f * (Lr[0] + Lf[0]);
+    c_fr[0] = s2 * s1;
+    c_f[0] = -s2 * s1 + 0.5f;
+}
+extern "C" int gcc_arch_coeffs(const float* Lfr, const float* Lf, const float* Lr, const float* dT, float* loss, float* c_fr,
+                               float* c_f, gcc_stream_t stream) {
+    if (!Lfr || !Lf || !Lr || !dT || !loss || !c_fr || !c_f) return GCC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(arch_coeffs_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, Lfr, Lf, Lr, dT, loss, c_fr, c_f);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

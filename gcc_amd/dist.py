@@ -1,0 +1,82 @@
+"""Data parallelism: one process per GPU, gradients summed over ranks on RCCL (torch.distributed
+backend "nccl" on ROCm) at the backward boundaries of the iteration; BatchNorm statistics stay
+rank-local (the reference has no SyncBN to mimic).  Initialised by the
+launcher environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), e.g. torch.distributed.run."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
+def rank():
+    return dist.get_rank() if is_dist() else 0
+
+
+def init_from_env(backend=None):
+    """Initialise the process group when launched with WORLD_SIZE > 1 (idempotent)."""
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    if ws <= 1 or is_dist():
+        return world_size()
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if backend == 'nccl':
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws)
+    return ws
+
+
+def local_device(opt):
+    """cuda:{LOCAL_RANK} under a multi-process launch, else cuda:{gpu_ids[0]} (models/Pix2Pix.py:356)"""
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        return torch.device('cuda:%d' % int(os.environ.get('LOCAL_RANK', '0')))
+    return torch.device('cuda:%d' % opt.gpu_ids[0])
+
+
+def broadcast_module(module, src=0):
+    """make replicas start identical (parameters and buffers)"""
+    if not is_dist():
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)
+
+
+def all_reduce_flat(flat_grads):
+    """sum the flat gradient buffer of one parameter group over ranks (scaled by 1/world inside the
+    Adam kernel via grad_scale)"""
+    if is_dist():
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+
+
+def all_reduce_grads(optimizer):
+    if not is_dist():
+        return
+    optimizer.plan.set_grad_scale(1.0 / world_size())
+    all_reduce_flat(optimizer.flat.grads)
+
+
+def mean_dict(d, device):
+    if not is_dist():
+        return d
+    keys = list(d.keys())
+    t = torch.tensor([d[k] for k in keys], dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    t /= world_size()
+    return type(d)((k, float(v)) for k, v in zip(keys, t.tolist()))
+
+
+def shard_range(n_items, r=None, w=None):
+    """contiguous [begin, end) share of n_items for rank r of w"""
+    r = rank() if r is None else r
+    w = world_size() if w is None else w
+    per, rem = divmod(n_items, w)
+    b = r * per + min(r, rem)
+    return b, b + per + (1 if r < rem else 0)

@@ -1,0 +1,472 @@
+"""Execution engine of the GCC Pix2Pix step on MI355X.
+
+The nn.Module trees in gcc_amd/models only *name and own* parameters (so state_dicts are
+interchangeable with the reference, SURVEY.md section 5 "checkpoint").  Everything that computes is
+here: explicit forward / backward schedules of HIP kernels (gcc_amd.ops -> libgcc_hip.so) over
+persistent NHWC bf16 activation buffers.  There is no autograd tape and no PyTorch operator on the
+path; the reference's in-place aliasing (SURVEY.md hazard H1) is made explicit by materialising the
+two activated copies each skip tensor is read through (LeakyReLU'd for the next down conv, ReLU'd
+inside the concat buffer of the up path).
+
+Reference anchors: U-Net models/Pix2Pix.py:20-130, PatchGAN :267-348, hooks :363-373,702-727.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH
+
+LRELU = 0.2
+
+
+# ------------------------------------------------------------------------------------------------
+# flat fp32 storage of a parameter group: one buffer for values, one for gradients
+# ------------------------------------------------------------------------------------------------
+class FlatParams:
+    """Re-homes parameters into one flat fp32 buffer (values) + one flat gradient buffer, keeping
+    every tensor's logical shape and strides (conv weights stay channels_last).  One fill zeroes all
+    gradients, one all-reduce exchanges them, one multi-tensor Adam launch updates them."""
+
+    def __init__(self, params, device):
+        self.params = [p for p in params]
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 3) & ~3
+        self.total = total
+        self.values = torch.zeros(max(total, 4), dtype=torch.float32, device=device)
+        self.grads = torch.zeros(max(total, 4), dtype=torch.float32, device=device)
+        self.grad_views = []
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                src = p.detach().to(device)
+                if src.dim() == 4 and src.shape[2] * src.shape[3] > 1:
+                    src = src.contiguous(memory_format=torch.channels_last)
+                else:
+                    src = src.contiguous()
+                v = torch.as_strided(self.values, src.shape, src.stride(), o)
+                v.copy_(src)
+                p.data = v
+                g = torch.as_strided(self.grads, src.shape, src.stride(), o)
+                p.grad = g
+                self.grad_views.append(g)
+
+    def zero_grad(self):
+        ops.fill(self.grads, 0.0)
+
+
+def bn_buffers_to(module, device):
+    for b in module.buffers():
+        b.data = b.data.to(device)
+
+
+# ------------------------------------------------------------------------------------------------
+class ConvOp:
+    """A Conv2d or ConvTranspose2d parameter set with its bf16 packings.
+
+    master weight [rows, cols, k, k] (channels_last):  Conv2d rows=Co cols=Ci ;
+    ConvTranspose2d rows=Cin cols=Cout == the adjoint Conv2d (big image -> small image) with
+    Co=rows, Ci=cols; its forward is that conv's backward-data."""
+
+    def __init__(self, weight, bias, k, stride, pad, transposed):
+        self.weight, self.bias = weight, bias
+        self.k, self.stride, self.pad, self.transposed = k, stride, pad, transposed
+        self.rows, self.cols = weight.shape[0], weight.shape[1]
+        dev = weight.device
+        taps = k * k
+        self.w = torch.zeros((self.rows, taps, ops.ceil8(self.cols)), dtype=torch.bfloat16, device=dev)
+        self.wt = torch.zeros((self.cols, taps, ops.ceil8(self.rows)), dtype=torch.bfloat16, device=dev)
+
+    def repack(self):
+        ops.pack_weights_into(self.weight.data, self.w, self.wt)
+
+    # -- forward ---------------------------------------------------------------------------
+    def forward(self, x, out, act=ACT_NONE, want_stats=False, use_bias=True):
+        b = self.bias.data if (self.bias is not None and use_bias) else None
+        if not self.transposed:
+            return ops.conv_fprop(x, self.w, self.rows, self.k, self.stride, self.pad, out=out, bias=b, act=act,
+                                  slope=LRELU, want_stats=want_stats)
+        N, _, H, W = out.shape
+        return ops.conv_dgrad(x, self.wt, self.cols, H, W, self.k, self.stride, self.pad, out=out, bias=b, act=act,
+                              slope=LRELU, want_stats=want_stats)
+
+    # -- gradient w.r.t. the layer input ------------------------------------------------------
+    def backward_data(self, dy, out):
+        if not self.transposed:
+            N, _, H, W = out.shape
+            return ops.conv_dgrad(dy, self.wt, self.cols, H, W, self.k, self.stride, self.pad, out=out)
+        return ops.conv_fprop(dy, self.w, self.rows, self.k, self.stride, self.pad, out=out)
+
+    # -- gradient w.r.t. the weight (accumulates into weight.grad) and bias -------------------------
+    def backward_weight(self, x, dy):
+        if not self.transposed:
+            ops.conv_wgrad(x, dy, self.weight.grad, self.k, self.stride, self.pad, accumulate=True)
+        else:
+            ops.conv_wgrad(dy, x, self.weight.grad, self.k, self.stride, self.pad, accumulate=True)
+        if self.bias is not None:
+            ops.channel_sum(dy, self.bias.grad, accumulate=True)
+
+
+class BNOp:
+    def __init__(self, bn: nn.BatchNorm2d):
+        self.bn = bn
+        self.C = bn.num_features
+
+    def finalize(self, stats, count, st, train):
+        bn = self.bn
+        if train:
+            ops.bn_finalize(stats, count, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, st,
+                            eps=bn.eps, momentum=bn.momentum)
+            bn.num_batches_tracked += 1
+        else:
+            ops.bn_eval_coeffs(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, st, eps=bn.eps)
+
+
+def _get(module, dotted):
+    m = module
+    for part in dotted.split('.'):
+        m = getattr(m, part)
+    return m
+
+
+# ------------------------------------------------------------------------------------------------
+# U-Net generator
+# ------------------------------------------------------------------------------------------------
+class UnetEngine:
+    """Forward / backward schedule of UnetGenertor(num_downs=D) for channel widths that are
+    multiples of 8 (pruned, irregular widths: see DESIGN.md 'next')."""
+
+    def __init__(self, module, num_downs, device, use_dropout=False):
+        self.module, self.D, self.device = module, num_downs, device
+        D = num_downs
+        self.use_dropout = use_dropout
+
+        def prefix(d):
+            return 'model' if d == 0 else 'model.model.1' + '.model.3' * (d - 1)
+        self.prefix = prefix
+        self.down, self.down_bn, self.up, self.up_bn = [None] * D, [None] * D, [None] * D, [None] * D
+        for d in range(D):
+            p = prefix(d)
+            cname = p + ('.model.0' if d == 0 else '.model.1')
+            c = _get(module, cname)
+            self.down[d] = ConvOp(c.weight, c.bias, 4, 2, 1, False)
+            if 0 < d < D - 1:
+                self.down_bn[d] = BNOp(_get(module, p + '.model.2'))
+            uname = p + ('.model.3' if d in (0, D - 1) else '.model.5')
+            u = _get(module, uname)
+            self.up[d] = ConvOp(u.weight, u.bias, 4, 2, 1, True)
+            if d > 0:
+                self.up_bn[d] = BNOp(_get(module, p + ('.model.4' if d == D - 1 else '.model.6')))
+        self.width = [self.down[d].rows for d in range(D)]          # channels of e[d]
+        self.uwidth = [self.up[d].cols for d in range(D)]           # channels of the up-conv output at depth d
+        for wdt in self.width + self.uwidth[1:]:
+            if wdt % 8:
+                raise NotImplementedError('U-Net widths must be multiples of 8 on this path (got %s / %s)'
+                                          % (self.width, self.uwidth))
+        self.drop_depths = [D - 2 - i for i in range(D - 5)] if use_dropout else []
+        self.hook_names = ['model.model.1.model.2', 'model.model.1.model.3.model.3.model.2',
+                           'model.model.1.model.3.model.3.model.4', 'model.model.1.model.4']
+        self.ctx = {}
+        self.seed = 0x5EED
+
+    def convs(self):
+        return [c for c in self.down + self.up if c is not None]
+
+    def repack(self):
+        for c in self.convs():
+            c.repack()
+
+    # ---------------------------------------------------------------------------------------
+    def _ctx(self, N, H, W):
+        key = (N, H, W)
+        if key in self.ctx:
+            return self.ctx[key]
+        D, dev, wd, uw = self.D, self.device, self.width, self.uwidth
+        c = type('UnetCtx', (), {})()
+        c.N, c.H, c.W = N, H, W
+        hs = [(H >> (d + 1), W >> (d + 1)) for d in range(D)]     # spatial size of e[d]
+        c.hs = hs
+        c.x_in = ops.new_act(N, 3, H, W, dev)
+        c.e = [None] * D        # raw conv output (pre-BN) at depth d (d = D-1: post-ReLU, fused)
+        c.lin = [None] * (D + 1)  # lin[d] = leaky_relu(e[d-1]) : input of down conv d
+        c.rcat = [None] * D     # rcat[d] = relu(cat(e[d-1] | u_d)) : input of up conv d-1
+        c.t = [None] * D        # raw up-conv output (pre-BN) of depth d, d >= 1
+        c.st_down = [None] * D
+        c.st_up = [None] * D
+        for d in range(D):
+            h, w = hs[d]
+            c.e[d] = ops.new_act(N, wd[d], h, w, dev)
+            if d < D - 1:
+                c.lin[d + 1] = ops.new_act(N, wd[d], h, w, dev)
+                c.rcat[d + 1] = ops.new_act(N, wd[d] + uw[d + 1], h, w, dev)
+            if 0 < d < D - 1:
+                c.st_down[d] = ops.BNState(wd[d], dev)
+            if d >= 1:
+                hh, ww = hs[d - 1]
+                c.t[d] = ops.new_act(N, uw[d], hh, ww, dev)
+                c.st_up[d] = ops.BNState(uw[d], dev)
+        c.out = ops.new_act(N, 3, H, W, dev)
+        # gradient buffers
+        c.g_out = ops.new_act(N, 3, H, W, dev)
+        c.g_rcat = [None] * D
+        c.g_lin = [None] * (D + 1)
+        c.g_t = [None] * D
+        for d in range(D):
+            h, w = hs[d]
+            if d < D - 1:
+                c.g_rcat[d + 1] = ops.new_act(N, wd[d] + uw[d + 1], h, w, dev)
+                c.g_lin[d + 1] = ops.new_act(N, wd[d], h, w, dev)
+            if d >= 1:
+                hh, ww = hs[d - 1]
+                c.g_t[d] = ops.new_act(N, uw[d], hh, ww, dev)
+        c.g_e_last = ops.new_act(N, wd[D - 1], hs[D - 1][0], hs[D - 1][1], dev)
+        c.g_e = [ops.new_act(N, wd[d], hs[d][0], hs[d][1], dev) for d in range(D - 1)]
+        c.train = True
+        c.iter_seed = 0
+        self.ctx[key] = c
+        return c
+
+    def features(self, c):
+        """the four hooked tensors, in the reference's order"""
+        return [c.lin[2], c.lin[4], c.rcat[4], c.rcat[2]]
+
+    # ---------------------------------------------------------------------------------------
+    def forward(self, N, H, W, train=True):
+        """x must already sit in ctx.x_in (use ctx(N,H,W).x_in); returns ctx (ctx.out = tanh image)."""
+        c = self._ctx(N, H, W)
+        D, wd, uw = self.D, self.width, self.uwidth
+        c.train = train
+        self.seed += 1
+        c.iter_seed = self.seed
+        # ---- down path
+        self.down[0].forward(c.x_in, c.e[0])
+        ops.bnact_fwd(c.e[0], c.lin[1], ops.cslice(c.rcat[1], 0, wd[0]), act=ACT_LRELU, act2=ACT_RELU)
+        for d in range(1, D - 1):
+            _, stats = self.down[d].forward(c.lin[d], c.e[d], want_stats=True)
+            n = N * c.hs[d][0] * c.hs[d][1]
+            self.down_bn[d].finalize(stats, n, c.st_down[d], train)
+            ops.bnact_fwd(c.e[d], c.lin[d + 1], ops.cslice(c.rcat[d + 1], 0, wd[d]), scale=c.st_down[d].scale,
+                          shift=c.st_down[d].shift, act=ACT_LRELU, act2=ACT_RELU)
+        self.down[D - 1].forward(c.lin[D - 1], c.e[D - 1], act=ACT_RELU)      # innermost: conv + ReLU fused
+        # ---- up path
+        src = c.e[D - 1]
+        for d in range(D - 1, 0, -1):
+            _, stats = self.up[d].forward(src, c.t[d], want_stats=True)
+            hh, ww = c.hs[d - 1]
+            self.up_bn[d].finalize(stats, N * hh * ww, c.st_up[d], train)
+            drop = 0.5 if (train and d in self.drop_depths) else 0.0
+            ops.bnact_fwd(c.t[d], ops.cslice(c.rcat[d], wd[d - 1], uw[d]), scale=c.st_up[d].scale,
+                          shift=c.st_up[d].shift, act=ACT_RELU, drop_p=drop, seed=c.iter_seed * 64 + d)
+            src = c.rcat[d]
+        self.up[0].forward(c.rcat[1], c.out, act=ACT_TANH)
+        return c
+
+    # ---------------------------------------------------------------------------------------
+    def backward(self, c, g_feat=None, wgrad=True):
+        """c.g_out holds dL/d(out).  g_feat: optional list of 4 gradients w.r.t. features(c).
+        Accumulates parameter gradients (wgrad) ; nothing is returned (the input image needs none)."""
+        D, wd, uw, N = self.D, self.width, self.uwidth, c.N
+        if g_feat is None:
+            g_feat = [None] * 4
+        # outermost: tanh' then the transposed conv
+        ops.bnact_bwd(c.out, None, c.g_out, c.g_out, in_act=ACT_TANH)
+        if wgrad:
+            self.up[0].backward_weight(c.rcat[1], c.g_out)
+        self.up[0].backward_data(c.g_out, c.g_rcat[1])
+        for d in range(1, D):
+            if d == 2 and g_feat[3] is not None:
+                ops.nhwc_add(g_feat[3], 0, c.g_rcat[2], 0, wd[1] + uw[2])
+            if d == 4 and g_feat[2] is not None:
+                ops.nhwc_add(g_feat[2], 0, c.g_rcat[4], 0, wd[3] + uw[4])
+            w = wd[d - 1]
+            bn = self.up_bn[d].bn
+            drop = 0.5 if (c.train and d in self.drop_depths) else 0.0
+            ops.bnact_bwd(c.t[d], ops.cslice(c.rcat[d], w, uw[d]), ops.cslice(c.g_rcat[d], w, uw[d]), c.g_t[d], bn=c.st_up[d],
+                          gamma=bn.weight.data, beta=bn.bias.data, bn_eval=not c.train, act=ACT_RELU, drop_p=drop,
+                          seed=c.iter_seed * 64 + d, dgamma=bn.weight.grad if wgrad else None,
+                          dbeta=bn.bias.grad if wgrad else None)
+            src = c.e[D - 1] if d == D - 1 else c.rcat[d + 1]
+            if wgrad:
+                self.up[d].backward_weight(src, c.g_t[d])
+            self.up[d].backward_data(c.g_t[d], c.g_e_last if d == D - 1 else c.g_rcat[d + 1])
+        # innermost down conv (+ fused ReLU)
+        ops.bnact_bwd(c.e[D - 1], None, c.g_e_last, c.g_e_last, in_act=ACT_RELU)
+        if wgrad:
+            self.down[D - 1].backward_weight(c.lin[D - 1], c.g_e_last)
+        self.down[D - 1].backward_data(c.g_e_last, c.g_lin[D - 1])
+        for d in range(D - 2, -1, -1):
+            # e[d] feeds lin[d+1] (LeakyReLU) and rcat[d+1][:w] (ReLU)
+            if d == 1 and g_feat[0] is not None:
+                ops.nhwc_add(g_feat[0], 0, c.g_lin[2], 0, wd[1])
+            if d == 3 and g_feat[1] is not None:
+                ops.nhwc_add(g_feat[1], 0, c.g_lin[4], 0, wd[3])
+            g2 = ops.cslice(c.g_rcat[d + 1], 0, wd[d])
+            if d > 0:
+                bn = self.down_bn[d].bn
+                ops.bnact_bwd(c.e[d], c.lin[d + 1], c.g_lin[d + 1], c.g_e[d], g2=g2, bn=c.st_down[d], gamma=bn.weight.data,
+                              beta=bn.bias.data, bn_eval=not c.train, act=ACT_LRELU, act2=ACT_RELU,
+                              dgamma=bn.weight.grad if wgrad else None, dbeta=bn.bias.grad if wgrad else None)
+            else:
+                ops.bnact_bwd(c.e[0], c.lin[1], c.g_lin[1], c.g_e[0], g2=g2, act=ACT_LRELU, act2=ACT_RELU)
+            if wgrad:
+                self.down[d].backward_weight(c.lin[d] if d > 0 else c.x_in, c.g_e[d])
+            if d > 0:
+                self.down[d].backward_data(c.g_e[d], c.g_lin[d])
+
+
+# ------------------------------------------------------------------------------------------------
+# PatchGAN discriminators (plain and selective-activation / masked)
+# ------------------------------------------------------------------------------------------------
+class PatchGANEngine:
+    def __init__(self, module, masked, threshold, device, n_layers=3):
+        self.module, self.masked, self.tau, self.device = module, masked, float(threshold), device
+        seq = module.model
+        idx = []
+        if not masked:
+            idx.append((0, None, None))
+            i = 2
+            for _ in range(n_layers):
+                idx.append((i, i + 1, None))
+                i += 3
+            idx.append((i, None, None))
+        else:
+            idx.append((0, None, 2))
+            i = 3
+            for _ in range(n_layers):
+                idx.append((i, i + 1, i + 2))
+                i += 4
+            idx.append((i, None, None))
+        self.idx = idx
+        self.L = len(idx)
+        self.conv, self.bn, self.gate = [], [], []
+        for li, (ci, bi, gi) in enumerate(idx):
+            m = getattr(seq, str(ci))
+            stride = 2 if li < self.L - 2 else 1
+            self.conv.append(ConvOp(m.weight, m.bias, 4, stride, 1, False))
+            self.bn.append(BNOp(getattr(seq, str(bi))) if bi is not None else None)
+            self.gate.append(getattr(seq, str(gi)) if gi is not None else None)
+        self.chan = [c.rows for c in self.conv]
+        self.in_nc = self.conv[0].cols
+        self.mask = [torch.ones(self.chan[i], dtype=torch.float32, device=device) if self.gate[i] is not None else None
+                     for i in range(self.L)]
+        self.hook_layers = (1, 3)      # BN of layer 1 ('model.3'/'model.4') and layer 3 ('model.9'/'model.12')
+        self.ctx = {}
+        self.gbuf = {}
+
+    def convs(self):
+        return self.conv
+
+    def repack(self):
+        for c in self.conv:
+            c.repack()
+
+    def refresh_masks(self):
+        for i in range(self.L):
+            if self.gate[i] is not None:
+                ops.gate_mask(self.gate[i].alpha.data, self.tau, self.mask[i])
+
+    def _sizes(self, H, W):
+        hs = []
+        h, w = H, W
+        for li in range(self.L):
+            s = self.conv[li].stride
+            h, w = (h + 2 - 4) // s + 1, (w + 2 - 4) // s + 1
+            hs.append((h, w))
+        return hs
+
+    def new_ctx(self, N, H, W, tag):
+        key = (N, H, W, tag)
+        if key in self.ctx:
+            return self.ctx[key]
+        dev = self.device
+        c = type('DCtx', (), {})()
+        c.N, c.H, c.W = N, H, W
+        c.hs = self._sizes(H, W)
+        c.x_in = ops.new_act(N, self.in_nc, H, W, dev)
+        c.a0 = ops.new_act(N, self.chan[0], c.hs[0][0], c.hs[0][1], dev)
+        c.g0 = ops.new_act(N, self.chan[0], c.hs[0][0], c.hs[0][1], dev) if self.masked else c.a0
+        c.c = [None] * self.L
+        c.y = [None] * self.L
+        c.st = [None] * self.L
+        for li in range(1, self.L - 1):
+            c.c[li] = ops.new_act(N, self.chan[li], c.hs[li][0], c.hs[li][1], dev)
+            c.y[li] = ops.new_act(N, self.chan[li], c.hs[li][0], c.hs[li][1], dev)
+            c.st[li] = ops.BNState(self.chan[li], dev)
+        c.pred = ops.new_act(N, 1, c.hs[-1][0], c.hs[-1][1], dev)
+        self.ctx[key] = c
+        return c
+
+    def _gbufs(self, N, H, W):
+        key = (N, H, W)
+        if key not in self.gbuf:
+            hs = self._sizes(H, W)
+            dev = self.device
+            g = type('DGrad', (), {})()
+            g.layer = [ops.new_act(N, self.chan[li], hs[li][0], hs[li][1], dev) for li in range(self.L)]
+            g.x_in = ops.new_act(N, self.in_nc, H, W, dev)
+            self.gbuf[key] = g
+        return self.gbuf[key]
+
+    def features(self, c):
+        return [c.y[1], c.y[3]]
+
+    def grad_pred_buffer(self, c):
+        return self._gbufs(c.N, c.H, c.W).layer[-1]
+
+    # ---------------------------------------------------------------------------------------
+    def forward(self, c, train=True):
+        """input already in c.x_in; returns c.pred"""
+        L = self.L
+        if self.masked:
+            self.refresh_masks()
+        self.conv[0].forward(c.x_in, c.a0, act=ACT_LRELU)
+        if self.masked:
+            ops.bnact_fwd(c.a0, c.g0, gate=self.mask[0], gate_after_act=True)
+        src = c.g0
+        for li in range(1, L - 1):
+            _, stats = self.conv[li].forward(src, c.c[li], want_stats=True)
+            n = c.N * c.hs[li][0] * c.hs[li][1]
+            self.bn[li].finalize(stats, n, c.st[li], train)
+            ops.bnact_fwd(c.c[li], c.y[li], scale=c.st[li].scale, shift=c.st[li].shift, gate=self.mask[li], act=ACT_LRELU)
+            src = c.y[li]
+        self.conv[L - 1].forward(src, c.pred)
+        c.train = train
+        return c.pred
+
+    def backward(self, c, has_pred_grad=True, g_feat=None, wgrad=True, agrad=False, need_dx=True):
+        """dL/dpred must be in grad_pred_buffer(c) when has_pred_grad; g_feat = optional [g(y1), g(y3)].
+        wgrad: accumulate conv/BN parameter gradients; agrad: accumulate alpha gradients.
+        Returns dL/d(x_in) (NHWC bf16, same layout as c.x_in) when need_dx."""
+        L = self.L
+        G = self._gbufs(c.N, c.H, c.W)
+        if g_feat is None:
+            g_feat = [None, None]
+        feat_of = {1: g_feat[0], 3: g_feat[1]}
+        if has_pred_grad:
+            if wgrad:
+                self.conv[L - 1].backward_weight(c.y[L - 2], G.layer[L - 1])
+            self.conv[L - 1].backward_data(G.layer[L - 1], G.layer[L - 2])
+        for li in range(L - 2, 0, -1):
+            g1, g2 = G.layer[li], feat_of.get(li)
+            if li == L - 2 and not has_pred_grad:
+                assert g2 is not None, 'nothing to back-propagate'
+                g1, g2 = g2, None
+            bn = self.bn[li].bn
+            gate = self.gate[li]
+            ops.bnact_bwd(c.c[li], c.y[li], g1, G.layer[li], g2=g2, bn=c.st[li], gamma=bn.weight.data, beta=bn.bias.data,
+                          gate=self.mask[li], act=ACT_LRELU, act2=ACT_LRELU, dgamma=bn.weight.grad if wgrad else None,
+                          dbeta=bn.bias.grad if wgrad else None,
+                          dalpha=gate.alpha.grad if (agrad and gate is not None) else None)
+            src = c.g0 if li == 1 else c.y[li - 1]
+            if wgrad:
+                self.conv[li].backward_weight(src, G.layer[li])
+            self.conv[li].backward_data(G.layer[li], G.layer[li - 1])
+        gate = self.gate[0]
+        ops.bnact_bwd(c.a0, None, G.layer[0], G.layer[0], gate=self.mask[0], gate_after_act=True, in_act=ACT_LRELU,
+                      dalpha=gate.alpha.grad if (agrad and gate is not None) else None)
+        if wgrad:
+            self.conv[0].backward_weight(c.x_in, G.layer[0])
+        if need_dx:
+            self.conv[0].backward_data(G.layer[0], G.x_in)
+            return G.x_in
+        return None

@@ -1,0 +1,604 @@
+"""Pix2Pix GCC model on MI355X -- the reference's ``models/Pix2Pix.py`` surface
+(set_input / forward / optimize_parameters / optimizer_netD_arch / ... ) over the HIP engine.
+
+What is kept name-for-name (callers: train.py:84-172, test.py, metric/test_metric.py,
+utils/prune_util.py): class names, constructor signatures, ``netG`` / ``netD`` module trees whose
+``state_dict`` keys equal the reference's (module paths such as ``model.model.1.model.2.weight``),
+``loss_names`` / ``visual_names``, the optimizers list, schedulers, checkpoint dict layout.
+
+What is different: the module trees only own parameters; every tensor operation of the step is a
+hand-written gfx950 kernel scheduled by gcc_amd.engine (no autograd graph).  The step is written
+out explicitly in the order of models/Pix2Pix.py:565-593 and its helpers (:464-552).
+Under data parallelism (torch.distributed initialised by the launcher) gradients are summed over
+ranks on RCCL at the five backward boundaries of the iteration.
+"""
+import copy
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import dist as gdist
+from .. import engine, ops
+from .._lib import GccError
+from ..utils import util
+from .DifferentiableOp import DifferentiableOP
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter-owning module trees (state_dict-compatible with the reference)
+# ------------------------------------------------------------------------------------------------
+def _attach(root, dotted, leaf):
+    parts = dotted.split('.')
+    m = root
+    for p in parts[:-1]:
+        if not hasattr(m, p):
+            m.add_module(p, nn.Module())
+        m = getattr(m, p)
+    m.add_module(parts[-1], leaf)
+
+
+def _bn(c):
+    return nn.BatchNorm2d(c, affine=True, track_running_stats=True)
+
+
+class UnetGenertor(nn.Module):
+    """Parameter tree of the reference's UnetGenertor (models/Pix2Pix.py:79-130; spelling kept).
+    Depth d block prefix: 'model' (d=0) / 'model.model.1' + '.model.3'*(d-1)."""
+
+    def __init__(self, input_nc, output_nc, num_downs, ngf=64, norm_layer=None, use_dropout=False,
+                 filter_cfgs=None, channel_cfgs=None):
+        super().__init__()
+        D = num_downs
+        self.num_downs, self.use_dropout = D, use_dropout
+        if filter_cfgs is None:
+            wd = [min(ngf * 2 ** d, ngf * 8) for d in range(D)]
+            down_in = [input_nc] + wd[:-1]
+            up_in = [2 * wd[d] for d in range(D - 1)] + [wd[D - 1]]
+            up_out = [output_nc] + wd[:-1]
+        else:
+            if D != 8:
+                raise NotImplementedError('filter_cfgs describe the num_downs=8 generator')
+            if any(int(v) == 0 for v in list(filter_cfgs)[:15]) or any(int(v) == 0 for v in list(channel_cfgs)[:15]):
+                raise NotImplementedError('pruned generators with removed blocks (zero widths) are not on the '
+                                          'MI355X path yet')
+            f, c = [int(v) for v in filter_cfgs], [int(v) for v in channel_cfgs]
+            wd = f[:8]
+            down_in = [input_nc] + c[:7]
+            up_in = [c[14 - d] for d in range(8)]
+            up_out = [output_nc] + [f[15 - d] for d in range(1, 8)]
+
+        def prefix(d):
+            return 'model' if d == 0 else 'model.model.1' + '.model.3' * (d - 1)
+        _attach(self, 'model.model.0', nn.Conv2d(down_in[0], wd[0], 4, 2, 1, bias=False))
+        for d in range(1, D):
+            p = prefix(d)
+            _attach(self, p + '.model.1', nn.Conv2d(down_in[d], wd[d], 4, 2, 1, bias=False))
+            if d < D - 1:
+                _attach(self, p + '.model.2', _bn(wd[d]))
+        p = prefix(D - 1)
+        _attach(self, p + '.model.3', nn.ConvTranspose2d(up_in[D - 1], up_out[D - 1], 4, 2, 1, bias=False))
+        _attach(self, p + '.model.4', _bn(up_out[D - 1]))
+        for d in range(D - 2, 0, -1):
+            p = prefix(d)
+            _attach(self, p + '.model.5', nn.ConvTranspose2d(up_in[d], up_out[d], 4, 2, 1, bias=False))
+            _attach(self, p + '.model.6', _bn(up_out[d]))
+        _attach(self, 'model.model.3', nn.ConvTranspose2d(up_in[0], up_out[0], 4, 2, 1, bias=True))
+
+    def forward(self, x):
+        raise GccError('UnetGenertor owns parameters only; run it through Pix2PixModel (gcc_amd.engine.UnetEngine)')
+
+
+def _patchgan_tree(self, input_nc, ndf, n_layers, masked, threshold):
+    ch = [ndf * min(2 ** i, 8) for i in range(n_layers + 1)]
+    seq = nn.Module()
+    self.add_module('model', seq)
+    i = 0
+    seq.add_module(str(i), nn.Conv2d(input_nc, ch[0], 4, 2, 1))
+    i += 2
+    if masked:
+        seq.add_module(str(i), DifferentiableOP(ch[0], threshold))
+        i += 1
+    for n in range(1, n_layers + 1):
+        stride = 2 if n < n_layers else 1
+        seq.add_module(str(i), nn.Conv2d(ch[n - 1], ch[n], 4, stride, 1, bias=False))
+        seq.add_module(str(i + 1), _bn(ch[n]))
+        i += 2
+        if masked:
+            seq.add_module(str(i), DifferentiableOP(ch[n], threshold))
+            i += 1
+        i += 1        # LeakyReLU slot
+    seq.add_module(str(i), nn.Conv2d(ch[n_layers], 1, 4, 1, 1))
+
+
+class NLayerDiscriminator(nn.Module):
+    """PatchGAN parameter tree (models/Pix2Pix.py:267-305): convs at model.0/2/5/8/11, BN at 3/6/9."""
+
+    def __init__(self, input_nc=3, ndf=64, n_layers=3):
+        super().__init__()
+        _patchgan_tree(self, input_nc, ndf, n_layers, False, 0.5)
+
+
+class MaskNLayerDiscriminator(nn.Module):
+    """Selective-activation PatchGAN (models/Pix2Pix.py:307-348): convs at model.0/3/7/11/15,
+    BN at 4/8/12, gates (alpha) at 2/5/9/13."""
+
+    def __init__(self, input_nc=3, ndf=64, n_layers=3, threshold=0.5):
+        super().__init__()
+        _patchgan_tree(self, input_nc, ndf, n_layers, True, threshold)
+
+
+# ------------------------------------------------------------------------------------------------
+class HipAdam(torch.optim.Optimizer):
+    """torch.optim.Optimizer facade (so LambdaLR/StepLR schedulers work unchanged) whose step() is
+    one multi-tensor gcc_adam_step launch over a FlatParams group."""
+
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, l1=None):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        dev = params[0].device
+        self.flat = engine.FlatParams(params, dev)
+        self.plan = ops.AdamPlan(params, self.flat.grad_views, dev, l1=l1)
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        self.plan.step(g['lr'], g['betas'], g['eps'])
+
+
+# ------------------------------------------------------------------------------------------------
+class Pix2PixModel(nn.Module):
+
+    def __init__(self, opt, filter_cfgs=None, channel_cfgs=None):
+        super().__init__()
+        self.opt = opt
+        if len(opt.gpu_ids) == 0 or not torch.cuda.is_available():
+            raise GccError('gcc_amd runs on MI355X only (no CPU path): need a visible GPU and gpu_ids >= 0')
+        self.device = gdist.local_device(opt)
+        ops.lib()                      # fail loudly here if libgcc_hip.so is not built
+        self.filter_cfgs, self.channel_cfgs = filter_cfgs, channel_cfgs
+        self.loss_names = ['G_GAN', 'G_L1', 'D_real', 'D_fake']
+        self.visual_names = ['real_A', 'fake_B', 'real_B']
+        self.current_D_arch_diff_loss = 0.0
+        self.teacher_model = None
+
+        if opt.backbone == 'resnet':
+            raise NotImplementedError('backbone resnet (MobileResnetGenerator) is not on the MI355X path yet')
+        self.generator_extract_layers = ['model.model.1.model.2', 'model.model.1.model.3.model.3.model.2',
+                                         'model.model.1.model.3.model.3.model.4', 'model.model.1.model.4']
+        self.discriminator_extract_layers = ['model.4', 'model.12'] if opt.darts_discriminator else ['model.3', 'model.9']
+
+        self.optimizers = []
+        self.netG = UnetGenertor(3, 3, opt.num_downs, ngf=opt.ngf, use_dropout=not opt.no_dropout,
+                                 filter_cfgs=filter_cfgs, channel_cfgs=channel_cfgs)
+        self.distill = bool(opt.online_distillation or opt.normal_distillation)
+        self.transform_convs = []
+        if self.distill:
+            t_w = [opt.teacher_ngf * 2, opt.teacher_ngf * 8, opt.teacher_ngf * 16, opt.teacher_ngf * 4]
+            if channel_cfgs is None:
+                s_w = [opt.ngf * 2, opt.ngf * 8, opt.ngf * 16, opt.ngf * 4]
+            else:
+                s_w = [channel_cfgs[1], channel_cfgs[3], channel_cfgs[-4], channel_cfgs[-2]]
+            self.transform_convs = [nn.Conv2d(s, t, 1, 1, 0, bias=False) for s, t in zip(s_w, t_w)]
+        if opt.darts_discriminator:
+            self.loss_names += ['D_arch_diff', 'D_arch', 'teacher_D_arch_diff']
+            self.netD = MaskNLayerDiscriminator(input_nc=6, ndf=opt.ndf, threshold=opt.threshold)
+        else:
+            self.netD = NLayerDiscriminator(input_nc=6, ndf=opt.ndf)
+        self.init_net()
+
+        # ---- optimizers over flat parameter groups (models/Pix2Pix.py:382,415,430-440)
+        dev = self.device
+        g_params, g_l1 = [], []
+        for m in self.netG.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                for p in m.parameters():
+                    g_params.append(p)
+                    g_l1.append(opt.lambda_weight if (p.dim() == 4 and opt.lambda_weight > 0.0) else 0.0)
+            elif isinstance(m, nn.BatchNorm2d):
+                g_params += [m.weight, m.bias]
+                g_l1 += [opt.lambda_scale if (opt.lambda_scale > 0.0 and not opt.lambda_weight > 0.0) else 0.0, 0.0]
+        for t in self.transform_convs:
+            t.to(dev)
+            g_params.append(t.weight)
+            g_l1.append(0.0)
+        self.optimizer_G = HipAdam(g_params, lr=opt.lr, betas=(0.5, 0.999), l1=g_l1)
+        w_params, a_params = [], []
+        for m in self.netD.modules():
+            if isinstance(m, (nn.Conv2d, nn.BatchNorm2d)):
+                w_params += list(m.parameters())
+            elif isinstance(m, DifferentiableOP):
+                a_params += list(m.parameters())
+        self.optimizer_D = HipAdam(w_params, lr=opt.lr, betas=(0.5, 0.999))
+        if opt.darts_discriminator:
+            self.optimizer_arch = HipAdam(a_params, lr=opt.arch_lr)
+            if opt.arch_lr_step:
+                arch_opt = copy.deepcopy(opt)
+                arch_opt.lr_policy = 'step'
+                arch_opt.lr_decay_iters = opt.n_epochs - 1
+                self.arch_scheduler = util.get_scheduler(self.optimizer_arch, arch_opt)
+
+        # ---- engines
+        self.G = engine.UnetEngine(self.netG, opt.num_downs, dev, use_dropout=not opt.no_dropout)
+        self.D = engine.PatchGANEngine(self.netD, bool(opt.darts_discriminator), opt.threshold, dev)
+        self.T = [engine.ConvOp(t.weight, None, 1, 1, 0, False) for t in self.transform_convs]
+        self.refresh_weights()
+
+        self.optimizers += [self.optimizer_G, self.optimizer_D]
+        self.schedulers = [util.get_scheduler(o, opt) for o in self.optimizers]
+        if opt.darts_discriminator and opt.arch_lr_step:
+            self.schedulers.append(self.arch_scheduler)
+        # device scalars: every loss of the iteration lives in one fp32 vector (read on demand)
+        self._lossvec = torch.zeros(32, dtype=torch.float32, device=dev)
+        self._slot = {n: i for i, n in enumerate(
+            ['G_GAN', 'G_L1', 'D_real', 'D_fake', 'D_arch_fake', 'D_arch_fake_real', 'D_arch_real', 'D_arch_diff',
+             'D_arch', 'teacher_D_arch_diff', 'arch_c_fr', 'arch_c_f', 'scratch0', 'scratch1', 'scratch2', 'ema_prev'])}
+        self._dist_out = torch.zeros((6, 2), dtype=torch.float32, device=dev)
+        self._dist_ws = {}
+        self._fake_nchw = None
+        self._ema_started = False
+        self._world = gdist.world_size()
+
+    # ---------------------------------------------------------------------------------------
+    def _l(self, name):
+        i = self._slot[name]
+        return self._lossvec[i:i + 1]
+
+    def refresh_weights(self):
+        """re-derive the bf16 weight packings from the fp32 masters (after init / load / Adam)"""
+        self.G.repack()
+        self.D.repack()
+        for t in self.T:
+            t.repack()
+
+    def init_net(self):
+        self.netG.to(self.device)
+        self.netD.to(self.device)
+        for m in self.netD.modules():
+            if isinstance(m, DifferentiableOP):
+                m.threshold = m.threshold.to(self.device)
+        util.init_weights(self.netG, init_type='normal', init_gain=0.02)
+        util.init_weights(self.netD, init_type='normal', init_gain=0.02)
+        gdist.broadcast_module(self.netG)
+        gdist.broadcast_module(self.netD)
+
+    # ---------------------------------------------------------------------------------------
+    def set_input(self, input):
+        self.input = input
+        AtoB = self.opt.direction == 'AtoB'
+        self.real_A = input['A' if AtoB else 'B'].to(self.device, torch.float32).contiguous()
+        self.real_B = input['B' if AtoB else 'A'].to(self.device, torch.float32).contiguous()
+        self.image_paths = [input.get('A_paths' if AtoB else 'B_paths'), input.get('B_paths' if AtoB else 'A_paths')]
+        N, _, H, W = self.real_A.shape
+        if getattr(self, '_A', None) is None or tuple(self._A.shape) != (N, 3, H, W):
+            self._A = ops.new_act(N, 3, H, W, self.device)
+            self._B = ops.new_act(N, 3, H, W, self.device)
+        ops.nchw_to_nhwc(self.real_A, self._A)
+        ops.nchw_to_nhwc(self.real_B, self._B)
+
+    def forward(self):
+        """fake_B = G(real_A)  (models/Pix2Pix.py:460-462)"""
+        N, _, H, W = self._A.shape
+        c = self.G._ctx(N, H, W)
+        ops.nhwc_copy(self._A, 0, c.x_in, 0, 3)
+        self._gctx = self.G.forward(N, H, W, train=self.netG.training)
+        self._fake = self._gctx.out
+        self._fake_nchw = None
+
+    @property
+    def fake_B(self):
+        if self._fake_nchw is None:
+            self._fake_nchw = ops.nhwc_to_nchw(self._fake, 3)
+        return self._fake_nchw
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _pack_pair(self, ctx, second):
+        """ctx.x_in = cat(real_A, second) along channels (3 + 3, zero-filled to 8)"""
+        ops.nhwc_copy(self._A, 0, ctx.x_in, 0, 3)
+        ops.nhwc_copy(second, 0, ctx.x_in, 3, 3, cfill=5)
+
+    def _d_forward(self, tag, second):
+        N, _, H, W = self._A.shape
+        ctx = self.D.new_ctx(N, H, W, tag)
+        self._pack_pair(ctx, second)
+        self.D.forward(ctx, train=True)
+        return ctx
+
+    def _allreduce(self, optimizer):
+        gdist.all_reduce_grads(optimizer)
+
+    # -- D step (models/Pix2Pix.py:464-477) --------------------------------------------------------
+    def backward_D(self):
+        mode = self.opt.gan_mode
+        cf = self._d_forward('d_fake', self._fake)
+        cr = self._d_forward('d_real', self._B)
+        gp = self.D.grad_pred_buffer(cf)
+        ops.gan_loss(mode, cf.pred, False, True, self._l('D_fake'), dpred=gp, grad_weight=0.5)
+        self.D.backward(cf, wgrad=True, need_dx=False)
+        ops.gan_loss(mode, cr.pred, True, True, self._l('D_real'), dpred=gp, grad_weight=0.5)
+        self.D.backward(cr, wgrad=True, need_dx=False)
+
+    # -- G step (models/Pix2Pix.py:513-552) --------------------------------------------------------
+    def backward_G(self):
+        opt, mode = self.opt, self.opt.gan_mode
+        gc = self._gctx
+        cg = self._d_forward('g_fake', self._fake)
+        self._dctx_g = cg
+        ops.gan_loss(mode, cg.pred, True, False, self._l('G_GAN'), dpred=self.D.grad_pred_buffer(cg))
+        dx = self.D.backward(cg, wgrad=False, need_dx=True)
+        ops.l1_loss(self._fake, self._B, self._l('G_L1'), weight=opt.lambda_L1, da=gc.g_out)
+        ops.nhwc_add(dx, 3, gc.g_out, 0, 3)
+        g_feat = None
+        if self.distill:
+            T = self.teacher_model
+            self.Tfake_B = T.fake_B
+            # teacher D (train mode, frozen) on the student's fake: features for the last two terms (:531-533)
+            ct = T._d_forward('on_student', self._fake)
+            feats = self.G.features(gc) + T.D.features(ct)
+            N = feats[0].shape[0]
+            tf, dtf = [], []
+            for i in range(4):
+                f = feats[i]
+                buf = self._tbuf(i, N, self.T[i].rows, f.shape[2], f.shape[3])
+                self.T[i].forward(f, buf[0])
+                tf.append(buf[0])
+                dtf.append(buf[1])
+            tf += feats[4:]
+            dtf += [self._tbuf(4 + j, N, feats[4 + j].shape[1], feats[4 + j].shape[2], feats[4 + j].shape[3])[1]
+                    for j in range(2)]
+            for i in range(6):
+                f, t = tf[i], self.target_distillation_features[i]
+                ws = self._dws(i, N, f.shape[1], f.shape[2] * f.shape[3])
+                ops.distill_fwd(f, t, self._dist_out[i], ws)
+                ops.distill_bwd(f, t, opt.lambda_gram, opt.lambda_content, dtf[i], ws)
+            g_feat = []
+            for i in range(4):
+                self.T[i].backward_weight(feats[i], dtf[i])
+                gbuf = self._tbuf(10 + i, N, feats[i].shape[1], feats[i].shape[2], feats[i].shape[3])[0]
+                self.T[i].backward_data(dtf[i], gbuf)
+                g_feat.append(gbuf)
+            dx2 = T.D.backward(ct, has_pred_grad=False, g_feat=[dtf[4], dtf[5]], wgrad=False, need_dx=True)
+            ops.nhwc_add(dx2, 3, gc.g_out, 0, 3)
+        self.G.backward(gc, g_feat=g_feat, wgrad=True)
+
+    def _tbuf(self, i, N, C, H, W):
+        key = ('t', i, N, C, H, W)
+        if key not in self._dist_ws:
+            self._dist_ws[key] = (ops.new_act(N, C, H, W, self.device), ops.new_act(N, C, H, W, self.device))
+        return self._dist_ws[key]
+
+    def _dws(self, i, N, C, HW):
+        key = ('w', i, N, C, HW)
+        if key not in self._dist_ws:
+            self._dist_ws[key] = torch.empty(ops.distill_workspace_bytes(N, C, HW), dtype=torch.uint8, device=self.device)
+        return self._dist_ws[key]
+
+    # -- one iteration (models/Pix2Pix.py:565-583) ----------------------------------------------------
+    def optimize_parameters(self):
+        if self.opt.online_distillation:
+            T = self.teacher_model
+            T.set_input(self.input)
+            T.optimize_parameters()
+            # the reference clones; here the teacher's activation buffers of this iteration are
+            # simply not overwritten before the student consumes them (separate contexts)
+            self.target_distillation_features = T.get_distillation_features()
+        self.forward()
+        self.optimizer_D.zero_grad()
+        self.backward_D()
+        self._allreduce(self.optimizer_D)
+        self.optimizer_D.step()
+        self.D.repack()
+        self.optimizer_G.zero_grad()
+        self.backward_G()
+        self._allreduce(self.optimizer_G)
+        self.optimizer_G.step()          # L1_sparsity() (:554-563) is fused into the Adam kernel
+        self.G.repack()
+        for t in self.T:
+            t.repack()
+
+    # -- architecture step (models/Pix2Pix.py:479-511, 585-593) -----------------------------------------
+    def get_D_arch_diff(self, isTeacher=False):
+        """three hinge terms on one fake / real pair; the |.| difference (EMA'd for the teacher)"""
+        mode = self.opt.gan_mode
+        cf = self._d_forward('a_fake', self._fake)
+        cr = self._d_forward('a_real', self._B)
+        ops.gan_loss(mode, cf.pred, False, True, self._l('D_arch_fake'))
+        ops.gan_loss(mode, cf.pred, True, False, self._l('D_arch_fake_real'))
+        ops.gan_loss(mode, cr.pred, True, True, self._l('D_arch_real'))
+        out = self._l('teacher_D_arch_diff' if isTeacher else 'D_arch_diff')
+        if isTeacher and self._ema_started:
+            b = float(self.opt.ema_beta)
+            ops.scalar_op(1, self._l('D_arch_fake_real'), self._l('D_arch_fake'), out, c=out, k0=b, k1=1.0 - b)
+        else:
+            ops.scalar_op(0, self._l('D_arch_fake_real'), self._l('D_arch_fake'), out)
+        self._ema_started = True
+        self.current_D_arch_diff_loss = out
+        return cf, cr
+
+    def backward_D_arch(self):
+        T = self.teacher_model
+        T.get_D_arch_diff(isTeacher=True)
+        ops.scalar_op(2, T._l('teacher_D_arch_diff'), T._l('teacher_D_arch_diff'), self._l('teacher_D_arch_diff'), k0=0.0)
+        cf, cr = self.get_D_arch_diff(isTeacher=False)
+        # loss_D_arch = |d_S - d_T| + (L_real + L_fake)/2 ; coefficients of the three hinge gradients
+        ops.arch_coeffs(self._l('D_arch_fake_real'), self._l('D_arch_fake'), self._l('D_arch_real'),
+                        self._l('teacher_D_arch_diff'), self._l('D_arch'), self._l('arch_c_fr'), self._l('arch_c_f'))
+        mode = self.opt.gan_mode
+        gp = self.D.grad_pred_buffer(cf)
+        ops.gan_loss(mode, cf.pred, True, False, self._l('scratch0'), dpred=gp, weight_dev=self._l('arch_c_fr'))
+        ops.gan_loss(mode, cf.pred, False, True, self._l('scratch1'), dpred=gp, weight_dev=self._l('arch_c_f'),
+                     dpred_accumulate=True)
+        self.D.backward(cf, wgrad=False, agrad=True, need_dx=False)
+        ops.gan_loss(mode, cr.pred, True, True, self._l('scratch2'), dpred=gp, grad_weight=0.5)
+        self.D.backward(cr, wgrad=False, agrad=True, need_dx=False)
+
+    def optimizer_netD_arch(self):
+        self.forward()
+        T = self.teacher_model
+        T.set_input(self.input)
+        T.forward()
+        self.optimizer_arch.zero_grad()
+        self.backward_D_arch()
+        self._allreduce(self.optimizer_arch)
+        self.optimizer_arch.step()
+
+    def clipping_mask_alpha(self):
+        for m in self.netD.modules():
+            if isinstance(m, DifferentiableOP):
+                m.clip_alpha()
+
+    # -- bookkeeping surface ----------------------------------------------------------------------
+    def print_sparse_info(self, logger):
+        for name, m in self.named_modules():
+            if isinstance(m, DifferentiableOP):
+                mask = m.get_current_mask()
+                logger.info('%s sparsity ratio: %.2f' % (name, float((mask == 0.0).sum()) / mask.numel()))
+
+    def adaptive_ema_beta(self, epoch):
+        self.opt.ema_beta = 1.0 - epoch / (self.opt.n_epochs + self.opt.n_epochs_decay)
+
+    def update_learning_rate(self, epoch):
+        for s in self.schedulers:
+            s.step()
+        self.adaptive_ema_beta(epoch)
+        lr = self.optimizers[0].param_groups[0]['lr']
+        print('learning rate = %.7f\tema beta = %.7f' % (lr, self.opt.ema_beta))
+
+    def set_requires_grad(self, nets, requires_grad=False):
+        for net in (nets if isinstance(nets, list) else [nets]):
+            if net is not None:
+                for p in net.parameters():
+                    p.requires_grad = requires_grad
+
+    def save_models(self, epoch, save_dir, fid=None, isbest=False, direction='AtoB'):
+        if gdist.rank() != 0:
+            return
+        util.mkdirs(save_dir)
+        ckpt = {'G': _portable(self.netG.state_dict()), 'D': _portable(self.netD.state_dict()), 'epoch': epoch,
+                'cfg': (self.filter_cfgs, self.channel_cfgs), 'fid': fid}
+        name = 'model_best_%s.pth' % direction if isbest else 'model_%d.pth' % epoch
+        torch.save(ckpt, os.path.join(save_dir, name))
+
+    def load_models(self, load_path, load_discriminator=True):
+        ckpt = torch.load(load_path, map_location='cpu')
+        self.netG.load_state_dict(ckpt['G'])
+        if load_discriminator:
+            self.netD.load_state_dict(ckpt['D'])
+        self.refresh_weights()
+        print('loading the model from %s' % load_path)
+        return ckpt['fid'], float('inf')
+
+    def model_train(self):
+        self.netG.train()
+        self.netD.train()
+
+    def model_eval(self):
+        self.netG.eval()
+        self.netD.eval()
+
+    def get_current_visuals(self):
+        ret = OrderedDict()
+        for name in self.visual_names:
+            ret[name] = getattr(self, name)
+        return ret
+
+    def get_current_losses(self):
+        """host read of the device loss scalars (the only sync of the iteration; print_freq cadence)"""
+        v = self._lossvec.cpu()
+        d = self._dist_out.cpu()
+        ret = OrderedDict()
+        for name in self.loss_names:
+            if name == 'content':
+                val = self.opt.lambda_content * float(d[:, 1].sum())
+            elif name == 'gram':
+                val = self.opt.lambda_gram * float(d[:, 0].sum())
+            else:
+                val = float(v[self._slot[name]])
+            ret[name] = val
+        if self._world > 1:
+            ret = gdist.mean_dict(ret, self.device)
+        return ret
+
+    def init_distillation(self):
+        if self.distill:
+            if self.opt.lambda_content > 0.0:
+                self.loss_names.append('content')
+            if self.opt.lambda_gram > 0.0:
+                self.loss_names.append('gram')
+            self.visual_names.append('Tfake_B')
+
+    def get_distillation_features(self):
+        """4 generator features (hooked modules of :366-369) + 2 discriminator features, as the
+        tensors the reference's hooks end up holding (post in-place activation, hazard H1)"""
+        return self.G.features(self._gctx) + self.D.features(self._dctx_g)
+
+    def get_cfg(self):
+        return self.filter_cfgs, self.channel_cfgs
+
+    # -- pruning cfgs (integer logic on host copies of the small per-channel vectors) ---------------
+    def _bn_names(self):
+        D = self.opt.num_downs
+        pre = self.G.prefix
+        return [pre(d) + '.model.2' for d in range(1, D - 1)] + [pre(D - 1) + '.model.4'] + \
+               [pre(d) + '.model.6' for d in range(D - 2, 0, -1)]
+
+    def scale_prune_cfg(self, threshold):
+        """filter_cfgs / channel_cfgs of models/Pix2Pix.py:823-860 (count of gamma > tau per BatchNorm)"""
+        sd = {k: v.detach().cpu() for k, v in self.netG.state_dict().items() if k.endswith('.weight') and v.dim() == 1}
+        ngf, D = self.opt.ngf, self.opt.num_downs
+        f, c = [ngf], [ngf]
+        inner_up = self.G.prefix(D - 1) + '.model.4'
+        last_down = self.G.prefix(D - 2) + '.model.2'
+        up_flag, up_num = False, 0
+        for name in self._bn_names():
+            cnt = int((sd[name + '.weight'] > threshold).sum())
+            f.append(cnt)
+            if name == inner_up:
+                up_flag = True
+                if cnt == 0:
+                    f[-2] = 0
+            if up_flag:
+                up_num += 1
+                if f[-2 * up_num] == 0:
+                    f[-1] = 0
+                    cnt = 0
+                c.append(cnt + f[-1 - 2 * up_num])
+            else:
+                c.append(cnt)
+            if name == last_down:
+                f.append(0 if f[-1] == 0 else ngf * 8)
+                c.append(0 if f[-2] == 0 else ngf * 8)
+        return f, c
+
+    def scale_prune(self, threshold):
+        f, c = self.scale_prune_cfg(float(threshold))
+        return Pix2PixModel(self.opt, filter_cfgs=f, channel_cfgs=c)
+
+    def prune(self, threshold, lottery_path=None):
+        if self.opt.scale_prune:
+            return self.scale_prune(threshold)
+        raise NotImplementedError('only scale pruning is on the MI355X path yet (norm / resnet pruning: next)')
+
+    def max_min_bn_scale(self):
+        p3 = self.G.prefix(5)
+        prunable = [p3 + '.model.2', p3 + '.model.3.model.2', p3 + '.model.3.model.3.model.4',
+                    p3 + '.model.3.model.6', p3 + '.model.6']
+        sd = self.netG.state_dict()
+        un_max, pr_max, mn = float('inf'), -float('inf'), float('inf')
+        for name in self._bn_names():
+            w = sd[name + '.weight'].detach().cpu()
+            if name in prunable:
+                pr_max = max(float(w.max()), pr_max)
+            else:
+                un_max = min(float(w.max()), un_max)
+            mn = min(float(w.min()), mn)
+        return min(pr_max, un_max), mn
+
+
+def _portable(sd):
+    """NCHW-contiguous fp32 CPU copies, as a reference checkpoint stores them"""
+    return OrderedDict((k, v.detach().to('cpu').contiguous()) for k, v in sd.items())

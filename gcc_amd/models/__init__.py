@@ -1,0 +1,11 @@
+"""Host-side mirror of the reference's ``models`` package (models/__init__.py:3-15)."""
+
+
+def get_model_class(opt):
+    if opt.model == 'pix2pix':
+        from .Pix2Pix import Pix2PixModel
+        return Pix2PixModel
+    if opt.model in ('srgan', 'sagan', 'cyclegan'):
+        raise NotImplementedError('%s: not yet on the MI355X path (SURVEY.md section 8 rows a17-a19 are '
+                                  'scheduled after the Pix2Pix row is at parity)' % opt.model)
+    raise NotImplementedError('%s not implemented' % opt.model)

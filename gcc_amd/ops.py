@@ -247,15 +247,23 @@ def gate_mask(alpha, tau, mask):
 GAN_MODES = {'hinge': 0, 'lsgan': 1, 'vanilla': 2, 'wgangp': 3}
 
 
-def gan_loss(mode, pred, target_is_real, for_discriminator, loss, weight=1.0, accumulate=False, dpred=None):
+def gan_loss(mode, pred, target_is_real, for_discriminator, loss, dpred=None, grad_weight=1.0, weight_dev=None,
+             dpred_accumulate=False):
+    """loss[0] = GANLoss value ; dpred (+)= grad_weight * (*weight_dev) * dL/dpred"""
     pp, N, Cc, H, W, ld = geom(pred)
     assert Cc == 1
     dp = None
     if dpred is not None:
         dp, _, _, _, _, ldd = geom(dpred)
         assert ldd == ld
-    check(lib().gcc_gan_loss(GAN_MODES[mode], int(target_is_real), int(for_discriminator), pp, ld, 0, N * H * W,
-                             float(weight), loss.data_ptr(), int(accumulate), dp, None, 0, stream()), 'gcc_gan_loss')
+    check(lib().gcc_gan_loss_ex(GAN_MODES[mode], int(target_is_real), int(for_discriminator), pp, ld, 0, N * H * W,
+                                loss.data_ptr(), dp, float(grad_weight), _p(weight_dev), int(dpred_accumulate), stream()),
+          'gcc_gan_loss')
+
+
+def arch_coeffs(Lfr, Lf, Lr, dT, loss, c_fr, c_f):
+    check(lib().gcc_arch_coeffs(Lfr.data_ptr(), Lf.data_ptr(), Lr.data_ptr(), dT.data_ptr(), loss.data_ptr(),
+                                c_fr.data_ptr(), c_f.data_ptr(), stream()), 'gcc_arch_coeffs')
 
 
 def l1_loss(a, b, loss, weight=1.0, accumulate=False, da=None):

@@ -196,6 +196,15 @@ int gcc_gate_mask(const float* alpha, float tau, float* mask, int C, gcc_stream_
 int gcc_gan_loss(int mode, int target_is_real, int for_discriminator, const void* pred, int ld, int off,
                  size_t pixels, float weight, float* loss, int accumulate, void* dpred,
                  void* ws, size_t ws_bytes, gcc_stream_t stream);
+/* same loss; `loss` receives the unweighted value, dpred (+)= grad_weight * (*grad_weight_dev) * dL/dpred.
+ * grad_weight_dev (device scalar, may be NULL) carries data-dependent signs of the arch loss without
+ * a host round trip (models/Pix2Pix.py:479-487). */
+int gcc_gan_loss_ex(int mode, int target_is_real, int for_discriminator, const void* pred, int ld, int off,
+                    size_t pixels, float* loss, void* dpred, float grad_weight, const float* grad_weight_dev,
+                    int dpred_accumulate, gcc_stream_t stream);
+/* arch-step scalars: loss = | |Lfr-Lf| - dT | + (Lr+Lf)/2 and its partial derivatives c_fr, c_f */
+int gcc_arch_coeffs(const float* Lfr, const float* Lf, const float* Lr, const float* dT, float* loss, float* c_fr,
+                    float* c_f, gcc_stream_t stream);
 /* mean |a-b| * weight (nn.L1Loss, models/Pix2Pix.py:520) over C channels; da = weight*sign(a-b)/count */
 int gcc_l1_loss(const void* a, int lda, int aoff, const void* b, int ldb, int boff, int C, size_t pixels,
                 float weight, float* loss, int accumulate, void* da, int ldda, int daoff,

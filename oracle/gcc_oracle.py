@@ -44,6 +44,43 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 LRELU = 0.2
 
+# ----------------------------------------------------------------------------------------------
+# optional storage-precision emulation: when EMULATE_BF16 is True every tensor the MI355X path keeps
+# in bf16 (conv weights as the MFMA sees them, conv outputs, activated tensors, and their gradients
+# on the way back) is rounded to bf16 here too.  Tests use it to MEASURE the deviation bf16 storage
+# alone induces, so that tolerances are derived rather than guessed.  Off by default: the oracle
+# proper is fp32 like the reference.
+# ----------------------------------------------------------------------------------------------
+EMULATE_BF16 = False
+
+
+class _RoundBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def _q(x):
+    return _RoundBF16.apply(x) if EMULATE_BF16 else x
+
+
+class _RoundFwdOnly(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _qw(w):
+    return _RoundFwdOnly.apply(w) if (EMULATE_BF16 and w is not None and w.dim() == 4) else w
+
 
 # ----------------------------------------------------------------------------------------------
 # names
@@ -166,38 +203,38 @@ def unet_forward(sd: SD, x: Tensor, num_downs: int = 8, train: bool = True,
     drop_depths = unet_dropout_depths(D) if dropout else []
 
     def conv(t, key):
-        return F.conv2d(t, sd[key + '.weight'], sd.get(key + '.bias'), stride=2, padding=1)
+        return F.conv2d(t, _qw(sd[key + '.weight']), sd.get(key + '.bias'), stride=2, padding=1)
 
     def convT(t, key):
-        return F.conv_transpose2d(t, sd[key + '.weight'], sd.get(key + '.bias'), stride=2, padding=1)
+        return F.conv_transpose2d(t, _qw(sd[key + '.weight']), sd.get(key + '.bias'), stride=2, padding=1)
 
     e: List[Tensor] = [None] * D
-    e[0] = conv(x, 'model.model.0')
+    e[0] = _q(conv(_q(x), 'model.model.0'))
     for d in range(1, D):
         p = unet_block_prefix(d)
-        z = conv(F.leaky_relu(e[d - 1], LRELU), p + '.model.1')
+        z = _q(conv(_q(F.leaky_relu(e[d - 1], LRELU)), p + '.model.1'))
         if d < D - 1:
             z = batch_norm(sd, p + '.model.2', z, train)
             if features is not None and (p + '.model.2') in hook:
-                features[p + '.model.2'] = F.leaky_relu(z, LRELU)       # hazard H1
+                features[p + '.model.2'] = _q(F.leaky_relu(z, LRELU))       # hazard H1
         e[d] = z
 
     p = unet_block_prefix(D - 1)
-    u = batch_norm(sd, p + '.model.4', convT(F.relu(e[D - 1]), p + '.model.3'), train)
+    u = batch_norm(sd, p + '.model.4', _q(convT(_q(F.relu(e[D - 1])), p + '.model.3')), train)
     cat = torch.cat([F.leaky_relu(e[D - 2], LRELU), u], 1)
     for d in range(D - 2, 0, -1):
         p = unet_block_prefix(d)
-        r = F.relu(cat)
+        r = _q(F.relu(cat))
         if features is not None and (p + '.model.4') in hook:
             features[p + '.model.4'] = r
-        u = batch_norm(sd, p + '.model.6', convT(r, p + '.model.5'), train)
+        u = batch_norm(sd, p + '.model.6', _q(convT(r, p + '.model.5')), train)
         if d in drop_depths and train:
             if dropout_masks is not None and d in dropout_masks:
                 u = u * dropout_masks[d]
             else:
                 u = F.dropout(u, 0.5, True)
         cat = torch.cat([F.leaky_relu(e[d - 1], LRELU), u], 1)
-    out = torch.tanh(convT(F.relu(cat), 'model.model.3'))
+    out = _q(torch.tanh(convT(_q(F.relu(cat)), 'model.model.3')))
     if features is not None:       # keep the reference's hook-firing order
         for k in hook:
             if k in features:
@@ -239,7 +276,7 @@ def patchgan_forward(sd: SD, x: Tensor, masked: bool = False, threshold: float =
     n = len(lay)
     for li, (ci, bi, gi) in enumerate(lay):
         stride = 2 if li < n - 2 else 1
-        h = F.conv2d(h, sd['model.%d.weight' % ci], sd.get('model.%d.bias' % ci), stride=stride, padding=1)
+        h = _q(F.conv2d(_q(h), _qw(sd['model.%d.weight' % ci]), sd.get('model.%d.bias' % ci), stride=stride, padding=1))
         if li == n - 1:
             break
         if bi is not None:

@@ -288,13 +288,16 @@ def test_gan_loss(mode):
             if mode == 'hinge' and not ford and not real:
                 continue
             pr = pred.clone().requires_grad_(True)
-            l = O.gan_loss(mode, pr, real, ford) * 0.5
-            l.backward()
+            l = O.gan_loss(mode, pr, real, ford)
+            (l * 0.5).backward()
             loss = torch.zeros(1, device=DEV)
             dp = ops.new_act(2, 1, 30, 30, DEV)
-            ops.gan_loss(mode, pd, real, ford, loss, weight=0.5, dpred=dp)
+            ops.gan_loss(mode, pd, real, ford, loss, dpred=dp, grad_weight=0.5)
             assert abs(loss.item() - l.item()) < 1e-4 * max(1, abs(l.item())), (mode, real, ford)
             close(to_cpu(dp), pr.grad, tol=1e-2, floor=1e-9, what='dpred %s' % mode)
+            wd = torch.full((1,), -2.0, device=DEV)
+            ops.gan_loss(mode, pd, real, ford, loss, dpred=dp, grad_weight=0.5, weight_dev=wd, dpred_accumulate=True)
+            close(to_cpu(dp), -pr.grad, tol=2e-2, floor=1e-9, what='dpred accumulate %s' % mode)
 
 
 def test_l1_loss():
