@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/s of the Pix2Pix GCC iteration at 256x256 on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path over one synthetic batch of 16 paired 256x256 images per GPU:
+    set_input(train) -> optimize_parameters() -> set_input(val) -> clipping_mask_alpha() ->
+    optimizer_netD_arch()                                   (reference train.py:144-151)
+for BASELINE.json configs[1]: student U-Net ngf 32 + selective-activation PatchGAN ndf 128, online
+teacher ngf 64 / ndf 128, hinge GAN loss, lambda_L1 100, content 50, gram 1e4, bf16 MFMA compute.
+Inputs are resident in HBM before the timed region.  One JSON line is printed by rank 0.
+
+roofline: the dominant kernel is the implicit-GEMM convolution (igemm_kernel, conv fprop / dgrad /
+ConvTranspose).  Every launch of it inside the timed region is bracketed by HIP events on the
+launch stream; achieved = sum of algorithmic FLOPs (2*M*Cout*taps*Cin, padding excluded) / sum of
+measured durations; peak = 2.5 PFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md).
+cpu_baseline: the oracle (CPU restatement pinned to the reference) timed on this host's cores on a
+bounded sample (N=1, same architecture, 1 warm-up + 3 timed iterations), rank 0 at --gpus 1 only.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GCC_ARGV = ['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--ngf', '32', '--ndf', '128',
+            '--online_distillation', '--darts_discriminator', '--lambda_content', '50', '--lambda_gram', '1e4',
+            '--arch_lr', '1e-4', '--arch_lr_step', '--gpu_ids', '0']
+FLOP_PER_IMG = 679.3e9      # 514.0 (optimize_parameters) + 165.3 (arch step) GFLOP
+PEAK_BF16 = 2.5e15
+
+
+def log(msg):
+    if int(os.environ.get('RANK', '0')) == 0:
+        print('[bench %s] %s' % (time.strftime('%H:%M:%S'), msg), file=sys.stderr, flush=True)
+
+
+def build(batch):
+    from gcc_amd.options import options
+    from gcc_amd.models import get_model_class
+    opt = options.parse(GCC_ARGV)
+    opt.isTrain = True
+    opt.batch_size = batch
+    cls = get_model_class(opt)
+    torch.manual_seed(0)
+    model = cls(opt)
+    topt = copy.deepcopy(opt)
+    topt.ngf, topt.ndf = opt.teacher_ngf, opt.teacher_ndf
+    topt.darts_discriminator = topt.online_distillation = False
+    teacher = cls(topt)
+    teacher.model_train()
+    model.teacher_model = teacher
+    model.init_distillation()
+    teacher.init_distillation()
+    model.model_train()
+    return model, opt
+
+
+def synthetic(batch, rank, device, size=256):
+    def pair(seed):
+        g = torch.Generator().manual_seed(seed)
+        a = torch.rand(batch, 3, size, size, generator=g) * 2 - 1
+        b = torch.rand(batch, 3, size, size, generator=g) * 2 - 1
+        return {'A': a.to(device), 'B': b.to(device), 'A_paths': [''] * batch, 'B_paths': [''] * batch}
+    return pair(1234 + rank), pair(4321 + rank)
+
+
+def one_step(model, train, val):
+    model.set_input(train)
+    model.optimize_parameters()
+    model.set_input(val)
+    model.clipping_mask_alpha()
+    model.optimizer_netD_arch()
+
+
+def cpu_baseline(iters=3):
+    """oracle on the host cores: N=1, full-size networks"""
+    from oracle import gcc_oracle as O
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, 16))     # measured on the 256-core host: 16 threads 0.62 s/it, 32: 0.89, 64: 79 (oversubscribed)
+    torch.set_num_threads(ncores)
+    opt = O.Opt(ngf=32, ndf=128, teacher_ngf=64, teacher_ndf=128, num_downs=8, no_dropout=False, direction='BtoA')
+    m = O.build_gcc_pair(opt, seed=0)
+    g = torch.Generator().manual_seed(1234)
+    A, B = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1, torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    vA, vB = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1, torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+
+    def it():
+        m.set_input(A, B)
+        m.optimize_parameters()
+        m.set_input(vA, vB)
+        m.clipping_mask_alpha()
+        m.optimizer_netD_arch()
+    t0 = time.time()
+    it()
+    first = time.time() - t0
+    log('cpu_baseline: warm-up iteration %.1f s on %d threads' % (first, ncores))
+    iters = max(1, min(iters, int(30.0 / max(first, 1e-3))))
+    t0 = time.time()
+    for _ in range(iters):
+        it()
+    dt = (time.time() - t0) / iters
+    return {'value': round(1.0 / dt, 4), 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'N=1 256x256, same GCC iteration (student ngf32/ndf128 + teacher ngf64/ndf128), fp32, '
+                      '1 warm-up + %d timed iterations, %.2f s/iteration' % (iters, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    from gcc_amd import dist as gdist
+    from gcc_amd import ops
+    world = gdist.init_from_env()
+    rank = gdist.rank()
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    model, opt = build(args.batch)
+    device = model.device
+    torch.cuda.set_device(device)
+    train, val = synthetic(args.batch, rank, device)
+
+    log('model built on %s (world %d); warm-up %d steps' % (device, world, args.warmup))
+    for i in range(args.warmup):
+        one_step(model, train, val)
+        if i == 0:
+            torch.cuda.synchronize()
+            log('first step done')
+    torch.cuda.synchronize()
+    log('warm-up done; timing %d steps' % args.steps)
+    if world > 1:
+        torch.distributed.barrier()
+    if not args.no_roofline:
+        ops.PROFILE.start()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(model, train, val)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    log('timed region: %.3f s (%.1f ms/step)' % (dt, 1000 * dt / args.steps))
+    roof = None
+    if not args.no_roofline:
+        roof = ops.PROFILE.stop()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = model.get_current_losses()
+    if rank != 0:
+        return
+    imgs = world * args.batch * args.steps
+    value = imgs / dt
+    out = {
+        'metric': 'training images/sec at 256x256 (pix2pix GCC)', 'value': round(value, 2), 'unit': 'images/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * dt / args.steps, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'Pix2Pix cityscapes 256x256 GCC distill+darts iteration (optimize_parameters + '
+                               'optimizer_netD_arch), student ngf32 / masked PatchGAN ndf128, teacher ngf64 / ndf128, '
+                               'filter_cfgs=None (no pretrained checkpoint to prune)',
+                   'batch_per_gpu': args.batch, 'global_batch': world * args.batch, 'image': '256x256',
+                   'parallelism': 'dp%d' % world},
+        'step_tflops': round(FLOP_PER_IMG * args.batch * args.steps / dt / 1e12, 2),
+        'step_mfma_frac': round(FLOP_PER_IMG * args.batch * args.steps / dt / PEAK_BF16, 4),
+        'loss_check': {k: round(v, 4) for k, v in losses.items()},
+    }
+    if roof is not None:
+        out['roofline'] = roof
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

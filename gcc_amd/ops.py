@@ -14,6 +14,58 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, check  # noqa: F401
 _ws_cache = {}
 
 
+class _Profile:
+    """Optional per-launch timing of the MFMA kernels with HIP events on the launch stream
+    (bench.py's roofline block).  Inactive by default: zero overhead on the product path."""
+
+    def __init__(self):
+        self.active = False
+        self.records = []
+
+    def start(self):
+        self.records = []
+        self.active = True
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, kind, flops, e0):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((kind, flops, e0, e1))
+
+    def stop(self, peak=2.5e15):
+        self.active = False
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, flops, e0, e1 in self.records:
+            a = agg.setdefault(kind, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        self.records = []
+        if not agg:
+            return None
+        dom = max(agg, key=lambda k: agg[k][1])
+        out = None
+        per = {}
+        for kind, (fl, sec, n) in agg.items():
+            per[kind] = {'launches': n, 'avg_us': round(1e6 * sec / n, 2), 'tflops': round(fl / sec / 1e12, 2),
+                         'time_s': round(sec, 4)}
+            if kind == dom:
+                out = {'bound': 'mfma', 'kernel': kind, 'achieved': round(fl / sec / 1e12, 2), 'peak': peak / 1e12,
+                       'unit': 'TFLOP/s', 'frac': round(fl / sec / peak, 4), 'traffic': None, 'launches': n,
+                       'avg_launch_us': round(1e6 * sec / n, 2),
+                       'algorithmic_gflop_per_launch': round(fl / n / 1e9, 3)}
+        out['per_kernel'] = per
+        return out
+
+
+PROFILE = _Profile()
+
+
 def lib():
     return _lib.load()
 
@@ -105,7 +157,10 @@ def conv_fprop(x, w, Co, k, stride, pad, out=None, bias=None, act=ACT_NONE, slop
         tiles = lib().gcc_conv_stat_tiles(C.byref(d), 0)
         stats = torch.empty((tiles, 2, Co), dtype=torch.float32, device=x.device)
     ep = _epilogue(bias, act, slope, stats)
+    e0 = PROFILE.begin() if PROFILE.active else None
     check(lib().gcc_conv_fprop(C.byref(d), xp, w.data_ptr(), yp, C.byref(ep), stream()), 'gcc_conv_fprop')
+    if e0 is not None:
+        PROFILE.end('igemm_kernel (conv fprop/dgrad)', 2.0 * N * Ho * Wo * Co * k * k * Ci, e0)
     return (out, stats) if want_stats else out
 
 
@@ -122,7 +177,10 @@ def conv_dgrad(dy, wt, Ci, H, W, k, stride, pad, out=None, bias=None, act=ACT_NO
         tiles = lib().gcc_conv_stat_tiles(C.byref(d), 1)
         stats = torch.empty((tiles, 2, Ci), dtype=torch.float32, device=dy.device)
     ep = _epilogue(bias, act, slope, stats)
+    e0 = PROFILE.begin() if PROFILE.active else None
     check(lib().gcc_conv_dgrad(C.byref(d), yp, wt.data_ptr(), xp, C.byref(ep), stream()), 'gcc_conv_dgrad')
+    if e0 is not None:
+        PROFILE.end('igemm_kernel (conv fprop/dgrad)', 2.0 * N * Ho * Wo * Co * k * k * Ci, e0)
     return (out, stats) if want_stats else out
 
 
@@ -135,8 +193,11 @@ def conv_wgrad(x, dy, dw, k, stride, pad, accumulate=False):
     d = conv_desc(N, H, W, Ci, Co, k, stride, pad, ldx, ldy)
     need = lib().gcc_conv_wgrad_workspace(C.byref(d))
     ws = workspace(need, x.device, 'wgrad')
+    e0 = PROFILE.begin() if PROFILE.active else None
     check(lib().gcc_conv_wgrad(C.byref(d), xp, yp, dw.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel(),
                                stream()), 'gcc_conv_wgrad')
+    if e0 is not None:
+        PROFILE.end('wgrad_kernel (+ slab reduce)', 2.0 * N * Ho * Wo * Co * k * k * Ci, e0)
     return dw
 
 
