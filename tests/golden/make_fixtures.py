@@ -20,6 +20,7 @@ Fixtures
   pix2pix_pretrain_d6.npz  plain Pix2Pix (no teacher, plain D, lambda_scale 1e-2): 2 iterations
   ops.npz               DifferentiableOP fwd/bwd (alpha <,==,> tau), GANLoss x4 modes, gram,
                         LambdaLR values, init_weights statistics
+  options.json          options.parse() results for 7 command lines (flag surface + per-model overrides)
   prune_d8.npz          scale_prune / norm_prune cfgs + max_min_* at several thresholds (ngf 8)
 """
 import copy
@@ -325,9 +326,31 @@ def fixture_prune_d8():
     print('prune_d8 ok: bn cfg@1.0 =', list(out['bn.f.3']))
 
 
+def fixture_options():
+    import json
+    from options import options
+    cases = []
+    for argv in (['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--ngf', '32', '--lambda_scale', '1e-2'],
+                 ['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--ngf', '32', '--ndf', '128',
+                  '--darts_discriminator', '--arch_lr', '1e-4', '--arch_lr_step', '--scale_prune', '--target_budget', '3.0',
+                  '--online_distillation', '--lambda_content', '50', '--lambda_gram', '1e4', '--gpu_ids', '0'],
+                 ['--dataroot', './database/maps', '--model', 'pix2pix'],
+                 ['--dataroot', './database/edges2shoes-r', '--model', 'pix2pix', '--gpu_ids', '0,1'],
+                 ['--dataroot', './database/horse2zebra', '--model', 'cyclegan', '--lambda_weight', '1e-3'],
+                 ['--dataroot', './database/celeb', '--model', 'sagan'],
+                 ['--dataroot', './database/church', '--model', 'sagan', '--gpu_ids', '-1']):
+        sys.argv = ['train.py'] + argv
+        parsed = vars(options.parse())
+        parsed = {k: ('inf' if v == float('inf') else v) for k, v in parsed.items()}
+        cases.append({'argv': argv, 'parsed': parsed})
+    json.dump(cases, open(os.path.join(HERE, 'options.json'), 'w'), indent=1, sort_keys=True)
+    print('options ok', len(cases))
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     import_reference()
+    fixture_options()
     fixture_ops()
     fixture_eval_d8()
     fixture_gcc_d6()

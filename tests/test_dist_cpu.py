@@ -1,0 +1,84 @@
+"""Data-parallel plumbing on CPU: world_size-2 gloo process groups (127.0.0.1)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from gcc_amd import dist as gdist
+    assert gdist.init_from_env(backend='gloo') == world
+    assert gdist.world_size() == world and gdist.rank() == rank
+    # gradient exchange: the sum over ranks of per-shard gradients, scaled by 1/world in the optimizer,
+    # equals the full-batch mean gradient for any per-sample-mean loss (BatchNorm statistics excepted)
+    torch.manual_seed(0)
+    w = torch.randn(5, 3, dtype=torch.float64, requires_grad=True)
+    x = torch.randn(8, 3, dtype=torch.float64)
+    y = torch.randn(8, 5, dtype=torch.float64)
+    full = ((x @ w.t() - y) ** 2).mean()
+    gfull = torch.autograd.grad(full, w)[0]
+    b, e = gdist.shard_range(8)
+    loc = ((x[b:e] @ w.t() - y[b:e]) ** 2).mean()
+    g = torch.autograd.grad(loc, w)[0].clone()
+    flat = g.reshape(-1).clone()
+    gdist.all_reduce_flat(flat)
+    ok_grad = torch.allclose(flat.reshape(5, 3) / world, gfull, atol=1e-12)
+    # replicas start identical
+    m = torch.nn.Linear(4, 4)
+    torch.manual_seed(rank + 10)
+    torch.nn.init.normal_(m.weight)
+    gdist.broadcast_module(m)
+    t = m.weight.detach().clone()
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    ok_bcast = all(torch.equal(gathered[0], gg) for gg in gathered)
+    md = gdist.mean_dict({'a': float(rank), 'b': 2.0}, 'cpu')
+    ok_mean = abs(md['a'] - (world - 1) / 2) < 1e-12 and md['b'] == 2.0
+    q.put((rank, ok_grad, ok_bcast, ok_mean, (b, e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gloo_world2_gradient_exchange():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in range(2)]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    res.sort()
+    assert [r[4] for r in res] == [(0, 4), (4, 8)]
+    for r in res:
+        assert r[1] and r[2] and r[3], r
+
+
+def test_shard_range_partitions():
+    from gcc_amd import dist as gdist
+    for n in (1, 7, 8, 16, 17):
+        for w in (1, 2, 3, 8):
+            parts = [gdist.shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            for a, b in zip(parts[:-1], parts[1:]):
+                assert a[1] == b[0]
