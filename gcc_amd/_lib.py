@@ -101,6 +101,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise GccError('libgcc_hip.so is not built (%s missing): the HIP kernels are the only '
                        'implementation of this path -- build them with gcc_amd/csrc/build.sh' % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime: it must be resident first so that this library binds to
+    # the same libamdhip64 (and the same device/stream state) instead of initialising a second one
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is missing

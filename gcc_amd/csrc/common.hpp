@@ -75,10 +75,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 __host__ __device__ static inline int ceil8(int v) { return (v + 7) & ~7; }
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-#define GCC_CHECK_LAUNCH()                                   \
-    do {                                                     \
-        if (hipGetLastError() != hipSuccess) return GCC_ERR_LAUNCH; \
+#include <stdio.h>
+#define GCC_CHECK_LAUNCH()                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = hipGetLastError();                                                      \
+        if (e_ != hipSuccess) {                                                                 \
+            fprintf(stderr, "[libgcc_hip] %s:%d launch failed: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return GCC_ERR_LAUNCH;                                                              \
+        }                                                                                       \
     } while (0)
+// errors left behind by other users of the HIP runtime in this thread (e.g. a failed capability
+// probe) must not be reported as ours: every entry point starts from a clean error state
+#define GCC_ENTER() (void)hipGetLastError()
 
 // XCD-aware remap of a linear workgroup id (8 XCDs, round-robin dispatch): logical tiles that are
 // adjacent end up on the same XCD (shared L2).  Bijective for any nwg.

@@ -331,6 +331,7 @@ int check_conv(const gcc_conv_t* c) {
 // internal entry (also used by distill.hip): `batch` independent problems, strides in elements
 int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const void* w, void* dst, const gcc_epilogue_t* ep,
                        int batch, long src_bstride, long wgt_bstride, long dst_bstride, hipStream_t st) {
+    GCC_ENTER();
     int rc = check_conv(c);
     if (rc) return rc;
     if (!src || !w || !dst) return GCC_ERR_BAD_ARG;
@@ -377,6 +378,7 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
 }
 
 extern "C" int gcc_conv_stat_tiles(const gcc_conv_t* c, int dgrad) {
+    GCC_ENTER();
     if (check_conv(c)) return 0;
     if (!dgrad) {
         const int Ho = gcc_conv_out(c->H, c->KH, c->stride, c->pad), Wo = gcc_conv_out(c->W, c->KW, c->stride, c->pad);
@@ -388,10 +390,12 @@ extern "C" int gcc_conv_stat_tiles(const gcc_conv_t* c, int dgrad) {
 
 extern "C" int gcc_conv_fprop(const gcc_conv_t* c, const void* x, const void* w, void* y,
                               const gcc_epilogue_t* ep, gcc_stream_t stream) {
+    GCC_ENTER();
     return gcc_internal_igemm(c, 0, x, w, y, ep, 1, 0, 0, 0, (hipStream_t)stream);
 }
 
 extern "C" int gcc_conv_dgrad(const gcc_conv_t* c, const void* dy, const void* wt, void* dx,
                               const gcc_epilogue_t* ep, gcc_stream_t stream) {
+    GCC_ENTER();
     return gcc_internal_igemm(c, 1, dy, wt, dx, ep, 1, 0, 0, 0, (hipStream_t)stream);
 }

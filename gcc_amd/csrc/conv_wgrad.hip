@@ -227,6 +227,7 @@ extern "C" size_t gcc_conv_wgrad_workspace(const gcc_conv_t* c) { return gcc_int
 // writes dw + b*Co*taps*Ci
 int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float* dw, int accumulate, void* ws,
                        size_t ws_bytes, int batch, long x_bstride, long dy_bstride, hipStream_t st) {
+    GCC_ENTER();
     if (!c || !x || !dy || !dw || !ws) return GCC_ERR_BAD_ARG;
     if (c->N <= 0 || c->H <= 0 || c->W <= 0 || c->Ci <= 0 || c->Co <= 0 || c->KH <= 0 || c->KW <= 0 ||
         c->stride <= 0 || c->pad < 0)
@@ -268,5 +269,6 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
 
 extern "C" int gcc_conv_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float* dw, int accumulate,
                               void* ws, size_t ws_bytes, gcc_stream_t stream) {
+    GCC_ENTER();
     return gcc_internal_wgrad(c, x, dy, dw, accumulate, ws, ws_bytes, 1, 0, 0, (hipStream_t)stream);
 }

@@ -271,10 +271,12 @@ extern "C" const char* gcc_strerror(int code) {
         default: return "unknown error";
     }
 }
-extern "C" int gcc_version(void) { return 100; }
+extern "C" int gcc_version(void) {
+    GCC_ENTER(); return 100; }
 
 extern "C" int gcc_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int N, int C, int H, int W, int ld, int off, int Cfill,
                                          gcc_stream_t stream) {
+    GCC_ENTER();
     if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0 || off + (Cfill > C ? Cfill : C) > ld) return GCC_ERR_BAD_ARG;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, src,
                        (bf16_t*)dst, N, C, H * W, ld, off, Cfill);
@@ -283,6 +285,7 @@ extern "C" int gcc_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int N, int
 }
 extern "C" int gcc_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int N, int C, int H, int W, int ld, int off,
                                          gcc_stream_t stream) {
+    GCC_ENTER();
     if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0 || off + C > ld) return GCC_ERR_BAD_ARG;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)src, dst, N, C, H * W, ld, off);
@@ -304,14 +307,17 @@ static int nhwc_copy_impl(const void* src, int lds, int soff, void* dst, int ldd
 }
 extern "C" int gcc_nhwc_copy(const void* src, int lds, int soff, void* dst, int ldd, int doff, int C, int Cfill, size_t pixels,
                              gcc_stream_t stream) {
+    GCC_ENTER();
     return nhwc_copy_impl(src, lds, soff, dst, ldd, doff, C, Cfill, pixels, 0, stream);
 }
 extern "C" int gcc_nhwc_add(const void* src, int lds, int soff, void* dst, int ldd, int doff, int C, size_t pixels,
                             gcc_stream_t stream) {
+    GCC_ENTER();
     return nhwc_copy_impl(src, lds, soff, dst, ldd, doff, C, C, pixels, 1, stream);
 }
 
 extern "C" int gcc_pack_weights(const float* master, int rows, int taps, int cols, void* w, void* wt, gcc_stream_t stream) {
+    GCC_ENTER();
     if (!master || rows <= 0 || taps <= 0 || cols <= 0 || (!w && !wt)) return GCC_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (w) {
@@ -337,6 +343,7 @@ extern "C" size_t gcc_loss_workspace(size_t pixels, int C) {
 extern "C" int gcc_gan_loss(int mode, int target_is_real, int for_discriminator, const void* pred, int ld, int off,
                             size_t pixels, float weight, float* loss, int accumulate, void* dpred, void* ws, size_t ws_bytes,
                             gcc_stream_t stream) {
+    GCC_ENTER();
     (void)ws; (void)ws_bytes;
     if (!pred || !loss || pixels == 0 || (ld & 7) || (off & 7) || mode < 0 || mode > 3) return GCC_ERR_BAD_ARG;
     if (mode == 0 && !for_discriminator && !target_is_real) return GCC_ERR_BAD_ARG;   // reference asserts
@@ -349,6 +356,7 @@ extern "C" int gcc_gan_loss(int mode, int target_is_real, int for_discriminator,
 extern "C" int gcc_gan_loss_ex(int mode, int target_is_real, int for_discriminator, const void* pred, int ld, int off,
                                size_t pixels, float* loss, void* dpred, float grad_weight, const float* grad_weight_dev,
                                int dpred_accumulate, gcc_stream_t stream) {
+    GCC_ENTER();
     if (!pred || !loss || pixels == 0 || (ld & 7) || (off & 7) || mode < 0 || mode > 3) return GCC_ERR_BAD_ARG;
     if (mode == 0 && !for_discriminator && !target_is_real) return GCC_ERR_BAD_ARG;
     hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mode, target_is_real, for_discriminator,
@@ -374,6 +382,7 @@ __global__ void arch_coeffs_kernel(const float* Lfr, const float* Lf, const floa
 }
 extern "C" int gcc_arch_coeffs(const float* Lfr, const float* Lf, const float* Lr, const float* dT, float* loss, float* c_fr,
                                float* c_f, gcc_stream_t stream) {
+    GCC_ENTER();
     if (!Lfr || !Lf || !Lr || !dT || !loss || !c_fr || !c_f) return GCC_ERR_BAD_ARG;
     hipLaunchKernelGGL(arch_coeffs_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, Lfr, Lf, Lr, dT, loss, c_fr, c_f);
     GCC_CHECK_LAUNCH();
@@ -383,6 +392,7 @@ extern "C" int gcc_arch_coeffs(const float* Lfr, const float* Lf, const float* L
 extern "C" int gcc_l1_loss(const void* a, int lda, int aoff, const void* b, int ldb, int boff, int C, size_t pixels,
                            float weight, float* loss, int accumulate, void* da, int ldda, int daoff, void* ws,
                            size_t ws_bytes, gcc_stream_t stream) {
+    GCC_ENTER();
     if (!a || !b || !loss || !ws || C <= 0 || pixels == 0) return GCC_ERR_BAD_ARG;
     if ((lda | aoff | ldb | boff) & 7 || (da && ((ldda | daoff) & 7))) return GCC_ERR_BAD_ARG;
     if (ws_bytes < RED_BLOCKS * sizeof(float)) return GCC_ERR_WORKSPACE;
@@ -430,6 +440,7 @@ extern "C" size_t gcc_distill_workspace(int N, int C, int HW) {
 
 extern "C" int gcc_distill_fwd(const void* f, int ldf, int foff, const void* t, int ldt, int toff, int N, int C, int HW,
                                float* out2, void* ws, size_t ws_bytes, gcc_stream_t stream) {
+    GCC_ENTER();
     if (!f || !t || !out2 || !ws || N <= 0 || C <= 0 || HW <= 0 || (C & 7)) return GCC_ERR_BAD_ARG;
     if ((ldf | foff | ldt | toff) & 7) return GCC_ERR_BAD_ARG;
     const DistillWs L = distill_layout(N, C, HW);
@@ -472,6 +483,7 @@ extern "C" int gcc_distill_fwd(const void* f, int ldf, int foff, const void* t, 
 extern "C" int gcc_distill_bwd(const void* f, int ldf, int foff, const void* t, int ldt, int toff, int N, int C, int HW,
                                float wg, float wc, void* df, int lddf, int dfoff, void* ws, size_t ws_bytes,
                                gcc_stream_t stream) {
+    GCC_ENTER();
     if (!f || !t || !df || !ws || N <= 0 || C <= 0 || HW <= 0 || (C & 7)) return GCC_ERR_BAD_ARG;
     if ((ldf | foff | ldt | toff | lddf | dfoff) & 7) return GCC_ERR_BAD_ARG;
     const DistillWs L = distill_layout(N, C, HW);
@@ -494,6 +506,7 @@ extern "C" int gcc_distill_bwd(const void* f, int ldf, int foff, const void* t, 
 
 extern "C" int gcc_adam_step(const gcc_adam_tensor_t* tensors, const gcc_adam_chunk_t* chunks, int nchunks, int chunk_elems,
                              float lr, float beta1, float beta2, float eps, int step, gcc_stream_t stream) {
+    GCC_ENTER();
     if (!tensors || !chunks || nchunks <= 0 || chunk_elems <= 0 || step < 1) return GCC_ERR_BAD_ARG;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -504,12 +517,14 @@ extern "C" int gcc_adam_step(const gcc_adam_tensor_t* tensors, const gcc_adam_ch
 }
 
 extern "C" int gcc_fill_f32(float* p, float v, size_t n, gcc_stream_t stream) {
+    GCC_ENTER();
     if (!p || n == 0) return GCC_ERR_BAD_ARG;
     hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, v, n);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }
 extern "C" int gcc_clamp_f32(float* p, float lo, float hi, size_t n, gcc_stream_t stream) {
+    GCC_ENTER();
     if (!p || n == 0) return GCC_ERR_BAD_ARG;
     hipLaunchKernelGGL(clamp_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, lo, hi, n);
     GCC_CHECK_LAUNCH();
@@ -517,6 +532,7 @@ extern "C" int gcc_clamp_f32(float* p, float lo, float hi, size_t n, gcc_stream_
 }
 extern "C" int gcc_scalar_op(int op, const float* a, const float* b, const float* c, float k0, float k1, float* out,
                              gcc_stream_t stream) {
+    GCC_ENTER();
     if (!a || !b || !out || op < 0 || op > 2) return GCC_ERR_BAD_ARG;
     hipLaunchKernelGGL(scalar_ops_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, op, a, b, c, k0, k1, out);
     GCC_CHECK_LAUNCH();

@@ -341,6 +341,7 @@ bool aligned8(int a, int b) { return !((a & 7) || (b & 7)); }
 extern "C" int gcc_bn_finalize(const float* stats_partial, int tiles, int C, double count, const float* gamma,
                                const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                                float* mean, float* rstd, float* scale, float* shift, gcc_stream_t stream) {
+    GCC_ENTER();
     if (!stats_partial || tiles <= 0 || C <= 0 || count <= 0 || !scale || !shift) return GCC_ERR_BAD_ARG;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, stats_partial, tiles, C,
                        count, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift);
@@ -351,6 +352,7 @@ extern "C" int gcc_bn_finalize(const float* stats_partial, int tiles, int C, dou
 extern "C" int gcc_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                                   const float* running_var, float eps, int C, float* scale, float* shift,
                                   gcc_stream_t stream) {
+    GCC_ENTER();
     if (!running_mean || !running_var || !scale || !shift || C <= 0) return GCC_ERR_BAD_ARG;
     hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
                        running_mean, running_var, eps, C, scale, shift);
@@ -360,6 +362,7 @@ extern "C" int gcc_bn_eval_coeffs(const float* gamma, const float* beta, const f
 
 extern "C" int gcc_bnact_fwd(const gcc_bnact_t* p, const void* x, int ldx, int xoff, void* y, int ldy, int yoff,
                              void* y2, int ldy2, int y2off, int C, size_t pixels, gcc_stream_t stream) {
+    GCC_ENTER();
     if (!p || !x || (!y && !y2) || C <= 0 || pixels == 0) return GCC_ERR_BAD_ARG;
     if (!aligned8(ldx, xoff) || (y && !aligned8(ldy, yoff)) || (y2 && !aligned8(ldy2, y2off))) return GCC_ERR_BAD_ARG;
     FwdArgs a;
@@ -392,6 +395,7 @@ extern "C" int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_s
                                 const void* y, int ldy, int yoff, const void* g1, int ldg1, int g1off, const void* g2,
                                 int ldg2, int g2off, void* dx, int lddx, int dxoff, int C, size_t pixels, void* ws,
                                 size_t ws_bytes, gcc_stream_t stream) {
+    GCC_ENTER();
     if (!p || !x || !g1 || !dx || !ws || C <= 0 || pixels == 0) return GCC_ERR_BAD_ARG;
     if (!aligned8(ldx, xoff) || !aligned8(ldg1, g1off) || !aligned8(lddx, dxoff)) return GCC_ERR_BAD_ARG;
     if ((y && !aligned8(ldy, yoff)) || (g2 && !aligned8(ldg2, g2off))) return GCC_ERR_BAD_ARG;
@@ -425,6 +429,7 @@ extern "C" int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_s
 extern "C" int gcc_bnact_bwd(const gcc_bnact_bwd_t* p, const void* x, int ldx, int xoff, const void* y, int ldy, int yoff,
                              const void* g1, int ldg1, int g1off, const void* g2, int ldg2, int g2off, void* dx, int lddx,
                              int dxoff, int C, size_t pixels, void* ws, size_t ws_bytes, gcc_stream_t stream) {
+    GCC_ENTER();
     return gcc_bnact_bwd_ex(p, GCC_ACT_NONE, 0.f, x, ldx, xoff, y, ldy, yoff, g1, ldg1, g1off, g2, ldg2, g2off, dx, lddx,
                             dxoff, C, pixels, ws, ws_bytes, stream);
 }
@@ -437,6 +442,7 @@ extern "C" size_t gcc_channel_sum_workspace(int C, size_t pixels) {
 
 extern "C" int gcc_channel_sum(const void* x, int ld, int off, int C, size_t pixels, float* out, int accumulate,
                                void* ws, size_t ws_bytes, gcc_stream_t stream) {
+    GCC_ENTER();
     if (!x || !out || !ws || C <= 0 || pixels == 0 || !aligned8(ld, off)) return GCC_ERR_BAD_ARG;
     if (ws_bytes < gcc_channel_sum_workspace(C, pixels)) return GCC_ERR_WORKSPACE;
     SumArgs a;
@@ -454,6 +460,7 @@ extern "C" int gcc_channel_sum(const void* x, int ld, int off, int C, size_t pix
 }
 
 extern "C" int gcc_gate_mask(const float* alpha, float tau, float* mask, int C, gcc_stream_t stream) {
+    GCC_ENTER();
     if (!alpha || !mask || C <= 0) return GCC_ERR_BAD_ARG;
     hipLaunchKernelGGL(gate_mask_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, alpha, tau, mask, C);
     GCC_CHECK_LAUNCH();

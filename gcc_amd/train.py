@@ -1,0 +1,114 @@
+"""Training entry point: the reference's train.py loop (train.py:75-174) on the MI355X path.
+
+    python -m gcc_amd.train --dataroot ./database/cityscapes/ --model pix2pix --ngf 32 --ndf 128 \\
+        --online_distillation --darts_discriminator --lambda_content 50 --lambda_gram 1e4 ...
+    (data parallel: python -m torch.distributed.run --nproc-per-node 8 -m gcc_amd.train ...)
+
+Data loading is outside the accelerated path: if the reference's own
+``data`` package is importable (run from a checkout of it) its loaders are used unchanged --
+they only have to yield the batch dict {'A','B','A_paths','B_paths'}; otherwise
+``--dataroot synthetic[:N]`` yields seeded U[-1,1) pairs of that shape.  Evaluation (FID / mIoU,
+reference metric/) needs third-party weights and stays with the reference's test.py.
+"""
+import copy
+import os
+import time
+
+import torch
+
+from . import dist as gdist
+from .models import get_model_class
+from .options import options
+from .utils import util
+
+
+class SyntheticPairs:
+    def __init__(self, opt, n_batches, seed):
+        self.opt, self.n, self.seed = opt, n_batches, seed
+
+    def __len__(self):
+        return self.n * self.opt.batch_size
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed)
+        b, s = self.opt.batch_size, self.opt.crop_size
+        for _ in range(self.n):
+            yield {'A': torch.rand(b, 3, s, s, generator=g) * 2 - 1, 'B': torch.rand(b, 3, s, s, generator=g) * 2 - 1,
+                   'A_paths': [''] * b, 'B_paths': [''] * b}
+
+
+def make_datasets(opt):
+    root = str(opt.dataroot)
+    if root.startswith('synthetic'):
+        n = int(root.split(':')[1]) if ':' in root else 8
+        r = gdist.rank()
+        return SyntheticPairs(opt, n, 1234 + r), SyntheticPairs(opt, n, 4321 + r)
+    from data import create_split_dataset      # the reference's loaders (data/__init__.py:52-58)
+    return create_split_dataset(opt)
+
+
+def attach_teacher(model, opt, model_class):
+    """train.py:92-105"""
+    topt = copy.deepcopy(opt)
+    topt.ngf, topt.ndf = opt.teacher_ngf, opt.teacher_ndf
+    topt.darts_discriminator = topt.online_distillation = False
+    topt.generator_only = False
+    teacher = model_class(topt)
+    teacher.model_train()
+    if opt.teacher_initial_path is not None:
+        teacher.load_models(opt.teacher_initial_path, load_discriminator=False)
+    model.teacher_model = teacher
+    model.init_distillation()
+    teacher.init_distillation()
+    return teacher
+
+
+def main(argv=None):
+    gdist.init_from_env()
+    opt = options.parse(argv)
+    opt.isTrain = True
+    exp = os.path.join(opt.checkpoints_dir, opt.name)
+    util.mkdirs(exp)
+    logger = util.get_logger(os.path.join(exp, 'logger.log' if gdist.rank() == 0 else 'logger.rank%d.log' % gdist.rank()))
+    model_class = get_model_class(opt)
+    model = model_class(opt)
+    if opt.norm_prune or opt.scale_prune:
+        from .utils.prune_util import prune
+        model = prune(model, opt, logger)
+    if opt.online_distillation:
+        attach_teacher(model, opt, model_class)
+    if opt.initial_path is not None:
+        model.load_models(opt.initial_path, load_discriminator=False)
+    train_set, val_set = make_datasets(opt)
+    logger.info('The number of training images = %d' % len(train_set))
+    total_iters = 0
+    for epoch in range(opt.epoch_count, opt.n_epochs + opt.n_epochs_decay + 1):
+        model.model_train()
+        logger.info('\nEpoch:%d' % epoch)
+        t_epoch = time.time()
+        val_iter = iter(val_set)
+        epoch_iter = 0
+        for data in train_set:
+            t0 = time.time()
+            total_iters += opt.batch_size
+            epoch_iter += opt.batch_size
+            model.set_input(data)
+            model.optimize_parameters()
+            if opt.darts_discriminator and model.teacher_model is not None:
+                model.set_input(next(val_iter))
+                model.clipping_mask_alpha()
+                model.optimizer_netD_arch()
+            if total_iters % opt.print_freq == 0:
+                losses = model.get_current_losses()
+                msg = '(epoch: %d, iters: %d, time: %.3f) ' % (epoch, epoch_iter, (time.time() - t0) / opt.batch_size)
+                logger.info(msg + ' '.join('%s: %.3f' % kv for kv in losses.items()))
+        if epoch % opt.save_epoch_freq == 0 and epoch == opt.n_epochs + opt.n_epochs_decay:
+            model.save_models(epoch, os.path.join(exp, 'checkpoints'))
+        model.print_sparse_info(logger)
+        logger.info('End of epoch %d / %d \t Time Taken: %d sec' % (epoch, opt.n_epochs + opt.n_epochs_decay,
+                                                                    time.time() - t_epoch))
+        model.update_learning_rate(epoch)
+
+
+if __name__ == '__main__':
+    main()
