@@ -20,7 +20,8 @@ class conv_t(C.Structure):
 
 
 class epilogue_t(C.Structure):
-    _fields_ = [('bias', C.c_void_p), ('act', C.c_int), ('slope', C.c_float), ('stats_partial', C.c_void_p)]
+    _fields_ = [('bias', C.c_void_p), ('act', C.c_int), ('slope', C.c_float), ('stats_partial', C.c_void_p),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 
 class bnact_t(C.Structure):
@@ -55,6 +56,7 @@ PROTOTYPES = {
     'gcc_strerror': (C.c_char_p, [_I]),
     'gcc_version': (_I, []),
     'gcc_conv_stat_tiles': (_I, [C.POINTER(conv_t), _I]),
+    'gcc_conv_workspace': (_Z, [C.POINTER(conv_t), _I]),
     'gcc_conv_fprop': (_I, [C.POINTER(conv_t), _P, _P, _P, C.POINTER(epilogue_t), _P]),
     'gcc_conv_dgrad': (_I, [C.POINTER(conv_t), _P, _P, _P, C.POINTER(epilogue_t), _P]),
     'gcc_conv_wgrad_workspace': (_Z, [C.POINTER(conv_t)]),

@@ -35,6 +35,11 @@ struct IgemmParams {
     int ntiles;
     // optional batch of independent problems on blockIdx.y (per-image 1x1 products of the gram loss)
     long src_bstride, dst_bstride, wgt_bstride;   // elements
+    // split-K (small grids: U-Net bottleneck, 1-channel PatchGAN head): blockIdx.y = K slice, fp32
+    // partial tiles go to `partial` [phase][slice][rows_max][Cpad]; splitk_epilogue_kernel finishes
+    int ksplit, kper;
+    float* partial;
+    int rows_max, Cpad;
 };
 
 constexpr int BP = 128;  // pixels per tile
@@ -85,7 +90,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
     const int M = p.N * Hg * Wg;
     const int Ktot = TA * TB * p.Ct;
-    const int nk = (Ktot + BK - 1) / BK;
+    const int nk_all = (Ktot + BK - 1) / BK;
+    const int ks_idx = p.ksplit > 1 ? blockIdx.y : 0;
+    const int kbeg = ks_idx * p.kper;
+    const int nk = p.ksplit > 1 ? min(p.kper, nk_all - kbeg) : nk_all;
 
     const int nwg = gridDim.x;
     const int tile = xcd_remap(blockIdx.x, nwg);
@@ -102,9 +110,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         return;
     }
 
-    const bf16_t* srcp = p.src + (size_t)blockIdx.y * p.src_bstride;
-    const bf16_t* wgtp = p.wgt + (size_t)blockIdx.y * p.wgt_bstride;
-    bf16_t* dstp = p.dst + (size_t)blockIdx.y * p.dst_bstride;
+    const int bidx = p.ksplit > 1 ? 0 : blockIdx.y;
+    const bf16_t* srcp = p.src + (size_t)bidx * p.src_bstride;
+    const bf16_t* wgtp = p.wgt + (size_t)bidx * p.wgt_bstride;
+    bf16_t* dstp = p.dst + (size_t)bidx * p.dst_bstride;
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)srcp, 0, p.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)wgtp, 0, p.wgt_bytes, 0x00020000);
 
@@ -136,7 +145,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     i32x4 ra[4];
     i32x4 rw[C::W_CHUNKS];
 
-    auto issue_loads = [&](int kt) {
+    auto issue_loads = [&](int kt_local) {
+        const int kt = kbeg + kt_local;
         const int k = kt * BK + chunk * 8;
         int tap, cc;
         if (uniform_tap) {
@@ -231,6 +241,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
     // ---- epilogue ------------------------------------------------------------------------------
     // acc[i][j][r]: channel = wc*TC + i*16 + 4*lq + r ; pixel = wp*TP + j*16 + lr
+    if (p.ksplit > 1) {
+        float* part = p.partial + ((size_t)(blockIdx.z * p.ksplit + ks_idx) * p.rows_max) * p.Cpad;
+#pragma unroll
+        for (int j = 0; j < C::PB; j++) {
+            const int m = m0 + wp * C::TP + j * 16 + lr;
+            if (m < M) {
+#pragma unroll
+                for (int i = 0; i < C::CB; i++) {
+                    const int cl = n0 + wc * C::TC + i * 16 + 4 * lq;
+                    *(f32x4*)(part + (size_t)m * p.Cpad + cl) = acc[i][j];
+                }
+            }
+        }
+        return;
+    }
     char* sO = smem;
 #pragma unroll
     for (int i = 0; i < C::CB; i++) {
@@ -300,6 +325,82 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
 }
 
+// finish a split-K launch: sum the K slices, bias + activation, bf16 NHWC store (same pixel map)
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams p) {
+    int py = 0, px = 0, Hg, Wg, ostr = 1;
+    if (!p.dgrad) { Hg = p.Hd; Wg = p.Wd; }
+    else {
+        const int s = p.stride;
+        py = blockIdx.z / s; px = blockIdx.z % s; ostr = s;
+        Hg = (p.Hd - py + s - 1) / s; Wg = (p.Wd - px + s - 1) / s;
+    }
+    const int M = p.N * Hg * Wg;
+    const int CH = ceil8(p.Cout) / 8;
+    const size_t total = (size_t)M * CH;
+    const float* base = p.partial + (size_t)blockIdx.z * p.ksplit * p.rows_max * p.Cpad;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const int m = (int)(q / CH);
+        const int c0 = (int)(q - (size_t)m * CH) * 8;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < p.ksplit; s++) {
+            const float* r = base + ((size_t)s * p.rows_max + m) * p.Cpad + c0;
+            const f32x4 a = *(const f32x4*)r, b = *(const f32x4*)(r + 4);
+            v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+            v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const bool ok = c0 + j < p.Cout;
+            const float bv = (p.bias && ok) ? p.bias[c0 + j] : 0.f;
+            v[j] = ok ? apply_act(v[j] + bv, p.act, p.slope) : 0.f;
+        }
+        const int n = m / (Hg * Wg);
+        const int r = m - n * (Hg * Wg);
+        const int oy = r / Wg, ox = r - oy * Wg;
+        const size_t o = ((size_t)(n * p.Hd + oy * ostr + py) * p.Wd + (ox * ostr + px)) * p.ldd + p.doff + c0;
+        *(i32x4*)(p.dst + o) = pack8(v);
+    }
+}
+
+// per-channel sum / sum of squares of an NHWC bf16 tensor -> stats[0][2][C] (one 8-channel chunk per block)
+__global__ __launch_bounds__(256) void channel_stats_kernel(const bf16_t* __restrict__ x, int ld, int off, int C, size_t pixels,
+                                                            float* __restrict__ stats) {
+    __shared__ float red[2][256][9];
+    const int c0 = blockIdx.x * 8;
+    float s[8], ss[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] = ss[j] = 0.f;
+    for (size_t pix = threadIdx.x; pix < pixels; pix += 256) {
+        float v[8];
+        unpack8(*(const i32x4*)(x + pix * ld + off + c0), v);
+#pragma unroll
+        for (int j = 0; j < 8; j++) { s[j] += v[j]; ss[j] += v[j] * v[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) { red[0][threadIdx.x][j] = s[j]; red[1][threadIdx.x][j] = ss[j]; }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int j = threadIdx.x & 7, w = threadIdx.x >> 3;
+        float t = 0.f;
+        for (int q = 0; q < 256; q++) t += red[w][q][j];
+        if (c0 + j < C) stats[(size_t)w * C + c0 + j] = t;
+    }
+}
+
+struct SplitPlan { int ksplit, kper; };
+// split only launches that cannot fill the chip and have a long K loop
+static SplitPlan plan_ksplit(long blocks, int nk) {
+    SplitPlan sp = {1, nk};
+    if (blocks >= 128 || nk < 16) return sp;
+    int s = (int)((512 + blocks - 1) / blocks);
+    if (s > nk / 4) s = nk / 4;
+    if (s < 2) return sp;
+    sp.kper = (nk + s - 1) / s;
+    sp.ksplit = (nk + sp.kper - 1) / sp.kper;
+    if (sp.ksplit < 2) { sp.ksplit = 1; sp.kper = nk; }
+    return sp;
+}
+
 template <int BC>
 int launch(const IgemmParams& p, int phases, int batch, hipStream_t st) {
     using C = Cfg<BC>;
@@ -308,9 +409,16 @@ int launch(const IgemmParams& p, int phases, int batch, hipStream_t st) {
         hipFuncSetAttribute((const void*)igemm_kernel<BC>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_set = true;
     }
-    dim3 grid(p.mtiles_max * p.ntiles, batch, phases);
+    dim3 grid(p.mtiles_max * p.ntiles, p.ksplit > 1 ? p.ksplit : batch, phases);
     hipLaunchKernelGGL(igemm_kernel<BC>, grid, dim3(256), C::LDS_BYTES, st, p);
     GCC_CHECK_LAUNCH();
+    if (p.ksplit > 1) {
+        const size_t total = (size_t)p.rows_max * (ceil8(p.Cout) / 8);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks, 1, phases), dim3(256), 0, st, p);
+        GCC_CHECK_LAUNCH();
+    }
     return GCC_OK;
 }
 
@@ -370,11 +478,56 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
     if (batch < 1 || (batch > 1 && p.stats)) return GCC_ERR_BAD_ARG;
     const int phases = dgrad ? c->stride * c->stride : 1;
     if (dgrad && (c->KH < c->stride || c->KW < c->stride)) return GCC_ERR_UNSUPPORTED;
-    if (p.Cout > 64) { p.ntiles = cdiv(p.Cout, 128); return launch<128>(p, phases, batch, st); }
-    if (p.Cout > 32) { p.ntiles = 1; return launch<64>(p, phases, batch, st); }
-    if (p.Cout > 16) { p.ntiles = 1; return launch<32>(p, phases, batch, st); }
-    p.ntiles = 1;
-    return launch<16>(p, phases, batch, st);
+    int BC;
+    if (p.Cout > 64) { BC = 128; p.ntiles = cdiv(p.Cout, 128); }
+    else if (p.Cout > 32) { BC = 64; p.ntiles = 1; }
+    else if (p.Cout > 16) { BC = 32; p.ntiles = 1; }
+    else { BC = 16; p.ntiles = 1; }
+    // ---- split-K decision (needs caller workspace; without it the launch simply is not split) ------
+    p.ksplit = 1; p.kper = 0; p.partial = nullptr; p.rows_max = (int)max_rows; p.Cpad = p.ntiles * BC;
+    float* stats_out = p.stats;
+    if (batch == 1 && ep && ep->workspace) {
+        const int taps_max = dgrad ? cdiv(c->KH, c->stride) * cdiv(c->KW, c->stride) : c->KH * c->KW;
+        const int nk = cdiv(taps_max * p.Ct, BK);
+        const SplitPlan sp = plan_ksplit((long)p.mtiles_max * p.ntiles * phases, nk);
+        const size_t need = (size_t)phases * sp.ksplit * max_rows * p.Cpad * sizeof(float);
+        if (sp.ksplit > 1 && need <= ep->workspace_bytes && (((uintptr_t)ep->workspace) & 15) == 0) {
+            p.ksplit = sp.ksplit; p.kper = sp.kper; p.partial = (float*)ep->workspace;
+            p.stats = nullptr;       // statistics are taken from the finished tensor below
+        }
+    }
+    switch (BC) {
+        case 128: rc = launch<128>(p, phases, batch, st); break;
+        case 64: rc = launch<64>(p, phases, batch, st); break;
+        case 32: rc = launch<32>(p, phases, batch, st); break;
+        default: rc = launch<16>(p, phases, batch, st); break;
+    }
+    if (rc) return rc;
+    if (p.ksplit > 1 && stats_out) {
+        const int tiles = p.mtiles_max * phases;
+        if (tiles > 1 &&
+            hipMemsetAsync(stats_out + (size_t)2 * p.Cout, 0, (size_t)(tiles - 1) * 2 * p.Cout * sizeof(float), st) != hipSuccess)
+            return GCC_ERR_LAUNCH;
+        const size_t pixels = (size_t)p.N * p.Hd * p.Wd;
+        hipLaunchKernelGGL(channel_stats_kernel, dim3(ceil8(p.Cout) / 8), dim3(256), 0, st, p.dst, p.ldd, p.doff, p.Cout,
+                           pixels, stats_out);
+        GCC_CHECK_LAUNCH();
+    }
+    return GCC_OK;
+}
+
+extern "C" size_t gcc_conv_workspace(const gcc_conv_t* c, int dgrad) {
+    if (check_conv(c)) return 0;
+    const int Ho = gcc_conv_out(c->H, c->KH, c->stride, c->pad), Wo = gcc_conv_out(c->W, c->KW, c->stride, c->pad);
+    const int phases = dgrad ? c->stride * c->stride : 1;
+    const size_t max_rows = dgrad ? (size_t)c->N * cdiv(c->H, c->stride) * cdiv(c->W, c->stride) : (size_t)c->N * Ho * Wo;
+    const int Cout = dgrad ? c->Ci : c->Co, Ct = ceil8(dgrad ? c->Co : c->Ci);
+    int BC, ntiles = 1;
+    if (Cout > 64) { BC = 128; ntiles = cdiv(Cout, 128); } else if (Cout > 32) BC = 64; else if (Cout > 16) BC = 32; else BC = 16;
+    const int taps_max = dgrad ? cdiv(c->KH, c->stride) * cdiv(c->KW, c->stride) : c->KH * c->KW;
+    const SplitPlan sp = plan_ksplit((long)((max_rows + BP - 1) / BP) * ntiles * phases, cdiv(taps_max * Ct, BK));
+    if (sp.ksplit <= 1) return 0;
+    return (size_t)phases * sp.ksplit * max_rows * ntiles * BC * sizeof(float);
 }
 
 extern "C" int gcc_conv_stat_tiles(const gcc_conv_t* c, int dgrad) {

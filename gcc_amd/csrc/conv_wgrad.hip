@@ -47,6 +47,9 @@ struct WgradParams {
     FastDiv dHW, dW, dCip, dKW;
     int batch;                       // independent problems on blockIdx.y (gram matrices per image)
     long x_bstride, dy_bstride;      // elements
+    int direct;                      // 1: no split -> write (accumulate) straight into dW, no slab / fold pass
+    int accumulate;
+    float* dw;
 };
 
 constexpr int TP = 64;          // pixels per step
@@ -167,7 +170,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 
     // acc[i][j][r] = dW[co = co0 + wb*64 + j*16 + (lane&15)][col = col0 + wa*64 + i*16 + 4*(lane>>4) + r]
-    float* slab = p.out + ((size_t)split * p.batch + bidx) * p.Co * p.ncols;
+    float* slab = p.direct ? p.dw + (size_t)bidx * p.Co * p.ncols
+                           : p.out + ((size_t)split * p.batch + bidx) * p.Co * p.ncols;
+    const bool rmw = p.direct && p.accumulate;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int co = co0 + wb * 64 + j * 16 + (lane & 15);
@@ -175,9 +180,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int col = col0 + wa * 64 + i * 16 + 4 * (lane >> 4);
-                if (col < p.ncols) *(f32x4*)(slab + (size_t)co * p.ncols + col) = acc[i][j];
+                if (col < p.ncols) {
+                    f32x4* d = (f32x4*)(slab + (size_t)co * p.ncols + col);
+                    f32x4 v = acc[i][j];
+                    if (rmw) { const f32x4 o = *d; v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+                    *d = v;
+                }
             }
         }
+    }
+}
+
+// regular widths (Ci % 8 == 0: slab layout == dW layout): 16-byte fold
+__global__ void wgrad_reduce_vec_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splits, size_t n4,
+                                        int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 s = ((const f32x4*)slabs)[i];
+        for (int z = 1; z < splits; z++) {
+            const f32x4 v = ((const f32x4*)slabs)[(size_t)z * n4 + i];
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
+        if (accumulate) { const f32x4 o = ((const f32x4*)dw)[i]; s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3]; }
+        ((f32x4*)dw)[i] = s;
     }
 }
 
@@ -202,8 +226,10 @@ int plan_splits(const gcc_conv_t* c, int batch, int* ksteps_per_split) {
     const int ksteps = (int)((M + TP - 1) / TP);
     const int ncols = c->KH * c->KW * ceil8(c->Ci);
     const int tiles = cdiv(ncols, TCOL) * cdiv(c->Co, TCO) * batch;
-    int splits = cdiv(1024, tiles);
-    const int max_splits = ksteps / 4 > 0 ? ksteps / 4 : 1;   // at least 4 k-steps (256 pixels) per split
+    // enough tiles to fill the chip (2 workgroups per CU resident): no split, dW written directly;
+    // otherwise split the pixel range so that ~512 workgroups exist, >= 8 k-steps (512 pixels) each
+    int splits = tiles >= 192 ? 1 : cdiv(512, tiles);
+    const int max_splits = ksteps / 8 > 0 ? ksteps / 8 : 1;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     const int per = cdiv(ksteps, splits);
@@ -248,6 +274,9 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
     p.M = (int)M; p.x_bytes = (uint32_t)xb; p.dy_bytes = (uint32_t)yb;
     const int splits = plan_splits(c, batch, &p.ksteps_per_split);
     p.batch = batch; p.x_bstride = x_bstride; p.dy_bstride = dy_bstride;
+    const bool regular = (c->Ci & 7) == 0 && (((uintptr_t)dw) & 15) == 0;
+    p.direct = (splits == 1 && regular) ? 1 : 0;
+    p.accumulate = accumulate; p.dw = dw;
     p.col_tiles = cdiv(p.ncols, TCOL); p.co_tiles = cdiv(c->Co, TCO);
     p.dHW = make_fastdiv(Ho * Wo); p.dW = make_fastdiv(Wo); p.dCip = make_fastdiv(p.Cip); p.dKW = make_fastdiv(c->KW);
     static bool attr_set = false;
@@ -258,11 +287,20 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
     }
     hipLaunchKernelGGL(wgrad_kernel, dim3(p.col_tiles * p.co_tiles, batch, splits), dim3(256), lds, st, p);
     GCC_CHECK_LAUNCH();
+    if (p.direct) return GCC_OK;
     const size_t total = (size_t)batch * c->Co * c->KH * c->KW * c->Ci;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits,
-                       batch * c->Co, c->KH * c->KW, c->Ci, p.Cip, accumulate);
+    if (regular) {
+        const size_t n4 = total / 4;
+        int blocks = (int)((n4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits, n4,
+                           accumulate);
+    } else {
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits,
+                           batch * c->Co, c->KH * c->KW, c->Ci, p.Cip, accumulate);
+    }
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

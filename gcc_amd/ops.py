@@ -140,9 +140,15 @@ def pack_weights_into(master, w, wt):
                                  wt.data_ptr() if wt is not None else None, stream()), 'gcc_pack_weights')
 
 
-def _epilogue(bias, act, slope, stats):
+def _epilogue(bias, act, slope, stats, d=None, dgrad=0, device=None):
+    wsp, wsb = None, 0
+    if d is not None:
+        need = lib().gcc_conv_workspace(C.byref(d), dgrad)
+        if need:
+            ws = workspace(need, device, 'splitk')
+            wsp, wsb = ws.data_ptr(), ws.numel()
     return _lib.epilogue_t(bias.data_ptr() if bias is not None else None, act, slope,
-                           stats.data_ptr() if stats is not None else None)
+                           stats.data_ptr() if stats is not None else None, wsp, wsb)
 
 
 def conv_fprop(x, w, Co, k, stride, pad, out=None, bias=None, act=ACT_NONE, slope=0.2, want_stats=False):
@@ -156,7 +162,7 @@ def conv_fprop(x, w, Co, k, stride, pad, out=None, bias=None, act=ACT_NONE, slop
     if want_stats:
         tiles = lib().gcc_conv_stat_tiles(C.byref(d), 0)
         stats = torch.empty((tiles, 2, Co), dtype=torch.float32, device=x.device)
-    ep = _epilogue(bias, act, slope, stats)
+    ep = _epilogue(bias, act, slope, stats, d, 0, x.device)
     e0 = PROFILE.begin() if PROFILE.active else None
     check(lib().gcc_conv_fprop(C.byref(d), xp, w.data_ptr(), yp, C.byref(ep), stream()), 'gcc_conv_fprop')
     if e0 is not None:
@@ -176,7 +182,7 @@ def conv_dgrad(dy, wt, Ci, H, W, k, stride, pad, out=None, bias=None, act=ACT_NO
     if want_stats:
         tiles = lib().gcc_conv_stat_tiles(C.byref(d), 1)
         stats = torch.empty((tiles, 2, Ci), dtype=torch.float32, device=dy.device)
-    ep = _epilogue(bias, act, slope, stats)
+    ep = _epilogue(bias, act, slope, stats, d, 1, dy.device)
     e0 = PROFILE.begin() if PROFILE.active else None
     check(lib().gcc_conv_dgrad(C.byref(d), yp, wt.data_ptr(), xp, C.byref(ep), stream()), 'gcc_conv_dgrad')
     if e0 is not None:

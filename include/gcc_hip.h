@@ -66,7 +66,13 @@ typedef struct {
     int act;              /* GCC_ACT_* */
     float slope;          /* LeakyReLU slope */
     float* stats_partial; /* NULL, or [gcc_conv_stat_tiles()][2][channels] fp32 */
+    void* workspace;      /* NULL, or gcc_conv_workspace() bytes: lets small-grid launches (U-Net bottleneck,
+                             1-channel PatchGAN head) split their K loop over more workgroups */
+    size_t workspace_bytes;
 } gcc_epilogue_t;
+
+/* split-K scratch a fprop (dgrad=0) / dgrad (dgrad=1) launch can use; 0 when it would not split */
+size_t gcc_conv_workspace(const gcc_conv_t* c, int dgrad);
 
 /* number of partial-statistics rows a fprop/dgrad launch writes (one per 128-pixel tile) */
 int gcc_conv_stat_tiles(const gcc_conv_t* c, int dgrad);

@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from gcc_amd import _lib
     assert ctypes.sizeof(_lib.conv_t) == 13 * 4
-    assert ctypes.sizeof(_lib.epilogue_t) == 24
+    assert ctypes.sizeof(_lib.epilogue_t) == 40
     assert ctypes.sizeof(_lib.adam_tensor_t) == 48
     assert ctypes.sizeof(_lib.adam_chunk_t) == 16
     assert ctypes.sizeof(_lib.bnact_t) == 56

@@ -57,6 +57,9 @@ CONV_CASES = [
     (1, 10, 10, 24, 40, 3, 1, 1),      # channels not a multiple of 64 / 16
     (3, 2, 2, 256, 256, 4, 2, 1),      # U-Net bottleneck 2x2 -> 1x1
     (1, 32, 32, 3, 32, 4, 2, 1),       # U-Net first layer
+    (2, 4, 4, 512, 512, 4, 2, 1),      # U-Net bottleneck, K = 8192: split-K path (fprop and dgrad)
+    (4, 12, 12, 1024, 1, 4, 1, 1),     # PatchGAN head, Cout = 1, K = 16384: split-K path
+    (16, 2, 2, 256, 384, 4, 2, 1),     # split-K with an N tail (384 = 3 x 128)
 ]
 
 
