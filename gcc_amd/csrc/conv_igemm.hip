@@ -10,6 +10,7 @@
 // MFMA operand roles are swapped (A = weights, B = pixels) so that each lane ends up holding
 // 4 consecutive output channels of one pixel; the epilogue (bias, activation, bf16 rounding,
 // optional BatchNorm partial sums) goes through LDS and leaves as coalesced 16-byte NHWC stores.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace {
@@ -61,7 +62,11 @@ struct Cfg {
     static constexpr int LDS_BYTES = LDS_BYTES_LOOP > LDS_BYTES_EPI ? LDS_BYTES_LOOP : LDS_BYTES_EPI;
 };
 
-template <int BC>
+// GLDS = true : tiles are staged global -> LDS directly (buffer_load ... lds, 1 KiB per wave-instruction,
+//               XOR swizzle applied on the per-lane SOURCE address, zero fill by the descriptor range
+//               check), one barrier per k-step: no staging VGPRs, no ds_write traffic.
+// GLDS = false: register-staged variant (kept for A/B measurement).
+template <int BC, bool GLDS, bool UT>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     using C = Cfg<BC>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -118,80 +123,113 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)wgtp, 0, p.wgt_bytes, 0x00020000);
 
     // ---- per-thread gather rows (4 pixel rows, fixed 16-B chunk column) ----------------------
-    const int chunk = tid & 7;
-    int a_base[4], a_iy[4], a_ix[4];
+    // register staging: row = (tid>>3) + 32*i, chunk = tid&7 (swizzled on the LDS write)
+    // LDS-DMA        : wave-instruction q = wave*4+i covers rows 8q..8q+7; lane -> row 8q + (lane>>3),
+    //                  physical chunk lane&7, which must hold logical chunk (lane&7) ^ (row&7)
+    const int chunk = GLDS ? ((lane & 7) ^ (lane >> 3)) : (tid & 7);
+    int a_off[4], a_iy[4], a_ix[4];      // byte offset of the row's (iy0, ix0) pixel (+ chunk), and iy0 / ix0
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int m = m0 + (tid >> 3) + 32 * i;
+        const int rloc = GLDS ? ((wave * 4 + i) * 8 + (lane >> 3)) : ((tid >> 3) + 32 * i);
+        const int m = m0 + rloc;
         if (m < M) {
             const int n = m / (Hg * Wg);
             const int r = m - n * (Hg * Wg);
             const int oy = r / Wg;
             const int ox = r - oy * Wg;
-            a_base[i] = n * p.Hs * p.Ws;
             a_iy[i] = oy * sy + dy0;
             a_ix[i] = ox * sy + dx0;
+            a_off[i] = (((n * p.Hs + a_iy[i]) * p.Ws + a_ix[i]) * p.lds_ + p.soff) * 2 + (UT ? chunk * 16 : 0);
         } else {
-            a_base[i] = 0; a_iy[i] = -(1 << 28); a_ix[i] = 0;   // always out of range -> zeros
+            a_off[i] = 0; a_iy[i] = -(1 << 28); a_ix[i] = 0;   // always out of range -> zeros
         }
     }
     // weight rows of this thread
-    int w_row[C::W_CHUNKS];
+    constexpr int WPW = BC / 32;                       // LDS-DMA weight instructions per wave (0 for BC=16: waves 0,1 issue one)
+    constexpr int W_N = GLDS ? (WPW > 0 ? WPW : 1) : C::W_CHUNKS;
+    int w_off[W_N];
+    bool w_ok[W_N];
 #pragma unroll
-    for (int i = 0; i < C::W_CHUNKS; i++) w_row[i] = (tid >> 3) + 32 * i;
+    for (int i = 0; i < W_N; i++) {
+        const int wr = GLDS ? ((wave * (WPW > 0 ? WPW : 1) + i) * 8 + (lane >> 3)) : ((tid >> 3) + 32 * i);
+        const int row = n0 + wr;
+        w_ok[i] = row < p.Cout && (GLDS || BC >= 32 || wr < BC);
+        w_off[i] = row * p.ldw * 2 + (UT ? chunk * 16 : 0);
+    }
 
-    const bool uniform_tap = (p.Ct % BK) == 0;
+    // K walk without divisions: (ta, tb) = tap coordinates, cc = channel offset inside the tap.
+    // UT (Ct % 64 == 0): one tap per k-step, wave-uniform state (scalar registers);
+    // otherwise every thread walks the tap of its own 8-channel chunk.
+    const int tap_row_bytes = p.Ws * p.lds_ * 2 * dstep;   // bytes per +1 in `ta`
+    const int tap_col_bytes = p.lds_ * 2 * dstep;          // bytes per +1 in `tb`
+    int ta, tb, cc;
+    {
+        const int k0 = kbeg * BK + (UT ? 0 : chunk * 8);
+        const int tap0 = k0 / p.Ct;
+        cc = k0 - tap0 * p.Ct;
+        ta = tap0 / TB;
+        tb = tap0 - ta * TB;
+    }
 
-    i32x4 ra[4];
-    i32x4 rw[C::W_CHUNKS];
+    i32x4 ra[GLDS ? 1 : 4];
+    i32x4 rw[GLDS ? 1 : C::W_CHUNKS];
 
-    auto issue_loads = [&](int kt_local) {
-        const int kt = kbeg + kt_local;
-        const int k = kt * BK + chunk * 8;
-        int tap, cc;
-        if (uniform_tap) {
-            const int kb = kt * BK;
-            tap = kb / p.Ct;               // wave-uniform
-            cc = kb - tap * p.Ct + chunk * 8;
-        } else {
-            tap = k / p.Ct;
-            cc = k - tap * p.Ct;
-        }
-        const bool kval = k < Ktot;
-        const int a = tap / TB;
-        const int b = tap - a * TB;
-        const int dy = a * dstep;
-        const int dx = b * dstep;
+    // issue the global loads of the next k-step (in order); GLDS: straight into LDS stage `stage`
+    auto issue_loads = [&](int stage) {
+        const bool kval = ta < TA;
+        const int dyo = ta * dstep, dxo = tb * dstep;
+        const int pix_off = ta * tap_row_bytes + tb * tap_col_bytes + cc * 2;
+        const int wt_off = (((kh0 + ta * kstep) * p.KW + (kw0 + tb * kstep)) * p.Ct + cc) * 2;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int iy = a_iy[i] + dy;
-            const int ix = a_ix[i] + dx;
-            const bool ok = kval && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
-            const uint32_t off = ok ? (uint32_t)(((a_base[i] + iy * p.Ws + ix) * p.lds_ + p.soff + cc) * 2) : OOB;
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0);
+            const bool ok = kval && (unsigned)(a_iy[i] + dyo) < (unsigned)p.Hs && (unsigned)(a_ix[i] + dxo) < (unsigned)p.Ws;
+            const uint32_t off = ok ? (uint32_t)(a_off[i] + pix_off) : OOB;
+            if constexpr (GLDS) {
+                char* dst = sA + stage * (BP * BK * 2) + (wave * 4 + i) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, LDS_PTR(void, dst), 16, off, 0, 0, 0);
+            } else {
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0);
+            }
         }
-        const int wtap = (kh0 + a * kstep) * p.KW + (kw0 + b * kstep);
+        if constexpr (GLDS) {
+            if (WPW > 0 || wave < 2) {       // wave-uniform
 #pragma unroll
-        for (int i = 0; i < C::W_CHUNKS; i++) {
-            const int row = n0 + w_row[i];
-            const bool ok = kval && row < p.Cout && (BC >= 32 || w_row[i] < BC);
-            const uint32_t off = ok ? (uint32_t)((row * p.ldw + wtap * p.Ct + cc) * 2) : OOB;
-            rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wgt, off, 0, 0);
+                for (int i = 0; i < W_N; i++) {
+                    const uint32_t off = (kval && w_ok[i]) ? (uint32_t)(w_off[i] + wt_off) : OOB;
+                    char* dst = sW + stage * (BC * BK * 2) + (wave * (WPW > 0 ? WPW : 1) + i) * 1024;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, LDS_PTR(void, dst), 16, off, 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < C::W_CHUNKS; i++) {
+                const uint32_t off = (kval && w_ok[i]) ? (uint32_t)(w_off[i] + wt_off) : OOB;
+                rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wgt, off, 0, 0);
+            }
+        }
+        // advance to the next k-step
+        cc += BK;
+        if constexpr (UT) {
+            if (cc == p.Ct) { cc = 0; if (++tb == TB) { tb = 0; ++ta; } }
+        } else {
+            while (cc >= p.Ct) { cc -= p.Ct; if (++tb == TB) { tb = 0; ++ta; } }
         }
     };
 
     auto write_lds = [&](int stage) {
-        char* a = sA + stage * (BP * BK * 2);
-        char* w = sW + stage * (BC * BK * 2);
+        if constexpr (!GLDS) {
+            char* a = sA + stage * (BP * BK * 2);
+            char* w = sW + stage * (BC * BK * 2);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int row = (tid >> 3) + 32 * i;
-            *(i32x4*)(a + row * 128 + ((chunk ^ (row & 7)) << 4)) = ra[i];
-        }
+            for (int i = 0; i < 4; i++) {
+                const int row = (tid >> 3) + 32 * i;
+                *(i32x4*)(a + row * 128 + ((chunk ^ (row & 7)) << 4)) = ra[i];
+            }
 #pragma unroll
-        for (int i = 0; i < C::W_CHUNKS; i++) {
-            const int row = w_row[i];
-            if (BC >= 32 || row < BC) *(i32x4*)(w + row * 128 + ((chunk ^ (row & 7)) << 4)) = rw[i];
+            for (int i = 0; i < C::W_CHUNKS; i++) {
+                const int row = (tid >> 3) + 32 * i;
+                if (BC >= 32 || row < BC) *(i32x4*)(w + row * 128 + ((chunk ^ (row & 7)) << 4)) = rw[i];
+            }
         }
     };
 
@@ -201,20 +239,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < C::PB; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- pipeline: registers hold tile t+1 while LDS[t&1] is consumed --------------------------
-    issue_loads(0);
-    write_lds(0);
-    if (nk > 1) issue_loads(1);
-    __syncthreads();
-
     const int lr = lane & 15;
     const int lq = lane >> 4;
-    for (int kt = 0; kt < nk; kt++) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            write_lds(cur ^ 1);                 // tile kt+1 (its loads were issued one step ago)
-            if (kt + 2 < nk) issue_loads(kt + 2);
-        }
+    auto compute = [&](int cur) {
         const char* a = sA + cur * (BP * BK * 2);
         const char* w = sW + cur * (BC * BK * 2);
 #pragma unroll
@@ -236,7 +263,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                 for (int j = 0; j < C::PB; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
         }
+    };
+
+    if constexpr (GLDS) {
+        // one barrier per k-step: [tile kt landed for every wave AND everyone left tile kt-1] ->
+        // issue tile kt+1 into the buffer tile kt-1 occupied -> compute tile kt while it flies
+        issue_loads(0);
+        for (int kt = 0; kt < nk; kt++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk) issue_loads((kt + 1) & 1);
+            compute(kt & 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    } else {
+        // registers hold tile t+1 while LDS[t&1] is consumed
+        issue_loads(0);
+        write_lds(0);
+        if (nk > 1) issue_loads(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt++) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) {
+                write_lds(cur ^ 1);                 // tile kt+1 (its loads were issued one step ago)
+                if (kt + 2 < nk) issue_loads(0);
+            }
+            compute(cur);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
@@ -401,16 +456,33 @@ static SplitPlan plan_ksplit(long blocks, int nk) {
     return sp;
 }
 
+static int g_use_glds = -1;
+static bool use_glds() {
+    if (g_use_glds < 0) {
+        const char* e = getenv("GCC_IGEMM_GLDS");
+        g_use_glds = e ? (atoi(e) != 0) : 1;
+    }
+    return g_use_glds != 0;
+}
+
 template <int BC>
 int launch(const IgemmParams& p, int phases, int batch, hipStream_t st) {
     using C = Cfg<BC>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)igemm_kernel<BC>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipFuncSetAttribute((const void*)igemm_kernel<BC, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipFuncSetAttribute((const void*)igemm_kernel<BC, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipFuncSetAttribute((const void*)igemm_kernel<BC, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_set = true;
     }
     dim3 grid(p.mtiles_max * p.ntiles, p.ksplit > 1 ? p.ksplit : batch, phases);
-    hipLaunchKernelGGL(igemm_kernel<BC>, grid, dim3(256), C::LDS_BYTES, st, p);
+    const bool ut = (p.Ct % BK) == 0;
+    if (!use_glds())
+        hipLaunchKernelGGL((igemm_kernel<BC, false, false>), grid, dim3(256), C::LDS_BYTES, st, p);
+    else if (ut)
+        hipLaunchKernelGGL((igemm_kernel<BC, true, true>), grid, dim3(256), C::LDS_BYTES, st, p);
+    else
+        hipLaunchKernelGGL((igemm_kernel<BC, true, false>), grid, dim3(256), C::LDS_BYTES, st, p);
     GCC_CHECK_LAUNCH();
     if (p.ksplit > 1) {
         const size_t total = (size_t)p.rows_max * (ceil8(p.Cout) / 8);

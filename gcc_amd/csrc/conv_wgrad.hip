@@ -191,21 +191,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
-// regular widths (Ci % 8 == 0: slab layout == dW layout): 16-byte fold
-__global__ void wgrad_reduce_vec_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splits, size_t n4,
-                                        int accumulate) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        f32x4 s = ((const f32x4*)slabs)[i];
-        for (int z = 1; z < splits; z++) {
-            const f32x4 v = ((const f32x4*)slabs)[(size_t)z * n4 + i];
-            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+// regular widths (Ci % 8 == 0: slab layout == dW layout): 16-byte fold.  256 threads = 64 outputs
+// (float4) x 4 split lanes, so that layers with a small dW and hundreds of pixel splits (first
+// layers: 262144 pixels) still spread over many workgroups and short dependent chains.
+__global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                               int splits, size_t n4, int accumulate) {
+    __shared__ f32x4 sh[4][64];
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    for (size_t base = (size_t)blockIdx.x * 64; base < n4; base += (size_t)gridDim.x * 64) {
+        const size_t i = base + o;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (i < n4) {
+            for (int z = sl; z < splits; z += 4) {
+                const f32x4 v = ((const f32x4*)slabs)[(size_t)z * n4 + i];
+                s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+            }
         }
-        if (accumulate) { const f32x4 o = ((const f32x4*)dw)[i]; s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3]; }
-        ((f32x4*)dw)[i] = s;
+        sh[sl][o] = s;
+        __syncthreads();
+        if (sl == 0 && i < n4) {
+            for (int q = 1; q < 4; q++) { const f32x4 v = sh[q][o]; s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3]; }
+            if (accumulate) { const f32x4 ov = ((const f32x4*)dw)[i]; s[0] += ov[0]; s[1] += ov[1]; s[2] += ov[2]; s[3] += ov[3]; }
+            ((f32x4*)dw)[i] = s;
+        }
+        __syncthreads();
     }
 }
 
-// dW[co][tap][ci] (+)= sum_z slab[z][co][tap][cip]
+// irregular widths: dW[co][tap][ci] (+)= sum_z slab[z][co][tap][cip]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splits, int Co,
                                     int taps, int Ci, int Cip, int accumulate) {
     const size_t total = (size_t)Co * taps * Ci;
@@ -291,8 +304,8 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
     const size_t total = (size_t)batch * c->Co * c->KH * c->KW * c->Ci;
     if (regular) {
         const size_t n4 = total / 4;
-        int blocks = (int)((n4 + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
+        int blocks = (int)((n4 + 63) / 64);
+        if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits, n4,
                            accumulate);
     } else {

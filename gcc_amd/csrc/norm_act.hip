@@ -376,9 +376,9 @@ extern "C" int gcc_bnact_fwd(const gcc_bnact_t* p, const void* x, int ldx, int x
 }
 
 static int bwd_blocks(size_t pixels, const Layout& L) {
-    size_t b = (pixels + (size_t)L.PPB * 16 - 1) / ((size_t)L.PPB * 16);
+    size_t b = (pixels + (size_t)L.PPB * 4 - 1) / ((size_t)L.PPB * 4);
     if (b < 1) b = 1;
-    if (b > 1024) b = 1024;
+    if (b > 2048) b = 2048;
     return (int)b;
 }
 

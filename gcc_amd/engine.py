@@ -17,6 +17,8 @@ from . import ops
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH
 
 LRELU = 0.2
+# run weight-gradient kernels on a side stream, concurrently with the data-gradient / BN chain
+OVERLAP_WGRAD = True
 
 
 # ------------------------------------------------------------------------------------------------
@@ -99,6 +101,15 @@ class ConvOp:
 
     # -- gradient w.r.t. the weight (accumulates into weight.grad) and bias -------------------------
     def backward_weight(self, x, dy):
+        if OVERLAP_WGRAD:
+            side = ops.SideStream.get(x.device)
+            side.fork()
+            with torch.cuda.stream(side.stream):
+                self._backward_weight(x, dy)
+        else:
+            self._backward_weight(x, dy)
+
+    def _backward_weight(self, x, dy):
         if not self.transposed:
             ops.conv_wgrad(x, dy, self.weight.grad, self.k, self.stride, self.pad, accumulate=True)
         else:
@@ -312,6 +323,7 @@ class UnetEngine:
                 self.down[d].backward_weight(c.lin[d] if d > 0 else c.x_in, c.g_e[d])
             if d > 0:
                 self.down[d].backward_data(c.g_e[d], c.g_lin[d])
+        ops.SideStream.get(self.device).join()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -466,7 +478,9 @@ class PatchGANEngine:
                       dalpha=gate.alpha.grad if (agrad and gate is not None) else None)
         if wgrad:
             self.conv[0].backward_weight(c.x_in, G.layer[0])
+        dx = None
         if need_dx:
             self.conv[0].backward_data(G.layer[0], G.x_in)
-            return G.x_in
-        return None
+            dx = G.x_in
+        ops.SideStream.get(self.device).join()
+        return dx

@@ -361,6 +361,7 @@ class Pix2PixModel(nn.Module):
                 gbuf = self._tbuf(10 + i, N, feats[i].shape[1], feats[i].shape[2], feats[i].shape[3])[0]
                 self.T[i].backward_data(dtf[i], gbuf)
                 g_feat.append(gbuf)
+            ops.SideStream.get(self.device).join()
             dx2 = T.D.backward(ct, has_pred_grad=False, g_feat=[dtf[4], dtf[5]], wgrad=False, need_dx=True)
             ops.nhwc_add(dx2, 3, gc.g_out, 0, 3)
         self.G.backward(gc, g_feat=g_feat, wgrad=True)

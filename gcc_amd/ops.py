@@ -88,6 +88,38 @@ def workspace(nbytes, device, slot='default'):
     return buf
 
 
+class SideStream:
+    """A second HIP stream per device: MFMA-bound weight-gradient kernels run on it while the
+    HBM-bound BatchNorm / activation backward chain continues on the main stream."""
+    _inst = {}
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.dirty = False
+
+    @classmethod
+    def get(cls, device):
+        key = str(device)
+        if key not in cls._inst:
+            cls._inst[key] = SideStream(device)
+        return cls._inst[key]
+
+    def fork(self):
+        """everything enqueued on the main stream so far happens-before later side-stream work"""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.stream.wait_event(ev)
+        self.dirty = True
+
+    def join(self):
+        """the main stream waits for all side-stream work enqueued so far"""
+        if self.dirty:
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            torch.cuda.current_stream().wait_event(ev)
+            self.dirty = False
+
+
 def new_act(N, Cc, H, W, device, ld=None):
     """Zero-initialised NHWC bf16 activation [N, Cc, H, W] with pixel stride ld >= ceil8(Cc)."""
     ld = ld or ceil8(Cc)
@@ -302,7 +334,7 @@ def bnact_bwd(x, y, g1, dx, g2=None, bn=None, gamma=None, beta=None, bn_eval=Fal
 def channel_sum(x, out, accumulate=False):
     xp, N, Cc, H, W, ld = geom(x)
     need = lib().gcc_channel_sum_workspace(Cc, N * H * W)
-    ws = workspace(need, x.device, 'bnbwd')
+    ws = workspace(need, x.device, 'chansum')
     check(lib().gcc_channel_sum(xp, ld, 0, Cc, N * H * W, out.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel(),
                                 stream()), 'gcc_channel_sum')
 
