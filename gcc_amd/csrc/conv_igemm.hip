@@ -13,7 +13,9 @@
 #include <stdlib.h>
 #include "common.hpp"
 
-namespace {
+// named (not anonymous) namespace: hipcc fails to emit the host stub of a kernel template with internal
+// linkage whose body holds lambdas inside an `if constexpr` branch
+namespace gcc_igemm {
 
 struct IgemmParams {
     const bf16_t* src;   // gather source (x for fprop, dy for dgrad)
@@ -43,22 +45,29 @@ struct IgemmParams {
     int rows_max, Cpad;
 };
 
-constexpr int BP = 128;  // pixels per tile
 constexpr int BK = 64;   // k per step
 constexpr uint32_t OOB = 0x7FFFFFF0u;
 
-template <int BC>
+// BP pixels x BC channels per workgroup.  BP = 128: 4 waves (2 workgroups per CU); BP = 256: 8 waves,
+// one workgroup per CU -- the big tiles halve the L2 -> LDS traffic per MFMA (128x128x64 needs 64 FLOP/B,
+// i.e. ~39 TB/s of L2 bandwidth at the 2.5 PF peak, more than the 8 L2s deliver; 256x256 needs half).
+template <int BP, int BC>
 struct Cfg {
+    static constexpr int WAVES = BP / 32;                  // 4 or 8
+    static constexpr int NT = WAVES * 64;
     static constexpr int WC = (BC >= 128) ? 2 : 1;        // waves along channels
-    static constexpr int WP = 4 / WC;                      // waves along pixels
+    static constexpr int WP = WAVES / WC;                  // waves along pixels
     static constexpr int TC = BC / WC;                     // channels per wave
     static constexpr int TP = BP / WP;                     // pixels per wave
     static constexpr int CB = TC / 16;
     static constexpr int PB = TP / 16;
-    static constexpr int W_CHUNKS = (BC * 8 + 255) / 256;  // 16-B weight chunks per thread per step
+    static constexpr int WI = BC / 8;                      // 1-KiB weight staging instructions per k-step
+    static constexpr int WPW = WI / WAVES;                 // ... per wave (0: the first WI waves issue one)
+    static constexpr int WN_GLDS = WPW > 0 ? WPW : 1;      // weight staging instructions a wave issues per k-step
+    static constexpr int W_CHUNKS = (BC * 8 + NT - 1) / NT;  // register path: 16-B weight chunks per thread
     static constexpr int LDS_BYTES_LOOP = 2 * (BP + BC) * BK * 2;
     static constexpr int OSTRIDE = BC * 2 + 16;            // epilogue tile row stride (bytes)
-    static constexpr int LDS_BYTES_EPI = BP * OSTRIDE + 2 * 256 * 4;
+    static constexpr int LDS_BYTES_EPI = BP * OSTRIDE + 2 * NT * 4;
     static constexpr int LDS_BYTES = LDS_BYTES_LOOP > LDS_BYTES_EPI ? LDS_BYTES_LOOP : LDS_BYTES_EPI;
 };
 
@@ -66,16 +75,18 @@ struct Cfg {
 //               XOR swizzle applied on the per-lane SOURCE address, zero fill by the descriptor range
 //               check), one barrier per k-step: no staging VGPRs, no ds_write traffic.
 // GLDS = false: register-staged variant (kept for A/B measurement).
-template <int BC, bool GLDS, bool UT>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
-    using C = Cfg<BC>;
+template <int BP, int BC, bool GLDS, bool UT>
+__global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams p) {
+    using C = Cfg<BP, BC>;
+    static_assert(GLDS || BP == 128, "register staging is only kept for the 128-pixel tile");
+    constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;                          // pixels  [2][BP][128 B]
     char* sW = smem + 2 * BP * BK * 2;        // weights [2][BC][128 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA bases stay scalar
     const int wc = wave % C::WC;
     const int wp = wave / C::WC;
 
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         }
     }
     // weight rows of this thread
-    constexpr int WPW = BC / 32;                       // LDS-DMA weight instructions per wave (0 for BC=16: waves 0,1 issue one)
+    constexpr int WPW = C::WPW;                        // LDS-DMA weight instructions per wave (0: waves < WI issue one)
     constexpr int W_N = GLDS ? (WPW > 0 ? WPW : 1) : C::W_CHUNKS;
     int w_off[W_N];
     bool w_ok[W_N];
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             }
         }
         if constexpr (GLDS) {
-            if (WPW > 0 || wave < 2) {       // wave-uniform
+            if (WPW > 0 || wave < C::WI) {       // wave-uniform
 #pragma unroll
                 for (int i = 0; i < W_N; i++) {
                     const uint32_t off = (kval && w_ok[i]) ? (uint32_t)(w_off[i] + wt_off) : OOB;
@@ -265,7 +276,64 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         }
     };
 
-    if constexpr (GLDS) {
+    if constexpr (GLDS && UT) {
+        // Uniform-tap fast path: a tap spans Ct/64 consecutive k-steps, so the per-row source offsets
+        // (bounds checks included) are computed once per tap and then just advance by 128 bytes per
+        // k-step; the loop body is 8 LDS-DMA + 8 adds + 16 ds_read + 32 MFMA per wave.
+        static_assert(C::WN_GLDS <= 4, "weight staging instructions per wave");
+        uint32_t cur_a[4], cur_w[4];   // literal bound on purpose: with a template-dependent bound hipcc (ROCm 7.2)
+                                       // silently drops the host stub of this instantiation
+        int left;                                  // k-steps left in the current tap (scalar)
+        auto load_tap = [&]() {
+            const bool kval = ta < TA;
+            const int dyo = ta * dstep, dxo = tb * dstep;
+            const int pix_off = ta * tap_row_bytes + tb * tap_col_bytes + cc * 2;
+            const int wt_off = (((kh0 + ta * kstep) * p.KW + (kw0 + tb * kstep)) * p.Ct + cc) * 2;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bool ok = kval && (unsigned)(a_iy[i] + dyo) < (unsigned)p.Hs && (unsigned)(a_ix[i] + dxo) < (unsigned)p.Ws;
+                cur_a[i] = ok ? (uint32_t)(a_off[i] + pix_off) : OOB;
+            }
+#pragma unroll
+            for (int i = 0; i < W_N; i++) cur_w[i] = (kval && w_ok[i]) ? (uint32_t)(w_off[i] + wt_off) : OOB;
+            left = (p.Ct - cc) / BK;
+        };
+        auto issue = [&](int stage) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                char* dst = sA + stage * (BP * BK * 2) + (wave * 4 + i) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, LDS_PTR(void, dst), 16, cur_a[i], 0, 0, 0);
+                cur_a[i] += BK * 2;
+            }
+            if (WPW > 0 || wave < C::WI) {
+#pragma unroll
+                for (int i = 0; i < W_N; i++) {
+                    char* dst = sW + stage * (BC * BK * 2) + (wave * (WPW > 0 ? WPW : 1) + i) * 1024;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, LDS_PTR(void, dst), 16, cur_w[i], 0, 0, 0);
+                    cur_w[i] += BK * 2;
+                }
+            }
+        };
+        auto next_step = [&]() {
+            if (--left == 0) {                      // wave-uniform, once per tap
+                cc = 0;
+                if (++tb == TB) { tb = 0; ++ta; }
+                load_tap();
+            }
+        };
+        load_tap();
+        issue(0);
+        next_step();
+        for (int kt = 0; kt < nk; kt++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            issue((kt + 1) & 1);                    // past the end of K the offsets are out of range: zero fill, unused
+            next_step();                            // (rare) tap change: its VALU work hides under the MFMAs below
+            compute(kt & 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else if constexpr (GLDS) {
         // one barrier per k-step: [tile kt landed for every wave AND everyone left tile kt-1] ->
         // issue tile kt+1 into the buffer tile kt-1 occupied -> compute tile kt while it flies
         issue_loads(0);
@@ -338,7 +406,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int CPR = BC / 8;                 // chunks per pixel row
     constexpr int NCH = BP * CPR;
     const int cend = ceil8(p.Cout);
-    for (int q = tid; q < NCH; q += 256) {
+    for (int q = tid; q < NCH; q += NT) {
         const int row = q / CPR;
         const int cch = q - row * CPR;
         const int m = m0 + row;
@@ -356,23 +424,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     // BatchNorm partial statistics of the rounded outputs (rows >= M are exact zeros)
     if (p.stats) {
         float* sR = (float*)(smem + BP * C::OSTRIDE);
-        constexpr int PARTS = 256 / BC < 1 ? 1 : 256 / BC;
+        constexpr int PARTS = NT / BC;
         constexpr int ROWS = BP / PARTS;
         const int c = tid % BC;
         const int part = tid / BC;
         float s = 0.f, ss = 0.f;
-        if (BC >= 256 || part < PARTS) {
+        if (part < PARTS) {
             for (int r = part * ROWS; r < (part + 1) * ROWS; r++) {
                 const float v = bf2f(*(const bf16_t*)(sO + r * C::OSTRIDE + c * 2));
                 s += v; ss += v * v;
             }
         }
-        sR[tid] = s; sR[256 + tid] = ss;
+        sR[tid] = s; sR[NT + tid] = ss;
         __syncthreads();
         if (tid < BC && n0 + tid < p.Cout) {
             float ts = 0.f, tss = 0.f;
 #pragma unroll
-            for (int q = 0; q < PARTS; q++) { ts += sR[q * BC + tid]; tss += sR[256 + q * BC + tid]; }
+            for (int q = 0; q < PARTS; q++) { ts += sR[q * BC + tid]; tss += sR[NT + q * BC + tid]; }
             const int trow = blockIdx.z * p.mtiles_max + mt;
             p.stats[((size_t)trow * 2 + 0) * p.Cout + n0 + tid] = ts;
             p.stats[((size_t)trow * 2 + 1) * p.Cout + n0 + tid] = tss;
@@ -465,24 +533,32 @@ static bool use_glds() {
     return g_use_glds != 0;
 }
 
-template <int BC>
+template <int BP, int BC>
 int launch(const IgemmParams& p, int phases, int batch, hipStream_t st) {
-    using C = Cfg<BC>;
+    using C = Cfg<BP, BC>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)igemm_kernel<BC, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        hipFuncSetAttribute((const void*)igemm_kernel<BC, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        hipFuncSetAttribute((const void*)igemm_kernel<BC, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipFuncSetAttribute((const void*)igemm_kernel<BP, BC, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipFuncSetAttribute((const void*)igemm_kernel<BP, BC, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if constexpr (BP == 128)
+            hipFuncSetAttribute((const void*)igemm_kernel<BP, BC, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_set = true;
     }
     dim3 grid(p.mtiles_max * p.ntiles, p.ksplit > 1 ? p.ksplit : batch, phases);
     const bool ut = (p.Ct % BK) == 0;
-    if (!use_glds())
-        hipLaunchKernelGGL((igemm_kernel<BC, false, false>), grid, dim3(256), C::LDS_BYTES, st, p);
-    else if (ut)
-        hipLaunchKernelGGL((igemm_kernel<BC, true, true>), grid, dim3(256), C::LDS_BYTES, st, p);
-    else
-        hipLaunchKernelGGL((igemm_kernel<BC, true, false>), grid, dim3(256), C::LDS_BYTES, st, p);
+    bool launched = false;
+    if constexpr (BP == 128) {
+        if (!use_glds()) {
+            hipLaunchKernelGGL((igemm_kernel<BP, BC, false, false>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
+            launched = true;
+        }
+    }
+    if (!launched) {
+        if (ut)
+            hipLaunchKernelGGL((igemm_kernel<BP, BC, true, true>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
+        else
+            hipLaunchKernelGGL((igemm_kernel<BP, BC, true, false>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
+    }
     GCC_CHECK_LAUNCH();
     if (p.ksplit > 1) {
         const size_t total = (size_t)p.rows_max * (ceil8(p.Cout) / 8);
@@ -492,6 +568,44 @@ int launch(const IgemmParams& p, int phases, int batch, hipStream_t st) {
         GCC_CHECK_LAUNCH();
     }
     return GCC_OK;
+}
+
+// Tile choice (shared by the launcher, gcc_conv_stat_tiles and gcc_conv_workspace).
+struct TilePlan { int BP, BC, ntiles, mtiles; };
+static int g_big_tiles = -1, g_big_min = 200;
+static TilePlan select_tile(size_t max_rows, int Cout, int phases, int nk, int batch) {
+    TilePlan t;
+    t.BP = 128;
+    if (Cout > 64) { t.BC = 128; t.ntiles = cdiv(Cout, 128); }
+    else if (Cout > 32) { t.BC = 64; t.ntiles = 1; }
+    else if (Cout > 16) { t.BC = 32; t.ntiles = 1; }
+    else { t.BC = 16; t.ntiles = 1; }
+    if (g_big_tiles < 0) {
+        const char* e = getenv("GCC_IGEMM_BIG");
+        g_big_tiles = e ? atoi(e) : 2;
+        const char* m = getenv("GCC_IGEMM_BIG_MIN");      // test hook: minimum number of 256-pixel tiles
+        if (m) g_big_min = atoi(m);
+    }
+    // 256-pixel tiles (one 8-wave workgroup per CU) when they still fill the chip and the K loop is
+    // long enough to amortise the un-overlapped prologue / epilogue of a lone workgroup
+    if (g_big_tiles && use_glds() && batch == 1 && Cout >= 128 && nk >= 24) {
+        const long m256 = (long)((max_rows + 255) / 256);
+        if (g_big_tiles >= 2 && Cout % 256 == 0 && m256 * (Cout / 256) * phases >= g_big_min) {
+            t.BP = 256; t.BC = 256; t.ntiles = Cout / 256;
+        } else if (m256 * cdiv(Cout, 128) * phases >= g_big_min) {
+            t.BP = 256; t.BC = 128; t.ntiles = cdiv(Cout, 128);
+        }
+    }
+    t.mtiles = (int)((max_rows + t.BP - 1) / t.BP);
+    return t;
+}
+static int conv_nk(const gcc_conv_t* c, int dgrad) {
+    const int taps_max = dgrad ? cdiv(c->KH, c->stride) * cdiv(c->KW, c->stride) : c->KH * c->KW;
+    return cdiv(taps_max * ceil8(dgrad ? c->Co : c->Ci), BK);
+}
+static size_t conv_max_rows(const gcc_conv_t* c, int dgrad) {
+    if (!dgrad) return (size_t)c->N * gcc_conv_out(c->H, c->KH, c->stride, c->pad) * gcc_conv_out(c->W, c->KW, c->stride, c->pad);
+    return (size_t)c->N * cdiv(c->H, c->stride) * cdiv(c->W, c->stride);
 }
 
 int check_conv(const gcc_conv_t* c) {
@@ -506,7 +620,8 @@ int check_conv(const gcc_conv_t* c) {
     return GCC_OK;
 }
 
-}  // namespace
+}  // namespace gcc_igemm
+using namespace gcc_igemm;
 
 // internal entry (also used by distill.hip): `batch` independent problems, strides in elements
 int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const void* w, void* dst, const gcc_epilogue_t* ep,
@@ -545,34 +660,34 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
     const size_t db = (size_t)p.N * p.Hd * p.Wd * p.ldd * 2;
     if (sb >= OOB || wb >= OOB || db >= (size_t)1 << 32) return GCC_ERR_UNSUPPORTED;
     p.src_bytes = (uint32_t)sb; p.wgt_bytes = (uint32_t)wb;
-    p.mtiles_max = (int)((max_rows + BP - 1) / BP);
     p.src_bstride = src_bstride; p.wgt_bstride = wgt_bstride; p.dst_bstride = dst_bstride;
     if (batch < 1 || (batch > 1 && p.stats)) return GCC_ERR_BAD_ARG;
     const int phases = dgrad ? c->stride * c->stride : 1;
     if (dgrad && (c->KH < c->stride || c->KW < c->stride)) return GCC_ERR_UNSUPPORTED;
-    int BC;
-    if (p.Cout > 64) { BC = 128; p.ntiles = cdiv(p.Cout, 128); }
-    else if (p.Cout > 32) { BC = 64; p.ntiles = 1; }
-    else if (p.Cout > 16) { BC = 32; p.ntiles = 1; }
-    else { BC = 16; p.ntiles = 1; }
+    const TilePlan tp = select_tile(max_rows, p.Cout, phases, conv_nk(c, dgrad), batch);
+    const int BC = tp.BC;
+    p.ntiles = tp.ntiles;
+    p.mtiles_max = tp.mtiles;
     // ---- split-K decision (needs caller workspace; without it the launch simply is not split) ------
     p.ksplit = 1; p.kper = 0; p.partial = nullptr; p.rows_max = (int)max_rows; p.Cpad = p.ntiles * BC;
     float* stats_out = p.stats;
-    if (batch == 1 && ep && ep->workspace) {
-        const int taps_max = dgrad ? cdiv(c->KH, c->stride) * cdiv(c->KW, c->stride) : c->KH * c->KW;
-        const int nk = cdiv(taps_max * p.Ct, BK);
-        const SplitPlan sp = plan_ksplit((long)p.mtiles_max * p.ntiles * phases, nk);
+    if (batch == 1 && tp.BP == 128 && ep && ep->workspace) {
+        const SplitPlan sp = plan_ksplit((long)p.mtiles_max * p.ntiles * phases, conv_nk(c, dgrad));
         const size_t need = (size_t)phases * sp.ksplit * max_rows * p.Cpad * sizeof(float);
         if (sp.ksplit > 1 && need <= ep->workspace_bytes && (((uintptr_t)ep->workspace) & 15) == 0) {
             p.ksplit = sp.ksplit; p.kper = sp.kper; p.partial = (float*)ep->workspace;
             p.stats = nullptr;       // statistics are taken from the finished tensor below
         }
     }
-    switch (BC) {
-        case 128: rc = launch<128>(p, phases, batch, st); break;
-        case 64: rc = launch<64>(p, phases, batch, st); break;
-        case 32: rc = launch<32>(p, phases, batch, st); break;
-        default: rc = launch<16>(p, phases, batch, st); break;
+    if (tp.BP == 256) {
+        rc = BC == 256 ? launch<256, 256>(p, phases, batch, st) : launch<256, 128>(p, phases, batch, st);
+    } else {
+        switch (BC) {
+            case 128: rc = launch<128, 128>(p, phases, batch, st); break;
+            case 64: rc = launch<128, 64>(p, phases, batch, st); break;
+            case 32: rc = launch<128, 32>(p, phases, batch, st); break;
+            default: rc = launch<128, 16>(p, phases, batch, st); break;
+        }
     }
     if (rc) return rc;
     if (p.ksplit > 1 && stats_out) {
@@ -590,27 +705,22 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
 
 extern "C" size_t gcc_conv_workspace(const gcc_conv_t* c, int dgrad) {
     if (check_conv(c)) return 0;
-    const int Ho = gcc_conv_out(c->H, c->KH, c->stride, c->pad), Wo = gcc_conv_out(c->W, c->KW, c->stride, c->pad);
     const int phases = dgrad ? c->stride * c->stride : 1;
-    const size_t max_rows = dgrad ? (size_t)c->N * cdiv(c->H, c->stride) * cdiv(c->W, c->stride) : (size_t)c->N * Ho * Wo;
-    const int Cout = dgrad ? c->Ci : c->Co, Ct = ceil8(dgrad ? c->Co : c->Ci);
-    int BC, ntiles = 1;
-    if (Cout > 64) { BC = 128; ntiles = cdiv(Cout, 128); } else if (Cout > 32) BC = 64; else if (Cout > 16) BC = 32; else BC = 16;
-    const int taps_max = dgrad ? cdiv(c->KH, c->stride) * cdiv(c->KW, c->stride) : c->KH * c->KW;
-    const SplitPlan sp = plan_ksplit((long)((max_rows + BP - 1) / BP) * ntiles * phases, cdiv(taps_max * Ct, BK));
+    const size_t max_rows = conv_max_rows(c, dgrad);
+    const int nk = conv_nk(c, dgrad);
+    const TilePlan tp = select_tile(max_rows, dgrad ? c->Ci : c->Co, phases, nk, 1);
+    if (tp.BP != 128) return 0;
+    const SplitPlan sp = plan_ksplit((long)tp.mtiles * tp.ntiles * phases, nk);
     if (sp.ksplit <= 1) return 0;
-    return (size_t)phases * sp.ksplit * max_rows * ntiles * BC * sizeof(float);
+    return (size_t)phases * sp.ksplit * max_rows * tp.ntiles * tp.BC * sizeof(float);
 }
 
 extern "C" int gcc_conv_stat_tiles(const gcc_conv_t* c, int dgrad) {
     GCC_ENTER();
     if (check_conv(c)) return 0;
-    if (!dgrad) {
-        const int Ho = gcc_conv_out(c->H, c->KH, c->stride, c->pad), Wo = gcc_conv_out(c->W, c->KW, c->stride, c->pad);
-        return (int)(((size_t)c->N * Ho * Wo + BP - 1) / BP);
-    }
-    const int s = c->stride;
-    return (int)(((size_t)c->N * cdiv(c->H, s) * cdiv(c->W, s) + BP - 1) / BP) * s * s;
+    const int phases = dgrad ? c->stride * c->stride : 1;
+    const TilePlan tp = select_tile(conv_max_rows(c, dgrad), dgrad ? c->Ci : c->Co, phases, conv_nk(c, dgrad), 1);
+    return tp.mtiles * phases;
 }
 
 extern "C" int gcc_conv_fprop(const gcc_conv_t* c, const void* x, const void* w, void* y,

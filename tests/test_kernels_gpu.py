@@ -60,6 +60,9 @@ CONV_CASES = [
     (2, 4, 4, 512, 512, 4, 2, 1),      # U-Net bottleneck, K = 8192: split-K path (fprop and dgrad)
     (4, 12, 12, 1024, 1, 4, 1, 1),     # PatchGAN head, Cout = 1, K = 16384: split-K path
     (16, 2, 2, 256, 384, 4, 2, 1),     # split-K with an N tail (384 = 3 x 128)
+    (2, 32, 32, 128, 128, 4, 2, 1),    # 256x128 tile candidates (forced by GCC_IGEMM_BIG_MIN=1 in the second test pass)
+    (2, 16, 16, 256, 384, 4, 1, 1),    # 256-pixel tiles with M and N tails, fprop and dgrad
+    (3, 20, 20, 128, 512, 4, 2, 1),    # 256x256 tiles (GCC_IGEMM_BIG=2), ragged M
 ]
 
 
