@@ -12,8 +12,8 @@ teacher ngf 64 / ndf 128, hinge GAN loss, lambda_L1 100, content 50, gram 1e4, b
 Inputs are resident in HBM before the timed region.  One JSON line is printed by rank 0.
 
 roofline: the dominant kernel is the implicit-GEMM convolution (igemm_kernel, conv fprop / dgrad /
-ConvTranspose).  Every launch of it inside the timed region is bracketed by HIP events on the
-launch stream; achieved = sum of algorithmic FLOPs (2*M*Cout*taps*Cin, padding excluded) / sum of
+ConvTranspose).  Every launch of it inside the first 3 steps of the timed region is bracketed by HIP
+events on the launch stream (bracketing all steps costs ~6% throughput); achieved = sum of algorithmic FLOPs (2*M*Cout*taps*Cin, padding excluded) / sum of
 measured durations; peak = 2.5 PFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md).
 cpu_baseline: the oracle (CPU restatement pinned to the reference) timed on this host's cores on a
 bounded sample (N=1, same architecture, 1 warm-up + 3 timed iterations), rank 0 at --gpus 1 only.
@@ -149,11 +149,12 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     if not args.no_roofline:
-        ops.PROFILE.start()
+        ops.PROFILE.start(steps=min(args.steps, 3))   # HIP events bracket the igemm launches of the first 3 timed steps
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(model, train, val)
+        ops.PROFILE.step_done()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()

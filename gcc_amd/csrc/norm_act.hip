@@ -142,28 +142,35 @@ struct BwdArgs {
 };
 
 // pass 1: dz (-> dx buffer) and per-block partial sums {sum dz, sum dz*xhat, sum g*zd}
+// GATE: a gate mask and/or d(alpha) is involved (needs z = bn(x) and a third sum); DROP: dropout.
+// The plain BatchNorm+activation case (both false) keeps 32 fewer live registers -> higher occupancy
+// for what is a pure HBM-streaming kernel.
+template <bool GATE, bool DROP>
 __global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(const BwdArgs a) {
-    __shared__ float red[3][256][9];
+    __shared__ float red[GATE ? 3 : 2][256][9];
     const int ch = threadIdx.x & (a.L.CHP - 1);
     const int pl = threadIdx.x >> a.L.sh;
     const int c0 = ch * 8;
     const bool active = ch < a.L.CH;
-    float mu[8], rs[8], sc[8], sf[8], gm[8];
-    float s0[8], s1[8], s2[8];
+    float mu[8], rs[8], sc[GATE || DROP ? 8 : 1], sf[GATE || DROP ? 8 : 1], gm[GATE ? 8 : 1];
+    float s0[8], s1[8], s2[GATE ? 8 : 1];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int c = c0 + j;
         const bool v = active && c < a.C;
         mu[j] = (v && a.p.bn) ? a.p.mean[c] : 0.f;
-        rs[j] = (v && a.p.bn) ? a.p.rstd[c] : 1.f;
-        const float g = (v && a.p.bn && a.p.gamma) ? a.p.gamma[c] : 1.f;
-        const float b = (v && a.p.bn && a.p.beta) ? a.p.beta[c] : 0.f;
-        sc[j] = g * rs[j];
-        sf[j] = b - mu[j] * sc[j];
-        gm[j] = v ? (a.p.gate ? a.p.gate[c] : 1.f) : 0.f;
-        s0[j] = s1[j] = s2[j] = 0.f;
+        rs[j] = (v && a.p.bn) ? a.p.rstd[c] : (v ? 1.f : 0.f);
+        if constexpr (GATE || DROP) {
+            const float g = (v && a.p.bn && a.p.gamma) ? a.p.gamma[c] : 1.f;
+            const float b = (v && a.p.bn && a.p.beta) ? a.p.beta[c] : 0.f;
+            sc[j] = g * rs[j];
+            sf[j] = b - mu[j] * sc[j];
+        }
+        if constexpr (GATE) { gm[j] = v ? (a.p.gate ? a.p.gate[c] : 1.f) : 0.f; s2[j] = 0.f; }
+        s0[j] = s1[j] = 0.f;
     }
     const float keep_scale = a.p.drop_p > 0.f ? 1.f / (1.f - a.p.drop_p) : 1.f;
+    const float evs = (a.p.bn && a.p.bn_eval) ? 1.f : 0.f;
     if (active) {
         for (size_t pix = (size_t)blockIdx.x * a.L.PPB + pl; pix < a.pixels; pix += (size_t)gridDim.x * a.L.PPB) {
             float xv[8], yv[8], g1v[8], g2v[8], dz[8];
@@ -173,32 +180,42 @@ __global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(const BwdArgs a) 
             if (a.g2) unpack8(*(const i32x4*)(a.g2 + pix * a.ldg2 + a.g2off + c0), g2v);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const float z = xv[j] * sc[j] + sf[j];
                 float df = 1.f;
-                if (a.p.drop_p > 0.f) {
+                if constexpr (DROP) {
                     const float u = rng_uniform(a.p.seed, pix * (size_t)a.C + c0 + j);
                     df = u >= a.p.drop_p ? keep_scale : 0.f;
                 }
-                const float zd = z * df;
-                float g, ga;   // g: gradient at the gate output side ; ga: factor for dalpha
-                if (!a.p.gate_after_act) {
-                    const float yo = a.y ? yv[j] : apply_act(zd * gm[j], a.p.act, a.p.slope);
+                float zd = 0.f;
+                if constexpr (GATE || DROP) zd = (xv[j] * sc[j] + sf[j]) * df;
+                float g;
+                if constexpr (GATE) {
+                    float ga;
+                    if (!a.p.gate_after_act) {
+                        const float yo = a.y ? yv[j] : apply_act(zd * gm[j], a.p.act, a.p.slope);
+                        g = g1v[j] * act_grad_from_out(yo, a.p.act, a.p.slope);
+                        if (a.g2) g += g2v[j] * act_grad_from_out(yo, a.p.act2, a.p.slope);
+                        ga = g * zd;
+                        g *= gm[j];
+                    } else {
+                        const float ao = apply_act(zd, a.p.act, a.p.slope);
+                        ga = g1v[j] * ao;
+                        g = g1v[j] * gm[j] * act_grad_from_out(ao, a.p.act, a.p.slope);
+                    }
+                    s2[j] += ga;
+                } else {
+                    // no gate: y (saved) or x itself (identity activation) gives the activation derivative
+                    const float yo = a.y ? yv[j] : (DROP ? apply_act(zd, a.p.act, a.p.slope) : xv[j]);
                     g = g1v[j] * act_grad_from_out(yo, a.p.act, a.p.slope);
                     if (a.g2) g += g2v[j] * act_grad_from_out(yo, a.p.act2, a.p.slope);
-                    ga = g * zd;
-                    g *= gm[j];
-                } else {
-                    const float ao = apply_act(zd, a.p.act, a.p.slope);
-                    ga = g1v[j] * ao;
-                    g = g1v[j] * gm[j] * act_grad_from_out(ao, a.p.act, a.p.slope);
                 }
                 float d = g * df;
                 if (!a.p.bn) d *= act_grad_from_out(xv[j], a.in_act, a.in_slope);
-                if (a.p.bn_eval) d *= sc[j];
+                const float xh = (xv[j] - mu[j]) * rs[j];
+                if constexpr (GATE || DROP) { if (evs != 0.f) d *= sc[j]; }
+                else { if (evs != 0.f) d *= rs[j] * (a.p.gamma ? a.p.gamma[c0 + j < a.C ? c0 + j : 0] : 1.f); }
                 dz[j] = d;
                 s0[j] += d;
-                s1[j] += d * (xv[j] - mu[j]) * rs[j];
-                s2[j] += ga;
+                s1[j] += d * xh;
             }
             *(i32x4*)(a.dx + pix * a.lddx + a.dxoff + c0) = pack8(dz);
         }
@@ -206,7 +223,8 @@ __global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(const BwdArgs a) 
     // fold the pixel lanes of this block
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        red[0][threadIdx.x][j] = s0[j]; red[1][threadIdx.x][j] = s1[j]; red[2][threadIdx.x][j] = s2[j];
+        red[0][threadIdx.x][j] = s0[j]; red[1][threadIdx.x][j] = s1[j];
+        if constexpr (GATE) red[2][threadIdx.x][j] = s2[j];
     }
     __syncthreads();
     if (pl == 0 && active) {
@@ -215,7 +233,8 @@ __global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(const BwdArgs a) 
             float t0 = 0.f, t1 = 0.f, t2 = 0.f;
             for (int q = 0; q < a.L.PPB; q++) {
                 const int t = q * a.L.CHP + ch;
-                t0 += red[0][t][j]; t1 += red[1][t][j]; t2 += red[2][t][j];
+                t0 += red[0][t][j]; t1 += red[1][t][j];
+                if constexpr (GATE) t2 += red[2][t][j];
             }
             float* o = a.partial + (size_t)blockIdx.x * 3 * a.C8;
             o[0 * a.C8 + c0 + j] = t0; o[1 * a.C8 + c0 + j] = t1; o[2 * a.C8 + c0 + j] = t2;
@@ -415,7 +434,12 @@ extern "C" int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_s
     a.partial = (float*)ws;
     a.totals = a.partial + (size_t)blocks * 3 * a.C8;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bnact_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+    const bool gate = p->gate != nullptr || p->dalpha != nullptr || p->gate_after_act;
+    const bool drop = p->drop_p > 0.f;
+    if (gate && drop) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<true, true>), dim3(blocks), dim3(256), 0, st, a);
+    else if (gate) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<true, false>), dim3(blocks), dim3(256), 0, st, a);
+    else if (drop) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<false, true>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bnact_bwd_reduce_kernel<false, false>), dim3(blocks), dim3(256), 0, st, a);
     GCC_CHECK_LAUNCH();
     hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3((a.C8 + 31) / 32), dim3(1024), 0, st, a, blocks);
     GCC_CHECK_LAUNCH();
