@@ -218,18 +218,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __re
     }
 }
 
-// irregular widths: dW[co][tap][ci] (+)= sum_z slab[z][co][tap][cip]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splits, int Co,
-                                    int taps, int Ci, int Cip, int accumulate) {
+// irregular widths (Ci % 8 != 0: 3- and 6-channel first layers): dW[co][tap][ci] (+)= sum_z slab[z][co][tap][cip]
+// same shape as the vector fold: 64 outputs x 4 split lanes per workgroup
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splits,
+                                                           int Co, int taps, int Ci, int Cip, int accumulate) {
+    __shared__ float sh[4][64];
     const size_t total = (size_t)Co * taps * Ci;
     const size_t slab = (size_t)Co * taps * Cip;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % Ci);
-        const size_t rt = i / Ci;   // co*taps + tap
-        const size_t src = rt * Cip + c;
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
+        const size_t i = base + o;
         float s = 0.f;
-        for (int z = 0; z < splits; z++) s += slabs[z * slab + src];
-        dw[i] = accumulate ? dw[i] + s : s;
+        if (i < total) {
+            const int c = (int)(i % Ci);
+            const size_t src = (i / Ci) * Cip + c;
+            for (int z = sl; z < splits; z += 4) s += slabs[z * slab + src];
+        }
+        sh[sl][o] = s;
+        __syncthreads();
+        if (sl == 0 && i < total) {
+            s += sh[1][o] + sh[2][o] + sh[3][o];
+            dw[i] = accumulate ? dw[i] + s : s;
+        }
+        __syncthreads();
     }
 }
 
@@ -309,7 +320,7 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
         hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits, n4,
                            accumulate);
     } else {
-        int blocks = (int)((total + 255) / 256);
+        int blocks = (int)((total + 63) / 64);
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits,
                            batch * c->Co, c->KH * c->KW, c->Ci, p.Cip, accumulate);

@@ -15,8 +15,8 @@ struct Layout {
     int sh;      // log2(CHP)
     int PPB;     // pixels per block sweep
 };
-static bool make_layout(int C, Layout* L) {
-    L->CH = (C + 7) / 8;
+static bool make_layout(int C, Layout* L, int V = 8) {
+    L->CH = ((C + 7) / 8) * (8 / V);      // V-channel chunks per pixel (storage is padded to 8 channels)
     if (L->CH > 256) return false;
     L->CHP = 1; L->sh = 0;
     while (L->CHP < L->CH) { L->CHP <<= 1; L->sh++; }
@@ -75,6 +75,21 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
         scale[c] = g * r;
         shift[c] = b - rm[c] * g * r;
     }
+}
+
+template <int V> __device__ __forceinline__ void ldv(const bf16_t* p, float* f);
+template <> __device__ __forceinline__ void ldv<8>(const bf16_t* p, float* f) { unpack8(*(const i32x4*)p, f); }
+template <> __device__ __forceinline__ void ldv<4>(const bf16_t* p, float* f) {
+    const i32x2 v = *(const i32x2*)p;
+    f[0] = __uint_as_float((uint32_t)v[0] << 16); f[1] = __uint_as_float((uint32_t)v[0] & 0xffff0000u);
+    f[2] = __uint_as_float((uint32_t)v[1] << 16); f[3] = __uint_as_float((uint32_t)v[1] & 0xffff0000u);
+}
+template <int V> __device__ __forceinline__ void stv(bf16_t* p, const float* f);
+template <> __device__ __forceinline__ void stv<8>(bf16_t* p, const float* f) { *(i32x4*)p = pack8(f); }
+template <> __device__ __forceinline__ void stv<4>(bf16_t* p, const float* f) {
+    i32x2 v;
+    v[0] = (int)pack2bf(f[0], f[1]); v[1] = (int)pack2bf(f[2], f[3]);
+    *(i32x2*)p = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -145,17 +160,18 @@ struct BwdArgs {
 // GATE: a gate mask and/or d(alpha) is involved (needs z = bn(x) and a third sum); DROP: dropout.
 // The plain BatchNorm+activation case (both false) keeps 32 fewer live registers -> higher occupancy
 // for what is a pure HBM-streaming kernel.
-template <bool GATE, bool DROP>
+// V = channels per thread (4: 8-byte accesses, half the per-channel state -> twice the occupancy)
+template <bool GATE, bool DROP, int V>
 __global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(const BwdArgs a) {
-    __shared__ float red[GATE ? 3 : 2][256][9];
+    __shared__ float red[GATE ? 3 : 2][256][V + 1];
     const int ch = threadIdx.x & (a.L.CHP - 1);
     const int pl = threadIdx.x >> a.L.sh;
-    const int c0 = ch * 8;
+    const int c0 = ch * V;
     const bool active = ch < a.L.CH;
-    float mu[8], rs[8], sc[GATE || DROP ? 8 : 1], sf[GATE || DROP ? 8 : 1], gm[GATE ? 8 : 1];
-    float s0[8], s1[8], s2[GATE ? 8 : 1];
+    float mu[V], rs[V], sc[GATE || DROP ? V : 1], sf[GATE || DROP ? V : 1], gm[GATE ? V : 1];
+    float s0[V], s1[V], s2[GATE ? V : 1];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < V; j++) {
         const int c = c0 + j;
         const bool v = active && c < a.C;
         mu[j] = (v && a.p.bn) ? a.p.mean[c] : 0.f;
@@ -173,13 +189,13 @@ __global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(const BwdArgs a) 
     const float evs = (a.p.bn && a.p.bn_eval) ? 1.f : 0.f;
     if (active) {
         for (size_t pix = (size_t)blockIdx.x * a.L.PPB + pl; pix < a.pixels; pix += (size_t)gridDim.x * a.L.PPB) {
-            float xv[8], yv[8], g1v[8], g2v[8], dz[8];
-            unpack8(*(const i32x4*)(a.x + pix * a.ldx + a.xoff + c0), xv);
-            if (a.y) unpack8(*(const i32x4*)(a.y + pix * a.ldy + a.yoff + c0), yv);
-            unpack8(*(const i32x4*)(a.g1 + pix * a.ldg1 + a.g1off + c0), g1v);
-            if (a.g2) unpack8(*(const i32x4*)(a.g2 + pix * a.ldg2 + a.g2off + c0), g2v);
+            float xv[V], yv[V], g1v[V], g2v[V], dz[V];
+            ldv<V>(a.x + pix * a.ldx + a.xoff + c0, xv);
+            if (a.y) ldv<V>(a.y + pix * a.ldy + a.yoff + c0, yv);
+            ldv<V>(a.g1 + pix * a.ldg1 + a.g1off + c0, g1v);
+            if (a.g2) ldv<V>(a.g2 + pix * a.ldg2 + a.g2off + c0, g2v);
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
+            for (int j = 0; j < V; j++) {
                 float df = 1.f;
                 if constexpr (DROP) {
                     const float u = rng_uniform(a.p.seed, pix * (size_t)a.C + c0 + j);
@@ -217,19 +233,19 @@ __global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(const BwdArgs a) 
                 s0[j] += d;
                 s1[j] += d * xh;
             }
-            *(i32x4*)(a.dx + pix * a.lddx + a.dxoff + c0) = pack8(dz);
+            stv<V>(a.dx + pix * a.lddx + a.dxoff + c0, dz);
         }
     }
     // fold the pixel lanes of this block
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < V; j++) {
         red[0][threadIdx.x][j] = s0[j]; red[1][threadIdx.x][j] = s1[j];
         if constexpr (GATE) red[2][threadIdx.x][j] = s2[j];
     }
     __syncthreads();
     if (pl == 0 && active) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < V; j++) {
             float t0 = 0.f, t1 = 0.f, t2 = 0.f;
             for (int q = 0; q < a.L.PPB; q++) {
                 const int t = q * a.L.CHP + ch;
@@ -395,9 +411,9 @@ extern "C" int gcc_bnact_fwd(const gcc_bnact_t* p, const void* x, int ldx, int x
 }
 
 static int bwd_blocks(size_t pixels, const Layout& L) {
-    size_t b = (pixels + (size_t)L.PPB * 4 - 1) / ((size_t)L.PPB * 4);
+    size_t b = (pixels + (size_t)L.PPB * 8 - 1) / ((size_t)L.PPB * 8);
     if (b < 1) b = 1;
-    if (b > 2048) b = 2048;
+    if (b > 1024) b = 1024;       // 4 workgroups per CU; also bounds the per-block partial rows the finalize folds
     return (int)b;
 }
 
@@ -436,10 +452,14 @@ extern "C" int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_s
     hipStream_t st = (hipStream_t)stream;
     const bool gate = p->gate != nullptr || p->dalpha != nullptr || p->gate_after_act;
     const bool drop = p->drop_p > 0.f;
-    if (gate && drop) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<true, true>), dim3(blocks), dim3(256), 0, st, a);
-    else if (gate) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<true, false>), dim3(blocks), dim3(256), 0, st, a);
-    else if (drop) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<false, true>), dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((bnact_bwd_reduce_kernel<false, false>), dim3(blocks), dim3(256), 0, st, a);
+    {
+        BwdArgs r = a;                      // the reduce pass runs 4 channels per thread
+        if (!make_layout(C, &r.L, 4)) return GCC_ERR_UNSUPPORTED;
+        if (gate && drop) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<true, true, 4>), dim3(blocks), dim3(256), 0, st, r);
+        else if (gate) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<true, false, 4>), dim3(blocks), dim3(256), 0, st, r);
+        else if (drop) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<false, true, 4>), dim3(blocks), dim3(256), 0, st, r);
+        else hipLaunchKernelGGL((bnact_bwd_reduce_kernel<false, false, 4>), dim3(blocks), dim3(256), 0, st, r);
+    }
     GCC_CHECK_LAUNCH();
     hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3((a.C8 + 31) / 32), dim3(1024), 0, st, a, blocks);
     GCC_CHECK_LAUNCH();
