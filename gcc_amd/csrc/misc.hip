@@ -93,6 +93,37 @@ __global__ void pack_wt_kernel(const float* __restrict__ m, int rows, int taps, 
     }
 }
 
+// multi-tensor form: one launch repacks every conv of an optimizer group (device work list)
+__global__ __launch_bounds__(256) void pack_multi_kernel(const gcc_pack_desc_t* __restrict__ descs,
+                                                         const gcc_pack_item_t* __restrict__ items) {
+    __shared__ float t[32][33];
+    const gcc_pack_item_t it = items[blockIdx.x];
+    const gcc_pack_desc_t d = descs[it.tensor];
+    if (it.kind == 0) {                 // W: [rows][taps][colsp], linear chunk of 2048 elements
+        const size_t total = (size_t)d.rows * d.taps * d.colsp;
+        const size_t beg = (size_t)it.a * 2048;
+        bf16_t* w = (bf16_t*)d.w;
+        for (size_t i = beg + threadIdx.x; i < beg + 2048 && i < total; i += 256) {
+            const int c = (int)(i % d.colsp);
+            const size_t rt = i / d.colsp;
+            w[i] = c < d.cols ? f2bf(d.master[rt * d.cols + c]) : (bf16_t)0;
+        }
+    } else {                            // Wt: [cols][taps][rowsp], one 32x32 tile of one tap
+        const int tap = it.a, r0 = it.b * 32, c0 = it.c * 32;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int k = ty; k < 32; k += 8) {
+            const int r = r0 + k, c = c0 + tx;
+            t[k][tx] = (r < d.rows && c < d.cols) ? d.master[((size_t)r * d.taps + tap) * d.cols + c] : 0.f;
+        }
+        __syncthreads();
+        bf16_t* wt = (bf16_t*)d.wt;
+        for (int k = ty; k < 32; k += 8) {
+            const int c = c0 + k, r = r0 + tx;
+            if (c < d.cols && r < d.rowsp) wt[((size_t)c * d.taps + tap) * d.rowsp + r] = f2bf(t[tx][k]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // block-wide sum (256 threads) -> thread 0
 __device__ __forceinline__ float block_sum256(float v, float* sh) {
@@ -332,6 +363,15 @@ extern "C" int gcc_pack_weights(const float* master, int rows, int taps, int col
                            cols, rowsp, (bf16_t*)wt);
         GCC_CHECK_LAUNCH();
     }
+    return GCC_OK;
+}
+
+extern "C" int gcc_pack_weights_multi(const gcc_pack_desc_t* descs, const gcc_pack_item_t* items, int nitems,
+                                      gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!descs || !items || nitems <= 0) return GCC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pack_multi_kernel, dim3(nitems), dim3(256), 0, (hipStream_t)stream, descs, items);
+    GCC_CHECK_LAUNCH();
     return GCC_OK;
 }
 

@@ -122,13 +122,23 @@ class BNOp:
     def __init__(self, bn: nn.BatchNorm2d):
         self.bn = bn
         self.C = bn.num_features
+        self.pending_batches = 0           # num_batches_tracked increments not yet written to the buffer
+        bn.register_state_dict_pre_hook(lambda module, prefix, keep_vars: self.flush_counter())
+
+    def flush_counter(self):
+        """num_batches_tracked is bookkeeping only (momentum is fixed): it is counted on the host and
+        written into the module's buffer when a state_dict is taken, instead of one tiny kernel per
+        BatchNorm application."""
+        if self.pending_batches:
+            self.bn.num_batches_tracked += self.pending_batches
+            self.pending_batches = 0
 
     def finalize(self, stats, count, st, train):
         bn = self.bn
         if train:
             ops.bn_finalize(stats, count, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, st,
                             eps=bn.eps, momentum=bn.momentum)
-            bn.num_batches_tracked += 1
+            self.pending_batches += 1
         else:
             ops.bn_eval_coeffs(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, st, eps=bn.eps)
 
@@ -184,8 +194,9 @@ class UnetEngine:
         return [c for c in self.down + self.up if c is not None]
 
     def repack(self):
-        for c in self.convs():
-            c.repack()
+        if getattr(self, '_pack', None) is None:
+            self._pack = ops.PackPlan(self.convs(), self.device)
+        self._pack.run()
 
     # ---------------------------------------------------------------------------------------
     def _ctx(self, N, H, W):
@@ -369,8 +380,9 @@ class PatchGANEngine:
         return self.conv
 
     def repack(self):
-        for c in self.conv:
-            c.repack()
+        if getattr(self, '_pack', None) is None:
+            self._pack = ops.PackPlan(self.conv, self.device)
+        self._pack.run()
 
     def refresh_masks(self):
         for i in range(self.L):

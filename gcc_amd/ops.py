@@ -185,6 +185,40 @@ def pack_weights_into(master, w, wt):
                                  wt.data_ptr() if wt is not None else None, stream()), 'gcc_pack_weights')
 
 
+class PackPlan:
+    """One launch that refreshes the bf16 W / Wt packings of a list of convs (engine.ConvOp) from their
+    fp32 masters.  Pointers must stay valid (flat parameter storage, persistent packings)."""
+
+    def __init__(self, convs, device):
+        convs = list(convs)
+        D = (_lib.pack_desc_t * len(convs))()
+        items = []
+        for i, c in enumerate(convs):
+            rows, cols, taps = c.rows, c.cols, c.k * c.k
+            colsp, rowsp = ceil8(cols), ceil8(rows)
+            D[i] = _lib.pack_desc_t(c.weight.data_ptr(), c.w.data_ptr(), c.wt.data_ptr(), rows, taps, cols, colsp, rowsp, 0)
+            for a in range((rows * taps * colsp + 2047) // 2048):
+                items.append((i, 0, a, 0, 0))
+            for tap in range(taps):
+                for rb in range((rowsp + 31) // 32):
+                    for cb in range((cols + 31) // 32):
+                        items.append((i, 1, tap, rb, cb))
+        import numpy as np
+        arr = np.zeros((len(items), 6), dtype=np.int32)
+        arr[:, :5] = np.asarray(items, dtype=np.int32).reshape(-1, 5)
+        self.n = len(items)
+        self.d_desc = torch.frombuffer(bytearray(bytes(D)), dtype=torch.uint8).to(device)
+        self.d_items = torch.from_numpy(arr).to(device)
+        self.ptrs = [c.weight.data_ptr() for c in convs]
+        self.convs = convs
+
+    def run(self):
+        if [c.weight.data_ptr() for c in self.convs] != self.ptrs:
+            raise _lib.GccError('parameter storage moved after the pack plan was built')
+        check(lib().gcc_pack_weights_multi(self.d_desc.data_ptr(), self.d_items.data_ptr(), self.n, stream()),
+              'gcc_pack_weights_multi')
+
+
 def _epilogue(bias, act, slope, stats, d=None, dgrad=0, device=None):
     wsp, wsb = None, 0
     if d is not None:

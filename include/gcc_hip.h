@@ -100,6 +100,13 @@ int gcc_conv_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float* dw
 int gcc_pack_weights(const float* master, int rows, int taps, int cols, void* w, void* wt,
                      gcc_stream_t stream);
 
+/* multi-tensor form: DEVICE arrays built once per optimizer group.  kind 0: W chunk `a` (2048 output
+ * elements); kind 1: one 32x32 tile (row block b, column block c) of tap `a` for Wt. */
+typedef struct { const float* master; void* w; void* wt; int rows, taps, cols, colsp, rowsp; int pad_; } gcc_pack_desc_t;
+typedef struct { int tensor, kind, a, b, c, pad_; } gcc_pack_item_t;
+int gcc_pack_weights_multi(const gcc_pack_desc_t* descs, const gcc_pack_item_t* items, int nitems,
+                           gcc_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Tensor packing between the public NCHW fp32 surface and NHWC bf16.
  * Replaces torch.cat((real_A, fake_B), 1) at models/Pix2Pix.py:467,471,494,499,516 and the
