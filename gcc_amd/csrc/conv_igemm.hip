@@ -515,7 +515,7 @@ struct SplitPlan { int ksplit, kper; };
 static SplitPlan plan_ksplit(long blocks, int nk) {
     SplitPlan sp = {1, nk};
     if (blocks >= 128 || nk < 16) return sp;
-    int s = (int)((512 + blocks - 1) / blocks);
+    int s = (int)((1024 + blocks - 1) / blocks);
     if (s > nk / 4) s = nk / 4;
     if (s < 2) return sp;
     sp.kper = (nk + s - 1) / s;

@@ -161,9 +161,10 @@ struct BwdArgs {
 // The plain BatchNorm+activation case (both false) keeps 32 fewer live registers -> higher occupancy
 // for what is a pure HBM-streaming kernel.
 // V = channels per thread (4: 8-byte accesses, half the per-channel state -> twice the occupancy)
+// 1024-thread workgroups: 4x fewer per-block partial rows for the finalize to fold at equal waves in flight
 template <bool GATE, bool DROP, int V>
-__global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(const BwdArgs a) {
-    __shared__ float red[GATE ? 3 : 2][256][V + 1];
+__global__ __launch_bounds__(1024) void bnact_bwd_reduce_kernel(const BwdArgs a) {
+    __shared__ float red[GATE ? 3 : 2][1024][V + 1];
     const int ch = threadIdx.x & (a.L.CHP - 1);
     const int pl = threadIdx.x >> a.L.sh;
     const int c0 = ch * V;
@@ -411,9 +412,10 @@ extern "C" int gcc_bnact_fwd(const gcc_bnact_t* p, const void* x, int ldx, int x
 }
 
 static int bwd_blocks(size_t pixels, const Layout& L) {
-    size_t b = (pixels + (size_t)L.PPB * 8 - 1) / ((size_t)L.PPB * 8);
+    // (L is the 8-channel, 256-thread layout; the reduce pass covers 8x its pixels per sweep)
+    size_t b = (pixels + (size_t)L.PPB * 8 * 4 - 1) / ((size_t)L.PPB * 8 * 4);
     if (b < 1) b = 1;
-    if (b > 1024) b = 1024;       // 4 workgroups per CU; also bounds the per-block partial rows the finalize folds
+    if (b > 256) b = 256;         // one 16-wave workgroup per CU; bounds the partial rows the finalize folds
     return (int)b;
 }
 
@@ -453,12 +455,13 @@ extern "C" int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_s
     const bool gate = p->gate != nullptr || p->dalpha != nullptr || p->gate_after_act;
     const bool drop = p->drop_p > 0.f;
     {
-        BwdArgs r = a;                      // the reduce pass runs 4 channels per thread
+        BwdArgs r = a;                      // the reduce pass runs 4 channels per thread, 1024 threads per workgroup
         if (!make_layout(C, &r.L, 4)) return GCC_ERR_UNSUPPORTED;
-        if (gate && drop) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<true, true, 4>), dim3(blocks), dim3(256), 0, st, r);
-        else if (gate) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<true, false, 4>), dim3(blocks), dim3(256), 0, st, r);
-        else if (drop) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<false, true, 4>), dim3(blocks), dim3(256), 0, st, r);
-        else hipLaunchKernelGGL((bnact_bwd_reduce_kernel<false, false, 4>), dim3(blocks), dim3(256), 0, st, r);
+        r.L.PPB = 1024 / r.L.CHP;
+        if (gate && drop) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<true, true, 4>), dim3(blocks), dim3(1024), 0, st, r);
+        else if (gate) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<true, false, 4>), dim3(blocks), dim3(1024), 0, st, r);
+        else if (drop) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<false, true, 4>), dim3(blocks), dim3(1024), 0, st, r);
+        else hipLaunchKernelGGL((bnact_bwd_reduce_kernel<false, false, 4>), dim3(blocks), dim3(1024), 0, st, r);
     }
     GCC_CHECK_LAUNCH();
     hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3((a.C8 + 31) / 32), dim3(1024), 0, st, a, blocks);
