@@ -44,7 +44,8 @@ class adam_tensor_t(C.Structure):
 
 class pack_desc_t(C.Structure):
     _fields_ = [('master', C.c_void_p), ('w', C.c_void_p), ('wt', C.c_void_p), ('rows', C.c_int), ('taps', C.c_int),
-                ('cols', C.c_int), ('colsp', C.c_int), ('rowsp', C.c_int), ('pad_', C.c_int)]
+                ('cols', C.c_int), ('colsp', C.c_int), ('rowsp', C.c_int), ('row_split', C.c_int),
+                ('col_split', C.c_int), ('pad_', C.c_int)]
 
 
 class pack_item_t(C.Structure):
@@ -70,6 +71,7 @@ PROTOTYPES = {
     'gcc_conv_dgrad': (_I, [C.POINTER(conv_t), _P, _P, _P, C.POINTER(epilogue_t), _P]),
     'gcc_conv_wgrad_workspace': (_Z, [C.POINTER(conv_t)]),
     'gcc_conv_wgrad': (_I, [C.POINTER(conv_t), _P, _P, _P, _I, _P, _Z, _P]),
+    'gcc_conv_wgrad_seg': (_I, [C.POINTER(conv_t), _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     'gcc_pack_weights': (_I, [_P, _I, _I, _I, _P, _P, _P]),
     'gcc_pack_weights_multi': (_I, [_P, _P, _I, _P]),
     'gcc_nchw_f32_to_nhwc_bf16': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

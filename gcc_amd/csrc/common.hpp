@@ -76,6 +76,24 @@ __host__ __device__ static inline int ceil8(int v) { return (v + 7) & ~7; }
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 #include <stdio.h>
+// A channel dimension may be the concatenation of two tensors (U-Net skip | up path).  In memory each
+// part is padded to 8 channels, so logical channel l of an n-channel dimension whose first part has
+// `split` channels lives at l (+ ceil8(split) - split when l >= split).  split <= 0 or >= n: one part.
+__host__ __device__ static inline int seg_phys_size(int n, int split) {
+    return (split > 0 && split < n) ? ceil8(split) + ceil8(n - split) : ceil8(n);
+}
+__host__ __device__ static inline int seg_to_phys(int l, int n, int split) {
+    return (split > 0 && split < n && l >= split) ? l + ceil8(split) - split : l;
+}
+__host__ __device__ static inline int seg_to_logical(int p, int n, int split) {   // -1: padding
+    if (split <= 0 || split >= n) return p < n ? p : -1;
+    if (p < split) return p;
+    const int s8 = ceil8(split);
+    if (p < s8) return -1;
+    const int l = p - (s8 - split);
+    return l < n ? l : -1;
+}
+
 #define GCC_CHECK_LAUNCH()                                                                      \
     do {                                                                                        \
         hipError_t e_ = hipGetLastError();                                                      \

@@ -221,17 +221,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __re
 // irregular widths (Ci % 8 != 0: 3- and 6-channel first layers): dW[co][tap][ci] (+)= sum_z slab[z][co][tap][cip]
 // same shape as the vector fold: 64 outputs x 4 split lanes per workgroup
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splits,
-                                                           int Co, int taps, int Ci, int Cip, int accumulate) {
+                                                           int Co, int taps, int Ci, int Cip, int accumulate, int Cop,
+                                                           int row_split, int col_split) {
     __shared__ float sh[4][64];
     const size_t total = (size_t)Co * taps * Ci;
-    const size_t slab = (size_t)Co * taps * Cip;
+    const size_t slab = (size_t)Cop * taps * Cip;
     const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
     for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
         const size_t i = base + o;
         float s = 0.f;
         if (i < total) {
             const int c = (int)(i % Ci);
-            const size_t src = (i / Ci) * Cip + c;
+            const size_t rt = i / Ci;
+            const int tap = (int)(rt % taps), r = (int)(rt / taps);
+            const size_t src = ((size_t)seg_to_phys(r, Co, row_split) * taps + tap) * Cip + seg_to_phys(c, Ci, col_split);
             for (int z = sl; z < splits; z += 4) s += slabs[z * slab + src];
         }
         sh[sl][o] = s;
@@ -276,7 +279,8 @@ extern "C" size_t gcc_conv_wgrad_workspace(const gcc_conv_t* c) { return gcc_int
 // batched form: problem b reads x + b*x_bstride, dy + b*dy_bstride (elements; c->N images each) and
 // writes dw + b*Co*taps*Ci
 int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float* dw, int accumulate, void* ws,
-                       size_t ws_bytes, int batch, long x_bstride, long dy_bstride, hipStream_t st) {
+                       size_t ws_bytes, int batch, long x_bstride, long dy_bstride, hipStream_t st, int rows_l,
+                       int cols_l, int row_split, int col_split) {
     GCC_ENTER();
     if (!c || !x || !dy || !dw || !ws) return GCC_ERR_BAD_ARG;
     if (c->N <= 0 || c->H <= 0 || c->W <= 0 || c->Ci <= 0 || c->Co <= 0 || c->KH <= 0 || c->KW <= 0 ||
@@ -298,7 +302,8 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
     p.M = (int)M; p.x_bytes = (uint32_t)xb; p.dy_bytes = (uint32_t)yb;
     const int splits = plan_splits(c, batch, &p.ksteps_per_split);
     p.batch = batch; p.x_bstride = x_bstride; p.dy_bstride = dy_bstride;
-    const bool regular = (c->Ci & 7) == 0 && (((uintptr_t)dw) & 15) == 0;
+    const bool seg = rows_l > 0;      // c holds physical sizes, dw is [rows_l][taps][cols_l]
+    const bool regular = !seg && (c->Ci & 7) == 0 && (((uintptr_t)dw) & 15) == 0;
     p.direct = (splits == 1 && regular) ? 1 : 0;
     p.accumulate = accumulate; p.dw = dw;
     p.col_tiles = cdiv(p.ncols, TCOL); p.co_tiles = cdiv(c->Co, TCO);
@@ -322,8 +327,16 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
     } else {
         int blocks = (int)((total + 63) / 64);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits,
-                           batch * c->Co, c->KH * c->KW, c->Ci, p.Cip, accumulate);
+        if (seg) {
+            const size_t tl = (size_t)rows_l * c->KH * c->KW * cols_l;
+            blocks = (int)((tl + 63) / 64);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits, rows_l,
+                               c->KH * c->KW, cols_l, p.Cip, accumulate, c->Co, row_split, col_split);
+        } else {
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits,
+                               batch * c->Co, c->KH * c->KW, c->Ci, p.Cip, accumulate, batch * c->Co, 0, 0);
+        }
     }
     GCC_CHECK_LAUNCH();
     return GCC_OK;
@@ -332,5 +345,15 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
 extern "C" int gcc_conv_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float* dw, int accumulate,
                               void* ws, size_t ws_bytes, gcc_stream_t stream) {
     GCC_ENTER();
-    return gcc_internal_wgrad(c, x, dy, dw, accumulate, ws, ws_bytes, 1, 0, 0, (hipStream_t)stream);
+    return gcc_internal_wgrad(c, x, dy, dw, accumulate, ws, ws_bytes, 1, 0, 0, (hipStream_t)stream, 0, 0, 0, 0);
+}
+
+extern "C" int gcc_conv_wgrad_seg(const gcc_conv_t* c, const void* x, const void* dy, float* dw, int rows, int cols,
+                                  int row_split, int col_split, int accumulate, void* ws, size_t ws_bytes,
+                                  gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!c || rows <= 0 || cols <= 0) return GCC_ERR_BAD_ARG;
+    if (c->Co != seg_phys_size(rows, row_split) || c->Ci != seg_phys_size(cols, col_split)) return GCC_ERR_BAD_ARG;
+    return gcc_internal_wgrad(c, x, dy, dw, accumulate, ws, ws_bytes, 1, 0, 0, (hipStream_t)stream, rows, cols, row_split,
+                              col_split);
 }

@@ -5,7 +5,8 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
                        int batch, long src_bstride, long wgt_bstride, long dst_bstride, hipStream_t st);
 size_t gcc_internal_wgrad_workspace(const gcc_conv_t* c, int batch);
 int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float* dw, int accumulate, void* ws,
-                       size_t ws_bytes, int batch, long x_bstride, long dy_bstride, hipStream_t st);
+                       size_t ws_bytes, int batch, long x_bstride, long dy_bstride, hipStream_t st, int rows_l, int cols_l,
+                       int row_split, int col_split);
 
 namespace {
 
@@ -99,27 +100,31 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gcc_pack_desc_t* 
     __shared__ float t[32][33];
     const gcc_pack_item_t it = items[blockIdx.x];
     const gcc_pack_desc_t d = descs[it.tensor];
-    if (it.kind == 0) {                 // W: [rows][taps][colsp], linear chunk of 2048 elements
-        const size_t total = (size_t)d.rows * d.taps * d.colsp;
+    if (it.kind == 0) {                 // W: [rowsp][taps][colsp], linear chunk of 2048 elements
+        const size_t total = (size_t)d.rowsp * d.taps * d.colsp;
         const size_t beg = (size_t)it.a * 2048;
         bf16_t* w = (bf16_t*)d.w;
         for (size_t i = beg + threadIdx.x; i < beg + 2048 && i < total; i += 256) {
-            const int c = (int)(i % d.colsp);
+            const int cp = (int)(i % d.colsp);
             const size_t rt = i / d.colsp;
-            w[i] = c < d.cols ? f2bf(d.master[rt * d.cols + c]) : (bf16_t)0;
+            const int tap = (int)(rt % d.taps);
+            const int lr = seg_to_logical((int)(rt / d.taps), d.rows, d.row_split);
+            const int lc = seg_to_logical(cp, d.cols, d.col_split);
+            w[i] = (lr >= 0 && lc >= 0) ? f2bf(d.master[((size_t)lr * d.taps + tap) * d.cols + lc]) : (bf16_t)0;
         }
-    } else {                            // Wt: [cols][taps][rowsp], one 32x32 tile of one tap
+    } else {                            // Wt: [colsp][taps][rowsp], one 32x32 tile (physical indices) of one tap
         const int tap = it.a, r0 = it.b * 32, c0 = it.c * 32;
         const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
         for (int k = ty; k < 32; k += 8) {
-            const int r = r0 + k, c = c0 + tx;
-            t[k][tx] = (r < d.rows && c < d.cols) ? d.master[((size_t)r * d.taps + tap) * d.cols + c] : 0.f;
+            const int lr = seg_to_logical(r0 + k, d.rows, d.row_split);
+            const int lc = seg_to_logical(c0 + tx, d.cols, d.col_split);
+            t[k][tx] = (lr >= 0 && lc >= 0) ? d.master[((size_t)lr * d.taps + tap) * d.cols + lc] : 0.f;
         }
         __syncthreads();
         bf16_t* wt = (bf16_t*)d.wt;
         for (int k = ty; k < 32; k += 8) {
             const int c = c0 + k, r = r0 + tx;
-            if (c < d.cols && r < d.rowsp) wt[((size_t)c * d.taps + tap) * d.rowsp + r] = f2bf(t[tx][k]);
+            if (c < d.colsp && r < d.rowsp) wt[((size_t)c * d.taps + tap) * d.rowsp + r] = f2bf(t[tx][k]);
         }
     }
 }
@@ -494,9 +499,9 @@ extern "C" int gcc_distill_fwd(const void* f, int ldf, int foff, const void* t, 
     gcc_conv_t ct = {1, 1, HW, C, C, 1, 1, 1, 0, ldt, toff, ldt, toff};
     const size_t slab_bytes = L.total - L.slabs;
     int rc = gcc_internal_wgrad(&cf, f, f, (float*)(base + L.gf), 0, base + L.slabs, slab_bytes, N, (long)HW * ldf,
-                                (long)HW * ldf, st);
+                                (long)HW * ldf, st, 0, 0, 0, 0);
     if (rc) return rc;
-    rc = gcc_internal_wgrad(&ct, t, t, (float*)(base + L.gt), 0, base + L.slabs, slab_bytes, N, (long)HW * ldt, (long)HW * ldt, st);
+    rc = gcc_internal_wgrad(&ct, t, t, (float*)(base + L.gt), 0, base + L.slabs, slab_bytes, N, (long)HW * ldt, (long)HW * ldt, st, 0, 0, 0, 0);
     if (rc) return rc;
     const size_t ng = (size_t)N * C * C;
     const int b1 = grid_for(ng, 256 * 4, RED_BLOCKS);

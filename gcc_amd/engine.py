@@ -70,34 +70,47 @@ class ConvOp:
     ConvTranspose2d rows=Cin cols=Cout == the adjoint Conv2d (big image -> small image) with
     Co=rows, Ci=cols; its forward is that conv's backward-data."""
 
-    def __init__(self, weight, bias, k, stride, pad, transposed):
+    def __init__(self, weight, bias, k, stride, pad, transposed, row_split=0, col_split=0):
+        """row_split / col_split: the master's row / column dimension is a channel concatenation whose
+        first part has that many channels (each part padded to 8 in memory); 0 = a single tensor."""
         self.weight, self.bias = weight, bias
         self.k, self.stride, self.pad, self.transposed = k, stride, pad, transposed
         self.rows, self.cols = weight.shape[0], weight.shape[1]
+        # a split on a multiple of 8 needs no padding: treat as unsplit (keeps the direct wgrad path)
+        self.row_split = row_split if (0 < row_split < self.rows and row_split % 8) else 0
+        self.col_split = col_split if (0 < col_split < self.cols and col_split % 8) else 0
+        self.rows_p = ops.seg_phys(self.rows, self.row_split)
+        self.cols_p = ops.seg_phys(self.cols, self.col_split)
+        # channel counts the kernels are told: physical when the dimension is a padded concatenation
+        self.rows_k = self.rows_p if self.row_split else self.rows
+        self.cols_k = self.cols_p if self.col_split else self.cols
         dev = weight.device
         taps = k * k
-        self.w = torch.zeros((self.rows, taps, ops.ceil8(self.cols)), dtype=torch.bfloat16, device=dev)
-        self.wt = torch.zeros((self.cols, taps, ops.ceil8(self.rows)), dtype=torch.bfloat16, device=dev)
+        self.w = torch.zeros((self.rows_p, taps, self.cols_p), dtype=torch.bfloat16, device=dev)
+        self.wt = torch.zeros((self.cols_p, taps, self.rows_p), dtype=torch.bfloat16, device=dev)
+        self._pack = None
 
     def repack(self):
-        ops.pack_weights_into(self.weight.data, self.w, self.wt)
+        if self._pack is None:
+            self._pack = ops.PackPlan([self], self.weight.device)
+        self._pack.run()
 
     # -- forward ---------------------------------------------------------------------------
     def forward(self, x, out, act=ACT_NONE, want_stats=False, use_bias=True):
         b = self.bias.data if (self.bias is not None and use_bias) else None
         if not self.transposed:
-            return ops.conv_fprop(x, self.w, self.rows, self.k, self.stride, self.pad, out=out, bias=b, act=act,
+            return ops.conv_fprop(x, self.w, self.rows_k, self.k, self.stride, self.pad, out=out, bias=b, act=act,
                                   slope=LRELU, want_stats=want_stats)
         N, _, H, W = out.shape
-        return ops.conv_dgrad(x, self.wt, self.cols, H, W, self.k, self.stride, self.pad, out=out, bias=b, act=act,
+        return ops.conv_dgrad(x, self.wt, self.cols_k, H, W, self.k, self.stride, self.pad, out=out, bias=b, act=act,
                               slope=LRELU, want_stats=want_stats)
 
     # -- gradient w.r.t. the layer input ------------------------------------------------------
     def backward_data(self, dy, out):
         if not self.transposed:
             N, _, H, W = out.shape
-            return ops.conv_dgrad(dy, self.wt, self.cols, H, W, self.k, self.stride, self.pad, out=out)
-        return ops.conv_fprop(dy, self.w, self.rows, self.k, self.stride, self.pad, out=out)
+            return ops.conv_dgrad(dy, self.wt, self.cols_k, H, W, self.k, self.stride, self.pad, out=out)
+        return ops.conv_fprop(dy, self.w, self.rows_k, self.k, self.stride, self.pad, out=out)
 
     # -- gradient w.r.t. the weight (accumulates into weight.grad) and bias -------------------------
     def backward_weight(self, x, dy):
@@ -110,10 +123,12 @@ class ConvOp:
             self._backward_weight(x, dy)
 
     def _backward_weight(self, x, dy):
-        if not self.transposed:
-            ops.conv_wgrad(x, dy, self.weight.grad, self.k, self.stride, self.pad, accumulate=True)
+        cx, cdy = (x, dy) if not self.transposed else (dy, x)      # (conv input, conv output-gradient) of the adjoint pair
+        if self.row_split or self.col_split:
+            ops.conv_wgrad_seg(cx, cdy, self.weight.grad, self.rows, self.cols, self.row_split, self.col_split, self.k,
+                               self.stride, self.pad, accumulate=True)
         else:
-            ops.conv_wgrad(dy, x, self.weight.grad, self.k, self.stride, self.pad, accumulate=True)
+            ops.conv_wgrad(cx, cdy, self.weight.grad, self.k, self.stride, self.pad, accumulate=True)
         if self.bias is not None:
             ops.channel_sum(dy, self.bias.grad, accumulate=True)
 
@@ -175,15 +190,19 @@ class UnetEngine:
                 self.down_bn[d] = BNOp(_get(module, p + '.model.2'))
             uname = p + ('.model.3' if d in (0, D - 1) else '.model.5')
             u = _get(module, uname)
-            self.up[d] = ConvOp(u.weight, u.bias, 4, 2, 1, True)
+            # the up conv at depth d < D-1 reads cat(skip e[d] | up output of depth d+1): rows are a concatenation
+            self.up[d] = ConvOp(u.weight, u.bias, 4, 2, 1, True, row_split=(self.down[d].rows if d < D - 1 else 0))
             if d > 0:
                 self.up_bn[d] = BNOp(_get(module, p + ('.model.4' if d == D - 1 else '.model.6')))
         self.width = [self.down[d].rows for d in range(D)]          # channels of e[d]
         self.uwidth = [self.up[d].cols for d in range(D)]           # channels of the up-conv output at depth d
-        for wdt in self.width + self.uwidth[1:]:
-            if wdt % 8:
-                raise NotImplementedError('U-Net widths must be multiples of 8 on this path (got %s / %s)'
-                                          % (self.width, self.uwidth))
+        # channel offset of the up-path part inside the concat buffer of depth d (skip part padded to 8)
+        self.uoff = [0] + [ops.ceil8(self.width[d - 1]) for d in range(1, D)]
+        self.catw = [0] + [self.uoff[d] + ops.ceil8(self.uwidth[d]) for d in range(1, D)]    # physical concat width
+        # channel count the kernels are told for the concat buffer: the physical width when the skip part is
+        # padded inside it, else the plain sum (same convention as ConvOp.rows_k / cols_k)
+        self.catc = [0] + [self.catw[d] if self.width[d - 1] % 8 else self.width[d - 1] + self.uwidth[d]
+                           for d in range(1, D)]
         self.drop_depths = [D - 2 - i for i in range(D - 5)] if use_dropout else []
         self.hook_names = ['model.model.1.model.2', 'model.model.1.model.3.model.3.model.2',
                            'model.model.1.model.3.model.3.model.4', 'model.model.1.model.4']
@@ -220,7 +239,7 @@ class UnetEngine:
             c.e[d] = ops.new_act(N, wd[d], h, w, dev)
             if d < D - 1:
                 c.lin[d + 1] = ops.new_act(N, wd[d], h, w, dev)
-                c.rcat[d + 1] = ops.new_act(N, wd[d] + uw[d + 1], h, w, dev)
+                c.rcat[d + 1] = ops.new_act(N, self.catc[d + 1], h, w, dev, ld=self.catw[d + 1])
             if 0 < d < D - 1:
                 c.st_down[d] = ops.BNState(wd[d], dev)
             if d >= 1:
@@ -236,7 +255,7 @@ class UnetEngine:
         for d in range(D):
             h, w = hs[d]
             if d < D - 1:
-                c.g_rcat[d + 1] = ops.new_act(N, wd[d] + uw[d + 1], h, w, dev)
+                c.g_rcat[d + 1] = ops.new_act(N, self.catc[d + 1], h, w, dev, ld=self.catw[d + 1])
                 c.g_lin[d + 1] = ops.new_act(N, wd[d], h, w, dev)
             if d >= 1:
                 hh, ww = hs[d - 1]
@@ -277,7 +296,7 @@ class UnetEngine:
             hh, ww = c.hs[d - 1]
             self.up_bn[d].finalize(stats, N * hh * ww, c.st_up[d], train)
             drop = 0.5 if (train and d in self.drop_depths) else 0.0
-            ops.bnact_fwd(c.t[d], ops.cslice(c.rcat[d], wd[d - 1], uw[d]), scale=c.st_up[d].scale,
+            ops.bnact_fwd(c.t[d], ops.cslice(c.rcat[d], self.uoff[d], uw[d]), scale=c.st_up[d].scale,
                           shift=c.st_up[d].shift, act=ACT_RELU, drop_p=drop, seed=c.iter_seed * 64 + d)
             src = c.rcat[d]
         self.up[0].forward(c.rcat[1], c.out, act=ACT_TANH)
@@ -297,13 +316,13 @@ class UnetEngine:
         self.up[0].backward_data(c.g_out, c.g_rcat[1])
         for d in range(1, D):
             if d == 2 and g_feat[3] is not None:
-                ops.nhwc_add(g_feat[3], 0, c.g_rcat[2], 0, wd[1] + uw[2])
+                ops.nhwc_add(g_feat[3], 0, c.g_rcat[2], 0, self.catc[2])
             if d == 4 and g_feat[2] is not None:
-                ops.nhwc_add(g_feat[2], 0, c.g_rcat[4], 0, wd[3] + uw[4])
+                ops.nhwc_add(g_feat[2], 0, c.g_rcat[4], 0, self.catc[4])
             w = wd[d - 1]
             bn = self.up_bn[d].bn
             drop = 0.5 if (c.train and d in self.drop_depths) else 0.0
-            ops.bnact_bwd(c.t[d], ops.cslice(c.rcat[d], w, uw[d]), ops.cslice(c.g_rcat[d], w, uw[d]), c.g_t[d], bn=c.st_up[d],
+            ops.bnact_bwd(c.t[d], ops.cslice(c.rcat[d], self.uoff[d], uw[d]), ops.cslice(c.g_rcat[d], self.uoff[d], uw[d]), c.g_t[d], bn=c.st_up[d],
                           gamma=bn.weight.data, beta=bn.bias.data, bn_eval=not c.train, act=ACT_RELU, drop_p=drop,
                           seed=c.iter_seed * 64 + d, dgamma=bn.weight.grad if wgrad else None,
                           dbeta=bn.bias.grad if wgrad else None)

@@ -225,7 +225,10 @@ class Pix2PixModel(nn.Module):
         # ---- engines
         self.G = engine.UnetEngine(self.netG, opt.num_downs, dev, use_dropout=not opt.no_dropout)
         self.D = engine.PatchGANEngine(self.netD, bool(opt.darts_discriminator), opt.threshold, dev)
-        self.T = [engine.ConvOp(t.weight, None, 1, 1, 0, False) for t in self.transform_convs]
+        # the last two hooked features are concat buffers (skip | up path): their channel dimension is split
+        t_split = [0, 0, self.G.width[3], self.G.width[1]]
+        self.T = [engine.ConvOp(t.weight, None, 1, 1, 0, False, col_split=sp)
+                  for t, sp in zip(self.transform_convs, t_split)]
         self.refresh_weights()
 
         self.optimizers += [self.optimizer_G, self.optimizer_D]

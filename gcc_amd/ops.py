@@ -195,13 +195,14 @@ class PackPlan:
         items = []
         for i, c in enumerate(convs):
             rows, cols, taps = c.rows, c.cols, c.k * c.k
-            colsp, rowsp = ceil8(cols), ceil8(rows)
-            D[i] = _lib.pack_desc_t(c.weight.data_ptr(), c.w.data_ptr(), c.wt.data_ptr(), rows, taps, cols, colsp, rowsp, 0)
-            for a in range((rows * taps * colsp + 2047) // 2048):
+            colsp, rowsp = c.cols_p, c.rows_p
+            D[i] = _lib.pack_desc_t(c.weight.data_ptr(), c.w.data_ptr(), c.wt.data_ptr(), rows, taps, cols, colsp, rowsp,
+                                    c.row_split, c.col_split, 0)
+            for a in range((rowsp * taps * colsp + 2047) // 2048):
                 items.append((i, 0, a, 0, 0))
             for tap in range(taps):
                 for rb in range((rowsp + 31) // 32):
-                    for cb in range((cols + 31) // 32):
+                    for cb in range((colsp + 31) // 32):
                         items.append((i, 1, tap, rb, cb))
         import numpy as np
         arr = np.zeros((len(items), 6), dtype=np.int32)
@@ -283,6 +284,30 @@ def conv_wgrad(x, dy, dw, k, stride, pad, accumulate=False):
                                stream()), 'gcc_conv_wgrad')
     if e0 is not None:
         PROFILE.end('wgrad_kernel (+ slab reduce)', 2.0 * N * Ho * Wo * Co * k * k * Ci, e0)
+    return dw
+
+
+def seg_phys(n, split):
+    """physical channel count of an n-channel dimension made of two 8-padded parts (split = first part)"""
+    return ceil8(split) + ceil8(n - split) if 0 < split < n else ceil8(n)
+
+
+def conv_wgrad_seg(x, dy, dw, rows, cols, row_split, col_split, k, stride, pad, accumulate=True):
+    """weight gradient when x / dy carry concatenated (8-padded) channel parts; dw is the logical
+    [rows, cols, k, k] channels_last gradient"""
+    xp, N, Ci, H, W, ldx = geom(x)
+    yp, _, Co, Ho, Wo, ldy = geom(dy)
+    # the kernels work on the padded physical channel ranges (pad channels are zeros by the layout contract)
+    Cip, Cop = seg_phys(cols, col_split), seg_phys(rows, row_split)
+    assert Ci in (cols, Cip) and Co in (rows, Cop) and ldx >= Cip and ldy >= Cop, (Ci, Co, rows, cols, row_split, col_split)
+    assert tuple(dw.shape) == (rows, cols, k, k) and dw.dtype == torch.float32
+    d = conv_desc(N, H, W, Cip, Cop, k, stride, pad, ldx, ldy)
+    ws = workspace(lib().gcc_conv_wgrad_workspace(C.byref(d)), x.device, 'wgrad')
+    e0 = PROFILE.begin() if PROFILE.active else None
+    check(lib().gcc_conv_wgrad_seg(C.byref(d), xp, yp, dw.data_ptr(), rows, cols, row_split, col_split, int(accumulate),
+                                   ws.data_ptr(), ws.numel(), stream()), 'gcc_conv_wgrad_seg')
+    if e0 is not None:
+        PROFILE.end('wgrad_kernel (+ slab reduce)', 2.0 * N * Ho * Wo * rows * k * k * cols, e0)
     return dw
 
 

@@ -95,6 +95,12 @@ size_t gcc_conv_wgrad_workspace(const gcc_conv_t* c);
 int gcc_conv_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float* dw, int accumulate,
                    void* ws, size_t ws_bytes, gcc_stream_t stream);
 
+/* weight gradient when channel dimensions are concatenations (see gcc_pack_desc_t): `c` describes the
+ * PHYSICAL problem (c->Co = padded rows, c->Ci = padded cols); dw is the logical master-layout gradient
+ * [rows][taps][cols]. */
+int gcc_conv_wgrad_seg(const gcc_conv_t* c, const void* x, const void* dy, float* dw, int rows, int cols,
+                       int row_split, int col_split, int accumulate, void* ws, size_t ws_bytes, gcc_stream_t stream);
+
 /* fp32 master [rows][taps][cols] -> bf16 W [rows][taps][ceil8(cols)] and Wt [cols][taps][ceil8(rows)].
  * Either output may be NULL. */
 int gcc_pack_weights(const float* master, int rows, int taps, int cols, void* w, void* wt,
@@ -102,7 +108,11 @@ int gcc_pack_weights(const float* master, int rows, int taps, int cols, void* w,
 
 /* multi-tensor form: DEVICE arrays built once per optimizer group.  kind 0: W chunk `a` (2048 output
  * elements); kind 1: one 32x32 tile (row block b, column block c) of tap `a` for Wt. */
-typedef struct { const float* master; void* w; void* wt; int rows, taps, cols, colsp, rowsp; int pad_; } gcc_pack_desc_t;
+/* rows / cols are the master's logical sizes; row_split / col_split (0 = none) say that the dimension is
+ * a concatenation whose first part has that many channels: each part is padded to 8 channels in the
+ * packings (W = [rowsp][taps][colsp], Wt = [colsp][taps][rowsp], rowsp/colsp = padded physical sizes),
+ * matching activation buffers in which the two tensors sit in 8-aligned channel slices. */
+typedef struct { const float* master; void* w; void* wt; int rows, taps, cols, colsp, rowsp, row_split, col_split, pad_; } gcc_pack_desc_t;
 typedef struct { int tensor, kind, a, b, c, pad_; } gcc_pack_item_t;
 int gcc_pack_weights_multi(const gcc_pack_desc_t* descs, const gcc_pack_item_t* items, int nitems,
                            gcc_stream_t stream);

@@ -383,6 +383,35 @@ def unet_shapes(ngf: int, num_downs: int = 8, in_nc: int = 3, out_nc: int = 3) -
     return shp
 
 
+def unet_shapes_cfg(filter_cfgs: Sequence[int], channel_cfgs: Sequence[int], in_nc: int = 3, out_nc: int = 3):
+    """Shapes of UnetGenertor(filter_cfgs, channel_cfgs), num_downs = 8, no block removed
+    (models/Pix2Pix.py:85-127; index layout in SURVEY.md Appendix A.1)."""
+    f, c = [int(v) for v in filter_cfgs], [int(v) for v in channel_cfgs]
+    D = 8
+    shp: Dict[str, Tuple[int, ...]] = OrderedDict()
+
+    def bn(key, ch):
+        for sfx, v in (('weight', (ch,)), ('bias', (ch,)), ('running_mean', (ch,)), ('running_var', (ch,)),
+                       ('num_batches_tracked', ())):
+            shp[key + '.' + sfx] = v
+    shp['model.model.0.weight'] = (f[0], in_nc, 4, 4)
+    for d in range(1, D):
+        p = unet_block_prefix(d)
+        shp[p + '.model.1.weight'] = (f[d], c[d - 1], 4, 4)
+        if d < D - 1:
+            bn(p + '.model.2', f[d])
+    p = unet_block_prefix(D - 1)
+    shp[p + '.model.3.weight'] = (c[7], f[8], 4, 4)
+    bn(p + '.model.4', f[8])
+    for d in range(D - 2, 0, -1):
+        p = unet_block_prefix(d)
+        shp[p + '.model.5.weight'] = (c[14 - d], f[15 - d], 4, 4)
+        bn(p + '.model.6', f[15 - d])
+    shp['model.model.3.weight'] = (c[14], out_nc, 4, 4)
+    shp['model.model.3.bias'] = (out_nc,)
+    return shp
+
+
 def patchgan_shapes(ndf: int, in_nc: int = 6, masked: bool = False, n_layers: int = 3):
     shp: Dict[str, Tuple[int, ...]] = OrderedDict()
     lay = patchgan_layout(masked, n_layers)

@@ -21,6 +21,7 @@ Fixtures
   ops.npz               DifferentiableOP fwd/bwd (alpha <,==,> tau), GANLoss x4 modes, gram,
                         LambdaLR values, init_weights statistics
   options.json          options.parse() results for 7 command lines (flag surface + per-model overrides)
+  pix2pix_pruned_d8.npz pruned student built from filter_cfgs/channel_cfgs with irregular widths: eval image + 1 iteration
   prune_d8.npz          scale_prune / norm_prune cfgs + max_min_* at several thresholds (ngf 8)
 """
 import copy
@@ -326,6 +327,38 @@ def fixture_prune_d8():
     print('prune_d8 ok: bn cfg@1.0 =', list(out['bn.f.3']))
 
 
+def fixture_pruned_d8():
+    """pruned student (irregular widths from scale_prune at threshold 1.0 of the prune_d8 model): eval image and
+    one plain training iteration (recipe weights, seed 401/402)"""
+    z = np.load(os.path.join(HERE, 'prune_d8.npz'))
+    f, c = [int(v) for v in z['bn.f.3']], [int(v) for v in z['bn.c.3']]
+    opt = parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '-1', '--ngf', '8', '--ndf', '8',
+                 '--no_dropout'])
+    from models import get_model_class
+    model = get_model_class(opt)(opt, filter_cfgs=f, channel_cfgs=c)
+    load_recipe(model.netG, 401)
+    load_recipe(model.netD, 402)
+    out = {'f': np.array(f), 'c': np.array(c), 'seeds': np.array([401, 402]), 'direction': np.array(opt.direction)}
+    g = torch.Generator().manual_seed(8)
+    A = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    B = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    out['A'], out['B'] = A.numpy(), B.numpy()
+    model.model_eval()
+    model.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
+    with torch.no_grad():
+        model.forward()
+    out['eval.fake_B'] = model.fake_B.numpy().copy()
+    model.model_train()
+    model.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
+    model.optimize_parameters()
+    out['train.fake_B'] = model.fake_B.detach().numpy().copy()
+    for k, v in model.get_current_losses().items():
+        out['loss.%s' % k] = np.array(v, dtype=np.float64)
+    sd_np_sampled('final.G.', model.netG.state_dict(), out)
+    np.savez_compressed(os.path.join(HERE, 'pix2pix_pruned_d8.npz'), **out)
+    print('pix2pix_pruned_d8 ok: f =', f)
+
+
 def fixture_options():
     import json
     from options import options
@@ -356,3 +389,4 @@ if __name__ == '__main__':
     fixture_gcc_d6()
     fixture_pretrain_d6()
     fixture_prune_d8()
+    fixture_pruned_d8()

@@ -216,3 +216,27 @@ def test_prune_cfgs_bit_exact(golden_dir):
         f, c = O.norm_prune_cfg(G, float(t), ngf=8)
         assert f == [int(v) for v in z['norm.f.%d' % i]], (i, t)
         assert c == [int(v) for v in z['norm.c.%d' % i]], (i, t)
+
+
+def test_pruned_student_irregular_widths(golden_dir):
+    """generator built from filter_cfgs / channel_cfgs (widths such as 6, 21, 31, 29): eval image and one
+    training iteration against the reference"""
+    z = load(golden_dir, 'pix2pix_pruned_d8.npz')
+    f, c = [int(v) for v in z['f']], [int(v) for v in z['c']]
+    sG, sD = [int(v) for v in z['seeds']]
+    G = recipe_state_dict(O.unet_shapes_cfg(f, c), sG)
+    D = recipe_state_dict(O.patchgan_shapes(8, 6, False), sD)
+    A, B = torch.from_numpy(z['A']), torch.from_numpy(z['B'])
+    real_A = A if str(z['direction']) == 'AtoB' else B
+    with torch.no_grad():
+        out = O.unet_forward(G, real_A, 8, train=False)
+    np.testing.assert_allclose(out.numpy(), z['eval.fake_B'], atol=2e-5)
+    opt = O.Opt(ngf=8, ndf=8, num_downs=8, no_dropout=True, darts_discriminator=False, online_distillation=False,
+                direction=str(z['direction']))
+    m = O.Pix2PixOracle(opt, G, D, masked=False)
+    m.set_input(A, B)
+    m.optimize_parameters()
+    np.testing.assert_allclose(m.fake_B.numpy(), z['train.fake_B'], atol=2e-5)
+    for k in ('G_GAN', 'G_L1', 'D_real', 'D_fake'):
+        assert abs(m.losses[k] - float(z['loss.' + k])) < 1e-4 * max(1, abs(m.losses[k]))
+    _compare_sd(m.G, z, 'final.G.', atol=2e-5)

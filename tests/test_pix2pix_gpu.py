@@ -260,3 +260,51 @@ def test_gradients_vs_oracle(golden_dir):
         if t == 'alpha':
             check((t, k), sd[k].grad)
     assert not bad, bad
+
+
+def test_pruned_student_irregular_widths(golden_dir):
+    """student built from filter_cfgs / channel_cfgs with widths that are not multiples of 8 (6, 21, 31, 29 ...):
+    concat buffers hold the two parts in 8-aligned slices, weights are packed / folded through the segment
+    maps.  Eval image, training-mode image, losses and post-step weights against the reference golden."""
+    from tests.golden.recipe import sample_idx
+    z = load(golden_dir, 'pix2pix_pruned_d8.npz')
+    f, c = [int(v) for v in z['f']], [int(v) for v in z['c']]
+    from gcc_amd.options import options
+    from gcc_amd.models import get_model_class
+    opt = options.parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '0', '--ngf', '8',
+                         '--ndf', '8', '--no_dropout'])
+    opt.isTrain = True
+    model = get_model_class(opt)(opt, filter_cfgs=f, channel_cfgs=c)
+    sG, sD = [int(v) for v in z['seeds']]
+    load_recipe(model.netG, sG)
+    load_recipe(model.netD, sD)
+    model.refresh_weights()
+    data = {'A': torch.from_numpy(z['A']), 'B': torch.from_numpy(z['B']), 'A_paths': ['a'], 'B_paths': ['b']}
+    model.model_eval()
+    model.set_input(data)
+    model.forward()
+    e = (model.fake_B.cpu() - torch.from_numpy(z['eval.fake_B'])).abs()
+    print('pruned eval fake_B: max %.4g mean %.4g' % (e.max(), e.mean()))
+    assert e.max() <= 2e-2 and e.mean() <= 3e-3
+    model.model_train()
+    model.set_input(data)
+    model.optimize_parameters()
+    e = (model.fake_B.cpu() - torch.from_numpy(z['train.fake_B'])).abs()
+    print('pruned train fake_B: max %.4g mean %.4g' % (e.max(), e.mean()))
+    assert e.max() <= 2e-2 and e.mean() <= 3e-3
+    losses = model.get_current_losses()
+    for k in ('G_GAN', 'G_L1', 'D_real', 'D_fake'):
+        ref = float(z['loss.' + k])
+        assert abs(losses[k] - ref) <= 3e-2 * max(1.0, abs(ref)), (k, losses[k], ref)
+    sd = model.netG.state_dict()
+    for k in z.files:
+        if k.startswith('final.G.'):
+            name = k[len('final.G.'):]
+            g = sd[name].detach().float().cpu().reshape(-1)
+            g = g[sample_idx(g.numel())].numpy()
+            ref = z[k]
+            if name.endswith('num_batches_tracked'):
+                assert int(g[0]) == int(ref.reshape(-1)[0])
+                continue
+            tol = 3e-2 * max(1.0, float(np.abs(ref).max())) if 'running' in name else 2.2 * opt.lr + 1e-6
+            assert float(np.abs(g - ref).max()) <= tol, (name, float(np.abs(g - ref).max()), tol)
