@@ -566,42 +566,17 @@ class Pix2PixModel(nn.Module):
         return self.filter_cfgs, self.channel_cfgs
 
     # -- pruning cfgs (integer logic on host copies of the small per-channel vectors) ---------------
-    def _bn_names(self):
-        D = self.opt.num_downs
-        pre = self.G.prefix
-        return [pre(d) + '.model.2' for d in range(1, D - 1)] + [pre(D - 1) + '.model.4'] + \
-               [pre(d) + '.model.6' for d in range(D - 2, 0, -1)]
+    def _bn_sd(self):
+        return {k: v.detach().cpu() for k, v in self.netG.state_dict().items() if k.endswith('.weight') and v.dim() == 1}
 
     def scale_prune_cfg(self, threshold):
-        """filter_cfgs / channel_cfgs of models/Pix2Pix.py:823-860 (count of gamma > tau per BatchNorm)"""
-        sd = {k: v.detach().cpu() for k, v in self.netG.state_dict().items() if k.endswith('.weight') and v.dim() == 1}
-        ngf, D = self.opt.ngf, self.opt.num_downs
-        f, c = [ngf], [ngf]
-        inner_up = self.G.prefix(D - 1) + '.model.4'
-        last_down = self.G.prefix(D - 2) + '.model.2'
-        up_flag, up_num = False, 0
-        for name in self._bn_names():
-            cnt = int((sd[name + '.weight'] > threshold).sum())
-            f.append(cnt)
-            if name == inner_up:
-                up_flag = True
-                if cnt == 0:
-                    f[-2] = 0
-            if up_flag:
-                up_num += 1
-                if f[-2 * up_num] == 0:
-                    f[-1] = 0
-                    cnt = 0
-                c.append(cnt + f[-1 - 2 * up_num])
-            else:
-                c.append(cnt)
-            if name == last_down:
-                f.append(0 if f[-1] == 0 else ngf * 8)
-                c.append(0 if f[-2] == 0 else ngf * 8)
-        return f, c
+        from ..utils import prune_util
+        if torch.is_tensor(threshold):
+            threshold = threshold.detach().cpu()
+        return prune_util.scale_prune_cfg(self._bn_sd(), threshold, self.opt.ngf, self.opt.num_downs)
 
     def scale_prune(self, threshold):
-        f, c = self.scale_prune_cfg(float(threshold))
+        f, c = self.scale_prune_cfg(threshold)
         return Pix2PixModel(self.opt, filter_cfgs=f, channel_cfgs=c)
 
     def prune(self, threshold, lottery_path=None):
@@ -610,19 +585,8 @@ class Pix2PixModel(nn.Module):
         raise NotImplementedError('only scale pruning is on the MI355X path yet (norm / resnet pruning: next)')
 
     def max_min_bn_scale(self):
-        p3 = self.G.prefix(5)
-        prunable = [p3 + '.model.2', p3 + '.model.3.model.2', p3 + '.model.3.model.3.model.4',
-                    p3 + '.model.3.model.6', p3 + '.model.6']
-        sd = self.netG.state_dict()
-        un_max, pr_max, mn = float('inf'), -float('inf'), float('inf')
-        for name in self._bn_names():
-            w = sd[name + '.weight'].detach().cpu()
-            if name in prunable:
-                pr_max = max(float(w.max()), pr_max)
-            else:
-                un_max = min(float(w.max()), un_max)
-            mn = min(float(w.min()), mn)
-        return min(pr_max, un_max), mn
+        from ..utils import prune_util
+        return prune_util.max_min_bn_scale(self._bn_sd(), self.opt.num_downs)
 
 
 def _portable(sd):

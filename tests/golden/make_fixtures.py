@@ -22,6 +22,7 @@ Fixtures
                         LambdaLR values, init_weights statistics
   options.json          options.parse() results for 7 command lines (flag surface + per-model overrides)
   pix2pix_pruned_d8.npz pruned student built from filter_cfgs/channel_cfgs with irregular widths: eval image + 1 iteration
+  prune_search_d8.npz   binarysearch_threshold trajectory end points with a documented thop stand-in
   prune_d8.npz          scale_prune / norm_prune cfgs + max_min_* at several thresholds (ngf 8)
 """
 import copy
@@ -359,6 +360,69 @@ def fixture_pruned_d8():
     print('pix2pix_pruned_d8 ok: f =', f)
 
 
+def thop_standin_profile(model, inputs, verbose=False):
+    """Stand-in for thop.profile (thop is not installed here and the reference does not pin a version): counts,
+    with forward hooks on a real forward pass, Conv2d / ConvTranspose2d as out_elements * (Cin/groups) * kh * kw
+    and BatchNorm2d as 2 * elements -- the convention SURVEY.md section 8(c) documents for the reference's budgets."""
+    import torch.nn as nn
+    total = [0]
+    hooks = []
+
+    def conv_hook(m, i, o):
+        total[0] += o.numel() * (m.in_channels // m.groups) * m.kernel_size[0] * m.kernel_size[1]
+
+    def bn_hook(m, i, o):
+        total[0] += 2 * i[0].numel()
+    for m in model.modules():
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            hooks.append(m.register_forward_hook(conv_hook))
+        elif isinstance(m, nn.BatchNorm2d):
+            hooks.append(m.register_forward_hook(bn_hook))
+    was = model.training
+    model.eval()
+    with torch.no_grad():
+        model(*inputs)
+    model.train(was)
+    for h in hooks:
+        h.remove()
+    return float(total[0]), float(sum(p.numel() for p in model.parameters()))
+
+
+def fixture_prune_search():
+    """the reference's binarysearch_threshold (utils/prune_util.py:20-47) on the prune_d8 model, with the thop
+    stand-in above: returned threshold (fp32) and the cfgs of model.prune(threshold) for three budgets"""
+    import utils.prune_util as pu
+    pu.profile = thop_standin_profile
+    opt = parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '-1', '--ngf', '8', '--ndf', '4',
+                 '--scale_prune'])
+    from models import get_model_class
+    model = get_model_class(opt)(opt)
+    load_recipe(model.netG, 301)
+    with torch.no_grad():
+        gsp = torch.Generator().manual_seed(302)
+        for m in model.netG.modules():
+            if m.__class__.__name__ == 'BatchNorm2d':
+                m.weight.copy_(1.0 + 0.02 * torch.randn(m.weight.shape, generator=gsp))
+    full, _ = pu.get_flops_parms(model.netG, model.device, opt)
+    out = {'full_macs': np.array(full), 'seed_G': np.array(301)}
+    for i, frac in enumerate((0.45, 0.6, 0.8)):
+        target = round(full * frac, 3)
+        try:
+            thr = pu.binarysearch_threshold(model, target)
+            pm = model.prune(thr)
+            f, c = pm.get_cfg()
+            macs, _ = pu.get_flops_parms(pm.netG, pm.device, opt)
+            out['s%d.found' % i] = np.array(1)
+            out['s%d.threshold' % i] = np.array(float(thr), dtype=np.float32)
+            out['s%d.f' % i], out['s%d.c' % i] = np.array(f), np.array(c)
+            out['s%d.macs' % i] = np.array(macs)
+        except NotImplementedError:
+            out['s%d.found' % i] = np.array(0)
+        out['s%d.target' % i] = np.array(target)
+    np.savez_compressed(os.path.join(HERE, 'prune_search_d8.npz'), **out)
+    print('prune_search ok', {k: (v.tolist() if v.size < 3 else '...') for k, v in out.items() if 'thr' in k or 'found' in k or 'macs' in k})
+
+
 def fixture_options():
     import json
     from options import options
@@ -390,3 +454,4 @@ if __name__ == '__main__':
     fixture_pretrain_d6()
     fixture_prune_d8()
     fixture_pruned_d8()
+    fixture_prune_search()

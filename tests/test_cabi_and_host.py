@@ -131,3 +131,35 @@ def test_lr_schedule_matches_reference(golden_dir):
         sch.step()
         got.append(opt.param_groups[0]['lr'])
     np.testing.assert_allclose(got, z['lr_after_epoch'], rtol=1e-12, atol=1e-15)
+
+
+def test_prune_cfgs_and_budget_search_match_reference(golden_dir):
+    """integer prune contract (bit exact): cfg lists at several thresholds, the thop-convention MAC count and the
+    end point of the reference's binary search (run in the fixture script with a documented thop stand-in)"""
+    from oracle import gcc_oracle as O
+    from gcc_amd.utils import prune_util as PU
+    from tests.golden.recipe import recipe_state_dict
+    z = np.load(os.path.join(golden_dir, 'prune_d8.npz'))
+    G = recipe_state_dict(O.unet_shapes(8, 8), int(z['seed_G']))
+    gsp = torch.Generator().manual_seed(302)
+    for name in PU.bn_names(8):
+        G[name + '.weight'] = 1.0 + 0.02 * torch.randn(G[name + '.weight'].shape, generator=gsp)
+    mx, mn = PU.max_min_bn_scale(G)
+    assert [float(mx), float(mn)] == [float(v) for v in z['bn.max_min']]
+    for i, t in enumerate(z['bn.thresholds']):
+        f, c = PU.scale_prune_cfg(G, float(t), 8)
+        assert f == [int(v) for v in z['bn.f.%d' % i]] and c == [int(v) for v in z['bn.c.%d' % i]], i
+    s = np.load(os.path.join(golden_dir, 'prune_search_d8.npz'))
+    opt = type('O', (), dict(scale_prune=True, num_downs=8, ngf=8, dataroot='./database/cityscapes/', load_size=256))()
+    full = PU.cfg_macs(opt, [8, 16, 32, 64, 64, 64, 64, 64, 64, 64, 64, 64, 32, 16, 8],
+                       [8, 16, 32, 64, 64, 64, 64, 64, 128, 128, 128, 128, 64, 32, 16])
+    assert abs(full - float(s['full_macs'])) < 1e-9
+    from gcc_amd.models.Pix2Pix import UnetGenertor
+    assert abs(PU.unet_macs(UnetGenertor(3, 3, 8, ngf=8))[0] - float(s['full_macs'])) < 1e-9
+    for i in range(3):
+        if int(s['s%d.found' % i]):
+            thr = PU.binarysearch_threshold_sd(G, opt, float(s['s%d.target' % i]))
+            assert np.float32(float(thr)) == np.float32(s['s%d.threshold' % i]), i
+            f, c = PU.scale_prune_cfg(G, thr, 8)
+            assert f == [int(v) for v in s['s%d.f' % i]] and c == [int(v) for v in s['s%d.c' % i]]
+            assert abs(PU.cfg_macs(opt, f, c) - float(s['s%d.macs' % i])) < 1e-9
