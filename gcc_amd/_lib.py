@@ -27,14 +27,15 @@ class epilogue_t(C.Structure):
 class bnact_t(C.Structure):
     _fields_ = [('scale', C.c_void_p), ('shift', C.c_void_p), ('gate', C.c_void_p), ('gate_after_act', C.c_int),
                 ('act', C.c_int), ('slope', C.c_float), ('act2', C.c_int), ('drop_p', C.c_float),
-                ('seed', C.c_uint64)]
+                ('seed', C.c_uint64), ('groups', C.c_int), ('ld_residual', C.c_int), ('residual', C.c_void_p)]
 
 
 class bnact_bwd_t(C.Structure):
     _fields_ = [('bn', C.c_int), ('bn_eval', C.c_int), ('mean', C.c_void_p), ('rstd', C.c_void_p),
                 ('gamma', C.c_void_p), ('beta', C.c_void_p), ('gate', C.c_void_p), ('gate_after_act', C.c_int),
                 ('act', C.c_int), ('slope', C.c_float), ('act2', C.c_int), ('drop_p', C.c_float),
-                ('seed', C.c_uint64), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('dalpha', C.c_void_p)]
+                ('seed', C.c_uint64), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('dalpha', C.c_void_p),
+                ('groups', C.c_int), ('pad_', C.c_int)]
 
 
 class adam_tensor_t(C.Structure):
@@ -79,6 +80,13 @@ PROTOTYPES = {
     'gcc_nhwc_copy': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _Z, _P]),
     'gcc_nhwc_add': (_I, [_P, _I, _I, _P, _I, _I, _I, _Z, _P]),
     'gcc_bn_finalize': (_I, [_P, _I, _I, C.c_double, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    'gcc_in_finalize': (_I, [_P, _I, _I, _I, C.c_double, _F, _P, _P, _P, _P, _P]),
+    'gcc_channel_stats_tiles': (_I, [_Z, _I]),
+    'gcc_channel_stats': (_I, [_P, _I, _I, _I, _Z, _I, _P, _P]),
+    'gcc_reflect_pad': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'gcc_dwconv3x3_reflect': (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    'gcc_dwconv3x3_wgrad_workspace': (_Z, [_I, _I, _I, _I]),
+    'gcc_dwconv3x3_reflect_wgrad': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
     'gcc_bn_eval_coeffs': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     'gcc_bnact_fwd': (_I, [C.POINTER(bnact_t), _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _Z, _P]),
     'gcc_bnact_bwd_workspace': (_Z, [_I, _Z]),

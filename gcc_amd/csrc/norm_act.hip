@@ -38,6 +38,13 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     __shared__ double sh[2][32][33];
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
+    {   // group (InstanceNorm: one per image) on blockIdx.y
+        const size_t g = blockIdx.y;
+        part += g * (size_t)tiles * 2 * C;
+        if (mean) mean += g * C;
+        if (rstd) rstd += g * C;
+        scale += g * C; shift += g * C;
+    }
     double s = 0.0, ss = 0.0;
     if (c < C) {
         for (int t = pl; t < tiles; t += 32) {
@@ -99,6 +106,8 @@ struct FwdArgs {
     bf16_t* y; int ldy, yoff;
     bf16_t* y2; int ldy2, y2off;
     int C; size_t pixels; Layout L;
+    int groups;                       // > 1: InstanceNorm -- blockIdx.y = image, scale/shift are [groups][C]
+    const bf16_t* res; int ldres;     // optional residual added to y after the activation
 };
 
 __global__ __launch_bounds__(256) void bnact_fwd_kernel(const FwdArgs a) {
@@ -106,18 +115,24 @@ __global__ __launch_bounds__(256) void bnact_fwd_kernel(const FwdArgs a) {
     const int pl = threadIdx.x >> a.L.sh;
     if (ch >= a.L.CH) return;
     const int c0 = ch * 8;
+    const size_t gi = blockIdx.y;
+    const bf16_t* xg = a.x + gi * a.pixels * a.ldx;
+    bf16_t* yg = a.y ? a.y + gi * a.pixels * a.ldy : nullptr;
+    bf16_t* y2g = a.y2 ? a.y2 + gi * a.pixels * a.ldy2 : nullptr;
+    const bf16_t* rg = a.res ? a.res + gi * a.pixels * a.ldres : nullptr;
+    const size_t po = a.groups > 1 ? gi * a.C : 0;
     float sc[8], sf[8], gm[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int c = c0 + j;
         const bool v = c < a.C;
-        sc[j] = (v && a.p.scale) ? a.p.scale[c] : 1.f;
-        sf[j] = (v && a.p.shift) ? a.p.shift[c] : 0.f;
+        sc[j] = (v && a.p.scale) ? a.p.scale[po + c] : 1.f;
+        sf[j] = (v && a.p.shift) ? a.p.shift[po + c] : 0.f;
         gm[j] = v ? (a.p.gate ? a.p.gate[c] : 1.f) : 0.f;   // pad channels come out as exact zeros
     }
     const float keep_scale = a.p.drop_p > 0.f ? 1.f / (1.f - a.p.drop_p) : 1.f;
     for (size_t pix = (size_t)blockIdx.x * a.L.PPB + pl; pix < a.pixels; pix += (size_t)gridDim.x * a.L.PPB) {
-        const i32x4 raw = *(const i32x4*)(a.x + pix * a.ldx + a.xoff + c0);
+        const i32x4 raw = *(const i32x4*)(xg + pix * a.ldx + a.xoff + c0);
         float v[8], o1[8], o2[8];
         unpack8(raw, v);
 #pragma unroll
@@ -136,8 +151,14 @@ __global__ __launch_bounds__(256) void bnact_fwd_kernel(const FwdArgs a) {
             }
             o2[j] = apply_act(z, a.p.act2, a.p.slope);
         }
-        if (a.y) *(i32x4*)(a.y + pix * a.ldy + a.yoff + c0) = pack8(o1);
-        if (a.y2) *(i32x4*)(a.y2 + pix * a.ldy2 + a.y2off + c0) = pack8(o2);
+        if (rg) {
+            float rv[8];
+            unpack8(*(const i32x4*)(rg + pix * a.ldres + c0), rv);
+#pragma unroll
+            for (int j = 0; j < 8; j++) o1[j] += rv[j];
+        }
+        if (yg) *(i32x4*)(yg + pix * a.ldy + a.yoff + c0) = pack8(o1);
+        if (y2g) *(i32x4*)(y2g + pix * a.ldy2 + a.y2off + c0) = pack8(o2);
     }
 }
 
@@ -154,7 +175,27 @@ struct BwdArgs {
     float* totals;    // [3][C8]
     int in_act;       // activation already applied to x by the producer (conv epilogue): dx *= act'(x)
     float in_slope;
+    int groups;       // > 1: InstanceNorm -- blockIdx.y = image; mean/rstd/partial/totals are per group
+    int nblocks;      // reduce-pass workgroups per group
 };
+
+// per-group view of the arguments (group = blockIdx.y)
+__device__ __forceinline__ BwdArgs group_view(const BwdArgs& a0) {
+    BwdArgs a = a0;
+    if (a0.groups > 1) {
+        const size_t g = blockIdx.y;
+        a.x += g * a0.pixels * a0.ldx;
+        if (a.y) a.y += g * a0.pixels * a0.ldy;
+        a.g1 += g * a0.pixels * a0.ldg1;
+        if (a.g2) a.g2 += g * a0.pixels * a0.ldg2;
+        a.dx += g * a0.pixels * a0.lddx;
+        if (a.p.mean) a.p.mean = (const float*)a.p.mean + g * a0.C;
+        if (a.p.rstd) a.p.rstd = (const float*)a.p.rstd + g * a0.C;
+        a.partial += g * (size_t)a0.nblocks * 3 * a0.C8;
+        a.totals += g * 3 * (size_t)a0.C8;
+    }
+    return a;
+}
 
 // pass 1: dz (-> dx buffer) and per-block partial sums {sum dz, sum dz*xhat, sum g*zd}
 // GATE: a gate mask and/or d(alpha) is involved (needs z = bn(x) and a third sum); DROP: dropout.
@@ -163,8 +204,9 @@ struct BwdArgs {
 // V = channels per thread (4: 8-byte accesses, half the per-channel state -> twice the occupancy)
 // 1024-thread workgroups: 4x fewer per-block partial rows for the finalize to fold at equal waves in flight
 template <bool GATE, bool DROP, int V>
-__global__ __launch_bounds__(1024) void bnact_bwd_reduce_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(1024) void bnact_bwd_reduce_kernel(const BwdArgs a0) {
     __shared__ float red[GATE ? 3 : 2][1024][V + 1];
+    const BwdArgs a = group_view(a0);
     const int ch = threadIdx.x & (a.L.CHP - 1);
     const int pl = threadIdx.x >> a.L.sh;
     const int c0 = ch * V;
@@ -220,8 +262,16 @@ __global__ __launch_bounds__(1024) void bnact_bwd_reduce_kernel(const BwdArgs a)
                     }
                     s2[j] += ga;
                 } else {
-                    // no gate: y (saved) or x itself (identity activation) gives the activation derivative
-                    const float yo = a.y ? yv[j] : (DROP ? apply_act(zd, a.p.act, a.p.slope) : xv[j]);
+                    // no gate: the saved output y gives the activation derivative; without it, re-derive the
+                    // activation input (rare path: outputs that had a residual added are not usable as y)
+                    float yo;
+                    if (a.y) yo = yv[j];
+                    else if (DROP) yo = apply_act(zd, a.p.act, a.p.slope);
+                    else if (a.p.bn) {
+                        const int cc = c0 + j < a.C ? c0 + j : 0;
+                        const float gmm = a.p.gamma ? a.p.gamma[cc] : 1.f, bta = a.p.beta ? a.p.beta[cc] : 0.f;
+                        yo = apply_act((xv[j] - mu[j]) * rs[j] * gmm + bta, a.p.act, a.p.slope);
+                    } else yo = xv[j];
                     g = g1v[j] * act_grad_from_out(yo, a.p.act, a.p.slope);
                     if (a.g2) g += g2v[j] * act_grad_from_out(yo, a.p.act2, a.p.slope);
                 }
@@ -260,8 +310,9 @@ __global__ __launch_bounds__(1024) void bnact_bwd_reduce_kernel(const BwdArgs a)
 }
 
 // pass 2: totals over blocks; parameter gradients (+=)
-__global__ __launch_bounds__(1024) void bnact_bwd_finalize_kernel(const BwdArgs a, int blocks) {
+__global__ __launch_bounds__(1024) void bnact_bwd_finalize_kernel(const BwdArgs a0, int blocks) {
     __shared__ double sh[3][32][33];
+    const BwdArgs a = group_view(a0);
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double t[3] = {0.0, 0.0, 0.0};
@@ -286,7 +337,8 @@ __global__ __launch_bounds__(1024) void bnact_bwd_finalize_kernel(const BwdArgs 
 }
 
 // pass 3 (training BN only): dx = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)), in place over dz
-__global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(const BwdArgs a0) {
+    const BwdArgs a = group_view(a0);
     const int ch = threadIdx.x & (a.L.CHP - 1);
     const int pl = threadIdx.x >> a.L.sh;
     if (ch >= a.L.CH) return;
@@ -361,6 +413,43 @@ __global__ __launch_bounds__(1024) void channel_sum_finalize_kernel(const float*
     }
 }
 
+// per-channel sum / sum of squares in the conv-epilogue partial format: out[group][block][2][C]
+struct StatArgs { const bf16_t* x; int ld, off; int C; size_t pixels; Layout L; float* out; int nblocks; };
+__global__ __launch_bounds__(256) void channel_stats_g_kernel(const StatArgs a) {
+    __shared__ float red[2][256][9];
+    const int ch = threadIdx.x & (a.L.CHP - 1);
+    const int pl = threadIdx.x >> a.L.sh;
+    const int c0 = ch * 8;
+    const bool active = ch < a.L.CH;
+    const size_t g = blockIdx.y;
+    const bf16_t* xg = a.x + g * a.pixels * a.ld;
+    float s[8], ss[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] = ss[j] = 0.f;
+    if (active) {
+        for (size_t pix = (size_t)blockIdx.x * a.L.PPB + pl; pix < a.pixels; pix += (size_t)gridDim.x * a.L.PPB) {
+            float v[8];
+            unpack8(*(const i32x4*)(xg + pix * a.ld + a.off + c0), v);
+#pragma unroll
+            for (int j = 0; j < 8; j++) { s[j] += v[j]; ss[j] += v[j] * v[j]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) { red[0][threadIdx.x][j] = s[j]; red[1][threadIdx.x][j] = ss[j]; }
+    __syncthreads();
+    if (pl == 0 && active) {
+        float* o = a.out + (g * a.nblocks + blockIdx.x) * 2 * (size_t)a.C;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (c0 + j < a.C) {
+                float t0 = 0.f, t1 = 0.f;
+                for (int q = 0; q < a.L.PPB; q++) { t0 += red[0][q * a.L.CHP + ch][j]; t1 += red[1][q * a.L.CHP + ch][j]; }
+                o[c0 + j] = t0; o[a.C + c0 + j] = t1;
+            }
+        }
+    }
+}
+
 __global__ void gate_mask_kernel(const float* alpha, float tau, float* mask, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) {
@@ -373,6 +462,17 @@ __global__ void gate_mask_kernel(const float* alpha, float tau, float* mask, int
 bool aligned8(int a, int b) { return !((a & 7) || (b & 7)); }
 
 }  // namespace
+
+extern "C" int gcc_in_finalize(const float* stats_partial, int tiles_per_group, int groups, int C, double count, float eps,
+                               float* mean, float* rstd, float* scale, float* shift, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!stats_partial || tiles_per_group <= 0 || groups <= 0 || C <= 0 || count <= 0 || !scale || !shift) return GCC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32, groups), dim3(1024), 0, (hipStream_t)stream, stats_partial,
+                       tiles_per_group, C, count, (const float*)nullptr, (const float*)nullptr, eps, 0.f, (float*)nullptr,
+                       (float*)nullptr, mean, rstd, scale, shift);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
 
 extern "C" int gcc_bn_finalize(const float* stats_partial, int tiles, int C, double count, const float* gamma,
                                const float* beta, float eps, float momentum, float* running_mean, float* running_var,
@@ -405,8 +505,11 @@ extern "C" int gcc_bnact_fwd(const gcc_bnact_t* p, const void* x, int ldx, int x
     a.p = *p; a.x = (const bf16_t*)x; a.ldx = ldx; a.xoff = xoff;
     a.y = (bf16_t*)y; a.ldy = ldy; a.yoff = yoff; a.y2 = (bf16_t*)y2; a.ldy2 = ldy2; a.y2off = y2off;
     a.C = C; a.pixels = pixels;
+    a.groups = p->groups > 1 ? p->groups : 1;
+    a.res = (const bf16_t*)p->residual; a.ldres = p->ld_residual;
+    if (a.res && (a.ldres & 7)) return GCC_ERR_BAD_ARG;
     if (!make_layout(C, &a.L)) return GCC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bnact_fwd_kernel, dim3(stream_blocks(pixels, a.L, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bnact_fwd_kernel, dim3(stream_blocks(pixels, a.L, 4), a.groups), dim3(256), 0, (hipStream_t)stream, a);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }
@@ -419,7 +522,7 @@ static int bwd_blocks(size_t pixels, const Layout& L) {
     return (int)b;
 }
 
-extern "C" size_t gcc_bnact_bwd_workspace(int C, size_t pixels) {
+extern "C" size_t gcc_bnact_bwd_workspace(int C, size_t pixels) {      // per group
     Layout L;
     if (C <= 0 || !make_layout(C, &L)) return 0;
     const int C8 = (C + 7) & ~7;
@@ -437,7 +540,9 @@ extern "C" int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_s
     if (!aligned8(ldx, xoff) || !aligned8(ldg1, g1off) || !aligned8(lddx, dxoff)) return GCC_ERR_BAD_ARG;
     if ((y && !aligned8(ldy, yoff)) || (g2 && !aligned8(ldg2, g2off))) return GCC_ERR_BAD_ARG;
     if (p->bn && !p->bn_eval && (!p->mean || !p->rstd)) return GCC_ERR_BAD_ARG;
-    if (ws_bytes < gcc_bnact_bwd_workspace(C, pixels)) return GCC_ERR_WORKSPACE;
+    const int groups = p->groups > 1 ? p->groups : 1;
+    if (ws_bytes < gcc_bnact_bwd_workspace(C, pixels) * groups) return GCC_ERR_WORKSPACE;
+    if (groups > 1 && (p->dgamma || p->dbeta || p->dalpha)) return GCC_ERR_UNSUPPORTED;
     BwdArgs a;
     a.p = *p;
     a.x = (const bf16_t*)x; a.ldx = ldx; a.xoff = xoff;
@@ -449,8 +554,9 @@ extern "C" int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_s
     a.in_act = in_act; a.in_slope = in_slope;
     if (!make_layout(C, &a.L)) return GCC_ERR_UNSUPPORTED;
     const int blocks = bwd_blocks(pixels, a.L);
+    a.groups = groups; a.nblocks = blocks;
     a.partial = (float*)ws;
-    a.totals = a.partial + (size_t)blocks * 3 * a.C8;
+    a.totals = a.partial + (size_t)groups * blocks * 3 * a.C8;
     hipStream_t st = (hipStream_t)stream;
     const bool gate = p->gate != nullptr || p->dalpha != nullptr || p->gate_after_act;
     const bool drop = p->drop_p > 0.f;
@@ -458,16 +564,16 @@ extern "C" int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_s
         BwdArgs r = a;                      // the reduce pass runs 4 channels per thread, 1024 threads per workgroup
         if (!make_layout(C, &r.L, 4)) return GCC_ERR_UNSUPPORTED;
         r.L.PPB = 1024 / r.L.CHP;
-        if (gate && drop) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<true, true, 4>), dim3(blocks), dim3(1024), 0, st, r);
-        else if (gate) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<true, false, 4>), dim3(blocks), dim3(1024), 0, st, r);
-        else if (drop) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<false, true, 4>), dim3(blocks), dim3(1024), 0, st, r);
-        else hipLaunchKernelGGL((bnact_bwd_reduce_kernel<false, false, 4>), dim3(blocks), dim3(1024), 0, st, r);
+        if (gate && drop) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<true, true, 4>), dim3(blocks, groups), dim3(1024), 0, st, r);
+        else if (gate) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<true, false, 4>), dim3(blocks, groups), dim3(1024), 0, st, r);
+        else if (drop) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<false, true, 4>), dim3(blocks, groups), dim3(1024), 0, st, r);
+        else hipLaunchKernelGGL((bnact_bwd_reduce_kernel<false, false, 4>), dim3(blocks, groups), dim3(1024), 0, st, r);
     }
     GCC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3((a.C8 + 31) / 32), dim3(1024), 0, st, a, blocks);
+    hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3((a.C8 + 31) / 32, groups), dim3(1024), 0, st, a, blocks);
     GCC_CHECK_LAUNCH();
     if (p->bn && !p->bn_eval) {
-        hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(stream_blocks(pixels, a.L, 4)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(stream_blocks(pixels, a.L, 4), groups), dim3(256), 0, st, a);
         GCC_CHECK_LAUNCH();
     }
     return GCC_OK;
@@ -510,6 +616,29 @@ extern "C" int gcc_gate_mask(const float* alpha, float tau, float* mask, int C, 
     GCC_ENTER();
     if (!alpha || !mask || C <= 0) return GCC_ERR_BAD_ARG;
     hipLaunchKernelGGL(gate_mask_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, alpha, tau, mask, C);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+// statistics pass for tensors that do not come out of a convolution epilogue (depthwise conv outputs):
+// writes gcc_channel_stats_tiles() partial rows per group in the [tile][2][C] format gcc_*_finalize folds
+extern "C" int gcc_channel_stats_tiles(size_t pixels_per_group, int C) {
+    Layout L;
+    if (C <= 0 || !make_layout(C, &L)) return 0;
+    size_t b = (pixels_per_group + (size_t)L.PPB * 8 - 1) / ((size_t)L.PPB * 8);
+    if (b < 1) b = 1;
+    if (b > 256) b = 256;
+    return (int)b;
+}
+extern "C" int gcc_channel_stats(const void* x, int ld, int off, int C, size_t pixels_per_group, int groups, float* stats,
+                                 gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!x || !stats || C <= 0 || pixels_per_group == 0 || groups <= 0 || !aligned8(ld, off)) return GCC_ERR_BAD_ARG;
+    StatArgs a;
+    a.x = (const bf16_t*)x; a.ld = ld; a.off = off; a.C = C; a.pixels = pixels_per_group; a.out = stats;
+    if (!make_layout(C, &a.L)) return GCC_ERR_UNSUPPORTED;
+    a.nblocks = gcc_channel_stats_tiles(pixels_per_group, C);
+    hipLaunchKernelGGL(channel_stats_g_kernel, dim3(a.nblocks, groups), dim3(256), 0, (hipStream_t)stream, a);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

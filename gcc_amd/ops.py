@@ -367,8 +367,65 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
+def reflect_pad(src, dst, pad, backward=False):
+    """forward: dst [N,C,H+2p,W+2p] = ReflectionPad2d(p)(src); backward: dst [N,C,H,W] = adjoint of it applied to src"""
+    sp, N, Cc, Hs, Ws, lds = geom(src)
+    dp, _, _, Hd, Wd, ldd = geom(dst)
+    H, W = (Hd, Wd) if backward else (Hs, Ws)
+    assert (Hs, Ws) == ((H + 2 * pad, W + 2 * pad) if backward else (H, W))
+    check(lib().gcc_reflect_pad(sp, lds, dp, ldd, N, H, W, Cc, pad, int(backward), stream()), 'gcc_reflect_pad')
+
+
+def dwconv_fwd(x, w, bias, out):
+    xp, N, Cc, H, W, ldx = geom(x)
+    op, _, _, _, _, ldo = geom(out)
+    check(lib().gcc_dwconv3x3_reflect(0, xp, ldx, None, 0, op, ldo, w.data_ptr(), _p(bias), N, H, W, Cc, stream()),
+          'gcc_dwconv3x3_reflect')
+
+
+def dwconv_bwd_data(dy, w, out):
+    yp, N, Cc, H, W, ldy = geom(dy)
+    op, _, _, _, _, ldo = geom(out)
+    check(lib().gcc_dwconv3x3_reflect(1, None, 0, yp, ldy, op, ldo, w.data_ptr(), None, N, H, W, Cc, stream()),
+          'gcc_dwconv3x3_reflect')
+
+
+def dwconv_wgrad(x, dy, dw, dbias):
+    """dw [C,1,3,3] fp32 (+=), dbias [C] (+=)"""
+    xp, N, Cc, H, W, ldx = geom(x)
+    yp, _, _, _, _, ldy = geom(dy)
+    ws = workspace(lib().gcc_dwconv3x3_wgrad_workspace(N, H, W, Cc), x.device, 'dwwgrad')
+    check(lib().gcc_dwconv3x3_reflect_wgrad(xp, ldx, yp, ldy, dw.data_ptr(), _p(dbias), N, H, W, Cc, ws.data_ptr(), ws.numel(),
+                                            stream()), 'gcc_dwconv3x3_reflect_wgrad')
+
+
+class INState:
+    """per-application InstanceNorm statistics: [N][C] mean / rstd / scale / shift"""
+
+    def __init__(self, N, Cc, device):
+        z = torch.zeros((4, N, Cc), dtype=torch.float32, device=device)
+        self.mean, self.rstd, self.scale, self.shift = z[0], z[1], z[2], z[3]
+        self.N = N
+
+
+def channel_stats(x):
+    """per image partial sums of an activation in the conv-epilogue format [N][tiles][2][C]"""
+    xp, N, Cc, H, W, ld = geom(x)
+    tiles = lib().gcc_channel_stats_tiles(H * W, Cc)
+    st = torch.empty((N, tiles, 2, Cc), dtype=torch.float32, device=x.device)
+    check(lib().gcc_channel_stats(xp, ld, 0, Cc, H * W, N, st.data_ptr(), stream()), 'gcc_channel_stats')
+    return st
+
+
+def in_finalize(stats, count, st, eps=1e-5):
+    """stats [N][tiles][2][C] -> per image mean / rstd / scale / shift"""
+    N, tiles, _, Cc = stats.shape
+    check(lib().gcc_in_finalize(stats.data_ptr(), tiles, N, Cc, float(count), eps, st.mean.data_ptr(), st.rstd.data_ptr(),
+                                st.scale.data_ptr(), st.shift.data_ptr(), stream()), 'gcc_in_finalize')
+
+
 def bnact_fwd(x, y, y2=None, scale=None, shift=None, gate=None, gate_after_act=False, act=ACT_NONE, slope=0.2,
-              act2=ACT_NONE, drop_p=0.0, seed=0):
+              act2=ACT_NONE, drop_p=0.0, seed=0, groups=1, residual=None):
     xp, N, Cc, H, W, ldx = geom(x)
     yp, ldy = (None, 0)
     if y is not None:
@@ -376,13 +433,18 @@ def bnact_fwd(x, y, y2=None, scale=None, shift=None, gate=None, gate_after_act=F
     y2p, ldy2 = (None, 0)
     if y2 is not None:
         y2p, _, _, _, _, ldy2 = geom(y2)
-    p = _lib.bnact_t(_p(scale), _p(shift), _p(gate), int(gate_after_act), act, slope, act2, drop_p, seed)
-    check(lib().gcc_bnact_fwd(C.byref(p), xp, ldx, 0, yp, ldy, 0, y2p, ldy2, 0, Cc, N * H * W, stream()), 'gcc_bnact_fwd')
+    rp, ldr = (None, 0)
+    if residual is not None:
+        rp, _, _, _, _, ldr = geom(residual)
+    p = _lib.bnact_t(_p(scale), _p(shift), _p(gate), int(gate_after_act), act, slope, act2, drop_p, seed, groups, ldr, rp)
+    pixels = N * H * W if groups <= 1 else H * W
+    assert groups <= 1 or groups == N
+    check(lib().gcc_bnact_fwd(C.byref(p), xp, ldx, 0, yp, ldy, 0, y2p, ldy2, 0, Cc, pixels, stream()), 'gcc_bnact_fwd')
 
 
 def bnact_bwd(x, y, g1, dx, g2=None, bn=None, gamma=None, beta=None, bn_eval=False, gate=None, gate_after_act=False,
               act=ACT_NONE, slope=0.2, act2=ACT_NONE, drop_p=0.0, seed=0, dgamma=None, dbeta=None, dalpha=None,
-              in_act=ACT_NONE):
+              in_act=ACT_NONE, groups=1):
     """bn: BNState (training statistics) or None."""
     xp, N, Cc, H, W, ldx = geom(x)
     yp, ldy = (None, 0)
@@ -393,11 +455,12 @@ def bnact_bwd(x, y, g1, dx, g2=None, bn=None, gamma=None, beta=None, bn_eval=Fal
     if g2 is not None:
         g2p, _, _, _, _, ldg2 = geom(g2)
     dxp, _, _, _, _, lddx = geom(dx)
-    pixels = N * H * W
+    pixels = N * H * W if groups <= 1 else H * W
+    assert groups <= 1 or groups == N
     p = _lib.bnact_bwd_t(1 if bn is not None else 0, int(bn_eval), _p(bn.mean) if bn is not None else None,
                          _p(bn.rstd) if bn is not None else None, _p(gamma), _p(beta), _p(gate), int(gate_after_act),
-                         act, slope, act2, drop_p, seed, _p(dgamma), _p(dbeta), _p(dalpha))
-    need = lib().gcc_bnact_bwd_workspace(Cc, pixels)
+                         act, slope, act2, drop_p, seed, _p(dgamma), _p(dbeta), _p(dalpha), groups, 0)
+    need = lib().gcc_bnact_bwd_workspace(Cc, pixels) * max(1, groups)
     ws = workspace(need, x.device, 'bnbwd')
     check(lib().gcc_bnact_bwd_ex(C.byref(p), in_act, slope, xp, ldx, 0, yp, ldy, 0, g1p, ldg1, 0, g2p, ldg2, 0, dxp, lddx,
                                  0, Cc, pixels, ws.data_ptr(), ws.numel(), stream()), 'gcc_bnact_bwd')

@@ -147,6 +147,13 @@ int gcc_nhwc_add(const void* src, int lds, int soff, void* dst, int ldd, int dof
 int gcc_bn_finalize(const float* stats_partial, int tiles, int C, double count, const float* gamma,
                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                     float* mean, float* rstd, float* scale, float* shift, gcc_stream_t stream);
+/* InstanceNorm2d(affine=False, no running statistics; models/Pix2Pix.py:201, models/CycleGAN.py:145): per image
+ * and channel mean / rstd from [groups][tiles_per_group][2][C] partial sums (conv epilogue or gcc_channel_stats) */
+int gcc_in_finalize(const float* stats_partial, int tiles_per_group, int groups, int C, double count, float eps,
+                    float* mean, float* rstd, float* scale, float* shift, gcc_stream_t stream);
+int gcc_channel_stats_tiles(size_t pixels_per_group, int C);
+int gcc_channel_stats(const void* x, int ld, int off, int C, size_t pixels_per_group, int groups, float* stats,
+                      gcc_stream_t stream);
 /* eval mode: scale/shift from running statistics */
 int gcc_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, int C, float* scale, float* shift,
@@ -162,6 +169,10 @@ typedef struct {
     int act2;             /* activation written to y2 (if y2 != NULL): y2 = act2(gate(bn(x))) */
     float drop_p;         /* dropout probability (0 = off); applied after bn, before act (U-Net up path) */
     uint64_t seed;        /* counter-based RNG: keep = hash(seed, element index) >= p */
+    int groups;           /* <= 1: BatchNorm.  G > 1: InstanceNorm over G images -- `pixels` is per image, scale/shift
+                             are [G][C] (gcc_in_finalize), x/y/y2/residual hold the G images back to back */
+    int ld_residual;
+    const void* residual; /* optional NHWC bf16 tensor added to y after the activation (ResNet block) */
 } gcc_bnact_t;
 
 /* y[.., yoff+c] = act(...) ; optional second output y2 (e.g. the ReLU'd copy that lands in the
@@ -188,6 +199,9 @@ typedef struct {
     int act2;                /* activation of the second consumer (g2) */
     float drop_p; uint64_t seed;
     float* dgamma; float* dbeta; float* dalpha;  /* [C] fp32, accumulated into (+=) ; any may be NULL */
+    int groups;              /* G > 1: InstanceNorm backward (mean/rstd [G][C], no parameter gradients); workspace is
+                                G * gcc_bnact_bwd_workspace() */
+    int pad_;
 } gcc_bnact_bwd_t;
 
 size_t gcc_bnact_bwd_workspace(int C, size_t pixels);
@@ -201,6 +215,17 @@ int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_slope, const
                      const void* y, int ldy, int yoff, const void* g1, int ldg1, int g1off, const void* g2,
                      int ldg2, int g2off, void* dx, int lddx, int dxoff, int C, size_t pixels, void* ws,
                      size_t ws_bytes, gcc_stream_t stream);
+
+/* ReflectionPad2d (explicit copy; backward = adjoint gather) and the depthwise 3x3 convolution with
+ * ReflectionPad2d(1) of MobileResnetBlock / SeparableConv2d (models/Pix2Pix.py:132-197).
+ * gcc_dwconv3x3_reflect mode 0: out = conv(x) + bias ; mode 1: out = d(x) from dy.  w: fp32 [C][9] master. */
+int gcc_reflect_pad(const void* src, int lds, void* dst, int ldd, int N, int H, int W, int C, int pad, int backward,
+                    gcc_stream_t stream);
+int gcc_dwconv3x3_reflect(int mode, const void* x, int ldx, const void* dy, int lddy, void* out, int ldo, const float* w,
+                          const float* bias, int N, int H, int W, int C, gcc_stream_t stream);
+size_t gcc_dwconv3x3_wgrad_workspace(int N, int H, int W, int C);
+int gcc_dwconv3x3_reflect_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias, int N, int H,
+                                int W, int C, void* ws, size_t ws_bytes, gcc_stream_t stream);
 
 /* per-channel sum over pixels of an NHWC bf16 tensor (bias gradients): out[c] (+)= sum x[..,c] */
 int gcc_channel_sum(const void* x, int ld, int off, int C, size_t pixels, float* out, int accumulate,

@@ -44,7 +44,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.epilogue_t) == 40
     assert ctypes.sizeof(_lib.adam_tensor_t) == 48
     assert ctypes.sizeof(_lib.adam_chunk_t) == 16
-    assert ctypes.sizeof(_lib.bnact_t) == 56
+    assert ctypes.sizeof(_lib.bnact_t) == 72
 
 
 def test_options_match_reference_golden(golden_dir):

@@ -384,3 +384,74 @@ def test_bad_arguments_return_errors():
     assert lib.gcc_conv_fprop(C.byref(d), 1, 1, 1, None, None) == -1
     assert lib.gcc_conv_fprop(None, None, None, None, None, None) == -1
     assert b'workspace' in lib.gcc_strerror(-3)
+
+
+def test_reflect_pad_and_adjoint():
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    x = rb(torch.randn(2, 16, 9, 7, generator=g))
+    for pad in (1, 3):
+        xr = x.clone().requires_grad_(True)
+        ref = F.pad(xr, (pad,) * 4, mode='reflect')
+        gy = rb(torch.randn(ref.shape, generator=g))
+        ref.backward(gy)
+        out = ops.new_act(2, 16, 9 + 2 * pad, 7 + 2 * pad, DEV)
+        ops.reflect_pad(to_dev(x), out, pad)
+        close(to_cpu(out), ref.detach(), tol=0, floor=0, what='reflect pad')
+        dx = ops.new_act(2, 16, 9, 7, DEV)
+        ops.reflect_pad(to_dev(gy), dx, pad, backward=True)
+        close(to_cpu(dx), xr.grad, tol=1e-2, what='reflect pad adjoint')
+
+
+@pytest.mark.parametrize('C,H,W', [(32, 8, 8), (20, 6, 9), (256, 16, 16)])
+def test_depthwise_conv_reflect(C, H, W):
+    ops = _ops()
+    g = torch.Generator().manual_seed(C)
+    N = 2
+    x = rb(torch.randn(N, C, H, W, generator=g))
+    w = torch.randn(C, 1, 3, 3, generator=g) * 0.3
+    b = torch.randn(C, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(F.pad(xr, (1, 1, 1, 1), mode='reflect'), wr, br, groups=C)
+    gy = rb(torch.randn(ref.shape, generator=g))
+    ref.backward(gy)
+    xd, gd = to_dev(x), to_dev(gy)
+    wd, bd = w.to(DEV), b.to(DEV)
+    y = ops.new_act(N, C, H, W, DEV)
+    ops.dwconv_fwd(xd, wd, bd, y)
+    close(to_cpu(y), ref.detach(), what='dwconv fwd')
+    dx = ops.new_act(N, C, H, W, DEV)
+    ops.dwconv_bwd_data(gd, wd, dx)
+    close(to_cpu(dx), xr.grad, what='dwconv dgrad')
+    dw, db = torch.zeros_like(wd), torch.zeros_like(bd)
+    ops.dwconv_wgrad(xd, gd, dw, db)
+    close(dw.cpu(), wr.grad, tol=5e-3, floor=1e-3, what='dwconv wgrad')
+    close(db.cpu(), br.grad, tol=5e-3, floor=1e-3, what='dwconv bias grad')
+
+
+@pytest.mark.parametrize('C,relu,res', [(64, True, False), (24, False, True), (256, True, True)])
+def test_instance_norm_forward_backward(C, relu, res):
+    ops = _ops()
+    g = torch.Generator().manual_seed(C + 1)
+    N, H, W = 3, 8, 6
+    x = rb(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3)
+    r = rb(torch.randn(N, C, H, W, generator=g))
+    xr = x.clone().requires_grad_(True)
+    z = F.instance_norm(xr, eps=1e-5)
+    yref = F.relu(z) if relu else z
+    if res:
+        yref = yref + r
+    gy = rb(torch.randn(N, C, H, W, generator=g))
+    yref.backward(gy)
+    xd = to_dev(x)
+    st = ops.INState(N, C, DEV)
+    ops.in_finalize(ops.channel_stats(xd), H * W, st)
+    y = ops.new_act(N, C, H, W, DEV)
+    ops.bnact_fwd(xd, y, scale=st.scale, shift=st.shift, act=ops.ACT_RELU if relu else ops.ACT_NONE, groups=N,
+                  residual=to_dev(r) if res else None)
+    close(to_cpu(y), yref.detach(), what='instance norm fwd')
+    close(st.mean.cpu(), x.mean((2, 3)), tol=1e-4, floor=1e-5, what='IN mean')
+    dx = ops.new_act(N, C, H, W, DEV)
+    # backward of act(IN(x)) : the saved output for act' is y without the residual -> recompute from x (y=None)
+    ops.bnact_bwd(xd, None if res else y, to_dev(gy), dx, bn=st, act=ops.ACT_RELU if relu else ops.ACT_NONE, groups=N)
+    close(to_cpu(dx), xr.grad, tol=2e-2, what='instance norm bwd')
