@@ -1,4 +1,4 @@
-"""Execution engine of the GCC Pix2Pix step on MI355X.
+"""Execution engine of the GCC Pix2Pix / CycleGAN steps on MI355X.
 
 The nn.Module trees in gcc_amd/models only *name and own* parameters (so state_dicts are
 interchangeable with the reference, SURVEY.md section 5 "checkpoint").  Everything that computes is
@@ -512,6 +512,244 @@ class PatchGANEngine:
         dx = None
         if need_dx:
             self.conv[0].backward_data(G.layer[0], G.x_in)
+            dx = G.x_in
+        ops.SideStream.get(self.device).join()
+        return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# MobileResnet generator (--backbone resnet; CycleGAN)
+# ------------------------------------------------------------------------------------------------
+class DWOp:
+    """depthwise 3x3 conv behind a ReflectionPad2d(1): fp32 master [C,1,3,3] + bias read directly by the kernel"""
+
+    def __init__(self, conv):
+        self.weight, self.bias = conv.weight, conv.bias
+        self.C = conv.weight.shape[0]
+
+    def forward(self, x, out):
+        ops.dwconv_fwd(x, self.weight.data, self.bias.data if self.bias is not None else None, out)
+
+    def backward_data(self, dy, out):
+        ops.dwconv_bwd_data(dy, self.weight.data, out)
+
+    def backward_weight(self, x, dy):
+        def run():
+            ops.dwconv_wgrad(x, dy, self.weight.grad, self.bias.grad if self.bias is not None else None)
+        if OVERLAP_WGRAD:
+            side = ops.SideStream.get(x.device)
+            side.fork()
+            with torch.cuda.stream(side.stream):
+                run()
+        else:
+            run()
+
+
+class MobileResnetEngine:
+    """Forward / backward schedule of MobileResnetGenerator (models/Pix2Pix.py:132-265, models/CycleGAN.py:77-138):
+    pad3+conv7 | 2x conv3 s2 | residual blocks of (pad1, dw3x3, IN, 1x1, IN, ReLU, pad1, dw3x3, IN, 1x1, IN) | 2x convT3 s2 |
+    pad3+conv7+tanh, InstanceNorm2d(affine=False) after every conv.  Widths come from the module tree (pruned cfgs
+    with removed blocks included: a removed block is simply absent from the Sequential)."""
+
+    def __init__(self, module, device):
+        self.module, self.device = module, device
+        items = list(module.model.named_children())
+        convs = [(int(n), m) for n, m in items if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))]
+        blocks = [(int(n), m) for n, m in items if hasattr(m, 'conv_block')]
+        assert len(convs) == 6 and not isinstance(convs[0][1], nn.ConvTranspose2d)
+        self.stem = [ConvOp(convs[0][1].weight, convs[0][1].bias, 7, 1, 0, False),
+                     ConvOp(convs[1][1].weight, convs[1][1].bias, 3, 2, 1, False),
+                     ConvOp(convs[2][1].weight, convs[2][1].bias, 3, 2, 1, False)]
+        self.ups = [ConvOp(convs[3][1].weight, convs[3][1].bias, 3, 2, 1, True),
+                    ConvOp(convs[4][1].weight, convs[4][1].bias, 3, 2, 1, True)]
+        self.last = ConvOp(convs[5][1].weight, convs[5][1].bias, 7, 1, 0, False)
+        self.blocks = []
+        for idx, blk in blocks:
+            cb = blk.conv_block
+            s1, s2 = getattr(cb, '1').conv, getattr(cb, '6').conv
+            self.blocks.append(type('Blk', (), dict(
+                index=idx, dw1=DWOp(getattr(s1, '0')), pw1=ConvOp(getattr(s1, '2').weight, getattr(s1, '2').bias, 1, 1, 0, False),
+                dw2=DWOp(getattr(s2, '0')), pw2=ConvOp(getattr(s2, '2').weight, getattr(s2, '2').bias, 1, 1, 0, False)))())
+        self.relu_index = convs[2][0] + 2          # 'model.9': the ReLU behind the second stride-2 conv
+        self.in_nc, self.out_nc = self.stem[0].cols, self.last.rows
+        self.hook_names = ['model.9', 'model.12', 'model.15', 'model.18']
+        self.ctx, self.gbuf = {}, {}
+
+    def convs(self):
+        return self.stem + [c for b in self.blocks for c in (b.pw1, b.pw2)] + self.ups + [self.last]
+
+    def repack(self):
+        if getattr(self, '_pack', None) is None:
+            self._pack = ops.PackPlan(self.convs(), self.device)
+        self._pack.run()
+
+    # ---------------------------------------------------------------------------------------
+    def _ctx(self, N, H, W, tag='main'):
+        key = (N, H, W, tag)
+        if key in self.ctx:
+            return self.ctx[key]
+        dev = self.device
+        c = type('ResnetCtx', (), {})()
+        c.N, c.H, c.W = N, H, W
+        new = lambda Cc, h, w: ops.new_act(N, Cc, h, w, dev)
+        c.x_in = new(self.in_nc, H, W)
+        c.xpad = new(self.in_nc, H + 6, W + 6)
+        sz = [(H, W), (H // 2, W // 2), (H // 4, W // 4)]
+        c.sz = sz
+        c.s_raw = [new(self.stem[i].rows, *sz[i]) for i in range(3)]
+        c.s_act = [new(self.stem[i].rows, *sz[i]) for i in range(3)]
+        c.s_st = [ops.INState(N, self.stem[i].rows, dev) for i in range(3)]
+        h, w = sz[2]
+        c.blk = []
+        for b in self.blocks:
+            t = type('BlkCtx', (), {})()
+            cin, cmid, cout = b.dw1.C, b.pw1.rows, b.pw2.rows
+            t.d1, t.n1, t.p1, t.r1 = new(cin, h, w), new(cin, h, w), new(cmid, h, w), new(cmid, h, w)
+            t.d2, t.n2, t.p2, t.o = new(cmid, h, w), new(cmid, h, w), new(cout, h, w), new(cout, h, w)
+            t.st = [ops.INState(N, cc, dev) for cc in (cin, cmid, cmid, cout)]
+            c.blk.append(t)
+        usz = [sz[1], sz[0]]
+        c.t_raw = [new(self.ups[i].cols, *usz[i]) for i in range(2)]
+        c.t_act = [new(self.ups[i].cols, *usz[i]) for i in range(2)]
+        c.t_st = [ops.INState(N, self.ups[i].cols, dev) for i in range(2)]
+        c.ypad = new(self.ups[1].cols, H + 6, W + 6)
+        c.out = new(self.out_nc, H, W)
+        c.g_out = new(self.out_nc, H, W)
+        self.ctx[key] = c
+        return c
+
+    def _gbufs(self, N, H, W):
+        """gradient buffers shared by all contexts of one shape (a backward joins the side stream before returning)"""
+        key = (N, H, W)
+        if key in self.gbuf:
+            return self.gbuf[key]
+        dev = self.device
+        new = lambda Cc, h, w: ops.new_act(N, Cc, h, w, dev)
+        g = type('ResnetGrad', (), {})()
+        sz = [(H, W), (H // 2, W // 2), (H // 4, W // 4)]
+        h, w = sz[2]
+        g.ypad = new(self.ups[1].cols, H + 6, W + 6)
+        g.t = [new(self.ups[0].cols, *sz[1]), new(self.ups[1].cols, *sz[0])]
+        g.h = new(self.stem[2].rows, h, w)
+        g.tmp = new(self.stem[2].rows, h, w)
+        g.blk = []
+        for b in self.blocks:
+            cin, cmid, cout = b.dw1.C, b.pw1.rows, b.pw2.rows
+            g.blk.append((new(cout, h, w), new(cmid, h, w), new(cmid, h, w), new(cin, h, w)))
+        g.s = [new(self.stem[i].rows, *sz[i]) for i in range(2)]
+        g.xpad = new(self.in_nc, H + 6, W + 6)
+        g.x_in = new(self.in_nc, H, W)
+        self.gbuf[key] = g
+        return g
+
+    def features(self, c):
+        """outputs of the hooked modules ('model.9' ReLU, blocks 'model.12/15/18'), in that order"""
+        out = []
+        by_index = {b.index: i for i, b in enumerate(self.blocks)}
+        for name in self.hook_names:
+            i = int(name.split('.')[1])
+            if i == self.relu_index:
+                out.append(c.s_act[2])
+            elif i in by_index:
+                out.append(c.blk[by_index[i]].o)
+            else:
+                raise NotImplementedError('distillation hook %s is not a residual block of this (pruned) generator' % name)
+        return out
+
+    @staticmethod
+    def _inorm(x, y, st, act=ACT_NONE, residual=None):
+        N, _, H, W = x.shape
+        ops.in_finalize(ops.channel_stats(x), H * W, st)
+        ops.bnact_fwd(x, y, scale=st.scale, shift=st.shift, act=act, groups=N, residual=residual)
+
+    # ---------------------------------------------------------------------------------------
+    def forward(self, c, train=True):
+        """input already in c.x_in; returns c (c.out = tanh image).  InstanceNorm without running statistics and
+        dropout rate 0: train and eval are the same arithmetic."""
+        ops.reflect_pad(c.x_in, c.xpad, 3)
+        src = c.xpad
+        for i in range(3):
+            self.stem[i].forward(src, c.s_raw[i])
+            self._inorm(c.s_raw[i], c.s_act[i], c.s_st[i], act=ACT_RELU)
+            src = c.s_act[i]
+        for b, t in zip(self.blocks, c.blk):
+            b.dw1.forward(src, t.d1)
+            self._inorm(t.d1, t.n1, t.st[0])
+            b.pw1.forward(t.n1, t.p1)
+            self._inorm(t.p1, t.r1, t.st[1], act=ACT_RELU)
+            b.dw2.forward(t.r1, t.d2)
+            self._inorm(t.d2, t.n2, t.st[2])
+            b.pw2.forward(t.n2, t.p2)
+            self._inorm(t.p2, t.o, t.st[3], residual=src)
+            src = t.o
+        for i in range(2):
+            self.ups[i].forward(src, c.t_raw[i])
+            self._inorm(c.t_raw[i], c.t_act[i], c.t_st[i], act=ACT_RELU)
+            src = c.t_act[i]
+        ops.reflect_pad(src, c.ypad, 3)
+        self.last.forward(c.ypad, c.out, act=ACT_TANH)
+        return c
+
+    # ---------------------------------------------------------------------------------------
+    def backward(self, c, g_feat=None, wgrad=True, need_dx=False):
+        """c.g_out holds dL/d(out); g_feat: optional gradients w.r.t. features(c).  Accumulates parameter gradients
+        when wgrad; returns dL/d(x_in) when need_dx (the cycle / identity chains of CycleGAN)."""
+        N = c.N
+        G = self._gbufs(c.N, c.H, c.W)
+        gf = {}
+        if g_feat is not None:
+            for name, g in zip(self.hook_names, g_feat):
+                if g is not None:
+                    gf[int(name.split('.')[1])] = g
+        ops.bnact_bwd(c.out, None, c.g_out, c.g_out, in_act=ACT_TANH)
+        if wgrad:
+            self.last.backward_weight(c.ypad, c.g_out)
+        self.last.backward_data(c.g_out, G.ypad)
+        ops.reflect_pad(G.ypad, G.t[1], 3, backward=True)
+        n_blk = len(self.blocks)
+        for i in (1, 0):
+            ops.bnact_bwd(c.t_raw[i], c.t_act[i], G.t[i], G.t[i], bn=c.t_st[i], act=ACT_RELU, groups=N)
+            src = c.t_act[0] if i == 1 else (c.blk[-1].o if n_blk else c.s_act[2])
+            if wgrad:
+                self.ups[i].backward_weight(src, G.t[i])
+            self.ups[i].backward_data(G.t[i], G.t[0] if i == 1 else G.h)
+        for bi in range(n_blk - 1, -1, -1):
+            b, t = self.blocks[bi], c.blk[bi]
+            gp2, gn2, gr1, gn1 = G.blk[bi]
+            x_in = c.blk[bi - 1].o if bi > 0 else c.s_act[2]
+            if b.index in gf:
+                ops.nhwc_add(gf[b.index], 0, G.h, 0, G.h.shape[1])
+            ops.bnact_bwd(t.p2, None, G.h, gp2, bn=t.st[3], groups=N)
+            if wgrad:
+                b.pw2.backward_weight(t.n2, gp2)
+            b.pw2.backward_data(gp2, gn2)
+            ops.bnact_bwd(t.d2, None, gn2, gn2, bn=t.st[2], groups=N)
+            if wgrad:
+                b.dw2.backward_weight(t.r1, gn2)
+            b.dw2.backward_data(gn2, gr1)
+            ops.bnact_bwd(t.p1, t.r1, gr1, gr1, bn=t.st[1], act=ACT_RELU, groups=N)
+            if wgrad:
+                b.pw1.backward_weight(t.n1, gr1)
+            b.pw1.backward_data(gr1, gn1)
+            ops.bnact_bwd(t.d1, None, gn1, gn1, bn=t.st[0], groups=N)
+            if wgrad:
+                b.dw1.backward_weight(x_in, gn1)
+            b.dw1.backward_data(gn1, G.tmp)
+            ops.nhwc_add(G.tmp, 0, G.h, 0, G.h.shape[1])
+        if self.relu_index in gf:
+            ops.nhwc_add(gf[self.relu_index], 0, G.h, 0, G.h.shape[1])
+        g = G.h
+        for i in (2, 1, 0):
+            ops.bnact_bwd(c.s_raw[i], c.s_act[i], g, g, bn=c.s_st[i], act=ACT_RELU, groups=N)
+            if wgrad:
+                self.stem[i].backward_weight(c.s_act[i - 1] if i > 0 else c.xpad, g)
+            if i > 0:
+                self.stem[i].backward_data(g, G.s[i - 1])
+                g = G.s[i - 1]
+        dx = None
+        if need_dx:
+            self.stem[0].backward_data(g, G.xpad)
+            ops.reflect_pad(G.xpad, G.x_in, 3, backward=True)
             dx = G.x_in
         ops.SideStream.get(self.device).join()
         return dx

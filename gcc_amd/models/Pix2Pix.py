@@ -90,6 +90,59 @@ class UnetGenertor(nn.Module):
         raise GccError('UnetGenertor owns parameters only; run it through Pix2PixModel (gcc_amd.engine.UnetEngine)')
 
 
+class SeparableConv2d(nn.Module):
+    """depthwise kxk (+bias) -> InstanceNorm -> pointwise 1x1 (+bias)   (models/Pix2Pix.py:132-145); parameters only"""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(in_channels, in_channels, kernel_size, groups=in_channels, bias=True),
+                                  nn.InstanceNorm2d(in_channels), nn.Conv2d(in_channels, out_channels, 1, bias=True))
+
+
+class MobileResnetBlock(nn.Module):
+    """conv_block slots: 0 pad, 1 separable, 2 IN, 3 ReLU, 4 dropout, 5 pad, 6 separable, 7 IN
+    (models/Pix2Pix.py:147-197); out = x + conv_block(x)"""
+
+    def __init__(self, c_in, c_mid, c_out, dropout_rate=0.0):
+        super().__init__()
+        self.conv_block = nn.Sequential(nn.ReflectionPad2d(1), SeparableConv2d(c_in, c_mid), nn.InstanceNorm2d(c_mid),
+                                        nn.ReLU(True), nn.Dropout(dropout_rate), nn.ReflectionPad2d(1),
+                                        SeparableConv2d(c_mid, c_out), nn.InstanceNorm2d(c_out))
+
+
+class MobileResnetGenerator(nn.Module):
+    """Parameter tree of the reference's MobileResnetGenerator (models/Pix2Pix.py:199-265, models/CycleGAN.py:77-138).
+    cfg: 23 widths [stem x3, (mid, out) x n_blocks, up x2]; a block whose mid width is 0 is left out, which shifts
+    the Sequential indices behind it exactly as in the reference."""
+
+    def __init__(self, input_nc=3, output_nc=3, ngf=64, norm_layer=nn.InstanceNorm2d, dropout_rate=0, n_blocks=9,
+                 padding_type='reflect', opt=None, cfg=None):
+        super().__init__()
+        if norm_layer is not nn.InstanceNorm2d or padding_type != 'reflect' or dropout_rate != 0:
+            raise NotImplementedError('the MI355X path implements the configuration the reference trains: InstanceNorm, '
+                                      'reflect padding, dropout 0')
+        self.opt = opt
+        w = [int(v) for v in cfg] if cfg is not None else [ngf, 2 * ngf, 4 * ngf] + [4 * ngf] * (2 * n_blocks) + [2 * ngf, ngf]
+        assert len(w) == 5 + 2 * n_blocks, 'cfg must hold %d widths' % (5 + 2 * n_blocks)
+        seq = [nn.ReflectionPad2d(3), nn.Conv2d(input_nc, w[0], 7, bias=True), nn.InstanceNorm2d(w[0]), nn.ReLU(True)]
+        for i in (1, 2):
+            seq += [nn.Conv2d(w[i - 1], w[i], 3, stride=2, padding=1, bias=True), nn.InstanceNorm2d(w[i]), nn.ReLU(True)]
+        j = 3
+        for _ in range(n_blocks):
+            if w[j] != 0:
+                seq.append(MobileResnetBlock(w[j - 1], w[j], w[j + 1], dropout_rate))
+            j += 2
+        for i in (j, j + 1):
+            seq += [nn.ConvTranspose2d(w[i - 1], w[i], 3, stride=2, padding=1, output_padding=1, bias=True),
+                    nn.InstanceNorm2d(w[i]), nn.ReLU(True)]
+        seq += [nn.ReflectionPad2d(3), nn.Conv2d(w[j + 1], output_nc, 7, bias=True), nn.Tanh()]
+        self.model = nn.Sequential(*seq)
+
+    def forward(self, x):
+        raise GccError('MobileResnetGenerator owns parameters only; run it through the model classes '
+                       '(gcc_amd.engine.MobileResnetEngine)')
+
+
 def _patchgan_tree(self, input_nc, ndf, n_layers, masked, threshold):
     ch = [ndf * min(2 ** i, 8) for i in range(n_layers + 1)]
     seq = nn.Module()
@@ -166,20 +219,28 @@ class Pix2PixModel(nn.Module):
         self.current_D_arch_diff_loss = 0.0
         self.teacher_model = None
 
-        if opt.backbone == 'resnet':
-            raise NotImplementedError('backbone resnet (MobileResnetGenerator) is not on the MI355X path yet')
-        self.generator_extract_layers = ['model.model.1.model.2', 'model.model.1.model.3.model.3.model.2',
-                                         'model.model.1.model.3.model.3.model.4', 'model.model.1.model.4']
+        self.resnet = opt.backbone == 'resnet'
+        if self.resnet:
+            self.generator_extract_layers = ['model.9', 'model.12', 'model.15', 'model.18']
+        else:
+            self.generator_extract_layers = ['model.model.1.model.2', 'model.model.1.model.3.model.3.model.2',
+                                             'model.model.1.model.3.model.3.model.4', 'model.model.1.model.4']
         self.discriminator_extract_layers = ['model.4', 'model.12'] if opt.darts_discriminator else ['model.3', 'model.9']
 
         self.optimizers = []
-        self.netG = UnetGenertor(3, 3, opt.num_downs, ngf=opt.ngf, use_dropout=not opt.no_dropout,
-                                 filter_cfgs=filter_cfgs, channel_cfgs=channel_cfgs)
+        if self.resnet:
+            self.netG = MobileResnetGenerator(input_nc=3, output_nc=3, ngf=opt.ngf, cfg=filter_cfgs, opt=opt)
+        else:
+            self.netG = UnetGenertor(3, 3, opt.num_downs, ngf=opt.ngf, use_dropout=not opt.no_dropout,
+                                     filter_cfgs=filter_cfgs, channel_cfgs=channel_cfgs)
         self.distill = bool(opt.online_distillation or opt.normal_distillation)
         self.transform_convs = []
         if self.distill:
             t_w = [opt.teacher_ngf * 2, opt.teacher_ngf * 8, opt.teacher_ngf * 16, opt.teacher_ngf * 4]
-            if channel_cfgs is None:
+            if self.resnet:         # models/Pix2Pix.py:387-397: the four hooked tensors are all 4*ngf wide
+                t_w = [opt.teacher_ngf * 4] * 4
+                s_w = [opt.ngf * 4 if filter_cfgs is None else filter_cfgs[2]] * 4
+            elif channel_cfgs is None:
                 s_w = [opt.ngf * 2, opt.ngf * 8, opt.ngf * 16, opt.ngf * 4]
             else:
                 s_w = [channel_cfgs[1], channel_cfgs[3], channel_cfgs[-4], channel_cfgs[-2]]
@@ -223,10 +284,14 @@ class Pix2PixModel(nn.Module):
                 self.arch_scheduler = util.get_scheduler(self.optimizer_arch, arch_opt)
 
         # ---- engines
-        self.G = engine.UnetEngine(self.netG, opt.num_downs, dev, use_dropout=not opt.no_dropout)
+        if self.resnet:
+            self.G = engine.MobileResnetEngine(self.netG, dev)
+            t_split = [0, 0, 0, 0]
+        else:
+            self.G = engine.UnetEngine(self.netG, opt.num_downs, dev, use_dropout=not opt.no_dropout)
+            # the last two hooked features are concat buffers (skip | up path): their channel dimension is split
+            t_split = [0, 0, self.G.width[3], self.G.width[1]]
         self.D = engine.PatchGANEngine(self.netD, bool(opt.darts_discriminator), opt.threshold, dev)
-        # the last two hooked features are concat buffers (skip | up path): their channel dimension is split
-        t_split = [0, 0, self.G.width[3], self.G.width[1]]
         self.T = [engine.ConvOp(t.weight, None, 1, 1, 0, False, col_split=sp)
                   for t, sp in zip(self.transform_convs, t_split)]
         self.refresh_weights()
@@ -291,7 +356,10 @@ class Pix2PixModel(nn.Module):
         N, _, H, W = self._A.shape
         c = self.G._ctx(N, H, W)
         ops.nhwc_copy(self._A, 0, c.x_in, 0, 3)
-        self._gctx = self.G.forward(N, H, W, train=self.netG.training)
+        if self.resnet:
+            self._gctx = self.G.forward(c, train=self.netG.training)
+        else:
+            self._gctx = self.G.forward(N, H, W, train=self.netG.training)
         self._fake = self._gctx.out
         self._fake_nchw = None
 

@@ -243,6 +243,93 @@ def unet_forward(sd: SD, x: Tensor, num_downs: int = 8, train: bool = True,
 
 
 # ----------------------------------------------------------------------------------------------
+# MobileResnet generator (models/Pix2Pix.py:132-265, models/CycleGAN.py:77-138)
+# ----------------------------------------------------------------------------------------------
+def resnet_layout(sd: SD):
+    """(stem conv indices, block indices, up-conv indices, last conv index) from the state_dict keys: the
+    Sequential is [pad, conv7, IN, ReLU, conv3s2, IN, ReLU, conv3s2, IN, ReLU, blocks..., convT, IN, ReLU, convT,
+    IN, ReLU, pad, conv7, tanh]; removed blocks (cfg entry 0) shift the later indices."""
+    tops = sorted({int(k.split('.')[1]) for k in sd})
+    blocks = sorted({int(k.split('.')[1]) for k in sd if '.conv_block.' in k})
+    rest = [i for i in tops if i not in blocks]
+    return rest[:3], blocks, rest[3:5], rest[5]
+
+
+def instance_norm(x: Tensor) -> Tensor:
+    return F.instance_norm(x, eps=1e-5)
+
+
+def mobile_resnet_forward(sd: SD, x: Tensor, features: Optional[OrderedDict] = None,
+                          hook_idx: Sequence[int] = (9, 12, 15, 18)) -> Tensor:
+    """InstanceNorm2d(affine=False) everywhere, every conv has a bias (use_bias follows the norm type), reflect
+    padding in front of the 7x7 convs and inside the separable convs, residual blocks
+    x + IN(pw(IN(dw(pad(relu(IN(pw(IN(dw(pad(x))))))))))), dropout rate 0."""
+    stem, blocks, ups, last = resnet_layout(sd)
+
+    def W(i, sfx=''):
+        return _qw(sd['model.%d%s.weight' % (i, sfx)]), sd.get('model.%d%s.bias' % (i, sfx))
+
+    w, b = W(stem[0])
+    h = _q(F.relu(instance_norm(_q(F.conv2d(F.pad(_q(x), (3,) * 4, mode='reflect'), w, b)))))
+    for i in stem[1:]:
+        w, b = W(i)
+        h = _q(F.relu(instance_norm(_q(F.conv2d(h, w, b, stride=2, padding=1)))))
+    if features is not None and (stem[2] + 2) in hook_idx:
+        features['model.%d' % (stem[2] + 2)] = h
+
+    def sep(t, i, j):
+        wd, bd = sd['model.%d.conv_block.%d.conv.0.weight' % (i, j)], sd['model.%d.conv_block.%d.conv.0.bias' % (i, j)]
+        wp, bp = _qw(sd['model.%d.conv_block.%d.conv.2.weight' % (i, j)]), sd['model.%d.conv_block.%d.conv.2.bias' % (i, j)]
+        t = _q(F.conv2d(F.pad(t, (1,) * 4, mode='reflect'), wd, bd, groups=t.shape[1]))
+        t = _q(instance_norm(t))
+        return _q(F.conv2d(t, wp, bp))
+    for i in blocks:
+        t = _q(F.relu(instance_norm(sep(h, i, 1))))
+        t = instance_norm(sep(t, i, 6))
+        h = _q(h + t)
+        if features is not None and i in hook_idx:
+            features['model.%d' % i] = h
+    for i in ups:
+        w, b = W(i)
+        h = _q(F.relu(instance_norm(_q(F.conv_transpose2d(h, w, b, stride=2, padding=1, output_padding=1)))))
+    w, b = W(last)
+    return _q(torch.tanh(F.conv2d(F.pad(h, (3,) * 4, mode='reflect'), w, b)))
+
+
+def mobile_resnet_shapes(ngf: int, cfg: Optional[Sequence[int]] = None, n_blocks: int = 9, in_nc=3, out_nc=3):
+    """state_dict shapes of MobileResnetGenerator (cfg: 23 ints; None = unpruned)"""
+    if cfg is None:
+        cfg = [ngf, 2 * ngf, 4 * ngf] + [4 * ngf] * (2 * n_blocks) + [2 * ngf, ngf]
+    shp: Dict[str, Tuple[int, ...]] = OrderedDict()
+
+    def conv(i, co, ci, k, sfx=''):
+        shp['model.%d%s.weight' % (i, sfx)] = (co, ci, k, k)
+        shp['model.%d%s.bias' % (i, sfx)] = (co,)
+    conv(1, cfg[0], in_nc, 7)
+    conv(4, cfg[1], cfg[0], 3)
+    conv(7, cfg[2], cfg[1], 3)
+    idx, ci = 10, 2
+    for b in range(n_blocks):
+        c_in, c_mid, c_out = cfg[ci], cfg[ci + 1], cfg[ci + 2]
+        ci += 2
+        if c_mid == 0:
+            continue
+        for j, (a, o) in ((1, (c_in, c_mid)), (6, (c_mid, c_out))):
+            shp['model.%d.conv_block.%d.conv.0.weight' % (idx, j)] = (a, 1, 3, 3)
+            shp['model.%d.conv_block.%d.conv.0.bias' % (idx, j)] = (a,)
+            shp['model.%d.conv_block.%d.conv.2.weight' % (idx, j)] = (o, a, 1, 1)
+            shp['model.%d.conv_block.%d.conv.2.bias' % (idx, j)] = (o,)
+        idx += 1
+    for u in range(2):
+        shp['model.%d.weight' % idx] = (cfg[ci], cfg[ci + 1], 3, 3)       # ConvTranspose2d [in, out, k, k]
+        shp['model.%d.bias' % idx] = (cfg[ci + 1],)
+        ci += 1
+        idx += 3
+    conv(idx + 1, out_nc, cfg[ci], 7)
+    return shp
+
+
+# ----------------------------------------------------------------------------------------------
 # PatchGAN discriminators
 # ----------------------------------------------------------------------------------------------
 def patchgan_layout(masked: bool, n_layers: int = 3):
@@ -478,7 +565,7 @@ class Pix2PixOracle:
         self.G, self.D, self.T = G, D, (T or [])
         self.masked = masked
         self.teacher = teacher
-        self.g_hooks = unet_hook_names(opt.num_downs)
+        self.g_hooks = unet_hook_names(opt.num_downs)      # (resnet backbone: model.9 / 12 / 15 / 18)
         self.d_hooks = ['model.4', 'model.12'] if masked else ['model.3', 'model.9']
         self.g_feats: OrderedDict = OrderedDict()
         self.d_feats: OrderedDict = OrderedDict()
@@ -496,6 +583,8 @@ class Pix2PixOracle:
 
     # -- forward pieces ------------------------------------------------------------------
     def netG(self, x):
+        if getattr(self.opt, 'backbone', 'unet') == 'resnet':
+            return mobile_resnet_forward(self.G, x, features=self.g_feats)
         return unet_forward(self.G, x, self.opt.num_downs, self.train, dropout=not self.opt.no_dropout,
                             dropout_masks=self.dropout_masks, features=self.g_feats)
 

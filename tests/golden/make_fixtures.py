@@ -22,6 +22,7 @@ Fixtures
                         LambdaLR values, init_weights statistics
   options.json          options.parse() results for 7 command lines (flag surface + per-model overrides)
   pix2pix_pruned_d8.npz pruned student built from filter_cfgs/channel_cfgs with irregular widths: eval image + 1 iteration
+  pix2pix_resnet_gcc.npz  --backbone resnet (MobileResnet + InstanceNorm) GCC iteration: eval/train images, features, losses
   prune_search_d8.npz   binarysearch_threshold trajectory end points with a documented thop stand-in
   prune_d8.npz          scale_prune / norm_prune cfgs + max_min_* at several thresholds (ngf 8)
 """
@@ -423,6 +424,54 @@ def fixture_prune_search():
     print('prune_search ok', {k: (v.tolist() if v.size < 3 else '...') for k, v in out.items() if 'thr' in k or 'found' in k or 'macs' in k})
 
 
+def fixture_resnet_gcc():
+    """Pix2Pix with --backbone resnet (MobileResnetGenerator, InstanceNorm): student ngf 8 + masked D, online teacher
+    ngf 16, 64x64, N=2: eval image, then one GCC iteration + arch step (recipe weights 501..505)"""
+    opt = parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '-1', '--backbone', 'resnet',
+                 '--ngf', '8', '--ndf', '8', '--teacher_ngf', '16', '--online_distillation', '--darts_discriminator',
+                 '--lambda_content', '50', '--lambda_gram', '1e4', '--arch_lr', '1e-4', '--arch_lr_step'])
+    opt.teacher_ndf = 16
+    model, teacher = build_gcc(opt)
+    load_recipe(model.netG, 501)
+    load_recipe(model.netD, 502)
+    load_recipe(teacher.netG, 503)
+    load_recipe(teacher.netD, 504)
+    with torch.no_grad():
+        for i, t in enumerate(model.transform_convs):
+            t.weight.copy_(recipe_transform(t.weight.shape[0], t.weight.shape[1], 505 + i))
+        model.netD.model[2].alpha[0] = 0.3
+    out = {'direction': np.array(opt.direction), 'seeds': np.array([501, 502, 503, 504, 505]),
+           'G_keys': np.array(list(model.netG.state_dict().keys()))}
+    g = torch.Generator().manual_seed(77)
+    A, B, vA, vB = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1 for _ in range(4))
+    for n, t in (('A', A), ('B', B), ('vA', vA), ('vB', vB)):
+        out[n] = t.numpy()
+    model.model_eval()
+    model.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
+    with torch.no_grad():
+        model.forward()
+    out['eval.fake_B'] = model.fake_B.numpy().copy()
+    model.model_train()
+    model.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
+    model.optimize_parameters()
+    out['train.fake_B'] = model.fake_B.detach().numpy().copy()
+    out['train.Tfake_B'] = teacher.fake_B.detach().numpy().copy()
+    for j, f in enumerate(model.get_distillation_features()[:4]):
+        out['sfeat.%d' % j] = f.detach().numpy().copy()
+    for j, f in enumerate(model.target_distillation_features):
+        out['target.%d' % j] = f.detach().numpy().copy()
+    model.set_input({'A': vA, 'B': vB, 'A_paths': ['a'], 'B_paths': ['b']})
+    model.clipping_mask_alpha()
+    model.optimizer_netD_arch()
+    for k, v in model.get_current_losses().items():
+        out['loss.%s' % k] = np.array(v, dtype=np.float64)
+    sd_np_sampled('final.sG.', model.netG.state_dict(), out)
+    sd_np_sampled('final.tG.', teacher.netG.state_dict(), out)
+    sd_np_sampled('final.sD.', model.netD.state_dict(), out)
+    np.savez_compressed(os.path.join(HERE, 'pix2pix_resnet_gcc.npz'), **out)
+    print('pix2pix_resnet_gcc ok', {k: round(float(v), 4) for k, v in out.items() if k.startswith('loss.')})
+
+
 def fixture_options():
     import json
     from options import options
@@ -455,3 +504,4 @@ if __name__ == '__main__':
     fixture_prune_d8()
     fixture_pruned_d8()
     fixture_prune_search()
+    fixture_resnet_gcc()

@@ -63,6 +63,10 @@ CONV_CASES = [
     (2, 32, 32, 128, 128, 4, 2, 1),    # 256x128 tile candidates (forced by GCC_IGEMM_BIG_MIN=1 in the second test pass)
     (2, 16, 16, 256, 384, 4, 1, 1),    # 256-pixel tiles with M and N tails, fprop and dgrad
     (3, 20, 20, 128, 512, 4, 2, 1),    # 256x256 tiles (GCC_IGEMM_BIG=2), ragged M
+    (2, 22, 22, 3, 16, 7, 1, 0),       # MobileResnet stem: 7x7 on the reflect-padded image
+    (2, 22, 22, 16, 3, 7, 1, 0),       # MobileResnet head: 7x7 to 3 channels
+    (2, 16, 16, 16, 32, 3, 2, 1),      # MobileResnet down conv k3 s2; its dgrad is ConvTranspose(k3,s2,p1,output_padding=1)
+    (1, 16, 16, 128, 64, 3, 2, 1),
 ]
 
 
