@@ -367,7 +367,8 @@ def patchgan_forward(sd: SD, x: Tensor, masked: bool = False, threshold: float =
         if li == n - 1:
             break
         if bi is not None:
-            h = batch_norm(sd, 'model.%d' % bi, h, train)
+            # CycleGAN's plain (teacher) D uses InstanceNorm2d(affine=False) and conv biases: models/CycleGAN.py:139-177
+            h = batch_norm(sd, 'model.%d' % bi, h, train) if ('model.%d.weight' % bi) in sd else _q(instance_norm(h))
             raw_bn = h
         if li == 0:
             h = F.leaky_relu(h, LRELU)
@@ -499,7 +500,8 @@ def unet_shapes_cfg(filter_cfgs: Sequence[int], channel_cfgs: Sequence[int], in_
     return shp
 
 
-def patchgan_shapes(ndf: int, in_nc: int = 6, masked: bool = False, n_layers: int = 3):
+def patchgan_shapes(ndf: int, in_nc: int = 6, masked: bool = False, n_layers: int = 3, norm: str = 'batch'):
+    """norm='instance': the CycleGAN plain D (bias on every conv, no norm parameters)"""
     shp: Dict[str, Tuple[int, ...]] = OrderedDict()
     lay = patchgan_layout(masked, n_layers)
     chans = [ndf * min(2 ** i, 8) for i in range(n_layers + 1)]
@@ -507,7 +509,7 @@ def patchgan_shapes(ndf: int, in_nc: int = 6, masked: bool = False, n_layers: in
     for li, (ci, bi, gi) in enumerate(lay):
         cout = chans[li] if li < len(lay) - 1 else 1
         shp['model.%d.weight' % ci] = (cout, cin, 4, 4)
-        if bi is None:
+        if bi is None or norm == 'instance':
             shp['model.%d.bias' % ci] = (cout,)
         else:
             for s, v in (('weight', (cout,)), ('bias', (cout,)), ('running_mean', (cout,)),
@@ -545,6 +547,9 @@ class Opt:
         self.darts_discriminator = True
         self.online_distillation = True
         self.direction = 'AtoB'
+        self.lambda_A = 10.0            # CycleGAN
+        self.lambda_B = 10.0
+        self.lambda_identity = 0.5
         self.__dict__.update(kw)
 
 
@@ -734,6 +739,201 @@ def build_gcc_pair(opt: Opt, seed: int = 0) -> Pix2PixOracle:
     T = [(torch.rand((t, s, 1, 1), generator=g) * 2 - 1) / math.sqrt(s) for s, t in zip(s_w, t_w)]
     teacher = Pix2PixOracle(opt, tG, tD, masked=False)
     return Pix2PixOracle(opt, sG, sD, T, masked=opt.darts_discriminator, teacher=teacher)
+
+
+# ----------------------------------------------------------------------------------------------
+# CycleGAN step (models/CycleGAN.py:218-620)
+# ----------------------------------------------------------------------------------------------
+class ImagePool:
+    """utils/image_pool.py:5-54 -- history of generated images; draws from Python's ``random`` exactly as the
+    reference does (one uniform per image once the pool is full, one randint when it swaps)."""
+
+    def __init__(self, pool_size: int, rng=None):
+        import random as _random
+        self.pool_size, self.images, self.rng = pool_size, [], (rng or _random)
+
+    def query(self, images: Tensor) -> Tensor:
+        if self.pool_size == 0:
+            return images
+        out = []
+        for img in images:
+            img = img.detach().unsqueeze(0)
+            if len(self.images) < self.pool_size:
+                self.images.append(img)
+                out.append(img)
+            elif self.rng.uniform(0, 1) > 0.5:
+                j = self.rng.randint(0, self.pool_size - 1)
+                out.append(self.images[j].clone())
+                self.images[j] = img
+            else:
+                out.append(img)
+        return torch.cat(out, 0)
+
+
+class CycleGANOracle:
+    """MobileCycleGANModel reduced to its arithmetic.  G / D / T are dicts {'A': ..., 'B': ...}: netG_A maps A->B and
+    is judged by netD_A on domain B.  forward() runs each generator once per distinct input (the reference repeats
+    G_A(real_A) and G_B(real_B) only to refresh its hooks: same values, and autograd sums the same gradients)."""
+    HEAVY = ('model.1', 'model.4', 'model.19', 'model.22')
+
+    def __init__(self, opt: Opt, G: Dict[str, SD], D: Dict[str, SD], T: Optional[Dict[str, List[Tensor]]] = None,
+                 masked: bool = False, teacher: Optional['CycleGANOracle'] = None, pool_size: int = 50, rng=None):
+        self.opt, self.G, self.D, self.T = opt, G, D, (T or {'A': [], 'B': []})
+        self.masked, self.teacher = masked, teacher
+        self.d_hooks = ['model.4', 'model.12'] if masked else ['model.3', 'model.9']
+        self.g_feats = {'A': OrderedDict(), 'B': OrderedDict()}
+        self.d_feats = {'A': OrderedDict(), 'B': OrderedDict()}
+        self.pool = {'A': ImagePool(pool_size, rng), 'B': ImagePool(pool_size, rng)}     # keyed by the D that consumes it
+        self.cur_diff = {'A': 0.0, 'B': 0.0}
+        self.losses: Dict[str, float] = {}
+        self.lr_G = self.lr_D = opt.lr
+        self.lr_arch = opt.arch_lr
+        self.train = True
+        self.G_keys = {w: [k for k in G[w] if _is_float_param(k)] for w in 'AB'}
+        self.D_w_keys = {w: [k for k in D[w] if k.endswith('.weight') or k.endswith('.bias')] for w in 'AB'}
+        self.D_a_keys = {w: [k for k in D[w] if k.endswith('.alpha')] for w in 'AB'}
+        self.st_G, self.st_D, self.st_A = {}, {}, {}
+
+    def netG(self, w, x, hook=False):
+        return mobile_resnet_forward(self.G[w], x, features=self.g_feats[w] if hook else None)
+
+    def netD(self, w, x):
+        return patchgan_forward(self.D[w], x, self.masked, self.opt.threshold, self.train, features=self.d_feats[w],
+                                hook_names=self.d_hooks)
+
+    def set_input(self, A: Tensor, B: Tensor):
+        self.in_A, self.in_B = A, B
+        self.real_A, self.real_B = (A, B) if self.opt.direction == 'AtoB' else (B, A)
+
+    def forward(self):                                                       # :366-380
+        self.fake_B = self.netG('A', self.real_A, hook=True)
+        self.rec_A = self.netG('B', self.fake_B)
+        self.fake_A = self.netG('B', self.real_B, hook=True)
+        self.rec_B = self.netG('A', self.fake_A)
+        self.idt_A = self.netG('A', self.real_B)
+        self.idt_B = self.netG('B', self.real_A)
+
+    def features(self, w) -> List[Tensor]:
+        return list(self.g_feats[w].values()) + list(self.d_feats[w].values())
+
+    def _req(self, sd, keys, flag):
+        for k in keys:
+            sd[k].requires_grad_(flag)
+            if flag:
+                sd[k].grad = None
+
+    def optimize_parameters(self):                                           # :571-590
+        o = self.opt
+        T = self.teacher
+        if T is not None:
+            T.set_input(self.in_A, self.in_B)
+            T.optimize_parameters()
+            self.targets = {w: [f.detach().clone() for f in T.features(w)] for w in 'AB'}
+        for w in 'AB':
+            self._req(self.G[w], self.G_keys[w], True)
+            for t in self.T[w]:
+                t.requires_grad_(True)
+                t.grad = None
+            self._req(self.D[w], self.D_w_keys[w] + self.D_a_keys[w], False)
+        self.forward()
+        # ---- generators (:480-546); criterionGAN(pred, True) keeps for_discriminator's default True
+        L = {}
+        L['idt_A'] = F.l1_loss(self.idt_A, self.real_B) * o.lambda_B * o.lambda_identity
+        L['idt_B'] = F.l1_loss(self.idt_B, self.real_A) * o.lambda_A * o.lambda_identity
+        L['G_A'] = gan_loss(o.gan_mode, self.netD('A', self.fake_B), True, True)
+        L['G_B'] = gan_loss(o.gan_mode, self.netD('B', self.fake_A), True, True)
+        L['cycle_A'] = F.l1_loss(self.rec_A, self.real_A) * o.lambda_A
+        L['cycle_B'] = F.l1_loss(self.rec_B, self.real_B) * o.lambda_B
+        loss_G = L['G_A'] + L['G_B'] + L['cycle_A'] + L['cycle_B'] + L['idt_A'] + L['idt_B']
+        if T is not None:
+            # the teacher's discriminators see the student's fakes detached (:497-498): their two features enter the
+            # loss value but carry no gradient
+            T.netD('A', self.fake_B.detach())
+            T.netD('B', self.fake_A.detach())
+            for w, fake, tfake in (('A', self.fake_B, T.fake_B), ('B', self.fake_A, T.fake_A)):
+                feats = list(self.g_feats[w].values()) + [f.detach() for f in T.d_feats[w].values()]
+                gram_l = content_l = l1_l = 0.0
+                for i, f in enumerate(feats):
+                    if i < 4:
+                        f = F.conv2d(f, self.T[w][i])
+                    t = self.targets[w][i]
+                    gram_l = gram_l + F.mse_loss(gram(f), gram(t))
+                    content_l = content_l + F.mse_loss(f, t)
+                    l1_l = l1_l + F.l1_loss(fake, tfake.detach())           # inside the loop: counted once per feature
+                L['gram_' + w], L['content_' + w], L['L1_' + w] = o.lambda_gram * gram_l, o.lambda_content * content_l, o.lambda_L1 * l1_l
+                loss_G = loss_G + L['gram_' + w] + L['content_' + w] + L['L1_' + w]
+        loss_G.backward()
+        if o.lambda_weight > 0.0:                                            # L1_sparsity (:548-569)
+            for w in 'AB':
+                for k in self.G_keys[w]:
+                    if self.G[w][k].dim() == 4:
+                        name = k[:-len('.weight')]
+                        mult = 1.0 if name not in self.HEAVY else (1000.0 if name == 'model.19' else 2.0)
+                        self.G[w][k].grad.add_(o.lambda_weight * mult * torch.sign(self.G[w][k].detach()))
+        params = [self.G[w][k] for w in 'AB' for k in self.G_keys[w]] + [t for w in 'AB' for t in self.T[w]]
+        adam_step(params, [p.grad for p in params], self.st_G, self.lr_G, (0.5, 0.999))
+        for w in 'AB':
+            self._req(self.G[w], self.G_keys[w], False)
+            for t in self.T[w]:
+                t.requires_grad_(False)
+        for n in ('fake_A', 'fake_B', 'rec_A', 'rec_B', 'idt_A', 'idt_B'):
+            setattr(self, n, getattr(self, n).detach())
+        # ---- discriminators (:382-405): real first, then the pooled fake
+        for w, real, fake in (('A', self.real_B, self.fake_B), ('B', self.real_A, self.fake_A)):
+            self._req(self.D[w], self.D_w_keys[w], True)
+            pooled = self.pool[w].query(fake)
+            l_real = gan_loss(o.gan_mode, self.netD(w, real), True, True)
+            l_fake = gan_loss(o.gan_mode, self.netD(w, pooled.detach()), False, True)
+            L['D_' + w] = (l_real + l_fake) * 0.5
+            L['D_' + w].backward()
+        params = [self.D[w][k] for w in 'AB' for k in self.D_w_keys[w]]
+        adam_step(params, [p.grad for p in params], self.st_D, self.lr_D, (0.5, 0.999))
+        for w in 'AB':
+            self._req(self.D[w], self.D_w_keys[w], False)
+        self.losses.update({k: float(v.detach()) for k, v in L.items()})
+
+    def get_D_arch_diff(self, is_teacher: bool):                             # :417-459
+        o = self.opt
+        self.arch = {}
+        new = {}
+        for w, fake, real in (('A', self.fake_B, self.real_B), ('B', self.fake_A, self.real_A)):
+            pf = self.netD(w, fake.detach())
+            l_fake = gan_loss(o.gan_mode, pf, False, True)
+            l_fake_real = gan_loss(o.gan_mode, pf, True, False)
+            l_real = gan_loss(o.gan_mode, self.netD(w, real), True, True)
+            self.arch[w] = (l_fake, l_real)
+            new[w] = (l_fake_real - l_fake).abs()
+        if is_teacher and float(self.cur_diff['A']) != 0.0:       # one test (on A) switches the EMA for both
+            new = {w: o.ema_beta * new[w] + (1.0 - o.ema_beta) * self.cur_diff[w] for w in 'AB'}
+        self.cur_diff = new
+        return new['A'], new['B']
+
+    def clipping_mask_alpha(self):
+        with torch.no_grad():
+            for w in 'AB':
+                for k in self.D_a_keys[w]:
+                    self.D[w][k].clamp_(0, 1)
+
+    def optimizer_netD_arch(self):                                           # :592-600, 407-415
+        T = self.teacher
+        with torch.no_grad():
+            self.forward()
+            T.set_input(self.in_A, self.in_B)
+            T.forward()
+            t_diff = T.get_D_arch_diff(True)
+        for w in 'AB':
+            self._req(self.D[w], self.D_w_keys[w], False)
+            self._req(self.D[w], self.D_a_keys[w], True)
+        s_diff = self.get_D_arch_diff(False)
+        for i, w in enumerate('AB'):
+            loss = (s_diff[i] - t_diff[i]).abs() + (self.arch[w][0] + self.arch[w][1]) * 0.5
+            loss.backward()
+            self.losses.update({'D_arch_diff_' + w: float(s_diff[i].detach()), 'D_arch_' + w: float(loss.detach()),
+                                'teacher_netD_%s_arch_diff' % w: float(t_diff[i])})
+        params = [self.D[w][k] for w in 'AB' for k in self.D_a_keys[w]]
+        adam_step(params, [p.grad for p in params], self.st_A, self.lr_arch, (0.9, 0.999))
+        for w in 'AB':
+            self._req(self.D[w], self.D_a_keys[w], False)
 
 
 # ----------------------------------------------------------------------------------------------

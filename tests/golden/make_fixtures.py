@@ -23,6 +23,8 @@ Fixtures
   options.json          options.parse() results for 7 command lines (flag surface + per-model overrides)
   pix2pix_pruned_d8.npz pruned student built from filter_cfgs/channel_cfgs with irregular widths: eval image + 1 iteration
   pix2pix_resnet_gcc.npz  --backbone resnet (MobileResnet + InstanceNorm) GCC iteration: eval/train images, features, losses
+  cyclegan_gcc.npz      MobileCycleGAN student + online teacher, 2 x (optimize_parameters + arch step): images, features, losses, final state
+  cyclegan_pretrain.npz CycleGAN without teacher, --lambda_weight (heavy-layer L1 sparsity), 1 iteration; ImagePool(3) sequence
   prune_search_d8.npz   binarysearch_threshold trajectory end points with a documented thop stand-in
   prune_d8.npz          scale_prune / norm_prune cfgs + max_min_* at several thresholds (ngf 8)
 """
@@ -472,6 +474,101 @@ def fixture_resnet_gcc():
     print('pix2pix_resnet_gcc ok', {k: round(float(v), 4) for k, v in out.items() if k.startswith('loss.')})
 
 
+CYCLE_ARGV = ['--dataroot', './database/horse2zebra/', '--model', 'cyclegan', '--gpu_ids', '-1', '--ngf', '8', '--ndf', '8',
+              '--teacher_ngf', '16', '--online_distillation', '--darts_discriminator', '--lambda_content', '0.01',
+              '--lambda_gram', '10', '--arch_lr', '1e-4', '--arch_lr_step']
+
+
+def fixture_cyclegan():
+    """MobileCycleGANModel student (ngf 8, masked BN discriminators ndf 8) + online teacher (ngf 16, InstanceNorm
+    discriminators ndf 16), 64x64, N=2, recipe weights 601..: two iterations of optimize_parameters + arch step."""
+    opt = parse(CYCLE_ARGV)
+    opt.teacher_ndf = 16
+    model, teacher = build_gcc(opt)
+    nets = [(model.netG_A, 601), (model.netG_B, 602), (model.netD_A, 603), (model.netD_B, 604),
+            (teacher.netG_A, 605), (teacher.netG_B, 606), (teacher.netD_A, 607), (teacher.netD_B, 608)]
+    for n, sd in nets:
+        load_recipe(n, sd)
+    with torch.no_grad():
+        for i, t in enumerate(model.transform_A_convs):
+            t.weight.copy_(recipe_transform(t.weight.shape[0], t.weight.shape[1], 620 + i))
+        for i, t in enumerate(model.transform_B_convs):
+            t.weight.copy_(recipe_transform(t.weight.shape[0], t.weight.shape[1], 630 + i))
+        model.netD_A.model[2].alpha[0] = 0.3
+        model.netD_B.model[5].alpha[1] = 0.45
+    out = {'direction': np.array(opt.direction), 'gan_mode': np.array(opt.gan_mode),
+           'lambda_L1': np.array(opt.lambda_L1), 'lambda_A': np.array(opt.lambda_A), 'lambda_B': np.array(opt.lambda_B),
+           'lambda_identity': np.array(opt.lambda_identity),
+           'D_keys': np.array(list(model.netD_A.state_dict().keys())),
+           'TD_keys': np.array(list(teacher.netD_A.state_dict().keys())),
+           'loss_names': np.array(model.loss_names), 'teacher_loss_names': np.array(teacher.loss_names)}
+    g = torch.Generator().manual_seed(88)
+    for it in range(2):
+        A, B, vA, vB = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1 for _ in range(4))
+        for n, t in (('A', A), ('B', B), ('vA', vA), ('vB', vB)):
+            out['it%d.%s' % (it, n)] = t.numpy()
+        model.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
+        model.optimize_parameters()
+        if it == 0:
+            for n in ('fake_A', 'fake_B', 'rec_A', 'rec_B', 'idt_A', 'idt_B'):
+                out['it0.' + n] = getattr(model, n).detach().numpy().copy()
+            out['it0.Tfake_A'] = teacher.fake_A.detach().numpy().copy()
+            out['it0.Tfake_B'] = teacher.fake_B.detach().numpy().copy()
+            for w, tg in (('A', model.target_distillation_A_features), ('B', model.target_distillation_B_features)):
+                for j, f in enumerate(tg):
+                    out['it0.target_%s.%d' % (w, j)] = f.detach().numpy().copy()
+            for w in 'AB':
+                for j, f in enumerate(model.get_distillation_features(AorB=w)[:4]):
+                    out['it0.sfeat_%s.%d' % (w, j)] = f.detach().numpy().copy()
+        model.set_input({'A': vA, 'B': vB, 'A_paths': ['a'], 'B_paths': ['b']})
+        model.clipping_mask_alpha()
+        model.optimizer_netD_arch()
+        for k, v in model.get_current_losses().items():
+            out['it%d.loss.%s' % (it, k)] = np.array(v, dtype=np.float64)
+        for k, v in teacher.get_current_losses().items():
+            out['it%d.tloss.%s' % (it, k)] = np.array(v, dtype=np.float64)
+    for tag, net in (('sG_A', model.netG_A), ('sG_B', model.netG_B), ('sD_A', model.netD_A), ('sD_B', model.netD_B),
+                     ('tG_A', teacher.netG_A), ('tG_B', teacher.netG_B), ('tD_A', teacher.netD_A), ('tD_B', teacher.netD_B)):
+        sd_np_sampled('final.%s.' % tag, net.state_dict(), out)
+    for w, tc in (('A', model.transform_A_convs), ('B', model.transform_B_convs)):
+        for i, t in enumerate(tc):
+            out['final.T_%s.%d' % (w, i)] = t.weight.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'cyclegan_gcc.npz'), **out)
+    print('cyclegan_gcc ok', {k: round(float(v), 4) for k, v in out.items() if k.startswith('it1.loss.')})
+
+
+def fixture_cyclegan_pretrain():
+    """pretrain_for_pruning configuration: no teacher, InstanceNorm discriminators, --lambda_weight (L1 sparsity with the
+    heavy-layer multipliers): one iteration; plus the reference ImagePool on a full pool with Python's random seeded."""
+    import random
+    opt = parse(['--dataroot', './database/horse2zebra/', '--model', 'cyclegan', '--gpu_ids', '-1', '--ngf', '8', '--ndf', '8',
+                 '--lambda_weight', '1e-3'])
+    from models import get_model_class
+    model = get_model_class(opt)(opt)
+    for n, sd in ((model.netG_A, 641), (model.netG_B, 642), (model.netD_A, 643), (model.netD_B, 644)):
+        load_recipe(n, sd)
+    g = torch.Generator().manual_seed(89)
+    A, B = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1 for _ in range(2))
+    out = {'A': A.numpy(), 'B': B.numpy(), 'direction': np.array(opt.direction)}
+    model.model_train()
+    model.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
+    model.optimize_parameters()
+    for k, v in model.get_current_losses().items():
+        out['loss.%s' % k] = np.array(v, dtype=np.float64)
+    for tag, net in (('G_A', model.netG_A), ('G_B', model.netG_B), ('D_A', model.netD_A), ('D_B', model.netD_B)):
+        sd_np_sampled('final.%s.' % tag, net.state_dict(), out)
+    from utils.image_pool import ImagePool
+    random.seed(1234)
+    pool = ImagePool(3)
+    seq = []
+    for step in range(8):
+        imgs = torch.arange(2, dtype=torch.float32).reshape(2, 1, 1, 1) + 10 * step
+        seq.append(pool.query(imgs).reshape(-1).numpy().copy())
+    out['pool.returned'] = np.stack(seq)
+    np.savez_compressed(os.path.join(HERE, 'cyclegan_pretrain.npz'), **out)
+    print('cyclegan_pretrain ok', {k: round(float(v), 4) for k, v in out.items() if k.startswith('loss.')}, out['pool.returned'].tolist())
+
+
 def fixture_options():
     import json
     from options import options
@@ -495,13 +592,9 @@ def fixture_options():
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
+    only = sys.argv[1:]            # e.g. "make_fixtures.py cyclegan cyclegan_pretrain"; none = all
     import_reference()
-    fixture_options()
-    fixture_ops()
-    fixture_eval_d8()
-    fixture_gcc_d6()
-    fixture_pretrain_d6()
-    fixture_prune_d8()
-    fixture_pruned_d8()
-    fixture_prune_search()
-    fixture_resnet_gcc()
+    for fn in (fixture_options, fixture_ops, fixture_eval_d8, fixture_gcc_d6, fixture_pretrain_d6, fixture_prune_d8,
+               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain):
+        if not only or fn.__name__[len('fixture_'):] in only:
+            fn()

@@ -104,7 +104,8 @@ def test_init_statistics(golden_dir):
     assert float(sd['model.model.3.bias'].abs().max()) == 0.0
 
 
-def _compare_sd(got, z, prefix, atol, rtol=1e-4, skip=None):
+def _compare_sd(got, z, prefix, atol, rtol=1e-4, skip=None, outliers=0.0, hard=0.0):
+    """outliers: admissible fraction of elements above the tolerance, each still within ``hard``"""
     worst = 0.0
     for k in z.files:
         if not k.startswith(prefix):
@@ -118,9 +119,13 @@ def _compare_sd(got, z, prefix, atol, rtol=1e-4, skip=None):
         if ref.dtype.kind in 'iu':
             assert int(g[0]) == int(ref.reshape(-1)[0]), name
             continue
-        err = np.abs(g - ref).max()
+        d = np.abs(g - ref)
+        err = d.max()
         tol = atol + rtol * np.abs(ref).max()
-        assert err <= tol, (name, err, tol)
+        if outliers > 0.0:
+            assert (d > tol).sum() <= max(1, int(outliers * d.size)) and err <= hard, (name, err, tol, int((d > tol).sum()))
+        else:
+            assert err <= tol, (name, err, tol)
         worst = max(worst, err)
     return worst
 
@@ -289,3 +294,93 @@ def test_resnet_backbone_gcc_iteration(golden_dir):
     _compare_sd(m.G, z, 'final.sG.', atol=3e-5, skip=skip)
     _compare_sd(teacher.G, z, 'final.tG.', atol=3e-5, skip=skip)
     _compare_sd(m.D, z, 'final.sD.', atol=3e-5)
+
+
+def build_cyclegan_oracle(z):
+    """MobileCycleGAN student (ngf 8, masked BN D ndf 8) + teacher (ngf 16, InstanceNorm D ndf 16): cyclegan_gcc.npz"""
+    opt = O.Opt(ngf=8, ndf=8, teacher_ngf=16, teacher_ndf=16, direction=str(z['direction']), gan_mode=str(z['gan_mode']),
+                lambda_L1=float(z['lambda_L1']), lambda_A=float(z['lambda_A']), lambda_B=float(z['lambda_B']),
+                lambda_identity=float(z['lambda_identity']), lambda_content=0.01, lambda_gram=10.0)
+    gs, ds = O.mobile_resnet_shapes(8), O.patchgan_shapes(8, 3, True)
+    gt, dt = O.mobile_resnet_shapes(16), O.patchgan_shapes(16, 3, False, norm='instance')
+    teacher = O.CycleGANOracle(opt, {'A': recipe_state_dict(gt, 605), 'B': recipe_state_dict(gt, 606)},
+                               {'A': recipe_state_dict(dt, 607), 'B': recipe_state_dict(dt, 608)}, masked=False)
+    D = {'A': recipe_state_dict(ds, 603), 'B': recipe_state_dict(ds, 604)}
+    D['A']['model.2.alpha'][0] = 0.3
+    D['B']['model.5.alpha'][1] = 0.45
+    T = {'A': [recipe_transform(64, 32, 620 + i) for i in range(4)], 'B': [recipe_transform(64, 32, 630 + i) for i in range(4)]}
+    m = O.CycleGANOracle(opt, {'A': recipe_state_dict(gs, 601), 'B': recipe_state_dict(gs, 602)}, D, T, masked=True,
+                         teacher=teacher)
+    return m, teacher, opt
+
+
+def _pre_norm_bias(name):
+    return name.endswith('.bias') and not name.startswith('model.26')
+
+
+def test_cyclegan_two_iterations(golden_dir):
+    z = load(golden_dir, 'cyclegan_gcc.npz')
+    assert list(O.patchgan_shapes(8, 3, True).keys()) == [str(k) for k in z['D_keys']]
+    assert list(O.patchgan_shapes(16, 3, False, norm='instance').keys()) == [str(k) for k in z['TD_keys']]
+    m, teacher, opt = build_cyclegan_oracle(z)
+    for it in range(2):
+        m.set_input(torch.from_numpy(z['it%d.A' % it]), torch.from_numpy(z['it%d.B' % it]))
+        m.optimize_parameters()
+        if it == 0:
+            for n in ('fake_A', 'fake_B', 'rec_A', 'rec_B', 'idt_A', 'idt_B'):
+                np.testing.assert_allclose(getattr(m, n).numpy(), z['it0.' + n], atol=3e-5, err_msg=n)
+            np.testing.assert_allclose(teacher.fake_A.numpy(), z['it0.Tfake_A'], atol=3e-5)
+            np.testing.assert_allclose(teacher.fake_B.numpy(), z['it0.Tfake_B'], atol=3e-5)
+            for w in 'AB':
+                for j in range(6):
+                    ref = z['it0.target_%s.%d' % (w, j)]
+                    np.testing.assert_allclose(m.targets[w][j].numpy(), ref, atol=2e-5 + 1e-4 * np.abs(ref).max())
+                for j in range(4):
+                    ref = z['it0.sfeat_%s.%d' % (w, j)]
+                    np.testing.assert_allclose(list(m.g_feats[w].values())[j].detach().numpy(), ref,
+                                               atol=2e-5 + 1e-4 * np.abs(ref).max())
+        m.set_input(torch.from_numpy(z['it%d.vA' % it]), torch.from_numpy(z['it%d.vB' % it]))
+        m.clipping_mask_alpha()
+        m.optimizer_netD_arch()
+        for k in z.files:
+            for pre, who in (('it%d.loss.' % it, m), ('it%d.tloss.' % it, teacher)):
+                if k.startswith(pre):
+                    name, ref = k[len(pre):], float(z[k])
+                    assert abs(who.losses[name] - ref) <= 2e-4 * max(1.0, abs(ref)), (it, k, who.losses[name], ref)
+    # post-step weights: Adam's first steps are sign-like (|update| ~ lr = 2e-4 whatever the gradient's size), so an
+    # element whose gradient is ~0 amplifies fp32 summation-order noise (the oracle sums the gradients of one
+    # G_A(real_A) pass where the reference sums two identical passes).  Seen: 1 element in 2048 per tensor (median
+    # error 1e-7); allowed: 0.2% of a tensor's elements, each within the two steps' bound 2 * 2.2 * lr
+    kw = dict(atol=4e-5, skip=_pre_norm_bias, outliers=2e-3, hard=2 * 2.2 * 2e-4)
+    for w in 'AB':
+        _compare_sd(m.G[w], z, 'final.sG_%s.' % w, **kw)
+        _compare_sd(teacher.G[w], z, 'final.tG_%s.' % w, **kw)
+        _compare_sd(m.D[w], z, 'final.sD_%s.' % w, atol=4e-5)
+        # the InstanceNorm discriminator's inner conv biases also sit in front of a norm
+        _compare_sd(teacher.D[w], z, 'final.tD_%s.' % w, atol=4e-5,
+                    skip=lambda n: n in ('model.2.bias', 'model.5.bias', 'model.8.bias'))
+        for i in range(4):
+            np.testing.assert_allclose(m.T[w][i].detach().numpy(), z['final.T_%s.%d' % (w, i)], atol=1e-4)
+
+
+def test_cyclegan_pretrain_l1_sparsity_and_image_pool(golden_dir):
+    import random
+    z = load(golden_dir, 'cyclegan_pretrain.npz')
+    opt = O.Opt(ngf=8, ndf=8, direction=str(z['direction']), gan_mode='lsgan', lambda_weight=1e-3)
+    gs, ds = O.mobile_resnet_shapes(8), O.patchgan_shapes(8, 3, False, norm='instance')
+    m = O.CycleGANOracle(opt, {'A': recipe_state_dict(gs, 641), 'B': recipe_state_dict(gs, 642)},
+                         {'A': recipe_state_dict(ds, 643), 'B': recipe_state_dict(ds, 644)}, masked=False)
+    m.set_input(torch.from_numpy(z['A']), torch.from_numpy(z['B']))
+    m.optimize_parameters()
+    for k in z.files:
+        if k.startswith('loss.'):
+            ref = float(z[k])
+            assert abs(m.losses[k[5:]] - ref) <= 2e-4 * max(1.0, abs(ref)), (k, m.losses[k[5:]], ref)
+    for w in 'AB':
+        _compare_sd(m.G[w], z, 'final.G_%s.' % w, atol=3e-5, skip=_pre_norm_bias)
+        _compare_sd(m.D[w], z, 'final.D_%s.' % w, atol=3e-5, skip=lambda n: n in ('model.2.bias', 'model.5.bias', 'model.8.bias'))
+    random.seed(1234)
+    pool = O.ImagePool(3)
+    for step in range(8):
+        imgs = torch.arange(2, dtype=torch.float32).reshape(2, 1, 1, 1) + 10 * step
+        assert pool.query(imgs).reshape(-1).tolist() == z['pool.returned'][step].tolist(), step
