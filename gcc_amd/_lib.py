@@ -103,8 +103,8 @@ PROTOTYPES = {
     'gcc_l1_loss': (_I, [_P, _I, _I, _P, _I, _I, _I, _Z, _F, _P, _I, _P, _I, _I, _P, _Z, _P]),
     'gcc_loss_workspace': (_Z, [_Z, _I]),
     'gcc_distill_workspace': (_Z, [_I, _I, _I]),
-    'gcc_distill_fwd': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
-    'gcc_distill_bwd': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _F, _P, _I, _I, _P, _Z, _P]),
+    'gcc_distill_fwd': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
+    'gcc_distill_bwd': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _I, _I, _P, _Z, _P]),
     'gcc_adam_step': (_I, [_P, _P, _I, _I, _F, _F, _F, _F, _I, _P]),
     'gcc_fill_f32': (_I, [_P, _F, _Z, _P]),
     'gcc_clamp_f32': (_I, [_P, _F, _F, _Z, _P]),

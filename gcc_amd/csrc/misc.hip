@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void diff_reduce_kernel(const DiffArgs g) {
     const float t = block_sum256(acc, sh);
     if (threadIdx.x == 0) g.partial[blockIdx.x] = t;
 }
-// stage 2: out = f(sum partial): mode 0: (+)= weight*sum/count ; mode 1: sqrt(sum/count)
+// stage 2: out = f(sum partial): mode 0: (+)= weight*sum/count ; mode 1: sqrt(sum/count) ; mode 2: sum/count
 __global__ __launch_bounds__(256) void scalar_finalize_kernel(const float* partial, int n, double count, float weight,
                                                               float* out, int accumulate, int mode) {
     __shared__ float sh[4];
@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void scalar_finalize_kernel(const float* parti
     const float t = block_sum256(acc, sh);
     if (threadIdx.x == 0) {
         if (mode == 0) out[0] = (accumulate ? out[0] : 0.f) + weight * (float)((double)t / count);
-        else out[0] = sqrtf((float)((double)t / count));
+        else if (mode == 1) out[0] = sqrtf((float)((double)t / count));
+        else out[0] = (float)((double)t / count);
     }
 }
 
@@ -236,13 +237,14 @@ __global__ __launch_bounds__(256) void gram_diff_kernel(const float* __restrict_
     const float t = block_sum256(acc, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
-// df = kg * dfg + kc * (f - t),  kg = wg*2/(N*C*C*Lg*C*HW),  kc = wc/(N*C*HW*Lc)
+// df = kg * dfg + kc * (f - t),  kg = wg*2/(N*C*C*Lg*C*HW),  kc = wc/(N*C*HW*Lc)   (RMSE terms, Pix2Pix)
+// squared (plain MSE terms, CycleGAN): d(L^2) = 2 L dL  ->  kg = 2*kg0, kc = 2*kc0
 __global__ __launch_bounds__(256) void distill_combine_kernel(const bf16_t* __restrict__ f, int ldf, int foff,
                                                               const bf16_t* __restrict__ t, int ldt, int toff,
                                                               const bf16_t* __restrict__ dfg, int CH, size_t pixels,
-                                                              const float* scal, float kg0, float kc0, bf16_t* __restrict__ df,
-                                                              int lddf, int dfoff) {
-    const float kg = kg0 / scal[0], kc = kc0 / scal[1];
+                                                              const float* scal, float kg0, float kc0, int squared,
+                                                              bf16_t* __restrict__ df, int lddf, int dfoff) {
+    const float kg = squared ? 2.f * kg0 : kg0 / scal[0], kc = squared ? 2.f * kc0 : kc0 / scal[1];
     const size_t total = pixels * CH;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t pix = i / CH;
@@ -484,7 +486,7 @@ extern "C" size_t gcc_distill_workspace(int N, int C, int HW) {
 }
 
 extern "C" int gcc_distill_fwd(const void* f, int ldf, int foff, const void* t, int ldt, int toff, int N, int C, int HW,
-                               float* out2, void* ws, size_t ws_bytes, gcc_stream_t stream) {
+                               int squared, float* out2, void* ws, size_t ws_bytes, gcc_stream_t stream) {
     GCC_ENTER();
     if (!f || !t || !out2 || !ws || N <= 0 || C <= 0 || HW <= 0 || (C & 7)) return GCC_ERR_BAD_ARG;
     if ((ldf | foff | ldt | toff) & 7) return GCC_ERR_BAD_ARG;
@@ -509,7 +511,7 @@ extern "C" int gcc_distill_fwd(const void* f, int ldf, int foff, const void* t, 
                        ng, 1.f / ((float)C * (float)HW), (bf16_t*)(base + L.s), partial);
     GCC_CHECK_LAUNCH();
     hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)partial, b1, (double)ng, 1.f,
-                       scal + 0, 0, 1);
+                       scal + 0, 0, squared ? 2 : 1);
     GCC_CHECK_LAUNCH();
     DiffArgs g;
     g.a = (const bf16_t*)f; g.lda = ldf; g.aoff = foff; g.b = (const bf16_t*)t; g.ldb = ldt; g.boff = toff;
@@ -519,14 +521,14 @@ extern "C" int gcc_distill_fwd(const void* f, int ldf, int foff, const void* t, 
     hipLaunchKernelGGL(diff_reduce_kernel, dim3(b2), dim3(256), 0, st, g);
     GCC_CHECK_LAUNCH();
     hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)(partial + RED_BLOCKS), b2,
-                       (double)N * HW * C, 1.f, scal + 1, 0, 1);
+                       (double)N * HW * C, 1.f, scal + 1, 0, squared ? 2 : 1);
     GCC_CHECK_LAUNCH();
     if (hipMemcpyAsync(out2, scal, 2 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return GCC_ERR_LAUNCH;
     return GCC_OK;
 }
 
 extern "C" int gcc_distill_bwd(const void* f, int ldf, int foff, const void* t, int ldt, int toff, int N, int C, int HW,
-                               float wg, float wc, void* df, int lddf, int dfoff, void* ws, size_t ws_bytes,
+                               int squared, float wg, float wc, void* df, int lddf, int dfoff, void* ws, size_t ws_bytes,
                                gcc_stream_t stream) {
     GCC_ENTER();
     if (!f || !t || !df || !ws || N <= 0 || C <= 0 || HW <= 0 || (C & 7)) return GCC_ERR_BAD_ARG;
@@ -544,7 +546,7 @@ extern "C" int gcc_distill_bwd(const void* f, int ldf, int foff, const void* t, 
     const size_t pixels = (size_t)N * HW;
     hipLaunchKernelGGL(distill_combine_kernel, dim3(grid_for(pixels * (C / 8), 256 * 2, 4096)), dim3(256), 0, st,
                        (const bf16_t*)f, ldf, foff, (const bf16_t*)t, ldt, toff, (const bf16_t*)(base + L.dfg), C / 8, pixels,
-                       (const float*)(base + L.scal), (float)kg0, (float)kc0, (bf16_t*)df, lddf, dfoff);
+                       (const float*)(base + L.scal), (float)kg0, (float)kc0, squared, (bf16_t*)df, lddf, dfoff);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

@@ -380,12 +380,15 @@ class PatchGANEngine:
             idx.append((i, None, None))
         self.idx = idx
         self.L = len(idx)
-        self.conv, self.bn, self.gate = [], [], []
+        self.conv, self.bn, self.gate, self.inorm = [], [], [], []
         for li, (ci, bi, gi) in enumerate(idx):
             m = getattr(seq, str(ci))
             stride = 2 if li < self.L - 2 else 1
             self.conv.append(ConvOp(m.weight, m.bias, 4, stride, 1, False))
-            self.bn.append(BNOp(getattr(seq, str(bi))) if bi is not None else None)
+            norm = getattr(seq, str(bi)) if bi is not None else None
+            # CycleGAN's plain discriminator normalises per image (InstanceNorm2d, no parameters): models/CycleGAN.py:139-177
+            self.inorm.append(isinstance(norm, nn.InstanceNorm2d))
+            self.bn.append(BNOp(norm) if isinstance(norm, nn.BatchNorm2d) else None)
             self.gate.append(getattr(seq, str(gi)) if gi is not None else None)
         self.chan = [c.rows for c in self.conv]
         self.in_nc = self.conv[0].cols
@@ -434,7 +437,7 @@ class PatchGANEngine:
         for li in range(1, self.L - 1):
             c.c[li] = ops.new_act(N, self.chan[li], c.hs[li][0], c.hs[li][1], dev)
             c.y[li] = ops.new_act(N, self.chan[li], c.hs[li][0], c.hs[li][1], dev)
-            c.st[li] = ops.BNState(self.chan[li], dev)
+            c.st[li] = ops.INState(N, self.chan[li], dev) if self.inorm[li] else ops.BNState(self.chan[li], dev)
         c.pred = ops.new_act(N, 1, c.hs[-1][0], c.hs[-1][1], dev)
         self.ctx[key] = c
         return c
@@ -467,10 +470,15 @@ class PatchGANEngine:
             ops.bnact_fwd(c.a0, c.g0, gate=self.mask[0], gate_after_act=True)
         src = c.g0
         for li in range(1, L - 1):
-            _, stats = self.conv[li].forward(src, c.c[li], want_stats=True)
-            n = c.N * c.hs[li][0] * c.hs[li][1]
-            self.bn[li].finalize(stats, n, c.st[li], train)
-            ops.bnact_fwd(c.c[li], c.y[li], scale=c.st[li].scale, shift=c.st[li].shift, gate=self.mask[li], act=ACT_LRELU)
+            if self.inorm[li]:
+                self.conv[li].forward(src, c.c[li])
+                ops.in_finalize(ops.channel_stats(c.c[li]), c.hs[li][0] * c.hs[li][1], c.st[li])
+                ops.bnact_fwd(c.c[li], c.y[li], scale=c.st[li].scale, shift=c.st[li].shift, act=ACT_LRELU, groups=c.N)
+            else:
+                _, stats = self.conv[li].forward(src, c.c[li], want_stats=True)
+                n = c.N * c.hs[li][0] * c.hs[li][1]
+                self.bn[li].finalize(stats, n, c.st[li], train)
+                ops.bnact_fwd(c.c[li], c.y[li], scale=c.st[li].scale, shift=c.st[li].shift, gate=self.mask[li], act=ACT_LRELU)
             src = c.y[li]
         self.conv[L - 1].forward(src, c.pred)
         c.train = train
@@ -494,12 +502,15 @@ class PatchGANEngine:
             if li == L - 2 and not has_pred_grad:
                 assert g2 is not None, 'nothing to back-propagate'
                 g1, g2 = g2, None
-            bn = self.bn[li].bn
             gate = self.gate[li]
-            ops.bnact_bwd(c.c[li], c.y[li], g1, G.layer[li], g2=g2, bn=c.st[li], gamma=bn.weight.data, beta=bn.bias.data,
-                          gate=self.mask[li], act=ACT_LRELU, act2=ACT_LRELU, dgamma=bn.weight.grad if wgrad else None,
-                          dbeta=bn.bias.grad if wgrad else None,
-                          dalpha=gate.alpha.grad if (agrad and gate is not None) else None)
+            if self.inorm[li]:
+                ops.bnact_bwd(c.c[li], c.y[li], g1, G.layer[li], g2=g2, bn=c.st[li], act=ACT_LRELU, act2=ACT_LRELU, groups=c.N)
+            else:
+                bn = self.bn[li].bn
+                ops.bnact_bwd(c.c[li], c.y[li], g1, G.layer[li], g2=g2, bn=c.st[li], gamma=bn.weight.data, beta=bn.bias.data,
+                              gate=self.mask[li], act=ACT_LRELU, act2=ACT_LRELU, dgamma=bn.weight.grad if wgrad else None,
+                              dbeta=bn.bias.grad if wgrad else None,
+                              dalpha=gate.alpha.grad if (agrad and gate is not None) else None)
             src = c.g0 if li == 1 else c.y[li - 1]
             if wgrad:
                 self.conv[li].backward_weight(src, G.layer[li])

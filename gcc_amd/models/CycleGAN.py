@@ -1,0 +1,528 @@
+"""MobileCycleGAN GCC model on MI355X -- the reference's ``models/CycleGAN.py`` surface
+(set_input / forward / optimize_parameters / optimizer_netD_arch / save_models / ...) over the HIP engine.
+
+Kept name-for-name: class names and constructor signatures, the ``netG_A`` / ``netG_B`` / ``netD_A`` / ``netD_B``
+module trees (state_dict keys equal the reference's), ``loss_names`` / ``visual_names``, optimizers, schedulers and
+the checkpoint dict layout ('G_A', 'G_B', 'D_A', 'D_B', 'epoch', 'cfg', 'fid').
+
+The step is written out explicitly in the order of models/CycleGAN.py:571-600:
+    [teacher step] -> forward -> generators (identity, GAN, cycle, distillation) -> Adam(G)
+                   -> discriminators on (real, pooled fake) -> Adam(D);      arch step: alpha gates of both D.
+forward() runs each generator once per distinct input: the reference calls G_A(real_A) and G_B(real_B) twice only
+to leave its forward hooks pointing at those passes; InstanceNorm has no state and dropout is 0, so the second pass
+is the same arithmetic and autograd would add the same gradients.
+Naming: netG_A maps domain A -> B and is judged by netD_A (on domain B); side 'A' below means that pair.
+"""
+import copy
+import os
+import random
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import dist as gdist
+from .. import engine, ops
+from .._lib import GccError
+from ..utils import util
+from .DifferentiableOp import DifferentiableOP
+from .Pix2Pix import HipAdam, MobileResnetGenerator, _patchgan_tree, _portable
+
+HEAVY_SPARSITY = ('model.1', 'model.4', 'model.19', 'model.22')      # models/CycleGAN.py:243, 548-569
+
+
+class NLayerDiscriminator(nn.Module):
+    """InstanceNorm PatchGAN parameter tree (models/CycleGAN.py:139-177): convs (all biased) at model.0/2/5/8/11"""
+
+    def __init__(self, input_nc=3, ndf=64, n_layers=3):
+        super().__init__()
+        _patchgan_tree(self, input_nc, ndf, n_layers, False, 0.5, norm='instance')
+
+
+class MaskNLayerDiscriminator(nn.Module):
+    """Selective-activation PatchGAN with BatchNorm (models/CycleGAN.py:179-222): convs at model.0/3/7/11/15, BN at
+    4/8/12, gates (alpha) at 2/5/9/13"""
+
+    def __init__(self, input_nc=3, ndf=64, n_layers=3, threshold=0.5):
+        super().__init__()
+        _patchgan_tree(self, input_nc, ndf, n_layers, True, threshold)
+
+
+class ImagePool:
+    """utils/image_pool.py:5-54 on device buffers: the history holds NHWC bf16 images; the random draws are Python's
+    ``random`` in the reference's order (uniform per image once full, randint on a swap)."""
+
+    def __init__(self, pool_size):
+        self.pool_size = pool_size
+        self.images = []
+
+    def query(self, images, out):
+        """images: NHWC bf16 batch view [N,3,H,W]; out: batch buffer of the same geometry that receives the answer"""
+        N = images.shape[0]
+        for i in range(N):
+            src, dst = images[i:i + 1], out[i:i + 1]
+            if self.pool_size == 0:
+                ops.nhwc_copy(src, 0, dst, 0, 3)
+            elif len(self.images) < self.pool_size:
+                keep = ops.new_act(1, 3, images.shape[2], images.shape[3], images.device)
+                ops.nhwc_copy(src, 0, keep, 0, 3)
+                self.images.append(keep)
+                ops.nhwc_copy(src, 0, dst, 0, 3)
+            elif random.uniform(0, 1) > 0.5:
+                j = random.randint(0, self.pool_size - 1)
+                ops.nhwc_copy(self.images[j], 0, dst, 0, 3)
+                ops.nhwc_copy(src, 0, self.images[j], 0, 3)
+            else:
+                ops.nhwc_copy(src, 0, dst, 0, 3)
+        return out
+
+
+class MobileCycleGANModel(nn.Module):
+
+    def __init__(self, opt, cfg_AtoB=None, cfg_BtoA=None):
+        super().__init__()
+        self.opt = opt
+        if len(opt.gpu_ids) == 0 or not torch.cuda.is_available():
+            raise GccError('gcc_amd runs on MI355X only (no CPU path): need a visible GPU and gpu_ids >= 0')
+        self.device = gdist.local_device(opt)
+        ops.lib()
+        self.cfg_AtoB, self.cfg_BtoA = cfg_AtoB, cfg_BtoA
+        self.loss_names = ['D_A', 'G_A', 'cycle_A', 'idt_A', 'D_B', 'G_B', 'cycle_B', 'idt_B']
+        self.visual_names = ['real_A', 'fake_B', 'rec_A', 'idt_B', 'real_B', 'fake_A', 'rec_B', 'idt_A']
+        self.generator_extract_layers = ['model.9', 'model.12', 'model.15', 'model.18']
+        self.discriminator_extract_layers = ['model.4', 'model.12'] if opt.darts_discriminator else ['model.3', 'model.9']
+        self.heavy_sparsity = list(HEAVY_SPARSITY)
+        self.teacher_model = None
+        dev = self.device
+
+        self.netG_A = MobileResnetGenerator(ngf=opt.ngf, cfg=cfg_AtoB)
+        self.netG_B = MobileResnetGenerator(ngf=opt.ngf, cfg=cfg_BtoA)
+        self.distill = bool(opt.online_distillation or opt.normal_distillation)
+        self.transform_A_convs, self.transform_B_convs = [], []
+        if self.distill:
+            for cfg, lst in ((cfg_AtoB, self.transform_A_convs), (cfg_BtoA, self.transform_B_convs)):
+                s = opt.ngf * 4 if cfg is None else cfg[2]
+                lst += [nn.Conv2d(s, opt.teacher_ngf * 4, 1, 1, 0, bias=False).to(dev) for _ in range(4)]
+        masked = bool(opt.darts_discriminator)
+        if masked:
+            self.loss_names += ['D_arch_diff_A', 'D_arch_A', 'D_arch_diff_B', 'D_arch_B', 'teacher_netD_A_arch_diff',
+                                'teacher_netD_B_arch_diff']
+            self.netD_A = MaskNLayerDiscriminator(ndf=opt.ndf, threshold=opt.threshold)
+            self.netD_B = MaskNLayerDiscriminator(ndf=opt.ndf, threshold=opt.threshold)
+        else:
+            self.netD_A = NLayerDiscriminator(ndf=opt.ndf)
+            self.netD_B = NLayerDiscriminator(ndf=opt.ndf)
+        self.init_net()
+
+        # ---- optimizers over flat parameter groups (:245-343)
+        g_params, g_l1 = [], []
+        for net, tconvs in ((self.netG_A, self.transform_A_convs), (self.netG_B, self.transform_B_convs)):
+            for name, m in net.named_modules():
+                if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                    mult = 1.0 if name not in HEAVY_SPARSITY else (1000.0 if name == 'model.19' else 2.0)
+                    for p in m.parameters():
+                        g_params.append(p)
+                        g_l1.append(opt.lambda_weight * mult if (p.dim() == 4 and opt.lambda_weight > 0.0) else 0.0)
+            for t in tconvs:
+                g_params.append(t.weight)
+                g_l1.append(0.0)
+        self.optimizer_G = HipAdam(g_params, lr=opt.lr, betas=(0.5, 0.999), l1=g_l1)
+        w_params, a_params = [], []
+        for net in (self.netD_A, self.netD_B):
+            for m in net.modules():
+                if isinstance(m, (nn.Conv2d, nn.BatchNorm2d)):
+                    w_params += list(m.parameters())
+                elif isinstance(m, DifferentiableOP):
+                    a_params += list(m.parameters())
+        self.optimizer_D = HipAdam(w_params, lr=opt.lr, betas=(0.5, 0.999))
+        if masked:
+            self.optimizer_arch = HipAdam(a_params, lr=opt.arch_lr)
+            if opt.arch_lr_step:
+                arch_opt = copy.deepcopy(opt)
+                arch_opt.lr_policy = 'step'
+                arch_opt.lr_decay_iters = opt.n_epochs - 1
+                self.arch_scheduler = util.get_scheduler(self.optimizer_arch, arch_opt)
+
+        # ---- engines
+        self.G = {'A': engine.MobileResnetEngine(self.netG_A, dev), 'B': engine.MobileResnetEngine(self.netG_B, dev)}
+        self.D = {'A': engine.PatchGANEngine(self.netD_A, masked, opt.threshold, dev),
+                  'B': engine.PatchGANEngine(self.netD_B, masked, opt.threshold, dev)}
+        self.T = {'A': [engine.ConvOp(t.weight, None, 1, 1, 0, False) for t in self.transform_A_convs],
+                  'B': [engine.ConvOp(t.weight, None, 1, 1, 0, False) for t in self.transform_B_convs]}
+        self.refresh_weights()
+        self.pool = {'A': ImagePool(50), 'B': ImagePool(50)}     # fake_B_pool feeds D_A, fake_A_pool feeds D_B
+
+        self.optimizers = [self.optimizer_G, self.optimizer_D]
+        self.schedulers = [util.get_scheduler(o, opt) for o in self.optimizers]
+        if masked and opt.arch_lr_step:
+            self.schedulers.append(self.arch_scheduler)
+        names = []
+        for w in 'AB':
+            names += [n + w for n in ('G_', 'cycle_', 'idt_', 'D_real_', 'D_fake_', 'L1_', 'arch_fake_', 'arch_fake_real_',
+                                      'arch_real_', 'D_arch_diff_', 'D_arch_', 'teacher_diff_', 'arch_c_fr_', 'arch_c_f_',
+                                      's0_', 's1_', 's2_')]
+        self._slot = {n: i for i, n in enumerate(names)}
+        self._lossvec = torch.zeros(len(names) + 4, dtype=torch.float32, device=dev)
+        self._dist_out = {w: torch.zeros((6, 2), dtype=torch.float32, device=dev) for w in 'AB'}
+        self._bufs = {}
+        self._ema_started = False
+        self._world = gdist.world_size()
+        self._ctx = None
+        self._nchw = {}
+        self._dctx_last = {}
+
+    # ---------------------------------------------------------------------------------------
+    def _l(self, name):
+        i = self._slot[name]
+        return self._lossvec[i:i + 1]
+
+    def refresh_weights(self):
+        for w in 'AB':
+            self.G[w].repack()
+            self.D[w].repack()
+            for t in self.T[w]:
+                t.repack()
+
+    def init_net(self):
+        for net in (self.netG_A, self.netG_B, self.netD_A, self.netD_B):
+            net.to(self.device)
+            for m in net.modules():
+                if isinstance(m, DifferentiableOP):
+                    m.threshold = m.threshold.to(self.device)
+            util.init_weights(net, init_type='normal', init_gain=0.02)
+            gdist.broadcast_module(net)
+
+    # ---------------------------------------------------------------------------------------
+    def set_input(self, input):
+        self.input = input
+        AtoB = self.opt.direction == 'AtoB'
+        self.real_A = input['A' if AtoB else 'B'].to(self.device, torch.float32).contiguous()
+        self.real_B = input['B' if AtoB else 'A'].to(self.device, torch.float32).contiguous()
+        self.image_paths = [input.get('A_paths' if AtoB else 'B_paths'), input.get('B_paths' if AtoB else 'A_paths')]
+        N, _, H, W = self.real_A.shape
+        if getattr(self, '_A', None) is None or tuple(self._A.shape) != (N, 3, H, W):
+            self._A = ops.new_act(N, 3, H, W, self.device)
+            self._B = ops.new_act(N, 3, H, W, self.device)
+        ops.nchw_to_nhwc(self.real_A, self._A)
+        ops.nchw_to_nhwc(self.real_B, self._B)
+
+    def _g(self, w, tag, src):
+        """one generator pass: G_w on the NHWC image ``src``"""
+        N, _, H, W = src.shape
+        c = self.G[w]._ctx(N, H, W, tag)
+        ops.nhwc_copy(src, 0, c.x_in, 0, 3)
+        return self.G[w].forward(c)
+
+    def forward(self):
+        """six generator passes (:366-380); the contexts keep every activation for backward_G"""
+        c = {}
+        c['fake_B'] = self._g('A', 'fake', self._A)            # G_A(A)
+        c['rec_A'] = self._g('B', 'rec', c['fake_B'].out)      # G_B(G_A(A))
+        c['fake_A'] = self._g('B', 'fake', self._B)            # G_B(B)
+        c['rec_B'] = self._g('A', 'rec', c['fake_A'].out)      # G_A(G_B(B))
+        c['idt_A'] = self._g('A', 'idt', self._B)              # G_A(B)
+        c['idt_B'] = self._g('B', 'idt', self._A)              # G_B(A)
+        self._ctx = c
+        self._nchw = {}
+
+    def visual_forward(self):
+        self._ctx = {'fake_B': self._g('A', 'fake', self._A)}
+        self._nchw = {}
+
+    def _image(self, name):
+        if name not in self._nchw:
+            self._nchw[name] = ops.nhwc_to_nchw(self._ctx[name].out, 3)
+        return self._nchw[name]
+
+    fake_A = property(lambda self: self._image('fake_A'))
+    fake_B = property(lambda self: self._image('fake_B'))
+    rec_A = property(lambda self: self._image('rec_A'))
+    rec_B = property(lambda self: self._image('rec_B'))
+    idt_A = property(lambda self: self._image('idt_A'))
+    idt_B = property(lambda self: self._image('idt_B'))
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _d_forward(self, w, tag, img):
+        N, _, H, W = img.shape
+        ctx = self.D[w].new_ctx(N, H, W, tag)
+        ops.nhwc_copy(img, 0, ctx.x_in, 0, 3)
+        self.D[w].forward(ctx, train=True)
+        return ctx
+
+    def _buf(self, key, N, C, H, W):
+        key = (key, N, C, H, W)
+        if key not in self._bufs:
+            self._bufs[key] = ops.new_act(N, C, H, W, self.device)
+        return self._bufs[key]
+
+    def _dws(self, key, N, C, HW):
+        key = ('ws', key, N, C, HW)
+        if key not in self._bufs:
+            self._bufs[key] = torch.empty(ops.distill_workspace_bytes(N, C, HW), dtype=torch.uint8, device=self.device)
+        return self._bufs[key]
+
+    def _allreduce(self, optimizer):
+        gdist.all_reduce_grads(optimizer)
+
+    # -- generators (:480-546) ------------------------------------------------------------------------
+    def backward_G(self):
+        opt, mode, c = self.opt, self.opt.gan_mode, self._ctx
+        lam = {'A': opt.lambda_A, 'B': opt.lambda_B}
+        real = {'A': self._A, 'B': self._B}
+        T = self.teacher_model
+        # identity terms: idt_A = G_A(B) against B (weight lambda_B), idt_B = G_B(A) against A (weight lambda_A)
+        for w, dom in (('A', 'B'), ('B', 'A')):
+            ci = c['idt_' + w]
+            ops.l1_loss(ci.out, real[dom], self._l('idt_' + w), weight=lam[dom] * opt.lambda_identity, da=ci.g_out)
+            self.G[w].backward(ci)
+        # per side: fake = G_w(real), judged by D_w; the cycle through the other generator returns dL/d(fake)
+        for w, o, fake, rec in (('A', 'B', 'fake_B', 'rec_A'), ('B', 'A', 'fake_A', 'rec_B')):
+            cf, cr = c[fake], c[rec]
+            # the cycle that starts in G_w ends on G_w's input domain: rec_A = G_B(G_A(A)) against A, weight lambda_A
+            ops.l1_loss(cr.out, real[w], self._l('cycle_' + w), weight=lam[w], da=cr.g_out)
+            dx = self.G[o].backward(cr, need_dx=True)
+            ops.nhwc_copy(dx, 0, cf.g_out, 0, 3)
+            # GAN term: criterionGAN(D_w(fake), True) keeps for_discriminator's default True (:492-494)
+            cd = self._d_forward(w, 'g_fake', cf.out)
+            ops.gan_loss(mode, cd.pred, True, True, self._l('G_' + w), dpred=self.D[w].grad_pred_buffer(cd))
+            dxd = self.D[w].backward(cd, wgrad=False, need_dx=True)
+            ops.nhwc_add(dxd, 0, cf.g_out, 0, 3)
+            g_feat = None
+            if self.distill:
+                g_feat = self._distill_side(w, cf, T._ctx[fake])
+            self.G[w].backward(cf, g_feat=g_feat)
+
+    def _distill_side(self, w, cf, tcf):
+        """distillation terms of one generator (:497-541): four transformed generator features carry gradients; the
+        teacher discriminator's two features on the (detached) student fake only enter the loss value"""
+        opt, T = self.opt, self.teacher_model
+        N = cf.N
+        ct = T._d_forward(w, 'on_student', cf.out)
+        feats = self.G[w].features(cf) + T.D[w].features(ct)
+        targets = self.target_distillation_A_features if w == 'A' else self.target_distillation_B_features
+        g_feat = []
+        for i in range(6):
+            f, t = feats[i], targets[i]
+            if i < 4:
+                tf = self._buf(('tf', w, i), N, self.T[w][i].rows, f.shape[2], f.shape[3])
+                self.T[w][i].forward(f, tf)
+            else:
+                tf = f
+            ws = self._dws((w, i), N, tf.shape[1], tf.shape[2] * tf.shape[3])
+            ops.distill_fwd(tf, t, self._dist_out[w][i], ws, squared=True)
+            if i < 4:
+                dtf = self._buf(('dtf', w, i), N, tf.shape[1], tf.shape[2], tf.shape[3])
+                ops.distill_bwd(tf, t, opt.lambda_gram, opt.lambda_content, dtf, ws, squared=True)
+                self.T[w][i].backward_weight(f, dtf)
+                gbuf = self._buf(('gf', w, i), N, f.shape[1], f.shape[2], f.shape[3])
+                self.T[w][i].backward_data(dtf, gbuf)
+                g_feat.append(gbuf)
+        if opt.lambda_L1 > 0.0:
+            # criterionL1(fake, Tfake) is added once per feature inside the reference's loop: 6 x lambda_L1
+            tmp = self._buf(('l1', w), N, 3, cf.H, cf.W)
+            ops.l1_loss(cf.out, tcf.out, self._l('L1_' + w), weight=6.0 * opt.lambda_L1, da=tmp)
+            ops.nhwc_add(tmp, 0, cf.g_out, 0, 3)
+        ops.SideStream.get(self.device).join()
+        return g_feat
+
+    # -- discriminators (:382-405): real first, then the pooled fake --------------------------------------
+    def backward_D(self):
+        mode = self.opt.gan_mode
+        for w, real, fake in (('A', self._B, 'fake_B'), ('B', self._A, 'fake_A')):
+            img = self._ctx[fake].out
+            pooled = self.pool[w].query(img, self._buf(('pool', w), *img.shape))
+            cr = self._d_forward(w, 'd_real', real)
+            cf = self._d_forward(w, 'd_fake', pooled)
+            gp = self.D[w].grad_pred_buffer(cr)
+            ops.gan_loss(mode, cr.pred, True, True, self._l('D_real_' + w), dpred=gp, grad_weight=0.5)
+            self.D[w].backward(cr, wgrad=True, need_dx=False)
+            ops.gan_loss(mode, cf.pred, False, True, self._l('D_fake_' + w), dpred=gp, grad_weight=0.5)
+            self.D[w].backward(cf, wgrad=True, need_dx=False)
+            self._dctx_last[w] = cf          # what the reference's D hooks hold after the iteration
+
+    # -- one iteration (:571-590) -------------------------------------------------------------------------
+    def optimize_parameters(self):
+        if self.opt.online_distillation:
+            T = self.teacher_model
+            T.set_input(self.input)
+            T.optimize_parameters()
+            # the reference clones; here the teacher's activation buffers are not overwritten before they are consumed
+            self.target_distillation_A_features = T.get_distillation_features(AorB='A')
+            self.target_distillation_B_features = T.get_distillation_features(AorB='B')
+        self.forward()
+        self.optimizer_G.zero_grad()
+        self.backward_G()
+        self._allreduce(self.optimizer_G)
+        self.optimizer_G.step()          # L1_sparsity() (:548-569) is fused into the Adam kernel, per-tensor weights
+        for w in 'AB':
+            self.G[w].repack()
+            for t in self.T[w]:
+                t.repack()
+        self.optimizer_D.zero_grad()
+        self.backward_D()
+        self._allreduce(self.optimizer_D)
+        self.optimizer_D.step()
+        for w in 'AB':
+            self.D[w].repack()
+
+    # -- architecture step (:407-459, 592-600) ----------------------------------------------------------------
+    def get_D_arch_diff(self, isTeacher=False):
+        mode = self.opt.gan_mode
+        ctxs = {}
+        for w, fake, real in (('A', 'fake_B', self._B), ('B', 'fake_A', self._A)):
+            cf = self._d_forward(w, 'a_fake', self._ctx[fake].out)
+            cr = self._d_forward(w, 'a_real', real)
+            ops.gan_loss(mode, cf.pred, False, True, self._l('arch_fake_' + w))
+            ops.gan_loss(mode, cf.pred, True, False, self._l('arch_fake_real_' + w))
+            ops.gan_loss(mode, cr.pred, True, True, self._l('arch_real_' + w))
+            out = self._l('teacher_diff_' + w if isTeacher else 'D_arch_diff_' + w)
+            if isTeacher and self._ema_started:        # one flag for both sides, as the reference tests side A only
+                b = float(self.opt.ema_beta)
+                ops.scalar_op(1, self._l('arch_fake_real_' + w), self._l('arch_fake_' + w), out, c=out, k0=b, k1=1.0 - b)
+            else:
+                ops.scalar_op(0, self._l('arch_fake_real_' + w), self._l('arch_fake_' + w), out)
+            ctxs[w] = (cf, cr)
+        self._ema_started = True
+        return ctxs
+
+    def backward_D_arch(self):
+        T, mode = self.teacher_model, self.opt.gan_mode
+        T.get_D_arch_diff(isTeacher=True)
+        ctxs = self.get_D_arch_diff(isTeacher=False)
+        for w in 'AB':
+            cf, cr = ctxs[w]
+            ops.scalar_op(2, T._l('teacher_diff_' + w), T._l('teacher_diff_' + w), self._l('teacher_diff_' + w), k0=0.0)
+            ops.arch_coeffs(self._l('arch_fake_real_' + w), self._l('arch_fake_' + w), self._l('arch_real_' + w),
+                            self._l('teacher_diff_' + w), self._l('D_arch_' + w), self._l('arch_c_fr_' + w),
+                            self._l('arch_c_f_' + w))
+            gp = self.D[w].grad_pred_buffer(cf)
+            ops.gan_loss(mode, cf.pred, True, False, self._l('s0_' + w), dpred=gp, weight_dev=self._l('arch_c_fr_' + w))
+            ops.gan_loss(mode, cf.pred, False, True, self._l('s1_' + w), dpred=gp, weight_dev=self._l('arch_c_f_' + w),
+                         dpred_accumulate=True)
+            self.D[w].backward(cf, wgrad=False, agrad=True, need_dx=False)
+            ops.gan_loss(mode, cr.pred, True, True, self._l('s2_' + w), dpred=gp, grad_weight=0.5)
+            self.D[w].backward(cr, wgrad=False, agrad=True, need_dx=False)
+
+    def optimizer_netD_arch(self):
+        self.forward()
+        T = self.teacher_model
+        T.set_input(self.input)
+        T.forward()
+        self.optimizer_arch.zero_grad()
+        self.backward_D_arch()
+        self._allreduce(self.optimizer_arch)
+        self.optimizer_arch.step()
+
+    def clipping_mask_alpha(self):
+        for net in (self.netD_A, self.netD_B):
+            for m in net.modules():
+                if isinstance(m, DifferentiableOP):
+                    m.clip_alpha()
+
+    # -- bookkeeping surface ----------------------------------------------------------------------
+    def print_sparse_info(self, logger):
+        for tag, net in (('netD_A', self.netD_A), ('netD_B', self.netD_B)):
+            for name, m in net.named_modules():
+                if isinstance(m, DifferentiableOP):
+                    mask = m.get_current_mask()
+                    logger.info('%s %s sparsity ratio: %.2f' % (tag, name, float((mask == 0.0).sum()) / mask.numel()))
+            logger.info('-----------------------------------')
+
+    def adaptive_ema_beta(self, epoch):
+        self.opt.ema_beta = 1.0 - epoch / (self.opt.n_epochs + self.opt.n_epochs_decay)
+
+    def update_learning_rate(self, epoch):
+        for s in self.schedulers:
+            s.step()
+        self.adaptive_ema_beta(epoch)
+        print('learning rate = %.7f' % self.optimizers[0].param_groups[0]['lr'])
+
+    def set_requires_grad(self, nets, requires_grad=False):
+        for net in (nets if isinstance(nets, list) else [nets]):
+            if net is not None:
+                for p in net.parameters():
+                    p.requires_grad = requires_grad
+
+    def save_models(self, epoch, save_dir, fid=None, isbest=False, direction='AtoB'):
+        if gdist.rank() != 0:
+            return
+        util.mkdirs(save_dir)
+        ckpt = {'G_A': _portable(self.netG_A.state_dict()), 'G_B': _portable(self.netG_B.state_dict()),
+                'D_A': _portable(self.netD_A.state_dict()), 'D_B': _portable(self.netD_B.state_dict()),
+                'epoch': epoch, 'cfg': (self.cfg_AtoB, self.cfg_BtoA), 'fid': fid}
+        name = 'model_best_%s.pth' % direction if isbest else 'model_%d.pth' % epoch
+        torch.save(ckpt, os.path.join(save_dir, name))
+
+    def load_models(self, load_path, load_discriminator=True):
+        ckpt = torch.load(load_path, map_location='cpu')
+        self.netG_A.load_state_dict(ckpt['G_A'])
+        self.netG_B.load_state_dict(ckpt['G_B'])
+        if load_discriminator:
+            self.netD_A.load_state_dict(ckpt['D_A'])
+            self.netD_B.load_state_dict(ckpt['D_B'])
+        self.refresh_weights()
+        print('loading the model from %s' % load_path)
+
+    def model_train(self):
+        for net in (self.netG_A, self.netG_B, self.netD_A, self.netD_B):
+            net.train()
+
+    def model_eval(self):
+        for net in (self.netG_A, self.netG_B, self.netD_A, self.netD_B):
+            net.eval()
+
+    def get_current_visuals(self):
+        ret = OrderedDict()
+        for name in self.visual_names:
+            ret[name] = getattr(self, name)
+        return ret
+
+    @property
+    def Tfake_A(self):
+        return self.teacher_model.fake_A
+
+    @property
+    def Tfake_B(self):
+        return self.teacher_model.fake_B
+
+    def get_current_losses(self):
+        """host read of the device loss scalars (the only sync of the iteration)"""
+        v = self._lossvec.cpu()
+        d = {w: self._dist_out[w].cpu() for w in 'AB'}
+        s = self._slot
+        ret = OrderedDict()
+        for name in self.loss_names:
+            w = name[-1]
+            if name in ('D_A', 'D_B'):
+                val = 0.5 * (float(v[s['D_real_' + w]]) + float(v[s['D_fake_' + w]]))
+            elif name.startswith('content_'):
+                val = self.opt.lambda_content * float(d[w][:, 1].sum())
+            elif name.startswith('gram_'):
+                val = self.opt.lambda_gram * float(d[w][:, 0].sum())
+            elif name.startswith('teacher_netD_'):
+                val = float(v[s['teacher_diff_' + name[len('teacher_netD_')]]])
+            else:
+                val = float(v[s[name]])
+            ret[name] = val
+        if self._world > 1:
+            ret = gdist.mean_dict(ret, self.device)
+        return ret
+
+    def init_distillation(self):
+        if self.distill:
+            if self.opt.lambda_content > 0.0:
+                self.loss_names += ['content_A', 'content_B']
+            if self.opt.lambda_gram > 0.0:
+                self.loss_names += ['gram_A', 'gram_B']
+            if self.opt.lambda_L1 > 0.0:
+                self.loss_names += ['L1_A', 'L1_B']
+            self.visual_names += ['Tfake_A', 'Tfake_B']
+
+    def get_distillation_features(self, AorB='A'):
+        """4 generator features of the G(real) pass + the 2 discriminator features of the last D call of the iteration
+        (the pooled fake of the D step), as the reference's hooks end up holding them"""
+        w = AorB
+        return self.G[w].features(self._ctx['fake_B' if w == 'A' else 'fake_A']) + self.D[w].features(self._dctx_last[w])
+
+    def get_cfg(self):
+        return self.cfg_AtoB, self.cfg_BtoA

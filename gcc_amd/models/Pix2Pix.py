@@ -143,7 +143,9 @@ class MobileResnetGenerator(nn.Module):
                        '(gcc_amd.engine.MobileResnetEngine)')
 
 
-def _patchgan_tree(self, input_nc, ndf, n_layers, masked, threshold):
+def _patchgan_tree(self, input_nc, ndf, n_layers, masked, threshold, norm='batch'):
+    """norm='instance': the CycleGAN plain discriminator (InstanceNorm2d without parameters, a bias on every conv)"""
+    inorm = norm == 'instance'
     ch = [ndf * min(2 ** i, 8) for i in range(n_layers + 1)]
     seq = nn.Module()
     self.add_module('model', seq)
@@ -155,8 +157,8 @@ def _patchgan_tree(self, input_nc, ndf, n_layers, masked, threshold):
         i += 1
     for n in range(1, n_layers + 1):
         stride = 2 if n < n_layers else 1
-        seq.add_module(str(i), nn.Conv2d(ch[n - 1], ch[n], 4, stride, 1, bias=False))
-        seq.add_module(str(i + 1), _bn(ch[n]))
+        seq.add_module(str(i), nn.Conv2d(ch[n - 1], ch[n], 4, stride, 1, bias=inorm))
+        seq.add_module(str(i + 1), nn.InstanceNorm2d(ch[n]) if inorm else _bn(ch[n]))
         i += 2
         if masked:
             seq.add_module(str(i), DifferentiableOP(ch[n], threshold))

@@ -5,7 +5,10 @@ def get_model_class(opt):
     if opt.model == 'pix2pix':
         from .Pix2Pix import Pix2PixModel
         return Pix2PixModel
-    if opt.model in ('srgan', 'sagan', 'cyclegan'):
+    if opt.model == 'cyclegan':
+        from .CycleGAN import MobileCycleGANModel
+        return MobileCycleGANModel
+    if opt.model in ('srgan', 'sagan'):
         raise NotImplementedError('%s: not yet on the MI355X path (SURVEY.md section 8 rows a17-a19 are '
                                   'scheduled after the Pix2Pix row is at parity)' % opt.model)
     raise NotImplementedError('%s not implemented' % opt.model)

@@ -515,19 +515,20 @@ def distill_workspace_bytes(N, Cc, HW):
     return lib().gcc_distill_workspace(N, Cc, HW)
 
 
-def distill_fwd(f, t, out2, ws):
+def distill_fwd(f, t, out2, ws, squared=False):
+    """out2 = (gram term, content term): RMSE form (Pix2Pix) or, squared, plain MSE (CycleGAN)"""
     fp, N, Cc, H, W, ldf = geom(f)
     tp, _, _, _, _, ldt = geom(t)
-    check(lib().gcc_distill_fwd(fp, ldf, 0, tp, ldt, 0, N, Cc, H * W, out2.data_ptr(), ws.data_ptr(), ws.numel(),
-                                stream()), 'gcc_distill_fwd')
+    check(lib().gcc_distill_fwd(fp, ldf, 0, tp, ldt, 0, N, Cc, H * W, int(squared), out2.data_ptr(), ws.data_ptr(),
+                                ws.numel(), stream()), 'gcc_distill_fwd')
 
 
-def distill_bwd(f, t, wg, wc, df, ws):
+def distill_bwd(f, t, wg, wc, df, ws, squared=False):
     fp, N, Cc, H, W, ldf = geom(f)
     tp, _, _, _, _, ldt = geom(t)
     dp, _, _, _, _, ldd = geom(df)
-    check(lib().gcc_distill_bwd(fp, ldf, 0, tp, ldt, 0, N, Cc, H * W, float(wg), float(wc), dp, ldd, 0, ws.data_ptr(),
-                                ws.numel(), stream()), 'gcc_distill_bwd')
+    check(lib().gcc_distill_bwd(fp, ldf, 0, tp, ldt, 0, N, Cc, H * W, int(squared), float(wg), float(wc), dp, ldd, 0,
+                                ws.data_ptr(), ws.numel(), stream()), 'gcc_distill_bwd')
 
 
 class AdamPlan:

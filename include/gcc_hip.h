@@ -262,13 +262,14 @@ size_t gcc_loss_workspace(size_t pixels, int C);
 /* Feature distillation, models/Pix2Pix.py:537-548 + :733-740, for one feature pair:
  *   gram(f) = F F^T /(c h w) per image (F = [C][HW]);  Lg = sqrt(mse(gram(f), gram(t))) ;
  *   Lc = sqrt(mse(f, t)).   f,t: NHWC bf16 [N][HW][ld].
+ * squared != 0: the CycleGAN form (models/CycleGAN.py:516-517), plain MSE terms without the square root.
  * gcc_distill_fwd writes the two scalars (unweighted) into out[0..1] and keeps what backward needs
  * in ws; gcc_distill_bwd writes df = wg*dLg/df + wc*dLc/df (bf16, same layout as f). */
 size_t gcc_distill_workspace(int N, int C, int HW);
 int gcc_distill_fwd(const void* f, int ldf, int foff, const void* t, int ldt, int toff, int N, int C, int HW,
-                    float* out2, void* ws, size_t ws_bytes, gcc_stream_t stream);
+                    int squared, float* out2, void* ws, size_t ws_bytes, gcc_stream_t stream);
 int gcc_distill_bwd(const void* f, int ldf, int foff, const void* t, int ldt, int toff, int N, int C, int HW,
-                    float wg, float wc, void* df, int lddf, int dfoff, void* ws, size_t ws_bytes,
+                    int squared, float wg, float wc, void* df, int lddf, int dfoff, void* ws, size_t ws_bytes,
                     gcc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
