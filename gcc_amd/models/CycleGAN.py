@@ -526,3 +526,20 @@ class MobileCycleGANModel(nn.Module):
 
     def get_cfg(self):
         return self.cfg_AtoB, self.cfg_BtoA
+
+    # -- pruning (models/CycleGAN.py:794-900): integer logic on host copies of the weights -------------
+    def max_min_conv_norm(self, netG):
+        from ..utils import prune_util
+        return prune_util.max_min_conv_norm_resnet(netG, 'mean')
+
+    def get_prunenet_cfg(self, netG, threshold):
+        from ..utils import prune_util
+        return prune_util.resnet_prune_cfg(netG, threshold, 'mean')
+
+    def resnet_prune(self, threshold_AtoB, threshold_BtoA):
+        cfg_AtoB = self.get_prunenet_cfg(self.netG_A, threshold_AtoB)
+        cfg_BtoA = self.get_prunenet_cfg(self.netG_B, threshold_BtoA)
+        return MobileCycleGANModel(self.opt, cfg_AtoB=cfg_AtoB, cfg_BtoA=cfg_BtoA)
+
+    def prune(self, threshold, lottery_path=None):
+        return self.resnet_prune(threshold, lottery_path)

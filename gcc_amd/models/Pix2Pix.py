@@ -635,7 +635,7 @@ class Pix2PixModel(nn.Module):
     def get_cfg(self):
         return self.filter_cfgs, self.channel_cfgs
 
-    # -- pruning cfgs (integer logic on host copies of the small per-channel vectors) ---------------
+    # -- pruning cfgs (integer logic on host copies of the weights; models/Pix2Pix.py:742-952) -----------
     def _bn_sd(self):
         return {k: v.detach().cpu() for k, v in self.netG.state_dict().items() if k.endswith('.weight') and v.dim() == 1}
 
@@ -649,14 +649,35 @@ class Pix2PixModel(nn.Module):
         f, c = self.scale_prune_cfg(threshold)
         return Pix2PixModel(self.opt, filter_cfgs=f, channel_cfgs=c)
 
+    def norm_prune(self, threshold):
+        from ..utils import prune_util
+        f, c = prune_util.norm_prune_cfg(self.netG, threshold, self.opt.ngf)
+        return Pix2PixModel(self.opt, filter_cfgs=f, channel_cfgs=c)
+
+    def resnet_prune(self, threshold):
+        from ..utils import prune_util
+        return Pix2PixModel(self.opt, filter_cfgs=prune_util.resnet_prune_cfg(self.netG, threshold, 'union'))
+
     def prune(self, threshold, lottery_path=None):
+        """lottery_path is accepted and ignored: the reference's prune_util passes it (utils/prune_util.py:57) to a
+        method that does not take it (models/Pix2Pix.py:742; SURVEY.md hazard H7)"""
+        if self.opt.backbone == 'resnet':
+            return self.resnet_prune(threshold)
         if self.opt.scale_prune:
             return self.scale_prune(threshold)
-        raise NotImplementedError('only scale pruning is on the MI355X path yet (norm / resnet pruning: next)')
+        if self.opt.norm_prune:
+            return self.norm_prune(threshold)
+        raise NotImplementedError('only scale and norm pruning are supported!!!')
 
     def max_min_bn_scale(self):
         from ..utils import prune_util
         return prune_util.max_min_bn_scale(self._bn_sd(), self.opt.num_downs)
+
+    def max_min_conv_norm(self):
+        from ..utils import prune_util
+        if self.opt.backbone == 'resnet':
+            return prune_util.max_min_conv_norm_resnet(self.netG, 'union')
+        return prune_util.max_min_conv_norm_unet(self.netG)
 
 
 def _portable(sd):

@@ -73,8 +73,8 @@ def main(argv=None):
     model_class = get_model_class(opt)
     model = model_class(opt)
     if opt.norm_prune or opt.scale_prune:
-        from .utils.prune_util import prune
-        model = prune(model, opt, logger)
+        from .utils.prune_util import cyclegan_prune, prune
+        model = cyclegan_prune(model, opt, logger) if 'cyclegan' in opt.model else prune(model, opt, logger)
     if opt.online_distillation:
         attach_teacher(model, opt, model_class)
     if opt.initial_path is not None:

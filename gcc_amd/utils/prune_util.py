@@ -40,7 +40,162 @@ def unet_macs(netG, size=256):
 
 
 def get_flops_parms(model_netG, device, opt, verbose=False):
-    return unet_macs(model_netG, opt.load_size)
+    if hasattr(model_netG.model, 'model'):          # UnetGenertor: model.model.<i>
+        return unet_macs(model_netG, opt.load_size)
+    return mobile_resnet_macs(model_netG, opt.load_size)
+
+
+# ------------------------------------------------------------------------------------------------
+# MobileResnet generator (Pix2Pix --backbone resnet, CycleGAN)
+# ------------------------------------------------------------------------------------------------
+def resnet_cfg_macs(cfg, size=256, in_nc=3, out_nc=3):
+    """thop-convention G-MACs of MobileResnetGenerator(cfg) (23 widths) for a 1 x in_nc x size x size input, by shape
+    arithmetic: convs count out_elements * Cin/groups * k*k, InstanceNorm2d 2 * elements (same convention as the
+    BatchNorm count above).  Known answers: the reference's hard-coded CycleGAN cfgs were searched to 2.4 / 2.7 G
+    (scripts/cyclegan/train.sh, tolerance 0.05) and come out at 2.413 / 2.725 G here."""
+    w = [int(v) for v in cfg]
+    n_blocks = (len(w) - 5) // 2
+    h = size
+    total = h * h * w[0] * in_nc * 49 + 2 * w[0] * h * h
+    for i in (1, 2):
+        h //= 2
+        total += h * h * w[i] * w[i - 1] * 9 + 2 * w[i] * h * h
+    j = 3
+    for _ in range(n_blocks):
+        c_in, c_mid, c_out = w[j - 1], w[j], w[j + 1]
+        j += 2
+        if c_mid == 0:
+            continue
+        e = h * h
+        total += e * c_in * 9 + 2 * e * c_in + e * c_mid * c_in + 2 * e * c_mid          # dw, IN, pw, IN
+        total += e * c_mid * 9 + 2 * e * c_mid + e * c_out * c_mid + 2 * e * c_out
+    for i in (j, j + 1):
+        h *= 2
+        # thop counts a ConvTranspose2d like a conv: out_elements * Cin * k*k
+        total += h * h * w[i] * w[i - 1] * 9 + 2 * w[i] * h * h
+    total += h * h * out_nc * w[j + 1] * 49
+    return total / 1000 ** 3
+
+
+def mobile_resnet_cfg(netG):
+    """the 23-entry cfg a MobileResnetGenerator tree was built from (absent blocks read back as 0 / residual width)"""
+    convs = [(n, m) for n, m in netG.named_modules() if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))]
+    top = [(n, m) for n, m in convs if n.count('.') == 1]
+    pw = [(n, m) for n, m in convs if n.endswith('.conv.2')]
+    cfg = [m.out_channels for _, m in top[:3]]
+    for k in range(0, len(pw), 2):
+        cfg += [pw[k][1].out_channels, pw[k + 1][1].out_channels]
+    cfg += [top[3][1].out_channels, top[4][1].out_channels]
+    return cfg
+
+
+def mobile_resnet_macs(netG, size=256):
+    cfg = mobile_resnet_cfg(netG)
+    params = sum(p.numel() for p in netG.parameters())
+    return resnet_cfg_macs(cfg, size), params / 1000 ** 2
+
+
+RESNET_UNPRUNABLE = ['model.26'] + [n % i for i in range(10, 19) for n in ('model.%d.conv_block.1.conv.0',
+                                                                          'model.%d.conv_block.6.conv.0')]
+RESNET_RESIDUAL = ['model.7'] + ['model.%d.conv_block.6.conv.2' % i for i in range(10, 19)]
+
+
+def named_convs(netG):
+    """(name, fp32 CPU weight, is_transposed) of every conv in named_modules() order"""
+    return [(n, m.weight.detach().float().cpu().contiguous(), isinstance(m, nn.ConvTranspose2d))
+            for n, m in netG.named_modules() if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))]
+
+
+def filter_norms(w, transposed):
+    """L1 norm per output filter: dims (1,2,3) of a Conv2d weight, (0,2,3) of a ConvTranspose2d weight"""
+    return w.abs().sum((0, 2, 3) if transposed else (1, 2, 3))
+
+
+def _residual_mean_norm(convs):
+    res = [w for n, w, _ in convs if n in RESNET_RESIDUAL]
+    width = res[0].shape[0]
+    acc = [0.0] * width
+    for w in res:                       # the reference accumulates Python-side, filter by filter (models/CycleGAN.py:815-819)
+        nrm = filter_norms(w, False)
+        for i in range(width):
+            acc[i] += nrm[i]
+    return torch.FloatTensor(acc) / len(res)
+
+
+def resnet_prune_cfg(netG, threshold, rule='union'):
+    """filter cfg (23 ints) of a MobileResnet generator at an L1-norm threshold.  The residual stream (model.7 and every
+    block's second pointwise conv) shares one width: rule 'union' = filters above the threshold in ANY of those convs
+    (Pix2Pix.resnet_prune, models/Pix2Pix.py:904-952); rule 'mean' = filters whose norm averaged over those convs is
+    above it (CycleGAN.get_prunenet_cfg, models/CycleGAN.py:843-885)."""
+    convs = named_convs(netG)
+    if torch.is_tensor(threshold):
+        threshold = threshold.detach().float().cpu()
+    if rule == 'union':
+        res = [filter_norms(w, False) > threshold for n, w, _ in convs if n in RESNET_RESIDUAL]
+        keep = int((torch.stack(res).sum(0) > 0).sum())
+    else:
+        keep = int((_residual_mean_norm(convs) > threshold).sum())
+    cfg = []
+    for n, w, tr in convs:
+        if n in RESNET_UNPRUNABLE:
+            continue
+        cfg.append(keep if n in RESNET_RESIDUAL else int((filter_norms(w, tr) > threshold).sum()))
+    return cfg
+
+
+def max_min_conv_norm_resnet(netG, rule='union'):
+    """search interval of the norm threshold: (min over prunable convs of their largest filter norm, smallest filter
+    norm), as 0-dim fp32 tensors.  models/Pix2Pix.py:778-816 (resnet branch) / models/CycleGAN.py:798-839 (residual
+    convs enter with their mean norm)."""
+    convs = named_convs(netG)
+    mean = _residual_mean_norm(convs) if rule == 'mean' else None
+    un_max, mn = None, None
+    for n, w, tr in convs:
+        if n in RESNET_UNPRUNABLE:
+            continue
+        nrm = mean if (rule == 'mean' and n in RESNET_RESIDUAL) else filter_norms(w, tr)
+        un_max = nrm.max() if un_max is None else torch.min(nrm.max(), un_max)
+        mn = nrm.min() if mn is None else torch.min(nrm.min(), mn)
+    return un_max, mn
+
+
+# ------------------------------------------------------------------------------------------------
+# U-Net: L1-norm pruning (models/Pix2Pix.py:866-898, 778-818)
+# ------------------------------------------------------------------------------------------------
+def norm_prune_cfg(netG, threshold, ngf):
+    if torch.is_tensor(threshold):
+        threshold = threshold.detach().float().cpu()
+    f, c = [], []
+    up_num = 0
+    for name, w, tr in named_convs(netG):
+        cnt = int((filter_norms(w, tr) > threshold).sum())
+        f.append(cnt)
+        if tr:
+            up_num += 1
+            if name != 'model.model.3':
+                c.append(cnt + f[-1 - 2 * up_num])
+        else:
+            c.append(cnt)
+    if f[0] == 0:
+        f[0] = ngf
+        c[0] = ngf
+        c[-1] += ngf
+    return f, c
+
+
+def max_min_conv_norm_unet(netG):
+    p3 = _prefix(5)
+    prunable = [p3 + '.model.1', p3 + '.model.3.model.1', p3 + '.model.3.model.3.model.1',
+                p3 + '.model.3.model.3.model.3', p3 + '.model.3.model.5', p3 + '.model.5']
+    un_max, pr_max, mn = None, None, None
+    for n, w, tr in named_convs(netG):
+        nrm = filter_norms(w, tr)
+        if n in prunable:
+            pr_max = nrm.max() if pr_max is None else torch.max(nrm.max(), pr_max)
+        else:
+            un_max = nrm.max() if un_max is None else torch.min(nrm.max(), un_max)
+        mn = nrm.min() if mn is None else torch.min(nrm.min(), mn)
+    return torch.min(pr_max, un_max), mn
 
 
 def _prefix(d):
@@ -122,8 +277,28 @@ def binarysearch_threshold_sd(sd, opt, target_budget):
 
 
 def binarysearch_threshold(model, target_budget):
-    sd = {k: v.detach().cpu() for k, v in model.netG.state_dict().items() if k.endswith('.weight') and v.dim() == 1}
-    return binarysearch_threshold_sd(sd, model.opt, target_budget)
+    """utils/prune_util.py:20-47.  Scale pruning searches on the BatchNorm vectors alone; norm / resnet pruning asks the
+    model for its interval and cfg at each mid point (the MAC budget is shape arithmetic, no network is built)."""
+    opt = model.opt
+    if opt.scale_prune and opt.backbone != 'resnet':
+        sd = {k: v.detach().cpu() for k, v in model.netG.state_dict().items() if k.endswith('.weight') and v.dim() == 1}
+        return binarysearch_threshold_sd(sd, opt, target_budget)
+    max_scale, min_scale = model.max_min_conv_norm()
+    root = str(opt.dataroot)
+    tolerance = 0.01 if 'sr' in root else (0.001 if ('celeb' in root or 'church' in root) else 0.1)
+    while max_scale > min_scale:
+        mid = (max_scale + min_scale) / 2
+        if opt.backbone == 'resnet':
+            budget = resnet_cfg_macs(resnet_prune_cfg(model.netG, mid, 'union'), opt.load_size)
+        else:
+            budget = cfg_macs(opt, *norm_prune_cfg(model.netG, mid, opt.ngf))
+        if abs(target_budget - budget) <= tolerance:
+            return mid
+        elif target_budget - budget > tolerance:
+            max_scale = mid
+        else:
+            min_scale = mid
+    raise NotImplementedError('No appropriate threshold found')
 
 
 def cfg_macs(opt, f, c):
@@ -168,4 +343,57 @@ def prune(model, opt, logger):
     logger.info(filter_cfg)
     logger.info(channel_cfg)
     logger.info('MACs:%.7f G  |  Params:%.4f M' % (macs, params))
+    return pruned_model
+
+
+# ------------------------------------------------------------------------------------------------
+# CycleGAN (utils/prune_util.py:65-130)
+# ------------------------------------------------------------------------------------------------
+# the reference's cyclegan_prune overwrites whatever the search found with these two constants
+# (utils/prune_util.py:119-121; SURVEY.md hazard H7) -- kept, so that a run of the reference's script and a run of this
+# one build the same student
+CYCLEGAN_CFG_ATOB = [24, 48, 86, 72, 86, 47, 86, 44, 86, 43, 86, 43, 86, 29, 86, 30, 86, 37, 86, 36, 86, 48, 24]
+CYCLEGAN_CFG_BTOA = [24, 48, 96, 91, 96, 73, 96, 62, 96, 61, 96, 74, 96, 54, 96, 51, 96, 58, 96, 81, 96, 48, 24]
+
+
+def _search_cfg(netG, target, size, tolerance=0.05):
+    max_scale, min_scale = max_min_conv_norm_resnet(netG, 'mean')
+    while max_scale > min_scale:
+        mid = (max_scale + min_scale) / 2
+        cfg = resnet_prune_cfg(netG, mid, 'mean')
+        budget = resnet_cfg_macs(cfg, size)
+        print(float(mid), budget)
+        if abs(target - budget) <= tolerance:
+            return cfg
+        elif target - budget > tolerance:
+            max_scale = mid
+        else:
+            min_scale = mid
+    return None
+
+
+def cyclegan_binarysearch_cfg(model, target_budget, target_budget_B):
+    cfg_AtoB = _search_cfg(model.netG_A, target_budget, model.opt.load_size)
+    print('--------------------')
+    cfg_BtoA = _search_cfg(model.netG_B, target_budget_B, model.opt.load_size)
+    print(cfg_AtoB, cfg_BtoA)
+    if cfg_AtoB is None or cfg_BtoA is None:
+        raise NotImplementedError('No appropriate threshold found')
+    return cfg_AtoB, cfg_BtoA
+
+
+def cyclegan_prune(model, opt, logger):
+    if opt.target_budget is None or opt.target_budget_B is None:
+        raise NotImplementedError('the target budget must be exist!!!')
+    if opt.pretrain_path is None:
+        raise NotImplementedError('the pretrain path must be exist!!!')
+    model.load_models(opt.pretrain_path, load_discriminator=False)
+    cyclegan_binarysearch_cfg(model, opt.target_budget, opt.target_budget_B)
+    cfg_AtoB, cfg_BtoA = list(CYCLEGAN_CFG_ATOB), list(CYCLEGAN_CFG_BTOA)
+    pruned_model = type(model)(model.opt, cfg_AtoB=cfg_AtoB, cfg_BtoA=cfg_BtoA)
+    logger.info(cfg_AtoB)
+    logger.info(cfg_BtoA)
+    for tag, net in (('netG_A', pruned_model.netG_A), ('netG_B', pruned_model.netG_B)):
+        macs, params = get_flops_parms(net, pruned_model.device, pruned_model.opt)
+        logger.info('%s MACs:%.7f G  |  Params:%.4f M' % (tag, macs, params))
     return pruned_model

@@ -25,6 +25,7 @@ Fixtures
   pix2pix_resnet_gcc.npz  --backbone resnet (MobileResnet + InstanceNorm) GCC iteration: eval/train images, features, losses
   cyclegan_gcc.npz      MobileCycleGAN student + online teacher, 2 x (optimize_parameters + arch step): images, features, losses, final state
   cyclegan_pretrain.npz CycleGAN without teacher, --lambda_weight (heavy-layer L1 sparsity), 1 iteration; ImagePool(3) sequence
+  prune_resnet.npz      resnet_prune / CycleGAN get_prunenet_cfg cfgs + max_min_conv_norm; pruned MobileResnet (one with a block removed): eval + 1 iteration
   prune_search_d8.npz   binarysearch_threshold trajectory end points with a documented thop stand-in
   prune_d8.npz          scale_prune / norm_prune cfgs + max_min_* at several thresholds (ngf 8)
 """
@@ -569,6 +570,75 @@ def fixture_cyclegan_pretrain():
     print('cyclegan_pretrain ok', {k: round(float(v), 4) for k, v in out.items() if k.startswith('loss.')}, out['pool.returned'].tolist())
 
 
+def spread_filter_norms(net, seed):
+    """scale every conv filter by a seeded factor in [0.5, 1.5) so that norm thresholds prune different amounts"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in net.modules():
+            if m.__class__.__name__ in ('Conv2d', 'ConvTranspose2d'):
+                f = 0.5 + torch.rand(m.weight.shape[0], generator=g)
+                m.weight.mul_(f.reshape(-1, 1, 1, 1))
+
+
+def fixture_prune_resnet():
+    """resnet_prune (Pix2Pix, union-of-masks residual rule) and CycleGAN get_prunenet_cfg (mean-norm residual rule) +
+    their max_min_conv_norm at several thresholds; a pruned MobileResnet (irregular widths, and one with a residual
+    block removed): eval image and one plain training iteration"""
+    opt = parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '-1', '--backbone', 'resnet',
+                 '--ngf', '8', '--ndf', '8', '--norm_prune'])
+    from models import get_model_class
+    model = get_model_class(opt)(opt)
+    load_recipe(model.netG, 701)
+    spread_filter_norms(model.netG, 702)
+    out = {}
+    mx, mn = model.max_min_conv_norm()
+    out['p2p.max_min'] = np.array([float(mx), float(mn)], dtype=np.float64)
+    ths = [float(mn) * 0.5] + [float(mn) + q * (float(mx) - float(mn)) for q in (0.2, 0.5, 0.8, 0.999)]
+    out['p2p.thresholds'] = np.array(ths, dtype=np.float64)
+    for i, t in enumerate(ths):
+        out['p2p.f.%d' % i] = np.array(model.resnet_prune(t).get_cfg()[0])
+    copt = parse(['--dataroot', './database/horse2zebra/', '--model', 'cyclegan', '--gpu_ids', '-1', '--ngf', '8', '--ndf', '8',
+                  '--norm_prune'])
+    cm = get_model_class(copt)(copt)
+    load_recipe(cm.netG_A, 703)
+    spread_filter_norms(cm.netG_A, 704)
+    mx, mn = cm.max_min_conv_norm(cm.netG_A)
+    out['cyc.max_min'] = np.array([float(mx), float(mn)], dtype=np.float64)
+    ths = [float(mn) * 0.5] + [float(mn) + q * (float(mx) - float(mn)) for q in (0.2, 0.5, 0.8, 0.999)]
+    out['cyc.thresholds'] = np.array(ths, dtype=np.float64)
+    for i, t in enumerate(ths):
+        out['cyc.f.%d' % i] = np.array(cm.get_prunenet_cfg(cm.netG_A, t))
+    # pruned generators through the Pix2Pix step
+    g = torch.Generator().manual_seed(9)
+    A = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    B = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    out['A'], out['B'], out['direction'] = A.numpy(), B.numpy(), np.array(opt.direction)
+    cfg_a = [int(v) for v in out['p2p.f.2']]
+    cfg_b = list(cfg_a)
+    cfg_b[5] = 0                      # residual block 2 removed (its mid width is 0): later Sequential indices shift
+    for tag, cfg in (('a', cfg_a), ('b', cfg_b)):
+        popt = parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '-1', '--backbone', 'resnet',
+                      '--ngf', '8', '--ndf', '8'])
+        pm = get_model_class(popt)(popt, filter_cfgs=cfg)
+        load_recipe(pm.netG, 711)
+        load_recipe(pm.netD, 712)
+        out['pruned_%s.cfg' % tag] = np.array(cfg)
+        out['pruned_%s.G_keys' % tag] = np.array(list(pm.netG.state_dict().keys()))
+        pm.model_eval()
+        pm.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
+        with torch.no_grad():
+            pm.forward()
+        out['pruned_%s.eval.fake_B' % tag] = pm.fake_B.numpy().copy()
+        pm.model_train()
+        pm.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
+        pm.optimize_parameters()
+        for k, v in pm.get_current_losses().items():
+            out['pruned_%s.loss.%s' % (tag, k)] = np.array(v, dtype=np.float64)
+        sd_np_sampled('pruned_%s.final.G.' % tag, pm.netG.state_dict(), out)
+    np.savez_compressed(os.path.join(HERE, 'prune_resnet.npz'), **out)
+    print('prune_resnet ok:', list(out['p2p.f.2']), list(out['cyc.f.2']))
+
+
 def fixture_options():
     import json
     from options import options
@@ -595,6 +665,6 @@ if __name__ == '__main__':
     only = sys.argv[1:]            # e.g. "make_fixtures.py cyclegan cyclegan_pretrain"; none = all
     import_reference()
     for fn in (fixture_options, fixture_ops, fixture_eval_d8, fixture_gcc_d6, fixture_pretrain_d6, fixture_prune_d8,
-               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain):
+               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet):
         if not only or fn.__name__[len('fixture_'):] in only:
             fn()

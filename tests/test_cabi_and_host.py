@@ -163,3 +163,57 @@ def test_prune_cfgs_and_budget_search_match_reference(golden_dir):
             f, c = PU.scale_prune_cfg(G, thr, 8)
             assert f == [int(v) for v in s['s%d.f' % i]] and c == [int(v) for v in s['s%d.c' % i]]
             assert abs(PU.cfg_macs(opt, f, c) - float(s['s%d.macs' % i])) < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------
+# norm / resnet pruning cfgs (host logic on the parameter trees; golden: tests/golden/prune_resnet.npz, prune_d8.npz)
+# ---------------------------------------------------------------------------------------------------
+def _spread_filter_norms(net, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                f = 0.5 + torch.rand(m.weight.shape[0], generator=g)
+                m.weight.mul_(f.reshape(-1, 1, 1, 1))
+
+
+def _load_recipe(net, seed):
+    from collections import OrderedDict
+    from tests.golden.recipe import recipe_state_dict
+    net.load_state_dict(recipe_state_dict(OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items()), seed))
+
+
+def test_resnet_prune_cfgs_bit_exact(golden_dir):
+    from gcc_amd.models.Pix2Pix import MobileResnetGenerator
+    from gcc_amd.utils import prune_util as P
+    z = np.load(os.path.join(golden_dir, 'prune_resnet.npz'))
+    for tag, rule, seeds in (('p2p', 'union', (701, 702)), ('cyc', 'mean', (703, 704))):
+        net = MobileResnetGenerator(ngf=8)
+        _load_recipe(net, seeds[0])
+        _spread_filter_norms(net, seeds[1])
+        mx, mn = P.max_min_conv_norm_resnet(net, rule)
+        assert [float(mx), float(mn)] == [float(v) for v in z[tag + '.max_min']], tag
+        for i, t in enumerate(z[tag + '.thresholds']):
+            assert P.resnet_prune_cfg(net, float(t), rule) == [int(v) for v in z['%s.f.%d' % (tag, i)]], (tag, i)
+    # a cfg read back from a tree built from it (removed block included)
+    cfg = [int(v) for v in z['pruned_b.cfg']]
+    net = MobileResnetGenerator(ngf=8, cfg=cfg)
+    assert list(net.state_dict().keys()) == [str(k) for k in z['pruned_b.G_keys']]
+    # MAC budget by shape arithmetic: the reference's hard-coded CycleGAN students were searched to 2.4 / 2.7 G +- 0.05
+    assert abs(P.resnet_cfg_macs(P.CYCLEGAN_CFG_ATOB) - 2.4) <= 0.05 and abs(P.resnet_cfg_macs(P.CYCLEGAN_CFG_BTOA) - 2.7) <= 0.05
+    full = MobileResnetGenerator(ngf=8)
+    assert P.mobile_resnet_cfg(full) == [8, 16, 32] + [32] * 18 + [16, 8]
+    assert abs(P.mobile_resnet_macs(full, 256)[0] - P.resnet_cfg_macs([8, 16, 32] + [32] * 18 + [16, 8])) < 1e-12
+
+
+def test_unet_norm_prune_cfgs_bit_exact(golden_dir):
+    from gcc_amd.models.Pix2Pix import UnetGenertor
+    from gcc_amd.utils import prune_util as P
+    z = np.load(os.path.join(golden_dir, 'prune_d8.npz'))
+    net = UnetGenertor(3, 3, 8, ngf=8)
+    _load_recipe(net, int(z['seed_G']))
+    mx, mn = P.max_min_conv_norm_unet(net)
+    assert [float(mx), float(mn)] == [float(v) for v in z['norm.max_min']]
+    for i, t in enumerate(z['norm.thresholds']):
+        f, c = P.norm_prune_cfg(net, float(t), ngf=8)
+        assert f == [int(v) for v in z['norm.f.%d' % i]] and c == [int(v) for v in z['norm.c.%d' % i]], i

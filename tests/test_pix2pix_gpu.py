@@ -425,3 +425,49 @@ def test_pruned_student_irregular_widths(golden_dir):
                 continue
             tol = 3e-2 * max(1.0, float(np.abs(ref).max())) if 'running' in name else 2.2 * opt.lr + 1e-6
             assert float(np.abs(g - ref).max()) <= tol, (name, float(np.abs(g - ref).max()), tol)
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_pruned_resnet_generator(golden_dir, tag):
+    """MobileResnet student built from a resnet_prune cfg: 'a' irregular block widths (17, 15, 18 ...), 'b' the same with
+    one residual block removed (Sequential indices shift).  Eval image, one training iteration: losses, post-step
+    weights, against the reference golden."""
+    from tests.golden.recipe import sample_idx
+    from gcc_amd.options import options
+    from gcc_amd.models import get_model_class
+    z = load(golden_dir, 'prune_resnet.npz')
+    cfg = [int(v) for v in z['pruned_%s.cfg' % tag]]
+    opt = options.parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '0', '--backbone', 'resnet',
+                         '--ngf', '8', '--ndf', '8'])
+    opt.isTrain = True
+    model = get_model_class(opt)(opt, filter_cfgs=cfg)
+    assert list(model.netG.state_dict().keys()) == [str(k) for k in z['pruned_%s.G_keys' % tag]]
+    load_recipe(model.netG, 711)
+    load_recipe(model.netD, 712)
+    model.refresh_weights()
+    data = {'A': torch.from_numpy(z['A']), 'B': torch.from_numpy(z['B']), 'A_paths': ['a'], 'B_paths': ['b']}
+    model.model_eval()
+    model.set_input(data)
+    model.forward()
+    e = (model.fake_B.cpu() - torch.from_numpy(z['pruned_%s.eval.fake_B' % tag])).abs()
+    print('pruned resnet %s eval fake_B: max %.4g mean %.4g' % (tag, e.max(), e.mean()))
+    assert e.max() <= 4e-2 and e.mean() <= 6e-3
+    model.model_train()
+    model.set_input(data)
+    model.optimize_parameters()
+    losses = model.get_current_losses()
+    for k in ('G_GAN', 'G_L1', 'D_real', 'D_fake'):
+        ref = float(z['pruned_%s.loss.%s' % (tag, k)])
+        assert abs(losses[k] - ref) <= 3e-2 * max(1.0, abs(ref)), (k, losses[k], ref)
+    sd = model.netG.state_dict()
+    pre = 'pruned_%s.final.G.' % tag
+    last = [k for k in sd if k.endswith('.bias')][-1]
+    for k in z.files:
+        if k.startswith(pre):
+            name = k[len(pre):]
+            if name.endswith('.bias') and name != last:
+                continue
+            g = sd[name].detach().float().cpu().reshape(-1)
+            g = g[sample_idx(g.numel())].numpy()
+            err = float(np.abs(g - z[k]).max())
+            assert err <= 2.2 * opt.lr + 1e-6, (name, err)
