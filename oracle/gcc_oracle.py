@@ -937,6 +937,288 @@ class CycleGANOracle:
 
 
 # ----------------------------------------------------------------------------------------------
+# SAGAN (models/SAGAN.py): spectral norm, self attention, generator / discriminators, the step
+# ----------------------------------------------------------------------------------------------
+def spectral_weight(sd: SD, prefix: str) -> Tensor:
+    """SpectralNorm._update_u_v (models/SAGAN.py:25-38): one power iteration that overwrites u, v in ``sd`` (in eval
+    mode too), then W = W_bar / sigma with sigma = u^T W_bar v differentiable in W_bar only."""
+    w = sd[prefix + '.weight_bar']
+    u, v = sd[prefix + '.weight_u'], sd[prefix + '.weight_v']
+    h = w.shape[0]
+    wm = w.reshape(h, -1)
+    # ``.data =`` exactly as the reference: u, v keep their identity, so a graph built by an EARLIER call of the same
+    # layer (D on the real batch, then D on the fake batch, one backward) evaluates d sigma / d W_bar = u v^T with the
+    # vectors of the LATEST power iteration, while its forward value used the sigma of its own call.  The HIP path
+    # reproduces this: the gradient transform reads the live u, v and the context's own sigma.
+    t = torch.mv(wm.detach().t(), u)
+    v.data = t / (t.norm() + 1e-12)
+    t = torch.mv(wm.detach(), v)
+    u.data = t / (t.norm() + 1e-12)
+    sigma = u.dot(wm.mv(v))
+    return w / sigma
+
+
+def self_attention(sd: SD, prefix: str, x: Tensor) -> Tensor:
+    """Self_Attn.forward (models/SAGAN.py:72-104): energy = q^T k over the H*W positions, softmax over keys,
+    out = v . attention^T, y = gamma * out + x"""
+    b, c, hh, ww = x.shape
+    n = hh * ww
+    q = _q(F.conv2d(x, _qw(sd[prefix + '.query_conv.weight']), sd[prefix + '.query_conv.bias'])).reshape(b, -1, n)
+    k = _q(F.conv2d(x, _qw(sd[prefix + '.key_conv.weight']), sd[prefix + '.key_conv.bias'])).reshape(b, -1, n)
+    v = _q(F.conv2d(x, _qw(sd[prefix + '.value_conv.weight']), sd[prefix + '.value_conv.bias'])).reshape(b, -1, n)
+    attn = torch.softmax(torch.bmm(q.permute(0, 2, 1), k), dim=-1)
+    out = _q(torch.bmm(v, attn.permute(0, 2, 1)).reshape(b, c, hh, ww))
+    return _q(sd[prefix + '.gamma'] * out + x)
+
+
+def sagan_generator_forward(sd: SD, z: Tensor, train: bool = True, features: Optional[OrderedDict] = None) -> Tensor:
+    """Generator.forward (models/SAGAN.py:159-170), image_size 64: l1..l4 = SN(ConvTranspose) + BN + ReLU, attention
+    after l3 and l4, last = ConvTranspose + Tanh.  Hooks: 'l2' (post-ReLU), 'attn2'."""
+    h = _q(z.reshape(z.shape[0], z.shape[1], 1, 1))
+    for i, (stride, pad) in enumerate(((1, 0), (2, 1), (2, 1), (2, 1)), start=1):
+        w = _qw(spectral_weight(sd, 'l%d.0.module' % i))
+        h = _q(F.conv_transpose2d(h, w, sd['l%d.0.module.bias' % i], stride=stride, padding=pad))
+        h = _q(F.relu(batch_norm(sd, 'l%d.1' % i, h, train)))
+        if i == 2 and features is not None:
+            features['l2'] = h
+        if i == 3:
+            h = self_attention(sd, 'attn1', h)
+    h = self_attention(sd, 'attn2', h)
+    if features is not None:
+        features['attn2'] = h
+    return _q(torch.tanh(F.conv_transpose2d(h, _qw(sd['last.0.weight']), sd['last.0.bias'], stride=2, padding=1)))
+
+
+def sagan_discriminator_forward(sd: SD, x: Tensor, masked: bool = False, threshold: float = 0.5,
+                                features: Optional[OrderedDict] = None) -> Tensor:
+    """Discriminator / MaskDiscriminator.forward (models/SAGAN.py:172-274): l1..l4 = SN(Conv k4 s2 p1) [+ gate] +
+    LeakyReLU(0.1), attention after l3 and l4, last = Conv k4 (4x4 -> 1x1), squeezed.  Hooks: 'l2', 'attn2'."""
+    h = _q(x)
+    for i in range(1, 5):
+        w = _qw(spectral_weight(sd, 'l%d.0.module' % i))
+        h = _q(F.conv2d(h, w, sd['l%d.0.module.bias' % i], stride=2, padding=1))
+        if masked:
+            h = gate(h, sd['l%d.1.alpha' % i], threshold)
+        h = _q(F.leaky_relu(h, 0.1))
+        if i == 2 and features is not None:
+            features['l2'] = h
+        if i == 3:
+            h = self_attention(sd, 'attn1', h)
+    h = self_attention(sd, 'attn2', h)
+    if features is not None:
+        features['attn2'] = h
+    return F.conv2d(h, _qw(sd['last.0.weight']), sd['last.0.bias']).squeeze()
+
+
+def _attn_shapes(shp, name, c):
+    for n, co in (('query_conv', c // 8), ('key_conv', c // 8), ('value_conv', c)):
+        shp['%s.%s.weight' % (name, n)] = (co, c, 1, 1)
+        shp['%s.%s.bias' % (name, n)] = (co,)
+
+
+def sagan_generator_shapes(ngf: int = 64, z_dim: int = 128, filter_cfgs: Optional[Sequence[int]] = None):
+    """state_dict shapes in the reference's order: per SN layer bias, weight_u, weight_v, weight_bar (the order
+    _make_params registers them after deleting 'weight'), then the BN; l4 is registered before l1 (models/SAGAN.py:141-152)"""
+    w = list(filter_cfgs) if filter_cfgs is not None else [ngf * 8, ngf * 4, ngf * 2, ngf]
+    cin = [z_dim] + w[:3]
+    shp: Dict[str, Tuple[int, ...]] = OrderedDict()
+
+    def layer(i):
+        p = 'l%d.0.module' % i
+        ws = (cin[i - 1], w[i - 1], 4, 4)
+        shp[p + '.bias'] = (w[i - 1],)
+        shp[p + '.weight_u'] = (ws[0],)
+        shp[p + '.weight_v'] = (ws[1] * 16,)
+        shp[p + '.weight_bar'] = ws
+        for sfx, v in (('weight', (w[i - 1],)), ('bias', (w[i - 1],)), ('running_mean', (w[i - 1],)),
+                       ('running_var', (w[i - 1],)), ('num_batches_tracked', ())):
+            shp['l%d.1.%s' % (i, sfx)] = v
+    for i in (4, 1, 2, 3):
+        layer(i)
+    shp['last.0.weight'] = (w[3], 3, 4, 4)
+    shp['last.0.bias'] = (3,)
+    for name, c in (('attn1', w[2]), ('attn2', w[3])):
+        shp[name + '.gamma'] = (1,)
+        _attn_shapes(shp, name, c)
+    return shp
+
+
+def sagan_discriminator_shapes(ndf: int = 64, masked: bool = False):
+    w = [ndf, ndf * 2, ndf * 4, ndf * 8]
+    cin = [3] + w[:3]
+    shp: Dict[str, Tuple[int, ...]] = OrderedDict()
+
+    def layer(i):
+        p = 'l%d.0.module' % i
+        shp[p + '.bias'] = (w[i - 1],)
+        shp[p + '.weight_u'] = (w[i - 1],)
+        shp[p + '.weight_v'] = (cin[i - 1] * 16,)
+        shp[p + '.weight_bar'] = (w[i - 1], cin[i - 1], 4, 4)
+        if masked:
+            shp['l%d.1.alpha' % i] = (w[i - 1],)
+    for i in (4, 1, 2, 3):
+        layer(i)
+    shp['last.0.weight'] = (1, w[3], 4, 4)
+    shp['last.0.bias'] = (1,)
+    for name, c in (('attn1', w[2]), ('attn2', w[3])):
+        shp[name + '.gamma'] = (1,)
+        _attn_shapes(shp, name, c)
+    return shp
+
+
+class SAGANOracle:
+    """SAGANModel reduced to its arithmetic (models/SAGAN.py:276-560).  Adam betas (0, 0.9), D learning rate x4.
+    ``dup``: parameter names the reference lists twice in an optimizer (hazard H5: SpectralNorm / Self_Attn containers
+    and their children are both collected when distillation / the masked D build the lists) -- torch's Adam then
+    applies two sequential updates per step to those tensors, with the same gradient."""
+
+    def __init__(self, opt: Opt, G: SD, D: SD, T: Optional[List[Tensor]] = None, masked: bool = False,
+                 teacher: Optional['SAGANOracle'] = None):
+        self.opt, self.G, self.D, self.T = opt, G, D, (T or [])
+        self.masked, self.teacher = masked, teacher
+        self.g_feats, self.d_feats = OrderedDict(), OrderedDict()
+        self.train = True
+        self.cur_diff = 0.0
+        self.losses: Dict[str, float] = {}
+        self.lr_G, self.lr_D, self.lr_arch = opt.lr, opt.lr * 4, opt.arch_lr
+        trainable = lambda k: (k.endswith('.weight') or k.endswith('.bias') or k.endswith('.weight_bar') or k.endswith('.gamma'))
+        self.G_keys = [k for k in G if trainable(k)]
+        # set_requires_grad(netD, True) (models/SAGAN.py:513) also switches on the discriminator's power-iteration
+        # vectors u, v: they receive gradients through sigma = u . (W_bar v) and Adam updates in every D step (the
+        # generator's u, v never do)
+        self.D_w_keys = [k for k in D if not k.endswith('.alpha')]
+        self.D_a_keys = [k for k in D if k.endswith('.alpha')]
+        dup = lambda k: ('.module.' in k) or ('_conv.' in k)
+        self.G_dup = [k for k in self.G_keys if dup(k)] if self.T else []
+        self.D_dup = [k for k in self.D_w_keys if dup(k)] if masked else []
+        self.st_G, self.st_D, self.st_A = {}, {}, {}
+
+    def netG(self, z):
+        return sagan_generator_forward(self.G, z, self.train, features=self.g_feats)
+
+    def netD(self, x):
+        return sagan_discriminator_forward(self.D, x, self.masked, 0.5, features=self.d_feats)   # H6: --threshold ignored
+
+    def set_input(self, z, real):
+        self.z, self.real_img = z, real
+
+    def forward(self):
+        self.fake_img = self.netG(self.z)
+
+    def features(self):
+        return list(self.g_feats.values()) + list(self.d_feats.values())
+
+    def _req(self, sd, keys, flag):
+        for k in keys:
+            sd[k].requires_grad_(flag)
+            if flag:
+                sd[k].grad = None
+
+    @staticmethod
+    def _adam_dup(sd, keys, dup, extra, state, lr):
+        """one Adam step over keys (+ extra tensors); tensors listed twice get a second sequential update"""
+        params = [sd[k] for k in keys] + list(extra)
+        names = list(keys) + [None] * len(extra)
+        if 'per' not in state:
+            state['per'] = [dict() for _ in params]
+        for p, n, st in zip(params, names, state['per']):
+            if p.grad is None:
+                continue
+            for _ in range(2 if n in dup else 1):
+                adam_step([p], [p.grad], st, lr, (0.0, 0.9))
+
+    def optimize_parameters(self):
+        o, T = self.opt, self.teacher
+        if T is not None:
+            T.set_input(self.z, self.real_img)
+            T.optimize_parameters()
+            self.targets = [f.detach().clone() for f in T.features()]
+        self._req(self.G, self.G_keys, True)
+        for t in self.T:
+            t.requires_grad_(True)
+            t.grad = None
+        self.forward()
+        # ---- D (:370-381): real first, then the detached fake; no 0.5
+        self._req(self.D, self.D_w_keys, True)
+        self._req(self.D, self.D_a_keys, False)
+        l_real = gan_loss(o.gan_mode, self.netD(self.real_img), True, True)
+        l_fake = gan_loss(o.gan_mode, self.netD(self.fake_img.detach()), False, True)
+        (l_fake + l_real).backward()
+        self._adam_dup(self.D, self.D_w_keys, self.D_dup, [], self.st_D, self.lr_D)
+        self._req(self.D, self.D_w_keys, False)
+        # ---- G (:460-494)
+        l_gan = gan_loss(o.gan_mode, self.netD(self.fake_img), True, False)
+        loss_G = l_gan
+        self.losses.update(G_GAN=float(l_gan.detach()), D_real=float(l_real.detach()), D_fake=float(l_fake.detach()))
+        if T is not None:
+            feats = list(self.g_feats.values())
+            T.netD(self.fake_img)                     # not detached: gradient reaches the student through the teacher's D
+            feats = feats + list(T.d_feats.values())
+            l_gram = l_content = 0.0
+            for i, f in enumerate(feats):
+                if i < 2:
+                    f = F.conv2d(f, self.T[i])
+                t = self.targets[i]
+                l_gram = l_gram + rmse(gram(f), gram(t))
+                l_content = l_content + rmse(f, t)
+            l_gram, l_content = o.lambda_gram * l_gram, o.lambda_content * l_content
+            l_l1 = o.lambda_L1 * F.l1_loss(self.fake_img, T.fake_img.detach())
+            loss_G = loss_G + l_gram + l_content + l_l1
+            # the reference accumulates the distillation terms IN PLACE into the tensor that is also loss_G_GAN
+            # (``self.loss_G = self.loss_G_GAN`` then ``+=``, :465-488): the reported G_GAN is the whole generator loss
+            self.losses.update(gram=float(l_gram.detach()), content=float(l_content.detach()), L1=float(l_l1.detach()),
+                               G_GAN=float(loss_G.detach()))
+        loss_G.backward()
+        if o.lambda_weight > 0.0:                     # L1_sparsity (:496-506): convs that still own a '.weight'
+            for k in self.G_keys:
+                if k.endswith('.weight') and self.G[k].dim() == 4:
+                    self.G[k].grad.add_(o.lambda_weight * torch.sign(self.G[k].detach()))
+        elif o.lambda_scale > 0.0:
+            for k in self.G_keys:
+                if k.endswith('.weight') and self.G[k].dim() == 1:
+                    self.G[k].grad.add_(o.lambda_scale * torch.sign(self.G[k].detach()))
+        self._adam_dup(self.G, self.G_keys, self.G_dup, self.T, self.st_G, self.lr_G)
+        self.fake_img = self.fake_img.detach()
+        self._req(self.G, self.G_keys, False)
+        for t in self.T:
+            t.requires_grad_(False)
+
+    def get_D_arch_diff(self, is_teacher):
+        o = self.opt
+        pf = self.netD(self.fake_img.detach())
+        self.arch_fake = gan_loss(o.gan_mode, pf, False, True)
+        fake_real = gan_loss(o.gan_mode, pf, True, False)
+        self.arch_real = gan_loss(o.gan_mode, self.netD(self.real_img), True, True)
+        cur = (fake_real - self.arch_fake).abs()
+        if is_teacher and float(self.cur_diff) != 0.0:
+            cur = o.ema_beta * cur + (1.0 - o.ema_beta) * self.cur_diff
+        self.cur_diff = cur
+        return cur
+
+    def clipping_mask_alpha(self):
+        with torch.no_grad():
+            for k in self.D_a_keys:
+                self.D[k].clamp_(0, 1)
+
+    def optimizer_netD_arch(self):
+        T = self.teacher
+        with torch.no_grad():
+            self.forward()
+            T.set_input(self.z, self.real_img)
+            T.forward()
+            t_diff = T.get_D_arch_diff(True)
+        self._req(self.D, self.D_w_keys, False)
+        self._req(self.D, self.D_a_keys, True)
+        s_diff = self.get_D_arch_diff(False)
+        loss = (s_diff - t_diff).abs() + self.arch_real + self.arch_fake          # no 0.5 here (:388-389)
+        loss.backward()
+        adam_step([self.D[k] for k in self.D_a_keys], [self.D[k].grad for k in self.D_a_keys], self.st_A, self.lr_arch,
+                  (0.9, 0.999))
+        self._req(self.D, self.D_a_keys, False)
+        self.losses.update(D_arch_diff=float(s_diff.detach()), D_arch=float(loss.detach()), teacher_D_arch_diff=float(t_diff))
+
+
+# ----------------------------------------------------------------------------------------------
 # prune cfgs (integer contract; SURVEY.md Appendix A.1)
 # ----------------------------------------------------------------------------------------------
 def _unet_bn_names(num_downs: int = 8) -> List[str]:

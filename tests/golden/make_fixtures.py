@@ -26,6 +26,7 @@ Fixtures
   cyclegan_gcc.npz      MobileCycleGAN student + online teacher, 2 x (optimize_parameters + arch step): images, features, losses, final state
   cyclegan_pretrain.npz CycleGAN without teacher, --lambda_weight (heavy-layer L1 sparsity), 1 iteration; ImagePool(3) sequence
   prune_resnet.npz      resnet_prune / CycleGAN get_prunenet_cfg cfgs + max_min_conv_norm; pruned MobileResnet (one with a block removed): eval + 1 iteration
+  sagan_gcc.npz         SAGAN student + online teacher (spectral norm, self attention, duplicated optimizer entries): eval image, 2 x (iteration + arch step)
   prune_search_d8.npz   binarysearch_threshold trajectory end points with a documented thop stand-in
   prune_d8.npz          scale_prune / norm_prune cfgs + max_min_* at several thresholds (ngf 8)
 """
@@ -639,6 +640,81 @@ def fixture_prune_resnet():
     print('prune_resnet ok:', list(out['p2p.f.2']), list(out['cyc.f.2']))
 
 
+def fixture_sagan():
+    """SAGANModel student (ngf 8, masked D ndf 8) + online teacher (ngf 16, ndf 16), z_dim 128, 64x64, N=4, recipe
+    weights 801..: eval image, then two iterations of optimize_parameters + arch step.  torch >= 2 rejects the
+    reference's Adam(betas=(0, 0.9)) (int 0): the script casts betas to float on the way in (SURVEY.md hazard H7)."""
+    import torch.optim as optim
+    real_adam = optim.Adam
+
+    class FloatBetasAdam(real_adam):
+        def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), **kw):
+            super().__init__(params, lr=lr, betas=(float(betas[0]), float(betas[1])), **kw)
+    torch.optim.Adam = FloatBetasAdam
+    try:
+        opt = parse(['--dataroot', './database/celeb/', '--model', 'sagan', '--gpu_ids', '-1', '--ngf', '8', '--ndf', '8',
+                     '--teacher_ngf', '16', '--online_distillation', '--darts_discriminator', '--threshold', '0.1',
+                     '--lambda_L1', '1', '--lambda_content', '1', '--lambda_gram', '1', '--arch_lr', '1e-4'])
+        opt.teacher_ndf = 16
+        model, teacher = build_gcc(opt)
+    finally:
+        torch.optim.Adam = real_adam
+    for n, sd in ((model.netG, 801), (model.netD, 802), (teacher.netG, 803), (teacher.netD, 804)):
+        load_recipe(n, sd)
+    with torch.no_grad():
+        for i, t in enumerate(model.transform_convs):
+            t.weight.copy_(recipe_transform(t.weight.shape[0], t.weight.shape[1], 810 + i))
+        model.netD.l1[1].alpha[0] = 0.3
+        model.netD.l3[1].alpha[2] = 0.5
+    out = {'G_keys': np.array(list(model.netG.state_dict().keys())), 'D_keys': np.array(list(model.netD.state_dict().keys())),
+           'TD_keys': np.array(list(teacher.netD.state_dict().keys())), 'gan_mode': np.array(opt.gan_mode),
+           'lr': np.array(opt.lr), 'batch_size': np.array(opt.batch_size), 'crop_size': np.array(opt.crop_size),
+           'loss_names': np.array(model.loss_names),
+           'T_shapes': np.array([list(t.weight.shape[:2]) for t in model.transform_convs])}
+    for tag, optim_ in (('G', model.optimizer_G), ('D', model.optimizer_D)):
+        ids = [id(p) for p in optim_.param_groups[0]['params']]
+        names = {id(p): k for k, p in list(model.netG.named_parameters()) + list(model.netD.named_parameters())}
+        out['dup_' + tag] = np.array(sorted({names[i] for i in ids if ids.count(i) > 1 and i in names}))
+    g = torch.Generator().manual_seed(90)
+    z0 = torch.randn(4, 128, generator=g)
+    model.model_eval()
+    model.set_input({'z': z0, 'real_img': torch.zeros(4, 3, 64, 64), 'img_path': ['p'] * 4})
+    sdG_before = {k: v.clone() for k, v in model.netG.state_dict().items()}
+    with torch.no_grad():
+        model.forward()
+    out['eval.z'], out['eval.fake_img'] = z0.numpy(), model.fake_img.numpy().copy()
+    model.netG.load_state_dict(sdG_before)          # the eval pass moved u, v: put them back
+    model.model_train()
+    for it in range(2):
+        z, vz = torch.randn(4, 128, generator=g), torch.randn(4, 128, generator=g)
+        real, vreal = (torch.rand(4, 3, 64, 64, generator=g) * 2 - 1 for _ in range(2))
+        for n, t in (('z', z), ('vz', vz), ('real', real), ('vreal', vreal)):
+            out['it%d.%s' % (it, n)] = t.numpy()
+        model.set_input({'z': z, 'real_img': real, 'img_path': ['p'] * 4})
+        model.optimize_parameters()
+        if it == 0:
+            out['it0.fake_img'] = model.fake_img.detach().numpy().copy()
+            out['it0.Tfake_img'] = teacher.fake_img.detach().numpy().copy()
+            for j, f in enumerate(model.target_distillation_features):
+                out['it0.target.%d' % j] = f.detach().numpy().copy()
+            for j, f in enumerate(model.get_distillation_features()[:2]):
+                out['it0.sfeat.%d' % j] = f.detach().numpy().copy()
+        model.set_input({'z': vz, 'real_img': vreal, 'img_path': ['p'] * 4})
+        model.clipping_mask_alpha()
+        model.optimizer_netD_arch()
+        for k, v in model.get_current_losses().items():
+            out['it%d.loss.%s' % (it, k)] = np.array(v, dtype=np.float64)
+        for k, v in teacher.get_current_losses().items():
+            out['it%d.tloss.%s' % (it, k)] = np.array(v, dtype=np.float64)
+    for tag, net in (('sG', model.netG), ('sD', model.netD), ('tG', teacher.netG), ('tD', teacher.netD)):
+        sd_np_sampled('final.%s.' % tag, net.state_dict(), out)
+    for i, t in enumerate(model.transform_convs):
+        out['final.T.%d' % i] = t.weight.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'sagan_gcc.npz'), **out)
+    print('sagan_gcc ok', {k: round(float(v), 4) for k, v in out.items() if k.startswith('it1.loss.')})
+    print('  G keys', list(out['G_keys'])[:14], '\n  D keys', list(out['D_keys']), '\n  dup G', list(out['dup_G']), '\n  dup D', list(out['dup_D']))
+
+
 def fixture_options():
     import json
     from options import options
@@ -665,6 +741,6 @@ if __name__ == '__main__':
     only = sys.argv[1:]            # e.g. "make_fixtures.py cyclegan cyclegan_pretrain"; none = all
     import_reference()
     for fn in (fixture_options, fixture_ops, fixture_eval_d8, fixture_gcc_d6, fixture_pretrain_d6, fixture_prune_d8,
-               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet):
+               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan):
         if not only or fn.__name__[len('fixture_'):] in only:
             fn()
