@@ -99,7 +99,12 @@ PROTOTYPES = {
     'gcc_gate_mask': (_I, [_P, _F, _P, _I, _P]),
     'gcc_gan_loss': (_I, [_I, _I, _I, _P, _I, _I, _Z, _F, _P, _I, _P, _P, _Z, _P]),
     'gcc_gan_loss_ex': (_I, [_I, _I, _I, _P, _I, _I, _Z, _P, _P, _F, _P, _I, _P]),
-    'gcc_arch_coeffs': (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    'gcc_arch_coeffs': (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _P]),
+    'gcc_spectral_workspace': (_Z, [_I, _I, _I]),
+    'gcc_spectral_power_iteration': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
+    'gcc_spectral_grad': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
+    'gcc_attention_fwd': (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P]),
+    'gcc_attention_bwd': (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
     'gcc_l1_loss': (_I, [_P, _I, _I, _P, _I, _I, _I, _Z, _F, _P, _I, _P, _I, _I, _P, _Z, _P]),
     'gcc_loss_workspace': (_Z, [_Z, _I]),
     'gcc_distill_workspace': (_Z, [_I, _I, _I]),

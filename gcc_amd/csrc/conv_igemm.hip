@@ -391,9 +391,12 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
 #pragma unroll
         for (int j = 0; j < C::PB; j++) {
             const int pl = wp * C::TP + j * 16 + lr;
+            // rows past the end of the phase are padding: keep them exact zeros (the statistics below sum every row
+            // of the tile, and a bias would otherwise leak into them)
+            const bool live = !p.stats || (m0 + pl < M);
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = apply_act(acc[i][j][r] + bv[r], p.act, p.slope);
+            for (int r = 0; r < 4; r++) v[r] = live ? apply_act(acc[i][j][r] + bv[r], p.act, p.slope) : 0.f;
             i32x2 pk;
             pk[0] = (int)pack2bf(v[0], v[1]);
             pk[1] = (int)pack2bf(v[2], v[3]);

@@ -414,8 +414,9 @@ extern "C" int gcc_gan_loss_ex(int mode, int target_is_real, int for_discriminat
 }
 
 // arch step scalars (models/Pix2Pix.py:479-487): dS = |Lfr - Lf| ;
-// loss = |dS - dT| + (Lr + Lf)/2 ; c_fr = dloss/dLfr ; c_f = dloss/dLf   (dloss/dLr = 1/2)
-__global__ void arch_coeffs_kernel(const float* Lfr, const float* Lf, const float* Lr, const float* dT, float* loss,
+// loss = |dS - dT| + w (Lr + Lf) ; c_fr = dloss/dLfr ; c_f = dloss/dLf   (dloss/dLr = w)
+// w = 1/2 for Pix2Pix / CycleGAN, 1 for SAGAN (models/SAGAN.py:388-389)
+__global__ void arch_coeffs_kernel(const float* Lfr, const float* Lf, const float* Lr, const float* dT, float w, float* loss,
                                    float* c_fr, float* c_f) {
     if (threadIdx.x || blockIdx.x) return;
     const float a = Lfr[0] - Lf[0];
@@ -423,15 +424,16 @@ __global__ void arch_coeffs_kernel(const float* Lfr, const float* Lf, const floa
     const float s1 = a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
     const float b = dS - dT[0];
     const float s2 = b > 0.f ? 1.f : (b < 0.f ? -1.f : 0.f);
-    loss[0] = fabsf(b) + 0.5f * (Lr[0] + Lf[0]);
+    loss[0] = fabsf(b) + w * (Lr[0] + Lf[0]);
     c_fr[0] = s2 * s1;
-    c_f[0] = -s2 * s1 + 0.5f;
+    c_f[0] = -s2 * s1 + w;
 }
-extern "C" int gcc_arch_coeffs(const float* Lfr, const float* Lf, const float* Lr, const float* dT, float* loss, float* c_fr,
-                               float* c_f, gcc_stream_t stream) {
+extern "C" int gcc_arch_coeffs(const float* Lfr, const float* Lf, const float* Lr, const float* dT, float real_fake_weight,
+                               float* loss, float* c_fr, float* c_f, gcc_stream_t stream) {
     GCC_ENTER();
     if (!Lfr || !Lf || !Lr || !dT || !loss || !c_fr || !c_f) return GCC_ERR_BAD_ARG;
-    hipLaunchKernelGGL(arch_coeffs_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, Lfr, Lf, Lr, dT, loss, c_fr, c_f);
+    hipLaunchKernelGGL(arch_coeffs_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, Lfr, Lf, Lr, dT, real_fake_weight, loss,
+                       c_fr, c_f);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

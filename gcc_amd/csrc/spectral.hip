@@ -1,0 +1,195 @@
+// Spectral normalisation of a conv weight (reference models/SAGAN.py:17-70) on the fp32 master.
+//
+// The master W_bar is a 4-D nn.Parameter [R][C][k][k] stored channels_last (k > 1): element (r, c, t) sits at
+// r*C*T + t*C + c (T = k*k taps).  The reference flattens it as w.view(R, -1), i.e. column j = c*T + t; u has R
+// entries, v has C*T entries in THAT order (state_dict compatible).  All kernels below walk the physical layout
+// (coalesced) and translate to the logical column index where v is touched.
+//
+//   power iteration (every forward, train or eval):
+//       vt = W^T u ;  v = vt / (|vt| + 1e-12) ;  t = W v ;  u = t / (|t| + 1e-12) ;  sigma = u . t
+//       W_eff = W_bar / sigma                      (fp32, same layout; packed to bf16 by gcc_pack_weights)
+//   gradient through W_eff = W_bar / sigma(W_bar), with G = dL/dW_eff:
+//       inner = <G, W_bar> ;  dL/dsigma = -inner / sigma^2
+//       dW_bar += G / sigma + dL/dsigma * u v^T
+//       du     += dL/dsigma * t        (t = W_bar v of the forward call the gradient belongs to)
+//       dv     += dL/dsigma * W_bar^T u
+//   u, v in the gradient are the LIVE vectors (latest power iteration), sigma and t are the forward call's own: this is
+//   what the reference's autograd evaluates, because `u.data = ...` re-points the tensors earlier graphs saved.
+#include "common.hpp"
+
+namespace {
+
+struct SnArgs {
+    const float* w;       // W_bar
+    float* u;             // [R]
+    float* v;             // [C*T], logical order
+    int R, C, T;
+    float* vt;            // workspace [C*T], physical order
+    float* t;             // [R]  (kept per forward call)
+    float* scal;          // [4]: 0 |vt|^2, 1 |t|^2, 2 sigma, 3 inner
+    float* w_eff;         // [R*C*T]
+};
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) s += sh[i];
+    return s;
+}
+
+// vt[p] = sum_r W[r][p] * u[r]   (p physical column); accumulates |vt|^2 into scal[0] (zeroed by the caller)
+__global__ __launch_bounds__(256) void sn_wtu_kernel(const float* __restrict__ w, const float* __restrict__ u, int R, int K,
+                                                     float* __restrict__ vt, float* nrm2, float scale_by) {
+    __shared__ float sh[4];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float acc = 0.f;
+    if (p < K)
+        for (int r = 0; r < R; r++) acc += w[(size_t)r * K + p] * u[r];
+    acc *= scale_by;
+    if (p < K) vt[p] = acc;
+    const float s = block_sum(p < K ? acc * acc : 0.f, sh);
+    if (threadIdx.x == 0 && nrm2) atomicAdd(nrm2, s);
+}
+
+// t[r] = sum_p W[r][p] * vt[p] / (|vt| + eps) ; accumulates |t|^2 into scal[1]
+__global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w, const float* __restrict__ vt, int K,
+                                                    const float* scal, float* __restrict__ t, float* nrm2) {
+    __shared__ float sh[4];
+    const int r = blockIdx.x;
+    const float inv = 1.f / (sqrtf(scal[0]) + 1e-12f);
+    float acc = 0.f;
+    for (int p = threadIdx.x; p < K; p += 256) acc += w[(size_t)r * K + p] * vt[p];
+    const float s = block_sum(acc, sh) * inv;
+    if (threadIdx.x == 0) {
+        t[r] = s;
+        atomicAdd(nrm2, s * s);
+    }
+}
+
+// u, v, sigma
+__global__ __launch_bounds__(256) void sn_finalize_kernel(SnArgs a) {
+    const int K = a.C * a.T;
+    const float inv_v = 1.f / (sqrtf(a.scal[0]) + 1e-12f);
+    const float nt = sqrtf(a.scal[1]);
+    const float inv_t = 1.f / (nt + 1e-12f);
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < K; p += gridDim.x * 256) {
+        const int tt = p / a.C, c = p - tt * a.C;
+        a.v[c * a.T + tt] = a.vt[p] * inv_v;
+    }
+    if (blockIdx.x == 0) {
+        for (int r = threadIdx.x; r < a.R; r += 256) a.u[r] = a.t[r] * inv_t;
+        if (threadIdx.x == 0) a.scal[2] = a.scal[1] * inv_t;      // u . t = |t|^2 / (|t| + eps)
+    }
+}
+
+__global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__ w, const float* scal, float* __restrict__ w_eff,
+                                                       size_t n) {
+    const float inv = 1.f / scal[2];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) w_eff[i] = w[i] * inv;
+}
+
+__global__ __launch_bounds__(256) void sn_inner_kernel(const float* __restrict__ g, const float* __restrict__ w, size_t n,
+                                                       float* inner) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += g[i] * w[i];
+    const float s = block_sum(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(inner, s);
+}
+
+// dW_bar += G/sigma + dLds * u[r] * v[logical(p)] ;  du += dLds * t  (block 0)
+__global__ __launch_bounds__(256) void sn_grad_kernel(const float* __restrict__ g, const float* __restrict__ u,
+                                                      const float* __restrict__ v, const float* __restrict__ t_fwd,
+                                                      const float* sigma_fwd, const float* inner, int R, int C, int T,
+                                                      float* __restrict__ dw, float* __restrict__ du) {
+    const float sg = sigma_fwd[0];
+    const float inv = 1.f / sg, dlds = -inner[0] * inv * inv;
+    const int K = C * T;
+    const size_t n = (size_t)R * K;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / K), p = (int)(i - (size_t)r * K);
+        const int tt = p / C, c = p - tt * C;
+        dw[i] += g[i] * inv + dlds * u[r] * v[c * T + tt];
+    }
+    if (du && blockIdx.x == 0)
+        for (int r = threadIdx.x; r < R; r += 256) du[r] += dlds * t_fwd[r];
+}
+
+// dv[logical(p)] += dLds * vt[p]   with vt = W_bar^T u (physical order)
+__global__ __launch_bounds__(256) void sn_dv_kernel(const float* __restrict__ vt, const float* sigma_fwd, const float* inner,
+                                                    int C, int T, float* __restrict__ dv) {
+    const float inv = 1.f / sigma_fwd[0], dlds = -inner[0] * inv * inv;
+    const int K = C * T;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < K; p += gridDim.x * 256) {
+        const int tt = p / C, c = p - tt * C;
+        dv[c * T + tt] += dlds * vt[p];
+    }
+}
+
+int nblocks(size_t n, int cap = 1024) {
+    size_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" size_t gcc_spectral_workspace(int R, int C, int T) {
+    if (R <= 0 || C <= 0 || T <= 0) return 0;
+    return ((size_t)C * T + 64) * sizeof(float);
+}
+
+extern "C" int gcc_spectral_power_iteration(const float* w_bar, float* u, float* v, int R, int C, int T, float* t_out,
+                                            float* sigma_out, float* w_eff, void* ws, size_t ws_bytes, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!w_bar || !u || !v || !t_out || !sigma_out || !w_eff || !ws || R <= 0 || C <= 0 || T <= 0) return GCC_ERR_BAD_ARG;
+    if (ws_bytes < gcc_spectral_workspace(R, C, T)) return GCC_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int K = C * T;
+    float* scal = (float*)ws;                 // [0..3]
+    float* vt = scal + 64;
+    if (hipMemsetAsync(scal, 0, 4 * sizeof(float), st) != hipSuccess) return GCC_ERR_LAUNCH;
+    hipLaunchKernelGGL(sn_wtu_kernel, dim3((K + 255) / 256), dim3(256), 0, st, w_bar, (const float*)u, R, K, vt, scal + 0, 1.f);
+    GCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sn_wv_kernel, dim3(R), dim3(256), 0, st, w_bar, (const float*)vt, K, (const float*)scal, t_out, scal + 1);
+    GCC_CHECK_LAUNCH();
+    SnArgs a;
+    a.w = w_bar; a.u = u; a.v = v; a.R = R; a.C = C; a.T = T; a.vt = vt; a.t = t_out; a.scal = scal; a.w_eff = w_eff;
+    hipLaunchKernelGGL(sn_finalize_kernel, dim3(nblocks(K, 64)), dim3(256), 0, st, a);
+    GCC_CHECK_LAUNCH();
+    const size_t n = (size_t)R * K;
+    hipLaunchKernelGGL(sn_scale_kernel, dim3(nblocks(n)), dim3(256), 0, st, w_bar, (const float*)scal, w_eff, n);
+    GCC_CHECK_LAUNCH();
+    if (hipMemcpyAsync(sigma_out, scal + 2, sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return GCC_ERR_LAUNCH;
+    return GCC_OK;
+}
+
+extern "C" int gcc_spectral_grad(const float* g_eff, const float* w_bar, const float* u, const float* v, const float* t_fwd,
+                                 const float* sigma_fwd, int R, int C, int T, float* dw_bar, float* du, float* dv, void* ws,
+                                 size_t ws_bytes, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!g_eff || !w_bar || !u || !v || !t_fwd || !sigma_fwd || !dw_bar || !ws || R <= 0 || C <= 0 || T <= 0) return GCC_ERR_BAD_ARG;
+    if (ws_bytes < gcc_spectral_workspace(R, C, T)) return GCC_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int K = C * T;
+    const size_t n = (size_t)R * K;
+    float* scal = (float*)ws;
+    float* vt = scal + 64;
+    if (hipMemsetAsync(scal + 3, 0, sizeof(float), st) != hipSuccess) return GCC_ERR_LAUNCH;
+    hipLaunchKernelGGL(sn_inner_kernel, dim3(nblocks(n)), dim3(256), 0, st, g_eff, w_bar, n, scal + 3);
+    GCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sn_grad_kernel, dim3(nblocks(n)), dim3(256), 0, st, g_eff, u, v, t_fwd, sigma_fwd, (const float*)(scal + 3),
+                       R, C, T, dw_bar, du);
+    GCC_CHECK_LAUNCH();
+    if (dv) {
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3((K + 255) / 256), dim3(256), 0, st, w_bar, u, R, K, vt, (float*)nullptr, 1.f);
+        GCC_CHECK_LAUNCH();
+        hipLaunchKernelGGL(sn_dv_kernel, dim3(nblocks(K, 64)), dim3(256), 0, st, (const float*)vt, sigma_fwd,
+                           (const float*)(scal + 3), C, T, dv);
+        GCC_CHECK_LAUNCH();
+    }
+    return GCC_OK;
+}

@@ -62,7 +62,7 @@ def all_reduce_grads(optimizer, async_op=False):
     optimizer step."""
     if not is_dist():
         return None
-    optimizer.plan.set_grad_scale(1.0 / world_size())
+    optimizer.set_grad_scale(1.0 / world_size())
     if async_op:
         return dist.all_reduce(optimizer.flat.grads, op=dist.ReduceOp.SUM, async_op=True)
     all_reduce_flat(optimizer.flat.grads)

@@ -764,3 +764,329 @@ class MobileResnetEngine:
             dx = G.x_in
         ops.SideStream.get(self.device).join()
         return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# SAGAN: spectrally normalised convs, self attention, generator / discriminator engines
+# ------------------------------------------------------------------------------------------------
+class SNState:
+    """what one forward call of a spectrally normalised conv leaves behind for its backward: the bf16 packings of
+    W_bar / sigma of THAT call, sigma, and t = W_bar v (gradient of u)"""
+
+    def __init__(self, op):
+        dev = op.w_bar.device
+        taps = op.k * op.k
+        self.w = torch.zeros((ops.ceil8(op.rows), taps, ops.ceil8(op.cols)), dtype=torch.bfloat16, device=dev)
+        self.wt = torch.zeros((ops.ceil8(op.cols), taps, ops.ceil8(op.rows)), dtype=torch.bfloat16, device=dev)
+        self.sigma = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.t = torch.zeros(op.rows, dtype=torch.float32, device=dev)
+
+
+class SNConvOp:
+    """SpectralNorm(Conv2d | ConvTranspose2d) (models/SAGAN.py:17-70): parameters weight_bar, weight_u, weight_v, bias
+    of the wrapped module.  Every forward runs one power iteration (it moves u, v: eval passes too) and convolves
+    with W_bar / sigma; the weight gradient is folded through sigma into weight_bar.grad (and, for the discriminator
+    whose u, v the reference trains, into their gradients)."""
+
+    def __init__(self, inner, k, stride, pad, transposed, train_uv=False):
+        self.w_bar, self.u, self.v, self.bias = inner.weight_bar, inner.weight_u, inner.weight_v, inner.bias
+        self.k, self.stride, self.pad, self.transposed, self.train_uv = k, stride, pad, transposed, train_uv
+        self.rows, self.cols = self.w_bar.shape[0], self.w_bar.shape[1]
+        d = self.w_bar.data
+        self.w_eff = torch.empty_strided(d.shape, d.stride(), dtype=torch.float32, device=d.device)
+        self.g_eff = torch.empty_strided(d.shape, d.stride(), dtype=torch.float32, device=d.device)
+
+    def new_state(self):
+        return SNState(self)
+
+    def forward(self, st, x, out, act=ACT_NONE, slope=LRELU, want_stats=False):
+        ops.spectral_power_iteration(self.w_bar.data, self.u.data, self.v.data, st.t, st.sigma, self.w_eff)
+        ops.pack_weights_into(self.w_eff, st.w, st.wt)
+        b = self.bias.data if self.bias is not None else None
+        if not self.transposed:
+            return ops.conv_fprop(x, st.w, self.rows, self.k, self.stride, self.pad, out=out, bias=b, act=act, slope=slope,
+                                  want_stats=want_stats)
+        _, _, H, W = out.shape
+        return ops.conv_dgrad(x, st.wt, self.cols, H, W, self.k, self.stride, self.pad, out=out, bias=b, act=act, slope=slope,
+                              want_stats=want_stats)
+
+    def backward_data(self, st, dy, out):
+        if not self.transposed:
+            _, _, H, W = out.shape
+            return ops.conv_dgrad(dy, st.wt, self.cols, H, W, self.k, self.stride, self.pad, out=out)
+        return ops.conv_fprop(dy, st.w, self.rows, self.k, self.stride, self.pad, out=out)
+
+    def backward_weight(self, st, x, dy):
+        def run():
+            cx, cdy = (x, dy) if not self.transposed else (dy, x)
+            ops.conv_wgrad(cx, cdy, self.g_eff, self.k, self.stride, self.pad, accumulate=False)
+            ops.spectral_grad(self.g_eff, self.w_bar.data, self.u.data, self.v.data, st.t, st.sigma, self.w_bar.grad,
+                              du=self.u.grad if self.train_uv else None, dv=self.v.grad if self.train_uv else None)
+            if self.bias is not None:
+                ops.channel_sum(dy, self.bias.grad, accumulate=True)
+        if OVERLAP_WGRAD:
+            side = ops.SideStream.get(x.device)
+            side.fork()
+            with torch.cuda.stream(side.stream):
+                run()
+        else:
+            run()
+
+
+class AttnOp:
+    """Self_Attn (models/SAGAN.py:72-104): three biased 1x1 convs write q | k | v into channel slices of one buffer,
+    gcc_attention_* do the rest; y = gamma * attention + x"""
+
+    def __init__(self, module, device):
+        self.module = module
+        q, k, v = module.query_conv, module.key_conv, module.value_conv
+        self.C, self.C8 = v.weight.shape[0], q.weight.shape[0]
+        self.convs = [ConvOp(m.weight, m.bias, 1, 1, 0, False) for m in (q, k, v)]
+        c8p = ops.ceil8(self.C8)
+        self.offs = (0, c8p, 2 * c8p)
+        self.width = 2 * c8p + self.C
+        self.slices = ((0, self.C8), (c8p, self.C8), (2 * c8p, self.C))
+        self.device = device
+
+    def new_state(self, N, H, W):
+        st = type('AttnState', (), {})()
+        dev = self.device
+        st.qkv = ops.new_act(N, self.width, H, W, dev)
+        st.o = ops.new_act(N, self.C, H, W, dev)
+        st.y = ops.new_act(N, self.C, H, W, dev)
+        st.A = torch.zeros((N, H * W, H * W), dtype=torch.float32, device=dev)
+        return st
+
+    def grad_buffers(self, N, H, W):
+        g = type('AttnGrad', (), {})()
+        dev = self.device
+        g.dqkv = ops.new_act(N, self.width, H, W, dev)
+        g.dS = torch.zeros((N, H * W, H * W), dtype=torch.float32, device=dev)
+        g.tmp = ops.new_act(N, self.C, H, W, dev)
+        return g
+
+    def forward(self, st, x):
+        for conv, (off, w) in zip(self.convs, self.slices):
+            conv.forward(x, ops.cslice(st.qkv, off, w))
+        ops.attention_fwd(st.qkv, self.offs, x, self.module.gamma.data, self.C, self.C8, st.y, st.o, st.A)
+        return st.y
+
+    def backward(self, st, G, x, dy, dx, wgrad=True):
+        """dy: gradient w.r.t. y; dx receives dy (residual branch) + the data gradients of the three 1x1 convs"""
+        ops.attention_bwd(st.qkv, self.offs, st.o, st.A, self.module.gamma.data, dy, self.C, self.C8, G.dqkv, G.dS,
+                          dgamma=self.module.gamma.grad if wgrad else None)
+        ops.nhwc_copy(dy, 0, dx, 0, self.C)
+        for conv, (off, w) in zip(self.convs, self.slices):
+            d = ops.cslice(G.dqkv, off, w)
+            if wgrad:
+                conv.backward_weight(x, d)
+            conv.backward_data(d, G.tmp)
+            ops.nhwc_add(G.tmp, 0, dx, 0, self.C)
+
+
+class SaganGeneratorEngine:
+    """Generator(image_size=64) (models/SAGAN.py:106-170): z -> 4x4 -> 8 -> 16 -> attn1 -> 32 -> attn2 -> 64x64"""
+
+    def __init__(self, module, device):
+        self.module, self.device = module, device
+        geom = ((1, 0), (2, 1), (2, 1), (2, 1))
+        self.sn = [SNConvOp(getattr(module, 'l%d' % (i + 1))[0].module, 4, s, p, True) for i, (s, p) in enumerate(geom)]
+        self.bn = [BNOp(getattr(module, 'l%d' % (i + 1))[1]) for i in range(4)]
+        self.last = ConvOp(module.last[0].weight, module.last[0].bias, 4, 2, 1, True)
+        self.attn = [AttnOp(module.attn1, device), AttnOp(module.attn2, device)]
+        self.width = [op.cols for op in self.sn]
+        self.z_dim = self.sn[0].rows
+        self.ctx, self.gbuf = {}, {}
+
+    def convs(self):
+        return [self.last] + [c for a in self.attn for c in a.convs]
+
+    def repack(self):
+        if getattr(self, '_pack', None) is None:
+            self._pack = ops.PackPlan(self.convs(), self.device)
+        self._pack.run()
+
+    def _ctx(self, N, tag='main'):
+        key = (N, tag)
+        if key in self.ctx:
+            return self.ctx[key]
+        dev = self.device
+        c = type('SaganGCtx', (), {})()
+        c.N = N
+        c.z = ops.new_act(N, self.z_dim, 1, 1, dev)
+        c.size = [4, 8, 16, 32]
+        c.raw = [ops.new_act(N, self.width[i], c.size[i], c.size[i], dev) for i in range(4)]
+        c.act = [ops.new_act(N, self.width[i], c.size[i], c.size[i], dev) for i in range(4)]
+        c.bn = [ops.BNState(self.width[i], dev) for i in range(4)]
+        c.sn = [op.new_state() for op in self.sn]
+        c.attn = [self.attn[0].new_state(N, 16, 16), self.attn[1].new_state(N, 32, 32)]
+        c.out = ops.new_act(N, 3, 64, 64, dev)
+        c.g_out = ops.new_act(N, 3, 64, 64, dev)
+        c.train = True
+        self.ctx[key] = c
+        return c
+
+    def _gbufs(self, N):
+        if N not in self.gbuf:
+            dev = self.device
+            g = type('SaganGGrad', (), {})()
+            g.y = [ops.new_act(N, self.width[2], 16, 16, dev), ops.new_act(N, self.width[3], 32, 32, dev)]
+            g.act = [ops.new_act(N, self.width[i], s, s, dev) for i, s in enumerate((4, 8, 16, 32))]
+            g.raw = [ops.new_act(N, self.width[i], s, s, dev) for i, s in enumerate((4, 8, 16, 32))]
+            g.attn = [self.attn[0].grad_buffers(N, 16, 16), self.attn[1].grad_buffers(N, 32, 32)]
+            self.gbuf[N] = g
+        return self.gbuf[N]
+
+    def features(self, c):
+        """hooks 'l2' (post-ReLU) and 'attn2'"""
+        return [c.act[1], c.attn[1].y]
+
+    def forward(self, c, train=True):
+        """z already in c.z (NHWC [N,1,1,z_dim]); returns c (c.out = tanh image)"""
+        c.train = train
+        src = c.z
+        for i in range(4):
+            _, stats = self.sn[i].forward(c.sn[i], src, c.raw[i], want_stats=True)
+            self.bn[i].finalize(stats, c.N * c.size[i] * c.size[i], c.bn[i], train)
+            ops.bnact_fwd(c.raw[i], c.act[i], scale=c.bn[i].scale, shift=c.bn[i].shift, act=ACT_RELU)
+            src = c.act[i]
+            if i >= 2:
+                src = self.attn[i - 2].forward(c.attn[i - 2], src)
+        self.last.forward(src, c.out, act=ACT_TANH)
+        return c
+
+    def backward(self, c, g_feat=None, wgrad=True):
+        """c.g_out holds dL/d(image); g_feat: optional gradients w.r.t. features(c)"""
+        G = self._gbufs(c.N)
+        g_feat = g_feat or [None, None]
+        ops.bnact_bwd(c.out, None, c.g_out, c.g_out, in_act=ACT_TANH)
+        if wgrad:
+            self.last.backward_weight(c.attn[1].y, c.g_out)
+        self.last.backward_data(c.g_out, G.y[1])
+        if g_feat[1] is not None:
+            ops.nhwc_add(g_feat[1], 0, G.y[1], 0, self.width[3])
+        for i in (3, 2, 1, 0):
+            if i >= 2:
+                self.attn[i - 2].backward(c.attn[i - 2], G.attn[i - 2], c.act[i], G.y[i - 2], G.act[i], wgrad=wgrad)
+            if i == 1 and g_feat[0] is not None:
+                ops.nhwc_add(g_feat[0], 0, G.act[1], 0, self.width[1])
+            bn = self.bn[i].bn
+            ops.bnact_bwd(c.raw[i], c.act[i], G.act[i], G.raw[i], bn=c.bn[i], gamma=bn.weight.data, beta=bn.bias.data,
+                          bn_eval=not c.train, act=ACT_RELU, dgamma=bn.weight.grad if wgrad else None,
+                          dbeta=bn.bias.grad if wgrad else None)
+            src = c.z if i == 0 else (c.act[i - 1] if i - 1 < 2 else c.attn[i - 3].y)
+            if wgrad:
+                self.sn[i].backward_weight(c.sn[i], src, G.raw[i])
+            if i > 0:
+                self.sn[i].backward_data(c.sn[i], G.raw[i], G.y[i - 3] if i - 1 >= 2 else G.act[i - 1])
+        ops.SideStream.get(self.device).join()
+
+
+class SaganDiscriminatorEngine:
+    """Discriminator / MaskDiscriminator (models/SAGAN.py:172-274): 4 x [SN conv k4 s2 (+gate) + LeakyReLU(0.1)], attention
+    after l3 and l4, conv k4 on the 4x4 map -> one logit per image"""
+    SLOPE = 0.1
+
+    def __init__(self, module, masked, threshold, device):
+        self.module, self.masked, self.tau, self.device = module, masked, float(threshold), device
+        self.sn = [SNConvOp(getattr(module, 'l%d' % (i + 1))[0].module, 4, 2, 1, False, train_uv=True) for i in range(4)]
+        self.gate = [getattr(module, 'l%d' % (i + 1))[1] if masked else None for i in range(4)]
+        self.last = ConvOp(module.last[0].weight, module.last[0].bias, 4, 1, 0, False)
+        self.attn = [AttnOp(module.attn1, device), AttnOp(module.attn2, device)]
+        self.width = [op.rows for op in self.sn]
+        self.mask = [torch.ones(w, dtype=torch.float32, device=device) if masked else None for w in self.width]
+        self.size = [32, 16, 8, 4]
+        self.ctx, self.gbuf = {}, {}
+
+    def convs(self):
+        return [self.last] + [c for a in self.attn for c in a.convs]
+
+    def repack(self):
+        if getattr(self, '_pack', None) is None:
+            self._pack = ops.PackPlan(self.convs(), self.device)
+        self._pack.run()
+
+    def refresh_masks(self):
+        for i in range(4):
+            if self.gate[i] is not None:
+                ops.gate_mask(self.gate[i].alpha.data, self.tau, self.mask[i])
+
+    def new_ctx(self, N, tag):
+        key = (N, tag)
+        if key in self.ctx:
+            return self.ctx[key]
+        dev = self.device
+        c = type('SaganDCtx', (), {})()
+        c.N = N
+        c.x_in = ops.new_act(N, 3, 64, 64, dev)
+        c.raw = [ops.new_act(N, self.width[i], self.size[i], self.size[i], dev) for i in range(4)]
+        c.act = [ops.new_act(N, self.width[i], self.size[i], self.size[i], dev) for i in range(4)]
+        c.sn = [op.new_state() for op in self.sn]
+        c.attn = [self.attn[0].new_state(N, 8, 8), self.attn[1].new_state(N, 4, 4)]
+        c.pred = ops.new_act(N, 1, 1, 1, dev)
+        self.ctx[key] = c
+        return c
+
+    def _gbufs(self, N):
+        if N not in self.gbuf:
+            dev = self.device
+            g = type('SaganDGrad', (), {})()
+            g.pred = ops.new_act(N, 1, 1, 1, dev)
+            g.y = [ops.new_act(N, self.width[2], 8, 8, dev), ops.new_act(N, self.width[3], 4, 4, dev)]
+            g.act = [ops.new_act(N, self.width[i], self.size[i], self.size[i], dev) for i in range(4)]
+            g.raw = [ops.new_act(N, self.width[i], self.size[i], self.size[i], dev) for i in range(4)]
+            g.attn = [self.attn[0].grad_buffers(N, 8, 8), self.attn[1].grad_buffers(N, 4, 4)]
+            g.x_in = ops.new_act(N, 3, 64, 64, dev)
+            self.gbuf[N] = g
+        return self.gbuf[N]
+
+    def features(self, c):
+        """hooks 'l2' (post-LeakyReLU) and 'attn2'"""
+        return [c.act[1], c.attn[1].y]
+
+    def grad_pred_buffer(self, c):
+        return self._gbufs(c.N).pred
+
+    def forward(self, c):
+        if self.masked:
+            self.refresh_masks()
+        src = c.x_in
+        for i in range(4):
+            self.sn[i].forward(c.sn[i], src, c.raw[i])
+            ops.bnact_fwd(c.raw[i], c.act[i], gate=self.mask[i], act=ACT_LRELU, slope=self.SLOPE)
+            src = c.act[i]
+            if i >= 2:
+                src = self.attn[i - 2].forward(c.attn[i - 2], src)
+        self.last.forward(src, c.pred)
+        return c.pred
+
+    def backward(self, c, has_pred_grad=True, g_feat=None, wgrad=True, agrad=False, need_dx=True):
+        """dL/dpred in grad_pred_buffer(c) when has_pred_grad; g_feat = optional [g('l2'), g('attn2')]"""
+        G = self._gbufs(c.N)
+        g_feat = g_feat or [None, None]
+        if has_pred_grad:
+            if wgrad:
+                self.last.backward_weight(c.attn[1].y, G.pred)
+            self.last.backward_data(G.pred, G.y[1])
+            if g_feat[1] is not None:
+                ops.nhwc_add(g_feat[1], 0, G.y[1], 0, self.width[3])
+        else:
+            assert g_feat[1] is not None, 'nothing to back-propagate'
+            ops.nhwc_copy(g_feat[1], 0, G.y[1], 0, self.width[3])
+        for i in (3, 2, 1, 0):
+            if i >= 2:
+                self.attn[i - 2].backward(c.attn[i - 2], G.attn[i - 2], c.act[i], G.y[i - 2], G.act[i], wgrad=wgrad)
+            if i == 1 and g_feat[0] is not None:
+                ops.nhwc_add(g_feat[0], 0, G.act[1], 0, self.width[1])
+            gate = self.gate[i]
+            ops.bnact_bwd(c.raw[i], c.act[i], G.act[i], G.raw[i], gate=self.mask[i], act=ACT_LRELU, slope=self.SLOPE,
+                          dalpha=gate.alpha.grad if (agrad and gate is not None) else None)
+            src = c.x_in if i == 0 else (c.act[i - 1] if i - 1 < 2 else c.attn[i - 3].y)
+            if wgrad:
+                self.sn[i].backward_weight(c.sn[i], src, G.raw[i])
+            if i > 0:
+                self.sn[i].backward_data(c.sn[i], G.raw[i], G.y[i - 3] if i - 1 >= 2 else G.act[i - 1])
+            elif need_dx:
+                self.sn[0].backward_data(c.sn[0], G.raw[0], G.x_in)
+        ops.SideStream.get(self.device).join()
+        return G.x_in if need_dx else None

@@ -189,20 +189,38 @@ class HipAdam(torch.optim.Optimizer):
     """torch.optim.Optimizer facade (so LambdaLR/StepLR schedulers work unchanged) whose step() is
     one multi-tensor gcc_adam_step launch over a FlatParams group."""
 
-    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, l1=None):
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, l1=None, dup=()):
+        """dup: parameters (members of params) the reference lists twice in this optimizer (SAGAN, SURVEY.md hazard
+        H5): torch's Adam then applies two sequential updates per step to them, with the same gradient and the step
+        counter advancing twice -- reproduced by a second plan over those tensors that is stepped twice."""
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         dev = params[0].device
         self.flat = engine.FlatParams(params, dev)
-        self.plan = ops.AdamPlan(params, self.flat.grad_views, dev, l1=l1)
+        l1 = list(l1) if l1 is not None else [0.0] * len(params)
+        dup_ids = {id(p) for p in dup}
+        once = [i for i, p in enumerate(params) if id(p) not in dup_ids]
+        twice = [i for i, p in enumerate(params) if id(p) in dup_ids]
+        pick = lambda idx, seq: [seq[i] for i in idx]
+        self.plan = ops.AdamPlan(pick(once, params), pick(once, self.flat.grad_views), dev, l1=pick(once, l1)) if once else None
+        self.plan_dup = ops.AdamPlan(pick(twice, params), pick(twice, self.flat.grad_views), dev, l1=pick(twice, l1)) if twice else None
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
 
+    def set_grad_scale(self, s):
+        for plan in (self.plan, self.plan_dup):
+            if plan is not None:
+                plan.set_grad_scale(s)
+
     @torch.no_grad()
     def step(self, closure=None):
         g = self.param_groups[0]
-        self.plan.step(g['lr'], g['betas'], g['eps'])
+        if self.plan is not None:
+            self.plan.step(g['lr'], g['betas'], g['eps'])
+        if self.plan_dup is not None:
+            self.plan_dup.step(g['lr'], g['betas'], g['eps'])
+            self.plan_dup.step(g['lr'], g['betas'], g['eps'])
 
 
 # ------------------------------------------------------------------------------------------------

@@ -495,8 +495,45 @@ def gan_loss(mode, pred, target_is_real, for_discriminator, loss, dpred=None, gr
           'gcc_gan_loss')
 
 
-def arch_coeffs(Lfr, Lf, Lr, dT, loss, c_fr, c_f):
-    check(lib().gcc_arch_coeffs(Lfr.data_ptr(), Lf.data_ptr(), Lr.data_ptr(), dT.data_ptr(), loss.data_ptr(),
+def spectral_power_iteration(w_bar, u, v, t_out, sigma_out, w_eff, slot='sn_fwd'):
+    """one power iteration on the fp32 master (updates u, v in place), sigma and W_eff = W_bar / sigma"""
+    R, Cc, kh, kw = w_bar.shape
+    ws = workspace(lib().gcc_spectral_workspace(R, Cc, kh * kw), w_bar.device, slot)
+    check(lib().gcc_spectral_power_iteration(w_bar.data_ptr(), u.data_ptr(), v.data_ptr(), R, Cc, kh * kw, t_out.data_ptr(),
+                                             sigma_out.data_ptr(), w_eff.data_ptr(), ws.data_ptr(), ws.numel(), stream()),
+          'gcc_spectral_power_iteration')
+
+
+def spectral_grad(g_eff, w_bar, u, v, t_fwd, sigma_fwd, dw_bar, du=None, dv=None, slot='sn_bwd'):
+    R, Cc, kh, kw = w_bar.shape
+    ws = workspace(lib().gcc_spectral_workspace(R, Cc, kh * kw), w_bar.device, slot)
+    check(lib().gcc_spectral_grad(g_eff.data_ptr(), w_bar.data_ptr(), u.data_ptr(), v.data_ptr(), t_fwd.data_ptr(),
+                                  sigma_fwd.data_ptr(), R, Cc, kh * kw, dw_bar.data_ptr(), _p(du), _p(dv), ws.data_ptr(),
+                                  ws.numel(), stream()), 'gcc_spectral_grad')
+
+
+def attention_fwd(qkv, offs, x, gamma, Cc, C8, y, o, A):
+    """qkv: NHWC bf16 buffer holding q | k | v at channel offsets offs; y = gamma * softmax(q^T k) v + x"""
+    qp, B, _, H, W, ldq = geom(qkv)
+    xp, _, _, _, _, ldx = geom(x)
+    yp, _, _, _, _, ldy = geom(y)
+    op, _, _, _, _, ldo = geom(o)
+    check(lib().gcc_attention_fwd(qp, ldq, offs[0], offs[1], offs[2], xp, ldx, gamma.data_ptr(), B, H * W, Cc, C8, yp, ldy,
+                                  op, ldo, A.data_ptr(), stream()), 'gcc_attention_fwd')
+
+
+def attention_bwd(qkv, offs, o, A, gamma, dy, Cc, C8, dqkv, dS, dgamma=None):
+    qp, B, _, H, W, ldq = geom(qkv)
+    op, _, _, _, _, ldo = geom(o)
+    dyp, _, _, _, _, lddy = geom(dy)
+    dqp, _, _, _, _, lddq = geom(dqkv)
+    assert lddq == ldq
+    check(lib().gcc_attention_bwd(qp, ldq, offs[0], offs[1], offs[2], op, ldo, A.data_ptr(), gamma.data_ptr(), dyp, lddy, B,
+                                  H * W, Cc, C8, dqp, lddq, dS.data_ptr(), _p(dgamma), stream()), 'gcc_attention_bwd')
+
+
+def arch_coeffs(Lfr, Lf, Lr, dT, loss, c_fr, c_f, weight=0.5):
+    check(lib().gcc_arch_coeffs(Lfr.data_ptr(), Lf.data_ptr(), Lr.data_ptr(), dT.data_ptr(), float(weight), loss.data_ptr(),
                                 c_fr.data_ptr(), c_f.data_ptr(), stream()), 'gcc_arch_coeffs')
 
 

@@ -250,9 +250,10 @@ int gcc_gan_loss(int mode, int target_is_real, int for_discriminator, const void
 int gcc_gan_loss_ex(int mode, int target_is_real, int for_discriminator, const void* pred, int ld, int off,
                     size_t pixels, float* loss, void* dpred, float grad_weight, const float* grad_weight_dev,
                     int dpred_accumulate, gcc_stream_t stream);
-/* arch-step scalars: loss = | |Lfr-Lf| - dT | + (Lr+Lf)/2 and its partial derivatives c_fr, c_f */
-int gcc_arch_coeffs(const float* Lfr, const float* Lf, const float* Lr, const float* dT, float* loss, float* c_fr,
-                    float* c_f, gcc_stream_t stream);
+/* arch-step scalars: loss = | |Lfr-Lf| - dT | + w (Lr+Lf) and its partial derivatives c_fr, c_f
+ * (w = 1/2: models/Pix2Pix.py:505-509, models/CycleGAN.py:410-414; w = 1: models/SAGAN.py:388-389) */
+int gcc_arch_coeffs(const float* Lfr, const float* Lf, const float* Lr, const float* dT, float real_fake_weight,
+                    float* loss, float* c_fr, float* c_f, gcc_stream_t stream);
 /* mean |a-b| * weight (nn.L1Loss, models/Pix2Pix.py:520) over C channels; da = weight*sign(a-b)/count */
 int gcc_l1_loss(const void* a, int lda, int aoff, const void* b, int ldb, int boff, int C, size_t pixels,
                 float weight, float* loss, int accumulate, void* da, int ldda, int daoff,
@@ -271,6 +272,35 @@ int gcc_distill_fwd(const void* f, int ldf, int foff, const void* t, int ldt, in
 int gcc_distill_bwd(const void* f, int ldf, int foff, const void* t, int ldt, int toff, int N, int C, int HW,
                     int squared, float wg, float wc, void* df, int lddf, int dfoff, void* ws, size_t ws_bytes,
                     gcc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SAGAN (models/SAGAN.py).
+ * Spectral normalisation, SpectralNorm._update_u_v (:25-38), on the fp32 master W_bar [R][C][k][k] (channels_last for
+ * k > 1; the reference's w.view(R, -1) column order c*T + t is kept for v, T = k*k): one power iteration that
+ * overwrites u [R] and v [C*T], t_out = W_bar v (kept by the caller for the gradient of u), sigma = u . t_out, and
+ * W_eff = W_bar / sigma (fp32, same layout; feed it to gcc_pack_weights).  Runs on every forward, eval included.
+ * gcc_spectral_grad folds G = dL/dW_eff into the master's gradient:
+ *   dW_bar += G/sigma + s u v^T,  du += s t_fwd,  dv += s W_bar^T u,   s = -<G, W_bar>/sigma^2
+ * with the LIVE u, v and the forward call's own sigma / t (what the reference's autograd evaluates, see
+ * csrc/spectral.hip).  du / dv may be NULL (generator: u, v are never trained; discriminator: set_requires_grad
+ * switches them on, :513). */
+size_t gcc_spectral_workspace(int R, int C, int T);
+int gcc_spectral_power_iteration(const float* w_bar, float* u, float* v, int R, int C, int T, float* t_out,
+                                 float* sigma_out, float* w_eff, void* ws, size_t ws_bytes, gcc_stream_t stream);
+int gcc_spectral_grad(const float* g_eff, const float* w_bar, const float* u, const float* v, const float* t_fwd,
+                      const float* sigma_fwd, int R, int C, int T, float* dw_bar, float* du, float* dv, void* ws,
+                      size_t ws_bytes, gcc_stream_t stream);
+/* Self attention, Self_Attn.forward (:72-104), per image over N = H*W <= 1024 positions: q, k (C8 channels) and v
+ * (C <= 512 channels) are channel slices (qoff / koff / voff) of one NHWC bf16 buffer; y = gamma * softmax(q^T k) v + x.
+ * Saved for backward: o (pre-gamma output, bf16 [B][N][ldo]) and A (fp32 [B][N][N]).
+ * gcc_attention_bwd: dq / dk / dv into the same slices of dqkv, dgamma (+=); dS is an fp32 [B][N][N] scratch.  The
+ * residual branch (dx += dy) belongs to the caller. */
+int gcc_attention_fwd(const void* qkv, int ldq, int qoff, int koff, int voff, const void* x, int ldx,
+                      const float* gamma, int B, int N, int C, int C8, void* y, int ldy, void* o, int ldo,
+                      float* A, gcc_stream_t stream);
+int gcc_attention_bwd(const void* qkv, int ldq, int qoff, int koff, int voff, const void* o, int ldo,
+                      const float* A, const float* gamma, const void* dy, int lddy, int B, int N, int C, int C8,
+                      void* dqkv, int lddq, float* dS, float* dgamma, gcc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer: multi-tensor Adam (torch.optim.Adam, no weight decay; models/Pix2Pix.py:382,415,

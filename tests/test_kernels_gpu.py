@@ -152,6 +152,30 @@ def test_conv_transpose_as_dgrad_with_stats_and_tanh():
     close(dw.cpu(), wr.grad, tol=5e-3, floor=1e-4, what='convT wgrad')
 
 
+def test_conv_stats_with_bias_on_partial_tiles():
+    """BatchNorm partial statistics of a biased conv whose M tile is only partly filled (SAGAN generator: spectrally
+    normalised ConvTranspose2d with bias in front of a BatchNorm): the padding rows must not contribute the bias"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    x = rb(torch.randn(4, 64, 4, 4, generator=g))
+    w = rb(torch.randn(64, 32, 4, 4, generator=g) * 0.1)
+    b = torch.randn(32, generator=g)
+    wp, wtp = ops.pack_weights(master_cl(w))
+    y, stats = ops.conv_dgrad(to_dev(x), wtp, 32, 8, 8, 4, 2, 1, bias=b.to(DEV), want_stats=True)
+    yg = to_cpu(y)
+    close(yg, F.conv_transpose2d(x, w, b, stride=2, padding=1), what='biased convT')
+    st = stats.sum(0).cpu()
+    close(st[0], yg.sum((0, 2, 3)), tol=1e-3, floor=1e-3, what='stats sum (bias, partial tile)')
+    close(st[1], (yg * yg).sum((0, 2, 3)), tol=1e-3, floor=1e-3, what='stats sumsq (bias, partial tile)')
+    w2 = rb(torch.randn(24, 16, 3, 3, generator=g) * 0.1)
+    b2 = torch.randn(24, generator=g)
+    x2 = rb(torch.randn(1, 16, 9, 9, generator=g))
+    wp2, _ = ops.pack_weights(master_cl(w2))
+    y2, st2 = ops.conv_fprop(to_dev(x2), wp2, 24, 3, 1, 1, bias=b2.to(DEV), want_stats=True)
+    y2g = to_cpu(y2)
+    close(st2.sum(0).cpu()[0], y2g.sum((0, 2, 3)), tol=1e-3, floor=1e-3, what='fprop stats sum (bias, partial tile)')
+
+
 def test_conv_channel_slices():
     """conv reading from / writing into channel slices of wider (concat) buffers"""
     ops = _ops()

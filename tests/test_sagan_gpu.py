@@ -1,0 +1,320 @@
+"""SAGAN on the HIP path: spectral-norm and attention kernels against plain PyTorch fp32, the model against the
+reference's golden vectors (tests/golden/sagan_gcc.npz) and the oracle's gradients.  Tolerances as in
+tests/test_pix2pix_gpu.py unless stated."""
+import copy
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_pix2pix_gpu import DEV, _rel, load, load_recipe
+
+pytestmark = pytest.mark.gpu
+
+
+def _rb(t):
+    return t.bfloat16().float()
+
+
+def _to_nhwc(ops, x):
+    buf = ops.new_act(x.shape[0], x.shape[1], x.shape[2], x.shape[3], DEV)
+    ops.nchw_to_nhwc(x.to(DEV).contiguous(), buf)
+    return buf
+
+
+@pytest.mark.parametrize('shape,transposed', [((32, 16, 4, 4), False), ((128, 24, 4, 4), True), ((8, 3, 4, 4), False)])
+def test_spectral_norm_power_iteration_and_gradient(shape, transposed):
+    """one power iteration, sigma, W_bar / sigma and the gradient fold against autograd (fp32 on both sides)"""
+    from gcc_amd import ops
+    g = torch.Generator().manual_seed(shape[0])
+    w = torch.randn(shape, generator=g) * 0.1
+    u0, v0 = torch.randn(shape[0], generator=g), torch.randn(shape[1] * 16, generator=g)
+    G = torch.randn(shape, generator=g)
+    # reference arithmetic (models/SAGAN.py:25-38) with autograd through sigma
+    wr = w.clone().requires_grad_(True)
+    wm = wr.reshape(shape[0], -1)
+    v = torch.mv(wm.detach().t(), u0)
+    v = v / (v.norm() + 1e-12)
+    t = torch.mv(wm.detach(), v)
+    u = (t / (t.norm() + 1e-12)).requires_grad_(True)
+    vv = v.clone().requires_grad_(True)
+    sigma = u.dot(wm.mv(vv))
+    ((wr / sigma) * G).sum().backward()
+    # device: the master is channels_last like a FlatParams-homed conv weight
+    wd = w.to(DEV).contiguous(memory_format=torch.channels_last)
+    ud, vd = u0.to(DEV), v0.to(DEV)
+    t_d, s_d = torch.zeros(shape[0], device=DEV), torch.zeros(1, device=DEV)
+    w_eff = torch.empty_like(wd)
+    ops.spectral_power_iteration(wd, ud, vd, t_d, s_d, w_eff)
+    torch.cuda.synchronize()
+    assert torch.allclose(ud.cpu(), u.detach(), atol=1e-5) and torch.allclose(vd.cpu(), v, atol=1e-5)
+    assert abs(s_d.item() - sigma.item()) <= 1e-5 * abs(sigma.item())
+    assert torch.allclose(w_eff.cpu(), (w / sigma.detach()), atol=1e-5)
+    Gd = G.to(DEV).contiguous(memory_format=torch.channels_last)
+    dw, du, dv = torch.zeros_like(wd), torch.zeros_like(ud), torch.zeros_like(vd)
+    ops.spectral_grad(Gd, wd, ud, vd, t_d, s_d, dw, du=du, dv=dv)
+    torch.cuda.synchronize()
+    assert _rel(dw.cpu(), wr.grad) <= 1e-4, _rel(dw.cpu(), wr.grad)
+    assert _rel(du.cpu(), u.grad) <= 1e-4 and _rel(dv.cpu(), vv.grad) <= 1e-4
+
+
+@pytest.mark.parametrize('B,C,H', [(2, 64, 16), (3, 16, 8), (2, 512, 4), (1, 48, 32)])
+def test_self_attention_forward_backward(B, C, H):
+    """y = gamma * softmax(q^T k) v + x and its gradients w.r.t. q, k, v, gamma (q, k with C // 8 channels)"""
+    from gcc_amd import ops
+    g = torch.Generator().manual_seed(C + H)
+    C8, N = C // 8, H * H
+    q, k = _rb(torch.randn(B, C8, H, H, generator=g)), _rb(torch.randn(B, C8, H, H, generator=g))
+    v, x = _rb(torch.randn(B, C, H, H, generator=g)), _rb(torch.randn(B, C, H, H, generator=g))
+    dy = _rb(torch.randn(B, C, H, H, generator=g))
+    gamma = torch.tensor([0.7])
+    qr, kr, vr, gr = (t.clone().requires_grad_(True) for t in (q, k, v, gamma))
+    attn = torch.softmax(torch.bmm(qr.reshape(B, C8, N).permute(0, 2, 1), kr.reshape(B, C8, N)), dim=-1)
+    o = torch.bmm(vr.reshape(B, C, N), attn.permute(0, 2, 1)).reshape(B, C, H, H)
+    y_ref = gr * o + x
+    (y_ref * dy).sum().backward()
+    c8p = ops.ceil8(C8)
+    offs = (0, c8p, 2 * c8p)
+    qkv = ops.new_act(B, 2 * c8p + C, H, H, DEV)
+    for t, off in ((q, 0), (k, c8p), (v, 2 * c8p)):
+        ops.nhwc_copy(_to_nhwc(ops, t), 0, qkv, off, t.shape[1])
+    xd = _to_nhwc(ops, x)
+    y, od = ops.new_act(B, C, H, H, DEV), ops.new_act(B, C, H, H, DEV)
+    A = torch.zeros((B, N, N), device=DEV)
+    gd = gamma.to(DEV)
+    ops.attention_fwd(qkv, offs, xd, gd, C, C8, y, od, A)
+    torch.cuda.synchronize()
+    assert torch.allclose(A.cpu(), attn.detach(), atol=2e-6 + 1e-5 * float(attn.max()))
+    assert _rel(ops.nhwc_to_nchw(y, C).cpu(), y_ref.detach()) <= 5e-3
+    dqkv = ops.new_act(B, 2 * c8p + C, H, H, DEV)
+    dS = torch.zeros((B, N, N), device=DEV)
+    dgam = torch.zeros(1, device=DEV)
+    ops.attention_bwd(qkv, offs, od, A, gd, _to_nhwc(ops, dy), C, C8, dqkv, dS, dgamma=dgam)
+    torch.cuda.synchronize()
+    full = ops.nhwc_to_nchw(dqkv, 2 * c8p + C).cpu()
+    assert _rel(full[:, :C8], qr.grad) <= 1e-2, ('dq', _rel(full[:, :C8], qr.grad))
+    assert _rel(full[:, c8p:c8p + C8], kr.grad) <= 1e-2, ('dk', _rel(full[:, c8p:c8p + C8], kr.grad))
+    assert _rel(full[:, 2 * c8p:], vr.grad) <= 1e-2, ('dv', _rel(full[:, 2 * c8p:], vr.grad))
+    assert abs(dgam.item() - gr.grad.item()) <= 1e-2 * abs(gr.grad.item()) + 1e-3
+
+
+SAGAN_ARGV = ['--dataroot', './database/celeb/', '--model', 'sagan', '--gpu_ids', '0', '--ngf', '8', '--ndf', '8',
+              '--teacher_ngf', '16', '--online_distillation', '--darts_discriminator', '--threshold', '0.1',
+              '--lambda_L1', '1', '--lambda_content', '1', '--lambda_gram', '1', '--arch_lr', '1e-4']
+
+
+def _build(z):
+    from gcc_amd.options import options
+    from gcc_amd.models import get_model_class
+    from tests.golden.recipe import recipe_transform
+    opt = options.parse(SAGAN_ARGV)
+    opt.isTrain = True
+    opt.teacher_ndf = 16
+    cls = get_model_class(opt)
+    model = cls(opt)
+    topt = copy.deepcopy(opt)
+    topt.ngf, topt.ndf = opt.teacher_ngf, opt.teacher_ndf
+    topt.darts_discriminator = topt.online_distillation = False
+    teacher = cls(topt)
+    teacher.model_train()
+    model.teacher_model = teacher
+    model.init_distillation()
+    teacher.init_distillation()
+    for net, seed in ((model.netG, 801), (model.netD, 802), (teacher.netG, 803), (teacher.netD, 804)):
+        load_recipe(net, seed)
+    with torch.no_grad():
+        for i, t in enumerate(model.transform_convs):
+            t.weight.copy_(recipe_transform(t.weight.shape[0], t.weight.shape[1], 810 + i).to(DEV))
+        model.netD.state_dict()['l1.1.alpha'][0] = 0.3
+        model.netD.state_dict()['l3.1.alpha'][2] = 0.5
+    model.refresh_weights()
+    teacher.refresh_weights()
+    model.model_train()
+    return model, teacher, opt
+
+
+def _batch(z, zk, rk):
+    return {'z': torch.from_numpy(z[zk]), 'real_img': torch.from_numpy(z[rk]), 'img_path': ['p'] * 4}
+
+
+_ZERO_G = lambda n: n.endswith('.module.bias') or n.endswith('key_conv.bias')
+_ZERO_D = lambda n: n.endswith('key_conv.bias') or n == 'attn2.value_conv.bias'
+
+
+def test_sagan_two_iterations_vs_reference_golden(golden_dir):
+    from tests.golden.recipe import sample_idx
+    z = load(golden_dir, 'sagan_gcc.npz')
+    model, teacher, opt = _build(z)
+    assert list(model.netG.state_dict().keys()) == [str(k) for k in z['G_keys']]
+    assert list(model.netD.state_dict().keys()) == [str(k) for k in z['D_keys']]
+    assert list(teacher.netD.state_dict().keys()) == [str(k) for k in z['TD_keys']]
+    assert opt.gan_mode == str(z['gan_mode']) and abs(opt.lr - float(z['lr'])) < 1e-12
+    assert model.loss_names == [str(k) for k in z['loss_names']]
+    # eval image on the recipe state; then restore u, v (the eval pass moved them, as in the fixture script)
+    sd0 = {k: v.clone() for k, v in model.netG.state_dict().items()}
+    model.model_eval()
+    model.set_input({'z': torch.from_numpy(z['eval.z']), 'real_img': torch.zeros(4, 3, 64, 64), 'img_path': ['p'] * 4})
+    model.forward()
+    e = (model.fake_img.cpu() - torch.from_numpy(z['eval.fake_img'])).abs()
+    print('eval fake_img: max %.4g mean %.4g' % (e.max(), e.mean()))
+    assert e.max() <= 2e-2 and e.mean() <= 3e-3
+    model.netG.load_state_dict(sd0)
+    model.model_train()
+    # the same two iterations on the oracle with bf16 storage emulated: the reference's arithmetic plus the rounding
+    # points of the HIP path.  Behind sign-like Adam steps (beta1 = 0) the fp32 reference and any bf16 pipeline drift
+    # apart (iteration 1: G_GAN 1.667 emulated vs 1.478 fp32), while the HIP path must stay on the emulated trajectory.
+    from oracle import gcc_oracle as O
+    from tests.test_oracle_golden import build_sagan_oracle
+    emu = []
+    O.EMULATE_BF16 = True
+    try:
+        om, ot, _ = build_sagan_oracle(z)
+        for it in range(2):
+            om.set_input(torch.from_numpy(z['it%d.z' % it]), torch.from_numpy(z['it%d.real' % it]))
+            om.optimize_parameters()
+            om.set_input(torch.from_numpy(z['it%d.vz' % it]), torch.from_numpy(z['it%d.vreal' % it]))
+            om.clipping_mask_alpha()
+            om.optimizer_netD_arch()
+            emu.append((dict(om.losses), dict(ot.losses)))
+    finally:
+        O.EMULATE_BF16 = False
+    for it in range(2):
+        model.set_input(_batch(z, 'it%d.z' % it, 'it%d.real' % it))
+        model.optimize_parameters()
+        if it == 0:
+            e = (model.fake_img.cpu() - torch.from_numpy(z['it0.fake_img'])).abs()
+            print('it0 fake_img: max %.4g mean %.4g' % (e.max(), e.mean()))
+            assert e.max() <= 2e-2 and e.mean() <= 3e-3
+            e = (teacher.fake_img.cpu() - torch.from_numpy(z['it0.Tfake_img'])).abs()
+            assert e.max() <= 2e-2 and e.mean() <= 3e-3
+            for j, f in enumerate(model.G.features(model._gctx)):
+                ref = torch.from_numpy(z['it0.sfeat.%d' % j])
+                err = (f.float().cpu() - ref).abs().max().item() / ref.abs().max().item()
+                print('student feature %d: rel max err %.4g' % (j, err))
+                assert err <= 3e-2
+            for j in range(4):
+                ref = torch.from_numpy(z['it0.target.%d' % j])
+                err = (model.target_distillation_features[j].float().cpu() - ref).abs().max().item() / ref.abs().max().item()
+                print('target %d: rel max err %.4g' % (j, err))
+                # target 3 is the teacher discriminator's attn2 feature computed AFTER its Adam step: with beta1 = 0 the
+                # step is a pure sign step of 4e-4 per weight, so gradient elements whose sign bf16 rounding flips move the
+                # 4x4 feature (oracle with bf16 storage emulated: 7.2% on this input)
+                assert err <= (3e-2 if j < 3 else 0.12)
+        model.set_input(_batch(z, 'it%d.vz' % it, 'it%d.vreal' % it))
+        model.clipping_mask_alpha()
+        model.optimizer_netD_arch()
+        losses, tl = model.get_current_losses(), teacher.get_current_losses()
+        for k in z.files:
+            for pre, got, em in (('it%d.loss.' % it, losses, emu[it][0]), ('it%d.tloss.' % it, tl, emu[it][1])):
+                if k.startswith(pre):
+                    name, ref = k[len(pre):], float(z[k])
+                    print('it%d %s %s: got %.5g  reference %.5g  bf16-emulating oracle %.5g' % (it, pre[-6], name, got[name], ref, em[name]))
+                    # bar: 3e-2 of the emulated trajectory; against the fp32 reference 3e-2 before the first Adam step
+                    # has acted (iteration 0: D_real, D_fake, content, gram, L1), else the measured drift 0.25
+                    assert abs(got[name] - em[name]) <= 3e-2 * max(1.0, abs(em[name])), (it, k, got[name], em[name])
+                    pre_step = it == 0 and name in ('D_real', 'D_fake', 'content', 'gram', 'L1')
+                    assert abs(got[name] - ref) <= (3e-2 if pre_step else 0.25) * max(1.0, abs(ref)), (it, k, got[name], ref)
+    for tag, net, zero in (('sG', model.netG, _ZERO_G), ('sD', model.netD, _ZERO_D), ('tG', teacher.netG, _ZERO_G),
+                           ('tD', teacher.netD, _ZERO_D)):
+        sd = net.state_dict()
+        prefix = 'final.%s.' % tag
+        dup = tag in ('sG', 'sD')
+        for k in z.files:
+            if not k.startswith(prefix):
+                continue
+            name = k[len(prefix):]
+            if zero(name):
+                continue
+            ref = z[k]
+            g = sd[name].detach().float().cpu().reshape(-1)
+            g = g[sample_idx(g.numel())].numpy()
+            if name.endswith('num_batches_tracked'):
+                assert int(g[0]) == int(ref.reshape(-1)[0]), (tag, name)
+                continue
+            lr = opt.lr * (4 if 'D' in tag else 1)
+            if name.endswith('running_mean') or name.endswith('running_var'):
+                tol = 3e-2 * max(1.0, float(np.abs(ref).max()))
+            elif name.endswith('alpha'):
+                tol = 2.2 * opt.arch_lr * 2 + 1e-6
+            elif name.endswith('weight_u') or name.endswith('weight_v'):
+                tol = 8e-2            # unit vectors re-derived from W_bar by each power iteration (+ Adam steps in D): they
+                                      # inherit the sign-step differences of W_bar, amplified by the matvec
+            else:
+                # Adam with beta1 = 0, beta2 = 0.9: update t moves a weight by at most lr * sqrt((1 - 0.9^t) / 0.1); a
+                # flipped gradient sign doubles the distance.  2 steps, 4 updates for the duplicated entries.
+                n_upd = 4 if (dup and ('.module.' in name or '_conv.' in name)) else 2
+                tol = 2.2 * lr * sum(((1 - 0.9 ** t) / 0.1) ** 0.5 for t in range(1, n_upd + 1)) + 1e-6
+            err = float(np.abs(g - ref).max())
+            assert err <= tol, (tag, name, err, tol)
+
+
+def test_sagan_gradients_vs_oracle(golden_dir):
+    """one iteration + arch step with every learning rate 0: every parameter gradient (u, v of the discriminators
+    included) against the oracle's autograd gradient, fp32 and bf16-storage-emulated"""
+    from oracle import gcc_oracle as O
+    from tests.test_oracle_golden import build_sagan_oracle
+    z = load(golden_dir, 'sagan_gcc.npz')
+    model, teacher, opt = _build(z)
+    for m in (model, teacher):
+        for o in (m.optimizer_G, m.optimizer_D):
+            o.param_groups[0]['lr'] = 0.0
+    model.optimizer_arch.param_groups[0]['lr'] = 0.0
+    zz, real, vz, vreal = (torch.from_numpy(z['it0.' + k]) for k in ('z', 'real', 'vz', 'vreal'))
+
+    def oracle_grads(emulate):
+        O.EMULATE_BF16 = emulate
+        try:
+            om, ot, _ = build_sagan_oracle(z)
+            for o in (om, ot):
+                o.lr_G = o.lr_D = o.lr_arch = 0.0
+            om.set_input(zz, real)
+            om.optimize_parameters()
+            g = {}
+            for tag, who in (('t', ot), ('s', om)):
+                for k in who.G_keys:
+                    g[(tag + 'G', k)] = who.G[k].grad.clone()
+                for k in who.D_w_keys:
+                    g[(tag + 'D', k)] = who.D[k].grad.clone()
+            for i in range(2):
+                g[('T', i)] = om.T[i].grad.clone()
+            om.set_input(vz, vreal)
+            om.clipping_mask_alpha()
+            om.optimizer_netD_arch()
+            for k in om.D_a_keys:
+                g[('alpha', k)] = om.D[k].grad.clone()
+            return g
+        finally:
+            O.EMULATE_BF16 = False
+    g32, g16 = oracle_grads(False), oracle_grads(True)
+    model.set_input({'z': zz, 'real_img': real, 'img_path': ['p'] * 4})
+    model.optimize_parameters()
+    torch.cuda.synchronize()
+    bad = []
+
+    def check(key, g):
+        g = g.float().cpu()
+        zero = (key[0][1:] == 'G' and _ZERO_G(key[1])) or (key[0][1:] == 'D' and _ZERO_D(key[1]))
+        if zero:
+            return
+        r32, r16, floor = _rel(g, g32[key]), _rel(g, g16[key]), _rel(g16[key], g32[key])
+        print('%-6s %-30s vs fp32 %.4f  vs bf16-emulated %.4f  (emulated vs fp32 %.4f)' % (key[0], key[1], r32, r16, floor))
+        if not (r16 <= 6e-2 or r32 <= 1.5 * floor + 2e-2):
+            bad.append((key, r32, r16, floor))
+    for tag, net in (('tD', teacher.netD), ('tG', teacher.netG), ('sD', model.netD), ('sG', model.netG)):
+        sd = net.state_dict(keep_vars=True)
+        for (t, k) in g32:
+            if t == tag:
+                check((t, k), sd[k].grad)
+    for i in range(2):
+        check(('T', i), model.transform_convs[i].weight.grad)
+    model.set_input({'z': vz, 'real_img': vreal, 'img_path': ['p'] * 4})
+    model.clipping_mask_alpha()
+    model.optimizer_netD_arch()
+    torch.cuda.synchronize()
+    sd = model.netD.state_dict(keep_vars=True)
+    for (t, k) in g32:
+        if t == 'alpha':
+            check((t, k), sd[k].grad)
+    assert not bad, bad
