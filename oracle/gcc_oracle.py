@@ -547,6 +547,9 @@ class Opt:
         self.darts_discriminator = True
         self.online_distillation = True
         self.direction = 'AtoB'
+        self.lambda_SR_adversarial = 1e-3   # SRGAN
+        self.lambda_SR_content = 0.0
+        self.lambda_SR_perceptual = 1.0
         self.lambda_A = 10.0            # CycleGAN
         self.lambda_B = 10.0
         self.lambda_identity = 0.5
@@ -1211,6 +1214,274 @@ class SAGANOracle:
         self._req(self.D, self.D_a_keys, True)
         s_diff = self.get_D_arch_diff(False)
         loss = (s_diff - t_diff).abs() + self.arch_real + self.arch_fake          # no 0.5 here (:388-389)
+        loss.backward()
+        adam_step([self.D[k] for k in self.D_a_keys], [self.D[k].grad for k in self.D_a_keys], self.st_A, self.lr_arch,
+                  (0.9, 0.999))
+        self._req(self.D, self.D_a_keys, False)
+        self.losses.update(D_arch_diff=float(s_diff.detach()), D_arch=float(loss.detach()), teacher_D_arch_diff=float(t_diff))
+
+
+# ----------------------------------------------------------------------------------------------
+# SRGAN (models/SRGAN.py, models/GANLoss.py:95-145, data/sr_dataset.py:15-64)
+# ----------------------------------------------------------------------------------------------
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+VGG19_CFG = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512)   # up to conv5_4
+
+
+def to_imagenet_norm(img: Tensor) -> Tensor:
+    """convert_image(img, source='[-1, 1]', target='imagenet-norm')"""
+    mean = torch.tensor(IMAGENET_MEAN, dtype=img.dtype).reshape(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, dtype=img.dtype).reshape(1, 3, 1, 1)
+    return ((img + 1.) / 2. - mean) / std
+
+
+def srresnet_forward(sd: SD, x: Tensor, train: bool = True, features: Optional[OrderedDict] = None,
+                     hook_idx: Sequence[int] = (3, 7, 11, 15)) -> Tensor:
+    """Generator.forward (models/SRGAN.py:139-199): k9 conv + PReLU | residual blocks (conv3 BN PReLU conv3 BN, +x) |
+    conv3 BN + long skip | 2 x (conv3 -> PixelShuffle(2) -> PReLU) | k9 conv + tanh.  Hooks: outputs of residual blocks"""
+    def conv(t, name, pad):
+        return _q(F.conv2d(t, _qw(sd[name + '.weight']), sd[name + '.bias'], padding=pad))
+    h = _q(F.prelu(conv(_q(x), 'conv_block1.conv_block.0', 4), sd['conv_block1.conv_block.1.weight']))
+    skip = h
+    n_blocks = len({k.split('.')[1] for k in sd if k.startswith('residual_blocks.')})
+    for i in range(n_blocks):
+        p = 'residual_blocks.%d.' % i
+        t = _q(batch_norm(sd, p + 'conv_block1.conv_block.1', conv(h, p + 'conv_block1.conv_block.0', 1), train))
+        t = _q(F.prelu(t, sd[p + 'conv_block1.conv_block.2.weight']))
+        t = batch_norm(sd, p + 'conv_block2.conv_block.1', conv(t, p + 'conv_block2.conv_block.0', 1), train)
+        h = _q(t + h)
+        if features is not None and i in hook_idx:
+            features['residual_blocks.%d' % i] = h
+    t = batch_norm(sd, 'conv_block2.conv_block.1', conv(h, 'conv_block2.conv_block.0', 1), train)
+    h = _q(t + skip)
+    for j in range(2):
+        p = 'subpixel_convolutional_blocks.%d.' % j
+        h = _q(F.prelu(F.pixel_shuffle(conv(h, p + 'conv', 1), 2), sd[p + 'prelu.weight']))
+    return _q(torch.tanh(F.conv2d(h, _qw(sd['conv_block3.conv_block.0.weight']), sd['conv_block3.conv_block.0.bias'], padding=4)))
+
+
+def sr_discriminator_forward(sd: SD, x: Tensor, masked: bool = False, threshold: float = 0.5, train: bool = True,
+                             features: Optional[OrderedDict] = None) -> Tensor:
+    """Discriminator / MaskDiscriminator.forward (models/SRGAN.py:201-297), n_blocks 4: conv3 (stride 1, 2, 1, 2) [+BN]
+    [+gate] + LeakyReLU(0.2); global average pool; Linear -> one logit per image.  Hooks: conv_blocks.1 / .3 outputs."""
+    h = _q(x)
+    n_blocks = len({k.split('.')[1] for k in sd if k.startswith('conv_blocks.')})
+    for i in range(n_blocks):
+        p = 'conv_blocks.%d.conv_block.' % i
+        h = _q(F.conv2d(h, _qw(sd[p + '0.weight']), sd[p + '0.bias'], stride=1 if i % 2 == 0 else 2, padding=1))
+        j = 1
+        if i != 0:
+            h = batch_norm(sd, p + '1', h, train)
+            j = 2
+        if masked:
+            h = gate(h, sd[p + '%d.alpha' % j], threshold)
+        h = _q(F.leaky_relu(h, 0.2))
+        if features is not None and i in (1, 3):
+            features['conv_blocks.%d' % i] = h
+    return F.linear(h.mean((2, 3)), sd['fc1.weight'], sd['fc1.bias'])
+
+
+def vgg_features(sd: SD, x: Tensor, cfg=VGG19_CFG) -> Tensor:
+    """TruncatedVGG19(i=5, j=4) (models/GANLoss.py:95-145): vgg19.features[:36] -- conv3 + ReLU ... up to relu5_4; the
+    channel widths come from the weights (the golden fixture uses a narrow stand-in: torchvision is not in the image)"""
+    h, idx = _q(x), 0
+    for c in cfg:
+        if c == 'M':
+            h = F.max_pool2d(h, 2, 2)
+        else:
+            h = _q(F.relu(F.conv2d(h, _qw(sd['truncated_vgg19.%d.weight' % idx]), sd['truncated_vgg19.%d.bias' % idx], padding=1)))
+            idx += 1
+        idx += 1
+    return h
+
+
+def srresnet_shapes(ngf: int = 64, n_blocks: int = 16, filter_cfgs: Optional[Sequence[int]] = None):
+    shp: Dict[str, Tuple[int, ...]] = OrderedDict()
+
+    def conv(name, co, ci, k):
+        shp[name + '.weight'] = (co, ci, k, k)
+        shp[name + '.bias'] = (co,)
+
+    def bn(name, c):
+        for sfx, v in (('weight', (c,)), ('bias', (c,)), ('running_mean', (c,)), ('running_var', (c,)), ('num_batches_tracked', ())):
+            shp['%s.%s' % (name, sfx)] = v
+    conv('conv_block1.conv_block.0', ngf, 3, 9)
+    shp['conv_block1.conv_block.1.weight'] = (1,)
+    for i in range(n_blocks):
+        inner = ngf if filter_cfgs is None else int(filter_cfgs[i])
+        p = 'residual_blocks.%d.' % i
+        conv(p + 'conv_block1.conv_block.0', inner, ngf, 3)
+        bn(p + 'conv_block1.conv_block.1', inner)
+        shp[p + 'conv_block1.conv_block.2.weight'] = (1,)
+        conv(p + 'conv_block2.conv_block.0', ngf, inner, 3)
+        bn(p + 'conv_block2.conv_block.1', ngf)
+    conv('conv_block2.conv_block.0', ngf, ngf, 3)
+    bn('conv_block2.conv_block.1', ngf)
+    for j in range(2):
+        conv('subpixel_convolutional_blocks.%d.conv' % j, 4 * ngf, ngf, 3)
+        shp['subpixel_convolutional_blocks.%d.prelu.weight' % j] = (1,)
+    conv('conv_block3.conv_block.0', 3, ngf, 9)
+    return shp
+
+
+def sr_discriminator_shapes(ndf: int = 64, masked: bool = False, n_blocks: int = 4):
+    shp: Dict[str, Tuple[int, ...]] = OrderedDict()
+    cin = 3
+    for i in range(n_blocks):
+        co = (ndf if i == 0 else cin * 2) if i % 2 == 0 else cin
+        p = 'conv_blocks.%d.conv_block.' % i
+        shp[p + '0.weight'] = (co, cin, 3, 3)
+        shp[p + '0.bias'] = (co,)
+        j = 1
+        if i != 0:
+            for sfx, v in (('weight', (co,)), ('bias', (co,)), ('running_mean', (co,)), ('running_var', (co,)), ('num_batches_tracked', ())):
+                shp['%s1.%s' % (p, sfx)] = v
+            j = 2
+        if masked:
+            shp['%s%d.alpha' % (p, j)] = (co,)
+        cin = co
+    shp['fc1.weight'] = (1, cin)
+    shp['fc1.bias'] = (1,)
+    return shp
+
+
+def vgg_shapes(widths=VGG19_CFG):
+    shp: Dict[str, Tuple[int, ...]] = OrderedDict()
+    cin, idx = 3, 0
+    for c in widths:
+        if c != 'M':
+            shp['truncated_vgg19.%d.weight' % idx] = (c, cin, 3, 3)
+            shp['truncated_vgg19.%d.bias' % idx] = (c,)
+            cin = c
+            idx += 1
+        idx += 1
+    return shp
+
+
+class SRGANOracle:
+    """SRGAN model class reduced to its arithmetic (models/SRGAN.py:299-481).  Generator first, then discriminator;
+    vanilla (BCE-with-logits) GAN loss; after backward_G the model's real_hr / fake_hr ARE the ImageNet-normalised
+    tensors (:449-450), so the discriminator trains on those.  Under distillation the optimizer is built from
+    Conv / BatchNorm / Linear modules only: the PReLU slopes are left out and stay frozen (hazard H5)."""
+
+    def __init__(self, opt: Opt, G: SD, D: SD, V: SD, T: Optional[List[Tensor]] = None, masked: bool = False,
+                 teacher: Optional['SRGANOracle'] = None, vgg_cfg=VGG19_CFG):
+        self.opt, self.G, self.D, self.V, self.T = opt, G, D, V, (T or [])
+        self.masked, self.teacher, self.vgg_cfg = masked, teacher, vgg_cfg
+        self.g_feats, self.d_feats = OrderedDict(), OrderedDict()
+        self.train = True
+        self.cur_diff = 0.0
+        self.losses: Dict[str, float] = {}
+        self.lr_G = self.lr_D = opt.lr
+        self.lr_arch = opt.arch_lr
+        is_prelu = lambda k: G[k].shape == (1,) and k.endswith('.weight')
+        self.G_keys = [k for k in G if _is_float_param(k) and not (self.T and is_prelu(k))]
+        self.D_w_keys = [k for k in D if k.endswith('.weight') or k.endswith('.bias')]
+        self.D_a_keys = [k for k in D if k.endswith('.alpha')]
+        self.st_G, self.st_D, self.st_A = {}, {}, {}
+
+    def netG(self, x):
+        return srresnet_forward(self.G, x, self.train, features=self.g_feats)
+
+    def netD(self, x):
+        return sr_discriminator_forward(self.D, x, self.masked, self.opt.threshold, self.train, features=self.d_feats)
+
+    def set_input(self, lr_img, hr_img):
+        self.real_lr, self.real_hr = lr_img, hr_img
+        self.in_lr, self.in_hr = lr_img, hr_img
+
+    def forward(self):
+        self.fake_hr = self.netG(self.real_lr)
+
+    def features(self):
+        return list(self.g_feats.values()) + list(self.d_feats.values())
+
+    def _req(self, sd, keys, flag):
+        for k in keys:
+            sd[k].requires_grad_(flag)
+            if flag:
+                sd[k].grad = None
+
+    def optimize_parameters(self):
+        o, T = self.opt, self.teacher
+        if T is not None:
+            T.set_input(self.in_lr, self.in_hr)
+            T.optimize_parameters()
+            self.targets = [f.detach().clone() for f in T.features()]
+        self._req(self.G, self.G_keys, True)
+        for t in self.T:
+            t.requires_grad_(True)
+            t.grad = None
+        self.forward()
+        # ---- generator (:446-480)
+        self._req(self.D, self.D_w_keys + self.D_a_keys, False)
+        l_content = F.mse_loss(self.fake_hr, self.real_hr) * o.lambda_SR_content
+        real_n, fake_n = to_imagenet_norm(self.real_hr), to_imagenet_norm(self.fake_hr)
+        l_gan = gan_loss(o.gan_mode, self.netD(fake_n), True, True) * o.lambda_SR_adversarial
+        l_perc = F.mse_loss(vgg_features(self.V, fake_n, self.vgg_cfg), vgg_features(self.V, real_n, self.vgg_cfg).detach()) * o.lambda_SR_perceptual
+        loss_G = l_content + l_gan + l_perc
+        self.losses.update(G_GAN=float(l_gan.detach()), content=float(l_content.detach()), perceptual=float(l_perc.detach()))
+        if T is not None:
+            feats = list(self.g_feats.values())
+            T.netD(fake_n)
+            feats = feats + list(T.d_feats.values())
+            l_gram = l_c = 0.0
+            for i, f in enumerate(feats):
+                if i < 4:
+                    f = F.conv2d(f, self.T[i])
+                t = self.targets[i]
+                l_gram = l_gram + rmse(gram(f), gram(t))
+                l_c = l_c + rmse(f, t)
+            l_gram, l_c = o.lambda_gram * l_gram, o.lambda_content * l_c
+            l_l1 = o.lambda_L1 * F.l1_loss(fake_n, T.fake_hr.detach())       # both already ImageNet-normalised
+            loss_G = loss_G + l_gram + l_c + l_l1
+            self.losses.update(gram=float(l_gram.detach()), content=float(l_c.detach()), L1=float(l_l1.detach()))
+        loss_G.backward()
+        params = [self.G[k] for k in self.G_keys] + list(self.T)
+        adam_step(params, [p.grad for p in params], self.st_G, self.lr_G, (0.9, 0.999))
+        self._req(self.G, self.G_keys, False)
+        for t in self.T:
+            t.requires_grad_(False)
+        self.real_hr, self.fake_hr = real_n.detach(), fake_n.detach()
+        # ---- discriminator (:378-388): on the normalised images, real first
+        self._req(self.D, self.D_w_keys, True)
+        l_real = gan_loss(o.gan_mode, self.netD(self.real_hr), True, True)
+        l_fake = gan_loss(o.gan_mode, self.netD(self.fake_hr), False, True)
+        (l_real + l_fake).backward()
+        adam_step([self.D[k] for k in self.D_w_keys], [self.D[k].grad for k in self.D_w_keys], self.st_D, self.lr_D, (0.9, 0.999))
+        self._req(self.D, self.D_w_keys, False)
+        self.losses.update(D_real=float(l_real.detach()), D_fake=float(l_fake.detach()))
+
+    def get_D_arch_diff(self, is_teacher):
+        o = self.opt
+        self.real_hr, self.fake_hr = to_imagenet_norm(self.real_hr), to_imagenet_norm(self.fake_hr)
+        pf = self.netD(self.fake_hr.detach())
+        self.arch_fake = gan_loss(o.gan_mode, pf, False, True)
+        fake_real = gan_loss(o.gan_mode, pf, True, False)
+        self.arch_real = gan_loss(o.gan_mode, self.netD(self.real_hr), True, True)
+        cur = (fake_real - self.arch_fake).abs()
+        if is_teacher and float(self.cur_diff) != 0.0:
+            cur = o.ema_beta * cur + (1.0 - o.ema_beta) * self.cur_diff
+        self.cur_diff = cur
+        return cur
+
+    def clipping_mask_alpha(self):
+        with torch.no_grad():
+            for k in self.D_a_keys:
+                self.D[k].clamp_(0, 1)
+
+    def optimizer_netD_arch(self):
+        T = self.teacher
+        with torch.no_grad():
+            self.forward()
+            T.set_input(self.in_lr, self.in_hr)
+            T.forward()
+            t_diff = T.get_D_arch_diff(True)
+        self._req(self.D, self.D_w_keys, False)
+        self._req(self.D, self.D_a_keys, True)
+        s_diff = self.get_D_arch_diff(False)
+        loss = (s_diff - t_diff).abs() + self.arch_real + self.arch_fake
         loss.backward()
         adam_step([self.D[k] for k in self.D_a_keys], [self.D[k].grad for k in self.D_a_keys], self.st_A, self.lr_arch,
                   (0.9, 0.999))

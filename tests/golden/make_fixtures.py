@@ -27,6 +27,7 @@ Fixtures
   cyclegan_pretrain.npz CycleGAN without teacher, --lambda_weight (heavy-layer L1 sparsity), 1 iteration; ImagePool(3) sequence
   prune_resnet.npz      resnet_prune / CycleGAN get_prunenet_cfg cfgs + max_min_conv_norm; pruned MobileResnet (one with a block removed): eval + 1 iteration
   sagan_gcc.npz         SAGAN student + online teacher (spectral norm, self attention, duplicated optimizer entries): eval image, 2 x (iteration + arch step)
+  srgan_gcc.npz         SRGAN student + online teacher (SRResNet, avg-pool discriminator, VGG stand-in): eval image, 2 x (iteration + arch step)
   prune_search_d8.npz   binarysearch_threshold trajectory end points with a documented thop stand-in
   prune_d8.npz          scale_prune / norm_prune cfgs + max_min_* at several thresholds (ngf 8)
 """
@@ -41,7 +42,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from recipe import recipe_state_dict, recipe_transform, sample_idx  # noqa: E402
+from recipe import recipe_state_dict, recipe_transform, sample_idx, srgan_condition  # noqa: E402
 REF = '/root/reference'
 
 
@@ -715,6 +716,104 @@ def fixture_sagan():
     print('  G keys', list(out['G_keys'])[:14], '\n  D keys', list(out['D_keys']), '\n  dup G', list(out['dup_G']), '\n  dup D', list(out['dup_D']))
 
 
+VGG_STANDIN = (8, 8, 'M', 16, 16, 'M', 32, 32, 32, 32, 'M', 64, 64, 64, 64, 'M', 64, 64, 64, 64, 'M')
+
+
+def vgg19_standin(pretrained=True):
+    """torchvision is not in the image: an nn.Module with the layer sequence of torchvision's vgg19().features (conv3 +
+    ReLU(inplace) ... MaxPool2d(2, 2), 37 layers) at 1/8 of the widths and unset weights (the fixture loads recipe
+    weights).  The reference's TruncatedVGG19 only iterates ``vgg.features.children()``."""
+    import torch.nn as nn
+    layers, cin = [], 3
+    for c in VGG_STANDIN:
+        if c == 'M':
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, c, 3, padding=1), nn.ReLU(inplace=True)]
+            cin = c
+    m = nn.Module()
+    m.features = nn.Sequential(*layers)
+    return m
+
+
+def fixture_srgan():
+    """SRGAN student (ngf 8, masked D ndf 8) + online teacher (ngf 16, ndf 16), 12x12 -> 48x48, N=2, VGG stand-in,
+    recipe weights 901..: eval image, two iterations of optimize_parameters + arch step.  The reference's parser does
+    not declare --generator_only although parse() reads it (SURVEY.md hazard H7): the script adds the flag."""
+    import torchvision.models.vgg as tvgg
+    tvgg.vgg19 = vgg19_standin
+    if 'PIL' not in sys.modules:
+        try:
+            import PIL  # noqa: F401
+        except ImportError:
+            _stub('PIL', Image=None)
+    from options import options as ref_options
+    if not any('--generator_only' in a.option_strings for a in ref_options.parser._actions):
+        ref_options.parser.add_argument('--generator_only', action='store_true')
+    import models.GANLoss as ref_ganloss
+    ref_ganloss.vgg19 = vgg19_standin
+    opt = parse(['--dataroot', './database/sr/', '--model', 'srgan', '--gpu_ids', '-1', '--ngf', '8', '--ndf', '8',
+                 '--teacher_ngf', '16', '--online_distillation', '--darts_discriminator', '--lambda_content', '1',
+                 '--lambda_gram', '1', '--lambda_L1', '0.5', '--lambda_SR_content', '0.5', '--arch_lr', '1e-4'])
+    opt.teacher_ndf = 16
+    model, teacher = build_gcc(opt)
+    for n, sd in ((model.netG, 901), (model.netD, 902), (teacher.netG, 903), (teacher.netD, 904),
+                  (model.truncated_vgg19, 905)):
+        load_recipe(n, sd)
+    for n in (model.netG, model.netD, teacher.netG, teacher.netD):
+        srgan_condition(n.state_dict())
+    srgan_condition({'truncated_vgg19.' + k if not k.startswith('truncated_vgg19.') else k: v
+                     for k, v in model.truncated_vgg19.state_dict().items()})
+    teacher.truncated_vgg19.load_state_dict(model.truncated_vgg19.state_dict())
+    with torch.no_grad():
+        for i, t in enumerate(model.transform_convs):
+            t.weight.copy_(recipe_transform(t.weight.shape[0], t.weight.shape[1], 910 + i))
+        model.netD.conv_blocks[0].conv_block[1].alpha[0] = 0.3
+        model.netD.conv_blocks[2].conv_block[2].alpha[1] = 0.5
+    out = {'G_keys': np.array(list(model.netG.state_dict().keys())), 'D_keys': np.array(list(model.netD.state_dict().keys())),
+           'TD_keys': np.array(list(teacher.netD.state_dict().keys())),
+           'V_keys': np.array(list(model.truncated_vgg19.state_dict().keys())),
+           'gan_mode': np.array(opt.gan_mode), 'lr': np.array(opt.lr), 'threshold': np.array(opt.threshold),
+           'loss_names': np.array(model.loss_names),
+           'G_optimizer_names': np.array([k for k, p in model.netG.named_parameters()
+                                          if any(p is q for q in model.optimizer_G.param_groups[0]['params'])])}
+    g = torch.Generator().manual_seed(91)
+    lr0 = torch.rand(2, 3, 12, 12, generator=g) * 2 - 1
+    model.model_eval()
+    model.set_input({'lr': lr0, 'hr': torch.zeros(2, 3, 48, 48), 'lr_names': ['a'] * 2, 'hr_names': ['b'] * 2})
+    with torch.no_grad():
+        model.forward()
+    out['eval.lr'], out['eval.fake_hr'] = lr0.numpy(), model.fake_hr.numpy().copy()
+    model.model_train()
+    for it in range(2):
+        lr_, vlr = (torch.rand(2, 3, 12, 12, generator=g) * 2 - 1 for _ in range(2))
+        hr_, vhr = (torch.rand(2, 3, 48, 48, generator=g) * 2 - 1 for _ in range(2))
+        for n, t in (('lr', lr_), ('hr', hr_), ('vlr', vlr), ('vhr', vhr)):
+            out['it%d.%s' % (it, n)] = t.numpy()
+        model.set_input({'lr': lr_, 'hr': hr_, 'lr_names': ['a'] * 2, 'hr_names': ['b'] * 2})
+        model.optimize_parameters()
+        if it == 0:
+            out['it0.fake_hr_norm'] = model.fake_hr.detach().numpy().copy()       # ImageNet-normalised by backward_G
+            for j, f in enumerate(model.target_distillation_features):
+                out['it0.target.%d' % j] = f.detach().numpy().copy()
+            for j, f in enumerate(model.get_distillation_features()[:4]):
+                out['it0.sfeat.%d' % j] = f.detach().numpy().copy()
+        model.set_input({'lr': vlr, 'hr': vhr, 'lr_names': ['a'] * 2, 'hr_names': ['b'] * 2})
+        model.clipping_mask_alpha()
+        model.optimizer_netD_arch()
+        for k, v in model.get_current_losses().items():
+            out['it%d.loss.%s' % (it, k)] = np.array(v, dtype=np.float64)
+        for k, v in teacher.get_current_losses().items():
+            out['it%d.tloss.%s' % (it, k)] = np.array(v, dtype=np.float64)
+    for tag, net in (('sG', model.netG), ('sD', model.netD), ('tG', teacher.netG), ('tD', teacher.netD)):
+        sd_np_sampled('final.%s.' % tag, net.state_dict(), out)
+    for i, t in enumerate(model.transform_convs):
+        out['final.T.%d' % i] = t.weight.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'srgan_gcc.npz'), **out)
+    print('srgan_gcc ok', {k: round(float(v), 4) for k, v in out.items() if k.startswith('it1.loss.')})
+    print('  loss names', list(out['loss_names']), len(out['G_optimizer_names']), len(out['G_keys']))
+
+
 def fixture_options():
     import json
     from options import options
@@ -741,6 +840,6 @@ if __name__ == '__main__':
     only = sys.argv[1:]            # e.g. "make_fixtures.py cyclegan cyclegan_pretrain"; none = all
     import_reference()
     for fn in (fixture_options, fixture_ops, fixture_eval_d8, fixture_gcc_d6, fixture_pretrain_d6, fixture_prune_d8,
-               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan):
+               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan, fixture_srgan):
         if not only or fn.__name__[len('fixture_'):] in only:
             fn()

@@ -33,6 +33,23 @@ def recipe_state_dict(shapes, seed):
     return sd
 
 
+def srgan_condition(sd):
+    """In-place re-scaling of recipe values for the SRGAN nets (a name -> tensor mapping, e.g. a state_dict): the
+    un-normalised VGG stack gets He-scaled conv weights (N(0, .02) through 16 plain convs underflows to zero features),
+    the discriminator's Linear head N(0, .1) instead of the BatchNorm rule's ~1, and the PReLU slopes distinct positive
+    values in [0.1, 0.4) (the HIP path differentiates activations on their output, which needs a positive slope)."""
+    i = 0
+    with torch.no_grad():
+        for k, v in sd.items():
+            if k.startswith('truncated_vgg19.') and v.dim() == 4:
+                v.mul_((2.0 / (v.shape[1] * 9)) ** 0.5 / 0.02)
+            elif k == 'fc1.weight':
+                v.sub_(1.0).mul_(5.0)
+            elif tuple(v.shape) == (1,) and k.endswith('.weight'):
+                v.fill_(0.1 + 0.3 * ((i * 0.37) % 1.0))
+                i += 1
+
+
 def recipe_transform(cout, cin, seed):
     g = torch.Generator().manual_seed(seed)
     return (torch.rand((cout, cin, 1, 1), generator=g) * 2 - 1) / (cin ** 0.5)
