@@ -106,7 +106,12 @@ PROTOTYPES = {
     'gcc_attention_fwd': (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P]),
     'gcc_attention_bwd': (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
     'gcc_l1_loss': (_I, [_P, _I, _I, _P, _I, _I, _I, _Z, _F, _P, _I, _P, _I, _I, _P, _Z, _P]),
+    'gcc_mse_loss': (_I, [_P, _I, _I, _P, _I, _I, _I, _Z, _F, _P, _I, _P, _I, _I, _P, _Z, _P]),
     'gcc_loss_workspace': (_Z, [_Z, _I]),
+    'gcc_prelu': (_I, [_I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P]),
+    'gcc_maxpool2x2': (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    'gcc_pool_linear_fwd': (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
+    'gcc_pool_linear_bwd': (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P]),
     'gcc_distill_workspace': (_Z, [_I, _I, _I]),
     'gcc_distill_fwd': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
     'gcc_distill_bwd': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _I, _I, _P, _Z, _P]),

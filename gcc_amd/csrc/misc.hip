@@ -186,7 +186,7 @@ __global__ __launch_bounds__(1024) void gan_loss_kernel(int mode, int real, int 
 // stage 1 of L1 / squared-difference reductions over C channels of NHWC tensors
 struct DiffArgs {
     const bf16_t* a; int lda, aoff; const bf16_t* b; int ldb, boff; int C, CH; size_t pixels;
-    float* partial; bf16_t* da; int ldda, daoff; float gscale; int mode;   // mode 0: |a-b| ; 1: (a-b)^2
+    float* partial; bf16_t* da; int ldda, daoff; float gscale; int mode;   // mode 0: |a-b| ; 1, 2: (a-b)^2 (2: with gradient)
 };
 __global__ __launch_bounds__(256) void diff_reduce_kernel(const DiffArgs g) {
     __shared__ float sh[4];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void diff_reduce_kernel(const DiffArgs g) {
         for (int j = 0; j < 8; j++) {
             const float d = (c0 + j < g.C) ? av[j] - bv[j] : 0.f;
             if (g.mode == 0) { acc += fabsf(d); dv[j] = d > 0.f ? g.gscale : (d < 0.f ? -g.gscale : 0.f); }
-            else { acc += d * d; dv[j] = 0.f; }
+            else { acc += d * d; dv[j] = g.gscale * d; }            // mode 2: gscale = 2 * weight / count
         }
         if (g.da) *(i32x4*)(g.da + pix * g.ldda + g.daoff + c0) = pack8(dv);
     }
@@ -451,6 +451,30 @@ extern "C" int gcc_l1_loss(const void* a, int lda, int aoff, const void* b, int 
     g.da = (bf16_t*)da; g.ldda = ldda; g.daoff = daoff;
     const double count = (double)pixels * C;
     g.gscale = (float)(weight / count); g.mode = 0;
+    const int blocks = grid_for(pixels * g.CH, 256 * 4, RED_BLOCKS);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(diff_reduce_kernel, dim3(blocks), dim3(256), 0, st, g);
+    GCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, blocks, count, weight, loss,
+                       accumulate, 0);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+// nn.MSELoss: weight * mean((a-b)^2) ; da = weight * 2 (a-b) / count
+extern "C" int gcc_mse_loss(const void* a, int lda, int aoff, const void* b, int ldb, int boff, int C, size_t pixels,
+                           float weight, float* loss, int accumulate, void* da, int ldda, int daoff, void* ws,
+                           size_t ws_bytes, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!a || !b || !loss || !ws || C <= 0 || pixels == 0) return GCC_ERR_BAD_ARG;
+    if ((lda | aoff | ldb | boff) & 7 || (da && ((ldda | daoff) & 7))) return GCC_ERR_BAD_ARG;
+    if (ws_bytes < RED_BLOCKS * sizeof(float)) return GCC_ERR_WORKSPACE;
+    DiffArgs g;
+    g.a = (const bf16_t*)a; g.lda = lda; g.aoff = aoff; g.b = (const bf16_t*)b; g.ldb = ldb; g.boff = boff;
+    g.C = C; g.CH = (C + 7) / 8; g.pixels = pixels; g.partial = (float*)ws;
+    g.da = (bf16_t*)da; g.ldda = ldda; g.daoff = daoff;
+    const double count = (double)pixels * C;
+    g.gscale = (float)(2.0 * weight / count); g.mode = 2;
     const int blocks = grid_for(pixels * g.CH, 256 * 4, RED_BLOCKS);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(diff_reduce_kernel, dim3(blocks), dim3(256), 0, st, g);

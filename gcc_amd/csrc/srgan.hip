@@ -1,0 +1,264 @@
+// SRGAN-specific streaming kernels (reference models/SRGAN.py, models/GANLoss.py:95-145): PReLU with a learnable scalar
+// slope (optionally fused with PixelShuffle(2)), 2x2 max pooling of the VGG stack, global average pool + Linear head of
+// the discriminator.  All HBM-bound, NHWC bf16, 16-byte accesses.
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ---- PReLU (+ PixelShuffle(2)) -------------------------------------------------------------------
+// r == 1: y[p][c] = prelu(x[p][c]).
+// r == 2: x is [N][H][W][4C] (conv output), y is [N][2H][2W][C]:  y[n][2h+i][2w+j][c] = prelu(x[n][h][w][4c + 2i + j])
+//         (nn.PixelShuffle(2) then nn.PReLU(): the slope is one scalar, so the order does not matter).
+// One thread handles 8 output channels of one input pixel (for r == 2: 32 input channels -> 4 output pixels).
+struct PreluArgs {
+    const bf16_t* x; int ldx; bf16_t* y; int ldy; const float* slope; int C; int N, H, W, r;
+    const bf16_t* dy; int lddy; bf16_t* dx; int lddx; float* dslope;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void prelu_kernel(const PreluArgs a) {
+    __shared__ float sh[4];
+    const float s = a.slope[0];
+    const int CH = (a.C + 7) / 8;
+    const size_t pixels = (size_t)a.N * a.H * a.W;
+    const size_t total = pixels * CH;
+    float ds = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t pix = i / CH;
+        const int c0 = (int)(i - pix * CH) * 8;
+        if (a.r == 1) {
+            float xv[8], ov[8];
+            unpack8(*(const i32x4*)(a.x + pix * a.ldx + c0), xv);
+            if (!BWD) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) ov[j] = (c0 + j < a.C) ? (xv[j] > 0.f ? xv[j] : s * xv[j]) : 0.f;
+                *(i32x4*)(a.y + pix * a.ldy + c0) = pack8(ov);
+            } else {
+                float gv[8];
+                unpack8(*(const i32x4*)(a.dy + pix * a.lddy + c0), gv);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const bool live = c0 + j < a.C;
+                    ov[j] = live ? (xv[j] > 0.f ? gv[j] : s * gv[j]) : 0.f;
+                    if (live && xv[j] <= 0.f) ds += gv[j] * xv[j];
+                }
+                *(i32x4*)(a.dx + pix * a.lddx + c0) = pack8(ov);
+            }
+        } else {
+            const int w = (int)(pix % a.W);
+            const size_t nh = pix / a.W;
+            const int h = (int)(nh % a.H);
+            const size_t n = nh / a.H;
+            // 32 input channels 4*c0 .. 4*c0+31
+            float xv[32];
+#pragma unroll
+            for (int q = 0; q < 4; q++) unpack8(*(const i32x4*)(a.x + pix * a.ldx + 4 * c0 + 8 * q), xv + 8 * q);
+            float dxv[32];
+#pragma unroll
+            for (int sp = 0; sp < 4; sp++) {            // sub-pixel (i, j) = (sp >> 1, sp & 1)
+                const size_t opix = (n * (2 * a.H) + 2 * h + (sp >> 1)) * (size_t)(2 * a.W) + 2 * w + (sp & 1);
+                if (!BWD) {
+                    float ov[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const float v = xv[4 * j + sp];
+                        ov[j] = (c0 + j < a.C) ? (v > 0.f ? v : s * v) : 0.f;
+                    }
+                    *(i32x4*)(a.y + opix * a.ldy + c0) = pack8(ov);
+                } else {
+                    float gv[8];
+                    unpack8(*(const i32x4*)(a.dy + opix * a.lddy + c0), gv);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const float v = xv[4 * j + sp];
+                        const bool live = c0 + j < a.C;
+                        dxv[4 * j + sp] = live ? (v > 0.f ? gv[j] : s * gv[j]) : 0.f;
+                        if (live && v <= 0.f) ds += gv[j] * v;
+                    }
+                }
+            }
+            if (BWD) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) *(i32x4*)(a.dx + pix * a.lddx + 4 * c0 + 8 * q) = pack8(dxv + 8 * q);
+            }
+        }
+    }
+    if (BWD && a.dslope) {
+        const float t = block_sum256(ds, sh);
+        if (threadIdx.x == 0) atomicAdd(a.dslope, t);
+    }
+}
+
+// ---- MaxPool2d(2, 2) ------------------------------------------------------------------------------
+// backward routes dy to the first maximum of the window in (h, w) scan order, as ATen's max_pool2d_with_indices does
+template <bool BWD>
+__global__ __launch_bounds__(256) void maxpool_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
+                                                      const bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict__ dx, int lddx,
+                                                      int N, int Ho, int Wo, int C) {
+    const int CH = (C + 7) / 8;
+    const size_t total = (size_t)N * Ho * Wo * CH;
+    const int Hi = 2 * Ho, Wi = 2 * Wo;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t opix = i / CH;
+        const int c0 = (int)(i - opix * CH) * 8;
+        const int wo = (int)(opix % Wo);
+        const size_t t = opix / Wo;
+        const int ho = (int)(t % Ho);
+        const size_t n = t / Ho;
+        float v[4][8];
+        size_t ip[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            ip[q] = (n * Hi + 2 * ho + (q >> 1)) * (size_t)Wi + 2 * wo + (q & 1);
+            unpack8(*(const i32x4*)(x + ip[q] * ldx + c0), v[q]);
+        }
+        if (!BWD) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = fmaxf(fmaxf(v[0][j], v[1][j]), fmaxf(v[2][j], v[3][j]));
+            *(i32x4*)(y + opix * ldy + c0) = pack8(o);
+        } else {
+            float g[8], o[4][8];
+            unpack8(*(const i32x4*)(dy + opix * lddy + c0), g);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                int best = 0;
+#pragma unroll
+                for (int q = 1; q < 4; q++)
+                    if (v[q][j] > v[best][j]) best = q;
+#pragma unroll
+                for (int q = 0; q < 4; q++) o[q][j] = (q == best) ? g[j] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) *(i32x4*)(dx + ip[q] * lddx + c0) = pack8(o[q]);
+        }
+    }
+}
+
+// ---- AdaptiveAvgPool2d((1,1)) + Linear(C, 1) -------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_mean_kernel(const bf16_t* __restrict__ x, int ldx, int C, int HW, float* __restrict__ pooled) {
+    __shared__ float sh[4];
+    const int n = blockIdx.y, c = blockIdx.x;            // one channel per block (C <= a few hundred, HW <= 10^4)
+    float acc = 0.f;
+    for (int p = threadIdx.x; p < HW; p += 256) acc += bf2f(x[((size_t)n * HW + p) * ldx + c]);
+    const float t = block_sum256(acc, sh);
+    if (threadIdx.x == 0) pooled[(size_t)n * C + c] = t / (float)HW;
+}
+__global__ __launch_bounds__(256) void linear_head_kernel(const float* __restrict__ pooled, const float* __restrict__ w, const float* __restrict__ b,
+                                                          int C, bf16_t* __restrict__ logit, int ldl) {
+    __shared__ float sh[4];
+    const int n = blockIdx.x;
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) acc += pooled[(size_t)n * C + c] * w[c];
+    const float t = block_sum256(acc, sh);
+    if (threadIdx.x == 0) logit[(size_t)n * ldl] = f2bf(t + b[0]);
+}
+// dx[n][p][c] = dlogit[n] * w[c] / HW
+__global__ __launch_bounds__(256) void pool_head_bwd_kernel(const bf16_t* __restrict__ dlogit, int ldl, const float* __restrict__ w, int C, int HW,
+                                                            int N, bf16_t* __restrict__ dx, int lddx) {
+    const int CH = (C + 7) / 8;
+    const size_t total = (size_t)N * HW * CH;
+    const float inv = 1.f / (float)HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t pix = i / CH;
+        const int c0 = (int)(i - pix * CH) * 8;
+        const float g = bf2f(dlogit[(pix / HW) * ldl]) * inv;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = (c0 + j < C) ? g * w[c0 + j] : 0.f;
+        *(i32x4*)(dx + pix * lddx + c0) = pack8(o);
+    }
+}
+// dw[c] += sum_n dlogit[n] * pooled[n][c] ; db += sum_n dlogit[n]
+__global__ __launch_bounds__(256) void linear_head_wgrad_kernel(const bf16_t* __restrict__ dlogit, int ldl, const float* __restrict__ pooled, int N,
+                                                                int C, float* __restrict__ dw, float* __restrict__ db) {
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
+        float acc = 0.f;
+        for (int n = 0; n < N; n++) acc += bf2f(dlogit[(size_t)n * ldl]) * pooled[(size_t)n * C + c];
+        dw[c] += acc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && db) {
+        float acc = 0.f;
+        for (int n = 0; n < N; n++) acc += bf2f(dlogit[(size_t)n * ldl]);
+        db[0] += acc;
+    }
+}
+
+int grid_for(size_t items, int cap = 4096) {
+    size_t b = (items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" int gcc_prelu(int backward, const void* x, int ldx, const float* slope, int C, int N, int H, int W, int shuffle,
+                         void* y, int ldy, const void* dy, int lddy, void* dx, int lddx, float* dslope, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!x || !slope || C <= 0 || N <= 0 || H <= 0 || W <= 0 || (shuffle != 1 && shuffle != 2)) return GCC_ERR_BAD_ARG;
+    if (backward ? (!dy || !dx) : !y) return GCC_ERR_BAD_ARG;
+    if ((ldx & 7) || (!backward && (ldy & 7)) || (backward && ((lddy | lddx) & 7))) return GCC_ERR_BAD_ARG;
+    if (shuffle == 2 && (C & 7)) return GCC_ERR_UNSUPPORTED;          // 4C input channels are read as whole 32-channel groups
+    PreluArgs a;
+    a.x = (const bf16_t*)x; a.ldx = ldx; a.y = (bf16_t*)y; a.ldy = ldy; a.slope = slope; a.C = C; a.N = N; a.H = H; a.W = W;
+    a.r = shuffle; a.dy = (const bf16_t*)dy; a.lddy = lddy; a.dx = (bf16_t*)dx; a.lddx = lddx; a.dslope = dslope;
+    const size_t items = (size_t)N * H * W * ((C + 7) / 8);
+    if (backward) hipLaunchKernelGGL(prelu_kernel<true>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(prelu_kernel<false>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, a);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+extern "C" int gcc_maxpool2x2(int backward, const void* x, int ldx, void* y, int ldy, const void* dy, int lddy, void* dx,
+                              int lddx, int N, int Ho, int Wo, int C, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!x || N <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (ldx & 7)) return GCC_ERR_BAD_ARG;
+    if (backward ? (!dy || !dx || ((lddy | lddx) & 7)) : (!y || (ldy & 7))) return GCC_ERR_BAD_ARG;
+    const size_t items = (size_t)N * Ho * Wo * ((C + 7) / 8);
+    if (backward)
+        hipLaunchKernelGGL(maxpool_kernel<true>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                           (bf16_t*)nullptr, 0, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, N, Ho, Wo, C);
+    else
+        hipLaunchKernelGGL(maxpool_kernel<false>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                           (bf16_t*)y, ldy, (const bf16_t*)nullptr, 0, (bf16_t*)nullptr, 0, N, Ho, Wo, C);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+extern "C" int gcc_pool_linear_fwd(const void* x, int ldx, int N, int HW, int C, const float* w, const float* b, float* pooled,
+                                   void* logit, int ldl, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!x || !w || !b || !pooled || !logit || N <= 0 || HW <= 0 || C <= 0 || (ldx & 7)) return GCC_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pool_mean_kernel, dim3(C, N), dim3(256), 0, st, (const bf16_t*)x, ldx, C, HW, pooled);
+    GCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(linear_head_kernel, dim3(N), dim3(256), 0, st, (const float*)pooled, w, b, C, (bf16_t*)logit, ldl);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+extern "C" int gcc_pool_linear_bwd(const void* dlogit, int ldl, const float* w, const float* pooled, int N, int HW, int C,
+                                   void* dx, int lddx, float* dw, float* db, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!dlogit || !w || !pooled || N <= 0 || HW <= 0 || C <= 0) return GCC_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) {
+        if (lddx & 7) return GCC_ERR_BAD_ARG;
+        hipLaunchKernelGGL(pool_head_bwd_kernel, dim3(grid_for((size_t)N * HW * ((C + 7) / 8))), dim3(256), 0, st,
+                           (const bf16_t*)dlogit, ldl, w, C, HW, N, (bf16_t*)dx, lddx);
+        GCC_CHECK_LAUNCH();
+    }
+    if (dw) {
+        hipLaunchKernelGGL(linear_head_wgrad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const bf16_t*)dlogit, ldl, pooled, N,
+                           C, dw, db);
+        GCC_CHECK_LAUNCH();
+    }
+    return GCC_OK;
+}

@@ -1090,3 +1090,361 @@ class SaganDiscriminatorEngine:
                 self.sn[0].backward_data(c.sn[0], G.raw[0], G.x_in)
         ops.SideStream.get(self.device).join()
         return G.x_in if need_dx else None
+
+
+# ------------------------------------------------------------------------------------------------
+# SRGAN: SRResNet generator, avg-pool discriminator, truncated VGG19 (models/SRGAN.py, models/GANLoss.py:95-145)
+# ------------------------------------------------------------------------------------------------
+class SRResNetEngine:
+    """Generator (models/SRGAN.py:139-199): conv9 + PReLU | n x [conv3 BN PReLU conv3 BN, + x] | conv3 BN + long skip |
+    2 x [conv3 -> PixelShuffle(2) -> PReLU] | conv9 + tanh.  train_prelu False: the slopes receive no gradient (the
+    reference's distillation optimizer does not hold them)."""
+
+    def __init__(self, module, device, train_prelu=True):
+        self.module, self.device, self.train_prelu = module, device, train_prelu
+        cb = lambda m, i: getattr(m.conv_block, str(i))
+        c1 = module.conv_block1
+        self.first = ConvOp(cb(c1, 0).weight, cb(c1, 0).bias, 9, 1, 4, False)
+        self.first_slope = cb(c1, 1).weight
+        self.blocks = []
+        for blk in module.residual_blocks.children():
+            b1, b2 = blk.conv_block1, blk.conv_block2
+            self.blocks.append(type('SRBlock', (), dict(
+                conv1=ConvOp(cb(b1, 0).weight, cb(b1, 0).bias, 3, 1, 1, False), bn1=BNOp(cb(b1, 1)), slope=cb(b1, 2).weight,
+                conv2=ConvOp(cb(b2, 0).weight, cb(b2, 0).bias, 3, 1, 1, False), bn2=BNOp(cb(b2, 1))))())
+        c2 = module.conv_block2
+        self.mid = ConvOp(cb(c2, 0).weight, cb(c2, 0).bias, 3, 1, 1, False)
+        self.mid_bn = BNOp(cb(c2, 1))
+        self.sub = [(ConvOp(s.conv.weight, s.conv.bias, 3, 1, 1, False), s.prelu.weight)
+                    for s in module.subpixel_convolutional_blocks.children()]
+        c3 = module.conv_block3
+        self.last = ConvOp(cb(c3, 0).weight, cb(c3, 0).bias, 9, 1, 4, False)
+        self.C = self.first.rows
+        self.hook_blocks = (3, 7, 11, 15)
+        self.ctx, self.gbuf = {}, {}
+
+    def convs(self):
+        return [self.first, self.mid, self.last] + [c for b in self.blocks for c in (b.conv1, b.conv2)] + [c for c, _ in self.sub]
+
+    def repack(self):
+        if getattr(self, '_pack', None) is None:
+            self._pack = ops.PackPlan(self.convs(), self.device)
+        self._pack.run()
+
+    def _ctx(self, N, H, W, tag='main'):
+        key = (N, H, W, tag)
+        if key in self.ctx:
+            return self.ctx[key]
+        dev, C = self.device, self.C
+        new = lambda Cc, s=1: ops.new_act(N, Cc, H * s, W * s, dev)
+        c = type('SRCtx', (), {})()
+        c.N, c.H, c.W = N, H, W
+        c.x_in = new(3)
+        c.raw0, c.h0 = new(C), new(C)
+        c.blk = []
+        for b in self.blocks:
+            t = type('SRBlkCtx', (), {})()
+            ci = b.conv1.rows
+            t.r1, t.z1, t.a1, t.r2, t.out = new(ci), new(ci), new(ci), new(C), new(C)
+            t.st1, t.st2 = ops.BNState(ci, dev), ops.BNState(C, dev)
+            c.blk.append(t)
+        c.rm, c.hm, c.st_m = new(C), new(C), ops.BNState(C, dev)
+        c.s_raw = [new(4 * C, 1), new(4 * C, 2)]
+        c.s_act = [new(C, 2), new(C, 4)]
+        c.out = new(3, 4)
+        c.g_out = new(3, 4)
+        c.train = True
+        self.ctx[key] = c
+        return c
+
+    def _gbufs(self, N, H, W):
+        key = (N, H, W)
+        if key not in self.gbuf:
+            dev, C = self.device, self.C
+            new = lambda Cc, s=1: ops.new_act(N, Cc, H * s, W * s, dev)
+            g = type('SRGrad', (), {})()
+            g.s_act = [new(C, 2), new(C, 4)]
+            g.s_raw = [new(4 * C, 1), new(4 * C, 2)]
+            g.hm, g.rm, g.h, g.tmp, g.h0, g.raw0 = new(C), new(C), new(C), new(C), new(C), new(C)
+            g.blk = [(new(C), new(b.conv1.rows), new(b.conv1.rows), new(b.conv1.rows)) for b in self.blocks]
+            self.gbuf[key] = g
+        return self.gbuf[key]
+
+    def features(self, c):
+        return [c.blk[i].out for i in self.hook_blocks if i < len(c.blk)]
+
+    def forward(self, c, train=True):
+        """low-resolution image already in c.x_in; returns c (c.out = tanh image at 4x)"""
+        c.train = train
+        N, hw = c.N, c.H * c.W
+        self.first.forward(c.x_in, c.raw0)
+        ops.prelu_fwd(c.raw0, self.first_slope.data, c.h0)
+        h = c.h0
+        for b, t in zip(self.blocks, c.blk):
+            _, st = b.conv1.forward(h, t.r1, want_stats=True)
+            b.bn1.finalize(st, N * hw, t.st1, train)
+            ops.bnact_fwd(t.r1, t.z1, scale=t.st1.scale, shift=t.st1.shift)
+            ops.prelu_fwd(t.z1, b.slope.data, t.a1)
+            _, st = b.conv2.forward(t.a1, t.r2, want_stats=True)
+            b.bn2.finalize(st, N * hw, t.st2, train)
+            ops.bnact_fwd(t.r2, t.out, scale=t.st2.scale, shift=t.st2.shift, residual=h)
+            h = t.out
+        _, st = self.mid.forward(h, c.rm, want_stats=True)
+        self.mid_bn.finalize(st, N * hw, c.st_m, train)
+        ops.bnact_fwd(c.rm, c.hm, scale=c.st_m.scale, shift=c.st_m.shift, residual=c.h0)
+        h = c.hm
+        for j, (conv, slope) in enumerate(self.sub):
+            conv.forward(h, c.s_raw[j])
+            ops.prelu_fwd(c.s_raw[j], slope.data, c.s_act[j], shuffle=2)
+            h = c.s_act[j]
+        self.last.forward(h, c.out, act=ACT_TANH)
+        return c
+
+    def backward(self, c, g_feat=None, wgrad=True):
+        """c.g_out holds dL/d(image); g_feat: optional gradients w.r.t. features(c)"""
+        G = self._gbufs(c.N, c.H, c.W)
+        gf = dict(zip(self.hook_blocks, g_feat)) if g_feat is not None else {}
+        ds = lambda p: p.grad if (wgrad and self.train_prelu) else None
+        ops.bnact_bwd(c.out, None, c.g_out, c.g_out, in_act=ACT_TANH)
+        if wgrad:
+            self.last.backward_weight(c.s_act[1], c.g_out)
+        self.last.backward_data(c.g_out, G.s_act[1])
+        for j in (1, 0):
+            conv, slope = self.sub[j]
+            ops.prelu_bwd(c.s_raw[j], slope.data, G.s_act[j], G.s_raw[j], dslope=ds(slope), shuffle=2)
+            src = c.s_act[0] if j == 1 else c.hm
+            if wgrad:
+                conv.backward_weight(src, G.s_raw[j])
+            conv.backward_data(G.s_raw[j], G.s_act[0] if j == 1 else G.hm)
+        # hm = BN(mid(h_last)) + h0
+        bn = self.mid_bn.bn
+        ops.nhwc_copy(G.hm, 0, G.h0, 0, self.C)                 # long skip: dL/dh0 starts with dL/dhm
+        ops.bnact_bwd(c.rm, None, G.hm, G.rm, bn=c.st_m, gamma=bn.weight.data, beta=bn.bias.data, bn_eval=not c.train,
+                      dgamma=bn.weight.grad if wgrad else None, dbeta=bn.bias.grad if wgrad else None)
+        h_last = c.blk[-1].out if self.blocks else c.h0
+        if wgrad:
+            self.mid.backward_weight(h_last, G.rm)
+        self.mid.backward_data(G.rm, G.h)
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            b, t = self.blocks[bi], c.blk[bi]
+            g_r2, g_a1, g_z1, g_r1 = G.blk[bi]
+            h_in = c.blk[bi - 1].out if bi > 0 else c.h0
+            if bi in gf and gf[bi] is not None:
+                ops.nhwc_add(gf[bi], 0, G.h, 0, self.C)
+            bn2, bn1 = b.bn2.bn, b.bn1.bn
+            ops.bnact_bwd(t.r2, None, G.h, g_r2, bn=t.st2, gamma=bn2.weight.data, beta=bn2.bias.data, bn_eval=not c.train,
+                          dgamma=bn2.weight.grad if wgrad else None, dbeta=bn2.bias.grad if wgrad else None)
+            if wgrad:
+                b.conv2.backward_weight(t.a1, g_r2)
+            b.conv2.backward_data(g_r2, g_a1)
+            ops.prelu_bwd(t.z1, b.slope.data, g_a1, g_z1, dslope=ds(b.slope))
+            ops.bnact_bwd(t.r1, None, g_z1, g_r1, bn=t.st1, gamma=bn1.weight.data, beta=bn1.bias.data, bn_eval=not c.train,
+                          dgamma=bn1.weight.grad if wgrad else None, dbeta=bn1.bias.grad if wgrad else None)
+            if wgrad:
+                b.conv1.backward_weight(h_in, g_r1)
+            b.conv1.backward_data(g_r1, G.tmp)
+            ops.nhwc_add(G.tmp, 0, G.h, 0, self.C)
+        ops.nhwc_add(G.h, 0, G.h0, 0, self.C)
+        ops.prelu_bwd(c.raw0, self.first_slope.data, G.h0, G.raw0, dslope=ds(self.first_slope))
+        if wgrad:
+            self.first.backward_weight(c.x_in, G.raw0)
+        ops.SideStream.get(self.device).join()
+
+
+class SRDiscriminatorEngine:
+    """Discriminator / MaskDiscriminator (models/SRGAN.py:201-297): conv3 blocks (stride 1, 2, 1, 2 ...) with BatchNorm
+    from the second on, [gate], LeakyReLU(0.2); global average pool; Linear(C, 1)"""
+
+    def __init__(self, module, masked, threshold, device):
+        self.module, self.masked, self.tau, self.device = module, masked, float(threshold), device
+        self.conv, self.bn, self.gate = [], [], []
+        for i, blk in enumerate(module.conv_blocks.children()):
+            layers = list(blk.conv_block.children())
+            self.conv.append(ConvOp(layers[0].weight, layers[0].bias, 3, 1 if i % 2 == 0 else 2, 1, False))
+            self.bn.append(BNOp(layers[1]) if isinstance(layers[1], nn.BatchNorm2d) else None)
+            gates = [m for m in layers if hasattr(m, 'alpha')]
+            self.gate.append(gates[0] if gates else None)
+        self.fc = module.fc1
+        self.L = len(self.conv)
+        self.chan = [c.rows for c in self.conv]
+        self.mask = [torch.ones(w, dtype=torch.float32, device=device) if g is not None else None
+                     for w, g in zip(self.chan, self.gate)]
+        self.hook_layers = (1, 3)
+        self.ctx, self.gbuf = {}, {}
+
+    def convs(self):
+        return self.conv
+
+    def repack(self):
+        if getattr(self, '_pack', None) is None:
+            self._pack = ops.PackPlan(self.conv, self.device)
+        self._pack.run()
+
+    def refresh_masks(self):
+        for i in range(self.L):
+            if self.gate[i] is not None:
+                ops.gate_mask(self.gate[i].alpha.data, self.tau, self.mask[i])
+
+    def _sizes(self, H, W):
+        out = []
+        for i in range(self.L):
+            if i % 2 == 1:
+                H, W = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+            out.append((H, W))
+        return out
+
+    def new_ctx(self, N, H, W, tag):
+        key = (N, H, W, tag)
+        if key in self.ctx:
+            return self.ctx[key]
+        dev = self.device
+        c = type('SRDCtx', (), {})()
+        c.N, c.H, c.W = N, H, W
+        c.hs = self._sizes(H, W)
+        c.x_in = ops.new_act(N, 3, H, W, dev)
+        c.raw = [ops.new_act(N, self.chan[i], *c.hs[i], dev) for i in range(self.L)]
+        c.act = [ops.new_act(N, self.chan[i], *c.hs[i], dev) for i in range(self.L)]
+        c.st = [ops.BNState(self.chan[i], dev) if self.bn[i] is not None else None for i in range(self.L)]
+        c.pooled = torch.zeros((N, self.chan[-1]), dtype=torch.float32, device=dev)
+        c.pred = ops.new_act(N, 1, 1, 1, dev)
+        c.train = True
+        self.ctx[key] = c
+        return c
+
+    def _gbufs(self, N, H, W):
+        key = (N, H, W)
+        if key not in self.gbuf:
+            dev = self.device
+            hs = self._sizes(H, W)
+            g = type('SRDGrad', (), {})()
+            g.pred = ops.new_act(N, 1, 1, 1, dev)
+            g.act = [ops.new_act(N, self.chan[i], *hs[i], dev) for i in range(self.L)]
+            g.raw = [ops.new_act(N, self.chan[i], *hs[i], dev) for i in range(self.L)]
+            g.x_in = ops.new_act(N, 3, H, W, dev)
+            self.gbuf[key] = g
+        return self.gbuf[key]
+
+    def features(self, c):
+        return [c.act[i] for i in self.hook_layers]
+
+    def grad_pred_buffer(self, c):
+        return self._gbufs(c.N, c.H, c.W).pred
+
+    def forward(self, c, train=True):
+        c.train = train
+        if self.masked:
+            self.refresh_masks()
+        src = c.x_in
+        for i in range(self.L):
+            if self.bn[i] is not None:
+                _, st = self.conv[i].forward(src, c.raw[i], want_stats=True)
+                self.bn[i].finalize(st, c.N * c.hs[i][0] * c.hs[i][1], c.st[i], train)
+                ops.bnact_fwd(c.raw[i], c.act[i], scale=c.st[i].scale, shift=c.st[i].shift, gate=self.mask[i], act=ACT_LRELU)
+            else:
+                self.conv[i].forward(src, c.raw[i])
+                ops.bnact_fwd(c.raw[i], c.act[i], gate=self.mask[i], act=ACT_LRELU)
+            src = c.act[i]
+        ops.pool_linear_fwd(src, self.fc.weight.data, self.fc.bias.data, c.pooled, c.pred)
+        return c.pred
+
+    def backward(self, c, has_pred_grad=True, g_feat=None, wgrad=True, agrad=False, need_dx=True):
+        G = self._gbufs(c.N, c.H, c.W)
+        g_feat = g_feat or [None, None]
+        feat_of = dict(zip(self.hook_layers, g_feat))
+        L = self.L
+        if has_pred_grad:
+            ops.pool_linear_bwd(G.pred, self.fc.weight.data, c.pooled, c.act[L - 1], dx=G.act[L - 1],
+                                dw=self.fc.weight.grad if wgrad else None, db=self.fc.bias.grad if wgrad else None)
+        for i in range(L - 1, -1, -1):
+            gf = feat_of.get(i)
+            if i == L - 1 and not has_pred_grad:
+                assert gf is not None, 'nothing to back-propagate'
+                ops.nhwc_copy(gf, 0, G.act[i], 0, self.chan[i])
+            elif gf is not None:
+                ops.nhwc_add(gf, 0, G.act[i], 0, self.chan[i])
+            gate = self.gate[i]
+            da = gate.alpha.grad if (agrad and gate is not None) else None
+            if self.bn[i] is not None:
+                bn = self.bn[i].bn
+                ops.bnact_bwd(c.raw[i], c.act[i], G.act[i], G.raw[i], bn=c.st[i], gamma=bn.weight.data, beta=bn.bias.data,
+                              bn_eval=not c.train, gate=self.mask[i], act=ACT_LRELU, dgamma=bn.weight.grad if wgrad else None,
+                              dbeta=bn.bias.grad if wgrad else None, dalpha=da)
+            else:
+                ops.bnact_bwd(c.raw[i], c.act[i], G.act[i], G.raw[i], gate=self.mask[i], act=ACT_LRELU, dalpha=da)
+            src = c.x_in if i == 0 else c.act[i - 1]
+            if wgrad:
+                self.conv[i].backward_weight(src, G.raw[i])
+            if i > 0:
+                self.conv[i].backward_data(G.raw[i], G.act[i - 1])
+            elif need_dx:
+                self.conv[0].backward_data(G.raw[0], G.x_in)
+        ops.SideStream.get(self.device).join()
+        return G.x_in if need_dx else None
+
+
+class VGGEngine:
+    """TruncatedVGG19 (models/GANLoss.py:95-145): frozen conv3 + ReLU stack with 2x2 max pools; forward and the data
+    gradient only (the weights never train)."""
+
+    def __init__(self, module, device):
+        self.device = device
+        self.layers = []                      # ('conv', ConvOp) | ('pool', None); ReLU is fused into the conv
+        for m in module.truncated_vgg19.children():
+            if isinstance(m, nn.Conv2d):
+                self.layers.append(('conv', ConvOp(m.weight, m.bias, 3, 1, 1, False)))
+            elif isinstance(m, nn.MaxPool2d):
+                self.layers.append(('pool', None))
+        self.ctx, self.gbuf = {}, {}
+
+    def repack(self):
+        ops.PackPlan([c for k, c in self.layers if k == 'conv'], self.device).run()
+
+    def _shapes(self, H, W):
+        out, C = [], 3
+        for kind, conv in self.layers:
+            if kind == 'conv':
+                C = conv.rows
+            else:
+                H, W = H // 2, W // 2
+            out.append((C, H, W))
+        return out
+
+    def new_ctx(self, N, H, W, tag):
+        key = (N, H, W, tag)
+        if key not in self.ctx:
+            c = type('VGGCtx', (), {})()
+            c.N, c.H, c.W = N, H, W
+            c.x_in = ops.new_act(N, 3, H, W, self.device)
+            c.act = [ops.new_act(N, C, h, w, self.device) for C, h, w in self._shapes(H, W)]
+            self.ctx[key] = c
+        return self.ctx[key]
+
+    def forward(self, c):
+        src = c.x_in
+        for (kind, conv), out in zip(self.layers, c.act):
+            if kind == 'conv':
+                conv.forward(src, out, act=ACT_RELU)
+            else:
+                ops.maxpool_fwd(src, out)
+            src = out
+        return src
+
+    def backward(self, c, g_last):
+        """g_last: dL/d(output feature map), consumed in place; returns dL/d(x_in)"""
+        key = (c.N, c.H, c.W)
+        if key not in self.gbuf:
+            self.gbuf[key] = ([ops.new_act(c.N, C, h, w, self.device) for C, h, w in self._shapes(c.H, c.W)],
+                              ops.new_act(c.N, 3, c.H, c.W, self.device))
+        gact, gx = self.gbuf[key]
+        g = g_last
+        for i in range(len(self.layers) - 1, -1, -1):
+            kind, conv = self.layers[i]
+            src = c.act[i - 1] if i > 0 else c.x_in
+            dst = gact[i - 1] if i > 0 else gx
+            if kind == 'conv':
+                ops.bnact_bwd(c.act[i], None, g, g, in_act=ACT_RELU)
+                conv.backward_data(g, dst)
+            else:
+                ops.maxpool_bwd(src, g, dst)
+            g = dst
+        return gx

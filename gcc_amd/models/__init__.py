@@ -11,7 +11,7 @@ def get_model_class(opt):
     if opt.model == 'sagan':
         from .SAGAN import SAGANModel
         return SAGANModel
-    if opt.model in ('srgan',):
-        raise NotImplementedError('%s: not yet on the MI355X path (SURVEY.md section 8 rows a17-a19 are '
-                                  'scheduled after the Pix2Pix row is at parity)' % opt.model)
+    if opt.model == 'srgan':
+        from .SRGAN import SRGAN
+        return SRGAN
     raise NotImplementedError('%s not implemented' % opt.model)

@@ -548,6 +548,65 @@ def l1_loss(a, b, loss, weight=1.0, accumulate=False, da=None):
                             ldda, 0, ws.data_ptr(), ws.numel(), stream()), 'gcc_l1_loss')
 
 
+def mse_loss(a, b, loss, weight=1.0, accumulate=False, da=None):
+    """loss (+)= weight * mean((a-b)^2); da = its gradient"""
+    ap, N, Cc, H, W, lda = geom(a)
+    bp, _, _, _, _, ldb = geom(b)
+    dap, ldda = (None, 0)
+    if da is not None:
+        dap, _, _, _, _, ldda = geom(da)
+    ws = workspace(lib().gcc_loss_workspace(N * H * W, Cc), a.device, 'loss')
+    check(lib().gcc_mse_loss(ap, lda, 0, bp, ldb, 0, Cc, N * H * W, float(weight), loss.data_ptr(), int(accumulate), dap,
+                             ldda, 0, ws.data_ptr(), ws.numel(), stream()), 'gcc_mse_loss')
+
+
+def prelu_fwd(x, slope, y, shuffle=1):
+    """y = prelu(x) (shuffle 1) or prelu(pixel_shuffle(x, 2)): x [N,4C,H,W] -> y [N,C,2H,2W]"""
+    xp, N, Cx, H, W, ldx = geom(x)
+    yp, _, Cy, _, _, ldy = geom(y)
+    check(lib().gcc_prelu(0, xp, ldx, slope.data_ptr(), Cy, N, H, W, shuffle, yp, ldy, None, 0, None, 0, None, stream()), 'gcc_prelu')
+
+
+def prelu_bwd(x, slope, dy, dx, dslope=None, shuffle=1):
+    xp, N, Cx, H, W, ldx = geom(x)
+    dyp, _, Cy, _, _, lddy = geom(dy)
+    dxp, _, _, _, _, lddx = geom(dx)
+    check(lib().gcc_prelu(1, xp, ldx, slope.data_ptr(), Cy, N, H, W, shuffle, None, 0, dyp, lddy, dxp, lddx, _p(dslope),
+                          stream()), 'gcc_prelu')
+
+
+def maxpool_fwd(x, y):
+    xp, N, Cc, H, W, ldx = geom(x)
+    yp, _, _, Ho, Wo, ldy = geom(y)
+    assert (H, W) == (2 * Ho, 2 * Wo)
+    check(lib().gcc_maxpool2x2(0, xp, ldx, yp, ldy, None, 0, None, 0, N, Ho, Wo, Cc, stream()), 'gcc_maxpool2x2')
+
+
+def maxpool_bwd(x, dy, dx):
+    xp, N, Cc, H, W, ldx = geom(x)
+    dyp, _, _, Ho, Wo, lddy = geom(dy)
+    dxp, _, _, _, _, lddx = geom(dx)
+    check(lib().gcc_maxpool2x2(1, xp, ldx, None, 0, dyp, lddy, dxp, lddx, N, Ho, Wo, Cc, stream()), 'gcc_maxpool2x2')
+
+
+def pool_linear_fwd(x, w, b, pooled, logit):
+    xp, N, Cc, H, W, ldx = geom(x)
+    lp, _, _, _, _, ldl = geom(logit)
+    check(lib().gcc_pool_linear_fwd(xp, ldx, N, H * W, Cc, w.data_ptr(), b.data_ptr(), pooled.data_ptr(), lp, ldl, stream()),
+          'gcc_pool_linear_fwd')
+
+
+def pool_linear_bwd(dlogit, w, pooled, like, dx=None, dw=None, db=None):
+    """like: the pooled activation tensor (geometry); dx (same geometry) / dw (+=) / db (+=) are optional"""
+    _, N, Cc, H, W, _ = geom(like)
+    dlp, _, _, _, _, ldl = geom(dlogit)
+    dxp, lddx = (None, 0)
+    if dx is not None:
+        dxp, _, _, _, _, lddx = geom(dx)
+    check(lib().gcc_pool_linear_bwd(dlp, ldl, w.data_ptr(), pooled.data_ptr(), N, H * W, Cc, dxp, lddx, _p(dw), _p(db), stream()),
+          'gcc_pool_linear_bwd')
+
+
 def distill_workspace_bytes(N, Cc, HW):
     return lib().gcc_distill_workspace(N, Cc, HW)
 

@@ -258,6 +258,10 @@ int gcc_arch_coeffs(const float* Lfr, const float* Lf, const float* Lr, const fl
 int gcc_l1_loss(const void* a, int lda, int aoff, const void* b, int ldb, int boff, int C, size_t pixels,
                 float weight, float* loss, int accumulate, void* da, int ldda, int daoff,
                 void* ws, size_t ws_bytes, gcc_stream_t stream);
+/* nn.MSELoss (models/SRGAN.py:447, 457): weight * mean((a-b)^2); da = weight * 2 (a-b) / count */
+int gcc_mse_loss(const void* a, int lda, int aoff, const void* b, int ldb, int boff, int C, size_t pixels,
+                 float weight, float* loss, int accumulate, void* da, int ldda, int daoff,
+                 void* ws, size_t ws_bytes, gcc_stream_t stream);
 size_t gcc_loss_workspace(size_t pixels, int C);
 
 /* Feature distillation, models/Pix2Pix.py:537-548 + :733-740, for one feature pair:
@@ -301,6 +305,24 @@ int gcc_attention_fwd(const void* qkv, int ldq, int qoff, int koff, int voff, co
 int gcc_attention_bwd(const void* qkv, int ldq, int qoff, int koff, int voff, const void* o, int ldo,
                       const float* A, const float* gamma, const void* dy, int lddy, int B, int N, int C, int C8,
                       void* dqkv, int lddq, float* dS, float* dgamma, gcc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SRGAN (models/SRGAN.py, models/GANLoss.py:95-145).
+ * gcc_prelu: nn.PReLU() with its single learnable slope (device scalar), optionally fused with the nn.PixelShuffle(2)
+ * in front of it (SubPixelConvolutionalBlock, :68-99): shuffle == 2 reads x [N][H][W][4C] and writes y [N][2H][2W][C],
+ * y[n][2h+i][2w+j][c] = prelu(x[n][h][w][4c+2i+j]).  backward != 0: dx (layout of x) from dy (layout of y), and
+ * dslope (+=, may be NULL: the distillation optimizer of the reference leaves the PReLU slopes out, :349-352).
+ * gcc_maxpool2x2: nn.MaxPool2d(2, 2) of the VGG stack; backward routes to the first maximum in scan order.
+ * gcc_pool_linear_*: AdaptiveAvgPool2d((1,1)) + Linear(C, 1) of the discriminators (:245-262): pooled [N][C] fp32 is
+ * kept for the backward pass, logit is bf16 [N][ldl] (one pixel per image, as gcc_gan_loss reads it). */
+int gcc_prelu(int backward, const void* x, int ldx, const float* slope, int C, int N, int H, int W, int shuffle,
+              void* y, int ldy, const void* dy, int lddy, void* dx, int lddx, float* dslope, gcc_stream_t stream);
+int gcc_maxpool2x2(int backward, const void* x, int ldx, void* y, int ldy, const void* dy, int lddy, void* dx, int lddx,
+                   int N, int Ho, int Wo, int C, gcc_stream_t stream);
+int gcc_pool_linear_fwd(const void* x, int ldx, int N, int HW, int C, const float* w, const float* b, float* pooled,
+                        void* logit, int ldl, gcc_stream_t stream);
+int gcc_pool_linear_bwd(const void* dlogit, int ldl, const float* w, const float* pooled, int N, int HW, int C,
+                        void* dx, int lddx, float* dw, float* db, gcc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer: multi-tensor Adam (torch.optim.Adam, no weight decay; models/Pix2Pix.py:382,415,

@@ -1,0 +1,403 @@
+"""SRGAN on the HIP path: PReLU / pixel-shuffle, max-pool, pool+linear and MSE kernels against plain PyTorch fp32; the
+model against the reference's golden vectors (tests/golden/srgan_gcc.npz), the bf16-emulating oracle's trajectory and the
+oracle's gradients."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_pix2pix_gpu import DEV, _rel, load, load_recipe
+
+pytestmark = pytest.mark.gpu
+VGG_STANDIN = (8, 8, 'M', 16, 16, 'M', 32, 32, 32, 32, 'M', 64, 64, 64, 64, 'M', 64, 64, 64, 64, 'M')
+
+
+def _rb(t):
+    return t.bfloat16().float()
+
+
+def _to_nhwc(ops, x):
+    buf = ops.new_act(x.shape[0], x.shape[1], x.shape[2], x.shape[3], DEV)
+    ops.nchw_to_nhwc(x.to(DEV).contiguous(), buf)
+    return buf
+
+
+@pytest.mark.parametrize('C,shuffle', [(16, 1), (20, 1), (8, 2), (64, 2)])
+def test_prelu_and_pixel_shuffle(C, shuffle):
+    from gcc_amd import ops
+    g = torch.Generator().manual_seed(C + shuffle)
+    N, H, W = 2, 5, 6
+    x = _rb(torch.randn(N, C * shuffle * shuffle, H, W, generator=g))
+    a = torch.tensor([0.3])
+    xr, ar = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    y_ref = F.prelu(F.pixel_shuffle(xr, shuffle) if shuffle > 1 else xr, ar)
+    dy = _rb(torch.randn(y_ref.shape, generator=g))
+    (y_ref * dy).sum().backward()
+    xd, ad = _to_nhwc(ops, x), a.to(DEV)
+    y = ops.new_act(N, C, H * shuffle, W * shuffle, DEV)
+    ops.prelu_fwd(xd, ad, y, shuffle=shuffle)
+    assert _rel(ops.nhwc_to_nchw(y, C).cpu(), y_ref.detach()) <= 5e-3
+    dx = ops.new_act(N, C * shuffle * shuffle, H, W, DEV)
+    da = torch.zeros(1, device=DEV)
+    ops.prelu_bwd(xd, ad, _to_nhwc(ops, dy), dx, dslope=da, shuffle=shuffle)
+    torch.cuda.synchronize()
+    assert _rel(ops.nhwc_to_nchw(dx).cpu(), xr.grad) <= 5e-3
+    assert abs(da.item() - ar.grad.item()) <= 5e-3 * abs(ar.grad.item()) + 1e-4
+
+
+def test_maxpool_pool_linear_mse():
+    from gcc_amd import ops
+    g = torch.Generator().manual_seed(3)
+    N, C, H, W = 2, 24, 8, 6
+    x = _rb(torch.randn(N, C, H, W, generator=g))
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 2, 2)
+    dy = _rb(torch.randn(y_ref.shape, generator=g))
+    (y_ref * dy).sum().backward()
+    xd = _to_nhwc(ops, x)
+    y = ops.new_act(N, C, H // 2, W // 2, DEV)
+    ops.maxpool_fwd(xd, y)
+    assert torch.equal(ops.nhwc_to_nchw(y, C).cpu(), y_ref.detach())
+    dx = ops.new_act(N, C, H, W, DEV)
+    ops.maxpool_bwd(xd, _to_nhwc(ops, dy), dx)
+    assert torch.equal(ops.nhwc_to_nchw(dx, C).cpu(), xr.grad)
+    # global average pool + Linear(C, 1)
+    w, b = torch.randn(1, C, generator=g) * 0.2, torch.randn(1, generator=g)
+    xr2, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    logit_ref = F.linear(xr2.mean((2, 3)), wr, br)
+    dl = _rb(torch.randn(N, 1, generator=g))
+    (logit_ref * dl).sum().backward()
+    pooled = torch.zeros(N, C, device=DEV)
+    logit = ops.new_act(N, 1, 1, 1, DEV)
+    wd, bd = w.to(DEV), b.to(DEV)
+    ops.pool_linear_fwd(xd, wd, bd, pooled, logit)
+    assert _rel(ops.nhwc_to_nchw(logit, 1).cpu().reshape(N, 1), logit_ref.detach()) <= 5e-3
+    dxd, dw, db = ops.new_act(N, C, H, W, DEV), torch.zeros(1, C, device=DEV), torch.zeros(1, device=DEV)
+    ops.pool_linear_bwd(_to_nhwc(ops, dl.reshape(N, 1, 1, 1)), wd, pooled, xd, dx=dxd, dw=dw, db=db)
+    torch.cuda.synchronize()
+    assert _rel(ops.nhwc_to_nchw(dxd, C).cpu(), xr2.grad) <= 5e-3
+    assert _rel(dw.cpu(), wr.grad) <= 1e-3 and abs(db.item() - br.grad.item()) <= 1e-4
+    # MSE with gradient
+    a_, b_ = _rb(torch.randn(N, C, H, W, generator=g)), _rb(torch.randn(N, C, H, W, generator=g))
+    ar = a_.clone().requires_grad_(True)
+    l_ref = F.mse_loss(ar, b_) * 0.7
+    l_ref.backward()
+    loss, da = torch.zeros(1, device=DEV), ops.new_act(N, C, H, W, DEV)
+    ops.mse_loss(_to_nhwc(ops, a_), _to_nhwc(ops, b_), loss, weight=0.7, da=da)
+    assert abs(loss.item() - l_ref.item()) <= 1e-4 * abs(l_ref.item())
+    assert _rel(ops.nhwc_to_nchw(da, C).cpu(), ar.grad) <= 5e-3
+
+
+SRGAN_ARGV = ['--dataroot', './database/sr/', '--model', 'srgan', '--gpu_ids', '0', '--ngf', '8', '--ndf', '8',
+              '--teacher_ngf', '16', '--online_distillation', '--darts_discriminator', '--lambda_content', '1',
+              '--lambda_gram', '1', '--lambda_L1', '0.5', '--lambda_SR_content', '0.5', '--arch_lr', '1e-4']
+
+
+def _build(z):
+    from gcc_amd.options import options
+    from gcc_amd.models import get_model_class
+    from tests.golden.recipe import recipe_transform, srgan_condition
+    os.environ['GCC_VGG19_RANDOM'] = '1'
+    opt = options.parse(SRGAN_ARGV)
+    opt.isTrain = True
+    opt.teacher_ndf = 16
+    cls = get_model_class(opt)
+    model = cls(opt, vgg_widths=VGG_STANDIN)
+    topt = copy.deepcopy(opt)
+    topt.ngf, topt.ndf = opt.teacher_ngf, opt.teacher_ndf
+    topt.darts_discriminator = topt.online_distillation = False
+    teacher = cls(topt, vgg_widths=VGG_STANDIN)
+    teacher.model_train()
+    model.teacher_model = teacher
+    model.init_distillation()
+    teacher.init_distillation()
+    for net, seed in ((model.netG, 901), (model.netD, 902), (teacher.netG, 903), (teacher.netD, 904),
+                      (model.truncated_vgg19, 905), (teacher.truncated_vgg19, 905)):
+        load_recipe(net, seed)
+        srgan_condition(net.state_dict())
+    with torch.no_grad():
+        for i, t in enumerate(model.transform_convs):
+            t.weight.copy_(recipe_transform(t.weight.shape[0], t.weight.shape[1], 910 + i).to(DEV))
+        model.netD.state_dict()['conv_blocks.0.conv_block.1.alpha'][0] = 0.3
+        model.netD.state_dict()['conv_blocks.2.conv_block.2.alpha'][1] = 0.5
+    for m in (model, teacher):
+        m.refresh_weights()
+        m.V.repack()
+    model.model_train()
+    return model, teacher, opt
+
+
+def _batch(z, a, b):
+    return {'lr': torch.from_numpy(z[a]), 'hr': torch.from_numpy(z[b]), 'lr_names': ['a'] * 2, 'hr_names': ['b'] * 2}
+
+
+_ZERO_G = lambda n: n.endswith('.conv_block.0.bias') and not n.startswith('conv_block1.') and not n.startswith('conv_block3.')
+_ZERO_D = lambda n: n.endswith('.conv_block.0.bias') and not n.startswith('conv_blocks.0.')
+
+
+def test_srgan_two_iterations_vs_reference_golden(golden_dir):
+    from tests.golden.recipe import sample_idx
+    from oracle import gcc_oracle as O
+    from tests.test_oracle_golden import build_srgan_oracle
+    z = load(golden_dir, 'srgan_gcc.npz')
+    model, teacher, opt = _build(z)
+    assert list(model.netG.state_dict().keys()) == [str(k) for k in z['G_keys']]
+    assert list(model.netD.state_dict().keys()) == [str(k) for k in z['D_keys']]
+    assert list(teacher.netD.state_dict().keys()) == [str(k) for k in z['TD_keys']]
+    assert list(model.truncated_vgg19.state_dict().keys()) == [str(k) for k in z['V_keys']]
+    assert model.loss_names == [str(k) for k in z['loss_names']] and opt.gan_mode == str(z['gan_mode'])
+    names = {id(p): k for k, p in model.netG.named_parameters()}
+    held = sorted(names[id(p)] for p in model.optimizer_G.param_groups[0]['params'] if id(p) in names)
+    assert held == sorted(str(k) for k in z['G_optimizer_names'])          # hazard H5: no PReLU slope under distillation
+    model.model_eval()
+    model.set_input({'lr': torch.from_numpy(z['eval.lr']), 'hr': torch.zeros(2, 3, 48, 48), 'lr_names': ['a'] * 2, 'hr_names': ['b'] * 2})
+    model.forward()
+    e = (model.fake_hr.cpu() - torch.from_numpy(z['eval.fake_hr'])).abs()
+    print('eval fake_hr: max %.4g mean %.4g' % (e.max(), e.mean()))
+    assert e.max() <= 3e-2 and e.mean() <= 4e-3
+    model.model_train()
+    emu = []
+    O.EMULATE_BF16 = True
+    try:
+        om, ot, _ = build_srgan_oracle(z)
+        for it in range(2):
+            om.set_input(torch.from_numpy(z['it%d.lr' % it]), torch.from_numpy(z['it%d.hr' % it]))
+            om.optimize_parameters()
+            om.set_input(torch.from_numpy(z['it%d.vlr' % it]), torch.from_numpy(z['it%d.vhr' % it]))
+            om.clipping_mask_alpha()
+            om.optimizer_netD_arch()
+            emu.append((dict(om.losses), dict(ot.losses)))
+    finally:
+        O.EMULATE_BF16 = False
+    for it in range(2):
+        model.set_input(_batch(z, 'it%d.lr' % it, 'it%d.hr' % it))
+        model.optimize_parameters()
+        if it == 0:
+            ref = torch.from_numpy(z['it0.fake_hr_norm'])
+            e = (model.fake_hr.cpu() - ref).abs()
+            print('it0 fake_hr (ImageNet-normalised): max %.4g mean %.4g' % (e.max(), e.mean()))
+            assert e.max() <= 0.15 and e.mean() <= 2e-2            # the normalisation divides by 2 std ~ 0.45: x2.2 of the [-1,1] bar
+            for j, f in enumerate(model.G.features(model._gctx)):
+                r = torch.from_numpy(z['it0.sfeat.%d' % j])
+                err = (f.float().cpu() - r).abs().max().item() / r.abs().max().item()
+                print('student feature %d: rel max err %.4g' % (j, err))
+                assert err <= 3e-2
+            for j in range(6):
+                r = torch.from_numpy(z['it0.target.%d' % j])
+                err = (model.target_distillation_features[j].float().cpu() - r).abs().max().item() / r.abs().max().item()
+                print('target %d: rel max err %.4g' % (j, err))
+                assert err <= (3e-2 if j < 4 else 8e-2)
+        model.set_input(_batch(z, 'it%d.vlr' % it, 'it%d.vhr' % it))
+        model.clipping_mask_alpha()
+        model.optimizer_netD_arch()
+        losses, tl = model.get_current_losses(), teacher.get_current_losses()
+        for k in z.files:
+            for pre, got, em in (('it%d.loss.' % it, losses, emu[it][0]), ('it%d.tloss.' % it, tl, emu[it][1])):
+                if k.startswith(pre):
+                    name, ref = k[len(pre):], float(z[k])
+                    print('it%d %s %s: got %.5g  reference %.5g  bf16-emulating oracle %.5g' % (it, pre[-6], name, got[name], ref, em[name]))
+                    assert abs(got[name] - em[name]) <= 4e-2 * max(1.0, abs(em[name])), (it, k, got[name], em[name])
+                    assert abs(got[name] - ref) <= (4e-2 if it == 0 else 0.15) * max(1.0, abs(ref)), (it, k, got[name], ref)
+    for tag, net, zero in (('sG', model.netG, _ZERO_G), ('sD', model.netD, _ZERO_D), ('tG', teacher.netG, _ZERO_G),
+                           ('tD', teacher.netD, _ZERO_D)):
+        sd = net.state_dict()
+        prefix = 'final.%s.' % tag
+        for k in z.files:
+            if not k.startswith(prefix):
+                continue
+            name = k[len(prefix):]
+            if zero(name):
+                continue
+            ref = z[k]
+            g = sd[name].detach().float().cpu().reshape(-1)
+            g = g[sample_idx(g.numel())].numpy()
+            if name.endswith('num_batches_tracked'):
+                assert int(g[0]) == int(ref.reshape(-1)[0]), (tag, name)
+                continue
+            if name.endswith('running_mean') or name.endswith('running_var'):
+                tol = 4e-2 * max(1.0, float(np.abs(ref).max()))
+            elif name.endswith('alpha'):
+                tol = 2.2 * opt.arch_lr * 2 + 1e-6
+            else:
+                tol = 2.2 * opt.lr * 2 + 1e-6
+            err = float(np.abs(g - ref).max())
+            assert err <= tol, (tag, name, err, tol)
+
+
+def test_srgan_gradients_vs_oracle(golden_dir):
+    """every parameter gradient of one SRGAN iteration + arch step against the oracle (fp32 and bf16-emulated).  The
+    teacher generator's gradient passes through the un-normalised 16-conv VGG stack (ReLU / max-pool decisions flip under
+    bf16 rounding): its three realisations (HIP, emulated, fp32) sit ~40% apart from each other, so for it this test only
+    bounds the HIP path by that floor; the sharp checks of the SRResNet and VGG backward passes are the two engine tests
+    below."""
+    from oracle import gcc_oracle as O
+    from tests.test_oracle_golden import build_srgan_oracle
+    z = load(golden_dir, 'srgan_gcc.npz')
+    model, teacher, opt = _build(z)
+    for m in (model, teacher):
+        for o in (m.optimizer_G, m.optimizer_D):
+            o.param_groups[0]['lr'] = 0.0
+    model.optimizer_arch.param_groups[0]['lr'] = 0.0
+    lr_, hr_, vlr, vhr = (torch.from_numpy(z['it0.' + k]) for k in ('lr', 'hr', 'vlr', 'vhr'))
+
+    def oracle_grads(emulate):
+        O.EMULATE_BF16 = emulate
+        try:
+            om, ot, _ = build_srgan_oracle(z)
+            for o in (om, ot):
+                o.lr_G = o.lr_D = o.lr_arch = 0.0
+            om.set_input(lr_, hr_)
+            om.optimize_parameters()
+            g = {}
+            for tag, who in (('t', ot), ('s', om)):
+                for k in who.G_keys:
+                    g[(tag + 'G', k)] = who.G[k].grad.clone()
+                for k in who.D_w_keys:
+                    g[(tag + 'D', k)] = who.D[k].grad.clone()
+            for i in range(4):
+                g[('T', i)] = om.T[i].grad.clone()
+            om.set_input(vlr, vhr)
+            om.clipping_mask_alpha()
+            om.optimizer_netD_arch()
+            for k in om.D_a_keys:
+                g[('alpha', k)] = om.D[k].grad.clone()
+            return g
+        finally:
+            O.EMULATE_BF16 = False
+    g32, g16 = oracle_grads(False), oracle_grads(True)
+    model.set_input({'lr': lr_, 'hr': hr_, 'lr_names': ['a'] * 2, 'hr_names': ['b'] * 2})
+    model.optimize_parameters()
+    torch.cuda.synchronize()
+    bad = []
+
+    def check(key, g):
+        g = g.float().cpu()
+        if (key[0][1:] == 'G' and _ZERO_G(key[1])) or (key[0][1:] == 'D' and _ZERO_D(key[1])):
+            return
+        if g.numel() == 1:
+            return      # PReLU slopes: one number, a cancelling sum over a whole activation tensor -- its relative error in
+                        # this chaotic full iteration is noise; test_srresnet_engine_shallow_backward pins it to 3e-2
+        r32, r16, floor = _rel(g, g32[key]), _rel(g, g16[key]), _rel(g16[key], g32[key])
+        print('%-6s %-52s vs fp32 %.4f  vs bf16-emulated %.4f  (emulated vs fp32 %.4f)' % (key[0], key[1], r32, r16, floor))
+        # small tensors (PReLU slopes are single numbers whose gradient is a cancelling sum, BatchNorm vectors of 8-16
+        # entries) have a relative error that is itself noisy: 3x the measured bf16 deviation instead of 1.5x
+        k = 3.0 if g.numel() <= 64 else 1.5
+        if not (r16 <= 6e-2 or r32 <= k * floor + 2e-2):
+            bad.append((key, r32, r16, floor))
+    for tag, net in (('tD', teacher.netD), ('tG', teacher.netG), ('sD', model.netD), ('sG', model.netG)):
+        sd = net.state_dict(keep_vars=True)
+        for (t, k) in g32:
+            if t == tag:
+                check((t, k), sd[k].grad)
+    for i in range(4):
+        check(('T', i), model.transform_convs[i].weight.grad)
+    model.set_input({'lr': vlr, 'hr': vhr, 'lr_names': ['a'] * 2, 'hr_names': ['b'] * 2})
+    model.clipping_mask_alpha()
+    model.optimizer_netD_arch()
+    torch.cuda.synchronize()
+    sd = model.netD.state_dict(keep_vars=True)
+    for (t, k) in g32:
+        if t == 'alpha':
+            check((t, k), sd[k].grad)
+    assert not bad, bad
+
+
+def test_srresnet_engine_shallow_backward():
+    """SRResNetEngine with 2 residual blocks: image, hooked features, every parameter gradient (PReLU slopes included)
+    against the oracle's autograd with bf16 storage emulated (bar 3e-2; the fp32 oracle is printed beside it)"""
+    from collections import OrderedDict
+    from gcc_amd import engine, ops
+    from gcc_amd.models.SRGAN import Generator
+    from oracle import gcc_oracle as O
+    from tests.golden.recipe import srgan_condition
+    net = Generator(n_channels=16, n_blocks=2).to(DEV)
+    load_recipe(net, 75)
+    srgan_condition(net.state_dict())
+    engine.FlatParams(list(net.parameters()), DEV)
+    eng = engine.SRResNetEngine(net, DEV)
+    eng.hook_blocks = (0, 1)
+    eng.repack()
+    g = torch.Generator().manual_seed(8)
+    N, H = 2, 10
+    x = _rb(torch.rand(N, 3, H, H, generator=g) * 2 - 1)
+    g_out = _rb(torch.randn(N, 3, 4 * H, 4 * H, generator=g) * 0.1)
+    g_feat = [_rb(torch.randn(N, 16, H, H, generator=g) * 0.05) for _ in range(2)]
+
+    def run_oracle(emulate):
+        O.EMULATE_BF16 = emulate
+        try:
+            sd = OrderedDict((k, v.detach().float().cpu().contiguous().clone().requires_grad_(v.dtype.is_floating_point))
+                             for k, v in net.state_dict().items())
+            feats = OrderedDict()
+            out = O.srresnet_forward(sd, x, True, features=feats, hook_idx=(0, 1))
+            ((out * g_out).sum() + sum((f * gf).sum() for f, gf in zip(feats.values(), g_feat))).backward()
+            return sd, out.detach(), feats
+        finally:
+            O.EMULATE_BF16 = False
+    sd32, out32, _ = run_oracle(False)
+    sd16, out16, feats16 = run_oracle(True)
+    c = eng._ctx(N, H, H)
+    ops.nhwc_copy(_to_nhwc(ops, x), 0, c.x_in, 0, 3)
+    eng.forward(c, train=True)
+    assert _rel(ops.nhwc_to_nchw(c.out, 3).cpu(), out16) <= 2e-2
+    for f, fr in zip(eng.features(c), feats16.values()):
+        assert _rel(f.float().cpu(), fr.detach()) <= 2e-2
+    ops.nhwc_copy(_to_nhwc(ops, g_out), 0, c.g_out, 0, 3)
+    eng.backward(c, g_feat=[_to_nhwc(ops, t) for t in g_feat])
+    torch.cuda.synchronize()
+    bad = []
+    for k, p in net.state_dict(keep_vars=True).items():
+        if not p.dtype.is_floating_point or sd32[k].grad is None or _ZERO_G(k):
+            continue
+        r32, r16 = _rel(p.grad.float().cpu(), sd32[k].grad), _rel(p.grad.float().cpu(), sd16[k].grad)
+        print('%-52s vs fp32 %.4f  vs bf16-emulated %.4f' % (k, r32, r16))
+        if r16 > 3e-2:
+            bad.append((k, r32, r16))
+    assert not bad, bad
+
+
+def test_vgg_engine_forward_backward():
+    """truncated VGG (narrow stand-in): feature map and dL/d(input) against the oracle with bf16 storage emulated"""
+    from collections import OrderedDict
+    from gcc_amd import engine, ops
+    from gcc_amd.models.SRGAN import TruncatedVGG19
+    from oracle import gcc_oracle as O
+    from tests.golden.recipe import srgan_condition
+    net = TruncatedVGG19(i=5, j=4, widths=VGG_STANDIN).to(DEV)
+    load_recipe(net, 76)
+    srgan_condition(net.state_dict())
+    for m in net.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    eng = engine.VGGEngine(net, DEV)
+    eng.repack()
+    g = torch.Generator().manual_seed(9)
+    N, H = 2, 48
+    x = _rb(torch.randn(N, 3, H, H, generator=g))
+    sd = OrderedDict((k, v.detach().float().cpu().contiguous()) for k, v in net.state_dict().items())
+    res = {}
+    for emulate in (False, True):
+        O.EMULATE_BF16 = emulate
+        try:
+            xr = x.clone().requires_grad_(True)
+            f = O.vgg_features(sd, xr, VGG_STANDIN[:-1])
+            if not emulate:
+                gf = _rb(torch.randn(f.shape, generator=g) * 0.1)
+            (f * gf).sum().backward()
+            res[emulate] = (f.detach(), xr.grad)
+        finally:
+            O.EMULATE_BF16 = False
+    c = eng.new_ctx(N, H, H, 't')
+    ops.nhwc_copy(_to_nhwc(ops, x), 0, c.x_in, 0, 3)
+    out = eng.forward(c)
+    r = _rel(out.float().cpu(), res[True][0])
+    print('feature map vs emulated %.4f, vs fp32 %.4f' % (r, _rel(out.float().cpu(), res[False][0])))
+    assert r <= 3e-2
+    dx = eng.backward(c, _to_nhwc(ops, gf))
+    torch.cuda.synchronize()
+    r16, r32, floor = _rel(ops.nhwc_to_nchw(dx, 3).cpu(), res[True][1]), _rel(ops.nhwc_to_nchw(dx, 3).cpu(), res[False][1]), _rel(res[True][1], res[False][1])
+    print('dL/dx vs emulated %.4f, vs fp32 %.4f (emulated vs fp32 %.4f)' % (r16, r32, floor))
+    assert r16 <= 6e-2 or r32 <= 1.5 * floor + 2e-2
