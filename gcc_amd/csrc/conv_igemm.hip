@@ -43,6 +43,7 @@ struct IgemmParams {
     int ksplit, kper;
     float* partial;
     int rows_max, Cpad;
+    int raw_partial;     // leave the fp32 partial tiles to the caller (no splitk_epilogue_kernel)
 };
 
 constexpr int BK = 64;   // k per step
@@ -255,25 +256,41 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
     auto compute = [&](int cur) {
         const char* a = sA + cur * (BP * BK * 2);
         const char* w = sW + cur * (BC * BK * 2);
+        // Both k-slices (2 x 32) of the stage are held in registers: the fragment reads of slice 1 are issued while
+        // the MFMAs of slice 0 run (the compiler's own order reads two fragments, waits, issues four MFMAs -- LDS
+        // latency exposed at every group).  sched_group_barrier pins the interleave: all reads of slice 0, then one
+        // read of slice 1 per MFMA_PER_READ MFMAs, then the rest.
+        bf16x8 fw[2][C::CB], fa[2][C::PB];
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            bf16x8 fw[C::CB], fa[C::PB];
 #pragma unroll
             for (int i = 0; i < C::CB; i++) {
                 const int row = wc * C::TC + i * 16 + lr;
-                fw[i] = *(const bf16x8*)(w + row * 128 + (((ks * 4 + lq) ^ (row & 7)) << 4));
+                fw[ks][i] = *(const bf16x8*)(w + row * 128 + (((ks * 4 + lq) ^ (row & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < C::PB; j++) {
                 const int row = wp * C::TP + j * 16 + lr;
-                fa[j] = *(const bf16x8*)(a + row * 128 + (((ks * 4 + lq) ^ (row & 7)) << 4));
+                fa[ks][j] = *(const bf16x8*)(a + row * 128 + (((ks * 4 + lq) ^ (row & 7)) << 4));
             }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
 #pragma unroll
             for (int i = 0; i < C::CB; i++)
 #pragma unroll
                 for (int j = 0; j < C::PB; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
+        constexpr int READS = C::CB + C::PB;                 // fragment reads per k-slice
+        constexpr int MFMAS = C::CB * C::PB;                 // MFMAs per k-slice
+        constexpr int MPR = MFMAS / READS > 0 ? MFMAS / READS : 1;
+        __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);          // slice 0 fragments
+#pragma unroll
+        for (int r = 0; r < READS; r++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);        // MFMAs of slice 0 ...
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // ... covering one read of slice 1
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MFMAS - READS * MPR, 0);
     };
 
     if constexpr (GLDS && UT) {
@@ -364,7 +381,7 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
 
     // ---- epilogue ------------------------------------------------------------------------------
     // acc[i][j][r]: channel = wc*TC + i*16 + 4*lq + r ; pixel = wp*TP + j*16 + lr
-    if (p.ksplit > 1) {
+    if (p.partial) {      // split-K slices, or the raw fp32 route of the single-output-channel head (ksplit may be 1)
         float* part = p.partial + ((size_t)(blockIdx.z * p.ksplit + ks_idx) * p.rows_max) * p.Cpad;
 #pragma unroll
         for (int j = 0; j < C::PB; j++) {
@@ -563,7 +580,7 @@ int launch(const IgemmParams& p, int phases, int batch, hipStream_t st) {
             hipLaunchKernelGGL((igemm_kernel<BP, BC, true, false>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
     }
     GCC_CHECK_LAUNCH();
-    if (p.ksplit > 1) {
+    if (p.ksplit > 1 && !p.raw_partial) {
         const size_t total = (size_t)p.rows_max * (ceil8(p.Cout) / 8);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 1024) blocks = 1024;
@@ -626,6 +643,97 @@ int check_conv(const gcc_conv_t* c) {
 }  // namespace gcc_igemm
 using namespace gcc_igemm;
 
+// ---------------------------------------------------------------------------------------------
+// Single-output-channel convolutions (the PatchGAN head, 1024 -> 1, k4 s1 p1: 80 us per launch as a 128x16 implicit
+// GEMM because the gather re-reads the 31 MB input once per tap).  Reformulated so that the input is read once:
+//   fprop : T[pixel][tap] = x[pixel][:] . w[tap][:]   (a 1x1 conv with `taps` output channels, fp32 partial tiles)
+//           y[oy][ox] = bias + sum_tap T[(oy*s + kh - pad, ox*s + kw - pad)][tap]          (head_tapsum_kernel)
+//   wgrad : G[pixel][tap*8] = dy at the output position that tap connects the pixel to   (head_gather_kernel);
+//           dW[tap][:] = sum_pixels G[pixel][tap*8] x[pixel][:], a 1x1 weight gradient   (conv_wgrad.hip)
+//   (backward-data stays on the generic path: it is bound by writing dx and was measured no faster this way)
+struct HeadArgs {
+    const float* partial; int ksplit, rows_max, Cpad;
+    const float* bias; int act; float slope;
+    bf16_t* dst; int ldd, doff;
+    const bf16_t* dy; int lddy, dyoff;
+    bf16_t* g;
+    int N, H, W, Ho, Wo, KH, KW, stride, pad;
+};
+__global__ __launch_bounds__(256) void head_tapsum_kernel(const HeadArgs a) {
+    const size_t total = (size_t)a.N * a.Ho * a.Wo;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const int ox = (int)(q % a.Wo);
+        const size_t t = q / a.Wo;
+        const int oy = (int)(t % a.Ho);
+        const size_t n = t / a.Ho;
+        float acc = 0.f;
+        for (int kh = 0; kh < a.KH; kh++) {
+            const int iy = oy * a.stride + kh - a.pad;
+            if ((unsigned)iy >= (unsigned)a.H) continue;
+            for (int kw = 0; kw < a.KW; kw++) {
+                const int ix = ox * a.stride + kw - a.pad;
+                if ((unsigned)ix >= (unsigned)a.W) continue;
+                const size_t row = (n * a.H + iy) * (size_t)a.W + ix;
+                for (int s = 0; s < a.ksplit; s++) acc += a.partial[((size_t)s * a.rows_max + row) * a.Cpad + kh * a.KW + kw];
+            }
+        }
+        float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        o[0] = apply_act(acc + (a.bias ? a.bias[0] : 0.f), a.act, a.slope);
+        *(i32x4*)(a.dst + q * a.ldd + a.doff) = pack8(o);
+    }
+}
+// G[pixel][tap*8 + 0] = dy[n][oy][ox] with oy*s + kh - pad == iy (if such an output exists), zeros elsewhere
+__global__ __launch_bounds__(256) void head_gather_kernel(const HeadArgs a) {
+    const int taps = a.KH * a.KW;
+    const size_t total = (size_t)a.N * a.H * a.W * taps;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const int tap = (int)(q % taps);
+        const size_t pix = q / taps;
+        const int ix = (int)(pix % a.W);
+        const size_t t = pix / a.W;
+        const int iy = (int)(t % a.H);
+        const size_t n = t / a.H;
+        const int kh = tap / a.KW, kw = tap - kh * a.KW;
+        const int ny = iy + a.pad - kh, nx = ix + a.pad - kw;
+        float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ny >= 0 && nx >= 0 && ny % a.stride == 0 && nx % a.stride == 0) {
+            const int oy = ny / a.stride, ox = nx / a.stride;
+            if (oy < a.Ho && ox < a.Wo) o[0] = bf2f(a.dy[((n * a.Ho + oy) * (size_t)a.Wo + ox) * a.lddy + a.dyoff]);
+        }
+        *(i32x4*)(a.g + q * 8) = pack8(o);
+    }
+}
+
+static bool head_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GCC_IGEMM_HEAD"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+// rows of the tap matrix / bytes of the gathered dy matrix
+static size_t head_rows(const gcc_conv_t* c) { return (size_t)c->N * c->H * c->W; }
+static bool head_shape(const gcc_conv_t* c) {
+    return c->Co == 1 && c->KH * c->KW >= 4 && c->KH * c->KW <= 16 && ceil8(c->Ci) >= 256 && head_enabled();
+}
+size_t gcc_internal_head_gather_bytes(const gcc_conv_t* c) { return head_shape(c) ? head_rows(c) * c->KH * c->KW * 8 * 2 : 0; }
+int gcc_internal_head_gather(const gcc_conv_t* c, const void* dy, void* g, hipStream_t st) {
+    HeadArgs a = {};
+    a.dy = (const bf16_t*)dy; a.lddy = c->ldy; a.dyoff = c->yoff; a.g = (bf16_t*)g;
+    a.N = c->N; a.H = c->H; a.W = c->W; a.KH = c->KH; a.KW = c->KW; a.stride = c->stride; a.pad = c->pad;
+    a.Ho = gcc_conv_out(c->H, c->KH, c->stride, c->pad); a.Wo = gcc_conv_out(c->W, c->KW, c->stride, c->pad);
+    const size_t total = head_rows(c) * c->KH * c->KW;
+    size_t b = (total + 255) / 256;
+    hipLaunchKernelGGL(head_gather_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, st, a);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+static size_t head_fprop_workspace(const gcc_conv_t* c, int* ksplit_out) {
+    const size_t rows = head_rows(c);
+    const int nk = cdiv(ceil8(c->Ci), BK);
+    const SplitPlan sp = plan_ksplit((long)cdiv((int)rows, 128), nk);
+    if (ksplit_out) *ksplit_out = sp.ksplit;
+    return (size_t)sp.ksplit * rows * 16 * sizeof(float);
+}
+
 // internal entry (also used by distill.hip): `batch` independent problems, strides in elements
 int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const void* w, void* dst, const gcc_epilogue_t* ep,
                        int batch, long src_bstride, long wgt_bstride, long dst_bstride, hipStream_t st) {
@@ -635,6 +743,43 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
     if (!src || !w || !dst) return GCC_ERR_BAD_ARG;
     const int Ho = gcc_conv_out(c->H, c->KH, c->stride, c->pad);
     const int Wo = gcc_conv_out(c->W, c->KW, c->stride, c->pad);
+    if (batch == 1 && head_shape(c) && ep && ep->workspace && !ep->stats_partial && (((uintptr_t)ep->workspace) & 15) == 0) {
+        const int taps = c->KH * c->KW;
+        if (!dgrad) {
+            int ks = 1;
+            const size_t need = head_fprop_workspace(c, &ks);
+            if (need <= ep->workspace_bytes) {
+                // T = x . W16^T as fp32 partial tiles: the fprop packing's row 0 is [taps][Ci8], i.e. a 1x1 weight with `taps` rows
+                IgemmParams q;
+                q.src = (const bf16_t*)src; q.wgt = (const bf16_t*)w; q.dst = (bf16_t*)dst; q.bias = nullptr; q.stats = nullptr;
+                q.act = GCC_ACT_NONE; q.slope = 0.f;
+                q.N = c->N; q.KH = 1; q.KW = 1; q.stride = 1; q.pad = 0; q.dgrad = 0;
+                q.Hs = c->H; q.Ws = c->W; q.lds_ = c->ldx; q.soff = c->xoff; q.Hd = c->H; q.Wd = c->W; q.ldd = c->ldy; q.doff = c->yoff;
+                q.Ct = ceil8(c->Ci); q.Cout = taps; q.ldw = q.Ct;
+                const size_t rows = head_rows(c);
+                const size_t sb = rows * (size_t)q.lds_ * 2, wb = (size_t)taps * q.ldw * 2;
+                if (sb < OOB && wb < OOB) {
+                    q.src_bytes = (uint32_t)sb; q.wgt_bytes = (uint32_t)wb;
+                    q.src_bstride = q.wgt_bstride = q.dst_bstride = 0;
+                    q.ntiles = 1; q.mtiles_max = cdiv((int)rows, 128);
+                    const int nk = cdiv(q.Ct, BK);
+                    q.ksplit = ks; q.kper = cdiv(nk, ks); q.partial = (float*)ep->workspace; q.rows_max = (int)rows; q.Cpad = 16;
+                    q.raw_partial = 1;
+                    int rc2 = launch<128, 16>(q, 1, 1, st);
+                    if (rc2) return rc2;
+                    HeadArgs a = {};
+                    a.partial = q.partial; a.ksplit = q.ksplit; a.rows_max = q.rows_max; a.Cpad = 16;
+                    a.bias = ep->bias; a.act = ep->act; a.slope = ep->slope;
+                    a.dst = (bf16_t*)dst; a.ldd = c->ldy; a.doff = c->yoff;
+                    a.N = c->N; a.H = c->H; a.W = c->W; a.Ho = Ho; a.Wo = Wo; a.KH = c->KH; a.KW = c->KW; a.stride = c->stride; a.pad = c->pad;
+                    const size_t outs = (size_t)c->N * Ho * Wo;
+                    hipLaunchKernelGGL(head_tapsum_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, st, a);
+                    GCC_CHECK_LAUNCH();
+                    return GCC_OK;
+                }
+            }
+        }
+    }
     IgemmParams p;
     p.src = (const bf16_t*)src; p.wgt = (const bf16_t*)w; p.dst = (bf16_t*)dst;
     p.bias = ep ? ep->bias : nullptr;
@@ -672,7 +817,7 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
     p.ntiles = tp.ntiles;
     p.mtiles_max = tp.mtiles;
     // ---- split-K decision (needs caller workspace; without it the launch simply is not split) ------
-    p.ksplit = 1; p.kper = 0; p.partial = nullptr; p.rows_max = (int)max_rows; p.Cpad = p.ntiles * BC;
+    p.ksplit = 1; p.kper = 0; p.partial = nullptr; p.rows_max = (int)max_rows; p.Cpad = p.ntiles * BC; p.raw_partial = 0;
     float* stats_out = p.stats;
     if (batch == 1 && tp.BP == 128 && ep && ep->workspace) {
         const SplitPlan sp = plan_ksplit((long)p.mtiles_max * p.ntiles * phases, conv_nk(c, dgrad));
@@ -708,6 +853,7 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
 
 extern "C" size_t gcc_conv_workspace(const gcc_conv_t* c, int dgrad) {
     if (check_conv(c)) return 0;
+    if (head_shape(c) && !dgrad) return head_fprop_workspace(c, nullptr);
     const int phases = dgrad ? c->stride * c->stride : 1;
     const size_t max_rows = conv_max_rows(c, dgrad);
     const int nk = conv_nk(c, dgrad);

@@ -274,7 +274,35 @@ size_t gcc_internal_wgrad_workspace(const gcc_conv_t* c, int batch) {
     return (size_t)splits * batch * c->Co * c->KH * c->KW * ceil8(c->Ci) * sizeof(float);
 }
 
-extern "C" size_t gcc_conv_wgrad_workspace(const gcc_conv_t* c) { return gcc_internal_wgrad_workspace(c, 1); }
+// single-output-channel head (conv_igemm.hip): dW[0][tap][:] = sum_pixels G[pixel][tap*8] * x[pixel][:], a 1x1 weight
+// gradient with the gathered dy matrix G as its "dy"; rows tap*8 of that [taps*8][Ci] result are the master's rows
+size_t gcc_internal_head_gather_bytes(const gcc_conv_t* c);
+int gcc_internal_head_gather(const gcc_conv_t* c, const void* dy, void* g, hipStream_t st);
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+static gcc_conv_t head_conv1x1(const gcc_conv_t* c) {
+    const int taps = c->KH * c->KW;
+    gcc_conv_t c1 = {c->N, c->H, c->W, c->Ci, taps * 8, 1, 1, 1, 0, c->ldx, c->xoff, taps * 8, 0};
+    return c1;
+}
+static size_t head_wgrad_workspace(const gcc_conv_t* c) {
+    const size_t g = gcc_internal_head_gather_bytes(c);
+    if (!g) return 0;
+    const gcc_conv_t c1 = head_conv1x1(c);
+    return al256(g) + al256((size_t)c1.Co * ceil8(c->Ci) * sizeof(float)) + gcc_internal_wgrad_workspace(&c1, 1);
+}
+__global__ void head_rows_fold_kernel(const float* __restrict__ big, float* __restrict__ dw, int taps, int Cip, int accumulate) {
+    const int n = taps * Cip;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int t = i / Cip, cc = i - t * Cip;
+        const float v = big[(size_t)(t * 8) * Cip + cc];
+        dw[i] = accumulate ? dw[i] + v : v;
+    }
+}
+
+extern "C" size_t gcc_conv_wgrad_workspace(const gcc_conv_t* c) {
+    const size_t h = c ? head_wgrad_workspace(c) : 0;
+    return h ? h : gcc_internal_wgrad_workspace(c, 1);
+}
 
 // batched form: problem b reads x + b*x_bstride, dy + b*dy_bstride (elements; c->N images each) and
 // writes dw + b*Co*taps*Ci
@@ -345,6 +373,24 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
 extern "C" int gcc_conv_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float* dw, int accumulate,
                               void* ws, size_t ws_bytes, gcc_stream_t stream) {
     GCC_ENTER();
+    const size_t hw = c ? head_wgrad_workspace(c) : 0;
+    if (hw && ws && ws_bytes >= hw && x && dy && dw && (c->Ci & 7) == 0) {
+        hipStream_t st = (hipStream_t)stream;
+        char* base = (char*)ws;
+        const gcc_conv_t c1 = head_conv1x1(c);
+        const size_t gbytes = al256(gcc_internal_head_gather_bytes(c));
+        const size_t bbytes = al256((size_t)c1.Co * c->Ci * sizeof(float));
+        int rc = gcc_internal_head_gather(c, dy, base, st);
+        if (rc) return rc;
+        float* big = (float*)(base + gbytes);
+        rc = gcc_internal_wgrad(&c1, x, base, big, 0, base + gbytes + bbytes, ws_bytes - gbytes - bbytes, 1, 0, 0, st, 0, 0, 0, 0);
+        if (rc) return rc;
+        const int taps = c->KH * c->KW;
+        hipLaunchKernelGGL(head_rows_fold_kernel, dim3((taps * c->Ci + 255) / 256), dim3(256), 0, st, (const float*)big, dw, taps, c->Ci,
+                           accumulate);
+        GCC_CHECK_LAUNCH();
+        return GCC_OK;
+    }
     return gcc_internal_wgrad(c, x, dy, dw, accumulate, ws, ws_bytes, 1, 0, 0, (hipStream_t)stream, 0, 0, 0, 0);
 }
 

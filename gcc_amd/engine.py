@@ -10,6 +10,8 @@ inside the concat buffer of the up path).
 
 Reference anchors: U-Net models/Pix2Pix.py:20-130, PatchGAN :267-348, hooks :363-373,702-727.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -18,7 +20,7 @@ from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH
 
 LRELU = 0.2
 # run weight-gradient kernels on a side stream, concurrently with the data-gradient / BN chain
-OVERLAP_WGRAD = True
+OVERLAP_WGRAD = os.environ.get('GCC_OVERLAP_WGRAD', '1') != '0'
 
 
 # ------------------------------------------------------------------------------------------------

@@ -5,6 +5,7 @@ Activations are ``torch.bfloat16`` tensors of logical shape [N, C, H, W] in chan
 HIP stream and (elsewhere) torch.distributed -- every computation below is a libgcc_hip.so kernel.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -43,21 +44,31 @@ class _Profile:
         e.record()
         return e
 
-    def end(self, kind, flops, e0):
+    def end(self, kind, flops, e0, shape=None):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.records.append((kind, flops, e0, e1))
+        self.records.append((kind, flops, e0, e1, shape))
 
     def stop(self, peak=2.5e15):
         self.active = False
         torch.cuda.synchronize()
-        agg = {}
-        for kind, flops, e0, e1 in self.records:
+        agg, shapes = {}, {}
+        for kind, flops, e0, e1, shape in self.records:
+            sec = e0.elapsed_time(e1) * 1e-3
             a = agg.setdefault(kind, [0.0, 0.0, 0])
             a[0] += flops
-            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[1] += sec
             a[2] += 1
+            b = shapes.setdefault((kind.split(' ')[0], shape), [0.0, 0.0, 0])
+            b[0] += flops
+            b[1] += sec
+            b[2] += 1
         self.records = []
+        if os.environ.get('GCC_PROFILE_SHAPES') == '1':      # per-geometry table on stderr (tuning aid)
+            import sys
+            for (kind, shape), (fl, sec, n) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:40]:
+                print('%-14s %-44s n=%4d  total %7.3f ms  avg %7.1f us  %7.1f TFLOP/s' % (kind, shape, n, sec * 1e3, sec / n * 1e6,
+                                                                                         fl / sec / 1e12), file=sys.stderr)
         if not agg:
             return None
         dom = max(agg, key=lambda k: agg[k][1])
@@ -246,7 +257,8 @@ def conv_fprop(x, w, Co, k, stride, pad, out=None, bias=None, act=ACT_NONE, slop
     e0 = PROFILE.begin() if PROFILE.active else None
     check(lib().gcc_conv_fprop(C.byref(d), xp, w.data_ptr(), yp, C.byref(ep), stream()), 'gcc_conv_fprop')
     if e0 is not None:
-        PROFILE.end('igemm_kernel (conv fprop/dgrad)', 2.0 * N * Ho * Wo * Co * k * k * Ci, e0)
+        PROFILE.end('igemm_kernel (conv fprop/dgrad)', 2.0 * N * Ho * Wo * Co * k * k * Ci, e0,
+                    shape=('fprop', N, Ho, Wo, Ci, Co, k, stride))
     return (out, stats) if want_stats else out
 
 
@@ -266,7 +278,8 @@ def conv_dgrad(dy, wt, Ci, H, W, k, stride, pad, out=None, bias=None, act=ACT_NO
     e0 = PROFILE.begin() if PROFILE.active else None
     check(lib().gcc_conv_dgrad(C.byref(d), yp, wt.data_ptr(), xp, C.byref(ep), stream()), 'gcc_conv_dgrad')
     if e0 is not None:
-        PROFILE.end('igemm_kernel (conv fprop/dgrad)', 2.0 * N * Ho * Wo * Co * k * k * Ci, e0)
+        PROFILE.end('igemm_kernel (conv fprop/dgrad)', 2.0 * N * Ho * Wo * Co * k * k * Ci, e0,
+                    shape=('dgrad', N, Ho, Wo, Ci, Co, k, stride))
     return (out, stats) if want_stats else out
 
 
@@ -283,7 +296,7 @@ def conv_wgrad(x, dy, dw, k, stride, pad, accumulate=False):
     check(lib().gcc_conv_wgrad(C.byref(d), xp, yp, dw.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel(),
                                stream()), 'gcc_conv_wgrad')
     if e0 is not None:
-        PROFILE.end('wgrad_kernel (+ slab reduce)', 2.0 * N * Ho * Wo * Co * k * k * Ci, e0)
+        PROFILE.end('wgrad_kernel (+ slab reduce)', 2.0 * N * Ho * Wo * Co * k * k * Ci, e0, shape=('wgrad', N, Ho, Wo, Ci, Co, k, stride))
     return dw
 
 

@@ -14,6 +14,8 @@ SHAPES = [
     ('D.L2 128->256 k4s2 @128', 16, 128, 128, 128, 256, 4, 2, 1),
     ('D.L3 256->512 k4s2 @64', 16, 64, 64, 256, 512, 4, 2, 1),
     ('D.L4 512->1024 k4s1 @32', 16, 32, 32, 512, 1024, 4, 1, 1),
+    ('D.L5 1024->1 k4s1 @31', 16, 31, 31, 1024, 1, 4, 1, 1),
+    ('D.L1 6->128 k4s2 @256', 16, 256, 256, 6, 128, 4, 2, 1),
     ('tG.d1 64->128 k4s2 @128', 16, 128, 128, 64, 128, 4, 2, 1),
     ('tG.d2 128->256 k4s2 @64', 16, 64, 64, 128, 256, 4, 2, 1),
     ('tG.d3 256->512 k4s2 @32', 16, 32, 32, 256, 512, 4, 2, 1),
