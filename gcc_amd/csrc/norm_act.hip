@@ -4,6 +4,7 @@
 // loop, folded through LDS once per block and finished by a tiny second kernel (deterministic, no
 // float atomics).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -24,9 +25,15 @@ static bool make_layout(int C, Layout* L, int V = 8) {
     return true;
 }
 static int stream_blocks(size_t pixels, const Layout& L, int sweeps_per_block) {
+    static int sw = -1, cap = 2048;
+    if (sw < 0) {
+        const char* e = getenv("GCC_BN_SWEEPS"); sw = e ? atoi(e) : 0;
+        const char* m = getenv("GCC_BN_MAXBLK"); if (m) cap = atoi(m);
+    }
+    if (sw > 0) sweeps_per_block = sw;
     size_t b = (pixels + (size_t)L.PPB * sweeps_per_block - 1) / ((size_t)L.PPB * sweeps_per_block);
     if (b < 1) b = 1;
-    if (b > 2048) b = 2048;
+    if (b > (size_t)cap) b = cap;
     return (int)b;
 }
 
@@ -122,13 +129,26 @@ __global__ __launch_bounds__(256) void bnact_fwd_kernel(const FwdArgs a) {
     const bf16_t* rg = a.res ? a.res + gi * a.pixels * a.ldres : nullptr;
     const size_t po = a.groups > 1 ? gi * a.C : 0;
     float sc[8], sf[8], gm[8];
+    if (c0 + 8 <= a.C && ((po + c0) & 3) == 0) {
+        // whole chunk inside the channel range: the per-channel parameters come in as 16-byte loads (this prologue is
+        // a dependent global round trip paid by every workgroup before it streams anything)
+        const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 s0 = a.p.scale ? *(const f32x4*)(a.p.scale + po + c0) : one, s1 = a.p.scale ? *(const f32x4*)(a.p.scale + po + c0 + 4) : one;
+        const f32x4 t0 = a.p.shift ? *(const f32x4*)(a.p.shift + po + c0) : zero, t1 = a.p.shift ? *(const f32x4*)(a.p.shift + po + c0 + 4) : zero;
+        const f32x4 g0 = a.p.gate ? *(const f32x4*)(a.p.gate + c0) : one, g1 = a.p.gate ? *(const f32x4*)(a.p.gate + c0 + 4) : one;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int c = c0 + j;
-        const bool v = c < a.C;
-        sc[j] = (v && a.p.scale) ? a.p.scale[po + c] : 1.f;
-        sf[j] = (v && a.p.shift) ? a.p.shift[po + c] : 0.f;
-        gm[j] = v ? (a.p.gate ? a.p.gate[c] : 1.f) : 0.f;   // pad channels come out as exact zeros
+        for (int j = 0; j < 4; j++) {
+            sc[j] = s0[j]; sc[4 + j] = s1[j]; sf[j] = t0[j]; sf[4 + j] = t1[j]; gm[j] = g0[j]; gm[4 + j] = g1[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int c = c0 + j;
+            const bool v = c < a.C;
+            sc[j] = (v && a.p.scale) ? a.p.scale[po + c] : 1.f;
+            sf[j] = (v && a.p.shift) ? a.p.shift[po + c] : 0.f;
+            gm[j] = v ? (a.p.gate ? a.p.gate[c] : 1.f) : 0.f;   // pad channels come out as exact zeros
+        }
     }
     const float keep_scale = a.p.drop_p > 0.f ? 1.f / (1.f - a.p.drop_p) : 1.f;
     for (size_t pix = (size_t)blockIdx.x * a.L.PPB + pl; pix < a.pixels; pix += (size_t)gridDim.x * a.L.PPB) {
@@ -327,12 +347,22 @@ __global__ __launch_bounds__(1024) void bnact_bwd_finalize_kernel(const BwdArgs 
     if (pl == 0 && c < a.C8) {
         for (int q = 1; q < 32; q++)
             for (int k = 0; k < 3; k++) t[k] += sh[k][q][cl];
-        a.totals[c] = (float)t[0]; a.totals[a.C8 + c] = (float)t[1]; a.totals[2 * a.C8 + c] = (float)t[2];
         if (c < a.C) {
             if (a.p.dbeta) a.p.dbeta[c] += (float)t[0];
             if (a.p.dgamma) a.p.dgamma[c] += (float)t[1];
             if (a.p.dalpha) a.p.dalpha[c] += (float)t[2];
         }
+        // coefficients of the apply pass, dx = A dz + B x + K  (= gamma rstd (dz - mean(dz) - xhat mean(dz xhat))):
+        // one row each in `totals`, read by the apply kernel as 16-byte loads
+        float A = 0.f, B = 0.f, K = 0.f;
+        if (c < a.C && a.p.bn && !a.p.bn_eval) {
+            const float inv = 1.f / (float)a.pixels;
+            const float rs = a.p.rstd[c], mu = a.p.mean[c];
+            const float gr = (a.p.gamma ? a.p.gamma[c] : 1.f) * rs;
+            const float k0 = (float)t[0] * inv, k1 = (float)t[1] * inv;
+            A = gr; B = -gr * rs * k1; K = -gr * k0 + gr * rs * k1 * mu;
+        }
+        a.totals[c] = A; a.totals[a.C8 + c] = B; a.totals[2 * a.C8 + c] = K;
     }
 }
 
@@ -343,17 +373,15 @@ __global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(const BwdArgs a0) 
     const int pl = threadIdx.x >> a.L.sh;
     if (ch >= a.L.CH) return;
     const int c0 = ch * 8;
-    float mu[8], rs[8], k0[8], k1[8], gr[8];
-    const float inv = 1.f / (float)a.pixels;
+    float A[8], B[8], K[8];
+    {
+        const f32x4 a0_ = *(const f32x4*)(a.totals + c0), a1_ = *(const f32x4*)(a.totals + c0 + 4);
+        const f32x4 b0_ = *(const f32x4*)(a.totals + a.C8 + c0), b1_ = *(const f32x4*)(a.totals + a.C8 + c0 + 4);
+        const f32x4 k0_ = *(const f32x4*)(a.totals + 2 * a.C8 + c0), k1_ = *(const f32x4*)(a.totals + 2 * a.C8 + c0 + 4);
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int c = c0 + j;
-        const bool v = c < a.C;
-        mu[j] = v ? a.p.mean[c] : 0.f;
-        rs[j] = v ? a.p.rstd[c] : 0.f;
-        gr[j] = v ? (a.p.gamma ? a.p.gamma[c] : 1.f) * rs[j] : 0.f;
-        k0[j] = a.totals[c] * inv;
-        k1[j] = a.totals[a.C8 + c] * inv;
+        for (int j = 0; j < 4; j++) {
+            A[j] = a0_[j]; A[4 + j] = a1_[j]; B[j] = b0_[j]; B[4 + j] = b1_[j]; K[j] = k0_[j]; K[4 + j] = k1_[j];
+        }
     }
     for (size_t pix = (size_t)blockIdx.x * a.L.PPB + pl; pix < a.pixels; pix += (size_t)gridDim.x * a.L.PPB) {
         float xv[8], dz[8], o[8];
@@ -361,7 +389,7 @@ __global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(const BwdArgs a0) 
         bf16_t* dp = a.dx + pix * a.lddx + a.dxoff + c0;
         unpack8(*(const i32x4*)dp, dz);
 #pragma unroll
-        for (int j = 0; j < 8; j++) o[j] = gr[j] * (dz[j] - k0[j] - (xv[j] - mu[j]) * rs[j] * k1[j]);
+        for (int j = 0; j < 8; j++) o[j] = A[j] * dz[j] + B[j] * xv[j] + K[j];
         *(i32x4*)dp = pack8(o);
     }
 }
@@ -509,7 +537,7 @@ extern "C" int gcc_bnact_fwd(const gcc_bnact_t* p, const void* x, int ldx, int x
     a.res = (const bf16_t*)p->residual; a.ldres = p->ld_residual;
     if (a.res && (a.ldres & 7)) return GCC_ERR_BAD_ARG;
     if (!make_layout(C, &a.L)) return GCC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bnact_fwd_kernel, dim3(stream_blocks(pixels, a.L, 4), a.groups), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bnact_fwd_kernel, dim3(stream_blocks(pixels, a.L, 6), a.groups), dim3(256), 0, (hipStream_t)stream, a);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }
@@ -573,7 +601,7 @@ extern "C" int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_s
     hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3((a.C8 + 31) / 32, groups), dim3(1024), 0, st, a, blocks);
     GCC_CHECK_LAUNCH();
     if (p->bn && !p->bn_eval) {
-        hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(stream_blocks(pixels, a.L, 4), groups), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(stream_blocks(pixels, a.L, 6), groups), dim3(256), 0, st, a);
         GCC_CHECK_LAUNCH();
     }
     return GCC_OK;
