@@ -54,8 +54,14 @@ constexpr uint32_t OOB = 0x7FFFFFF0u;
 // i.e. ~39 TB/s of L2 bandwidth at the 2.5 PF peak, more than the 8 L2s deliver; 256x256 needs half).
 template <int BP, int BC>
 struct Cfg {
-    static constexpr int WAVES = BP / 32;                  // 4 or 8
+    // 128-pixel tiles: 4 waves (2 workgroups per CU); 256-pixel tiles: 8 waves (256x256: 128x64 per wave).
+    // Measured alternative for 256x256 (kept expressible through WAVES / AI): 4 waves of 128x128, one per SIMD with
+    // the whole AGPR file as accumulators -- a third less LDS fragment traffic per k-step, but with a single wave per
+    // SIMD nothing covers the barrier and the exposed first fragment reads of each k-step: 670 / 934 TFLOP/s on the
+    // PatchGAN L2 / L4 forward shapes against 936 / 1045 with 8 waves.
+    static constexpr int WAVES = BP / 32;
     static constexpr int NT = WAVES * 64;
+    static constexpr int AI = (BP / 8) / WAVES;            // 1-KiB pixel staging instructions per wave and k-step (4 or 8)
     static constexpr int WC = (BC >= 128) ? 2 : 1;        // waves along channels
     static constexpr int WP = WAVES / WC;                  // waves along pixels
     static constexpr int TC = BC / WC;                     // channels per wave
@@ -139,10 +145,12 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
     // LDS-DMA        : wave-instruction q = wave*4+i covers rows 8q..8q+7; lane -> row 8q + (lane>>3),
     //                  physical chunk lane&7, which must hold logical chunk (lane&7) ^ (row&7)
     const int chunk = GLDS ? ((lane & 7) ^ (lane >> 3)) : (tid & 7);
-    int a_off[4], a_iy[4], a_ix[4];      // byte offset of the row's (iy0, ix0) pixel (+ chunk), and iy0 / ix0
+    constexpr int AI = C::AI;
+    static_assert(AI <= 8 && (GLDS || AI == 4), "pixel staging instructions per wave");
+    int a_off[8], a_iy[8], a_ix[8];      // byte offset of the row's (iy0, ix0) pixel (+ chunk), and iy0 / ix0 (first AI used)
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int rloc = GLDS ? ((wave * 4 + i) * 8 + (lane >> 3)) : ((tid >> 3) + 32 * i);
+    for (int i = 0; i < AI; i++) {
+        const int rloc = GLDS ? ((wave * AI + i) * 8 + (lane >> 3)) : ((tid >> 3) + 32 * i);
         const int m = m0 + rloc;
         if (m < M) {
             const int n = m / (Hg * Wg);
@@ -193,11 +201,11 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
         const int pix_off = ta * tap_row_bytes + tb * tap_col_bytes + cc * 2;
         const int wt_off = (((kh0 + ta * kstep) * p.KW + (kw0 + tb * kstep)) * p.Ct + cc) * 2;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < AI; i++) {
             const bool ok = kval && (unsigned)(a_iy[i] + dyo) < (unsigned)p.Hs && (unsigned)(a_ix[i] + dxo) < (unsigned)p.Ws;
             const uint32_t off = ok ? (uint32_t)(a_off[i] + pix_off) : OOB;
             if constexpr (GLDS) {
-                char* dst = sA + stage * (BP * BK * 2) + (wave * 4 + i) * 1024;
+                char* dst = sA + stage * (BP * BK * 2) + (wave * AI + i) * 1024;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, LDS_PTR(void, dst), 16, off, 0, 0, 0);
             } else {
                 ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0);
@@ -297,8 +305,8 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
         // Uniform-tap fast path: a tap spans Ct/64 consecutive k-steps, so the per-row source offsets
         // (bounds checks included) are computed once per tap and then just advance by 128 bytes per
         // k-step; the loop body is 8 LDS-DMA + 8 adds + 16 ds_read + 32 MFMA per wave.
-        static_assert(C::WN_GLDS <= 4, "weight staging instructions per wave");
-        uint32_t cur_a[4], cur_w[4];   // literal bound on purpose: with a template-dependent bound hipcc (ROCm 7.2)
+        static_assert(C::WN_GLDS <= 8, "weight staging instructions per wave");
+        uint32_t cur_a[8], cur_w[8];   // literal bound on purpose: with a template-dependent bound hipcc (ROCm 7.2)
                                        // silently drops the host stub of this instantiation
         int left;                                  // k-steps left in the current tap (scalar)
         auto load_tap = [&]() {
@@ -307,7 +315,7 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
             const int pix_off = ta * tap_row_bytes + tb * tap_col_bytes + cc * 2;
             const int wt_off = (((kh0 + ta * kstep) * p.KW + (kw0 + tb * kstep)) * p.Ct + cc) * 2;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < AI; i++) {
                 const bool ok = kval && (unsigned)(a_iy[i] + dyo) < (unsigned)p.Hs && (unsigned)(a_ix[i] + dxo) < (unsigned)p.Ws;
                 cur_a[i] = ok ? (uint32_t)(a_off[i] + pix_off) : OOB;
             }
@@ -317,8 +325,8 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
         };
         auto issue = [&](int stage) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                char* dst = sA + stage * (BP * BK * 2) + (wave * 4 + i) * 1024;
+            for (int i = 0; i < AI; i++) {
+                char* dst = sA + stage * (BP * BK * 2) + (wave * AI + i) * 1024;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, LDS_PTR(void, dst), 16, cur_a[i], 0, 0, 0);
                 cur_a[i] += BK * 2;
             }
@@ -592,7 +600,7 @@ int launch(const IgemmParams& p, int phases, int batch, hipStream_t st) {
 
 // Tile choice (shared by the launcher, gcc_conv_stat_tiles and gcc_conv_workspace).
 struct TilePlan { int BP, BC, ntiles, mtiles; };
-static int g_big_tiles = -1, g_big_min = 200;
+static int g_big_tiles = -1, g_big_min = 200, g_big_nk = 24;
 static TilePlan select_tile(size_t max_rows, int Cout, int phases, int nk, int batch) {
     TilePlan t;
     t.BP = 128;
@@ -605,10 +613,12 @@ static TilePlan select_tile(size_t max_rows, int Cout, int phases, int nk, int b
         g_big_tiles = e ? atoi(e) : 2;
         const char* m = getenv("GCC_IGEMM_BIG_MIN");      // test hook: minimum number of 256-pixel tiles
         if (m) g_big_min = atoi(m);
+        const char* k = getenv("GCC_IGEMM_BIG_NK");       // tuning hook: minimum K depth (in 64-steps) for 256-pixel tiles
+        if (k) g_big_nk = atoi(k);
     }
     // 256-pixel tiles (one 8-wave workgroup per CU) when they still fill the chip and the K loop is
     // long enough to amortise the un-overlapped prologue / epilogue of a lone workgroup
-    if (g_big_tiles && use_glds() && batch == 1 && Cout >= 128 && nk >= 24) {
+    if (g_big_tiles && use_glds() && batch == 1 && Cout >= 128 && nk >= g_big_nk) {
         const long m256 = (long)((max_rows + 255) / 256);
         if (g_big_tiles >= 2 && Cout % 256 == 0 && m256 * (Cout / 256) * phases >= g_big_min) {
             t.BP = 256; t.BC = 256; t.ntiles = Cout / 256;
