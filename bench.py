@@ -163,6 +163,15 @@ def main():
     roof = None
     if not args.no_roofline:
         roof = ops.PROFILE.stop()
+        if roof is not None:
+            # HBM bytes per igemm launch from the PMC counters: collected in their own rocprofv3 passes (--pmc FETCH_SIZE,
+            # --pmc WRITE_SIZE; scratch/pmc_traffic.py applies the gfx950 corrections) and committed under profiles/
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_igemm_hbm_traffic.json')))
+            if files:
+                with open(files[-1]) as fh:
+                    roof['traffic'] = round(json.load(fh)['hbm_bytes_per_launch_corrected'])
+                roof['traffic_source'] = 'profiles/' + os.path.basename(files[-1]) + ' (bytes per launch, rocprofv3 PMC passes)'
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -152,19 +152,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             }
             const char* tx = sX + cur * TILE_BYTES;
             const char* ty = sY + cur * TILE_BYTES;
+            // both k-slices in registers; the transposing reads of slice 1 are issued under the MFMAs of slice 0
+            // (sched_group_barrier pins the order: the compiler otherwise reads, waits, and only then multiplies)
+            bf16x8 fx[2][4], fy[2][4];
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
-                bf16x8 fx[4], fy[4];
 #pragma unroll
-                for (int i = 0; i < 4; i++) fx[i] = tr_frag(tx, ks, wa * 64 + i * 16, lane);
+                for (int i = 0; i < 4; i++) fx[ks][i] = tr_frag(tx, ks, wa * 64 + i * 16, lane);
 #pragma unroll
-                for (int j = 0; j < 4; j++) fy[j] = tr_frag(ty, ks, wb * 64 + j * 16, lane);
+                for (int j = 0; j < 4; j++) fy[ks][j] = tr_frag(ty, ks, wb * 64 + j * 16, lane);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[i], fy[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[ks][i], fy[ks][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);          // slice 0: 8 fragments = 16 transposing reads
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
             __syncthreads();
         }
     }
