@@ -32,9 +32,15 @@ class SyntheticPairs:
     def __iter__(self):
         g = torch.Generator().manual_seed(self.seed)
         b, s = self.opt.batch_size, self.opt.crop_size
+        img = lambda size: torch.rand(b, 3, size, size, generator=g) * 2 - 1
         for _ in range(self.n):
-            yield {'A': torch.rand(b, 3, s, s, generator=g) * 2 - 1, 'B': torch.rand(b, 3, s, s, generator=g) * 2 - 1,
-                   'A_paths': [''] * b, 'B_paths': [''] * b}
+            if self.opt.model == 'sagan':            # data/sa_dataset.py:45
+                yield {'z': torch.randn(b, self.opt.z_dim, generator=g), 'real_img': img(s), 'img_path': [''] * b}
+            elif self.opt.model == 'srgan':          # data/sr_dataset.py:173
+                hr = self.opt.image_size
+                yield {'lr': img(hr // self.opt.upscale_factor), 'hr': img(hr), 'lr_names': [''] * b, 'hr_names': [''] * b}
+            else:
+                yield {'A': img(s), 'B': img(s), 'A_paths': [''] * b, 'B_paths': [''] * b}
 
 
 def make_datasets(opt):
