@@ -222,10 +222,12 @@ __device__ __forceinline__ BwdArgs group_view(const BwdArgs& a0) {
 // The plain BatchNorm+activation case (both false) keeps 32 fewer live registers -> higher occupancy
 // for what is a pure HBM-streaming kernel.
 // V = channels per thread (4: 8-byte accesses, half the per-channel state -> twice the occupancy)
-// 1024-thread workgroups: 4x fewer per-block partial rows for the finalize to fold at equal waves in flight
-template <bool GATE, bool DROP, int V>
-__global__ __launch_bounds__(1024) void bnact_bwd_reduce_kernel(const BwdArgs a0) {
-    __shared__ float red[GATE ? 3 : 2][1024][V + 1];
+// NTH = 256 (default): small workgroups with 5 KB of LDS, so that they can share a CU with the two 74 KB workgroups of the
+// weight-gradient kernel running on the side stream (with 1024-thread / 61 KB workgroups the two streams took turns:
+// the BatchNorm backward behind a big wgrad launch ran 4x slower than alone).  NTH = 1024 is kept for A/B.
+template <bool GATE, bool DROP, int V, int NTH>
+__global__ __launch_bounds__(NTH) void bnact_bwd_reduce_kernel(const BwdArgs a0) {
+    __shared__ float red[NTH][V + 1];
     const BwdArgs a = group_view(a0);
     const int ch = threadIdx.x & (a.L.CHP - 1);
     const int pl = threadIdx.x >> a.L.sh;
@@ -307,25 +309,29 @@ __global__ __launch_bounds__(1024) void bnact_bwd_reduce_kernel(const BwdArgs a0
             stv<V>(a.dx + pix * a.lddx + a.dxoff + c0, dz);
         }
     }
-    // fold the pixel lanes of this block
+    // fold the pixel lanes of this block, one statistic at a time through the same small LDS buffer
+    float* o = a.partial + (size_t)blockIdx.x * 3 * a.C8;
 #pragma unroll
-    for (int j = 0; j < V; j++) {
-        red[0][threadIdx.x][j] = s0[j]; red[1][threadIdx.x][j] = s1[j];
-        if constexpr (GATE) red[2][threadIdx.x][j] = s2[j];
-    }
-    __syncthreads();
-    if (pl == 0 && active) {
+    for (int k = 0; k < 3; k++) {
+        if (k == 2 && !GATE) {
+            if (pl == 0 && active) {
 #pragma unroll
-        for (int j = 0; j < V; j++) {
-            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-            for (int q = 0; q < a.L.PPB; q++) {
-                const int t = q * a.L.CHP + ch;
-                t0 += red[0][t][j]; t1 += red[1][t][j];
-                if constexpr (GATE) t2 += red[2][t][j];
+                for (int j = 0; j < V; j++) o[2 * a.C8 + c0 + j] = 0.f;
             }
-            float* o = a.partial + (size_t)blockIdx.x * 3 * a.C8;
-            o[0 * a.C8 + c0 + j] = t0; o[1 * a.C8 + c0 + j] = t1; o[2 * a.C8 + c0 + j] = t2;
+            break;
         }
+#pragma unroll
+        for (int j = 0; j < V; j++) red[threadIdx.x][j] = k == 0 ? s0[j] : (k == 1 ? s1[j] : s2[GATE ? j : 0]);
+        __syncthreads();
+        if (pl == 0 && active) {
+#pragma unroll
+            for (int j = 0; j < V; j++) {
+                float t = 0.f;
+                for (int q = 0; q < a.L.PPB; q++) t += red[q * a.L.CHP + ch][j];
+                o[k * a.C8 + c0 + j] = t;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -542,11 +548,20 @@ extern "C" int gcc_bnact_fwd(const gcc_bnact_t* p, const void* x, int ldx, int x
     return GCC_OK;
 }
 
+static int reduce_threads() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GCC_BN_REDUCE_THREADS"); v = (e && atoi(e) == 1024) ? 1024 : 256; }
+    return v;
+}
 static int bwd_blocks(size_t pixels, const Layout& L) {
-    // (L is the 8-channel, 256-thread layout; the reduce pass covers 8x its pixels per sweep)
-    size_t b = (pixels + (size_t)L.PPB * 8 * 4 - 1) / ((size_t)L.PPB * 8 * 4);
+    // (L is the 8-channel, 256-thread layout.)  256-thread reduce workgroups sweep PPB/2 pixels at a time: ~16 sweeps
+    // each, at most 4 workgroups per CU; the 1024-thread variant: one per CU.  Bounds the partial rows the finalize folds.
+    const bool small = reduce_threads() == 256;
+    const size_t per = small ? (size_t)L.PPB * 8 : (size_t)L.PPB * 8 * 4;
+    size_t b = (pixels + per - 1) / per;
     if (b < 1) b = 1;
-    if (b > 256) b = 256;         // one 16-wave workgroup per CU; bounds the partial rows the finalize folds
+    const size_t cap = small ? 1024 : 256;
+    if (b > cap) b = cap;
     return (int)b;
 }
 
@@ -589,13 +604,21 @@ extern "C" int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_s
     const bool gate = p->gate != nullptr || p->dalpha != nullptr || p->gate_after_act;
     const bool drop = p->drop_p > 0.f;
     {
-        BwdArgs r = a;                      // the reduce pass runs 4 channels per thread, 1024 threads per workgroup
+        BwdArgs r = a;                      // the reduce pass runs 4 channels per thread
         if (!make_layout(C, &r.L, 4)) return GCC_ERR_UNSUPPORTED;
-        r.L.PPB = 1024 / r.L.CHP;
-        if (gate && drop) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<true, true, 4>), dim3(blocks, groups), dim3(1024), 0, st, r);
-        else if (gate) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<true, false, 4>), dim3(blocks, groups), dim3(1024), 0, st, r);
-        else if (drop) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<false, true, 4>), dim3(blocks, groups), dim3(1024), 0, st, r);
-        else hipLaunchKernelGGL((bnact_bwd_reduce_kernel<false, false, 4>), dim3(blocks, groups), dim3(1024), 0, st, r);
+        const int nth = reduce_threads();
+        if (r.L.CHP > nth) return GCC_ERR_UNSUPPORTED;
+        r.L.PPB = nth / r.L.CHP;
+#define GCC_LAUNCH_REDUCE(G, D)                                                                                             \
+        do {                                                                                                                \
+            if (nth == 256) hipLaunchKernelGGL((bnact_bwd_reduce_kernel<G, D, 4, 256>), dim3(blocks, groups), dim3(256), 0, st, r);   \
+            else hipLaunchKernelGGL((bnact_bwd_reduce_kernel<G, D, 4, 1024>), dim3(blocks, groups), dim3(1024), 0, st, r);           \
+        } while (0)
+        if (gate && drop) GCC_LAUNCH_REDUCE(true, true);
+        else if (gate) GCC_LAUNCH_REDUCE(true, false);
+        else if (drop) GCC_LAUNCH_REDUCE(false, true);
+        else GCC_LAUNCH_REDUCE(false, false);
+#undef GCC_LAUNCH_REDUCE
     }
     GCC_CHECK_LAUNCH();
     hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3((a.C8 + 31) / 32, groups), dim3(1024), 0, st, a, blocks);

@@ -22,6 +22,7 @@ class _Profile:
     def __init__(self):
         self.active = False
         self.records = []
+        self.streaming = os.environ.get('GCC_PROFILE_STREAMING') == '1'     # also bracket the BN backward launches
 
     def start(self, steps=None):
         """steps: stop bracketing launches after this many step_done() calls (keeps the event
@@ -475,8 +476,12 @@ def bnact_bwd(x, y, g1, dx, g2=None, bn=None, gamma=None, beta=None, bn_eval=Fal
                          act, slope, act2, drop_p, seed, _p(dgamma), _p(dbeta), _p(dalpha), groups, 0)
     need = lib().gcc_bnact_bwd_workspace(Cc, pixels) * max(1, groups)
     ws = workspace(need, x.device, 'bnbwd')
+    e0 = PROFILE.begin() if (PROFILE.active and PROFILE.streaming) else None
     check(lib().gcc_bnact_bwd_ex(C.byref(p), in_act, slope, xp, ldx, 0, yp, ldy, 0, g1p, ldg1, 0, g2p, ldg2, 0, dxp, lddx,
                                  0, Cc, pixels, ws.data_ptr(), ws.numel(), stream()), 'gcc_bnact_bwd')
+    if e0 is not None:          # "flops" carries bytes here: 8 B/elem reduce (+6 apply) with training BN, 6 without
+        PROFILE.end('bnact_bwd (bytes)', float(N * H * W * ceil8(Cc)) * (14.0 if (bn is not None and not bn_eval) else 6.0), e0,
+                    shape=('bnbwd', N, Cc, H, W, 'bn' if bn is not None else 'act', 'gate' if gate is not None else ''))
 
 
 def channel_sum(x, out, accumulate=False):
