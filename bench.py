@@ -12,9 +12,13 @@ teacher ngf 64 / ndf 128, hinge GAN loss, lambda_L1 100, content 50, gram 1e4, b
 Inputs are resident in HBM before the timed region.  One JSON line is printed by rank 0.
 
 roofline: the dominant kernel is the implicit-GEMM convolution (igemm_kernel, conv fprop / dgrad /
-ConvTranspose).  Every launch of it inside the first 3 steps of the timed region is bracketed by HIP
-events on the launch stream (bracketing all steps costs ~6% throughput); achieved = sum of algorithmic FLOPs (2*M*Cout*taps*Cin, padding excluded) / sum of
-measured durations; peak = 2.5 PFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md).
+ConvTranspose).  Every launch of it inside the first 2 steps of the timed region is bracketed by HIP
+events on the launch stream (bracketing all steps costs ~6% throughput); achieved = sum of algorithmic FLOPs
+(2*M*Cout*taps*Cin, padding excluded) / sum of measured durations; peak = 2.5 PFLOP/s dense bf16 MFMA
+(MI355X_MICROARCH.md).  Those 2 steps run with the three production streams (student, online teacher, weight
+gradients) folded onto one, so that a launch's duration is the kernel's own and not its neighbours' share of the CUs;
+the other steps of the timed region run the production schedule (profiles/: rocprofv3 summaries of
+`bench.py --serialize-streams`, which agree with these durations, and of the default command).
 cpu_baseline: the oracle (CPU restatement pinned to the reference) timed on this host's cores on a
 bounded sample (N=1, same architecture, 1 warm-up + 3 timed iterations), rank 0 at --gpus 1 only.
 """
@@ -73,6 +77,14 @@ def synthetic(batch, rank, device, size=256):
     return pair(1234 + rank), pair(4321 + rank)
 
 
+def serialize_streams(model, engine, flag):
+    """the production schedule runs three HIP streams (student, online teacher, weight gradients): kernels of different
+    streams share the CUs, so a launch's wall duration there includes its neighbours'.  The roofline block wants the
+    kernel's own duration: the profiled steps run with everything on one stream."""
+    engine.OVERLAP_WGRAD = not flag
+    model.serialize_streams = flag
+
+
 def one_step(model, train, val):
     model.set_input(train)
     model.optimize_parameters()
@@ -124,6 +136,9 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--serialize-streams', action='store_true',
+                    help='run every step on one HIP stream (as the profiled steps do): for rocprofv3 runs whose per-kernel '
+                         'average must be the kernel\'s own duration')
     args = ap.parse_args()
 
     from gcc_amd import dist as gdist
@@ -148,11 +163,18 @@ def main():
     log('warm-up done; timing %d steps' % args.steps)
     if world > 1:
         torch.distributed.barrier()
-    if not args.no_roofline:
-        ops.PROFILE.start(steps=min(args.steps, 3))   # HIP events bracket the igemm launches of the first 3 timed steps
+    from gcc_amd import engine
+    n_prof = 0 if args.no_roofline else min(args.steps, 2)
+    if n_prof:
+        ops.PROFILE.start(steps=n_prof)   # HIP events bracket the igemm launches of the first 2 timed steps
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if n_prof and i == 0:
+            serialize_streams(model, engine, True)      # profiled steps: one stream, a launch's duration is its own
+        if n_prof and i == n_prof:
+            torch.cuda.synchronize()
+            serialize_streams(model, engine, args.serialize_streams)
         one_step(model, train, val)
         ops.PROFILE.step_done()
     torch.cuda.synchronize()

@@ -473,13 +473,31 @@ class Pix2PixModel(nn.Module):
         return self._dist_ws[key]
 
     # -- one iteration (models/Pix2Pix.py:565-583) ----------------------------------------------------
+    def _teacher_stream(self):
+        """the online teacher's own HIP stream (GCC_CONCURRENT_TEACHER=0 turns it off): its iteration only has to be
+        finished when the student's generator step reads its features, so the student's forward and discriminator step run
+        next to it -- the small U-Net layers of the two networks, which cannot fill the chip alone, overlap"""
+        if getattr(self, 'serialize_streams', False):           # bench.py's profiled steps: every launch's duration is its own
+            return False
+        if getattr(self, '_tstream', None) is None:
+            self._tstream = torch.cuda.Stream(device=self.device) if os.environ.get('GCC_CONCURRENT_TEACHER', '1') != '0' else False
+        return self._tstream
+
     def optimize_parameters(self):
         self.finish_G_update()
+        ts = None
         if self.opt.online_distillation:
             T = self.teacher_model
             T._defer_G_update = True
-            T.set_input(self.input)
-            T.optimize_parameters()
+            ts = self._teacher_stream()
+            if ts:
+                ts.wait_stream(torch.cuda.current_stream())      # after everything that still reads the teacher's buffers
+                with torch.cuda.stream(ts):
+                    T.set_input(self.input)
+                    T.optimize_parameters()
+            else:
+                T.set_input(self.input)
+                T.optimize_parameters()
             # the reference clones; here the teacher's activation buffers of this iteration are
             # simply not overwritten before the student consumes them (separate contexts)
             self.target_distillation_features = T.get_distillation_features()
@@ -490,6 +508,8 @@ class Pix2PixModel(nn.Module):
         self.optimizer_D.step()
         self.D.repack()
         self.optimizer_G.zero_grad()
+        if ts:
+            torch.cuda.current_stream().wait_stream(ts)          # the generator step reads the teacher's features
         self.backward_G()
         if self._defer_G_update and self._world > 1:
             # online teacher under data parallelism: its generator is not read again before the arch
@@ -531,11 +551,14 @@ class Pix2PixModel(nn.Module):
         self.current_D_arch_diff_loss = out
         return cf, cr
 
-    def backward_D_arch(self):
+    def backward_D_arch(self, ts=None):
         T = self.teacher_model
-        T.get_D_arch_diff(isTeacher=True)
-        ops.scalar_op(2, T._l('teacher_D_arch_diff'), T._l('teacher_D_arch_diff'), self._l('teacher_D_arch_diff'), k0=0.0)
+        if not ts:
+            T.get_D_arch_diff(isTeacher=True)
         cf, cr = self.get_D_arch_diff(isTeacher=False)
+        if ts:
+            torch.cuda.current_stream().wait_stream(ts)          # the teacher's difference was computed on its stream
+        ops.scalar_op(2, T._l('teacher_D_arch_diff'), T._l('teacher_D_arch_diff'), self._l('teacher_D_arch_diff'), k0=0.0)
         # loss_D_arch = |d_S - d_T| + (L_real + L_fake)/2 ; coefficients of the three hinge gradients
         ops.arch_coeffs(self._l('D_arch_fake_real'), self._l('D_arch_fake'), self._l('D_arch_real'),
                         self._l('teacher_D_arch_diff'), self._l('D_arch'), self._l('arch_c_fr'), self._l('arch_c_f'))
@@ -549,13 +572,23 @@ class Pix2PixModel(nn.Module):
         self.D.backward(cr, wgrad=False, agrad=True, need_dx=False)
 
     def optimizer_netD_arch(self):
-        self.forward()
         T = self.teacher_model
-        T.finish_G_update()
-        T.set_input(self.input)
-        T.forward()
+        ts = self._teacher_stream()
+        if ts:
+            ts.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ts):
+                T.finish_G_update()
+                T.set_input(self.input)
+                T.forward()
+                T.get_D_arch_diff(isTeacher=True)
+            self.forward()
+        else:
+            self.forward()
+            T.finish_G_update()
+            T.set_input(self.input)
+            T.forward()
         self.optimizer_arch.zero_grad()
-        self.backward_D_arch()
+        self.backward_D_arch(ts)
         self._allreduce(self.optimizer_arch)
         self.optimizer_arch.step()
 

@@ -104,8 +104,9 @@ def ceil8(v):
 
 
 def workspace(nbytes, device, slot='default'):
-    """Grow-only scratch buffer per (device, slot); all users are ordered on one stream."""
-    key = (str(device), slot)
+    """Grow-only scratch buffer per (device, slot, stream): all users of one buffer are ordered on one stream (the online
+    teacher may run on its own stream next to the student's)."""
+    key = (str(device), slot, stream())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -124,7 +125,8 @@ class SideStream:
 
     @classmethod
     def get(cls, device):
-        key = str(device)
+        """the side stream that belongs to the CURRENT stream of `device`"""
+        key = (str(device), stream())
         if key not in cls._inst:
             cls._inst[key] = SideStream(device)
         return cls._inst[key]
