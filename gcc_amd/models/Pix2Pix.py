@@ -389,6 +389,11 @@ class Pix2PixModel(nn.Module):
             self._fake_nchw = ops.nhwc_to_nchw(self._fake, 3)
         return self._fake_nchw
 
+    @property
+    def Tfake_B(self):
+        """the teacher's generated image of the same batch (models/Pix2Pix.py:523; a visual, converted on demand)"""
+        return self.teacher_model.fake_B
+
     # -- helpers ------------------------------------------------------------------------------
     def _pack_pair(self, ctx, second):
         """ctx.x_in = cat(real_A, second) along channels (3 + 3, zero-filled to 8)"""
@@ -417,7 +422,9 @@ class Pix2PixModel(nn.Module):
         self.D.backward(cr, wgrad=True, need_dx=False)
 
     # -- G step (models/Pix2Pix.py:513-552) --------------------------------------------------------
-    def backward_G(self):
+    def backward_G(self, ts=None):
+        """ts: the online teacher's stream -- joined only where its features are first read (the student's own GAN / L1
+        terms and the discriminator's data gradient do not depend on it)"""
         opt, mode = self.opt, self.opt.gan_mode
         gc = self._gctx
         cg = self._d_forward('g_fake', self._fake)
@@ -427,9 +434,10 @@ class Pix2PixModel(nn.Module):
         ops.l1_loss(self._fake, self._B, self._l('G_L1'), weight=opt.lambda_L1, da=gc.g_out)
         ops.nhwc_add(dx, 3, gc.g_out, 0, 3)
         g_feat = None
+        if ts:
+            torch.cuda.current_stream().wait_stream(ts)
         if self.distill:
             T = self.teacher_model
-            self.Tfake_B = T.fake_B
             # teacher D (train mode, frozen) on the student's fake: features for the last two terms (:531-533)
             ct = T._d_forward('on_student', self._fake)
             feats = self.G.features(gc) + T.D.features(ct)
@@ -458,6 +466,7 @@ class Pix2PixModel(nn.Module):
             ops.SideStream.get(self.device).join()
             dx2 = T.D.backward(ct, has_pred_grad=False, g_feat=[dtf[4], dtf[5]], wgrad=False, need_dx=True)
             ops.nhwc_add(dx2, 3, gc.g_out, 0, 3)
+            self._mark_teacher_free()
         self.G.backward(gc, g_feat=g_feat, wgrad=True)
 
     def _tbuf(self, i, N, C, H, W):
@@ -483,6 +492,18 @@ class Pix2PixModel(nn.Module):
             self._tstream = torch.cuda.Stream(device=self.device) if os.environ.get('GCC_CONCURRENT_TEACHER', '1') != '0' else False
         return self._tstream
 
+    def _mark_teacher_free(self):
+        """main stream: no later launch reads the teacher's buffers -- its stream may move on from here"""
+        self._teacher_free = torch.cuda.Event()
+        self._teacher_free.record(torch.cuda.current_stream())
+
+    def _release_teacher_stream(self, ts):
+        ev = getattr(self, '_teacher_free', None)
+        if ev is not None:
+            ts.wait_event(ev)
+        else:
+            ts.wait_stream(torch.cuda.current_stream())
+
     def optimize_parameters(self):
         self.finish_G_update()
         ts = None
@@ -491,7 +512,7 @@ class Pix2PixModel(nn.Module):
             T._defer_G_update = True
             ts = self._teacher_stream()
             if ts:
-                ts.wait_stream(torch.cuda.current_stream())      # after everything that still reads the teacher's buffers
+                self._release_teacher_stream(ts)                 # after the last launch that reads the teacher's buffers
                 with torch.cuda.stream(ts):
                     T.set_input(self.input)
                     T.optimize_parameters()
@@ -508,9 +529,7 @@ class Pix2PixModel(nn.Module):
         self.optimizer_D.step()
         self.D.repack()
         self.optimizer_G.zero_grad()
-        if ts:
-            torch.cuda.current_stream().wait_stream(ts)          # the generator step reads the teacher's features
-        self.backward_G()
+        self.backward_G(ts)
         if self._defer_G_update and self._world > 1:
             # online teacher under data parallelism: its generator is not read again before the arch
             # step, so its (largest, 218 MB) gradient bucket is reduced while the student's whole
@@ -559,6 +578,7 @@ class Pix2PixModel(nn.Module):
         if ts:
             torch.cuda.current_stream().wait_stream(ts)          # the teacher's difference was computed on its stream
         ops.scalar_op(2, T._l('teacher_D_arch_diff'), T._l('teacher_D_arch_diff'), self._l('teacher_D_arch_diff'), k0=0.0)
+        self._mark_teacher_free()
         # loss_D_arch = |d_S - d_T| + (L_real + L_fake)/2 ; coefficients of the three hinge gradients
         ops.arch_coeffs(self._l('D_arch_fake_real'), self._l('D_arch_fake'), self._l('D_arch_real'),
                         self._l('teacher_D_arch_diff'), self._l('D_arch'), self._l('arch_c_fr'), self._l('arch_c_f'))
@@ -575,7 +595,7 @@ class Pix2PixModel(nn.Module):
         T = self.teacher_model
         ts = self._teacher_stream()
         if ts:
-            ts.wait_stream(torch.cuda.current_stream())
+            self._release_teacher_stream(ts)
             with torch.cuda.stream(ts):
                 T.finish_G_update()
                 T.set_input(self.input)
