@@ -560,7 +560,9 @@ static int bwd_blocks(size_t pixels, const Layout& L) {
     const size_t per = small ? (size_t)L.PPB * 8 : (size_t)L.PPB * 8 * 4;
     size_t b = (pixels + per - 1) / per;
     if (b < 1) b = 1;
-    const size_t cap = small ? 1024 : 256;
+    static int capv = -1;
+    if (capv < 0) { const char* e = getenv("GCC_BN_REDUCE_CAP"); capv = e ? atoi(e) : 1024; }
+    const size_t cap = small ? (size_t)capv : 256;
     if (b > cap) b = cap;
     return (int)b;
 }
