@@ -195,14 +195,34 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwArgs a) {
         }
     }
 }
-__global__ void dwconv_wgrad_finalize_kernel(const float* partial, int blocks, int C, int C4, float* dw, float* db) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    for (int t = 0; t < 10; t++) {
-        double acc = 0.0;
-        for (int b = 0; b < blocks; b++) acc += partial[((size_t)b * 10 + t) * C4 + c];
-        if (t < 9) dw[(size_t)c * 9 + t] += (float)acc;
-        else if (db) db[c] += (float)acc;
+// grid (ceil(C / 32), 10 taps [9 = bias]); 256 threads = 32 channels x 8 slices of the partial rows; fixed order, so deterministic
+__global__ __launch_bounds__(256) void dwconv_wgrad_finalize_kernel(const float* partial, int blocks, int C, int C4, float* dw,
+                                                                    float* db) {
+    __shared__ double red[8][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl, t = blockIdx.y;
+    double acc = 0.0;
+    if (c < C) {
+        const float* p = partial + (size_t)t * C4 + c;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int b = sl;
+        for (; b + 24 < blocks; b += 32) {
+            a0 += p[(size_t)b * 10 * C4];
+            a1 += p[(size_t)(b + 8) * 10 * C4];
+            a2 += p[(size_t)(b + 16) * 10 * C4];
+            a3 += p[(size_t)(b + 24) * 10 * C4];
+        }
+        for (; b < blocks; b += 8) a0 += p[(size_t)b * 10 * C4];
+        acc = ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    }
+    red[sl][cl] = acc;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) v += red[q][cl];
+        if (t < 9) dw[(size_t)c * 9 + t] += (float)v;
+        else if (db) db[c] += (float)v;
     }
 }
 
@@ -276,7 +296,7 @@ extern "C" int gcc_dwconv3x3_reflect_wgrad(const void* x, int ldx, const void* d
     const int blocks = dw_blocks((size_t)N * H * W, a.PPB, 512);
     hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     GCC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dwconv_wgrad_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(dwconv_wgrad_finalize_kernel, dim3((C + 31) / 32, 10), dim3(256), 0, (hipStream_t)stream,
                        (const float*)ws, blocks, C, a.CH4 * 4, dw, dbias);
     GCC_CHECK_LAUNCH();
     return GCC_OK;

@@ -27,6 +27,7 @@ from .._lib import GccError
 from ..utils import util
 from .DifferentiableOp import DifferentiableOP
 from .Pix2Pix import HipAdam, MobileResnetGenerator, _patchgan_tree, _portable
+from ._streams import TeacherStreamMixin
 
 HEAVY_SPARSITY = ('model.1', 'model.4', 'model.19', 'model.22')      # models/CycleGAN.py:243, 548-569
 
@@ -77,7 +78,7 @@ class ImagePool:
         return out
 
 
-class MobileCycleGANModel(nn.Module):
+class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
 
     def __init__(self, opt, cfg_AtoB=None, cfg_BtoA=None):
         super().__init__()
@@ -265,7 +266,7 @@ class MobileCycleGANModel(nn.Module):
         gdist.all_reduce_grads(optimizer)
 
     # -- generators (:480-546) ------------------------------------------------------------------------
-    def backward_G(self):
+    def backward_G(self, ts=None):
         opt, mode, c = self.opt, self.opt.gan_mode, self._ctx
         lam = {'A': opt.lambda_A, 'B': opt.lambda_B}
         real = {'A': self._A, 'B': self._B}
@@ -289,7 +290,10 @@ class MobileCycleGANModel(nn.Module):
             ops.nhwc_add(dxd, 0, cf.g_out, 0, 3)
             g_feat = None
             if self.distill:
+                self._join(ts)              # first read of the teacher's features
                 g_feat = self._distill_side(w, cf, T._ctx[fake])
+                if w == 'B':
+                    self._mark_teacher_free()
             self.G[w].backward(cf, g_feat=g_feat)
 
     def _distill_side(self, w, cf, tcf):
@@ -342,16 +346,20 @@ class MobileCycleGANModel(nn.Module):
 
     # -- one iteration (:571-590) -------------------------------------------------------------------------
     def optimize_parameters(self):
+        ts = None
         if self.opt.online_distillation:
             T = self.teacher_model
-            T.set_input(self.input)
-            T.optimize_parameters()
+
+            def teacher_step():
+                T.set_input(self.input)
+                T.optimize_parameters()
+            ts = self._run_teacher(teacher_step)
             # the reference clones; here the teacher's activation buffers are not overwritten before they are consumed
             self.target_distillation_A_features = T.get_distillation_features(AorB='A')
             self.target_distillation_B_features = T.get_distillation_features(AorB='B')
         self.forward()
         self.optimizer_G.zero_grad()
-        self.backward_G()
+        self.backward_G(ts)
         self._allreduce(self.optimizer_G)
         self.optimizer_G.step()          # L1_sparsity() (:548-569) is fused into the Adam kernel, per-tensor weights
         for w in 'AB':
@@ -385,13 +393,17 @@ class MobileCycleGANModel(nn.Module):
         self._ema_started = True
         return ctxs
 
-    def backward_D_arch(self):
+    def backward_D_arch(self, ts=None):
         T, mode = self.teacher_model, self.opt.gan_mode
-        T.get_D_arch_diff(isTeacher=True)
+        if not ts:
+            T.get_D_arch_diff(isTeacher=True)
         ctxs = self.get_D_arch_diff(isTeacher=False)
+        self._join(ts)
+        for w in 'AB':
+            ops.scalar_op(2, T._l('teacher_diff_' + w), T._l('teacher_diff_' + w), self._l('teacher_diff_' + w), k0=0.0)
+        self._mark_teacher_free()
         for w in 'AB':
             cf, cr = ctxs[w]
-            ops.scalar_op(2, T._l('teacher_diff_' + w), T._l('teacher_diff_' + w), self._l('teacher_diff_' + w), k0=0.0)
             ops.arch_coeffs(self._l('arch_fake_real_' + w), self._l('arch_fake_' + w), self._l('arch_real_' + w),
                             self._l('teacher_diff_' + w), self._l('D_arch_' + w), self._l('arch_c_fr_' + w),
                             self._l('arch_c_f_' + w))
@@ -404,12 +416,17 @@ class MobileCycleGANModel(nn.Module):
             self.D[w].backward(cr, wgrad=False, agrad=True, need_dx=False)
 
     def optimizer_netD_arch(self):
-        self.forward()
         T = self.teacher_model
-        T.set_input(self.input)
-        T.forward()
+
+        def teacher_part():
+            T.set_input(self.input)
+            T.forward()
+            if self._teacher_stream():
+                T.get_D_arch_diff(isTeacher=True)
+        ts = self._run_teacher(teacher_part)
+        self.forward()
         self.optimizer_arch.zero_grad()
-        self.backward_D_arch()
+        self.backward_D_arch(ts)
         self._allreduce(self.optimizer_arch)
         self.optimizer_arch.step()
 

@@ -24,6 +24,7 @@ from .. import engine, ops
 from .._lib import GccError
 from ..utils import util
 from .DifferentiableOp import DifferentiableOP
+from ._streams import TeacherStreamMixin
 
 
 # ------------------------------------------------------------------------------------------------
@@ -224,7 +225,7 @@ class HipAdam(torch.optim.Optimizer):
 
 
 # ------------------------------------------------------------------------------------------------
-class Pix2PixModel(nn.Module):
+class Pix2PixModel(TeacherStreamMixin, nn.Module):
 
     def __init__(self, opt, filter_cfgs=None, channel_cfgs=None):
         super().__init__()
@@ -482,28 +483,6 @@ class Pix2PixModel(nn.Module):
         return self._dist_ws[key]
 
     # -- one iteration (models/Pix2Pix.py:565-583) ----------------------------------------------------
-    def _teacher_stream(self):
-        """the online teacher's own HIP stream (GCC_CONCURRENT_TEACHER=0 turns it off): its iteration only has to be
-        finished when the student's generator step reads its features, so the student's forward and discriminator step run
-        next to it -- the small U-Net layers of the two networks, which cannot fill the chip alone, overlap"""
-        if getattr(self, 'serialize_streams', False):           # bench.py's profiled steps: every launch's duration is its own
-            return False
-        if getattr(self, '_tstream', None) is None:
-            self._tstream = torch.cuda.Stream(device=self.device) if os.environ.get('GCC_CONCURRENT_TEACHER', '1') != '0' else False
-        return self._tstream
-
-    def _mark_teacher_free(self):
-        """main stream: no later launch reads the teacher's buffers -- its stream may move on from here"""
-        self._teacher_free = torch.cuda.Event()
-        self._teacher_free.record(torch.cuda.current_stream())
-
-    def _release_teacher_stream(self, ts):
-        ev = getattr(self, '_teacher_free', None)
-        if ev is not None:
-            ts.wait_event(ev)
-        else:
-            ts.wait_stream(torch.cuda.current_stream())
-
     def optimize_parameters(self):
         self.finish_G_update()
         ts = None

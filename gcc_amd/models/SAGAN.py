@@ -30,6 +30,7 @@ from .._lib import GccError
 from ..utils import util
 from .DifferentiableOp import DifferentiableOP
 from .Pix2Pix import HipAdam, _portable
+from ._streams import TeacherStreamMixin
 
 
 def l2normalize(v, eps=1e-12):
@@ -138,7 +139,7 @@ def _is_dup(name):
     return ('.module.' in name) or ('_conv.' in name)
 
 
-class SAGANModel(nn.Module):
+class SAGANModel(TeacherStreamMixin, nn.Module):
 
     def __init__(self, opt, filter_cfgs=None, channel_cfgs=None):
         super().__init__()
@@ -295,7 +296,7 @@ class SAGANModel(nn.Module):
         self.D.backward(cf, wgrad=True, need_dx=False)
 
     # -- G step (:460-494) ------------------------------------------------------------------------------------
-    def backward_G(self):
+    def backward_G(self, ts=None):
         opt, mode, gc = self.opt, self.opt.gan_mode, self._gctx
         cg = self._d_forward('g_fake', self._fake)
         self._dctx_g = cg
@@ -306,6 +307,7 @@ class SAGANModel(nn.Module):
         if self.distill:
             T = self.teacher_model
             N = gc.N
+            self._join(ts)                                       # first read of the teacher's state
             ct = T._d_forward('on_student', self._fake)          # teacher D (frozen) on the student's fake: not detached
             feats = self.G.features(gc) + T.D.features(ct)
             tf, dtf = [], []
@@ -333,14 +335,19 @@ class SAGANModel(nn.Module):
             tmp = self._buf('l1', N, 3, 64, 64)
             ops.l1_loss(self._fake, T._fake, self._l('L1'), weight=opt.lambda_L1, da=tmp)
             ops.nhwc_add(tmp, 0, gc.g_out, 0, 3)
+            self._mark_teacher_free()
         self.G.backward(gc, g_feat=g_feat, wgrad=True)
 
     # -- one iteration (:508-528) -----------------------------------------------------------------------------
     def optimize_parameters(self):
+        ts = None
         if self.opt.online_distillation:
             T = self.teacher_model
-            T.set_input(self.input)
-            T.optimize_parameters()
+
+            def teacher_step():
+                T.set_input(self.input)
+                T.optimize_parameters()
+            ts = self._run_teacher(teacher_step)
             self.target_distillation_features = T.get_distillation_features()
         self.forward()
         self.optimizer_D.zero_grad()
@@ -349,7 +356,7 @@ class SAGANModel(nn.Module):
         self.optimizer_D.step()
         self.D.repack()
         self.optimizer_G.zero_grad()
-        self.backward_G()
+        self.backward_G(ts)
         self._allreduce(self.optimizer_G)
         self.optimizer_G.step()          # L1_sparsity() (:496-506) is fused into the Adam kernel
         self.G.repack()
@@ -373,11 +380,14 @@ class SAGANModel(nn.Module):
         self._ema_started = True
         return cf, cr
 
-    def backward_D_arch(self):
+    def backward_D_arch(self, ts=None):
         T, mode = self.teacher_model, self.opt.gan_mode
-        T.get_D_arch_diff(isTeacher=True)
-        ops.scalar_op(2, T._l('teacher_D_arch_diff'), T._l('teacher_D_arch_diff'), self._l('teacher_D_arch_diff'), k0=0.0)
+        if not ts:
+            T.get_D_arch_diff(isTeacher=True)
         cf, cr = self.get_D_arch_diff(isTeacher=False)
+        self._join(ts)
+        ops.scalar_op(2, T._l('teacher_D_arch_diff'), T._l('teacher_D_arch_diff'), self._l('teacher_D_arch_diff'), k0=0.0)
+        self._mark_teacher_free()
         # loss_D_arch = |d_S - d_T| + L_real + L_fake  (no 1/2 here, :388-389)
         ops.arch_coeffs(self._l('D_arch_fake_real'), self._l('D_arch_fake'), self._l('D_arch_real'),
                         self._l('teacher_D_arch_diff'), self._l('D_arch'), self._l('arch_c_fr'), self._l('arch_c_f'), weight=1.0)
@@ -390,12 +400,17 @@ class SAGANModel(nn.Module):
         self.D.backward(cr, wgrad=False, agrad=True, need_dx=False)
 
     def optimizer_netD_arch(self):
-        self.forward()
         T = self.teacher_model
-        T.set_input(self.input)
-        T.forward()
+
+        def teacher_part():
+            T.set_input(self.input)
+            T.forward()
+            if self._teacher_stream():
+                T.get_D_arch_diff(isTeacher=True)
+        ts = self._run_teacher(teacher_part)
+        self.forward()
         self.optimizer_arch.zero_grad()
-        self.backward_D_arch()
+        self.backward_D_arch(ts)
         self._allreduce(self.optimizer_arch)
         self.optimizer_arch.step()
 

@@ -28,6 +28,7 @@ from .._lib import GccError
 from ..utils import util
 from .DifferentiableOp import DifferentiableOP
 from .Pix2Pix import HipAdam, _portable
+from ._streams import TeacherStreamMixin
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
@@ -150,7 +151,7 @@ class TruncatedVGG19(nn.Module):
         self.truncated_vgg19.load_state_dict({k: sd['features.' + k] for k in own})
 
 
-class SRGAN(nn.Module):
+class SRGAN(TeacherStreamMixin, nn.Module):
 
     def __init__(self, opt, filter_cfgs=None, channel_cfgs=None, vgg_widths=None):
         super().__init__()
@@ -348,7 +349,7 @@ class SRGAN(nn.Module):
         gdist.all_reduce_grads(optimizer)
 
     # -- generator (:446-480) ---------------------------------------------------------------------------------------
-    def backward_G(self):
+    def backward_G(self, ts=None):
         opt, mode, gc = self.opt, self.opt.gan_mode, self._gctx
         N, _, H, W = self._fake.shape
         g_img = self._buf('g_img', N, 3, H, W)               # dL/d(fake_hr in [-1, 1]) from the MSE content term
@@ -372,6 +373,7 @@ class SRGAN(nn.Module):
         g_feat = None
         if self.distill:
             T = self.teacher_model
+            self._join(ts)                                       # first read of the teacher's state
             ct = T._d_forward('on_student', self._fake_n)
             feats = self.G.features(gc) + T.D.features(ct)
             tf, dtf = [], []
@@ -399,6 +401,7 @@ class SRGAN(nn.Module):
             tmp = self._buf('l1', N, 3, H, W)
             ops.l1_loss(self._fake_n, T._fake_n, self._l('L1'), weight=opt.lambda_L1, da=tmp)
             ops.nhwc_add(tmp, 0, g_n, 0, 3)
+            self._mark_teacher_free()
         # chain rule through the normalisation: d(fake_n)/d(fake) = 1 / (2 std_c)
         ops.bnact_fwd(g_n, g_n, scale=self._norm_scale, shift=self._zero3)
         ops.nhwc_copy(g_img, 0, gc.g_out, 0, 3)
@@ -418,14 +421,18 @@ class SRGAN(nn.Module):
         self.D.backward(cf, wgrad=True, need_dx=False)
 
     def optimize_parameters(self):
+        ts = None
         if self.opt.online_distillation:
             T = self.teacher_model
-            T.set_input(self.input)
-            T.optimize_parameters()
+
+            def teacher_step():
+                T.set_input(self.input)
+                T.optimize_parameters()
+            ts = self._run_teacher(teacher_step)
             self.target_distillation_features = T.get_distillation_features()
         self.forward()
         self.optimizer_G.zero_grad()
-        self.backward_G()
+        self.backward_G(ts)
         self._allreduce(self.optimizer_G)
         self.optimizer_G.step()
         self.G.repack()
@@ -478,11 +485,14 @@ class SRGAN(nn.Module):
         self._ema_started = True
         return cf, cr
 
-    def backward_D_arch(self):
+    def backward_D_arch(self, ts=None):
         T, mode = self.teacher_model, self.opt.gan_mode
-        T.get_D_arch_diff(isTeacher=True)
-        ops.scalar_op(2, T._l('teacher_D_arch_diff'), T._l('teacher_D_arch_diff'), self._l('teacher_D_arch_diff'), k0=0.0)
+        if not ts:
+            T.get_D_arch_diff(isTeacher=True)
         cf, cr = self.get_D_arch_diff(isTeacher=False)
+        self._join(ts)
+        ops.scalar_op(2, T._l('teacher_D_arch_diff'), T._l('teacher_D_arch_diff'), self._l('teacher_D_arch_diff'), k0=0.0)
+        self._mark_teacher_free()
         ops.arch_coeffs(self._l('D_arch_fake_real'), self._l('D_arch_fake'), self._l('D_arch_real'),
                         self._l('teacher_D_arch_diff'), self._l('D_arch'), self._l('arch_c_fr'), self._l('arch_c_f'), weight=1.0)
         gp = self.D.grad_pred_buffer(cf)
@@ -494,12 +504,17 @@ class SRGAN(nn.Module):
         self.D.backward(cr, wgrad=False, agrad=True, need_dx=False)
 
     def optimizer_netD_arch(self):
-        self.forward()
         T = self.teacher_model
-        T.set_input(self.input)
-        T.forward()
+
+        def teacher_part():
+            T.set_input(self.input)
+            T.forward()
+            if self._teacher_stream():
+                T.get_D_arch_diff(isTeacher=True)
+        ts = self._run_teacher(teacher_part)
+        self.forward()
         self.optimizer_arch.zero_grad()
-        self.backward_D_arch()
+        self.backward_D_arch(ts)
         self._allreduce(self.optimizer_arch)
         self.optimizer_arch.step()
 

@@ -1,0 +1,49 @@
+"""Stream schedule shared by the model classes: the online teacher's iteration runs on its own HIP stream.
+
+The teacher's step and the student's forward / teacher-independent loss terms have no data dependence, so they are
+enqueued on two streams; the student's stream joins the teacher's where the teacher's features are first read, and the
+teacher's stream is released by an event recorded at the last main-stream launch that reads its buffers.  The many small
+layers of the two networks, which cannot fill 256 CUs alone, overlap; the arithmetic is unchanged.
+``GCC_CONCURRENT_TEACHER=0`` (or ``model.serialize_streams = True``, used by bench.py's profiled steps) keeps everything
+on one stream."""
+import os
+
+import torch
+
+
+class TeacherStreamMixin:
+    def _teacher_stream(self):
+        if getattr(self, 'serialize_streams', False):
+            return False
+        if getattr(self, '_tstream', None) is None:
+            on = os.environ.get('GCC_CONCURRENT_TEACHER', '1') != '0'
+            self._tstream = torch.cuda.Stream(device=self.device) if on else False
+        return self._tstream
+
+    def _mark_teacher_free(self):
+        """main stream: no later launch reads the teacher's buffers -- its stream may move on from here"""
+        self._teacher_free = torch.cuda.Event()
+        self._teacher_free.record(torch.cuda.current_stream())
+
+    def _release_teacher_stream(self, ts):
+        ev = getattr(self, '_teacher_free', None)
+        if ev is not None:
+            ts.wait_event(ev)
+        else:
+            ts.wait_stream(torch.cuda.current_stream())
+
+    def _run_teacher(self, fn):
+        """run fn() (teacher work) on the teacher's stream if there is one; returns the stream (or False)"""
+        ts = self._teacher_stream()
+        if ts:
+            self._release_teacher_stream(ts)
+            with torch.cuda.stream(ts):
+                fn()
+        else:
+            fn()
+        return ts
+
+    @staticmethod
+    def _join(ts):
+        if ts:
+            torch.cuda.current_stream().wait_stream(ts)
