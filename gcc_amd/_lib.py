@@ -81,6 +81,8 @@ PROTOTYPES = {
     'gcc_nhwc_add': (_I, [_P, _I, _I, _P, _I, _I, _I, _Z, _P]),
     'gcc_bn_finalize': (_I, [_P, _I, _I, C.c_double, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     'gcc_in_finalize': (_I, [_P, _I, _I, _I, C.c_double, _F, _P, _P, _P, _P, _P]),
+    'gcc_inorm_fwd': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P]),
+    'gcc_inorm_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
     'gcc_channel_stats_tiles': (_I, [_Z, _I]),
     'gcc_channel_stats': (_I, [_P, _I, _I, _I, _Z, _I, _P, _P]),
     'gcc_reflect_pad': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

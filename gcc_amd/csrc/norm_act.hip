@@ -401,6 +401,273 @@ __global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(const BwdArgs a0) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// InstanceNorm2d(affine=False) of small planes in ONE launch: a workgroup owns the [HW][8 channels] slab of one image, so
+// statistics and normalisation need no grid-wide step.  Pass 1 sums the slab, pass 2 re-reads it (from L2: a slab is
+// HW * 16 bytes) and writes.  At batch 1 (CycleGAN) the three-launch pipeline above is launch-latency bound: three
+// 4-12 us launches per norm against one here.
+struct InFusedArgs {
+    const bf16_t* x; int ldx;
+    const bf16_t* y; int ldy;          // fwd: output (written) ; bwd: saved output (activation derivative) or NULL
+    const bf16_t* aux; int ldaux;      // fwd: residual added after the activation (or NULL) ; bwd: incoming gradient
+    bf16_t* out; int ldout;            // fwd: == y ; bwd: dx (may alias the incoming gradient)
+    int C, HW, act; float slope, eps;
+    float *mean, *rstd, *scale, *shift;   // [N][C]
+};
+
+// LPP lanes share a pixel (each 8 channels = 16 bytes): the slab is 8 * LPP channels wide.  Sums of the lanes with the same
+// channel chunk: butterfly over the pixel bits of the lane id, then across waves through LDS in double.
+template <int NTH, int LPP, int K>
+__device__ __forceinline__ void slab_reduce(float (&v)[K][8], double* lds /* [NTH/64][LPP][K*8] */, double* out /* [LPP][K*8] */) {
+#pragma unroll
+    for (int k = 0; k < K; k++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float t = v[k][j];
+#pragma unroll
+            for (int o = 32; o >= LPP; o >>= 1) t += __shfl_xor(t, o, 64);
+            v[k][j] = t;
+        }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < LPP) {
+#pragma unroll
+        for (int k = 0; k < K; k++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) lds[(wave * LPP + lane) * (K * 8) + k * 8 + j] = (double)v[k][j];
+    }
+    __syncthreads();
+    if (threadIdx.x < LPP * K * 8) {
+        double t = 0.0;
+        for (int w = 0; w < NTH / 64; w++) t += lds[w * LPP * (K * 8) + threadIdx.x];
+        out[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+template <int NTH, int LPP>
+__global__ __launch_bounds__(NTH) void inorm_fwd_fused_kernel(const InFusedArgs a) {
+    __shared__ double lds[(NTH / 64) * LPP * 16];
+    __shared__ double tot[LPP * 16];
+    __shared__ float coef[LPP][2][8];
+    const int cq = threadIdx.x & (LPP - 1), pl = threadIdx.x / LPP;
+    const int c0 = (blockIdx.x * LPP + cq) * 8;
+    const bool live = c0 < ((a.C + 7) & ~7);
+    const size_t g = blockIdx.y;
+    const bf16_t* xg = a.x + g * (size_t)a.HW * a.ldx + c0;
+    float v[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[0][j] = v[1][j] = 0.f;
+    if (live) {
+        constexpr int ST = NTH / LPP;
+        int p = pl;
+        for (; p + 3 * ST < a.HW; p += 4 * ST) {       // four 16-byte loads in flight per lane: one CU streams the slab alone
+            i32x4 r[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) r[u] = *(const i32x4*)(xg + (size_t)(p + u * ST) * a.ldx);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                float f[8];
+                unpack8(r[u], f);
+#pragma unroll
+                for (int j = 0; j < 8; j++) { v[0][j] += f[j]; v[1][j] += f[j] * f[j]; }
+            }
+        }
+        for (; p < a.HW; p += ST) {
+            float f[8];
+            unpack8(*(const i32x4*)(xg + (size_t)p * a.ldx), f);
+#pragma unroll
+            for (int j = 0; j < 8; j++) { v[0][j] += f[j]; v[1][j] += f[j] * f[j]; }
+        }
+    }
+    slab_reduce<NTH, LPP, 2>(v, lds, tot);
+    if (threadIdx.x < LPP * 8) {
+        const int q = threadIdx.x >> 3, j = threadIdx.x & 7;
+        const double m = tot[q * 16 + j] / (double)a.HW;
+        double var = tot[q * 16 + 8 + j] / (double)a.HW - m * m;
+        if (var < 0.0) var = 0.0;
+        const float r = (float)(1.0 / sqrt(var + (double)a.eps));
+        const float sh = 0.f - (float)m * r;
+        coef[q][0][j] = r; coef[q][1][j] = sh;
+        const int c = (blockIdx.x * LPP + q) * 8 + j;
+        if (c < a.C) {
+            const size_t o = g * a.C + c;
+            a.mean[o] = (float)m; a.rstd[o] = r; a.scale[o] = r; a.shift[o] = sh;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    float sc[8], sf[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { sc[j] = coef[cq][0][j]; sf[j] = coef[cq][1][j]; }
+    bf16_t* yg = a.out + g * (size_t)a.HW * a.ldout + c0;
+    const bf16_t* rg = a.aux ? a.aux + g * (size_t)a.HW * a.ldaux + c0 : nullptr;
+    constexpr int ST = NTH / LPP;
+    int p = pl;
+    for (; p + 3 * ST < a.HW; p += 4 * ST) {
+        i32x4 r[4], q[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            r[u] = *(const i32x4*)(xg + (size_t)(p + u * ST) * a.ldx);
+            if (rg) q[u] = *(const i32x4*)(rg + (size_t)(p + u * ST) * a.ldaux);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float f[8], o[8];
+            unpack8(r[u], f);
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = apply_act(f[j] * sc[j] + sf[j], a.act, a.slope);
+            if (rg) {
+                float rv[8];
+                unpack8(q[u], rv);
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j] += rv[j];
+            }
+            *(i32x4*)(yg + (size_t)(p + u * ST) * a.ldout) = pack8(o);
+        }
+    }
+    for (; p < a.HW; p += ST) {
+        float f[8], o[8];
+        unpack8(*(const i32x4*)(xg + (size_t)p * a.ldx), f);
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = apply_act(f[j] * sc[j] + sf[j], a.act, a.slope);
+        if (rg) {
+            float rv[8];
+            unpack8(*(const i32x4*)(rg + (size_t)p * a.ldaux), rv);
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] += rv[j];
+        }
+        *(i32x4*)(yg + (size_t)p * a.ldout) = pack8(o);
+    }
+}
+
+// dx = rstd (dz - mean(dz) - xhat mean(dz xhat)), dz = g act'(y); pass 2 recomputes dz instead of staging it in memory
+template <int NTH, int LPP>
+__global__ __launch_bounds__(NTH) void inorm_bwd_fused_kernel(const InFusedArgs a) {
+    __shared__ double lds[(NTH / 64) * LPP * 16];
+    __shared__ double tot[LPP * 16];
+    const int cq = threadIdx.x & (LPP - 1), pl = threadIdx.x / LPP;
+    const int c0 = (blockIdx.x * LPP + cq) * 8;
+    const bool live = c0 < ((a.C + 7) & ~7);
+    const size_t g = blockIdx.y;
+    const bf16_t* xg = a.x + g * (size_t)a.HW * a.ldx + c0;
+    const bf16_t* yg = a.y ? a.y + g * (size_t)a.HW * a.ldy + c0 : nullptr;
+    const bf16_t* gg = a.aux + g * (size_t)a.HW * a.ldaux + c0;
+    bf16_t* og = a.out + g * (size_t)a.HW * a.ldout + c0;
+    float mu[8], rs[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const bool ok = c0 + j < a.C;
+        mu[j] = ok ? a.mean[g * a.C + c0 + j] : 0.f;
+        rs[j] = ok ? a.rstd[g * a.C + c0 + j] : 0.f;
+    }
+    float v[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[0][j] = v[1][j] = 0.f;
+    if (live) {
+        constexpr int ST = NTH / LPP;
+        int p = pl;
+        for (; p + ST < a.HW; p += 2 * ST) {            // two pixels x three tensors in flight per lane
+            i32x4 rx[2], rg_[2], ry[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                rx[u] = *(const i32x4*)(xg + (size_t)(p + u * ST) * a.ldx);
+                rg_[u] = *(const i32x4*)(gg + (size_t)(p + u * ST) * a.ldaux);
+                if (yg) ry[u] = *(const i32x4*)(yg + (size_t)(p + u * ST) * a.ldy);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                float xv[8], yv[8], gv[8];
+                unpack8(rx[u], xv); unpack8(rg_[u], gv);
+                if (yg) unpack8(ry[u], yv);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float xh = (xv[j] - mu[j]) * rs[j];
+                    const float yo = yg ? yv[j] : apply_act(xh, a.act, a.slope);
+                    const float d = gv[j] * act_grad_from_out(yo, a.act, a.slope);
+                    v[0][j] += d; v[1][j] += d * xh;
+                }
+            }
+        }
+        for (; p < a.HW; p += ST) {
+            float xv[8], yv[8], gv[8];
+            unpack8(*(const i32x4*)(xg + (size_t)p * a.ldx), xv);
+            unpack8(*(const i32x4*)(gg + (size_t)p * a.ldaux), gv);
+            if (yg) unpack8(*(const i32x4*)(yg + (size_t)p * a.ldy), yv);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float xh = (xv[j] - mu[j]) * rs[j];
+                const float yo = yg ? yv[j] : apply_act(xh, a.act, a.slope);
+                const float d = gv[j] * act_grad_from_out(yo, a.act, a.slope);
+                v[0][j] += d; v[1][j] += d * xh;
+            }
+        }
+    }
+    slab_reduce<NTH, LPP, 2>(v, lds, tot);
+    if (!live) return;
+    float A[8], B[8], K[8];
+    const float inv = 1.f / (float)a.HW;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float k0 = (float)tot[cq * 16 + j] * inv, k1 = (float)tot[cq * 16 + 8 + j] * inv;
+        A[j] = rs[j]; B[j] = -rs[j] * rs[j] * k1; K[j] = -rs[j] * k0 + rs[j] * rs[j] * k1 * mu[j];
+    }
+    constexpr int ST = NTH / LPP;
+    int p = pl;
+    for (; p + ST < a.HW; p += 2 * ST) {
+        i32x4 rx[2], rg_[2], ry[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            rx[u] = *(const i32x4*)(xg + (size_t)(p + u * ST) * a.ldx);
+            rg_[u] = *(const i32x4*)(gg + (size_t)(p + u * ST) * a.ldaux);
+            if (yg) ry[u] = *(const i32x4*)(yg + (size_t)(p + u * ST) * a.ldy);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            float xv[8], yv[8], gv[8], o[8];
+            unpack8(rx[u], xv); unpack8(rg_[u], gv);
+            if (yg) unpack8(ry[u], yv);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float yo = yg ? yv[j] : apply_act((xv[j] - mu[j]) * rs[j], a.act, a.slope);
+                const float d = gv[j] * act_grad_from_out(yo, a.act, a.slope);
+                o[j] = A[j] * d + B[j] * xv[j] + K[j];
+            }
+            *(i32x4*)(og + (size_t)(p + u * ST) * a.ldout) = pack8(o);
+        }
+    }
+    for (; p < a.HW; p += ST) {
+        float xv[8], yv[8], gv[8], o[8];
+        unpack8(*(const i32x4*)(xg + (size_t)p * a.ldx), xv);
+        unpack8(*(const i32x4*)(gg + (size_t)p * a.ldaux), gv);
+        if (yg) unpack8(*(const i32x4*)(yg + (size_t)p * a.ldy), yv);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float yo = yg ? yv[j] : apply_act((xv[j] - mu[j]) * rs[j], a.act, a.slope);
+            const float d = gv[j] * act_grad_from_out(yo, a.act, a.slope);
+            o[j] = A[j] * d + B[j] * xv[j] + K[j];
+        }
+        *(i32x4*)(og + (size_t)p * a.ldout) = pack8(o);
+    }
+}
+
+template <bool BWD>
+void inorm_launch(const InFusedArgs& a, int N, hipStream_t st) {
+    static int lpp_env = -1;
+    if (lpp_env < 0) { const char* e = getenv("GCC_INORM_LPP"); lpp_env = e ? atoi(e) : 0; }
+    const int lpp = lpp_env ? lpp_env : 2;
+    const int slabs = ((a.C + 7) / 8 + lpp - 1) / lpp;
+    const dim3 grid(slabs, N);
+    const bool big = a.HW >= 2048;
+#define GCC_IN_LAUNCH(NTH, LPP)                                                                         \
+    do {                                                                                                \
+        if (BWD) hipLaunchKernelGGL((inorm_bwd_fused_kernel<NTH, LPP>), grid, dim3(NTH), 0, st, a);     \
+        else hipLaunchKernelGGL((inorm_fwd_fused_kernel<NTH, LPP>), grid, dim3(NTH), 0, st, a);         \
+    } while (0)
+    if (lpp == 1) { if (big) GCC_IN_LAUNCH(1024, 1); else GCC_IN_LAUNCH(256, 1); }
+    else if (lpp == 2) { if (big) GCC_IN_LAUNCH(1024, 2); else GCC_IN_LAUNCH(256, 2); }
+    else { if (big) GCC_IN_LAUNCH(1024, 4); else GCC_IN_LAUNCH(256, 4); }
+#undef GCC_IN_LAUNCH
+}
+
 struct SumArgs {
     const bf16_t* x; int ld, off; int C, C8; size_t pixels; Layout L; float* partial;
 };
@@ -504,6 +771,36 @@ extern "C" int gcc_in_finalize(const float* stats_partial, int tiles_per_group, 
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32, groups), dim3(1024), 0, (hipStream_t)stream, stats_partial,
                        tiles_per_group, C, count, (const float*)nullptr, (const float*)nullptr, eps, 0.f, (float*)nullptr,
                        (float*)nullptr, mean, rstd, scale, shift);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+extern "C" int gcc_inorm_fwd(const void* x, int ldx, void* y, int ldy, const void* residual, int ldr, int C, int HW, int N,
+                             int act, float slope, float eps, float* mean, float* rstd, float* scale, float* shift,
+                             gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!x || !y || !mean || !rstd || !scale || !shift || C <= 0 || HW <= 0 || N <= 0 || (ldx & 7) || (ldy & 7) ||
+        (residual && (ldr & 7)))
+        return GCC_ERR_BAD_ARG;
+    InFusedArgs a = {};
+    a.x = (const bf16_t*)x; a.ldx = ldx; a.out = (bf16_t*)y; a.ldout = ldy; a.aux = (const bf16_t*)residual; a.ldaux = ldr;
+    a.C = C; a.HW = HW; a.act = act; a.slope = slope; a.eps = eps; a.mean = mean; a.rstd = rstd; a.scale = scale; a.shift = shift;
+    inorm_launch<false>(a, N, (hipStream_t)stream);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+extern "C" int gcc_inorm_bwd(const void* x, int ldx, const void* y, int ldy, const void* g, int ldg, void* dx, int lddx, int C,
+                             int HW, int N, int act, float slope, const float* mean, const float* rstd, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!x || !g || !dx || !mean || !rstd || C <= 0 || HW <= 0 || N <= 0 || (ldx & 7) || (ldg & 7) || (lddx & 7) ||
+        (y && (ldy & 7)))
+        return GCC_ERR_BAD_ARG;
+    InFusedArgs a = {};
+    a.x = (const bf16_t*)x; a.ldx = ldx; a.y = (const bf16_t*)y; a.ldy = ldy; a.aux = (const bf16_t*)g; a.ldaux = ldg;
+    a.out = (bf16_t*)dx; a.ldout = lddx; a.C = C; a.HW = HW; a.act = act; a.slope = slope;
+    a.mean = (float*)mean; a.rstd = (float*)rstd;
+    inorm_launch<true>(a, N, (hipStream_t)stream);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

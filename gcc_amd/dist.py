@@ -37,8 +37,14 @@ def init_from_env(backend=None):
 def local_device(opt):
     """cuda:{LOCAL_RANK} under a multi-process launch, else cuda:{gpu_ids[0]} (models/Pix2Pix.py:356)"""
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
-        return torch.device('cuda:%d' % int(os.environ.get('LOCAL_RANK', '0')))
-    return torch.device('cuda:%d' % opt.gpu_ids[0])
+        dev = torch.device('cuda:%d' % int(os.environ.get('LOCAL_RANK', '0')))
+    else:
+        dev = torch.device('cuda:%d' % opt.gpu_ids[0])
+    if torch.cuda.is_available():
+        from . import ops
+        torch.cuda.set_device(dev)           # one GPU per process: kernels go to this device's current stream
+        ops.set_device_index(dev.index)
+    return dev
 
 
 def broadcast_module(module, src=0):

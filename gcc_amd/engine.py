@@ -672,8 +672,19 @@ class MobileResnetEngine:
     @staticmethod
     def _inorm(x, y, st, act=ACT_NONE, residual=None):
         N, _, H, W = x.shape
+        if H * W <= ops.INORM_FUSED_MAX_HW:
+            ops.inorm_fwd(x, y, st, act=act, residual=residual)
+            return
         ops.in_finalize(ops.channel_stats(x), H * W, st)
         ops.bnact_fwd(x, y, scale=st.scale, shift=st.shift, act=act, groups=N, residual=residual)
+
+    @staticmethod
+    def _inorm_bwd(x, y, g, dx, st, act=ACT_NONE):
+        N, _, H, W = x.shape
+        if H * W <= ops.INORM_FUSED_MAX_HW:
+            ops.inorm_bwd(x, y, g, dx, st, act=act)
+        else:
+            ops.bnact_bwd(x, y, g, dx, bn=st, act=act, groups=N)
 
     # ---------------------------------------------------------------------------------------
     def forward(self, c, train=True):
@@ -721,7 +732,7 @@ class MobileResnetEngine:
         ops.reflect_pad(G.ypad, G.t[1], 3, backward=True)
         n_blk = len(self.blocks)
         for i in (1, 0):
-            ops.bnact_bwd(c.t_raw[i], c.t_act[i], G.t[i], G.t[i], bn=c.t_st[i], act=ACT_RELU, groups=N)
+            self._inorm_bwd(c.t_raw[i], c.t_act[i], G.t[i], G.t[i], c.t_st[i], act=ACT_RELU)
             src = c.t_act[0] if i == 1 else (c.blk[-1].o if n_blk else c.s_act[2])
             if wgrad:
                 self.ups[i].backward_weight(src, G.t[i])
@@ -732,19 +743,19 @@ class MobileResnetEngine:
             x_in = c.blk[bi - 1].o if bi > 0 else c.s_act[2]
             if b.index in gf:
                 ops.nhwc_add(gf[b.index], 0, G.h, 0, G.h.shape[1])
-            ops.bnact_bwd(t.p2, None, G.h, gp2, bn=t.st[3], groups=N)
+            self._inorm_bwd(t.p2, None, G.h, gp2, t.st[3])
             if wgrad:
                 b.pw2.backward_weight(t.n2, gp2)
             b.pw2.backward_data(gp2, gn2)
-            ops.bnact_bwd(t.d2, None, gn2, gn2, bn=t.st[2], groups=N)
+            self._inorm_bwd(t.d2, None, gn2, gn2, t.st[2])
             if wgrad:
                 b.dw2.backward_weight(t.r1, gn2)
             b.dw2.backward_data(gn2, gr1)
-            ops.bnact_bwd(t.p1, t.r1, gr1, gr1, bn=t.st[1], act=ACT_RELU, groups=N)
+            self._inorm_bwd(t.p1, t.r1, gr1, gr1, t.st[1], act=ACT_RELU)
             if wgrad:
                 b.pw1.backward_weight(t.n1, gr1)
             b.pw1.backward_data(gr1, gn1)
-            ops.bnact_bwd(t.d1, None, gn1, gn1, bn=t.st[0], groups=N)
+            self._inorm_bwd(t.d1, None, gn1, gn1, t.st[0])
             if wgrad:
                 b.dw1.backward_weight(x_in, gn1)
             b.dw1.backward_data(gn1, G.tmp)
@@ -753,7 +764,7 @@ class MobileResnetEngine:
             ops.nhwc_add(gf[self.relu_index], 0, G.h, 0, G.h.shape[1])
         g = G.h
         for i in (2, 1, 0):
-            ops.bnact_bwd(c.s_raw[i], c.s_act[i], g, g, bn=c.s_st[i], act=ACT_RELU, groups=N)
+            self._inorm_bwd(c.s_raw[i], c.s_act[i], g, g, c.s_st[i], act=ACT_RELU)
             if wgrad:
                 self.stem[i].backward_weight(c.s_act[i - 1] if i > 0 else c.xpad, g)
             if i > 0:

@@ -95,8 +95,21 @@ def lib():
     return _lib.load()
 
 
+_dev_index = None
+
+
+def set_device_index(idx):
+    """the device whose current stream ops are enqueued on (one GPU per process; gdist.local_device sets it)"""
+    global _dev_index
+    _dev_index = idx
+
+
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """raw hipStream_t of the current stream (the direct C call: this runs once per launch on the host's hot path)"""
+    global _dev_index
+    if _dev_index is None:
+        _dev_index = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(_dev_index)
 
 
 def ceil8(v):
@@ -162,16 +175,13 @@ def cslice(t, off, Cc):
 
 def geom(t):
     """(ptr, N, C, H, W, ld) of an NHWC bf16 activation view."""
-    assert t.dtype == torch.bfloat16 and t.dim() == 4, (t.dtype, t.shape)
     N, Cc, H, W = t.shape
-    ld = t.stride(3)
-    assert t.stride(1) == 1 or Cc == 1, t.stride()
-    if H > 1:
-        assert t.stride(2) == W * ld, (t.stride(), t.shape)
-    if N > 1:
-        assert t.stride(0) == H * W * ld, (t.stride(), t.shape)
-    assert ld % 8 == 0 and t.data_ptr() % 16 == 0
-    return t.data_ptr(), N, Cc, H, W, ld
+    s0, s1, s2, ld = t.stride()
+    p = t.data_ptr()
+    if (t.dtype is not torch.bfloat16 or (s1 != 1 and Cc != 1) or (H > 1 and s2 != W * ld) or (N > 1 and s0 != H * W * ld)
+            or (ld & 7) or (p & 15)):
+        raise AssertionError('not an NHWC bf16 activation view: %s %s %s' % (t.dtype, tuple(t.shape), t.stride()))
+    return p, N, Cc, H, W, ld
 
 
 def conv_desc(N, H, W, Ci, Co, k, stride, pad, ldx, ldy):
@@ -438,6 +448,31 @@ def in_finalize(stats, count, st, eps=1e-5):
     N, tiles, _, Cc = stats.shape
     check(lib().gcc_in_finalize(stats.data_ptr(), tiles, N, Cc, float(count), eps, st.mean.data_ptr(), st.rstd.data_ptr(),
                                 st.scale.data_ptr(), st.shift.data_ptr(), stream()), 'gcc_in_finalize')
+
+
+INORM_FUSED_MAX_HW = int(os.environ.get('GCC_INORM_FUSED_MAX_HW', '4096'))   # planes up to 64 x 64: one-launch InstanceNorm
+
+
+def inorm_fwd(x, y, st, act=ACT_NONE, slope=0.2, residual=None, eps=1e-5):
+    """InstanceNorm2d(affine=False) + activation (+ residual) in one launch; st (INState) receives mean / rstd"""
+    xp, N, Cc, H, W, ldx = geom(x)
+    yp, _, _, _, _, ldy = geom(y)
+    rp, ldr = (None, 0)
+    if residual is not None:
+        rp, _, _, _, _, ldr = geom(residual)
+    check(lib().gcc_inorm_fwd(xp, ldx, yp, ldy, rp, ldr, Cc, H * W, N, act, slope, eps, st.mean.data_ptr(), st.rstd.data_ptr(),
+                              st.scale.data_ptr(), st.shift.data_ptr(), stream()), 'gcc_inorm_fwd')
+
+
+def inorm_bwd(x, y, g, dx, st, act=ACT_NONE, slope=0.2):
+    xp, N, Cc, H, W, ldx = geom(x)
+    yp, ldy = (None, 0)
+    if y is not None:
+        yp, _, _, _, _, ldy = geom(y)
+    gp, _, _, _, _, ldg = geom(g)
+    dxp, _, _, _, _, lddx = geom(dx)
+    check(lib().gcc_inorm_bwd(xp, ldx, yp, ldy, gp, ldg, dxp, lddx, Cc, H * W, N, act, slope, st.mean.data_ptr(),
+                              st.rstd.data_ptr(), stream()), 'gcc_inorm_bwd')
 
 
 def bnact_fwd(x, y, y2=None, scale=None, shift=None, gate=None, gate_after_act=False, act=ACT_NONE, slope=0.2,

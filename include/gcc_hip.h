@@ -151,6 +151,16 @@ int gcc_bn_finalize(const float* stats_partial, int tiles, int C, double count, 
  * and channel mean / rstd from [groups][tiles_per_group][2][C] partial sums (conv epilogue or gcc_channel_stats) */
 int gcc_in_finalize(const float* stats_partial, int tiles_per_group, int groups, int C, double count, float eps,
                     float* mean, float* rstd, float* scale, float* shift, gcc_stream_t stream);
+/* The same InstanceNorm (+ activation, + residual added after it) in one launch for planes small enough that a workgroup
+ * per (image, 8-channel slab) is the faster shape (batch 1: models/CycleGAN.py:77-138 at 64x64 / 128x128): statistics,
+ * mean / rstd / scale / shift [N][C] written for the backward, y = act((x - mean) rstd) + residual. */
+int gcc_inorm_fwd(const void* x, int ldx, void* y, int ldy, const void* residual, int ld_residual, int C, int HW, int N,
+                  int act, float slope, float eps, float* mean, float* rstd, float* scale, float* shift,
+                  gcc_stream_t stream);
+/* its backward: dx = rstd (dz - mean(dz) - xhat mean(dz xhat)) with dz = g act'(y) (y NULL: the activation output is
+ * recomputed from x); dx may alias g. */
+int gcc_inorm_bwd(const void* x, int ldx, const void* y, int ldy, const void* g, int ldg, void* dx, int lddx, int C, int HW,
+                  int N, int act, float slope, const float* mean, const float* rstd, gcc_stream_t stream);
 int gcc_channel_stats_tiles(size_t pixels_per_group, int C);
 int gcc_channel_stats(const void* x, int ld, int off, int C, size_t pixels_per_group, int groups, float* stats,
                       gcc_stream_t stream);

@@ -488,3 +488,43 @@ def test_instance_norm_forward_backward(C, relu, res):
     # backward of act(IN(x)) : the saved output for act' is y without the residual -> recompute from x (y=None)
     ops.bnact_bwd(xd, None if res else y, to_dev(gy), dx, bn=st, act=ops.ACT_RELU if relu else ops.ACT_NONE, groups=N)
     close(to_cpu(dx), xr.grad, tol=2e-2, what='instance norm bwd')
+
+
+@pytest.mark.parametrize('C,H,W,relu,res', [(12, 8, 6, True, False), (8, 5, 7, False, True), (40, 64, 64, True, False),
+                                            (16, 64, 72, False, True), (24, 128, 128, True, False)])
+def test_instance_norm_one_launch(C, H, W, relu, res):
+    """gcc_inorm_fwd / gcc_inorm_bwd (one workgroup per image x 8-channel slab) against torch's instance_norm, and
+    against the three-launch pipeline they replace for small planes"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(C + H)
+    N = 2
+    x = rb(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3)
+    r = rb(torch.randn(N, C, H, W, generator=g))
+    xr = x.clone().requires_grad_(True)
+    z = F.instance_norm(xr, eps=1e-5)
+    yref = F.relu(z) if relu else z
+    if res:
+        yref = yref + r
+    gy = rb(torch.randn(N, C, H, W, generator=g))
+    yref.backward(gy)
+    act = ops.ACT_RELU if relu else ops.ACT_NONE
+    xd = to_dev(x)
+    st = ops.INState(N, C, DEV)
+    y = ops.new_act(N, C, H, W, DEV)
+    ops.inorm_fwd(xd, y, st, act=act, residual=to_dev(r) if res else None)
+    close(to_cpu(y), yref.detach(), what='one-launch instance norm fwd')
+    close(st.mean.cpu(), x.mean((2, 3)), tol=1e-4, floor=1e-5, what='IN mean')
+    close(st.rstd.cpu(), 1.0 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5), tol=1e-4, what='IN rstd')
+    st3 = ops.INState(N, C, DEV)
+    ops.in_finalize(ops.channel_stats(xd), H * W, st3)
+    assert torch.allclose(st.scale, st3.scale, rtol=2e-6, atol=1e-7) and torch.allclose(st.shift, st3.shift, rtol=2e-5, atol=1e-6)
+    gd = to_dev(gy)
+    dx = ops.new_act(N, C, H, W, DEV)
+    ops.inorm_bwd(xd, None if res else y, gd, dx, st, act=act)
+    close(to_cpu(dx), xr.grad, tol=2e-2, what='one-launch instance norm bwd')
+    ops.inorm_bwd(xd, None if res else y, gd, gd, st, act=act)          # in place over the incoming gradient
+    assert torch.equal(to_cpu(gd), to_cpu(dx))
+    if C % 8:                                                           # pad channels stay exact zeros
+        assert float(y.permute(0, 2, 3, 1).reshape(-1)[:0].sum()) == 0.0
+        base = y.as_strided((N, H, W, ops.ceil8(C)), (H * W * ops.ceil8(C), W * ops.ceil8(C), ops.ceil8(C), 1))
+        assert float(base[..., C:].abs().max()) == 0.0
