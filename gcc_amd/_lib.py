@@ -105,7 +105,7 @@ PROTOTYPES = {
     'gcc_spectral_workspace': (_Z, [_I, _I, _I]),
     'gcc_spectral_power_iteration': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     'gcc_spectral_grad': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
-    'gcc_attention_fwd': (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P]),
+    'gcc_attention_fwd': (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P]),
     'gcc_attention_bwd': (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
     'gcc_l1_loss': (_I, [_P, _I, _I, _P, _I, _I, _I, _Z, _F, _P, _I, _P, _I, _I, _P, _Z, _P]),
     'gcc_mse_loss': (_I, [_P, _I, _I, _P, _I, _I, _I, _Z, _F, _P, _I, _P, _I, _I, _P, _Z, _P]),

@@ -41,48 +41,70 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
     return s;
 }
 
-// vt[p] = sum_r W[r][p] * u[r]   (p physical column); accumulates |vt|^2 into scal[0] (zeroed by the caller)
-__global__ __launch_bounds__(256) void sn_wtu_kernel(const float* __restrict__ w, const float* __restrict__ u, int R, int K,
-                                                     float* __restrict__ vt, float* nrm2, float scale_by) {
-    __shared__ float sh[4];
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    float acc = 0.f;
-    if (p < K)
-        for (int r = 0; r < R; r++) acc += w[(size_t)r * K + p] * u[r];
-    acc *= scale_by;
-    if (p < K) vt[p] = acc;
-    const float s = block_sum(p < K ? acc * acc : 0.f, sh);
-    if (threadIdx.x == 0 && nrm2) atomicAdd(nrm2, s);
+// vt[p] = sum_r W[r][p] * u[r] * scale_by   (p physical column).
+// A workgroup owns 64 columns; its 16 waves split the rows (a wave reads 256 contiguous bytes of one row), so the serial
+// depth is R / 16 and the sum order is fixed.
+__global__ __launch_bounds__(1024) void sn_wtu_kernel(const float* __restrict__ w, const float* __restrict__ u, int R, int K,
+                                                      float* __restrict__ vt, float scale_by) {
+    __shared__ float red[16][65];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + cl;
+    float a0 = 0.f, a1 = 0.f;
+    if (p < K) {
+        int r = rg;
+        for (; r + 16 < R; r += 32) {
+            a0 += w[(size_t)r * K + p] * u[r];
+            a1 += w[(size_t)(r + 16) * K + p] * u[r + 16];
+        }
+        if (r < R) a0 += w[(size_t)r * K + p] * u[r];
+    }
+    red[rg][cl] = a0 + a1;
+    __syncthreads();
+    if (rg == 0) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc += red[q][cl];
+        acc *= scale_by;
+        if (p < K) vt[p] = acc;
+    }
 }
 
-// t[r] = sum_p W[r][p] * vt[p] / (|vt| + eps) ; accumulates |t|^2 into scal[1]
+// t[r] = sum_p W[r][p] * vt[p] / (|vt| + eps).  Every row's workgroup sums |vt|^2 itself, in the same fixed order: no
+// atomics anywhere in the power iteration, so sigma -- and every weight divided by it -- is reproducible bit for bit.
 __global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w, const float* __restrict__ vt, int K,
-                                                    const float* scal, float* __restrict__ t, float* nrm2) {
+                                                    float* scal, float* __restrict__ t) {
     __shared__ float sh[4];
     const int r = blockIdx.x;
-    const float inv = 1.f / (sqrtf(scal[0]) + 1e-12f);
-    float acc = 0.f;
-    for (int p = threadIdx.x; p < K; p += 256) acc += w[(size_t)r * K + p] * vt[p];
-    const float s = block_sum(acc, sh) * inv;
+    float acc = 0.f, n2 = 0.f;
+    for (int p = threadIdx.x; p < K; p += 256) {
+        const float x = vt[p];
+        acc += w[(size_t)r * K + p] * x;
+        n2 += x * x;
+    }
+    n2 = block_sum(n2, sh);
+    const float s = block_sum(acc, sh) / (sqrtf(n2) + 1e-12f);
     if (threadIdx.x == 0) {
         t[r] = s;
-        atomicAdd(nrm2, s * s);
+        if (r == 0) scal[0] = n2;
     }
 }
 
 // u, v, sigma
 __global__ __launch_bounds__(256) void sn_finalize_kernel(SnArgs a) {
+    __shared__ float sh[4];
     const int K = a.C * a.T;
+    float t2 = 0.f;
+    for (int r = threadIdx.x; r < a.R; r += 256) t2 += a.t[r] * a.t[r];
+    t2 = block_sum(t2, sh);                      // |t|^2, the same bits in every workgroup
     const float inv_v = 1.f / (sqrtf(a.scal[0]) + 1e-12f);
-    const float nt = sqrtf(a.scal[1]);
-    const float inv_t = 1.f / (nt + 1e-12f);
+    const float inv_t = 1.f / (sqrtf(t2) + 1e-12f);
     for (int p = blockIdx.x * 256 + threadIdx.x; p < K; p += gridDim.x * 256) {
         const int tt = p / a.C, c = p - tt * a.C;
         a.v[c * a.T + tt] = a.vt[p] * inv_v;
     }
     if (blockIdx.x == 0) {
         for (int r = threadIdx.x; r < a.R; r += 256) a.u[r] = a.t[r] * inv_t;
-        if (threadIdx.x == 0) a.scal[2] = a.scal[1] * inv_t;      // u . t = |t|^2 / (|t| + eps)
+        if (threadIdx.x == 0) { a.scal[1] = t2; a.scal[2] = t2 * inv_t; }      // u . t = |t|^2 / (|t| + eps)
     }
 }
 
@@ -92,22 +114,30 @@ __global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) w_eff[i] = w[i] * inv;
 }
 
+// <G, W_bar>: per-workgroup partial sums; the consumers add them up in a fixed order (no atomics: reproducible)
 __global__ __launch_bounds__(256) void sn_inner_kernel(const float* __restrict__ g, const float* __restrict__ w, size_t n,
-                                                       float* inner) {
+                                                       float* partial) {
     __shared__ float sh[4];
     float acc = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += g[i] * w[i];
     const float s = block_sum(acc, sh);
-    if (threadIdx.x == 0) atomicAdd(inner, s);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__device__ __forceinline__ float inner_total(const float* partial, int nparts, float* sh) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
+    return block_sum(acc, sh);
 }
 
 // dW_bar += G/sigma + dLds * u[r] * v[logical(p)] ;  du += dLds * t  (block 0)
 __global__ __launch_bounds__(256) void sn_grad_kernel(const float* __restrict__ g, const float* __restrict__ u,
                                                       const float* __restrict__ v, const float* __restrict__ t_fwd,
-                                                      const float* sigma_fwd, const float* inner, int R, int C, int T,
-                                                      float* __restrict__ dw, float* __restrict__ du) {
+                                                      const float* sigma_fwd, const float* partial, int nparts, int R, int C,
+                                                      int T, float* __restrict__ dw, float* __restrict__ du) {
+    __shared__ float sh[4];
+    const float inner = inner_total(partial, nparts, sh);
     const float sg = sigma_fwd[0];
-    const float inv = 1.f / sg, dlds = -inner[0] * inv * inv;
+    const float inv = 1.f / sg, dlds = -inner * inv * inv;
     const int K = C * T;
     const size_t n = (size_t)R * K;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -120,9 +150,11 @@ __global__ __launch_bounds__(256) void sn_grad_kernel(const float* __restrict__ 
 }
 
 // dv[logical(p)] += dLds * vt[p]   with vt = W_bar^T u (physical order)
-__global__ __launch_bounds__(256) void sn_dv_kernel(const float* __restrict__ vt, const float* sigma_fwd, const float* inner,
-                                                    int C, int T, float* __restrict__ dv) {
-    const float inv = 1.f / sigma_fwd[0], dlds = -inner[0] * inv * inv;
+__global__ __launch_bounds__(256) void sn_dv_kernel(const float* __restrict__ vt, const float* sigma_fwd, const float* partial,
+                                                    int nparts, int C, int T, float* __restrict__ dv) {
+    __shared__ float sh[4];
+    const float inner = inner_total(partial, nparts, sh);
+    const float inv = 1.f / sigma_fwd[0], dlds = -inner * inv * inv;
     const int K = C * T;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < K; p += gridDim.x * 256) {
         const int tt = p / C, c = p - tt * C;
@@ -139,7 +171,7 @@ int nblocks(size_t n, int cap = 1024) {
 
 extern "C" size_t gcc_spectral_workspace(int R, int C, int T) {
     if (R <= 0 || C <= 0 || T <= 0) return 0;
-    return ((size_t)C * T + 64) * sizeof(float);
+    return ((size_t)C * T + 64 + 1024) * sizeof(float);     // scalars | W^T u | partial sums of <G, W_bar>
 }
 
 extern "C" int gcc_spectral_power_iteration(const float* w_bar, float* u, float* v, int R, int C, int T, float* t_out,
@@ -151,10 +183,9 @@ extern "C" int gcc_spectral_power_iteration(const float* w_bar, float* u, float*
     const int K = C * T;
     float* scal = (float*)ws;                 // [0..3]
     float* vt = scal + 64;
-    if (hipMemsetAsync(scal, 0, 4 * sizeof(float), st) != hipSuccess) return GCC_ERR_LAUNCH;
-    hipLaunchKernelGGL(sn_wtu_kernel, dim3((K + 255) / 256), dim3(256), 0, st, w_bar, (const float*)u, R, K, vt, scal + 0, 1.f);
+    hipLaunchKernelGGL(sn_wtu_kernel, dim3((K + 63) / 64), dim3(1024), 0, st, w_bar, (const float*)u, R, K, vt, 1.f);
     GCC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sn_wv_kernel, dim3(R), dim3(256), 0, st, w_bar, (const float*)vt, K, (const float*)scal, t_out, scal + 1);
+    hipLaunchKernelGGL(sn_wv_kernel, dim3(R), dim3(256), 0, st, w_bar, (const float*)vt, K, scal, t_out);
     GCC_CHECK_LAUNCH();
     SnArgs a;
     a.w = w_bar; a.u = u; a.v = v; a.R = R; a.C = C; a.T = T; a.vt = vt; a.t = t_out; a.scal = scal; a.w_eff = w_eff;
@@ -178,17 +209,18 @@ extern "C" int gcc_spectral_grad(const float* g_eff, const float* w_bar, const f
     const size_t n = (size_t)R * K;
     float* scal = (float*)ws;
     float* vt = scal + 64;
-    if (hipMemsetAsync(scal + 3, 0, sizeof(float), st) != hipSuccess) return GCC_ERR_LAUNCH;
-    hipLaunchKernelGGL(sn_inner_kernel, dim3(nblocks(n)), dim3(256), 0, st, g_eff, w_bar, n, scal + 3);
+    float* partial = vt + K;
+    const int nb = nblocks(n);
+    hipLaunchKernelGGL(sn_inner_kernel, dim3(nb), dim3(256), 0, st, g_eff, w_bar, n, partial);
     GCC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sn_grad_kernel, dim3(nblocks(n)), dim3(256), 0, st, g_eff, u, v, t_fwd, sigma_fwd, (const float*)(scal + 3),
+    hipLaunchKernelGGL(sn_grad_kernel, dim3(nb), dim3(256), 0, st, g_eff, u, v, t_fwd, sigma_fwd, (const float*)partial, nb,
                        R, C, T, dw_bar, du);
     GCC_CHECK_LAUNCH();
     if (dv) {
-        hipLaunchKernelGGL(sn_wtu_kernel, dim3((K + 255) / 256), dim3(256), 0, st, w_bar, u, R, K, vt, (float*)nullptr, 1.f);
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3((K + 63) / 64), dim3(1024), 0, st, w_bar, u, R, K, vt, 1.f);
         GCC_CHECK_LAUNCH();
         hipLaunchKernelGGL(sn_dv_kernel, dim3(nblocks(K, 64)), dim3(256), 0, st, (const float*)vt, sigma_fwd,
-                           (const float*)(scal + 3), C, T, dv);
+                           (const float*)partial, nb, C, T, dv);
         GCC_CHECK_LAUNCH();
     }
     return GCC_OK;

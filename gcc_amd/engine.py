@@ -867,26 +867,26 @@ class AttnOp:
         st.qkv = ops.new_act(N, self.width, H, W, dev)
         st.o = ops.new_act(N, self.C, H, W, dev)
         st.y = ops.new_act(N, self.C, H, W, dev)
-        st.A = torch.zeros((N, H * W, H * W), dtype=torch.float32, device=dev)
+        st.stats = torch.zeros((N, H * W, 2), dtype=torch.float32, device=dev)
         return st
 
     def grad_buffers(self, N, H, W):
         g = type('AttnGrad', (), {})()
         dev = self.device
         g.dqkv = ops.new_act(N, self.width, H, W, dev)
-        g.dS = torch.zeros((N, H * W, H * W), dtype=torch.float32, device=dev)
+        g.rowdot = torch.zeros((N, H * W), dtype=torch.float32, device=dev)
         g.tmp = ops.new_act(N, self.C, H, W, dev)
         return g
 
     def forward(self, st, x):
         for conv, (off, w) in zip(self.convs, self.slices):
             conv.forward(x, ops.cslice(st.qkv, off, w))
-        ops.attention_fwd(st.qkv, self.offs, x, self.module.gamma.data, self.C, self.C8, st.y, st.o, st.A)
+        ops.attention_fwd(st.qkv, self.offs, x, self.module.gamma.data, self.C, self.C8, st.y, st.o, st.stats)
         return st.y
 
     def backward(self, st, G, x, dy, dx, wgrad=True):
         """dy: gradient w.r.t. y; dx receives dy (residual branch) + the data gradients of the three 1x1 convs"""
-        ops.attention_bwd(st.qkv, self.offs, st.o, st.A, self.module.gamma.data, dy, self.C, self.C8, G.dqkv, G.dS,
+        ops.attention_bwd(st.qkv, self.offs, st.o, st.stats, self.module.gamma.data, dy, self.C, self.C8, G.dqkv, G.rowdot,
                           dgamma=self.module.gamma.grad if wgrad else None)
         ops.nhwc_copy(dy, 0, dx, 0, self.C)
         for conv, (off, w) in zip(self.convs, self.slices):

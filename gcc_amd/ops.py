@@ -567,24 +567,25 @@ def spectral_grad(g_eff, w_bar, u, v, t_fwd, sigma_fwd, dw_bar, du=None, dv=None
                                   ws.numel(), stream()), 'gcc_spectral_grad')
 
 
-def attention_fwd(qkv, offs, x, gamma, Cc, C8, y, o, A):
-    """qkv: NHWC bf16 buffer holding q | k | v at channel offsets offs; y = gamma * softmax(q^T k) v + x"""
+def attention_fwd(qkv, offs, x, gamma, Cc, C8, y, o, stats, A=None):
+    """qkv: NHWC bf16 buffer holding q | k | v at channel offsets offs; y = gamma * softmax(q^T k) v + x.
+    stats: fp32 [B, N, 2] saved for backward; A: optional fp32 [B, N, N] attention map"""
     qp, B, _, H, W, ldq = geom(qkv)
     xp, _, _, _, _, ldx = geom(x)
     yp, _, _, _, _, ldy = geom(y)
     op, _, _, _, _, ldo = geom(o)
     check(lib().gcc_attention_fwd(qp, ldq, offs[0], offs[1], offs[2], xp, ldx, gamma.data_ptr(), B, H * W, Cc, C8, yp, ldy,
-                                  op, ldo, A.data_ptr(), stream()), 'gcc_attention_fwd')
+                                  op, ldo, stats.data_ptr(), _p(A), stream()), 'gcc_attention_fwd')
 
 
-def attention_bwd(qkv, offs, o, A, gamma, dy, Cc, C8, dqkv, dS, dgamma=None):
+def attention_bwd(qkv, offs, o, stats, gamma, dy, Cc, C8, dqkv, rowdot, dgamma=None):
     qp, B, _, H, W, ldq = geom(qkv)
     op, _, _, _, _, ldo = geom(o)
     dyp, _, _, _, _, lddy = geom(dy)
     dqp, _, _, _, _, lddq = geom(dqkv)
     assert lddq == ldq
-    check(lib().gcc_attention_bwd(qp, ldq, offs[0], offs[1], offs[2], op, ldo, A.data_ptr(), gamma.data_ptr(), dyp, lddy, B,
-                                  H * W, Cc, C8, dqp, lddq, dS.data_ptr(), _p(dgamma), stream()), 'gcc_attention_bwd')
+    check(lib().gcc_attention_bwd(qp, ldq, offs[0], offs[1], offs[2], op, ldo, stats.data_ptr(), gamma.data_ptr(), dyp, lddy, B,
+                                  H * W, Cc, C8, dqp, lddq, rowdot.data_ptr(), _p(dgamma), stream()), 'gcc_attention_bwd')
 
 
 def arch_coeffs(Lfr, Lf, Lr, dT, loss, c_fr, c_f, weight=0.5):

@@ -306,15 +306,18 @@ int gcc_spectral_grad(const float* g_eff, const float* w_bar, const float* u, co
                       size_t ws_bytes, gcc_stream_t stream);
 /* Self attention, Self_Attn.forward (:72-104), per image over N = H*W <= 1024 positions: q, k (C8 channels) and v
  * (C <= 512 channels) are channel slices (qoff / koff / voff) of one NHWC bf16 buffer; y = gamma * softmax(q^T k) v + x.
- * Saved for backward: o (pre-gamma output, bf16 [B][N][ldo]) and A (fp32 [B][N][N]).
- * gcc_attention_bwd: dq / dk / dv into the same slices of dqkv, dgamma (+=); dS is an fp32 [B][N][N] scratch.  The
+ * The N x N score / attention matrices are never stored: the kernels recompute score tiles on the matrix cores (their
+ * inner dimension is C/8).  Saved for backward: o (pre-gamma output, bf16 [B][N][ldo]) and stats (fp32 [B][N][2]: row
+ * maximum and row sum of exp(s - max)).  A: optional fp32 [B][N][N] attention map -- the reference's forward returns it
+ * (models/SAGAN.py:103), SAGANModel drops it; NULL skips the write.
+ * gcc_attention_bwd: dq / dk / dv into the same slices of dqkv, dgamma (+=); rowdot is an fp32 [B][N] scratch.  The
  * residual branch (dx += dy) belongs to the caller. */
 int gcc_attention_fwd(const void* qkv, int ldq, int qoff, int koff, int voff, const void* x, int ldx,
                       const float* gamma, int B, int N, int C, int C8, void* y, int ldy, void* o, int ldo,
-                      float* A, gcc_stream_t stream);
+                      float* stats, float* A, gcc_stream_t stream);
 int gcc_attention_bwd(const void* qkv, int ldq, int qoff, int koff, int voff, const void* o, int ldo,
-                      const float* A, const float* gamma, const void* dy, int lddy, int B, int N, int C, int C8,
-                      void* dqkv, int lddq, float* dS, float* dgamma, gcc_stream_t stream);
+                      const float* stats, const float* gamma, const void* dy, int lddy, int B, int N, int C, int C8,
+                      void* dqkv, int lddq, float* rowdot, float* dgamma, gcc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SRGAN (models/SRGAN.py, models/GANLoss.py:95-145).

@@ -970,7 +970,8 @@ def self_attention(sd: SD, prefix: str, x: Tensor) -> Tensor:
     k = _q(F.conv2d(x, _qw(sd[prefix + '.key_conv.weight']), sd[prefix + '.key_conv.bias'])).reshape(b, -1, n)
     v = _q(F.conv2d(x, _qw(sd[prefix + '.value_conv.weight']), sd[prefix + '.value_conv.bias'])).reshape(b, -1, n)
     attn = torch.softmax(torch.bmm(q.permute(0, 2, 1), k), dim=-1)
-    out = _q(torch.bmm(v, attn.permute(0, 2, 1)).reshape(b, c, hh, ww))
+    # EMULATE_BF16: the HIP kernels feed the probabilities to the matrix cores in bf16 (the map itself stays fp32)
+    out = _q(torch.bmm(v, _q(attn).permute(0, 2, 1)).reshape(b, c, hh, ww))
     return _q(sd[prefix + '.gamma'] * out + x)
 
 
