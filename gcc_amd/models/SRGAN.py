@@ -621,3 +621,34 @@ class SRGAN(TeacherStreamMixin, nn.Module):
 
     def get_cfg(self):
         return self.filter_cfgs, self.channel_cfgs
+
+    # -- pruning (models/SRGAN.py:703-830): per-block inner widths from BatchNorm scales or filter norms ----------------
+    def max_min_bn_scale(self):
+        from ..utils import prune_util
+        return prune_util.srgan_max_min_bn_scale(self.netG)
+
+    def max_min_conv_norm(self):
+        from ..utils import prune_util
+        return prune_util.srgan_max_min_conv_norm(self.netG)
+
+    def _pruned(self, threshold, scale, lottery_path):
+        from ..utils import prune_util
+        cfgs, _ = prune_util.srgan_prune_cfg(self.netG, threshold, scale)
+        pruned = SRGAN(self.opt, filter_cfgs=cfgs)
+        if lottery_path is not None:
+            # the reference calls pruned_model.lottery_theory, which models/SRGAN.py does not define (:795, :828)
+            raise AttributeError("'SRGAN' object has no attribute 'lottery_theory'")
+        return pruned
+
+    def norm_prune(self, threshold, lottery_path=None):
+        return self._pruned(threshold, False, lottery_path)
+
+    def scale_prune(self, threshold, lottery_path=None):
+        return self._pruned(threshold, True, lottery_path)
+
+    def prune(self, threshold, lottery_path=None):
+        if self.opt.scale_prune:
+            return self.scale_prune(threshold, lottery_path)
+        elif self.opt.norm_prune:
+            return self.norm_prune(threshold, lottery_path)
+        raise NotImplementedError('only scale and norm pruning are supported!!!')

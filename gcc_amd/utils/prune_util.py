@@ -40,9 +40,137 @@ def unet_macs(netG, size=256):
 
 
 def get_flops_parms(model_netG, device, opt, verbose=False):
+    """utils/prune_util.py:6-18: the input is chosen by the dataroot, as there ('sr' -> low-resolution image,
+    'celeb' / 'church' -> z vector, else load_size image)"""
+    root = str(opt.dataroot)
+    if 'sr' in root:
+        return srresnet_macs(model_netG, opt.image_size // opt.upscale_factor)
+    if 'celeb' in root or 'church' in root:
+        return sagan_generator_macs(model_netG)
     if hasattr(model_netG.model, 'model'):          # UnetGenertor: model.model.<i>
         return unet_macs(model_netG, opt.load_size)
     return mobile_resnet_macs(model_netG, opt.load_size)
+
+
+def _params_m(net):
+    return sum(p.numel() for p in net.parameters()) / 1000 ** 2
+
+
+# ------------------------------------------------------------------------------------------------
+# SRGAN (models/SRGAN.py:703-830) and SAGAN (models/SAGAN.py:692-750) generators
+# ------------------------------------------------------------------------------------------------
+def srresnet_cfg_macs(n, cfgs, lr, n_blocks=16):
+    """G-MACs of Generator(n_channels=n, filter_cfgs=cfgs) on a 1x3xlrxlr input, thop convention as restated for the
+    other generators (conv: out elements * Cin * k^2; BatchNorm: 2 * elements; PReLU / Tanh / PixelShuffle: 0 --
+    thop counts PReLU in eval mode only and the search runs on a freshly built, training-mode net)"""
+    f = [n] * n_blocks if cfgs is None else [int(v) for v in cfgs]
+    s2 = lr * lr
+    total = s2 * n * 3 * 81                                            # conv_block1 (k9)
+    for fi in f:
+        total += s2 * (fi * n * 9 + n * fi * 9) + 2 * s2 * (fi + n)    # two k3 convs + their BatchNorms
+    total += s2 * n * n * 9 + 2 * s2 * n                               # conv_block2 + BatchNorm
+    total += s2 * 4 * n * n * 9 + 4 * s2 * 4 * n * n * 9               # sub-pixel convs at lr and 2 lr
+    total += 16 * s2 * 3 * n * 81                                      # conv_block3 (k9) at 4 lr
+    return total / 1000 ** 3
+
+
+def srresnet_macs(netG, lr):
+    n = netG.conv_block1.conv_block[0].weight.shape[0]
+    cfgs = [b.conv_block1.conv_block[0].weight.shape[0] for b in netG.residual_blocks]
+    return srresnet_cfg_macs(n, cfgs, lr, len(cfgs)), _params_m(netG)
+
+
+def _srgan_unprunable(kind):
+    """the reference's lists, typos included: the max/min scans repeat block 15 sixteen times instead of naming every
+    block, and a missing comma fuses two conv names (models/SRGAN.py:716-748); the cfg scans name every block
+    (:770-773, :804-806)"""
+    if kind == 'scan_bn':
+        return {'conv_block2.conv_block.1', 'residual_blocks.15.conv_block2.conv_block.1'}
+    if kind == 'scan_conv':
+        return {'conv_block3.0', 'conv_block2.conv_block.0' 'subpixel_convolutional_blocks.0.conv',
+                'subpixel_convolutional_blocks.1.conv', 'residual_blocks.15.conv_block2.conv_block.0'}
+    if kind == 'cfg_bn':
+        return {'conv_block2.conv_block.1'} | {'residual_blocks.%d.conv_block2.conv_block.1' % i for i in range(16)}
+    return ({'conv_block1.conv_block.0', 'conv_block2.conv_block.0', 'subpixel_convolutional_blocks.0.conv',
+             'subpixel_convolutional_blocks.1.conv'} | {'residual_blocks.%d.conv_block2.conv_block.0' % i for i in range(16)})
+
+
+def srgan_max_min_bn_scale(netG):
+    """models/SRGAN.py:712-731"""
+    skip = _srgan_unprunable('scan_bn')
+    top, low = None, None
+    for name, m in netG.named_modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            w = m.weight.detach().float().cpu()
+            if name not in skip:
+                top = w.max() if top is None else torch.min(w.max(), top)
+            low = w.min() if low is None else torch.min(w.min(), low)
+    return top, low
+
+
+def srgan_max_min_conv_norm(netG):
+    """models/SRGAN.py:733-761 (input-channel L1 norms for Conv2d, as written there)"""
+    skip = _srgan_unprunable('scan_conv')
+    top, low = None, None
+    for name, m in netG.named_modules():
+        if isinstance(m, torch.nn.Conv2d) and name not in skip:
+            nrm = m.weight.detach().float().cpu().abs().sum((0, 2, 3))
+            top = nrm.max() if top is None else torch.min(nrm.max(), top)
+            low = nrm.min() if low is None else torch.min(nrm.min(), low)
+    return top, low
+
+
+def srgan_prune_cfg(netG, threshold, scale):
+    """filter_cfgs of scale_prune (:800-821, BatchNorm gamma > t) or norm_prune (:766-787, filter L1 norm > t): one
+    entry per residual block's first conv"""
+    if torch.is_tensor(threshold):
+        threshold = threshold.detach().float().cpu()
+    cfgs, masks = [], []
+    skip = _srgan_unprunable('cfg_bn' if scale else 'cfg_conv')
+    for name, m in netG.named_modules():
+        if scale and isinstance(m, torch.nn.BatchNorm2d) and name not in skip:
+            mask = m.weight.detach().float().cpu() > threshold
+        elif (not scale) and isinstance(m, torch.nn.Conv2d) and name not in skip:
+            mask = m.weight.detach().float().cpu().abs().sum((1, 2, 3)) > threshold
+        else:
+            continue
+        masks.append(mask)
+        cfgs.append(int(mask.sum()))
+    return cfgs, masks
+
+
+def sagan_cfg_macs(widths, z_dim=128):
+    """G-MACs of the SAGAN Generator(image_size 64) with l1..l4 widths as the reference's profile() sees them: thop
+    counts through forward hooks, and SpectralNorm.forward calls ``self.module.forward`` directly (models/SAGAN.py:
+    66-68), so the four spectrally normalised ConvTranspose layers are NOT counted.  What is: BatchNorm 2 * elements,
+    the attention 1x1 convs, nn.Softmax as thop counts it (rows * (3 N - 1)) and the last ConvTranspose.  ngf 48 gives
+    0.0189 G, which is what makes the reference script's --target_budget 0.016 (tolerance 0.001) a pruning target."""
+    w = [int(v) for v in widths]
+    side = [4, 8, 16, 32]
+    total = 0
+    for i in range(4):
+        total += 2 * side[i] * side[i] * w[i]
+    for c, n in ((w[2], 256), (w[3], 1024)):
+        total += n * (2 * (c // 8) * c + c * c) + n * (3 * n - 1)
+    total += 64 * 64 * 3 * w[3] * 16
+    return total / 1000 ** 3
+
+
+def sagan_generator_macs(netG):
+    widths = [getattr(netG, 'l%d' % i)[1].weight.shape[0] for i in (1, 2, 3, 4)]
+    z_dim = netG.l1[0].module.weight_bar.shape[0]
+    return sagan_cfg_macs(widths, z_dim), _params_m(netG)
+
+
+def sagan_scale_prune_cfg(netG, threshold):
+    """models/SAGAN.py:726-750"""
+    if torch.is_tensor(threshold):
+        threshold = threshold.detach().float().cpu()
+    cfg = {'l1': 0, 'l2': 0, 'l3': 0, 'l4': 0}
+    for name, m in netG.named_modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            cfg[name.split('.')[0]] = int((m.weight.detach().float().cpu() > threshold).sum())
+    return list(cfg.values())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -280,18 +408,32 @@ def binarysearch_threshold(model, target_budget):
     """utils/prune_util.py:20-47.  Scale pruning searches on the BatchNorm vectors alone; norm / resnet pruning asks the
     model for its interval and cfg at each mid point (the MAC budget is shape arithmetic, no network is built)."""
     opt = model.opt
-    if opt.scale_prune and opt.backbone != 'resnet':
+    kind = str(getattr(opt, 'model', 'pix2pix'))
+    if kind == 'srgan':
+        lr = opt.image_size // opt.upscale_factor
+        n = model.netG.conv_block1.conv_block[0].weight.shape[0]
+        max_scale, min_scale = model.max_min_bn_scale() if opt.scale_prune else model.max_min_conv_norm()
+        budget_of = lambda t: srresnet_cfg_macs(n, srgan_prune_cfg(model.netG, t, bool(opt.scale_prune))[0], lr)
+    elif kind == 'sagan':
+        if not opt.scale_prune:
+            raise NotImplementedError('only scale and norm pruning are supported!!!')   # norm_prune is `pass` there
+        max_scale, min_scale = model.max_min_bn_scale()
+        z_dim = model.netG.l1[0].module.weight_bar.shape[0]
+        budget_of = lambda t: sagan_cfg_macs(sagan_scale_prune_cfg(model.netG, t), z_dim)
+    elif opt.scale_prune and opt.backbone != 'resnet':
         sd = {k: v.detach().cpu() for k, v in model.netG.state_dict().items() if k.endswith('.weight') and v.dim() == 1}
         return binarysearch_threshold_sd(sd, opt, target_budget)
-    max_scale, min_scale = model.max_min_conv_norm()
+    else:
+        max_scale, min_scale = model.max_min_conv_norm()
+        if opt.backbone == 'resnet':
+            budget_of = lambda t: resnet_cfg_macs(resnet_prune_cfg(model.netG, t, 'union'), opt.load_size)
+        else:
+            budget_of = lambda t: cfg_macs(opt, *norm_prune_cfg(model.netG, t, opt.ngf))
     root = str(opt.dataroot)
     tolerance = 0.01 if 'sr' in root else (0.001 if ('celeb' in root or 'church' in root) else 0.1)
     while max_scale > min_scale:
         mid = (max_scale + min_scale) / 2
-        if opt.backbone == 'resnet':
-            budget = resnet_cfg_macs(resnet_prune_cfg(model.netG, mid, 'union'), opt.load_size)
-        else:
-            budget = cfg_macs(opt, *norm_prune_cfg(model.netG, mid, opt.ngf))
+        budget = budget_of(mid)
         if abs(target_budget - budget) <= tolerance:
             return mid
         elif target_budget - budget > tolerance:

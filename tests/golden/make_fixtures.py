@@ -379,11 +379,16 @@ def thop_standin_profile(model, inputs, verbose=False):
 
     def bn_hook(m, i, o):
         total[0] += 2 * i[0].numel()
+    def softmax_hook(m, i, o):          # thop's count_softmax: rows * (exp + add + div) = rows * (3 n - 1)
+        n = i[0].size(m.dim)
+        total[0] += (i[0].numel() // n) * (3 * n - 1)
     for m in model.modules():
         if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
             hooks.append(m.register_forward_hook(conv_hook))
         elif isinstance(m, nn.BatchNorm2d):
             hooks.append(m.register_forward_hook(bn_hook))
+        elif isinstance(m, nn.Softmax):
+            hooks.append(m.register_forward_hook(softmax_hook))
     was = model.training
     model.eval()
     with torch.no_grad():
@@ -814,6 +819,92 @@ def fixture_srgan():
     print('  loss names', list(out['loss_names']), len(out['G_optimizer_names']), len(out['G_keys']))
 
 
+def _spread_bn(net, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in net.modules():
+            if m.__class__.__name__ == 'BatchNorm2d':
+                m.weight.copy_(0.05 + torch.rand(m.weight.shape, generator=g))
+
+
+def fixture_prune_search_gan():
+    """the reference's own binarysearch_threshold + model.prune (utils/prune_util.py:20-63) for SRGAN (scale and norm
+    pruning) and SAGAN (scale pruning), with the thop stand-in; also max_min_bn_scale / max_min_conv_norm"""
+    import torchvision.models.vgg as tvgg
+    tvgg.vgg19 = vgg19_standin
+    if 'PIL' not in sys.modules:
+        try:
+            import PIL  # noqa: F401
+        except ImportError:
+            _stub('PIL', Image=None)
+    from options import options as ref_options
+    if not any('--generator_only' in a.option_strings for a in ref_options.parser._actions):
+        ref_options.parser.add_argument('--generator_only', action='store_true')
+    import models.GANLoss as ref_ganloss
+    ref_ganloss.vgg19 = vgg19_standin
+    import utils.prune_util as pu
+    pu.profile = thop_standin_profile
+    from models import get_model_class
+    out = {}
+    for tag, flag in (('sr_scale', '--scale_prune'), ('sr_norm', '--norm_prune')):
+        opt = parse(['--dataroot', './database/sr/', '--model', 'srgan', '--gpu_ids', '-1', '--ngf', '8', '--ndf', '8', flag])
+        model = get_model_class(opt)(opt)
+        load_recipe(model.netG, 951)
+        _spread_bn(model.netG, 952)
+        spread_filter_norms(model.netG, 953)
+        full, _ = pu.get_flops_parms(model.netG, model.device, opt)
+        out[tag + '.full_macs'] = np.array(full)
+        mx, mn = model.max_min_bn_scale() if flag == '--scale_prune' else model.max_min_conv_norm()
+        out[tag + '.max_min'] = np.array([float(mx), float(mn)], dtype=np.float64)
+        for i, frac in enumerate((0.7, 0.8, 0.9)):
+            target = round(full * frac, 4)
+            out['%s.s%d.target' % (tag, i)] = np.array(target)
+            try:
+                thr = pu.binarysearch_threshold(model, target)
+                pm = model.prune(thr)
+                macs, _ = pu.get_flops_parms(pm.netG, pm.device, opt)
+                out['%s.s%d.found' % (tag, i)] = np.array(1)
+                out['%s.s%d.threshold' % (tag, i)] = np.array(float(thr), dtype=np.float32)
+                out['%s.s%d.f' % (tag, i)] = np.array(pm.get_cfg()[0])
+                out['%s.s%d.macs' % (tag, i)] = np.array(macs)
+            except NotImplementedError:
+                out['%s.s%d.found' % (tag, i)] = np.array(0)
+    # torch >= 2.x rejects the reference's mixed int / float betas (0, 0.9): same shim as fixture_sagan, kept installed
+    # for the whole search (model.prune builds a new SAGANModel at every mid point)
+    real_adam = torch.optim.Adam
+
+    class FloatBetasAdam(real_adam):
+        def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), **kw):
+            super().__init__(params, lr=lr, betas=(float(betas[0]), float(betas[1])), **kw)
+    torch.optim.Adam = FloatBetasAdam
+    # ngf 32: a pruned l3 / l4 must keep >= 8 channels, or Self_Attn's in_dim // 8 query conv has no filters
+    opt = parse(['--dataroot', './database/celeb/', '--model', 'sagan', '--gpu_ids', '-1', '--ngf', '32', '--ndf', '8',
+                 '--scale_prune'])
+    model = get_model_class(opt)(opt)
+    load_recipe(model.netG, 961)
+    _spread_bn(model.netG, 962)
+    full, _ = pu.get_flops_parms(model.netG, model.device, opt)
+    out['sa.full_macs'] = np.array(full)
+    mx, mn = model.max_min_bn_scale()
+    out['sa.max_min'] = np.array([float(mx), float(mn)], dtype=np.float64)
+    for i, frac in enumerate((0.5, 0.65, 0.8)):
+        target = round(full * frac, 4)
+        out['sa.s%d.target' % i] = np.array(target)
+        try:
+            thr = pu.binarysearch_threshold(model, target)
+            pm = model.prune(thr)
+            macs, _ = pu.get_flops_parms(pm.netG, pm.device, opt)
+            out['sa.s%d.found' % i] = np.array(1)
+            out['sa.s%d.threshold' % i] = np.array(float(thr), dtype=np.float32)
+            out['sa.s%d.f' % i] = np.array(pm.get_cfg()[0])
+            out['sa.s%d.macs' % i] = np.array(macs)
+        except NotImplementedError:
+            out['sa.s%d.found' % i] = np.array(0)
+    torch.optim.Adam = real_adam
+    np.savez_compressed(os.path.join(HERE, 'prune_search_gan.npz'), **out)
+    print('prune_search_gan ok', {k: v.tolist() for k, v in out.items() if v.size < 20})
+
+
 def fixture_options():
     import json
     from options import options
@@ -840,6 +931,6 @@ if __name__ == '__main__':
     only = sys.argv[1:]            # e.g. "make_fixtures.py cyclegan cyclegan_pretrain"; none = all
     import_reference()
     for fn in (fixture_options, fixture_ops, fixture_eval_d8, fixture_gcc_d6, fixture_pretrain_d6, fixture_prune_d8,
-               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan, fixture_srgan):
+               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan, fixture_srgan, fixture_prune_search_gan):
         if not only or fn.__name__[len('fixture_'):] in only:
             fn()

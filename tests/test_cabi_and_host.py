@@ -217,3 +217,64 @@ def test_unet_norm_prune_cfgs_bit_exact(golden_dir):
     for i, t in enumerate(z['norm.thresholds']):
         f, c = P.norm_prune_cfg(net, float(t), ngf=8)
         assert f == [int(v) for v in z['norm.f.%d' % i]] and c == [int(v) for v in z['norm.c.%d' % i]], i
+
+
+def _spread_bn(net, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(0.05 + torch.rand(m.weight.shape, generator=g))
+
+
+def test_srgan_sagan_prune_search_vs_reference(golden_dir):
+    """binarysearch_threshold + prune cfgs of SRGAN (scale / norm) and SAGAN (scale) against the reference's own search
+    (tests/golden/make_fixtures.py::fixture_prune_search_gan: the reference's code with the thop stand-in)"""
+    import types
+    from gcc_amd.models.SRGAN import Generator as SRGenerator
+    from gcc_amd.models.SAGAN import Generator as SAGenerator
+    from gcc_amd.utils import prune_util as P
+    z = np.load(os.path.join(golden_dir, 'prune_search_gan.npz'))
+    for tag, scale in (('sr_scale', True), ('sr_norm', False)):
+        g = SRGenerator(n_channels=8)
+        _load_recipe(g, 951)
+        _spread_bn(g, 952)
+        _spread_filter_norms(g, 953)
+        opt = types.SimpleNamespace(model='srgan', image_size=96, upscale_factor=4, scale_prune=scale, norm_prune=not scale,
+                                    dataroot='./database/sr/', backbone='unet')
+        assert abs(P.get_flops_parms(g, None, opt)[0] - float(z[tag + '.full_macs'])) < 1e-12
+        mm = P.srgan_max_min_bn_scale(g) if scale else P.srgan_max_min_conv_norm(g)
+        assert [float(mm[0]), float(mm[1])] == [float(v) for v in z[tag + '.max_min']]
+        model = types.SimpleNamespace(opt=opt, netG=g, max_min_bn_scale=lambda: P.srgan_max_min_bn_scale(g),
+                                      max_min_conv_norm=lambda: P.srgan_max_min_conv_norm(g))
+        for i in range(3):
+            assert int(z['%s.s%d.found' % (tag, i)]) == 1
+            thr = P.binarysearch_threshold(model, float(z['%s.s%d.target' % (tag, i)]))
+            assert np.float32(float(thr)) == np.float32(z['%s.s%d.threshold' % (tag, i)]), (tag, i)
+            f, _ = P.srgan_prune_cfg(g, thr, scale)
+            assert f == [int(v) for v in z['%s.s%d.f' % (tag, i)]], (tag, i, f)      # norm pruning: 17 entries, as there
+            pruned = SRGenerator(n_channels=8, filter_cfgs=f)
+            assert abs(P.srresnet_macs(pruned, 24)[0] - float(z['%s.s%d.macs' % (tag, i)])) < 1e-12
+    g = SAGenerator(ngf=32)
+    _load_recipe(g, 961)
+    _spread_bn(g, 962)
+    opt = types.SimpleNamespace(model='sagan', scale_prune=True, norm_prune=False, dataroot='./database/celeb/', backbone='unet')
+    assert abs(P.get_flops_parms(g, None, opt)[0] - float(z['sa.full_macs'])) < 1e-12
+
+    def mm():
+        top = low = None
+        for m in g.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                w = m.weight.detach()
+                top = w.max() if top is None else torch.min(w.max(), top)
+                low = w.min() if low is None else torch.min(w.min(), low)
+        return top, low
+    assert [float(v) for v in mm()] == [float(v) for v in z['sa.max_min']]
+    model = types.SimpleNamespace(opt=opt, netG=g, max_min_bn_scale=mm)
+    for i in range(3):
+        assert int(z['sa.s%d.found' % i]) == 1
+        thr = P.binarysearch_threshold(model, float(z['sa.s%d.target' % i]))
+        assert np.float32(float(thr)) == np.float32(z['sa.s%d.threshold' % i]), i
+        f = P.sagan_scale_prune_cfg(g, thr)
+        assert f == [int(v) for v in z['sa.s%d.f' % i]]
+        assert abs(P.sagan_generator_macs(SAGenerator(ngf=32, filter_cfgs=f))[0] - float(z['sa.s%d.macs' % i])) < 1e-12
