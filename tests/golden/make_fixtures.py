@@ -905,6 +905,32 @@ def fixture_prune_search_gan():
     print('prune_search_gan ok', {k: v.tolist() for k, v in out.items() if v.size < 20})
 
 
+def fixture_checkpoint():
+    """a checkpoint file written by the reference's Pix2PixModel.save_models (masked D, ngf 4 / ndf 4, num_downs 8 at
+    256x256 would be 3 MB: the generator here is the d6 one of fixture_gcc_d6 at ngf 4), and the eval image the
+    reference produces from it"""
+    import tempfile
+    opt = parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '-1', '--ngf', '4', '--ndf', '4',
+                 '--num_downs', '6', '--load_size', '64', '--crop_size', '64', '--darts_discriminator'])
+    from models import get_model_class
+    model = get_model_class(opt)(opt)
+    load_recipe(model.netG, 971)
+    load_recipe(model.netD, 972)
+    with tempfile.TemporaryDirectory() as d:
+        model.save_models(7, d, fid=12.5)
+        blob = open(os.path.join(d, 'model_7.pth'), 'rb').read()
+    open(os.path.join(HERE, 'ref_checkpoint_pix2pix.pth'), 'wb').write(blob)
+    g = torch.Generator().manual_seed(973)
+    A = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    model.model_eval()
+    model.set_input({'A': A, 'B': A.clone(), 'A_paths': ['a'], 'B_paths': ['b']})
+    with torch.no_grad():
+        model.forward()
+    np.savez_compressed(os.path.join(HERE, 'ref_checkpoint_pix2pix.npz'), A=A.numpy(), fake_B=model.fake_B.numpy(),
+                        direction=np.array(opt.direction))
+    print('checkpoint ok: %d bytes' % len(blob))
+
+
 def fixture_options():
     import json
     from options import options
@@ -931,6 +957,6 @@ if __name__ == '__main__':
     only = sys.argv[1:]            # e.g. "make_fixtures.py cyclegan cyclegan_pretrain"; none = all
     import_reference()
     for fn in (fixture_options, fixture_ops, fixture_eval_d8, fixture_gcc_d6, fixture_pretrain_d6, fixture_prune_d8,
-               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan, fixture_srgan, fixture_prune_search_gan):
+               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan, fixture_srgan, fixture_prune_search_gan, fixture_checkpoint):
         if not only or fn.__name__[len('fixture_'):] in only:
             fn()
