@@ -78,6 +78,15 @@ class ImagePool:
         return out
 
 
+class _Half:
+    """one image set of a batched generator pass: views into the 2N context"""
+
+    def __init__(self, full, lo, hi):
+        self.full, self.lo, self.hi = full, lo, hi
+        self.N, self.H, self.W = hi - lo, full.H, full.W
+        self.out, self.g_out = full.out[lo:hi], full.g_out[lo:hi]
+
+
 class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
 
     def __init__(self, opt, cfg_AtoB=None, cfg_BtoA=None):
@@ -215,16 +224,30 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
         return self.G[w].forward(c)
 
     def forward(self):
-        """six generator passes (:366-380); the contexts keep every activation for backward_G"""
-        c = {}
-        c['fake_B'] = self._g('A', 'fake', self._A)            # G_A(A)
+        """six generator passes (:366-380) as four launches sets: G_A(A) and G_A(B) -- the fake and the identity image of
+        one generator -- run as ONE pass over a batch of 2N, likewise G_B(B) and G_B(A).  InstanceNorm statistics are per
+        image and every other layer is per pixel, so the arithmetic per image is the same as in two passes; at the
+        reference's batch size 1 this removes a third of the generator launches, which is what the step time is made
+        of.  The contexts keep every activation for backward_G."""
+        N, _, H, W = self._A.shape
+        c, full = {}, {}
+        for w, first, second in (('A', self._A, self._B), ('B', self._B, self._A)):
+            cx = self.G[w]._ctx(2 * N, H, W, 'fake_idt')
+            ops.nhwc_copy(first, 0, cx.x_in[:N], 0, 3)
+            ops.nhwc_copy(second, 0, cx.x_in[N:], 0, 3)
+            full[w] = self.G[w].forward(cx)
+        c['fake_B'], c['idt_A'] = _Half(full['A'], 0, N), _Half(full['A'], N, 2 * N)      # G_A(A), G_A(B)
+        c['fake_A'], c['idt_B'] = _Half(full['B'], 0, N), _Half(full['B'], N, 2 * N)      # G_B(B), G_B(A)
         c['rec_A'] = self._g('B', 'rec', c['fake_B'].out)      # G_B(G_A(A))
-        c['fake_A'] = self._g('B', 'fake', self._B)            # G_B(B)
         c['rec_B'] = self._g('A', 'rec', c['fake_A'].out)      # G_A(G_B(B))
-        c['idt_A'] = self._g('A', 'idt', self._B)              # G_A(B)
-        c['idt_B'] = self._g('B', 'idt', self._A)              # G_B(A)
         self._ctx = c
         self._nchw = {}
+
+    def _gfeatures(self, w, ctx):
+        """hooked generator features of one image set"""
+        if isinstance(ctx, _Half):
+            return [f[ctx.lo:ctx.hi] for f in self.G[w].features(ctx.full)]
+        return self.G[w].features(ctx)
 
     def visual_forward(self):
         self._ctx = {'fake_B': self._g('A', 'fake', self._A)}
@@ -272,10 +295,10 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
         real = {'A': self._A, 'B': self._B}
         T = self.teacher_model
         # identity terms: idt_A = G_A(B) against B (weight lambda_B), idt_B = G_B(A) against A (weight lambda_A)
+        # (their backward runs with the fake pass of the same generator below: one batch of 2N)
         for w, dom in (('A', 'B'), ('B', 'A')):
             ci = c['idt_' + w]
             ops.l1_loss(ci.out, real[dom], self._l('idt_' + w), weight=lam[dom] * opt.lambda_identity, da=ci.g_out)
-            self.G[w].backward(ci)
         # per side: fake = G_w(real), judged by D_w; the cycle through the other generator returns dL/d(fake)
         for w, o, fake, rec in (('A', 'B', 'fake_B', 'rec_A'), ('B', 'A', 'fake_A', 'rec_B')):
             cf, cr = c[fake], c[rec]
@@ -294,7 +317,7 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
                 g_feat = self._distill_side(w, cf, T._ctx[fake])
                 if w == 'B':
                     self._mark_teacher_free()
-            self.G[w].backward(cf, g_feat=g_feat)
+            self.G[w].backward(cf.full, g_feat=g_feat)
 
     def _distill_side(self, w, cf, tcf):
         """distillation terms of one generator (:497-541): four transformed generator features carry gradients; the
@@ -302,7 +325,7 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
         opt, T = self.opt, self.teacher_model
         N = cf.N
         ct = T._d_forward(w, 'on_student', cf.out)
-        feats = self.G[w].features(cf) + T.D[w].features(ct)
+        feats = self._gfeatures(w, cf) + T.D[w].features(ct)
         targets = self.target_distillation_A_features if w == 'A' else self.target_distillation_B_features
         g_feat = []
         for i in range(6):
@@ -318,8 +341,9 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
                 dtf = self._buf(('dtf', w, i), N, tf.shape[1], tf.shape[2], tf.shape[3])
                 ops.distill_bwd(tf, t, opt.lambda_gram, opt.lambda_content, dtf, ws, squared=True)
                 self.T[w][i].backward_weight(f, dtf)
-                gbuf = self._buf(('gf', w, i), N, f.shape[1], f.shape[2], f.shape[3])
-                self.T[w][i].backward_data(dtf, gbuf)
+                # feature gradient of the whole 2N pass: the identity half stays zero
+                gbuf = self._buf(('gf', w, i), 2 * N, f.shape[1], f.shape[2], f.shape[3])
+                self.T[w][i].backward_data(dtf, gbuf[:N])
                 g_feat.append(gbuf)
         if opt.lambda_L1 > 0.0:
             # criterionL1(fake, Tfake) is added once per feature inside the reference's loop: 6 x lambda_L1
@@ -539,7 +563,7 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
         """4 generator features of the G(real) pass + the 2 discriminator features of the last D call of the iteration
         (the pooled fake of the D step), as the reference's hooks end up holding them"""
         w = AorB
-        return self.G[w].features(self._ctx['fake_B' if w == 'A' else 'fake_A']) + self.D[w].features(self._dctx_last[w])
+        return self._gfeatures(w, self._ctx['fake_B' if w == 'A' else 'fake_A']) + self.D[w].features(self._dctx_last[w])
 
     def get_cfg(self):
         return self.cfg_AtoB, self.cfg_BtoA

@@ -89,7 +89,7 @@ def test_cyclegan_two_iterations_vs_reference_golden(golden_dir):
                 e = (getattr(teacher, n).cpu() - torch.from_numpy(z['it0.T' + n])).abs()
                 assert e.max() <= 4e-2 and e.mean() <= 6e-3, n
             for w in 'AB':
-                feats = model.G[w].features(model._ctx['fake_B' if w == 'A' else 'fake_A'])
+                feats = model._gfeatures(w, model._ctx['fake_B' if w == 'A' else 'fake_A'])
                 for j in range(4):
                     ref = torch.from_numpy(z['it0.sfeat_%s.%d' % (w, j)])
                     err = (feats[j].float().cpu() - ref).abs().max().item() / ref.abs().max().item()
