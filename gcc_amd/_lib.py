@@ -105,6 +105,14 @@ PROTOTYPES = {
     'gcc_spectral_workspace': (_Z, [_I, _I, _I]),
     'gcc_spectral_power_iteration': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     'gcc_spectral_grad': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
+    'gcc_argmax_channels': (_I, [_P, _I, _I, _Z, _P, _P]),
+    'gcc_confusion_hist': (_I, [_P, _P, _Z, _I, _P, _P]),
+    'gcc_psnr_workspace': (_Z, []),
+    'gcc_psnr_y_sse': (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _Z, _P]),
+    'gcc_activation_stats_workspace': (_Z, [_I, _I]),
+    'gcc_activation_stats': (_I, [_P, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    'gcc_frechet_workspace': (_Z, [_I]),
+    'gcc_frechet_distance': (_I, [_P, _P, _P, _P, _I, _I, C.c_double, _P, _P, _Z, _P]),
     'gcc_attention_fwd': (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P]),
     'gcc_attention_bwd': (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
     'gcc_l1_loss': (_I, [_P, _I, _I, _P, _I, _I, _I, _Z, _F, _P, _I, _P, _I, _I, _P, _Z, _P]),

@@ -598,11 +598,17 @@ class SRGAN(TeacherStreamMixin, nn.Module):
         return ret
 
     def get_current_psnr(self):
-        """PSNR on the luminance channel with a 4-pixel border cropped (convert_image 'y-channel', :653-657)"""
-        y = lambda img: (255. * ((img + 1.) / 2.).permute(0, 2, 3, 1)[:, 4:-4, 4:-4, :]).matmul(
-            torch.tensor([65.481, 128.553, 24.966], device=img.device)) / 255. + 16.
-        self.fake_hr_y, self.real_hr__y = y(self.fake_hr).squeeze(0), y(self.real_hr).squeeze(0)
-        mse = float(((self.fake_hr_y - self.real_hr__y) ** 2).mean())
+        """PSNR on the luminance channel with a 4-pixel border cropped (convert_image 'y-channel', :653-657;
+        skimage.metrics.peak_signal_noise_ratio with data_range 255 = 10 log10(255^2 / mse))"""
+        fake, real = self.fake_hr.float().contiguous(), self.real_hr.float().contiguous()
+        N, _, H, W = fake.shape
+        L = ops.lib()
+        sse = torch.zeros(1, dtype=torch.float64, device=fake.device)
+        ws = torch.empty(L.gcc_psnr_workspace(), dtype=torch.uint8, device=fake.device)
+        from .._lib import check
+        check(L.gcc_psnr_y_sse(fake.data_ptr(), real.data_ptr(), N, H, W, sse.data_ptr(), 0, ws.data_ptr(), ws.numel(),
+                               ops.stream()), 'gcc_psnr_y_sse')
+        mse = float(sse.item()) / (N * (H - 8) * (W - 8))
         return 10.0 * math.log10(255.0 ** 2 / mse) if mse > 0 else float('inf')
 
     def init_distillation(self):

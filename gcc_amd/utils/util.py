@@ -60,3 +60,27 @@ def get_scheduler(optimizer, opt):
     if opt.lr_policy == 'cosine':
         return lr_scheduler.CosineAnnealingLR(optimizer, T_max=opt.n_epochs, eta_min=0)
     raise NotImplementedError('learning rate policy [%s] is not implemented' % opt.lr_policy)
+
+
+def tensor2imgs(image_tensor, imtype=None, normalize=True, tile=False):
+    """utils/util.py:45-76: [-1, 1] (or [0, 1]) image tensors -> uint8 HWC numpy images (a 4-D batch gives [N, H, W, C]).
+    The value path of the evaluators: clip((x + 1) / 2 * 255) truncated to uint8."""
+    import numpy as np
+    imtype = np.uint8 if imtype is None else imtype
+    if isinstance(image_tensor, list):
+        return [tensor2imgs(t, imtype, normalize) for t in image_tensor]
+    if tile:
+        raise NotImplementedError('tiled visualisation is outside the evaluation path')
+    if image_tensor.dim() == 4:
+        return np.concatenate([tensor2imgs(t)[None] for t in image_tensor], axis=0)
+    if image_tensor.dim() == 2:
+        image_tensor = image_tensor.unsqueeze(0)
+    image_numpy = image_tensor.detach().cpu().float().numpy()
+    if normalize:
+        image_numpy = (np.transpose(image_numpy, (1, 2, 0)) + 1) / 2.0 * 255.0
+    else:
+        image_numpy = np.transpose(image_numpy, (1, 2, 0)) * 255.0
+    image_numpy = np.clip(image_numpy, 0, 255)
+    if image_numpy.shape[2] == 1:
+        image_numpy = image_numpy[:, :, 0]
+    return image_numpy.astype(imtype)

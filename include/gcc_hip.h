@@ -361,6 +361,35 @@ int gcc_scalar_op(int op, const float* a, const float* b, const float* c, float 
 int gcc_fill_f32(float* p, float v, size_t n, gcc_stream_t stream);
 int gcc_clamp_f32(float* p, float lo, float hi, size_t n, gcc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Evaluation arithmetic.  The evaluator networks (Inception, DRN) stay external: these entry
+ * points take their outputs as device tensors.
+ * gcc_argmax_channels: scores NCHW fp32 [N][C][HW] -> class index int32 [N][HW], numpy.argmax semantics
+ *   (metric/mIoU_score.py:212 `final.argmax(axis=1)`).
+ * gcc_confusion_hist: fast_hist (metric/mIoU_score.py:163-167): hist[n * label + pred] += 1 where 0 <= label < n; int64
+ *   [n][n], accumulated (+=) so that a whole evaluation set sums into one matrix.  Exact.
+ * gcc_psnr_y_sse: sum of squared luminance differences of two NCHW fp32 images in [-1, 1] with the 4-pixel border
+ *   cropped (models/SRGAN.py:653-657: convert_image(..., 'y-channel'), data/sr_dataset.py:36-37, 58-62); PSNR =
+ *   10 log10(255^2 N (H-8)(W-8) / sse).  f64 accumulation in a fixed order.
+ * gcc_activation_stats: mu = mean(act, 0), sigma = np.cov(act, rowvar=False) in f64 (metric/fid_score.py:327-328) of
+ *   activations [n][d] (fp32 or f64, row major).
+ * gcc_frechet_distance: metric/fid_score.py:219-284; out[0] = |mu1-mu2|^2 + tr(s1) + tr(s2) - 2 tr(sqrtm(s1 s2)) with
+ *   the matrix square root by `iterations` coupled Newton-Schulz steps on the GPU (f64) of s1 s2 + delta I, delta =
+ *   shift_rel |s1 s2|_F, solved at delta and 4 delta and extrapolated to delta = 0 (shift_rel = 0: one unshifted solve,
+ *   full-rank inputs only); out[1] = relative change of the trace over the last step (the caller's convergence check).
+ * --------------------------------------------------------------------------------------------- */
+int gcc_argmax_channels(const float* scores, int N, int C, size_t HW, int* pred, gcc_stream_t stream);
+int gcc_confusion_hist(const int* pred, const int* label, size_t count, int n, long long* hist, gcc_stream_t stream);
+size_t gcc_psnr_workspace(void);
+int gcc_psnr_y_sse(const float* fake, const float* real, int N, int H, int W, double* sse, int accumulate, void* ws,
+                   size_t ws_bytes, gcc_stream_t stream);
+size_t gcc_activation_stats_workspace(int n, int d);
+int gcc_activation_stats(const void* act, int is_f64, int n, int d, double* mu, double* sigma, void* ws, size_t ws_bytes,
+                         gcc_stream_t stream);
+size_t gcc_frechet_workspace(int d);
+int gcc_frechet_distance(const double* mu1, const double* sigma1, const double* mu2, const double* sigma2, int d,
+                         int iterations, double shift_rel, double* out, void* ws, size_t ws_bytes, gcc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,56 @@
+"""CPU restatement of the reference's evaluation arithmetic (TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import this; the product path never does).
+
+Pinned against the reference's own functions run in the build container (tests/golden/make_fixtures.py::fixture_metric
+-> tests/golden/metric.npz): calculate_frechet_distance (scipy.linalg.sqrtm), fast_hist, per_class_iu, convert_image.
+skimage is absent from the image: peak_signal_noise_ratio is restated from its published definition,
+10 log10(data_range^2 / mean((a - b)^2)) in float64."""
+import numpy as np
+from scipy import linalg
+
+
+def calculate_frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
+    """metric/fid_score.py:219-284"""
+    mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)
+    sigma1, sigma2 = np.atleast_2d(sigma1), np.atleast_2d(sigma2)
+    diff = mu1 - mu2
+    covmean, _ = linalg.sqrtm(sigma1.dot(sigma2), disp=False)
+    if not np.isfinite(covmean).all():
+        offset = np.eye(sigma1.shape[0]) * eps
+        covmean = linalg.sqrtm((sigma1 + offset).dot(sigma2 + offset))
+    if np.iscomplexobj(covmean):
+        covmean = covmean.real
+    return diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean)
+
+
+def activation_statistics(act):
+    """metric/fid_score.py:327-328"""
+    act = np.asarray(act, dtype=np.float64)
+    return np.mean(act, axis=0), np.cov(act, rowvar=False)
+
+
+def fast_hist(pred, label, n):
+    """metric/mIoU_score.py:163-167"""
+    k = (label >= 0) & (label < n)
+    return np.bincount(n * label[k].astype(int) + pred[k], minlength=n ** 2).reshape(n, n)
+
+
+def per_class_iu(hist):
+    """metric/mIoU_score.py:108-109"""
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist))
+
+
+def y_channel(img):
+    """data/sr_dataset.py:36-37, 58-62 on an NCHW float32 array in [-1, 1] -> [N, H-8, W-8] float32"""
+    x = (img.astype(np.float32) + np.float32(1.)) / np.float32(2.)
+    x = np.float32(255.) * np.transpose(x, (0, 2, 3, 1))[:, 4:-4, 4:-4, :]
+    w = np.array([65.481, 128.553, 24.966], dtype=np.float32)
+    return (x @ w) / np.float32(255.) + np.float32(16.)
+
+
+def psnr_y(fake, real):
+    """models/SRGAN.py:653-657 with skimage.metrics.peak_signal_noise_ratio(data_range=255.) restated"""
+    a, b = y_channel(fake).astype(np.float64), y_channel(real).astype(np.float64)
+    mse = np.mean((a - b) ** 2)
+    return 10 * np.log10(255. ** 2 / mse)

@@ -931,6 +931,53 @@ def fixture_checkpoint():
     print('checkpoint ok: %d bytes' % len(blob))
 
 
+def fixture_metric():
+    """evaluation arithmetic of the reference on seeded inputs: calculate_frechet_distance (scipy sqrtm) for a
+    well-conditioned and a rank-deficient pair, np.mean / np.cov statistics, fast_hist + per_class_iu, y-channel
+    conversion"""
+    # import stubs only (SURVEY.md section 8(c)): metric/fid_score.py:42 imports cv2.imread, metric/inception.py subclasses
+    # torchvision's Inception blocks at import time; the arithmetic below never touches either
+    sys.modules['cv2'].imread = None
+    base = type('InceptionBlock', (torch.nn.Module,), {})
+    sys.modules['torchvision.models'].inception = _stub('torchvision.models.inception', InceptionA=base, InceptionC=base,
+                                                        InceptionE=base)
+    sys.modules['torchvision'].models = sys.modules['torchvision.models']
+    from metric.fid_score import calculate_frechet_distance
+    rng = np.random.RandomState(77)
+    out = {}
+    for tag, d, n1, n2 in (('full', 48, 400, 300), ('wide', 96, 700, 500), ('rank', 40, 25, 30)):
+        basis = rng.randn(d, d) / np.sqrt(d)
+        a1 = (rng.randn(n1, d) * (0.2 + rng.rand(d))) @ basis + rng.randn(d) * 0.3
+        a2 = (rng.randn(n2, d) * (0.2 + rng.rand(d))) @ basis.T + rng.randn(d) * 0.3
+        a1, a2 = a1.astype(np.float32), a2.astype(np.float32)
+        m1, s1 = np.mean(a1.astype(np.float64), axis=0), np.cov(a1.astype(np.float64), rowvar=False)
+        m2, s2 = np.mean(a2.astype(np.float64), axis=0), np.cov(a2.astype(np.float64), rowvar=False)
+        out['%s.act1' % tag], out['%s.act2' % tag] = a1, a2
+        out['%s.mu1' % tag], out['%s.sigma1' % tag] = m1, s1
+        out['%s.fid' % tag] = np.array(float(calculate_frechet_distance(m1, s1, m2, s2)))
+    from metric.mIoU_score import fast_hist, per_class_iu
+    n = 19
+    label = rng.randint(-1, n + 3, size=4000).astype(np.int64)      # includes ignored labels (< 0, >= n; 255 in cityscapes)
+    label[rng.rand(label.size) < 0.05] = 255
+    scores = rng.randn(2, n, 40, 50).astype(np.float32)
+    scores[0, 3, 5, 7] = scores[0, 9, 5, 7] = scores[0].max() + 1          # a tie: the first maximum wins
+    pred = scores.argmax(axis=1).reshape(-1)
+    hist = fast_hist(pred, label, n)
+    out['iou.scores'], out['iou.label'], out['iou.pred'] = scores, label, pred.astype(np.int64)
+    out['iou.hist'] = hist.astype(np.int64)
+    out['iou.per_class'] = per_class_iu(hist.astype(np.float64))
+    out['iou.miou'] = np.array(round(np.nanmean(per_class_iu(hist.astype(np.float64)) * 100), 2))
+    from data.sr_dataset import convert_image
+    g = torch.Generator().manual_seed(78)
+    fake = torch.rand(2, 3, 40, 36, generator=g) * 2 - 1
+    real = (fake + 0.1 * torch.randn(2, 3, 40, 36, generator=g)).clamp(-1, 1)
+    out['psnr.fake'], out['psnr.real'] = fake.numpy(), real.numpy()
+    out['psnr.fake_y'] = convert_image(fake, source='[-1, 1]', target='y-channel').numpy()
+    out['psnr.real_y'] = convert_image(real, source='[-1, 1]', target='y-channel').numpy()
+    np.savez_compressed(os.path.join(HERE, 'metric.npz'), **out)
+    print('metric ok', {k: float(v) for k, v in out.items() if v.size == 1})
+
+
 def fixture_options():
     import json
     from options import options
@@ -957,6 +1004,6 @@ if __name__ == '__main__':
     only = sys.argv[1:]            # e.g. "make_fixtures.py cyclegan cyclegan_pretrain"; none = all
     import_reference()
     for fn in (fixture_options, fixture_ops, fixture_eval_d8, fixture_gcc_d6, fixture_pretrain_d6, fixture_prune_d8,
-               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan, fixture_srgan, fixture_prune_search_gan, fixture_checkpoint):
+               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan, fixture_srgan, fixture_prune_search_gan, fixture_checkpoint, fixture_metric):
         if not only or fn.__name__[len('fixture_'):] in only:
             fn()
