@@ -334,3 +334,128 @@ extern "C" int gcc_frechet_distance(const double* mu1, const double* sigma1, con
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }
+
+// =============================================================================================
+// Input pipeline (data/aligned_dataset.py:27-56, data/base_dataset.py:63-112): the paired image
+// is split, each half resized with PIL's BICUBIC, cropped, flipped, scaled to [0, 1] and normalised to [-1, 1].
+// Pillow (the reference's un-pinned image library; 12.2.0 in this image) resamples 8-bit images in two passes of
+// integer arithmetic -- horizontal, then vertical, with 22-bit fixed-point coefficients and a rounded, clipped uint8
+// intermediate (Resample.c: ImagingResampleHorizontal_8bpc / Vertical_8bpc).  The kernels below reproduce exactly that;
+// the coefficient tables (double precision, a few hundred entries) are built by the caller with Pillow's arithmetic
+// (gcc_amd/data/__init__.py::resample_coeffs) and passed in.
+namespace {
+
+constexpr int PRECISION_BITS = 32 - 8 - 2;
+
+__device__ __forceinline__ unsigned char clip8(int v) {
+    v >>= PRECISION_BITS;                       // arithmetic shift, as the C code's lookup index
+    return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// dst[y][xx][c] over the columns of src: bounds[xx] = {xmin, count}, coef[xx][0..count)
+__global__ __launch_bounds__(256) void resample_h_kernel(const unsigned char* __restrict__ src, size_t pitch, int H, int outW,
+                                                         const int* __restrict__ bounds, const int* __restrict__ coef, int ksize,
+                                                         unsigned char* __restrict__ dst) {
+    const size_t total = (size_t)H * outW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int y = (int)(i / outW), xx = (int)(i - (size_t)y * outW);
+        const int xmin = bounds[2 * xx], cnt = bounds[2 * xx + 1];
+        const int* k = coef + (size_t)xx * ksize;
+        const unsigned char* row = src + (size_t)y * pitch + (size_t)xmin * 3;
+        int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+        for (int x = 0; x < cnt; x++) {
+            const int kv = k[x];
+            s0 += row[3 * x] * kv; s1 += row[3 * x + 1] * kv; s2 += row[3 * x + 2] * kv;
+        }
+        unsigned char* o = dst + i * 3;
+        o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
+    }
+}
+// dst[yy][x][c] over the rows of src (tightly packed [H][W][3])
+__global__ __launch_bounds__(256) void resample_v_kernel(const unsigned char* __restrict__ src, size_t pitch, int W, int outH,
+                                                         const int* __restrict__ bounds, const int* __restrict__ coef, int ksize,
+                                                         unsigned char* __restrict__ dst) {
+    const size_t total = (size_t)outH * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int yy = (int)(i / W), x = (int)(i - (size_t)yy * W);
+        const int ymin = bounds[2 * yy], cnt = bounds[2 * yy + 1];
+        const int* k = coef + (size_t)yy * ksize;
+        const unsigned char* p = src + (size_t)ymin * pitch + (size_t)x * 3;
+        int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+        for (int y = 0; y < cnt; y++) {
+            const int kv = k[y];
+            s0 += p[0] * kv; s1 += p[1] * kv; s2 += p[2] * kv;
+            p += pitch;
+        }
+        unsigned char* o = dst + i * 3;
+        o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
+    }
+}
+// crop + horizontal flip + ToTensor (/255) + Normalize((x - 0.5) / 0.5): NCHW fp32, and the model's NHWC bf16 input
+__global__ __launch_bounds__(256) void crop_flip_norm_kernel(const unsigned char* __restrict__ src, size_t pitch, int x0, int y0,
+                                                             int ch, int cw, int flip, float* __restrict__ nchw,
+                                                             bf16_t* __restrict__ nhwc, int ld) {
+    const size_t total = (size_t)ch * cw;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int y = (int)(i / cw), x = (int)(i - (size_t)y * cw);
+        const int sx = flip ? (cw - 1 - x) : x;
+        const unsigned char* p = src + (size_t)(y0 + y) * pitch + (size_t)(x0 + sx) * 3;
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[c] = ((float)p[c] / 255.f - 0.5f) / 0.5f;
+        if (nchw) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) nchw[(size_t)c * total + i] = v[c];
+        }
+        if (nhwc) {
+            bf16_t* o = nhwc + i * ld;
+#pragma unroll
+            for (int c = 0; c < 3; c++) o[c] = f2bf(v[c]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gcc_resample_u8(const void* src, int in_h, int in_w, size_t pitch, void* dst, int out_h, int out_w,
+                               const int* hbounds, const int* hcoef, int hk, const int* vbounds, const int* vcoef, int vk,
+                               void* tmp, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!src || !dst || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || pitch < (size_t)in_w * 3) return GCC_ERR_BAD_ARG;
+    const bool need_h = out_w != in_w, need_v = out_h != in_h;
+    if ((need_h && (!hbounds || !hcoef || hk <= 0)) || (need_v && (!vbounds || !vcoef || vk <= 0))) return GCC_ERR_BAD_ARG;
+    if (need_h && need_v && !tmp) return GCC_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned char* s = (const unsigned char*)src;
+    size_t sp = pitch;
+    if (!need_h && !need_v) {        // PIL returns a copy
+        if (hipMemcpy2DAsync(dst, (size_t)in_w * 3, src, pitch, (size_t)in_w * 3, in_h, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return GCC_ERR_LAUNCH;
+        return GCC_OK;
+    }
+    if (need_h) {
+        unsigned char* o = (unsigned char*)(need_v ? tmp : dst);
+        hipLaunchKernelGGL(resample_h_kernel, dim3(nblk((size_t)in_h * out_w, 4096)), dim3(256), 0, st, s, sp, in_h, out_w, hbounds,
+                           hcoef, hk, o);
+        GCC_CHECK_LAUNCH();
+        s = o; sp = (size_t)out_w * 3;
+    }
+    if (need_v) {
+        hipLaunchKernelGGL(resample_v_kernel, dim3(nblk((size_t)out_h * out_w, 4096)), dim3(256), 0, st, s, sp, out_w, out_h, vbounds,
+                           vcoef, vk, (unsigned char*)dst);
+        GCC_CHECK_LAUNCH();
+    }
+    return GCC_OK;
+}
+
+extern "C" int gcc_crop_flip_normalize(const void* src, int H, int W, size_t pitch, int x0, int y0, int crop_h, int crop_w, int flip,
+                                       float* nchw, void* nhwc_bf16, int ld, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!src || (!nchw && !nhwc_bf16) || crop_h <= 0 || crop_w <= 0 || x0 < 0 || y0 < 0 || x0 + crop_w > W || y0 + crop_h > H ||
+        pitch < (size_t)W * 3 || (nhwc_bf16 && (ld < 3)))
+        return GCC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(crop_flip_norm_kernel, dim3(nblk((size_t)crop_h * crop_w, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char*)src, pitch, x0, y0, crop_h, crop_w, flip, nchw, (bf16_t*)nhwc_bf16, ld);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}

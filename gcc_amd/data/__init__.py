@@ -1,0 +1,157 @@
+"""Input pipeline of the aligned (paired A|B) datasets on MI355X (data/aligned_dataset.py:27-56,
+data/base_dataset.py:63-112): a decoded 8-bit RGB image is split, each half resized with PIL's BICUBIC, cropped,
+flipped, scaled and normalised on the GPU -- the per-image work of the reference's DataLoader workers, which 8 workers
+cannot deliver at the rate the HIP step consumes images.  Decoding the files stays on the host (out of scope).
+
+The augmentation parameters are drawn exactly as the reference draws them (``random.randint`` x 2, ``random.random``),
+so a seeded run sees the same crops and flips."""
+import math
+import random
+
+import numpy as np
+import torch
+
+from .. import ops
+from .._lib import GccError, check
+
+PRECISION_BITS = 32 - 8 - 2
+
+
+def get_params(opt, size):
+    """data/base_dataset.py:63-78"""
+    w, h = size
+    new_h, new_w = h, w
+    if opt.preprocess == 'resize_and_crop':
+        new_h = new_w = opt.load_size
+    elif opt.preprocess == 'scale_width_and_crop':
+        new_w = opt.load_size
+        new_h = opt.load_size * h // w
+    x = random.randint(0, int(np.maximum(0, new_w - opt.crop_size)))
+    y = random.randint(0, int(np.maximum(0, new_h - opt.crop_size)))
+    flip = random.random() > 0.5
+    return {'crop_pos': (x, y), 'flip': flip}
+
+
+def _bicubic(x):
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+_coeff_cache = {}
+
+
+def resample_coeffs(in_size, out_size):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc (Resample.c) for the BICUBIC filter over the whole axis:
+    (bounds int32 [out, 2], coefficients int32 [out, ksize], ksize).  Double arithmetic in Pillow's operation order."""
+    key = (in_size, out_size)
+    if key in _coeff_cache:
+        return _coeff_cache[key]
+    scale = float(np.float32(in_size) - np.float32(0.0)) / out_size
+    filterscale = scale if scale >= 1.0 else 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    coef = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for w in k:
+            ww += w
+        for x in range(xmax):
+            v = k[x] / ww if ww != 0.0 else k[x]
+            coef[xx, x] = int(-0.5 + v * (1 << PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    _coeff_cache[key] = (bounds, coef, ksize)
+    return _coeff_cache[key]
+
+
+class AlignedGpuPipeline:
+    """``pipe(AB)`` -> {'A', 'B'}: what AlignedDataset.__getitem__ returns for one decoded image, as device tensors
+    (NCHW fp32 in [-1, 1], the batch-dict contract of set_input)."""
+
+    def __init__(self, opt, device=None):
+        if not torch.cuda.is_available():
+            raise GccError('gcc_amd runs on MI355X only (no CPU path): need a visible GPU')
+        self.opt = opt
+        self.device = device or torch.device('cuda', torch.cuda.current_device())
+        self._tables = {}
+        if getattr(opt, 'preprocess', 'resize_and_crop') not in ('resize_and_crop', 'crop', 'none_exact'):
+            raise NotImplementedError('preprocess %s: the MI355X pipeline covers resize_and_crop and crop' % opt.preprocess)
+
+    def _dev_tables(self, n_in, n_out):
+        key = (n_in, n_out)
+        if key not in self._tables:
+            b, c, k = resample_coeffs(n_in, n_out)
+            self._tables[key] = (torch.from_numpy(b).to(self.device), torch.from_numpy(c).to(self.device), k)
+        return self._tables[key]
+
+    def resize(self, img, out_h, out_w):
+        """img: uint8 device tensor view [h, w, 3] (rows may be strided) -> uint8 [out_h, out_w, 3]"""
+        h, w, _ = img.shape
+        assert img.stride(2) == 1 and img.stride(1) == 3
+        dst = torch.empty((out_h, out_w, 3), dtype=torch.uint8, device=self.device)
+        hb, hc, hk = self._dev_tables(w, out_w) if out_w != w else (None, None, 0)
+        vb, vc, vk = self._dev_tables(h, out_h) if out_h != h else (None, None, 0)
+        tmp = torch.empty((h, out_w, 3), dtype=torch.uint8, device=self.device) if (hk and vk) else None
+        p = lambda t: t.data_ptr() if t is not None else None
+        check(ops.lib().gcc_resample_u8(img.data_ptr(), h, w, img.stride(0), dst.data_ptr(), out_h, out_w, p(hb), p(hc), hk,
+                                        p(vb), p(vc), vk, p(tmp), ops.stream()), 'gcc_resample_u8')
+        return dst
+
+    def finish(self, img, crop_pos, crop, flip, nhwc=None):
+        """crop + flip + ToTensor + Normalize of a uint8 [h, w, 3] device image -> fp32 [3, crop, crop]"""
+        h, w, _ = img.shape
+        x, y = crop_pos
+        tw = th = crop
+        if not (w > tw or h > th):          # __crop (:137-143) only crops when the image is larger
+            x, y, tw, th = 0, 0, w, h
+        out = torch.empty((3, th, tw), dtype=torch.float32, device=self.device)
+        check(ops.lib().gcc_crop_flip_normalize(img.data_ptr(), h, w, img.stride(0), x, y, th, tw, int(bool(flip)), out.data_ptr(),
+                                                nhwc.data_ptr() if nhwc is not None else None,
+                                                nhwc.stride(3) if nhwc is not None else 0, ops.stream()), 'gcc_crop_flip_normalize')
+        return out
+
+    def __call__(self, AB, params=None):
+        """AB: uint8 [h, 2w, 3] (host or device).  params: get_params() result; drawn here if None."""
+        opt = self.opt
+        AB = AB.to(self.device, non_blocking=True)
+        if AB.dtype != torch.uint8 or AB.dim() != 3 or AB.shape[2] != 3:
+            raise GccError('expected a decoded RGB image, uint8 [h, w, 3]')
+        AB = AB.contiguous()
+        h, w = AB.shape[0], AB.shape[1]
+        w2 = int(w / 2)
+        halves = (AB[:, :w2], AB[:, w2:w])                         # AB.crop((0, 0, w2, h)), AB.crop((w2, 0, w, h))
+        if params is None:
+            params = get_params(opt, (w2, h))
+        out = {}
+        for name, img in zip(('A', 'B'), halves):
+            if 'resize' in opt.preprocess:
+                img = self.resize(img, opt.load_size, opt.load_size)
+            flip = (not opt.no_flip) and params['flip']
+            if 'crop' in opt.preprocess:
+                out[name] = self.finish(img, params['crop_pos'], opt.crop_size, flip)
+            else:
+                out[name] = self.finish(img, (0, 0), max(img.shape[0], img.shape[1]) + 1, flip)
+        return out
+
+    def batch(self, images, paths=None):
+        """a list of decoded AB images -> the batch dict of set_input"""
+        items = [self(im) for im in images]
+        paths = paths or [''] * len(items)
+        return {'A': torch.stack([i['A'] for i in items]), 'B': torch.stack([i['B'] for i in items]),
+                'A_paths': list(paths), 'B_paths': list(paths)}

@@ -390,6 +390,22 @@ size_t gcc_frechet_workspace(int d);
 int gcc_frechet_distance(const double* mu1, const double* sigma1, const double* mu2, const double* sigma2, int d,
                          int iterations, double shift_rel, double* out, void* ws, size_t ws_bytes, gcc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Input pipeline (data/aligned_dataset.py:27-56, data/base_dataset.py:63-112) on decoded
+ * 8-bit RGB images in device memory ([H][W][3] rows of `pitch` bytes; a half of the paired A|B image is addressed by
+ * offsetting `src`).
+ * gcc_resample_u8: PIL's Image.resize(..., BICUBIC) -- any of its separable filters, the coefficient tables decide --
+ *   bit for bit: horizontal pass, uint8 intermediate, vertical pass, 22-bit fixed-point coefficients (hcoef [out_w][hk],
+ *   hbounds [out_w][2] = first source column and tap count; likewise v*), tmp = in_h * out_w * 3 bytes when both passes
+ *   run.  dst is tightly packed [out_h][out_w][3].
+ * gcc_crop_flip_normalize: __crop + __flip + ToTensor + Normalize((.5,.5,.5),(.5,.5,.5)): NCHW fp32 [3][crop_h][crop_w]
+ *   and / or the NHWC bf16 model input (pixel stride ld, channels 0..2 written).
+ * --------------------------------------------------------------------------------------------- */
+int gcc_resample_u8(const void* src, int in_h, int in_w, size_t pitch, void* dst, int out_h, int out_w, const int* hbounds,
+                    const int* hcoef, int hk, const int* vbounds, const int* vcoef, int vk, void* tmp, gcc_stream_t stream);
+int gcc_crop_flip_normalize(const void* src, int H, int W, size_t pitch, int x0, int y0, int crop_h, int crop_w, int flip,
+                            float* nchw, void* nhwc_bf16, int ld, gcc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -978,6 +978,45 @@ def fixture_metric():
     print('metric ok', {k: float(v) for k, v in out.items() if v.size == 1})
 
 
+def fixture_pipeline():
+    """the paired-image transform chain of data/aligned_dataset.py:40-53 with PIL 12.2.0 (torchvision absent: its
+    Resize / crop / flip / ToTensor / Normalize are spelled out with PIL + numpy), on seeded images: up- and
+    down-scaling resizes, two crop / flip draws of the reference's get_params"""
+    import random
+    from PIL import Image
+    from data.base_dataset import get_params
+    rng = np.random.RandomState(91)
+    out = {'pil_version': np.array(Image.__version__)}
+    for tag, h, w, load, crop in (('up', 64, 64, 78, 64), ('down', 90, 70, 48, 40), ('same', 32, 32, 32, 32)):
+        ab = (rng.rand(h, 2 * w, 3) * 255).astype(np.uint8)
+        ab[: h // 2, : w // 3] = 255                                  # saturated patches: the clip of the fixed-point sums
+        ab[h // 2:, w: w + w // 4] = 0
+        out[tag + '.AB'] = ab
+        opt = types.SimpleNamespace(preprocess='resize_and_crop', load_size=load, crop_size=crop, no_flip=False)
+        random.seed(5 + h)
+        for j in range(2):
+            AB = Image.fromarray(ab).convert('RGB')
+            ww, hh = AB.size
+            w2 = int(ww / 2)
+            A, B = AB.crop((0, 0, w2, hh)), AB.crop((w2, 0, ww, hh))
+            p = get_params(opt, A.size)
+            out['%s.%d.crop_pos' % (tag, j)], out['%s.%d.flip' % (tag, j)] = np.array(p['crop_pos']), np.array(p['flip'])
+            for name, img in (('A', A), ('B', B)):
+                img = img.resize((load, load), Image.BICUBIC)
+                if j == 0:
+                    out['%s.%s.resized' % (tag, name)] = np.array(img)
+                x, y = p['crop_pos']
+                if img.size[0] > crop or img.size[1] > crop:
+                    img = img.crop((x, y, x + crop, y + crop))
+                if p['flip']:
+                    img = img.transpose(Image.FLIP_LEFT_RIGHT)
+                t = torch.from_numpy(np.array(img)).permute(2, 0, 1).to(torch.float32).div(255)
+                t = t.sub_(0.5).div_(0.5)
+                out['%s.%d.%s' % (tag, j, name)] = t.numpy()
+    np.savez_compressed(os.path.join(HERE, 'pipeline.npz'), **out)
+    print('pipeline ok', {k: v.tolist() for k, v in out.items() if 'crop_pos' in k or 'flip' in k})
+
+
 def fixture_options():
     import json
     from options import options
@@ -1004,6 +1043,6 @@ if __name__ == '__main__':
     only = sys.argv[1:]            # e.g. "make_fixtures.py cyclegan cyclegan_pretrain"; none = all
     import_reference()
     for fn in (fixture_options, fixture_ops, fixture_eval_d8, fixture_gcc_d6, fixture_pretrain_d6, fixture_prune_d8,
-               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan, fixture_srgan, fixture_prune_search_gan, fixture_checkpoint, fixture_metric):
+               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan, fixture_srgan, fixture_prune_search_gan, fixture_checkpoint, fixture_metric, fixture_pipeline):
         if not only or fn.__name__[len('fixture_'):] in only:
             fn()

@@ -1,0 +1,94 @@
+"""Input pipeline: the oracle's restatement of Pillow's bicubic resample against PIL itself
+and the golden fixture (bit-exact), the host-side coefficient tables, and the HIP kernels against both."""
+import os
+import random
+import types
+
+import numpy as np
+import pytest
+import torch
+
+
+def _z(golden_dir):
+    return np.load(os.path.join(golden_dir, 'pipeline.npz'))
+
+
+CASES = (('up', 78, 64), ('down', 48, 40), ('same', 32, 32))
+
+
+def test_pipeline_oracle_bit_exact_vs_pil_golden(golden_dir):
+    from oracle import pipeline_oracle as P
+    z = _z(golden_dir)
+    for tag, load, crop in CASES:
+        ab = z[tag + '.AB']
+        w2 = ab.shape[1] // 2
+        for name, img in (('A', ab[:, :w2]), ('B', ab[:, w2:])):
+            assert np.array_equal(P.resample_bicubic(img, load, load), z['%s.%s.resized' % (tag, name)]), (tag, name)
+        for j in range(2):
+            A, B = P.aligned_item(ab, load, crop, tuple(int(v) for v in z['%s.%d.crop_pos' % (tag, j)]), bool(z['%s.%d.flip' % (tag, j)]))
+            assert np.array_equal(A, z['%s.%d.A' % (tag, j)]) and np.array_equal(B, z['%s.%d.B' % (tag, j)]), (tag, j)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    rng = np.random.RandomState(3)
+    for (h, w, oh, ow) in ((37, 53, 80, 91), (120, 77, 31, 40), (64, 64, 64, 100), (50, 50, 20, 50), (256, 256, 286, 286)):
+        img = (rng.rand(h, w, 3) * 255).astype(np.uint8)
+        ref = np.array(Image.fromarray(img).resize((ow, oh), Image.BICUBIC))
+        assert np.array_equal(P.resample_bicubic(img, oh, ow), ref), (h, w, oh, ow)
+
+
+def test_get_params_and_coefficients_host(golden_dir):
+    from gcc_amd.data import get_params, resample_coeffs
+    from oracle import pipeline_oracle as P
+    z = _z(golden_dir)
+    for tag, load, crop in CASES:
+        ab = z[tag + '.AB']
+        opt = types.SimpleNamespace(preprocess='resize_and_crop', load_size=load, crop_size=crop, no_flip=False)
+        random.seed(5 + ab.shape[0])
+        for j in range(2):
+            p = get_params(opt, (ab.shape[1] // 2, ab.shape[0]))
+            assert list(p['crop_pos']) == [int(v) for v in z['%s.%d.crop_pos' % (tag, j)]] and p['flip'] == bool(z['%s.%d.flip' % (tag, j)])
+    for n_in, n_out in ((64, 78), (90, 48), (70, 48), (256, 286), (300, 100)):
+        b, c, k = resample_coeffs(n_in, n_out)
+        for xx, (xmin, kk) in enumerate(P._coeffs(n_in, n_out)):
+            assert b[xx, 0] == xmin and b[xx, 1] == len(kk) and np.array_equal(c[xx, :len(kk)], kk) and not c[xx, len(kk):].any()
+
+
+@pytest.mark.gpu
+def test_pipeline_kernels_bit_exact(golden_dir):
+    from gcc_amd.data import AlignedGpuPipeline
+    z = _z(golden_dir)
+    for tag, load, crop in CASES:
+        ab = torch.from_numpy(z[tag + '.AB'])
+        opt = types.SimpleNamespace(preprocess='resize_and_crop', load_size=load, crop_size=crop, no_flip=False)
+        pipe = AlignedGpuPipeline(opt)
+        dev_ab = ab.cuda()
+        w2 = ab.shape[1] // 2
+        for name, img in (('A', dev_ab[:, :w2]), ('B', dev_ab[:, w2:])):
+            got = pipe.resize(img, load, load).cpu().numpy()
+            assert np.array_equal(got, z['%s.%s.resized' % (tag, name)]), (tag, name)
+        for j in range(2):
+            params = {'crop_pos': tuple(int(v) for v in z['%s.%d.crop_pos' % (tag, j)]), 'flip': bool(z['%s.%d.flip' % (tag, j)])}
+            item = pipe(ab, params)
+            assert np.array_equal(item['A'].cpu().numpy(), z['%s.%d.A' % (tag, j)]), (tag, j)
+            assert np.array_equal(item['B'].cpu().numpy(), z['%s.%d.B' % (tag, j)]), (tag, j)
+        random.seed(5 + ab.shape[0])                 # parameters drawn inside: the reference's sequence
+        item = pipe(ab)
+        assert np.array_equal(item['A'].cpu().numpy(), z['%s.0.A' % tag])
+    # the reference's default geometry: 256x256 halves -> 286 -> crop 256, against the oracle
+    from oracle import pipeline_oracle as P
+    rng = np.random.RandomState(11)
+    ab = (rng.rand(256, 512, 3) * 255).astype(np.uint8)
+    opt = types.SimpleNamespace(preprocess='resize_and_crop', load_size=286, crop_size=256, no_flip=False)
+    pipe = AlignedGpuPipeline(opt)
+    item = pipe(torch.from_numpy(ab), {'crop_pos': (17, 29), 'flip': True})
+    A, B = P.aligned_item(ab, 286, 256, (17, 29), True)
+    assert np.array_equal(item['A'].cpu().numpy(), A) and np.array_equal(item['B'].cpu().numpy(), B)
+    batch = pipe.batch([torch.from_numpy(ab)] * 2, ['p0', 'p1'])
+    assert batch['A'].shape == (2, 3, 256, 256) and batch['A_paths'] == ['p0', 'p1'] and batch['A'].dtype == torch.float32
+    # cityscapes options (options.py:168-169): load_size 256, no_flip -> split + scale only
+    opt = types.SimpleNamespace(preprocess='resize_and_crop', load_size=256, crop_size=256, no_flip=True)
+    item = AlignedGpuPipeline(opt)(torch.from_numpy(ab), {'crop_pos': (0, 0), 'flip': True})
+    A, B = P.aligned_item(ab, 256, 256, (0, 0), False)
+    assert np.array_equal(item['A'].cpu().numpy(), A) and np.array_equal(item['B'].cpu().numpy(), B)
