@@ -14,7 +14,6 @@ Reference behaviour reproduced on purpose:
     ``$GCC_VGG19_WEIGHTS`` (a torchvision ``vgg19`` state_dict: keys ``features.N.weight/bias``); without it the model
     refuses to build unless ``GCC_VGG19_RANDOM=1`` asks for seeded random weights (benchmarks / tests with a stand-in).
 """
-import copy
 import math
 import os
 from collections import OrderedDict
@@ -24,7 +23,7 @@ import torch.nn as nn
 
 from .. import dist as gdist
 from .. import engine, ops
-from .._lib import GccError
+from .._lib import GccError, check
 from ..utils import util
 from .DifferentiableOp import DifferentiableOP
 from .Pix2Pix import HipAdam, _portable
@@ -605,7 +604,6 @@ class SRGAN(TeacherStreamMixin, nn.Module):
         L = ops.lib()
         sse = torch.zeros(1, dtype=torch.float64, device=fake.device)
         ws = torch.empty(L.gcc_psnr_workspace(), dtype=torch.uint8, device=fake.device)
-        from .._lib import check
         check(L.gcc_psnr_y_sse(fake.data_ptr(), real.data_ptr(), N, H, W, sse.data_ptr(), 0, ws.data_ptr(), ws.numel(),
                                ops.stream()), 'gcc_psnr_y_sse')
         mse = float(sse.item()) / (N * (H - 8) * (W - 8))

@@ -5,7 +5,6 @@ absent from the image): Resize -> PIL ``img.resize((w, h), BICUBIC)``, __crop ->
 ``transpose(FLIP_LEFT_RIGHT)``, ToTensor -> uint8 / 255 as CHW float32, Normalize -> (x - 0.5) / 0.5.
 ``resample_bicubic`` restates Pillow's Resample.c (two integer passes, 22-bit coefficients); it is pinned to PIL 12.2.0
 itself in tests/test_pipeline.py and through tests/golden/pipeline.npz."""
-import math
 
 import numpy as np
 
