@@ -56,7 +56,7 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
+@pytest.mark.timeout(600)
 def test_gloo_world2_gradient_exchange():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -64,7 +64,7 @@ def test_gloo_world2_gradient_exchange():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=100) for _ in range(2)]
+    res = [q.get(timeout=480) for _ in range(2)]
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
