@@ -233,7 +233,10 @@ __global__ __launch_bounds__(NTH) void bnact_bwd_reduce_kernel(const BwdArgs a0)
     const int pl = threadIdx.x >> a.L.sh;
     const int c0 = ch * V;
     const bool active = ch < a.L.CH;
-    float mu[V], rs[V], sc[GATE || DROP ? V : 1], sf[GATE || DROP ? V : 1], gm[GATE ? V : 1];
+    // NOY: no saved activation output -- its sign is recomputed from x through the BatchNorm affine (2 bytes per element
+    // less to read than the saved y; this kernel is HBM-bound)
+    const bool NOY = !a.y && a.p.bn;
+    float mu[V], rs[V], sc[V], sf[V], gm[GATE ? V : 1];
     float s0[V], s1[V], s2[GATE ? V : 1];
 #pragma unroll
     for (int j = 0; j < V; j++) {
@@ -241,12 +244,12 @@ __global__ __launch_bounds__(NTH) void bnact_bwd_reduce_kernel(const BwdArgs a0)
         const bool v = active && c < a.C;
         mu[j] = (v && a.p.bn) ? a.p.mean[c] : 0.f;
         rs[j] = (v && a.p.bn) ? a.p.rstd[c] : (v ? 1.f : 0.f);
-        if constexpr (GATE || DROP) {
+        if (GATE || DROP || NOY) {
             const float g = (v && a.p.bn && a.p.gamma) ? a.p.gamma[c] : 1.f;
             const float b = (v && a.p.bn && a.p.beta) ? a.p.beta[c] : 0.f;
             sc[j] = g * rs[j];
             sf[j] = b - mu[j] * sc[j];
-        }
+        } else { sc[j] = 1.f; sf[j] = 0.f; }
         if constexpr (GATE) { gm[j] = v ? (a.p.gate ? a.p.gate[c] : 1.f) : 0.f; s2[j] = 0.f; }
         s0[j] = s1[j] = 0.f;
     }
@@ -289,11 +292,8 @@ __global__ __launch_bounds__(NTH) void bnact_bwd_reduce_kernel(const BwdArgs a0)
                     float yo;
                     if (a.y) yo = yv[j];
                     else if (DROP) yo = apply_act(zd, a.p.act, a.p.slope);
-                    else if (a.p.bn) {
-                        const int cc = c0 + j < a.C ? c0 + j : 0;
-                        const float gmm = a.p.gamma ? a.p.gamma[cc] : 1.f, bta = a.p.beta ? a.p.beta[cc] : 0.f;
-                        yo = apply_act((xv[j] - mu[j]) * rs[j] * gmm + bta, a.p.act, a.p.slope);
-                    } else yo = xv[j];
+                    else if (a.p.bn) yo = apply_act(xv[j] * sc[j] + sf[j], a.p.act, a.p.slope);   // the forward's own form
+                    else yo = xv[j];
                     g = g1v[j] * act_grad_from_out(yo, a.p.act, a.p.slope);
                     if (a.g2) g += g2v[j] * act_grad_from_out(yo, a.p.act2, a.p.slope);
                 }

@@ -324,7 +324,8 @@ class UnetEngine:
             w = wd[d - 1]
             bn = self.up_bn[d].bn
             drop = 0.5 if (c.train and d in self.drop_depths) else 0.0
-            ops.bnact_bwd(c.t[d], ops.cslice(c.rcat[d], self.uoff[d], uw[d]), ops.cslice(c.g_rcat[d], self.uoff[d], uw[d]), c.g_t[d], bn=c.st_up[d],
+            # y = None: the activation's sign is recomputed from the BatchNorm affine instead of reading the saved output
+            ops.bnact_bwd(c.t[d], None, ops.cslice(c.g_rcat[d], self.uoff[d], uw[d]), c.g_t[d], bn=c.st_up[d],
                           gamma=bn.weight.data, beta=bn.bias.data, bn_eval=not c.train, act=ACT_RELU, drop_p=drop,
                           seed=c.iter_seed * 64 + d, dgamma=bn.weight.grad if wgrad else None,
                           dbeta=bn.bias.grad if wgrad else None)
@@ -346,7 +347,7 @@ class UnetEngine:
             g2 = ops.cslice(c.g_rcat[d + 1], 0, wd[d])
             if d > 0:
                 bn = self.down_bn[d].bn
-                ops.bnact_bwd(c.e[d], c.lin[d + 1], c.g_lin[d + 1], c.g_e[d], g2=g2, bn=c.st_down[d], gamma=bn.weight.data,
+                ops.bnact_bwd(c.e[d], None, c.g_lin[d + 1], c.g_e[d], g2=g2, bn=c.st_down[d], gamma=bn.weight.data,
                               beta=bn.bias.data, bn_eval=not c.train, act=ACT_LRELU, act2=ACT_RELU,
                               dgamma=bn.weight.grad if wgrad else None, dbeta=bn.bias.grad if wgrad else None)
             else:
@@ -509,7 +510,7 @@ class PatchGANEngine:
                 ops.bnact_bwd(c.c[li], c.y[li], g1, G.layer[li], g2=g2, bn=c.st[li], act=ACT_LRELU, act2=ACT_LRELU, groups=c.N)
             else:
                 bn = self.bn[li].bn
-                ops.bnact_bwd(c.c[li], c.y[li], g1, G.layer[li], g2=g2, bn=c.st[li], gamma=bn.weight.data, beta=bn.bias.data,
+                ops.bnact_bwd(c.c[li], None, g1, G.layer[li], g2=g2, bn=c.st[li], gamma=bn.weight.data, beta=bn.bias.data,
                               gate=self.mask[li], act=ACT_LRELU, act2=ACT_LRELU, dgamma=bn.weight.grad if wgrad else None,
                               dbeta=bn.bias.grad if wgrad else None,
                               dalpha=gate.alpha.grad if (agrad and gate is not None) else None)
