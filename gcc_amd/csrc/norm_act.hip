@@ -98,6 +98,19 @@ template <> __device__ __forceinline__ void ldv<4>(const bf16_t* p, float* f) {
     f[0] = __uint_as_float((uint32_t)v[0] << 16); f[1] = __uint_as_float((uint32_t)v[0] & 0xffff0000u);
     f[2] = __uint_as_float((uint32_t)v[1] << 16); f[3] = __uint_as_float((uint32_t)v[1] & 0xffff0000u);
 }
+// raw loads kept apart from the unpack: the backward reduce pass prefetches the next pixel's vectors before it works on
+// the current ones (two pixels in flight per thread; with one, the pass ran at the memory latency, not the bandwidth)
+template <int V> struct RawVec;
+template <> struct RawVec<8> { typedef i32x4 type; };
+template <> struct RawVec<4> { typedef i32x2 type; };
+template <int V> __device__ __forceinline__ typename RawVec<V>::type ldraw(const bf16_t* p) {
+    return *(const typename RawVec<V>::type*)p;
+}
+__device__ __forceinline__ void unraw(const i32x4& v, float* f) { unpack8(v, f); }
+__device__ __forceinline__ void unraw(const i32x2& v, float* f) {
+    f[0] = __uint_as_float((uint32_t)v[0] << 16); f[1] = __uint_as_float((uint32_t)v[0] & 0xffff0000u);
+    f[2] = __uint_as_float((uint32_t)v[1] << 16); f[3] = __uint_as_float((uint32_t)v[1] & 0xffff0000u);
+}
 template <int V> __device__ __forceinline__ void stv(bf16_t* p, const float* f);
 template <> __device__ __forceinline__ void stv<8>(bf16_t* p, const float* f) { *(i32x4*)p = pack8(f); }
 template <> __device__ __forceinline__ void stv<4>(bf16_t* p, const float* f) {
@@ -256,12 +269,28 @@ __global__ __launch_bounds__(NTH) void bnact_bwd_reduce_kernel(const BwdArgs a0)
     const float keep_scale = a.p.drop_p > 0.f ? 1.f / (1.f - a.p.drop_p) : 1.f;
     const float evs = (a.p.bn && a.p.bn_eval) ? 1.f : 0.f;
     if (active) {
-        for (size_t pix = (size_t)blockIdx.x * a.L.PPB + pl; pix < a.pixels; pix += (size_t)gridDim.x * a.L.PPB) {
+        typedef typename RawVec<V>::type Raw;
+        const size_t pstep = (size_t)gridDim.x * a.L.PPB;
+        size_t pix = (size_t)blockIdx.x * a.L.PPB + pl;
+        Raw rx = {}, ry = {}, rg1 = {}, rg2 = {};
+        if (pix < a.pixels) {
+            rx = ldraw<V>(a.x + pix * a.ldx + a.xoff + c0);
+            if (a.y) ry = ldraw<V>(a.y + pix * a.ldy + a.yoff + c0);
+            rg1 = ldraw<V>(a.g1 + pix * a.ldg1 + a.g1off + c0);
+            if (a.g2) rg2 = ldraw<V>(a.g2 + pix * a.ldg2 + a.g2off + c0);
+        }
+        for (; pix < a.pixels; pix += pstep) {
             float xv[V], yv[V], g1v[V], g2v[V], dz[V];
-            ldv<V>(a.x + pix * a.ldx + a.xoff + c0, xv);
-            if (a.y) ldv<V>(a.y + pix * a.ldy + a.yoff + c0, yv);
-            ldv<V>(a.g1 + pix * a.ldg1 + a.g1off + c0, g1v);
-            if (a.g2) ldv<V>(a.g2 + pix * a.ldg2 + a.g2off + c0, g2v);
+            unraw(rx, xv); unraw(rg1, g1v);
+            if (a.y) unraw(ry, yv);
+            if (a.g2) unraw(rg2, g2v);
+            const size_t nx = pix + pstep;
+            if (nx < a.pixels) {                 // next pixel's loads fly while this one is computed and stored
+                rx = ldraw<V>(a.x + nx * a.ldx + a.xoff + c0);
+                if (a.y) ry = ldraw<V>(a.y + nx * a.ldy + a.yoff + c0);
+                rg1 = ldraw<V>(a.g1 + nx * a.ldg1 + a.g1off + c0);
+                if (a.g2) rg2 = ldraw<V>(a.g2 + nx * a.ldg2 + a.g2off + c0);
+            }
 #pragma unroll
             for (int j = 0; j < V; j++) {
                 float df = 1.f;
@@ -343,7 +372,19 @@ __global__ __launch_bounds__(1024) void bnact_bwd_finalize_kernel(const BwdArgs 
     const int c = blockIdx.x * 32 + cl;
     double t[3] = {0.0, 0.0, 0.0};
     if (c < a.C8) {
-        for (int b = pl; b < blocks; b += 32) {
+        // four partial rows (12 loads) in flight per thread: the pass is a latency chain otherwise
+        int b = pl;
+        for (; b + 96 < blocks; b += 128) {
+            float v[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float* o = a.partial + (size_t)(b + 32 * u) * 3 * a.C8;
+                v[u][0] = o[c]; v[u][1] = o[a.C8 + c]; v[u][2] = o[2 * a.C8 + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { t[0] += v[u][0]; t[1] += v[u][1]; t[2] += v[u][2]; }
+        }
+        for (; b < blocks; b += 32) {
             const float* o = a.partial + (size_t)b * 3 * a.C8;
             t[0] += o[c]; t[1] += o[a.C8 + c]; t[2] += o[2 * a.C8 + c];
         }
@@ -389,14 +430,25 @@ __global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(const BwdArgs a0) 
             A[j] = a0_[j]; A[4 + j] = a1_[j]; B[j] = b0_[j]; B[4 + j] = b1_[j]; K[j] = k0_[j]; K[4 + j] = k1_[j];
         }
     }
-    for (size_t pix = (size_t)blockIdx.x * a.L.PPB + pl; pix < a.pixels; pix += (size_t)gridDim.x * a.L.PPB) {
+    const size_t pstep = (size_t)gridDim.x * a.L.PPB;
+    size_t pix = (size_t)blockIdx.x * a.L.PPB + pl;
+    i32x4 rx = {}, rz = {};
+    if (pix < a.pixels) {
+        rx = *(const i32x4*)(a.x + pix * a.ldx + a.xoff + c0);
+        rz = *(const i32x4*)(a.dx + pix * a.lddx + a.dxoff + c0);
+    }
+    for (; pix < a.pixels; pix += pstep) {
         float xv[8], dz[8], o[8];
-        unpack8(*(const i32x4*)(a.x + pix * a.ldx + a.xoff + c0), xv);
-        bf16_t* dp = a.dx + pix * a.lddx + a.dxoff + c0;
-        unpack8(*(const i32x4*)dp, dz);
+        unpack8(rx, xv);
+        unpack8(rz, dz);
+        const size_t nx = pix + pstep;
+        if (nx < a.pixels) {                     // two pixels in flight per thread
+            rx = *(const i32x4*)(a.x + nx * a.ldx + a.xoff + c0);
+            rz = *(const i32x4*)(a.dx + nx * a.lddx + a.dxoff + c0);
+        }
 #pragma unroll
         for (int j = 0; j < 8; j++) o[j] = A[j] * dz[j] + B[j] * xv[j] + K[j];
-        *(i32x4*)dp = pack8(o);
+        *(i32x4*)(a.dx + pix * a.lddx + a.dxoff + c0) = pack8(o);
     }
 }
 

@@ -30,5 +30,5 @@ for name, N, C, H, W, gate in (('D.L1 gate-after-act', 16, 128, 128, 128, True),
         print('%-22s fwd %6.1f us (%5.2f TB/s @4B/elem)   bwd %6.1f us (%5.2f TB/s @6B/elem)' % (name, tf * 1e6, elems * 4 / tf / 1e12, tb * 1e6, elems * 6 / tb / 1e12))
     else:
         tf = timeit(lambda: ops.bnact_fwd(x, y, scale=st.scale, shift=st.shift, gate=mask, act=ops.ACT_LRELU))
-        tb = timeit(lambda: ops.bnact_bwd(x, y, g, dx, bn=st, gamma=gamma, beta=beta, gate=mask, act=ops.ACT_LRELU, dgamma=dg, dbeta=db, dalpha=da if gate else None))
-        print('%-22s fwd %6.1f us (%5.2f TB/s @4B/elem)   bwd %6.1f us (%5.2f TB/s @14B/elem)' % (name, tf * 1e6, elems * 4 / tf / 1e12, tb * 1e6, elems * 14 / tb / 1e12))
+        tb = timeit(lambda: ops.bnact_bwd(x, None, g, dx, bn=st, gamma=gamma, beta=beta, gate=mask, act=ops.ACT_LRELU, dgamma=dg, dbeta=db, dalpha=da if gate else None))
+        print('%-22s fwd %6.1f us (%5.2f TB/s @4B/elem)   bwd %6.1f us (%5.2f TB/s @12B/elem)' % (name, tf * 1e6, elems * 4 / tf / 1e12, tb * 1e6, elems * 14 / tb / 1e12))
