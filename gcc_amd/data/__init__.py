@@ -155,3 +155,42 @@ class AlignedGpuPipeline:
         paths = paths or [''] * len(items)
         return {'A': torch.stack([i['A'] for i in items]), 'B': torch.stack([i['B'] for i in items]),
                 'A_paths': list(paths), 'B_paths': list(paths)}
+
+
+class UnalignedGpuPipeline(AlignedGpuPipeline):
+    """``pipe(A_img, B_img)`` -> {'A', 'B'}: the per-image work of UnalignedDataset.__getitem__
+    (data/unaligned_dataset.py:45-75) after decoding: each image goes through get_transform(opt) with params=None, i.e.
+    Resize, torchvision's RandomCrop and RandomHorizontalFlip.  Their random draws are restated from torchvision
+    (absent from this image, so that sequence is unpinned): RandomCrop.get_params draws
+    ``torch.randint(0, h - th + 1, (1,))`` then ``torch.randint(0, w - tw + 1, (1,))`` unless the image already has the
+    crop size, RandomHorizontalFlip flips when ``torch.rand(1) < 0.5``.  ``index_B`` is the caller's
+    (``random.randint(0, B_size - 1)`` unless serial_batches, :62-65)."""
+
+    def _one(self, img):
+        opt = self.opt
+        img = img.to(self.device, non_blocking=True).contiguous()
+        if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
+            raise GccError('expected a decoded RGB image, uint8 [h, w, 3]')
+        if 'resize' in opt.preprocess:
+            img = self.resize(img, opt.load_size, opt.load_size)
+        x = y = 0
+        crop = opt.crop_size
+        h, w = img.shape[0], img.shape[1]
+        if 'crop' in opt.preprocess:
+            if not (h == crop and w == crop):
+                if h < crop or w < crop:
+                    raise ValueError('Required crop size %s is larger than input image size %s' % ((crop, crop), (h, w)))
+                y = int(torch.randint(0, h - crop + 1, size=(1,)).item())
+                x = int(torch.randint(0, w - crop + 1, size=(1,)).item())
+        else:
+            crop = max(h, w) + 1
+        flip = (not opt.no_flip) and bool(torch.rand(1) < 0.5)
+        if 'crop' in opt.preprocess:
+            out = torch.empty((3, crop, crop), dtype=torch.float32, device=self.device)
+            check(ops.lib().gcc_crop_flip_normalize(img.data_ptr(), h, w, img.stride(0), x, y, crop, crop, int(flip),
+                                                    out.data_ptr(), None, 0, ops.stream()), 'gcc_crop_flip_normalize')
+            return out
+        return self.finish(img, (0, 0), crop, flip)
+
+    def __call__(self, A_img, B_img):
+        return {'A': self._one(A_img), 'B': self._one(B_img)}

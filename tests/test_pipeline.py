@@ -92,3 +92,29 @@ def test_pipeline_kernels_bit_exact(golden_dir):
     item = AlignedGpuPipeline(opt)(torch.from_numpy(ab), {'crop_pos': (0, 0), 'flip': True})
     A, B = P.aligned_item(ab, 256, 256, (0, 0), False)
     assert np.array_equal(item['A'].cpu().numpy(), A) and np.array_equal(item['B'].cpu().numpy(), B)
+
+
+@pytest.mark.gpu
+def test_unaligned_pipeline_vs_oracle():
+    """UnalignedDataset's transform chain: the same kernels with torchvision's RandomCrop / RandomHorizontalFlip draws
+    (restated: torchvision is absent); checked against the oracle fed with the same draws"""
+    from gcc_amd.data import UnalignedGpuPipeline
+    from oracle import pipeline_oracle as P
+    rng = np.random.RandomState(21)
+    a = (rng.rand(200, 180, 3) * 255).astype(np.uint8)
+    b = (rng.rand(150, 260, 3) * 255).astype(np.uint8)
+    opt = types.SimpleNamespace(preprocess='resize_and_crop', load_size=96, crop_size=80, no_flip=False)
+    pipe = UnalignedGpuPipeline(opt)
+    torch.manual_seed(1234)
+    item = pipe(torch.from_numpy(a), torch.from_numpy(b))
+    torch.manual_seed(1234)
+    for name, img in (('A', a), ('B', b)):
+        r = P.resample_bicubic(img, 96, 96)
+        y = int(torch.randint(0, 96 - 80 + 1, size=(1,)).item())
+        x = int(torch.randint(0, 96 - 80 + 1, size=(1,)).item())
+        flip = bool(torch.rand(1) < 0.5)
+        c = r[y:y + 80, x:x + 80]
+        if flip:
+            c = c[:, ::-1]
+        ref = (np.transpose(c.astype(np.float32) / np.float32(255.), (2, 0, 1)) - np.float32(0.5)) / np.float32(0.5)
+        assert np.array_equal(item[name].cpu().numpy(), ref), name
