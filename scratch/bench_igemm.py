@@ -21,6 +21,11 @@ SHAPES = [
     ('tG.d3 256->512 k4s2 @32', 16, 32, 32, 256, 512, 4, 2, 1),
     ('tG.u3 adj 256->1024 k4s2 @32', 16, 32, 32, 256, 1024, 4, 2, 1),
     ('tG.u2 adj 128->512 k4s2 @64', 16, 64, 64, 128, 512, 4, 2, 1),
+    ('tG.d4 512->512 k4s2 @16', 16, 16, 16, 512, 512, 4, 2, 1),
+    ('tG.d5 512->512 k4s2 @8', 16, 8, 8, 512, 512, 4, 2, 1),
+    ('tG.u4 adj 512->1024 k4s2 @16', 16, 16, 16, 512, 1024, 4, 2, 1),
+    ('sG.d2 64->128 k4s2 @64', 16, 64, 64, 64, 128, 4, 2, 1),
+    ('sG.d3 128->256 k4s2 @32', 16, 32, 32, 128, 256, 4, 2, 1),
     # K scan on the D.L2 geometry (M = 65536, N = 256): nk = 16 .. 128 k-steps per workgroup
     ('Kscan 64->256 k4s2 @128', 16, 128, 128, 64, 256, 4, 2, 1),
     ('Kscan 128->256 k4s2 @128', 16, 128, 128, 128, 256, 4, 2, 1),
