@@ -194,3 +194,64 @@ class UnalignedGpuPipeline(AlignedGpuPipeline):
 
     def __call__(self, A_img, B_img):
         return {'A': self._one(A_img), 'B': self._one(B_img)}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Loader glue (data/image_folder.py:13-33, data/aligned_dataset.py:20-58, data/__init__.py:52-100): file listing and
+# decoding stay on the host (PIL; out of scope), everything after the decode runs on the GPU.
+# ------------------------------------------------------------------------------------------------------------------
+IMG_EXTENSIONS = ['.jpg', '.JPG', '.jpeg', '.JPEG', '.png', '.PNG', '.ppm', '.PPM', '.bmp', '.BMP', '.tif', '.TIF', '.tiff', '.TIFF']
+
+
+def make_dataset(dir, max_dataset_size=float('inf')):
+    """data/image_folder.py:24-33"""
+    import os
+    assert os.path.isdir(dir), '%s is not a valid directory' % dir
+    images = []
+    for root, _, fnames in sorted(os.walk(dir)):
+        for fname in fnames:
+            if any(fname.endswith(e) for e in IMG_EXTENSIONS):
+                images.append(os.path.join(root, fname))
+    return images[:min(max_dataset_size, len(images))]
+
+
+class AlignedGpuDataLoader:
+    """What ``create_dataset(opt)`` returns for ``--dataset_mode aligned``: iterating yields the batch dicts of
+    set_input.  Order: ``serial_batches`` -> file order, else a permutation drawn like torch's RandomSampler (a seed from the
+    default torch generator, ``torch.randperm`` on a generator of its own) -- the sequence a single-process DataLoader
+    gives.  Augmentation parameters come from get_params in item order.  ``decode_threads`` host threads decode ahead
+    (PIL releases the GIL)."""
+
+    def __init__(self, opt, device=None, decode_threads=8):
+        import os
+        self.opt = opt
+        self.paths = sorted(make_dataset(os.path.join(opt.dataroot, opt.phase), opt.max_dataset_size))
+        self.pipe = AlignedGpuPipeline(opt, device)
+        self.threads = int(decode_threads)
+
+    def __len__(self):
+        return len(self.paths)
+
+    @staticmethod
+    def decode(path):
+        from PIL import Image
+        return torch.from_numpy(np.asarray(Image.open(path).convert('RGB')).copy())
+
+    def order(self):
+        n = len(self.paths)
+        if self.opt.serial_batches:
+            return list(range(n))
+        torch.empty((), dtype=torch.int64).random_()          # DataLoader's per-epoch base seed for workers: drawn first
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        g = torch.Generator()
+        g.manual_seed(seed)
+        return torch.randperm(n, generator=g).tolist()
+
+    def __iter__(self):
+        from concurrent.futures import ThreadPoolExecutor
+        order, bs = self.order(), int(self.opt.batch_size)
+        with ThreadPoolExecutor(max(1, self.threads)) as pool:
+            futs = [pool.submit(self.decode, self.paths[i]) for i in order]
+            for b in range(0, len(order), bs):
+                idx = order[b:b + bs]
+                yield self.pipe.batch([f.result() for f in futs[b:b + bs]], [self.paths[i] for i in idx])

@@ -118,3 +118,76 @@ def test_unaligned_pipeline_vs_oracle():
             c = c[:, ::-1]
         ref = (np.transpose(c.astype(np.float32) / np.float32(255.), (2, 0, 1)) - np.float32(0.5)) / np.float32(0.5)
         assert np.array_equal(item[name].cpu().numpy(), ref), name
+
+
+def test_loader_order_matches_torch_random_sampler():
+    """the permutation of AlignedGpuDataLoader against torch's own DataLoader(shuffle=True) in a single process"""
+    from gcc_amd.data import AlignedGpuDataLoader
+    import torch.utils.data as tud
+    n = 37
+    ld = AlignedGpuDataLoader.__new__(AlignedGpuDataLoader)
+    ld.paths, ld.opt = list(range(n)), types.SimpleNamespace(serial_batches=False)
+    torch.manual_seed(2024)
+    mine = [ld.order() for _ in range(2)]
+    torch.manual_seed(2024)
+    dl = tud.DataLoader(list(range(n)), batch_size=1, shuffle=True, num_workers=0)
+    ref = [[int(b) for b in dl] for _ in range(2)]
+    assert mine == ref
+    ld.opt.serial_batches = True
+    assert ld.order() == list(range(n))
+
+
+@pytest.mark.gpu
+def test_aligned_loader_from_files(tmp_path):
+    """files on disk -> batch dicts: PNG decode on the host, the rest on the GPU; against the oracle with the same draws"""
+    from PIL import Image
+    from gcc_amd.data import AlignedGpuDataLoader
+    from oracle import pipeline_oracle as P
+    rng = np.random.RandomState(5)
+    d = tmp_path / 'train'
+    d.mkdir()
+    imgs = {}
+    for i in range(5):
+        a = (rng.rand(40, 96, 3) * 255).astype(np.uint8)
+        Image.fromarray(a).save(str(d / ('img_%02d.png' % i)))
+        imgs['img_%02d.png' % i] = a
+    (d / 'notes.txt').write_text('not an image')
+    opt = types.SimpleNamespace(dataroot=str(tmp_path), phase='train', max_dataset_size=float('inf'), preprocess='resize_and_crop',
+                                load_size=44, crop_size=40, no_flip=False, serial_batches=True, batch_size=2)
+    loader = AlignedGpuDataLoader(opt)
+    assert len(loader) == 5
+    random.seed(77)
+    batches = list(loader)
+    assert [b['A'].shape[0] for b in batches] == [2, 2, 1]
+    random.seed(77)
+    k = 0
+    for b in batches:
+        for j in range(b['A'].shape[0]):
+            name = 'img_%02d.png' % k
+            assert b['A_paths'][j].endswith(name) and b['B_paths'][j] == b['A_paths'][j]
+            x = random.randint(0, 4)
+            y = random.randint(0, 4)
+            flip = random.random() > 0.5
+            A, B = P.aligned_item(imgs[name], 44, 40, (x, y), flip)
+            assert np.array_equal(b['A'][j].cpu().numpy(), A) and np.array_equal(b['B'][j].cpu().numpy(), B), (name,)
+            k += 1
+
+
+@pytest.mark.gpu
+def test_train_loop_on_image_files(tmp_path):
+    """python -m gcc_amd.train on a directory of paired PNGs: the aligned loader feeds the Pix2Pix iteration"""
+    from PIL import Image
+    from gcc_amd import train
+    rng = np.random.RandomState(8)
+    d = tmp_path / 'data' / 'train'
+    d.mkdir(parents=True)
+    for i in range(3):
+        Image.fromarray((rng.rand(64, 128, 3) * 255).astype(np.uint8)).save(str(d / ('p%d.png' % i)))
+    argv = ['--dataroot', str(tmp_path / 'data'), '--model', 'pix2pix', '--gpu_ids', '0', '--ngf', '8', '--ndf', '8',
+            '--teacher_ngf', '16', '--online_distillation', '--darts_discriminator', '--load_size', '64', '--crop_size', '64', '--num_downs', '6',
+            '--n_epochs', '1', '--n_epochs_decay', '0', '--batch_size', '2', '--checkpoints_dir', str(tmp_path / 'ckpt'),
+            '--name', 'files', '--print_freq', '2']
+    train.main(argv)
+    log = (tmp_path / 'ckpt' / 'files' / 'logger.log').read_text()
+    assert 'The number of training images = 3' in log and 'End of epoch 1' in log
+    assert (tmp_path / 'ckpt' / 'files' / 'checkpoints' / 'model_1.pth').exists()
