@@ -107,6 +107,7 @@ PROTOTYPES = {
     'gcc_spectral_grad': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     'gcc_resample_u8': (_I, [_P, _I, _I, _Z, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P]),
     'gcc_crop_flip_normalize': (_I, [_P, _I, _I, _Z, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    'gcc_crop_convert': (_I, [_P, _I, _I, _Z, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     'gcc_argmax_channels': (_I, [_P, _I, _I, _Z, _P, _P]),
     'gcc_confusion_hist': (_I, [_P, _P, _Z, _I, _P, _P]),
     'gcc_psnr_workspace': (_Z, []),

@@ -391,9 +391,13 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const unsigned char* __
         o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
     }
 }
-// crop + horizontal flip + ToTensor (/255) + Normalize((x - 0.5) / 0.5): NCHW fp32, and the model's NHWC bf16 input
+// crop + horizontal flip + ToTensor (/255) + a range conversion, NCHW fp32 (and optionally the model's NHWC bf16 input):
+//   form 0  Normalize(mean, std): (v / 255 - mean[c]) / std[c]      (base_dataset.py:108-111; sr_dataset.py:52-56)
+//   form 1  convert_image '[-1, 1]': 2 * (v / 255) - 1              (sr_dataset.py:49-50)
+//   form 2  '[0, 1]': v / 255
+struct ConvArgs { float mean[3], stdv[3]; int form; };
 __global__ __launch_bounds__(256) void crop_flip_norm_kernel(const unsigned char* __restrict__ src, size_t pitch, int x0, int y0,
-                                                             int ch, int cw, int flip, float* __restrict__ nchw,
+                                                             int ch, int cw, int flip, const ConvArgs cv, float* __restrict__ nchw,
                                                              bf16_t* __restrict__ nhwc, int ld) {
     const size_t total = (size_t)ch * cw;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -402,7 +406,10 @@ __global__ __launch_bounds__(256) void crop_flip_norm_kernel(const unsigned char
         const unsigned char* p = src + (size_t)(y0 + y) * pitch + (size_t)(x0 + sx) * 3;
         float v[3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) v[c] = ((float)p[c] / 255.f - 0.5f) / 0.5f;
+        for (int c = 0; c < 3; c++) {
+            const float t = (float)p[c] / 255.f;
+            v[c] = cv.form == 0 ? (t - cv.mean[c]) / cv.stdv[c] : (cv.form == 1 ? 2.f * t - 1.f : t);
+        }
         if (nchw) {
 #pragma unroll
             for (int c = 0; c < 3; c++) nchw[(size_t)c * total + i] = v[c];
@@ -448,14 +455,24 @@ extern "C" int gcc_resample_u8(const void* src, int in_h, int in_w, size_t pitch
     return GCC_OK;
 }
 
-extern "C" int gcc_crop_flip_normalize(const void* src, int H, int W, size_t pitch, int x0, int y0, int crop_h, int crop_w, int flip,
-                                       float* nchw, void* nhwc_bf16, int ld, gcc_stream_t stream) {
+extern "C" int gcc_crop_convert(const void* src, int H, int W, size_t pitch, int x0, int y0, int crop_h, int crop_w, int flip,
+                                int form, const float* mean3, const float* std3, float* nchw, void* nhwc_bf16, int ld,
+                                gcc_stream_t stream) {
     GCC_ENTER();
     if (!src || (!nchw && !nhwc_bf16) || crop_h <= 0 || crop_w <= 0 || x0 < 0 || y0 < 0 || x0 + crop_w > W || y0 + crop_h > H ||
-        pitch < (size_t)W * 3 || (nhwc_bf16 && (ld < 3)))
+        pitch < (size_t)W * 3 || (nhwc_bf16 && (ld < 3)) || form < 0 || form > 2 || (form == 0 && (!mean3 || !std3)))
         return GCC_ERR_BAD_ARG;
+    ConvArgs cv = {};
+    cv.form = form;
+    for (int c = 0; c < 3; c++) { cv.mean[c] = form == 0 ? mean3[c] : 0.f; cv.stdv[c] = form == 0 ? std3[c] : 1.f; }
     hipLaunchKernelGGL(crop_flip_norm_kernel, dim3(nblk((size_t)crop_h * crop_w, 4096)), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned char*)src, pitch, x0, y0, crop_h, crop_w, flip, nchw, (bf16_t*)nhwc_bf16, ld);
+                       (const unsigned char*)src, pitch, x0, y0, crop_h, crop_w, flip, cv, nchw, (bf16_t*)nhwc_bf16, ld);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
+}
+
+extern "C" int gcc_crop_flip_normalize(const void* src, int H, int W, size_t pitch, int x0, int y0, int crop_h, int crop_w, int flip,
+                                       float* nchw, void* nhwc_bf16, int ld, gcc_stream_t stream) {
+    const float half[3] = {0.5f, 0.5f, 0.5f};
+    return gcc_crop_convert(src, H, W, pitch, x0, y0, crop_h, crop_w, flip, 0, half, half, nchw, nhwc_bf16, ld, stream);
 }

@@ -43,18 +43,28 @@ def _bicubic(x):
     return 0.0
 
 
+def _bilinear(x):
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return 1.0 - x
+    return 0.0
+
+
+_FILTERS = {'bicubic': (_bicubic, 2.0), 'bilinear': (_bilinear, 1.0)}
 _coeff_cache = {}
 
 
-def resample_coeffs(in_size, out_size):
-    """Pillow's precompute_coeffs + normalize_coeffs_8bpc (Resample.c) for the BICUBIC filter over the whole axis:
-    (bounds int32 [out, 2], coefficients int32 [out, ksize], ksize).  Double arithmetic in Pillow's operation order."""
-    key = (in_size, out_size)
+def resample_coeffs(in_size, out_size, filter='bicubic'):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc (Resample.c) for the BICUBIC (or BILINEAR) filter over the whole
+    axis: (bounds int32 [out, 2], coefficients int32 [out, ksize], ksize).  Double arithmetic in Pillow's operation order."""
+    key = (in_size, out_size, filter)
     if key in _coeff_cache:
         return _coeff_cache[key]
+    _bicubic, base_support = _FILTERS[filter]
     scale = float(np.float32(in_size) - np.float32(0.0)) / out_size
     filterscale = scale if scale >= 1.0 else 1.0
-    support = 2.0 * filterscale
+    support = base_support * filterscale
     ksize = int(math.ceil(support)) * 2 + 1
     bounds = np.zeros((out_size, 2), dtype=np.int32)
     coef = np.zeros((out_size, ksize), dtype=np.int32)
@@ -93,20 +103,20 @@ class AlignedGpuPipeline:
         if getattr(opt, 'preprocess', 'resize_and_crop') not in ('resize_and_crop', 'crop', 'none_exact'):
             raise NotImplementedError('preprocess %s: the MI355X pipeline covers resize_and_crop and crop' % opt.preprocess)
 
-    def _dev_tables(self, n_in, n_out):
-        key = (n_in, n_out)
+    def _dev_tables(self, n_in, n_out, filter='bicubic'):
+        key = (n_in, n_out, filter)
         if key not in self._tables:
-            b, c, k = resample_coeffs(n_in, n_out)
+            b, c, k = resample_coeffs(n_in, n_out, filter)
             self._tables[key] = (torch.from_numpy(b).to(self.device), torch.from_numpy(c).to(self.device), k)
         return self._tables[key]
 
-    def resize(self, img, out_h, out_w):
+    def resize(self, img, out_h, out_w, filter='bicubic'):
         """img: uint8 device tensor view [h, w, 3] (rows may be strided) -> uint8 [out_h, out_w, 3]"""
         h, w, _ = img.shape
         assert img.stride(2) == 1 and img.stride(1) == 3
         dst = torch.empty((out_h, out_w, 3), dtype=torch.uint8, device=self.device)
-        hb, hc, hk = self._dev_tables(w, out_w) if out_w != w else (None, None, 0)
-        vb, vc, vk = self._dev_tables(h, out_h) if out_h != h else (None, None, 0)
+        hb, hc, hk = self._dev_tables(w, out_w, filter) if out_w != w else (None, None, 0)
+        vb, vc, vk = self._dev_tables(h, out_h, filter) if out_h != h else (None, None, 0)
         tmp = torch.empty((h, out_w, 3), dtype=torch.uint8, device=self.device) if (hk and vk) else None
         p = lambda t: t.data_ptr() if t is not None else None
         check(ops.lib().gcc_resample_u8(img.data_ptr(), h, w, img.stride(0), dst.data_ptr(), out_h, out_w, p(hb), p(hc), hk,
@@ -255,3 +265,75 @@ class AlignedGpuDataLoader:
             for b in range(0, len(order), bs):
                 idx = order[b:b + bs]
                 yield self.pipe.batch([f.result() for f in futs[b:b + bs]], [self.paths[i] for i in idx])
+
+
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def _convert(img, form, device, mean=None, std=None):
+    """uint8 [h, w, 3] device image -> fp32 [3, h, w] through gcc_crop_convert (the whole image, no flip)"""
+    import ctypes
+    h, w, _ = img.shape
+    out = torch.empty((3, h, w), dtype=torch.float32, device=device)
+    arr = lambda v: (ctypes.c_float * 3)(*v) if v is not None else None
+    check(ops.lib().gcc_crop_convert(img.data_ptr(), h, w, img.stride(0), 0, 0, h, w, 0, form, arr(mean), arr(std),
+                                     out.data_ptr(), None, 0, ops.stream()), 'gcc_crop_convert')
+    return out
+
+
+class SRGpuPipeline(AlignedGpuPipeline):
+    """ImageTransforms of data/sr_dataset.py:66-121 on a decoded image: a random (train) or largest divisible centre (test)
+    crop is the HR image, PIL's BICUBIC downscale by ``upscale_factor`` the LR image; HR -> '[-1, 1]', LR ->
+    'imagenet-norm' (the reference's defaults, options.py:119-120).  ``pipe(img)`` -> {'lr', 'hr'}."""
+
+    def __init__(self, opt, device=None):
+        self.opt = opt
+        if not torch.cuda.is_available():
+            raise GccError('gcc_amd runs on MI355X only (no CPU path): need a visible GPU')
+        self.device = device or torch.device('cuda', torch.cuda.current_device())
+        self._tables = {}
+        if (opt.lr_img_type, opt.hr_img_type) != ('imagenet-norm', '[-1, 1]'):
+            raise NotImplementedError('the MI355X pipeline covers the reference defaults: lr imagenet-norm, hr [-1, 1]')
+
+    def __call__(self, img):
+        opt = self.opt
+        img = img.to(self.device, non_blocking=True).contiguous()
+        h, w = img.shape[0], img.shape[1]
+        s, crop = int(opt.upscale_factor), int(opt.image_size)
+        if str(opt.phase).lower() == 'train':
+            left = random.randint(1, w - crop)
+            top = random.randint(1, h - crop)
+            hr = img[top:top + crop, left:left + crop]
+        else:
+            xr, yr = w % s, h % s
+            hr = img[yr // 2:yr // 2 + (h - yr), xr // 2:xr // 2 + (w - xr)]
+        lr = self.resize(hr, int(hr.shape[0] / s), int(hr.shape[1] / s))
+        return {'lr': _convert(lr, 0, self.device, IMAGENET_MEAN, IMAGENET_STD), 'hr': _convert(hr, 1, self.device)}
+
+
+class SAGpuPipeline(AlignedGpuPipeline):
+    """SADataset's transform (data/sa_dataset.py:26-48): CenterCrop(160) if --center_crop, Resize((crop_size, crop_size))
+    with torchvision's default BILINEAR (PIL, antialiased), ToTensor, Normalize(.5, .5); z ~ torch.randn(z_dim) per item.
+    ``pipe(img)`` -> {'z', 'real_img'}."""
+
+    def __init__(self, opt, device=None):
+        self.opt = opt
+        if not torch.cuda.is_available():
+            raise GccError('gcc_amd runs on MI355X only (no CPU path): need a visible GPU')
+        self.device = device or torch.device('cuda', torch.cuda.current_device())
+        self._tables = {}
+
+    def __call__(self, img):
+        opt = self.opt
+        img = img.to(self.device, non_blocking=True).contiguous()
+        h, w = img.shape[0], img.shape[1]
+        if getattr(opt, 'center_crop', False):
+            th = tw = 160
+            if h < th or w < tw:
+                raise NotImplementedError('CenterCrop(160) pads images smaller than the crop: not on the MI355X path')
+            top, left = int(round((h - th) / 2.0)), int(round((w - tw) / 2.0))       # torchvision.transforms.functional.center_crop
+            img = img[top:top + th, left:left + tw]
+        size = int(opt.crop_size)
+        img = self.resize(img, size, size, filter='bilinear')
+        z = torch.randn(int(opt.z_dim))
+        return {'z': z.to(self.device), 'real_img': self.finish(img, (0, 0), size + 1, False)}

@@ -405,6 +405,10 @@ int gcc_resample_u8(const void* src, int in_h, int in_w, size_t pitch, void* dst
                     const int* hcoef, int hk, const int* vbounds, const int* vcoef, int vk, void* tmp, gcc_stream_t stream);
 int gcc_crop_flip_normalize(const void* src, int H, int W, size_t pitch, int x0, int y0, int crop_h, int crop_w, int flip,
                             float* nchw, void* nhwc_bf16, int ld, gcc_stream_t stream);
+/* the same with the range conversion chosen: form 0 Normalize(mean3, std3) (host arrays; ImageNet statistics for the SRGAN
+ * low-resolution input, data/sr_dataset.py:52-56), form 1 convert_image '[-1, 1]' = 2 (v / 255) - 1 (:49-50), form 2 v / 255 */
+int gcc_crop_convert(const void* src, int H, int W, size_t pitch, int x0, int y0, int crop_h, int crop_w, int flip, int form,
+                     const float* mean3, const float* std3, float* nchw, void* nhwc_bf16, int ld, gcc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -21,10 +21,16 @@ def _bicubic(x):
     return 0.0
 
 
-def _coeffs(in_size, out_size):
+def _bilinear(x):
+    x = abs(x)
+    return 1.0 - x if x < 1.0 else 0.0
+
+
+def _coeffs(in_size, out_size, filt='bicubic'):
     scale = in_size / out_size
     filterscale = max(scale, 1.0)
-    support = 2.0 * filterscale
+    support = (2.0 if filt == 'bicubic' else 1.0) * filterscale
+    _bicubic = globals()['_bicubic'] if filt == 'bicubic' else _bilinear
     out = []
     for xx in range(out_size):
         center = (xx + 0.5) * scale
@@ -39,22 +45,43 @@ def _coeffs(in_size, out_size):
     return out
 
 
-def _pass(img, out_size, axis):
+def _pass(img, out_size, axis, filt='bicubic'):
     img = np.moveaxis(img, axis, 0).astype(np.int64)
     res = np.empty((out_size,) + img.shape[1:], dtype=np.uint8)
-    for xx, (xmin, kk) in enumerate(_coeffs(img.shape[0], out_size)):
+    for xx, (xmin, kk) in enumerate(_coeffs(img.shape[0], out_size, filt)):
         acc = (1 << (PRECISION_BITS - 1)) + np.tensordot(kk, img[xmin:xmin + len(kk)], axes=(0, 0))
         res[xx] = np.clip(acc >> PRECISION_BITS, 0, 255)
     return np.moveaxis(res, 0, axis)
 
 
-def resample_bicubic(img, out_h, out_w):
+def resample_bicubic(img, out_h, out_w, filt='bicubic'):
     """uint8 [h, w, 3] -> uint8 [out_h, out_w, 3], horizontal pass first (Pillow's ImagingResample)"""
     if img.shape[1] != out_w:
-        img = _pass(img, out_w, 1)
+        img = _pass(img, out_w, 1, filt)
     if img.shape[0] != out_h:
-        img = _pass(img, out_h, 0)
+        img = _pass(img, out_h, 0, filt)
     return img.copy()
+
+
+def sr_item(img, crop, scale, left, top):
+    """ImageTransforms (data/sr_dataset.py:86-121), train split, with the crop position given: (lr imagenet-norm, hr [-1, 1])"""
+    hr = img[top:top + crop, left:left + crop]
+    lr = resample_bicubic(hr, crop // scale, crop // scale)
+    t = lambda a: np.transpose(a.astype(np.float32) / np.float32(255.), (2, 0, 1))
+    mean = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(3, 1, 1)
+    return (t(lr) - mean) / std, np.float32(2.) * t(hr) - np.float32(1.)
+
+
+def sa_item(img, size, center_crop):
+    """SADataset.get_transform (data/sa_dataset.py:26-38): CenterCrop(160), bilinear Resize, ToTensor, Normalize(.5, .5)"""
+    if center_crop:
+        h, w = img.shape[:2]
+        top, left = int(round((h - 160) / 2.0)), int(round((w - 160) / 2.0))
+        img = img[top:top + 160, left:left + 160]
+    r = resample_bicubic(img, size, size, 'bilinear')
+    t = np.transpose(r.astype(np.float32) / np.float32(255.), (2, 0, 1))
+    return (t - np.float32(0.5)) / np.float32(0.5)
 
 
 def aligned_item(AB, load_size, crop_size, crop_pos, flip, resize=True):

@@ -191,3 +191,63 @@ def test_train_loop_on_image_files(tmp_path):
     log = (tmp_path / 'ckpt' / 'files' / 'logger.log').read_text()
     assert 'The number of training images = 3' in log and 'End of epoch 1' in log
     assert (tmp_path / 'ckpt' / 'files' / 'checkpoints' / 'model_1.pth').exists()
+
+
+def test_oracle_bilinear_and_sr_sa_items_vs_pil():
+    """the oracle's bilinear resample and its SRGAN / SAGAN transform chains against PIL + torch, where PIL is present"""
+    Image = pytest.importorskip('PIL.Image')
+    from oracle import pipeline_oracle as P
+    rng = np.random.RandomState(31)
+    for (h, w, oh, ow) in ((160, 160, 64, 64), (37, 53, 80, 91), (218, 178, 64, 64)):
+        img = (rng.rand(h, w, 3) * 255).astype(np.uint8)
+        ref = np.array(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+        assert np.array_equal(P.resample_bicubic(img, oh, ow, 'bilinear'), ref), (h, w)
+    img = (rng.rand(130, 150, 3) * 255).astype(np.uint8)
+    pil = Image.fromarray(img)
+    hr = pil.crop((11, 7, 11 + 96, 7 + 96))
+    lr = hr.resize((24, 24), Image.BICUBIC)
+    tt = lambda im: torch.from_numpy(np.array(im)).permute(2, 0, 1).float().div(255)
+    mean = torch.tensor([0.485, 0.456, 0.406]).reshape(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).reshape(3, 1, 1)
+    lr_o, hr_o = P.sr_item(img, 96, 4, 11, 7)
+    assert np.array_equal(lr_o, ((tt(lr) - mean) / std).numpy()) and np.array_equal(hr_o, (2. * tt(hr) - 1.).numpy())
+    face = (rng.rand(218, 178, 3) * 255).astype(np.uint8)
+    c = Image.fromarray(face).crop((9, 29, 169, 189)).resize((64, 64), Image.BILINEAR)
+    assert np.array_equal(P.sa_item(face, 64, True), tt(c).sub_(0.5).div_(0.5).numpy())
+
+
+@pytest.mark.gpu
+def test_sr_and_sa_pipelines_bit_exact():
+    from gcc_amd.data import SAGpuPipeline, SRGpuPipeline
+    from oracle import pipeline_oracle as P
+    rng = np.random.RandomState(32)
+    img = (rng.rand(130, 150, 3) * 255).astype(np.uint8)
+    opt = types.SimpleNamespace(phase='train', image_size=96, upscale_factor=4, lr_img_type='imagenet-norm', hr_img_type='[-1, 1]')
+    pipe = SRGpuPipeline(opt)
+    random.seed(3)
+    item = pipe(torch.from_numpy(img))
+    random.seed(3)
+    left, top = random.randint(1, 150 - 96), random.randint(1, 130 - 96)
+    lr, hr = P.sr_item(img, 96, 4, left, top)
+    assert item['lr'].shape == (3, 24, 24) and item['hr'].shape == (3, 96, 96)
+    assert np.array_equal(item['lr'].cpu().numpy(), lr) and np.array_equal(item['hr'].cpu().numpy(), hr)
+    opt.phase = 'test'
+    odd = (rng.rand(101, 67, 3) * 255).astype(np.uint8)
+    item = SRGpuPipeline(opt)(torch.from_numpy(odd))
+    assert item['hr'].shape == (3, 100, 64) and item['lr'].shape == (3, 25, 16)
+    hr_u8 = odd[0:100, 1:65]                       # largest centre crop divisible by the scaling factor (:100-107)
+    lr_u8 = P.resample_bicubic(hr_u8, 25, 16)
+    t = lambda a: np.transpose(a.astype(np.float32) / np.float32(255.), (2, 0, 1))
+    assert np.array_equal(item['hr'].cpu().numpy(), np.float32(2.) * t(hr_u8) - np.float32(1.))
+    mean = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(3, 1, 1)
+    assert np.array_equal(item['lr'].cpu().numpy(), (t(lr_u8) - mean) / std)
+    face = (rng.rand(218, 178, 3) * 255).astype(np.uint8)
+    sopt = types.SimpleNamespace(center_crop=True, crop_size=64, z_dim=128)
+    torch.manual_seed(5)
+    it = SAGpuPipeline(sopt)(torch.from_numpy(face))
+    torch.manual_seed(5)
+    assert torch.equal(it['z'].cpu(), torch.randn(128))
+    assert np.array_equal(it['real_img'].cpu().numpy(), P.sa_item(face, 64, True))
+    sopt.center_crop = False
+    assert np.array_equal(SAGpuPipeline(sopt)(torch.from_numpy(face))['real_img'].cpu().numpy(), P.sa_item(face, 64, False))
