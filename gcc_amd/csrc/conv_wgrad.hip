@@ -1,11 +1,10 @@
 // Weight gradient of a convolution on MFMA for gfx950:
 //     dW[co][tap][ci] = sum over output pixels m of dY[m][co] * X[pixel(m, tap)][ci]
 // The contraction runs over pixels, which is the slow (strided) dimension of both NHWC operands, so
-// both LDS tiles are [64 pixels][128 channels] images (filled by 16-byte buffer loads, zero padding
-// by the hardware range check) and the MFMA fragments are fetched with the CDNA4 transposing read
-// ds_read_b64_tr_b16.  Rows are padded to 288 B so that the 8 pixel rows one half-wave touches per
-// transposed read land on 8 distinct 32-B bank groups (conflict-free), and ds_write_b128 stays on
-// whole 128-B bank rows.
+// both LDS tiles are [64 pixels][128 channels] images (filled by LDS-DMA, zero padding by the hardware
+// range check) and the MFMA fragments are fetched with the CDNA4 transposing read ds_read_b64_tr_b16.
+// The 32-byte windows of a row are XOR-swizzled with the row number so that the 8 pixel rows one
+// half-wave touches per transposed read land on 8 distinct 32-B bank groups (conflict-free).
 //
 // Tile: 128 (tap,ci) columns x 128 output channels, 64 pixels per step, 256 threads = 2x2 waves.
 // Split-K over pixels: every split writes an fp32 slab, gcc_wgrad_reduce folds the slabs into the
@@ -55,27 +54,37 @@ struct WgradParams {
 constexpr int TP = 64;          // pixels per step
 constexpr int TCOL = 128;
 constexpr int TCO = 128;
-constexpr int RS = 288;         // LDS row stride (bytes)
+constexpr int RS = 256;         // LDS row stride (bytes): 128 channels, no padding -- rows are laid down by 1-KiB LDS-DMA pieces
 constexpr int TILE_BYTES = TP * RS;
 constexpr uint32_t OOB = 0x7FFFFFF0u;
+
+// Both panels are [64 pixels][128 channels] images filled by LDS-DMA (buffer_load ... lds: one wave instruction lays
+// down 1 KiB = 4 pixel rows, lane L -> row L >> 4, 16-byte chunk L & 15; no staging registers, no ds_write).  The 32-byte
+// windows of a row are XOR-swizzled with the row number (on the SOURCE side: a lane fetches the channels that belong in
+// its physical slot), so that the 8 rows a half-wave touches per transposing read fall on 8 distinct bank groups.
+__device__ __forceinline__ int phys_col_bytes(int row, int col_bytes) {          // col_bytes: logical byte offset in the row
+    return ((((col_bytes >> 5) ^ (row & 7)) << 5) | (col_bytes & 31));
+}
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int ks, int colbase, int lane) {
     // 16x16x32 operand from a [pixel][channel] image: lane (g = lane>>4, i = lane&15) ends up with
     // channel colbase+i and the 8 pixel rows {ks*32 + 4g + 0..3, ks*32 + 16 + 4g + 0..3}.
     const int g = lane >> 4, i = lane & 15;
-    const char* a = tile + (ks * 32 + 4 * g + (i >> 2)) * RS + (colbase + 4 * (i & 3)) * 2;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a + 16 * RS));
+    const int r0 = ks * 32 + 4 * g + (i >> 2), r1 = r0 + 16;
+    const int cb = (colbase + 4 * (i & 3)) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + r0 * RS + phys_col_bytes(r0, cb)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + r1 * RS + phys_col_bytes(r1, cb)));
     s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sX = smem;                       // [2][64][288]
-    char* sY = smem + 2 * TILE_BYTES;      // [2][64][288]
+    char* sX = smem;                       // [2][64][256]
+    char* sY = smem + 2 * TILE_BYTES;      // [2][64][256]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave & 1, wb = wave >> 1;
 
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -92,43 +101,47 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)bidx * p.x_bstride), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + (size_t)bidx * p.dy_bstride), 0, p.dy_bytes, 0x00020000);
 
-    // this thread's 16-B column chunk of the X panel: fixed (tap, channel) for the whole K loop
-    const int chunk = tid & 15;
-    const int q = col0 + chunk * 8;
-    const bool col_ok = q < p.ncols;
-    const int tap = fdiv(q, p.dCip);
-    const int cx = q - tap * p.Cip;
-    const int kh = fdiv(tap, p.dKW);
-    const int kw = tap - kh * p.KW;
-    const int dyo = kh - p.pad, dxo = kw - p.pad;
-    const int coy = co0 + chunk * 8;
-    const bool co_ok = coy < ((p.Co + 7) & ~7);
+    // LDS-DMA pieces of this wave: piece i (0..3) covers pixel rows 4 * (4 * wave + i) + (lane >> 4).  The physical
+    // 16-byte chunk lane & 15 holds the logical chunk whose 32-byte window is XORed with (row & 7); row & 7 =
+    // 4 * (i & 1) + (lane >> 4), so a lane has two logical chunks (even / odd pieces), each with a fixed (tap, channel).
+    const int rsub = lane >> 4, pch = lane & 15;
+    int q_tap_dy[2], q_tap_dx[2], q_cx[2], q_coy[2];
+    bool q_colok[2], q_cook[2];
+#pragma unroll
+    for (int par = 0; par < 2; par++) {
+        const int r7 = 4 * par + rsub;
+        const int lch = (((pch >> 1) ^ r7) << 1) | (pch & 1);        // logical 16-byte chunk
+        const int q = col0 + lch * 8;
+        q_colok[par] = q < p.ncols;
+        const int tap = fdiv(q, p.dCip);
+        q_cx[par] = q - tap * p.Cip;
+        const int kh = fdiv(tap, p.dKW);
+        const int kw = tap - kh * p.KW;
+        q_tap_dy[par] = kh - p.pad; q_tap_dx[par] = kw - p.pad;
+        q_coy[par] = co0 + lch * 8;
+        q_cook[par] = q_coy[par] < ((p.Co + 7) & ~7);
+    }
 
-    i32x4 rx[4], ry[4];
-    auto issue_loads = [&](int kstep) {
+    auto issue_loads = [&](int kstep, int stage) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int m = kstep * TP + (tid >> 4) + 16 * i;
+            const int par = i & 1;
+            const int row = 4 * (4 * wave + i) + rsub;
+            const int m = kstep * TP + row;
             const bool mv = m < p.M;
             const int n = fdiv(m, p.dHW);
             const int r = m - n * (p.Ho * p.Wo);
             const int oy = fdiv(r, p.dW);
             const int ox = r - oy * p.Wo;
-            const int iy = oy * p.stride + dyo, ix = ox * p.stride + dxo;
-            const bool okx = mv && col_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const uint32_t offx = okx ? (uint32_t)((((n * p.H + iy) * p.W + ix) * p.ldx + p.xoff + cx) * 2) : OOB;
-            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, offx, 0, 0);
-            const bool oky = mv && co_ok;
-            const uint32_t offy = oky ? (uint32_t)((m * p.ldy + p.yoff + coy) * 2) : OOB;
-            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, offy, 0, 0);
-        }
-    };
-    auto write_lds = [&](int stage) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int row = (tid >> 4) + 16 * i;
-            *(i32x4*)(sX + stage * TILE_BYTES + row * RS + chunk * 16) = rx[i];
-            *(i32x4*)(sY + stage * TILE_BYTES + row * RS + chunk * 16) = ry[i];
+            const int iy = oy * p.stride + q_tap_dy[par], ix = ox * p.stride + q_tap_dx[par];
+            const bool okx = mv && q_colok[par] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const uint32_t offx = okx ? (uint32_t)((((n * p.H + iy) * p.W + ix) * p.ldx + p.xoff + q_cx[par]) * 2) : OOB;
+            const bool oky = mv && q_cook[par];
+            const uint32_t offy = oky ? (uint32_t)((m * p.ldy + p.yoff + q_coy[par]) * 2) : OOB;
+            char* dx = sX + stage * TILE_BYTES + (4 * wave + i) * 1024;
+            char* dy = sY + stage * TILE_BYTES + (4 * wave + i) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(void, dx), 16, offx, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, LDS_PTR(void, dy), 16, offy, 0, 0, 0);
         }
     };
 
@@ -140,16 +153,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 
     const int nk = k_end - k_begin;
     if (nk > 0) {
-        issue_loads(k_begin);
-        write_lds(0);
-        if (nk > 1) issue_loads(k_begin + 1);
-        __syncthreads();
+        // one barrier per step: [tile kt landed for every wave AND everyone left tile kt-1] -> issue tile kt+1 into the
+        // stage tile kt-1 occupied -> compute tile kt while it flies
+        issue_loads(k_begin, 0);
         for (int kt = 0; kt < nk; kt++) {
             const int cur = kt & 1;
-            if (kt + 1 < nk) {
-                write_lds(cur ^ 1);
-                if (kt + 2 < nk) issue_loads(k_begin + kt + 2);
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk) issue_loads(k_begin + kt + 1, cur ^ 1);
             const char* tx = sX + cur * TILE_BYTES;
             const char* ty = sY + cur * TILE_BYTES;
             // both k-slices in registers; the transposing reads of slice 1 are issued under the MFMAs of slice 0
@@ -176,7 +187,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-            __syncthreads();
         }
     }
 
