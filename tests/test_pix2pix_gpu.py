@@ -475,3 +475,45 @@ def test_pruned_resnet_generator(golden_dir, tag):
             g = g[sample_idx(g.numel())].numpy()
             err = float(np.abs(g - z[k]).max())
             assert err <= 2.2 * opt.lr + 1e-6, (name, err)
+
+
+@pytest.mark.parametrize('N,H,W', [(2, 64, 64), (1, 64, 96), (3, 96, 64), (5, 32, 160)])
+def test_non_square_and_odd_batches_vs_oracle(N, H, W):
+    """geometries the golden fixtures do not cover: non-square images, batch sizes that are not powers of two -- the eval
+    image and the discriminator logits against the oracle on the same recipe weights"""
+    from collections import OrderedDict
+    from oracle import gcc_oracle as O
+    from tests.golden.recipe import recipe_state_dict
+    model, _, opt = build_model(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '0', '--ngf', '8',
+                                 '--ndf', '8', '--num_downs', '5', '--no_dropout', '--darts_discriminator'])
+    load_recipe(model.netG, 4001)
+    load_recipe(model.netD, 4002)
+    model.refresh_weights()
+    g = torch.Generator().manual_seed(N * 1000 + H + W)
+    A = torch.rand(N, 3, H, W, generator=g) * 2 - 1
+    B = torch.rand(N, 3, H, W, generator=g) * 2 - 1
+    model.model_eval()
+    model.set_input({'A': A, 'B': B, 'A_paths': ['a'] * N, 'B_paths': ['b'] * N})
+    model.forward()
+    sdG = OrderedDict((k, v.detach().float().cpu()) for k, v in model.netG.state_dict().items())
+    x_in = B if opt.direction == 'BtoA' else A            # the cityscapes options set direction BtoA (options.py:186)
+    ref = O.unet_forward(sdG, x_in, num_downs=5, train=False)
+    O.EMULATE_BF16 = True
+    try:
+        emu = O.unet_forward(sdG, x_in, num_downs=5, train=False)
+    finally:
+        O.EMULATE_BF16 = False
+    e, ee, floor = (model.fake_B.cpu() - ref).abs(), (model.fake_B.cpu() - emu).abs(), (emu - ref).abs()
+    print('N%d %dx%d: vs fp32 max %.4g mean %.4g | vs bf16-emulating oracle max %.4g mean %.4g | emulated vs fp32 max %.4g mean %.4g' % (
+        N, H, W, e.max(), e.mean(), ee.max(), ee.mean(), floor.max(), floor.mean()))
+    assert ee.max() <= 4e-3 and ee.mean() <= 5e-4, (float(ee.max()), float(ee.mean()))      # measured: 1e-9 .. 5e-4
+    assert e.max() <= 2e-2 and e.mean() <= 3e-3, (float(e.max()), float(e.mean()))
+    # one training iteration runs (BatchNorm statistics over odd pixel counts, split-K plans of odd shapes) and stays finite
+    model.model_train()
+    model.set_input({'A': A, 'B': B, 'A_paths': ['a'] * N, 'B_paths': ['b'] * N})
+    model.optimize_parameters()
+    torch.cuda.synchronize()
+    for k, v in model.get_current_losses().items():
+        assert np.isfinite(v), (k, v)
+    for p in list(model.netG.parameters()) + list(model.netD.parameters()):
+        assert torch.isfinite(p).all()
