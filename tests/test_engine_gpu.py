@@ -135,3 +135,44 @@ def test_instance_norm_patchgan_engine_backward():
             continue
         check(k, p.grad.float().cpu(), sd[k].grad, sd16[k].grad)
     assert not bad, bad
+
+
+@pytest.mark.parametrize('N,H,W', [(1, 32, 48), (3, 40, 24), (5, 16, 64)])
+def test_engines_forward_non_square_odd_batch(N, H, W):
+    """MobileResnet and SRResNet engines on geometries the golden fixtures do not cover (non-square maps, batch sizes
+    that are not powers of two): forward against the oracle with bf16 storage emulated"""
+    from gcc_amd import engine, ops
+    from gcc_amd.models.Pix2Pix import MobileResnetGenerator
+    from gcc_amd.models.SRGAN import Generator
+    from oracle import gcc_oracle as O
+    from tests.golden.recipe import srgan_condition
+    g = torch.Generator().manual_seed(N + H + W)
+    x = _rb(torch.rand(N, 3, H, W, generator=g) * 2 - 1)
+    for kind in ('resnet', 'srresnet'):
+        if kind == 'resnet':
+            net = MobileResnetGenerator(ngf=16, n_blocks=3).to(DEV)
+            load_recipe(net, 171)
+        else:
+            net = Generator(n_channels=16, n_blocks=2).to(DEV)
+            load_recipe(net, 175)
+            srgan_condition(net.state_dict())
+        engine.FlatParams(list(net.parameters()), DEV)
+        eng = engine.MobileResnetEngine(net, DEV) if kind == 'resnet' else engine.SRResNetEngine(net, DEV)
+        eng.repack()
+        sd = OrderedDict((k, v.detach().float().cpu().contiguous().clone()) for k, v in net.state_dict().items())
+        O.EMULATE_BF16 = True
+        try:
+            ref = O.mobile_resnet_forward(sd, x) if kind == 'resnet' else O.srresnet_forward(sd, x, True)
+        finally:
+            O.EMULATE_BF16 = False
+        c = eng._ctx(N, H, W)
+        ops.nhwc_copy(_to_nhwc(ops, x), 0, c.x_in, 0, 3)
+        if kind == 'resnet':
+            eng.forward(c)
+        else:
+            eng.forward(c, train=True)
+        out = ops.nhwc_to_nchw(c.out, 3).cpu()
+        assert out.shape == ref.shape
+        r = _rel(out, ref.detach())
+        print('%s N%d %dx%d: rel to the bf16-emulating oracle %.2e' % (kind, N, H, W, r))
+        assert r <= 1e-2, (kind, r)
