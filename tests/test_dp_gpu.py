@@ -72,3 +72,53 @@ def test_two_ranks_stay_identical():
         assert np.array_equal(a[k], b[k]), 'replicas diverged in %s: gradients were not exchanged identically' % k
         assert np.isfinite(a[k]).all()
     assert a['losses'] == b['losses']          # logged losses are rank-averaged
+
+
+def _rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    from tests.test_pix2pix_gpu import GCC_ARGV, build_model
+
+    def run(use_dist):
+        torch.manual_seed(5)
+        model, teacher, opt = build_model(GCC_ARGV, teacher_ndf=16)
+        if use_dist:
+            model._world = teacher._world = 2        # take the data-parallel code paths (async teacher-G bucket included)
+        model.model_train()
+        g = torch.Generator().manual_seed(11)
+        out = []
+        for it in range(2):
+            A, B = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1, torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+            model.set_input({'A': A, 'B': B, 'A_paths': [''], 'B_paths': ['']})
+            model.optimize_parameters()
+            model.set_input({'A': B, 'B': A, 'A_paths': [''], 'B_paths': ['']})
+            model.clipping_mask_alpha()
+            model.optimizer_netD_arch()
+            torch.cuda.synchronize()
+            out.append(dict(model.get_current_losses()))
+        w = torch.cat([p.detach().float().reshape(-1) for p in list(model.netG.parameters()) + list(teacher.netG.parameters())]).cpu()
+        return out, w
+    ref_losses, ref_w = run(False)
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
+    losses, w = run(True)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put({'ref': ref_losses, 'got': losses, 'same_weights': bool(torch.equal(ref_w, w))})
+
+
+@pytest.mark.timeout(1500)
+def test_rccl_single_rank_with_teacher_stream():
+    """the nccl (= RCCL) backend itself, one rank: the bucket all-reduces issued from the main and the teacher stream, the
+    asynchronous teacher-generator bucket and its late wait -- results must equal the run without a process group"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=1200)
+    p.join(120)
+    assert p.exitcode == 0
+    assert res['got'] == res['ref'], (res['got'], res['ref'])
+    assert res['same_weights']
