@@ -12,10 +12,10 @@ teacher ngf 64 / ndf 128, hinge GAN loss, lambda_L1 100, content 50, gram 1e4, b
 Inputs are resident in HBM before the timed region.  One JSON line is printed by rank 0.
 
 roofline: the dominant kernel is the implicit-GEMM convolution (igemm_kernel, conv fprop / dgrad /
-ConvTranspose).  Every launch of it inside the first 2 steps of the timed region is bracketed by HIP
+ConvTranspose).  Every launch of it inside the first step of the timed region is bracketed by HIP
 events on the launch stream (bracketing all steps costs ~6% throughput); achieved = sum of algorithmic FLOPs
 (2*M*Cout*taps*Cin, padding excluded) / sum of measured durations; peak = 2.5 PFLOP/s dense bf16 MFMA
-(MI355X_MICROARCH.md).  Those 2 steps run with the three production streams (student, online teacher, weight
+(MI355X_MICROARCH.md).  That step runs with the three production streams (student, online teacher, weight
 gradients) folded onto one, so that a launch's duration is the kernel's own and not its neighbours' share of the CUs;
 the other steps of the timed region run the production schedule (profiles/: rocprofv3 summaries of
 `bench.py --serialize-streams`, which agree with these durations, and of the default command).
@@ -164,9 +164,9 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     from gcc_amd import engine
-    n_prof = 0 if args.no_roofline else min(args.steps, 2)
+    n_prof = 0 if args.no_roofline else min(args.steps, 1)
     if n_prof:
-        ops.PROFILE.start(steps=n_prof)   # HIP events bracket the igemm launches of the first 2 timed steps
+        ops.PROFILE.start(steps=n_prof)   # HIP events bracket the igemm launches of the first timed step (195 launches)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
