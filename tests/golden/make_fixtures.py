@@ -819,6 +819,44 @@ def fixture_srgan():
     print('  loss names', list(out['loss_names']), len(out['G_optimizer_names']), len(out['G_keys']))
 
 
+def fixture_srgan_content():
+    """SRGAN.optimize_content_parameters (models/SRGAN.py:514-522): the generator-only MSE step with the BatchNorm-scale
+    sparsity term (--lambda_scale), three iterations; no discriminator / VGG involved"""
+    import torchvision.models.vgg as tvgg
+    tvgg.vgg19 = vgg19_standin
+    if 'PIL' not in sys.modules:
+        try:
+            import PIL  # noqa: F401
+        except ImportError:
+            _stub('PIL', Image=None)
+    from options import options as ref_options
+    if not any('--generator_only' in a.option_strings for a in ref_options.parser._actions):
+        ref_options.parser.add_argument('--generator_only', action='store_true')
+    import models.GANLoss as ref_ganloss
+    ref_ganloss.vgg19 = vgg19_standin
+    opt = parse(['--dataroot', './database/sr/', '--model', 'srgan', '--gpu_ids', '-1', '--ngf', '8', '--ndf', '8',
+                 '--generator_only', '--lambda_scale', '0.01'])
+    from models import get_model_class
+    model = get_model_class(opt)(opt)
+    load_recipe(model.netG, 981)
+    srgan_condition(model.netG.state_dict())
+    model.model_train()
+    g = torch.Generator().manual_seed(982)
+    out = {'lr_G': np.array(opt.lr), 'loss_names': np.array(list(model.loss_names))}
+    for it in range(3):
+        lr_ = torch.rand(2, 3, 12, 12, generator=g) * 2 - 1
+        hr_ = torch.rand(2, 3, 48, 48, generator=g) * 2 - 1
+        out['it%d.lr' % it], out['it%d.hr' % it] = lr_.numpy(), hr_.numpy()
+        model.set_input({'lr': lr_, 'hr': hr_, 'lr_names': ['a'] * 2, 'hr_names': ['b'] * 2})
+        model.optimize_content_parameters()
+        out['it%d.loss_content' % it] = np.array(float(model.loss_content), dtype=np.float64)
+        if it == 0:
+            out['it0.fake_hr'] = model.fake_hr.detach().numpy().copy()
+    sd_np_sampled('final.G.', model.netG.state_dict(), out)
+    np.savez_compressed(os.path.join(HERE, 'srgan_content.npz'), **out)
+    print('srgan_content ok', [float(out['it%d.loss_content' % i]) for i in range(3)], list(out['loss_names']))
+
+
 def _spread_bn(net, seed):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
@@ -1043,6 +1081,6 @@ if __name__ == '__main__':
     only = sys.argv[1:]            # e.g. "make_fixtures.py cyclegan cyclegan_pretrain"; none = all
     import_reference()
     for fn in (fixture_options, fixture_ops, fixture_eval_d8, fixture_gcc_d6, fixture_pretrain_d6, fixture_prune_d8,
-               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan, fixture_srgan, fixture_prune_search_gan, fixture_checkpoint, fixture_metric, fixture_pipeline):
+               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan, fixture_srgan, fixture_prune_search_gan, fixture_checkpoint, fixture_metric, fixture_pipeline, fixture_srgan_content):
         if not only or fn.__name__[len('fixture_'):] in only:
             fn()

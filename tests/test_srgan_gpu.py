@@ -401,3 +401,46 @@ def test_vgg_engine_forward_backward():
     r16, r32, floor = _rel(ops.nhwc_to_nchw(dx, 3).cpu(), res[True][1]), _rel(ops.nhwc_to_nchw(dx, 3).cpu(), res[False][1]), _rel(res[True][1], res[False][1])
     print('dL/dx vs emulated %.4f, vs fp32 %.4f (emulated vs fp32 %.4f)' % (r16, r32, floor))
     assert r16 <= 6e-2 or r32 <= 1.5 * floor + 2e-2
+
+
+def test_srgan_content_pretraining_vs_reference_golden(golden_dir):
+    """optimize_content_parameters (models/SRGAN.py:514-522): generator-only MSE step with the BatchNorm-scale sparsity
+    term, three iterations against the reference's fixture (tests/golden/srgan_content.npz)"""
+    from gcc_amd.options import options
+    from gcc_amd.models import get_model_class
+    from tests.golden.recipe import sample_idx, srgan_condition
+    z = np.load(os.path.join(golden_dir, 'srgan_content.npz'))
+    os.environ['GCC_VGG19_RANDOM'] = '1'
+    opt = options.parse(['--dataroot', './database/sr/', '--model', 'srgan', '--gpu_ids', '0', '--ngf', '8', '--ndf', '8',
+                         '--generator_only', '--lambda_scale', '0.01'])
+    opt.isTrain = True
+    model = get_model_class(opt)(opt, vgg_widths=VGG_STANDIN)
+    assert model.loss_names == [str(k) for k in z['loss_names']]
+    load_recipe(model.netG, 981)
+    srgan_condition(model.netG.state_dict())
+    model.refresh_weights()
+    model.model_train()
+    for it in range(3):
+        model.set_input(_batch(z, 'it%d.lr' % it, 'it%d.hr' % it))
+        model.optimize_content_parameters()
+        got, ref = model.get_current_losses()['content'], float(z['it%d.loss_content' % it])
+        print('it%d content %.6f reference %.6f' % (it, got, ref))
+        assert abs(got - ref) <= (3e-3 if it == 0 else 2e-2) * ref, (it, got, ref)
+        if it == 0:
+            e = (model.fake_hr.cpu() - torch.from_numpy(z['it0.fake_hr'])).abs()
+            assert e.max() <= 2e-2 and e.mean() <= 3e-3
+    sd = model.netG.state_dict()
+    lr = float(z['lr_G'])
+    for k in z.files:
+        if not k.startswith('final.G.'):
+            continue
+        name, ref = k[len('final.G.'):], z[k]
+        g = sd[name].detach().float().cpu().reshape(-1)
+        g = g[sample_idx(g.numel())].numpy()
+        if name.endswith('num_batches_tracked'):
+            assert int(g[0]) == int(ref.reshape(-1)[0])
+        elif name.endswith('running_mean') or name.endswith('running_var'):
+            assert np.abs(g - ref).max() <= 3e-2 * max(1.0, float(np.abs(ref).max())), name
+        else:
+            # three Adam steps: each moves a weight by at most ~lr (beta1 0.9 bias-corrected: the first steps are sign-like)
+            assert np.abs(g - ref).max() <= 2.2 * lr * 3 + 1e-6, (name, float(np.abs(g - ref).max()))
