@@ -251,3 +251,33 @@ def test_sr_and_sa_pipelines_bit_exact():
     assert np.array_equal(it['real_img'].cpu().numpy(), P.sa_item(face, 64, True))
     sopt.center_crop = False
     assert np.array_equal(SAGpuPipeline(sopt)(torch.from_numpy(face))['real_img'].cpu().numpy(), P.sa_item(face, 64, False))
+
+
+@pytest.mark.gpu
+def test_evaluation_loop_writes_images(tmp_path):
+    """python -m gcc_amd.test: checkpoint -> model (cfg from the file) -> val split -> PNGs where the reference puts them;
+    the saved fake image equals the model's eval output through the reference's tensor2im arithmetic"""
+    from PIL import Image
+    from gcc_amd import test as gtest
+    from gcc_amd.models import get_model_class
+    from gcc_amd.options import options
+    rng = np.random.RandomState(9)
+    d = tmp_path / 'data' / 'val'
+    d.mkdir(parents=True)
+    for i in range(2):
+        Image.fromarray((rng.rand(256, 512, 3) * 255).astype(np.uint8)).save(str(d / ('v%d.png' % i)))
+    base = ['--dataroot', str(tmp_path / 'data'), '--model', 'pix2pix', '--gpu_ids', '0', '--ngf', '8', '--ndf', '8',
+            '--checkpoints_dir', str(tmp_path / 'ckpt'), '--name', 'ev', '--direction', 'AtoB']
+    opt = options.parse(base)
+    opt.isTrain = True
+    src = get_model_class(opt)(opt)
+    src.save_models(3, str(tmp_path / 'ckpt' / 'ev' / 'checkpoints'), fid=1.0)
+    model = gtest.main(base + ['--pretrain_path', str(tmp_path / 'ckpt' / 'ev' / 'checkpoints' / 'model_3.pth')])
+    res = tmp_path / 'ckpt' / 'ev' / 'test_results'
+    assert sorted(os.listdir(str(res))) == ['fake_B', 'v0.png', 'v1.png']
+    assert sorted(os.listdir(str(res / 'fake_B'))) == ['v0_fake_B.png', 'v1_fake_B.png']
+    saved = np.array(Image.open(str(res / 'fake_B' / 'v1_fake_B.png')))
+    fake = model.fake_B[0].cpu().float().numpy()                      # the last image the loop processed
+    assert np.array_equal(saved, ((np.transpose(fake, (1, 2, 0)) + 1) / 2.0 * 255.0).astype(np.uint8))
+    real = np.array(Image.open(str(res / 'v1.png')))
+    assert real.shape == (256, 256, 3)
