@@ -225,22 +225,15 @@ def make_dataset(dir, max_dataset_size=float('inf')):
     return images[:min(max_dataset_size, len(images))]
 
 
-class AlignedGpuDataLoader:
-    """What ``create_dataset(opt)`` returns for ``--dataset_mode aligned``: iterating yields the batch dicts of
-    set_input.  Order: ``serial_batches`` -> file order, else a permutation drawn like torch's RandomSampler (a seed from the
-    default torch generator, ``torch.randperm`` on a generator of its own) -- the sequence a single-process DataLoader
-    gives.  Augmentation parameters come from get_params in item order.  ``decode_threads`` host threads decode ahead
-    (PIL releases the GIL)."""
+class _GpuFileLoader:
+    """File listing + host decode (PIL on ``decode_threads`` threads; it releases the GIL) + GPU transforms + collation.
+    Order: ``serial_batches`` -> index order, else a permutation drawn like torch's RandomSampler inside a single-process
+    DataLoader (the per-epoch base seed first, then the sampler's seed from the default generator, ``torch.randperm`` on a
+    generator of its own).  Per-item random draws happen in item order, as with num_workers = 0."""
 
-    def __init__(self, opt, device=None, decode_threads=8):
-        import os
+    def __init__(self, opt, decode_threads=8):
         self.opt = opt
-        self.paths = sorted(make_dataset(os.path.join(opt.dataroot, opt.phase), opt.max_dataset_size))
-        self.pipe = AlignedGpuPipeline(opt, device)
         self.threads = int(decode_threads)
-
-    def __len__(self):
-        return len(self.paths)
 
     @staticmethod
     def decode(path):
@@ -248,7 +241,7 @@ class AlignedGpuDataLoader:
         return torch.from_numpy(np.asarray(Image.open(path).convert('RGB')).copy())
 
     def order(self):
-        n = len(self.paths)
+        n = len(self)
         if self.opt.serial_batches:
             return list(range(n))
         torch.empty((), dtype=torch.int64).random_()          # DataLoader's per-epoch base seed for workers: drawn first
@@ -257,14 +250,118 @@ class AlignedGpuDataLoader:
         g.manual_seed(seed)
         return torch.randperm(n, generator=g).tolist()
 
+    def item(self, index, pool):
+        raise NotImplementedError
+
+    @staticmethod
+    def collate(items):
+        out = {}
+        for k in items[0]:
+            v = [it[k] for it in items]
+            out[k] = torch.stack(v) if torch.is_tensor(v[0]) else list(v)
+        return out
+
     def __iter__(self):
         from concurrent.futures import ThreadPoolExecutor
         order, bs = self.order(), int(self.opt.batch_size)
         with ThreadPoolExecutor(max(1, self.threads)) as pool:
-            futs = [pool.submit(self.decode, self.paths[i]) for i in order]
+            for b in range(0, len(order), bs):
+                yield self.collate([self.item(i, pool) for i in order[b:b + bs]])
+
+
+class AlignedGpuDataLoader(_GpuFileLoader):
+    """What ``create_dataset(opt)`` returns for ``--dataset_mode aligned`` (data/aligned_dataset.py:20-58): iterating
+    yields the batch dicts of set_input; augmentation parameters come from get_params in item order."""
+
+    def __init__(self, opt, device=None, decode_threads=8):
+        import os
+        super().__init__(opt, decode_threads)
+        self.paths = sorted(make_dataset(os.path.join(opt.dataroot, opt.phase), opt.max_dataset_size))
+        self.pipe = AlignedGpuPipeline(opt, device)
+
+    def __len__(self):
+        return len(self.paths)
+
+    def __iter__(self):
+        from concurrent.futures import ThreadPoolExecutor
+        order, bs = self.order(), int(self.opt.batch_size)
+        with ThreadPoolExecutor(max(1, self.threads)) as pool:
+            futs = [pool.submit(self.decode, self.paths[i]) for i in order]        # decode ahead of the GPU
             for b in range(0, len(order), bs):
                 idx = order[b:b + bs]
                 yield self.pipe.batch([f.result() for f in futs[b:b + bs]], [self.paths[i] for i in idx])
+
+
+class UnalignedGpuDataLoader(_GpuFileLoader):
+    """``--dataset_mode unaligned`` (data/unaligned_dataset.py:20-78): <phase>A / <phase>B directories, B drawn with
+    ``random.randint(0, B_size - 1)`` unless serial_batches, length max(A_size, B_size)"""
+
+    def __init__(self, opt, device=None, decode_threads=8):
+        import os
+        super().__init__(opt, decode_threads)
+        self.A_paths = sorted(make_dataset(os.path.join(opt.dataroot, opt.phase + 'A'), opt.max_dataset_size))
+        self.B_paths = sorted(make_dataset(os.path.join(opt.dataroot, opt.phase + 'B'), opt.max_dataset_size))
+        self.pipe = UnalignedGpuPipeline(opt, device)
+
+    def __len__(self):
+        return max(len(self.A_paths), len(self.B_paths))
+
+    def item(self, index, pool):
+        a = self.A_paths[index % len(self.A_paths)]
+        ib = index % len(self.B_paths) if self.opt.serial_batches else random.randint(0, len(self.B_paths) - 1)
+        b = self.B_paths[ib]
+        fa, fb = pool.submit(self.decode, a), pool.submit(self.decode, b)
+        it = self.pipe(fa.result(), fb.result())
+        it['A_paths'], it['B_paths'] = a, b
+        return it
+
+
+class SRGpuDataLoader(_GpuFileLoader):
+    """``--dataset_mode sr`` (data/sr_dataset.py:123-184): every file of <dataroot>/<phase>, sorted"""
+
+    def __init__(self, opt, device=None, decode_threads=8):
+        import os
+        super().__init__(opt, decode_threads)
+        self.folder = os.path.join(opt.dataroot, opt.phase)
+        self.names = sorted(os.listdir(self.folder))
+        self.pipe = SRGpuPipeline(opt, device)
+
+    def __len__(self):
+        return len(self.names)
+
+    def item(self, index, pool):
+        import os
+        it = self.pipe(self.decode(os.path.join(self.folder, self.names[index])))
+        it['lr_names'] = it['hr_names'] = self.names[index]
+        return it
+
+
+class SAGpuDataLoader(_GpuFileLoader):
+    """``--dataset_mode sa`` (data/sa_dataset.py:9-55)"""
+
+    def __init__(self, opt, device=None, decode_threads=8):
+        import os
+        super().__init__(opt, decode_threads)
+        self.folder = os.path.join(opt.dataroot, opt.phase)
+        self.names = sorted(os.listdir(self.folder))
+        self.pipe = SAGpuPipeline(opt, device)
+
+    def __len__(self):
+        return len(self.names)
+
+    def item(self, index, pool):
+        import os
+        it = self.pipe(self.decode(os.path.join(self.folder, self.names[index])))
+        it['img_path'] = self.names[index]
+        return it
+
+
+def create_dataset(opt, device=None):
+    """data/__init__.py:52-57 for the four dataset modes"""
+    cls = {'aligned': AlignedGpuDataLoader, 'unaligned': UnalignedGpuDataLoader, 'sr': SRGpuDataLoader, 'sa': SAGpuDataLoader}
+    if opt.dataset_mode not in cls:
+        raise NotImplementedError('dataset_mode %s' % opt.dataset_mode)
+    return cls[opt.dataset_mode](opt, device)
 
 
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)

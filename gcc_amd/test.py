@@ -1,7 +1,7 @@
 """The reference's test.py (:12-155) on the MI355X path: rebuild the (pruned) model from a checkpoint's cfg, run the
 evaluation split through the generator in eval mode and write the images the reference's evaluators read
-(<checkpoints_dir>/<name>/test_results/...).  Pix2Pix reads the paired image files itself (gcc_amd.data); the other
-models take the reference's ``data`` package from the import path, as gcc_amd.train does.
+(<checkpoints_dir>/<name>/test_results/...).  The image files are read by gcc_amd.data (host decode, GPU transforms);
+GCC_HOST_DATALOADER=1 takes the reference's ``data`` package from the import path instead.
 
     python -m gcc_amd.test --dataroot ./database/cityscapes/ --model pix2pix --pretrain_path <ckpt.pth> --name <exp>
 """
@@ -16,9 +16,9 @@ from .utils import util
 
 
 def _dataset(opt):
-    if opt.dataset_mode == 'aligned' and os.environ.get('GCC_HOST_DATALOADER') != '1':
-        from .data import AlignedGpuDataLoader
-        return AlignedGpuDataLoader(opt)
+    if os.environ.get('GCC_HOST_DATALOADER') != '1':
+        from .data import create_dataset
+        return create_dataset(opt)
     from data import create_dataset          # the reference's loaders
     return create_dataset(opt)
 

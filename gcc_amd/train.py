@@ -49,11 +49,11 @@ def make_datasets(opt):
         n = int(root.split(':')[1]) if ':' in root else 8
         r = gdist.rank()
         return SyntheticPairs(opt, n, 1234 + r), SyntheticPairs(opt, n, 4321 + r)
-    if opt.dataset_mode == 'aligned' and os.environ.get('GCC_HOST_DATALOADER') != '1':
-        # paired images: host decode + GPU transforms (gcc_amd.data); two loaders over the same phase, as
-        # create_split_dataset builds them (data/__init__.py:59-66)
-        from .data import AlignedGpuDataLoader
-        return AlignedGpuDataLoader(opt), AlignedGpuDataLoader(opt)
+    if os.environ.get('GCC_HOST_DATALOADER') != '1':
+        # host decode + GPU transforms (gcc_amd.data); two loaders over the same phase, as create_split_dataset builds
+        # them (data/__init__.py:59-66)
+        from .data import create_dataset
+        return create_dataset(opt), create_dataset(opt)
     from data import create_split_dataset      # the reference's loaders (data/__init__.py:52-58)
     return create_split_dataset(opt)
 

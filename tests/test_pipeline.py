@@ -281,3 +281,59 @@ def test_evaluation_loop_writes_images(tmp_path):
     assert np.array_equal(saved, ((np.transpose(fake, (1, 2, 0)) + 1) / 2.0 * 255.0).astype(np.uint8))
     real = np.array(Image.open(str(res / 'v1.png')))
     assert real.shape == (256, 256, 3)
+
+
+@pytest.mark.gpu
+def test_unaligned_sr_sa_loaders_from_files(tmp_path):
+    """the three other dataset modes from files on disk: batch-dict keys and shapes, and the first items against the
+    oracle fed with the same random draws"""
+    from PIL import Image
+    from gcc_amd.data import create_dataset
+    from oracle import pipeline_oracle as P
+    rng = np.random.RandomState(15)
+
+    def write(dirname, n, h, w):
+        d = tmp_path / dirname
+        d.mkdir(parents=True)
+        arrs = []
+        for i in range(n):
+            a = (rng.rand(h + i, w + 2 * i, 3) * 255).astype(np.uint8)
+            Image.fromarray(a).save(str(d / ('f%02d.png' % i)))
+            arrs.append(a)
+        return arrs
+    A, B = write('cyc/trainA', 3, 70, 80), write('cyc/trainB', 2, 90, 75)
+    opt = types.SimpleNamespace(dataroot=str(tmp_path / 'cyc'), phase='train', dataset_mode='unaligned', max_dataset_size=float('inf'),
+                                preprocess='resize_and_crop', load_size=72, crop_size=64, no_flip=False, serial_batches=True,
+                                batch_size=2)
+    ld = create_dataset(opt)
+    assert len(ld) == 3
+    torch.manual_seed(42)
+    batches = list(ld)
+    assert [b['A'].shape for b in batches] == [(2, 3, 64, 64), (1, 3, 64, 64)] and len(batches[0]['A_paths']) == 2
+    assert batches[1]['B_paths'][0].endswith('trainB/f00.png')              # serial: index 2 % B_size
+    torch.manual_seed(42)
+    for name, img in (('A', A[0]), ('B', B[0])):                            # item 0: A's draws, then B's
+        r = P.resample_bicubic(img, 72, 72)
+        y = int(torch.randint(0, 9, size=(1,)).item())
+        x = int(torch.randint(0, 9, size=(1,)).item())
+        flip = bool(torch.rand(1) < 0.5)
+        c = r[y:y + 64, x:x + 64]
+        c = c[:, ::-1] if flip else c
+        ref = (np.transpose(c.astype(np.float32) / np.float32(255.), (2, 0, 1)) - np.float32(0.5)) / np.float32(0.5)
+        assert np.array_equal(batches[0][name][0].cpu().numpy(), ref), name
+    S = write('sr/train', 3, 110, 120)
+    sopt = types.SimpleNamespace(dataroot=str(tmp_path / 'sr'), phase='train', dataset_mode='sr', image_size=96, upscale_factor=4,
+                                 lr_img_type='imagenet-norm', hr_img_type='[-1, 1]', serial_batches=True, batch_size=2)
+    random.seed(9)
+    sb = list(create_dataset(sopt))
+    assert sb[0]['lr'].shape == (2, 3, 24, 24) and sb[0]['hr'].shape == (2, 3, 96, 96) and sb[0]['lr_names'] == ['f00.png', 'f01.png']
+    random.seed(9)
+    left, top = random.randint(1, 120 - 96), random.randint(1, 110 - 96)
+    lr, hr = P.sr_item(S[0], 96, 4, left, top)
+    assert np.array_equal(sb[0]['lr'][0].cpu().numpy(), lr) and np.array_equal(sb[0]['hr'][0].cpu().numpy(), hr)
+    F_ = write('sa/train', 2, 218, 178)
+    aopt = types.SimpleNamespace(dataroot=str(tmp_path / 'sa'), phase='train', dataset_mode='sa', center_crop=True, crop_size=64,
+                                 z_dim=16, serial_batches=True, batch_size=2)
+    ab = list(create_dataset(aopt))
+    assert ab[0]['z'].shape == (2, 16) and ab[0]['real_img'].shape == (2, 3, 64, 64) and ab[0]['img_path'] == ['f00.png', 'f01.png']
+    assert np.array_equal(ab[0]['real_img'][1].cpu().numpy(), P.sa_item(F_[1], 64, True))
