@@ -337,3 +337,37 @@ def test_unaligned_sr_sa_loaders_from_files(tmp_path):
     ab = list(create_dataset(aopt))
     assert ab[0]['z'].shape == (2, 16) and ab[0]['real_img'].shape == (2, 3, 64, 64) and ab[0]['img_path'] == ['f00.png', 'f01.png']
     assert np.array_equal(ab[0]['real_img'][1].cpu().numpy(), P.sa_item(F_[1], 64, True))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('which', ['cyclegan', 'sagan', 'srgan'])
+def test_train_loop_other_models_on_files(tmp_path, which):
+    """python -m gcc_amd.train on image files for the other dataset modes (unaligned / sa / sr): one short epoch"""
+    from PIL import Image
+    from gcc_amd import train
+    rng = np.random.RandomState(17)
+
+    def write(d, n, h, w):
+        d.mkdir(parents=True)
+        for i in range(n):
+            Image.fromarray((rng.rand(h, w, 3) * 255).astype(np.uint8)).save(str(d / ('i%d.png' % i)))
+    root = tmp_path / 'data'
+    common = ['--gpu_ids', '0', '--online_distillation', '--darts_discriminator', '--n_epochs', '1', '--n_epochs_decay', '0',
+              '--checkpoints_dir', str(tmp_path / 'ckpt'), '--name', which, '--print_freq', '1']
+    if which == 'cyclegan':
+        write(root / 'horse2zebra' / 'trainA', 2, 70, 80)
+        write(root / 'horse2zebra' / 'trainB', 3, 66, 90)
+        argv = ['--dataroot', str(root / 'horse2zebra'), '--model', 'cyclegan', '--ngf', '8', '--ndf', '8', '--teacher_ngf', '16',
+                '--load_size', '72', '--crop_size', '64', '--batch_size', '1']
+    elif which == 'sagan':
+        write(root / 'celeb' / 'train', 4, 218, 178)
+        argv = ['--dataroot', str(root / 'celeb'), '--model', 'sagan', '--ngf', '8', '--ndf', '8', '--teacher_ngf', '16',
+                '--batch_size', '2', '--z_dim', '32']
+    else:
+        os.environ['GCC_VGG19_RANDOM'] = '1'
+        write(root / 'sr' / 'train', 3, 120, 130)
+        argv = ['--dataroot', str(root / 'sr'), '--model', 'srgan', '--ngf', '8', '--ndf', '8', '--teacher_ngf', '16',
+                '--batch_size', '2']
+    train.main(argv + common)
+    log = (tmp_path / 'ckpt' / which / 'logger.log').read_text()
+    assert 'End of epoch 1' in log and 'nan' not in log.lower()
