@@ -20,6 +20,13 @@ def rank():
     return dist.get_rank() if is_dist() else 0
 
 
+def _local_index():
+    """LOCAL_RANK, folded onto the visible devices (one GPU per rank in production; a one-GPU rehearsal box maps every
+    rank to cuda:0)"""
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 1
+    return int(os.environ.get('LOCAL_RANK', '0')) % max(n, 1)
+
+
 def init_from_env(backend=None):
     """Initialise the process group when launched with WORLD_SIZE > 1 (idempotent)."""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
@@ -27,9 +34,10 @@ def init_from_env(backend=None):
         return world_size()
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
-    backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
-    if backend == 'nccl':
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    # GCC_DIST_BACKEND=gloo: rehearsal rigs that put several ranks on one GPU (RCCL refuses duplicate devices)
+    backend = backend or os.environ.get('GCC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if torch.cuda.is_available():
+        torch.cuda.set_device(_local_index())
     dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws)
     return ws
 
@@ -37,7 +45,7 @@ def init_from_env(backend=None):
 def local_device(opt):
     """cuda:{LOCAL_RANK} under a multi-process launch, else cuda:{gpu_ids[0]} (models/Pix2Pix.py:356)"""
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
-        dev = torch.device('cuda:%d' % int(os.environ.get('LOCAL_RANK', '0')))
+        dev = torch.device('cuda:%d' % _local_index())
     else:
         dev = torch.device('cuda:%d' % opt.gpu_ids[0])
     if torch.cuda.is_available():

@@ -122,3 +122,22 @@ def test_rccl_single_rank_with_teacher_stream():
     assert p.exitcode == 0
     assert res['got'] == res['ref'], (res['got'], res['ref'])
     assert res['same_weights']
+
+
+@pytest.mark.timeout(1500)
+def test_bench_two_ranks_driver_command_line():
+    """the driver's multi-GPU invocation of bench.py, rehearsed with two ranks on this box's one GPU (gloo in place of
+    RCCL, which refuses duplicate devices): barrier / max-over-ranks timing / rank-0 JSON line"""
+    import json
+    import subprocess
+    env = dict(os.environ, GCC_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1']
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1400)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['config']['global_batch'] == 32 and d['scaling'] == 'weak'
+    assert d['value'] > 0 and abs(d['value'] - 32 * 2 / (d['ms_per_step'] * 2 / 1000.0)) < 0.5
+    assert 'roofline' in d
