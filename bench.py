@@ -93,8 +93,9 @@ def one_step(model, train, val):
     model.optimizer_netD_arch()
 
 
-def cpu_baseline(iters=3):
-    """oracle on the host cores: N=1, full-size networks"""
+def cpu_baseline(iters=16):
+    """oracle on the host cores: N=1, full-size networks; a bounded sample of about 10 s (16 iterations at ~0.6 s, fewer if
+    the host is slower: at most 30 s)"""
     from oracle import gcc_oracle as O
     try:
         ncores = len(os.sched_getaffinity(0))
