@@ -20,7 +20,7 @@ gradients) folded onto one, so that a launch's duration is the kernel's own and 
 the other steps of the timed region run the production schedule (profiles/: rocprofv3 summaries of
 `bench.py --serialize-streams`, which agree with these durations, and of the default command).
 cpu_baseline: the oracle (CPU restatement pinned to the reference) timed on this host's cores on a
-bounded sample (N=1, same architecture, 1 warm-up + 3 timed iterations), rank 0 at --gpus 1 only.
+bounded sample (N=1, same architecture, 1 warm-up + 16 timed iterations, about 10 s), rank 0 at --gpus 1 only.
 """
 import argparse
 import copy
