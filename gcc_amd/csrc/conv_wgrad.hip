@@ -6,7 +6,8 @@
 // The 32-byte windows of a row are XOR-swizzled with the row number so that the 8 pixel rows one
 // half-wave touches per transposed read land on 8 distinct 32-B bank groups (conflict-free).
 //
-// Tile: 128 (tap,ci) columns x 128 output channels, 64 pixels per step, 256 threads = 2x2 waves.
+// Tile: 128 (tap,ci) columns x 128 output channels, 64 pixels per step, 256 threads = 2x2 waves; or 256 x 256 with
+// 8 waves of 128 x 64 for large outputs (WCfg).
 // Split-K over pixels: every split writes an fp32 slab, gcc_wgrad_reduce folds the slabs into the
 // fp32 master-layout gradient (deterministic; no float atomics).
 #include "common.hpp"
@@ -52,20 +53,36 @@ struct WgradParams {
 };
 
 constexpr int TP = 64;          // pixels per step
-constexpr int TCOL = 128;
-constexpr int TCO = 128;
-constexpr int RS = 256;         // LDS row stride (bytes): 128 channels, no padding -- rows are laid down by 1-KiB LDS-DMA pieces
-constexpr int TILE_BYTES = TP * RS;
 constexpr uint32_t OOB = 0x7FFFFFF0u;
 
-// Both panels are [64 pixels][128 channels] images filled by LDS-DMA (buffer_load ... lds: one wave instruction lays
-// down 1 KiB = 4 pixel rows, lane L -> row L >> 4, 16-byte chunk L & 15; no staging registers, no ds_write).  The 32-byte
-// windows of a row are XOR-swizzled with the row number (on the SOURCE side: a lane fetches the channels that belong in
-// its physical slot), so that the 8 rows a half-wave touches per transposing read fall on 8 distinct bank groups.
+// Tile configurations.  BIG = false: 128 columns x 128 output channels, 4 waves of 64 x 64 (two workgroups per CU).
+// BIG = true: 256 x 256, 8 waves of 128 (columns) x 64 (output channels) -- 0.375 transposed fragments per MFMA instead
+// of 0.5, one workgroup per CU; used when the output is large enough that the extra pixel splits stay few.
+template <bool BIG>
+struct WCfg {
+    static constexpr int WAVES = BIG ? 8 : 4;
+    static constexpr int NT = WAVES * 64;
+    static constexpr int TCOL = BIG ? 256 : 128;
+    static constexpr int TCO = BIG ? 256 : 128;
+    static constexpr int RS = TCOL * 2;                 // LDS row stride (bytes): no padding, rows are laid down by 1-KiB LDS-DMA pieces
+    static constexpr int TILE_BYTES = TP * RS;
+    static constexpr int CPR = RS / 16;                 // 16-byte chunks per row (16 or 32)
+    static constexpr int RPP = 64 / CPR;                // pixel rows per 1-KiB piece (4 or 2)
+    static constexpr int WCOL = BIG ? 128 : 64;         // columns per wave
+    static constexpr int FI = WCOL / 16;                // column fragments per wave (4 or 8)
+    static constexpr int FJ = 4;                        // output-channel fragments per wave (64 channels)
+    static constexpr int LDS_BYTES = 4 * TILE_BYTES;
+};
+
+// Both panels are [64 pixels][TCOL channels] images filled by LDS-DMA (buffer_load ... lds: one wave instruction lays
+// down 1 KiB = RPP pixel rows; no staging registers, no ds_write).  The 32-byte windows of a row are XOR-swizzled with
+// the row number (on the SOURCE side: a lane fetches the channels that belong in its physical slot), so that the 8 rows
+// a half-wave touches per transposing read fall on 8 distinct bank groups.
 __device__ __forceinline__ int phys_col_bytes(int row, int col_bytes) {          // col_bytes: logical byte offset in the row
     return ((((col_bytes >> 5) ^ (row & 7)) << 5) | (col_bytes & 31));
 }
 
+template <int RS>
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int ks, int colbase, int lane) {
     // 16x16x32 operand from a [pixel][channel] image: lane (g = lane>>4, i = lane&15) ends up with
     // channel colbase+i and the 8 pixel rows {ks*32 + 4g + 0..3, ks*32 + 16 + 4g + 0..3}.
@@ -78,19 +95,22 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int ks, int colbase,
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+template <bool BIG>
+__global__ __launch_bounds__(WCfg<BIG>::NT) void wgrad_kernel(const WgradParams p) {
+    using C = WCfg<BIG>;
+    constexpr int RS = C::RS, TILE_BYTES = C::TILE_BYTES, FI = C::FI, FJ = C::FJ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sX = smem;                       // [2][64][256]
-    char* sY = smem + 2 * TILE_BYTES;      // [2][64][256]
+    char* sX = smem;                       // [2][64][RS]
+    char* sY = smem + 2 * TILE_BYTES;      // [2][64][RS]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wa = wave & 1, wb = wave >> 1;
+    const int wa = wave & 1, wb = wave >> 1;               // 2 column groups x (2 or 4) output-channel groups
 
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int ct = tile % p.col_tiles;     // column tile fastest: neighbours share the dY panel
     const int ot = tile / p.col_tiles;
-    const int col0 = ct * TCOL, co0 = ot * TCO;
+    const int col0 = ct * C::TCOL, co0 = ot * C::TCO;
     const int split = blockIdx.z;
     const int k_begin = split * p.ksteps_per_split;
     int k_end = k_begin + p.ksteps_per_split;
@@ -101,43 +121,42 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)bidx * p.x_bstride), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + (size_t)bidx * p.dy_bstride), 0, p.dy_bytes, 0x00020000);
 
-    // LDS-DMA pieces of this wave: piece i (0..3) covers pixel rows 4 * (4 * wave + i) + (lane >> 4).  The physical
-    // 16-byte chunk lane & 15 holds the logical chunk whose 32-byte window is XORed with (row & 7); row & 7 =
-    // 4 * (i & 1) + (lane >> 4), so a lane has two logical chunks (even / odd pieces), each with a fixed (tap, channel).
-    const int rsub = lane >> 4, pch = lane & 15;
-    int q_tap_dy[2], q_tap_dx[2], q_cx[2], q_coy[2];
-    bool q_colok[2], q_cook[2];
+    // LDS-DMA pieces of this wave: piece i (0..3) of a panel covers pixel rows RPP * (4 * wave + i) + rsub.  The physical
+    // 16-byte chunk pch of a row holds the logical chunk whose 32-byte window is XORed with (row & 7); a lane meets at
+    // most four values of row & 7 (one per piece), each with a fixed (tap, channel).
+    const int rsub = lane / C::CPR, pch = lane % C::CPR;
+    int q_tap_dy[4], q_tap_dx[4], q_cx[4], q_coy[4];
+    bool q_colok[4], q_cook[4];
 #pragma unroll
-    for (int par = 0; par < 2; par++) {
-        const int r7 = 4 * par + rsub;
+    for (int i = 0; i < 4; i++) {
+        const int r7 = (C::RPP * (4 * wave + i) + rsub) & 7;
         const int lch = (((pch >> 1) ^ r7) << 1) | (pch & 1);        // logical 16-byte chunk
         const int q = col0 + lch * 8;
-        q_colok[par] = q < p.ncols;
+        q_colok[i] = q < p.ncols;
         const int tap = fdiv(q, p.dCip);
-        q_cx[par] = q - tap * p.Cip;
+        q_cx[i] = q - tap * p.Cip;
         const int kh = fdiv(tap, p.dKW);
         const int kw = tap - kh * p.KW;
-        q_tap_dy[par] = kh - p.pad; q_tap_dx[par] = kw - p.pad;
-        q_coy[par] = co0 + lch * 8;
-        q_cook[par] = q_coy[par] < ((p.Co + 7) & ~7);
+        q_tap_dy[i] = kh - p.pad; q_tap_dx[i] = kw - p.pad;
+        q_coy[i] = co0 + lch * 8;
+        q_cook[i] = q_coy[i] < ((p.Co + 7) & ~7);
     }
 
     auto issue_loads = [&](int kstep, int stage) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int par = i & 1;
-            const int row = 4 * (4 * wave + i) + rsub;
+            const int row = C::RPP * (4 * wave + i) + rsub;
             const int m = kstep * TP + row;
             const bool mv = m < p.M;
             const int n = fdiv(m, p.dHW);
             const int r = m - n * (p.Ho * p.Wo);
             const int oy = fdiv(r, p.dW);
             const int ox = r - oy * p.Wo;
-            const int iy = oy * p.stride + q_tap_dy[par], ix = ox * p.stride + q_tap_dx[par];
-            const bool okx = mv && q_colok[par] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const uint32_t offx = okx ? (uint32_t)((((n * p.H + iy) * p.W + ix) * p.ldx + p.xoff + q_cx[par]) * 2) : OOB;
-            const bool oky = mv && q_cook[par];
-            const uint32_t offy = oky ? (uint32_t)((m * p.ldy + p.yoff + q_coy[par]) * 2) : OOB;
+            const int iy = oy * p.stride + q_tap_dy[i], ix = ox * p.stride + q_tap_dx[i];
+            const bool okx = mv && q_colok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const uint32_t offx = okx ? (uint32_t)((((n * p.H + iy) * p.W + ix) * p.ldx + p.xoff + q_cx[i]) * 2) : OOB;
+            const bool oky = mv && q_cook[i];
+            const uint32_t offy = oky ? (uint32_t)((m * p.ldy + p.yoff + q_coy[i]) * 2) : OOB;
             char* dx = sX + stage * TILE_BYTES + (4 * wave + i) * 1024;
             char* dy = sY + stage * TILE_BYTES + (4 * wave + i) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(void, dx), 16, offx, 0, 0, 0);
@@ -145,11 +164,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[FI][FJ];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < FI; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = k_end - k_begin;
     if (nk > 0) {
@@ -165,42 +184,45 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             const char* ty = sY + cur * TILE_BYTES;
             // both k-slices in registers; the transposing reads of slice 1 are issued under the MFMAs of slice 0
             // (sched_group_barrier pins the order: the compiler otherwise reads, waits, and only then multiplies)
-            bf16x8 fx[2][4], fy[2][4];
+            bf16x8 fx[2][FI], fy[2][FJ];
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) fx[ks][i] = tr_frag(tx, ks, wa * 64 + i * 16, lane);
+                for (int i = 0; i < FI; i++) fx[ks][i] = tr_frag<RS>(tx, ks, wa * C::WCOL + i * 16, lane);
 #pragma unroll
-                for (int j = 0; j < 4; j++) fy[ks][j] = tr_frag(ty, ks, wb * 64 + j * 16, lane);
+                for (int j = 0; j < FJ; j++) fy[ks][j] = tr_frag<RS>(ty, ks, wb * 64 + j * 16, lane);
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-                for (int i = 0; i < 4; i++)
+                for (int i = 0; i < FI; i++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
+                    for (int j = 0; j < FJ; j++)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[ks][i], fy[ks][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);          // slice 0: 8 fragments = 16 transposing reads
+            constexpr int READS = 2 * (FI + FJ);                 // transposing reads per k-slice
+            constexpr int MFMAS = FI * FJ;
+            constexpr int MPR = MFMAS / (READS / 2) > 0 ? MFMAS / (READS / 2) : 1;      // MFMAs per pair of reads
+            __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);          // slice 0
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            for (int r = 0; r < READS / 2; r++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MFMAS - (READS / 2) * MPR, 0);
         }
     }
 
-    // acc[i][j][r] = dW[co = co0 + wb*64 + j*16 + (lane&15)][col = col0 + wa*64 + i*16 + 4*(lane>>4) + r]
+    // acc[i][j][r] = dW[co = co0 + wb*64 + j*16 + (lane&15)][col = col0 + wa*WCOL + i*16 + 4*(lane>>4) + r]
     float* slab = p.direct ? p.dw + (size_t)bidx * p.Co * p.ncols
                            : p.out + ((size_t)split * p.batch + bidx) * p.Co * p.ncols;
     const bool rmw = p.direct && p.accumulate;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < FJ; j++) {
         const int co = co0 + wb * 64 + j * 16 + (lane & 15);
         if (co < p.Co) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int col = col0 + wa * 64 + i * 16 + 4 * (lane >> 4);
+            for (int i = 0; i < FI; i++) {
+                const int col = col0 + wa * C::WCOL + i * 16 + 4 * (lane >> 4);
                 if (col < p.ncols) {
                     f32x4* d = (f32x4*)(slab + (size_t)co * p.ncols + col);
                     f32x4 v = acc[i][j];
@@ -268,21 +290,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-int plan_splits(const gcc_conv_t* c, int batch, int* ksteps_per_split) {
+int plan_splits(const gcc_conv_t* c, int batch, int* ksteps_per_split, bool* big_out = nullptr) {
     const int Ho = gcc_conv_out(c->H, c->KH, c->stride, c->pad), Wo = gcc_conv_out(c->W, c->KW, c->stride, c->pad);
     const long M = (long)c->N * Ho * Wo;
     const int ksteps = (int)((M + TP - 1) / TP);
     const int ncols = c->KH * c->KW * ceil8(c->Ci);
-    const int tiles = cdiv(ncols, TCOL) * cdiv(c->Co, TCO) * batch;
-    // enough tiles to fill the chip (2 workgroups per CU resident): no split, dW written directly;
-    // otherwise split the pixel range so that ~512 workgroups exist, >= 8 k-steps (512 pixels) each
-    int splits = tiles >= 192 ? 1 : cdiv(512, tiles);
-    const int max_splits = ksteps / 8 > 0 ? ksteps / 8 : 1;
-    if (splits > max_splits) splits = max_splits;
+    // 256 x 256 tiles (one workgroup per CU): large regular outputs only, where at most ~8 pixel splits fill the chip
+    static int big_mode = -1;
+    if (big_mode < 0) { const char* e = getenv("GCC_WGRAD_BIG"); big_mode = e ? atoi(e) : 1; }
+    const int tiles_big = cdiv(ncols, 256) * cdiv(c->Co, 256);
+    bool big = big_mode && batch == 1 && (c->Ci & 7) == 0 && c->Co >= 256 && ncols >= 256 && tiles_big >= 32 && ksteps >= 64;
+    int splits;
+    if (big) {
+        splits = tiles_big >= 200 ? 1 : cdiv(256, tiles_big);
+        const int max_splits = ksteps / 16 > 0 ? ksteps / 16 : 1;
+        if (splits > max_splits) splits = max_splits;
+    } else {
+        const int tiles = cdiv(ncols, 128) * cdiv(c->Co, 128) * batch;
+        // enough tiles to fill the chip (2 workgroups per CU resident): no split, dW written directly;
+        // otherwise split the pixel range so that ~512 workgroups exist, >= 8 k-steps (512 pixels) each
+        splits = tiles >= 192 ? 1 : cdiv(512, tiles);
+        const int max_splits = ksteps / 8 > 0 ? ksteps / 8 : 1;
+        if (splits > max_splits) splits = max_splits;
+    }
     if (splits < 1) splits = 1;
     const int per = cdiv(ksteps, splits);
     splits = cdiv(ksteps, per);
     *ksteps_per_split = per;
+    if (big_out) *big_out = big;
     return splits;
 }
 
@@ -349,21 +384,26 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
     const size_t xb = (size_t)c->N * c->H * c->W * c->ldx * 2, yb = M * c->ldy * 2;
     if (xb >= OOB || yb >= OOB || M >= (1u << 30)) return GCC_ERR_UNSUPPORTED;
     p.M = (int)M; p.x_bytes = (uint32_t)xb; p.dy_bytes = (uint32_t)yb;
-    const int splits = plan_splits(c, batch, &p.ksteps_per_split);
+    bool big = false;
+    const int splits = plan_splits(c, batch, &p.ksteps_per_split, &big);
     p.batch = batch; p.x_bstride = x_bstride; p.dy_bstride = dy_bstride;
     const bool seg = rows_l > 0;      // c holds physical sizes, dw is [rows_l][taps][cols_l]
     const bool regular = !seg && (c->Ci & 7) == 0 && (((uintptr_t)dw) & 15) == 0;
     p.direct = (splits == 1 && regular) ? 1 : 0;
     p.accumulate = accumulate; p.dw = dw;
-    p.col_tiles = cdiv(p.ncols, TCOL); p.co_tiles = cdiv(c->Co, TCO);
+    const int tcol = big ? 256 : 128;
+    p.col_tiles = cdiv(p.ncols, tcol); p.co_tiles = cdiv(c->Co, tcol);
     p.dHW = make_fastdiv(Ho * Wo); p.dW = make_fastdiv(Wo); p.dCip = make_fastdiv(p.Cip); p.dKW = make_fastdiv(c->KW);
     static bool attr_set = false;
-    const int lds = 4 * TILE_BYTES;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WCfg<false>::LDS_BYTES);
+        hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WCfg<true>::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(wgrad_kernel, dim3(p.col_tiles * p.co_tiles, batch, splits), dim3(256), lds, st, p);
+    if (big && regular)
+        hipLaunchKernelGGL(wgrad_kernel<true>, dim3(p.col_tiles * p.co_tiles, batch, splits), dim3(WCfg<true>::NT), WCfg<true>::LDS_BYTES, st, p);
+    else
+        hipLaunchKernelGGL(wgrad_kernel<false>, dim3(p.col_tiles * p.co_tiles, batch, splits), dim3(WCfg<false>::NT), WCfg<false>::LDS_BYTES, st, p);
     GCC_CHECK_LAUNCH();
     if (p.direct) return GCC_OK;
     const size_t total = (size_t)batch * c->Co * c->KH * c->KW * c->Ci;

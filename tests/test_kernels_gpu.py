@@ -67,6 +67,7 @@ CONV_CASES = [
     (2, 22, 22, 16, 3, 7, 1, 0),       # MobileResnet head: 7x7 to 3 channels
     (2, 16, 16, 16, 32, 3, 2, 1),      # MobileResnet down conv k3 s2; its dgrad is ConvTranspose(k3,s2,p1,output_padding=1)
     (1, 16, 16, 128, 64, 3, 2, 1),
+    (4, 33, 33, 264, 520, 4, 1, 1),    # wgrad 256x256 tiles: ragged columns (4224) and output channels (520), 4 pixel splits
 ]
 
 
