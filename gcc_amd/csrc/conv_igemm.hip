@@ -757,6 +757,299 @@ static size_t head_fprop_workspace(const gcc_conv_t* c, int* ksplit_out) {
     return (size_t)sp.ksplit * rows * 16 * sizeof(float);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Thin-input convolutions (<= 8 input channels: the image layers 3->ngf / 6->ndf, and the data gradient of the
+// ConvTranspose that produces the image).  K = taps x 8 is at most two k-steps of the implicit GEMM, whose launch is
+// then all prologue and epilogue (45 us for 6->128 at 256x256 against 15 us of HBM time).  Here a wave owns 16 output
+// pixels at a time and no LDS is involved: with one tap = 8 padded channels = 16 bytes, a 16x16x32 MFMA operand
+// (lane = pixel, 8 consecutive k) IS one 16-byte load of x per lane (tap kc*4 + lane/16), the weights of up to 128
+// output channels stay in registers for the whole launch, and the product is formed transposed (rows = output
+// channels, permuted so that a lane ends up with 8 consecutive channels of its pixel = one 16-byte store).
+struct ThinArgs {
+    const bf16_t* x; const bf16_t* w; bf16_t* y; const float* bias;
+    int act; float slope;
+    int H, W, Ho, Wo, KW, stride, pad, taps;
+    int ldx, xoff, ldy, yoff, Co;
+    uint32_t x_bytes;
+    int total;            // N * Ho * Wo
+};
+
+template <int NJ>      // 32-channel groups per workgroup column
+__global__ __launch_bounds__(256) void thin_fprop_kernel(const ThinArgs a) {
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int co_base = blockIdx.y * (NJ * 32);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (uint32_t)(a.Co * a.taps * 16), 0x00020000);
+
+    // weight operand: tile (t, h) row m = 4q + r holds channel co_base + 32t + 8q + 4h + r.  The NJ*8 operands live in
+    // LDS in fragment order ([operand][lane] x 16 bytes: a wave reads 1 KiB contiguous per MFMA), loaded once per
+    // workgroup: registers stay free for occupancy, which is what hides the load / store latencies here.
+    __shared__ __attribute__((aligned(16))) char wlds[NJ * 8 * 1024];
+#pragma unroll
+    for (int t = 0; t < NJ; t++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int kc = wave;
+            const int co = co_base + 32 * t + 8 * (i >> 2) + 4 * h + (i & 3);
+            const int tap = kc * 4 + g;
+            const uint32_t off = (co < a.Co && tap < a.taps) ? (uint32_t)((co * a.taps + tap) * 16) : OOB;
+            *(i32x4*)(wlds + (((t * 2 + h) * 4 + kc) * 64 + lane) * 16) = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0);
+        }
+    __syncthreads();
+    float bv[NJ][8];
+#pragma unroll
+    for (int t = 0; t < NJ; t++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int co = co_base + 32 * t + 8 * g + e;
+            bv[t][e] = (a.bias && co < a.Co) ? a.bias[co] : 0.f;
+        }
+    // out = v > 0 ? v : v * neg  covers none (1), ReLU (0) and LeakyReLU (slope); tanh layers take the generic kernel
+    const float neg = a.act == GCC_ACT_LRELU ? a.slope : (a.act == GCC_ACT_RELU ? 0.f : 1.f);
+    int tdy[4], tdx[4];
+#pragma unroll
+    for (int kc = 0; kc < 4; kc++) {
+        const int tap = kc * 4 + g;
+        const int kh = tap / a.KW;
+        tdy[kc] = tap < a.taps ? kh - a.pad : -(1 << 28);
+        tdx[kc] = tap - kh * a.KW - a.pad;
+    }
+
+    // tiles past the end fetch nothing (out-of-range offsets return zeros without touching memory)
+    auto fetch = [&](int tile, i32x4* xb) {
+        const int q = tile * 16 + i;
+        const bool qv = q < a.total;
+        const int n = q / (a.Ho * a.Wo);
+        const int r = q - n * (a.Ho * a.Wo);
+        const int oy = r / a.Wo;
+        const int ox = r - oy * a.Wo;
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) {
+            const int iy = oy * a.stride + tdy[kc], ix = ox * a.stride + tdx[kc];
+            const bool ok = qv && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const uint32_t off = ok ? (uint32_t)((((n * a.H + iy) * a.W + ix) * a.ldx + a.xoff) * 2) : OOB;
+            xb[kc] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+        }
+    };
+
+    constexpr int ROWB = NJ * 64 + 16;
+    __shared__ __attribute__((aligned(16))) char stage_all[4][16 * ROWB];
+    char* stage = stage_all[wave];
+
+    auto compute = [&](int tile, const i32x4* xb) {
+        f32x4 acc[NJ][2];
+#pragma unroll
+        for (int t = 0; t < NJ; t++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                acc[t][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++)
+                    acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        *(const bf16x8*)(wlds + (((t * 2 + h) * 4 + kc) * 64 + lane) * 16), __builtin_bit_cast(bf16x8, xb[kc]),
+                        acc[t][h], 0, 0, 0);
+            }
+        // lane (i, g) holds pixel tile*16 + i, channels co_base + 32t + 8g + {0..7} (h = 0: first four, h = 1: last four):
+        // a store from here would touch 16 rows x 64 bytes.  The wave's [16 pixels][NJ*64 bytes] block goes through a
+        // wave-private LDS image (row stride padded by 16 bytes: conflict-free both ways) so that each store instruction
+        // writes whole rows: 64 / (NJ*4) pixels x NJ*64 contiguous bytes.
+#pragma unroll
+        for (int t = 0; t < NJ; t++) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float v0 = acc[t][0][e] + bv[t][e], v1 = acc[t][1][e] + bv[t][4 + e];
+                o[e] = v0 > 0.f ? v0 : v0 * neg;
+                o[4 + e] = v1 > 0.f ? v1 : v1 * neg;
+            }
+            const int co = co_base + 32 * t + 8 * g;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (co + e >= a.Co) o[e] = 0.f;           // padding channels of the 8-wide group stay zero
+            *(i32x4*)(stage + i * ROWB + t * 64 + g * 16) = pack8(o);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int CPR = NJ * 4, PPI = 64 / CPR;       // 16-byte chunks per row, pixels per store instruction
+        const int c = lane % CPR, pl = lane / CPR;
+        const int co = co_base + c * 8;
+#pragma unroll
+        for (int sidx = 0; sidx < 16 / PPI; sidx++) {
+            const int pix = sidx * PPI + pl;
+            const i32x4 v = *(const i32x4*)(stage + pix * ROWB + c * 16);
+            const int q = tile * 16 + pix;
+            if (q < a.total && co < a.Co) *(i32x4*)(a.y + (size_t)q * a.ldy + a.yoff + co) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the image is rewritten by the next tile
+    };
+
+    // persistent waves, two pixel tiles in flight behind the one being multiplied; three statically named buffers
+    // (a rotating array would make the compiler wait for the newest loads at every iteration)
+    const int ntiles = (a.total + 15) >> 4;
+    const int nw = gridDim.x * 4;
+    int tile = blockIdx.x * 4 + wave;
+    i32x4 b0[4], b1[4], b2[4];
+    fetch(tile, b0);
+    fetch(tile + nw, b1);
+    while (tile < ntiles) {
+        fetch(tile + 2 * nw, b2);
+        compute(tile, b0);
+        tile += nw;
+        if (tile >= ntiles) break;
+        fetch(tile + 2 * nw, b0);
+        compute(tile, b1);
+        tile += nw;
+        if (tile >= ntiles) break;
+        fetch(tile + 2 * nw, b1);
+        compute(tile, b2);
+        tile += nw;
+    }
+}
+
+static bool thin_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GCC_IGEMM_THIN"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+static bool thin_shape(const gcc_conv_t* c) {
+    return ceil8(c->Ci) == 8 && c->KH * c->KW <= 16 && c->Co >= 16 && (size_t)c->Co * c->KH * c->KW * 16 < OOB && thin_enabled();
+}
+static int launch_thin(const gcc_conv_t* c, const void* x, const void* w, void* y, const gcc_epilogue_t* ep, hipStream_t st) {
+    ThinArgs a;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.y = (bf16_t*)y;
+    a.bias = ep ? ep->bias : nullptr; a.act = ep ? ep->act : GCC_ACT_NONE; a.slope = ep ? ep->slope : 0.f;
+    a.H = c->H; a.W = c->W; a.KW = c->KW; a.stride = c->stride; a.pad = c->pad; a.taps = c->KH * c->KW;
+    a.Ho = gcc_conv_out(c->H, c->KH, c->stride, c->pad); a.Wo = gcc_conv_out(c->W, c->KW, c->stride, c->pad);
+    a.ldx = c->ldx; a.xoff = c->xoff; a.ldy = c->ldy; a.yoff = c->yoff; a.Co = c->Co;
+    const size_t xb = (size_t)c->N * c->H * c->W * c->ldx * 2, outs = (size_t)c->N * a.Ho * a.Wo;
+    if (xb >= OOB || outs >= (size_t)1 << 30) return -1;
+    a.x_bytes = (uint32_t)xb; a.total = (int)outs;
+    const int ntiles = (a.total + 15) / 16;
+    // persistent waves: weights are fetched once per wave, so no more workgroups than fill the chip twice
+    // persistent waves: three workgroups per CU (the 128-channel form's 50 KB of LDS and 133 VGPRs allow exactly that;
+    // measured best for the narrower forms too)
+    const int nj = c->Co > 64 ? 4 : (c->Co > 32 ? 2 : 1);
+    const int cols = cdiv(c->Co, nj * 32);
+    int wgs = cdiv(ntiles, 4);
+    if (wgs > 768) wgs = 768;
+    const dim3 grid(wgs, cols);
+    if (nj == 4) hipLaunchKernelGGL(thin_fprop_kernel<4>, grid, dim3(256), 0, st, a);
+    else if (nj == 2) hipLaunchKernelGGL(thin_fprop_kernel<2>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(thin_fprop_kernel<1>, grid, dim3(256), 0, st, a);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+// Thin-output backward-data / ConvTranspose forward (<= 8 channels out, k4 s2 p1: the image-producing ConvTranspose of
+// the generators and the data gradient of the first discriminator layer).  As a 128 x 16 implicit GEMM each of the four
+// phases re-gathers dy and pays its own prologue (80 us for 128 -> 6 at 256 x 256 against 15 us of HBM time).  Here a
+// wave owns 16 horizontally adjacent output PAIRS (iy, 2j) / (iy, 2j+1) of one row parity: the 16 MFMA rows are
+// (pixel of the pair, channel), the contraction runs over the 2 x 3 dy pixels the pair touches x Co (a third of the weight
+// operand is structural zeros), the dy operand is one 16-byte load per lane straight from global memory, and the weight
+// operands of the row parity sit in LDS in fragment order.  Bound by the texture path (every dy byte is requested three
+// times per output pixel): 43 -> 17 us for 32 channels in, 55 -> 48 for 64, slower than the implicit GEMM for 128 (95 vs
+// 80 us), so it serves Co <= 64; the wide case needs dy rows staged in LDS (a ring of rows per workgroup) -- open.
+struct ThinDgradArgs {
+    const bf16_t* dy; const bf16_t* wt; bf16_t* dx; const float* bias;
+    int act; float slope;
+    int N, H, W, Ho, Wo, ldy, yoff, ldx, xoff, Ci, Co8;
+    uint32_t dy_bytes, wt_bytes;
+    int tiles_per_row, ntiles;        // per row parity: N * (H/2) * tiles_per_row
+};
+
+template <int NCC>      // 32-channel chunks of Co
+__global__ __launch_bounds__(256) void thin_dgrad_k4s2_kernel(const ThinDgradArgs a) {
+    constexpr int NK = 6 * NCC;
+    __shared__ __attribute__((aligned(16))) char wlds[NK * 1024];
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int py = blockIdx.y;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+    // operand f = (u, b, cc): dy row r + dr(u), dy column j + b (b = -1, 0, +1), channels 32cc + 8g ..
+    //   row parity 0 (iy = 2r)  : kh = 1 -> oy = r, kh = 3 -> oy = r - 1;   parity 1 (iy = 2r + 1): kh = 0 -> r + 1, kh = 2 -> r
+    //   pixel 0 (ix = 2j)       : kw = 1 -> ox = j, kw = 3 -> ox = j - 1;   pixel 1 (ix = 2j + 1) : kw = 0 -> j + 1, kw = 2 -> j
+    for (int f = wave; f < NK; f += 4) {
+        const int u = f / (3 * NCC), b = (f / NCC) % 3 - 1, cc = f % NCC;
+        const int px = i >> 3, ci = i & 7;
+        const int kh = py == 0 ? (u == 0 ? 1 : 3) : (u == 0 ? 0 : 2);
+        const int kw = px == 0 ? (b == 0 ? 1 : (b < 0 ? 3 : -1)) : (b > 0 ? 0 : (b == 0 ? 2 : -1));
+        const int co = 32 * cc + 8 * g;
+        const uint32_t off = (kw >= 0 && ci < a.Ci && co < a.Co8) ? (uint32_t)((((ci * 16 + kh * 4 + kw) * a.Co8) + co) * 2) : OOB;
+        *(i32x4*)(wlds + (f * 64 + lane) * 16) = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0);
+    }
+    __syncthreads();
+    const int ci0 = (g & 1) * 4, pxo = g >> 1;
+    float bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) bv[e] = (a.bias && ci0 + e < a.Ci) ? a.bias[ci0 + e] : 0.f;
+
+    const int nw = gridDim.x * 4;
+    for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += nw) {
+        const int jt = tile % a.tiles_per_row;
+        const int nr = tile / a.tiles_per_row;           // n * (H/2) + r
+        const int r = nr % (a.H >> 1), n = nr / (a.H >> 1);
+        const int j = jt * 16 + i;
+        i32x4 yb[NK];
+#pragma unroll
+        for (int f = 0; f < NK; f++) {
+            const int u = f / (3 * NCC), b = (f / NCC) % 3 - 1, cc = f % NCC;
+            const int oy = r + (py == 0 ? (u == 0 ? 0 : -1) : (u == 0 ? 1 : 0));
+            const int ox = j + b;
+            const int co = 32 * cc + 8 * g;
+            const bool ok = (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo && co < a.Co8;
+            const uint32_t off = ok ? (uint32_t)((((n * a.Ho + oy) * a.Wo + ox) * a.ldy + a.yoff + co) * 2) : OOB;
+            yb[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};       // two chains: MFMA back-to-back dependency
+#pragma unroll
+        for (int f = 0; f < NK; f += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(wlds + (f * 64 + lane) * 16),
+                                                           __builtin_bit_cast(bf16x8, yb[f]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(wlds + ((f + 1) * 64 + lane) * 16),
+                                                           __builtin_bit_cast(bf16x8, yb[f + 1]), acc1, 0, 0, 0);
+        }
+        // lane (i, g): output pixel (iy = 2r + py, ix = 2j + (g >> 1)), channels 4 (g & 1) + {0..3}
+        const int ix = 2 * j + pxo;
+        if (ix < a.W) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                o[e] = apply_act(acc0[e] + acc1[e] + bv[e], a.act, a.slope);
+                if (ci0 + e >= a.Ci) o[e] = 0.f;
+            }
+            i32x2 v = {(int)pack2bf(o[0], o[1]), (int)pack2bf(o[2], o[3])};
+            *(i32x2*)(a.dx + ((size_t)(n * a.H + 2 * r + py) * a.W + ix) * a.ldx + a.xoff + ci0) = v;
+        }
+    }
+}
+
+static bool thin_dgrad_shape(const gcc_conv_t* c) {
+    return ceil8(c->Ci) == 8 && c->KH == 4 && c->KW == 4 && c->stride == 2 && c->pad == 1 && !(c->H & 1) && !(c->W & 1) &&
+           c->Co >= 16 && c->Co <= 64 && thin_enabled();
+}
+static int launch_thin_dgrad(const gcc_conv_t* c, const void* dy, const void* wt, void* dx, const gcc_epilogue_t* ep, hipStream_t st) {
+    ThinDgradArgs a;
+    a.dy = (const bf16_t*)dy; a.wt = (const bf16_t*)wt; a.dx = (bf16_t*)dx;
+    a.bias = ep ? ep->bias : nullptr; a.act = ep ? ep->act : GCC_ACT_NONE; a.slope = ep ? ep->slope : 0.f;
+    a.N = c->N; a.H = c->H; a.W = c->W; a.Ho = c->H / 2; a.Wo = c->W / 2;
+    a.ldy = c->ldy; a.yoff = c->yoff; a.ldx = c->ldx; a.xoff = c->xoff; a.Ci = c->Ci; a.Co8 = ceil8(c->Co);
+    const size_t yb = (size_t)c->N * a.Ho * a.Wo * c->ldy * 2, wb = (size_t)c->Ci * 16 * a.Co8 * 2;
+    const size_t xb = (size_t)c->N * c->H * c->W * c->ldx * 2;
+    if (yb >= OOB || wb >= OOB || xb >= OOB) return -1;
+    a.dy_bytes = (uint32_t)yb; a.wt_bytes = (uint32_t)wb;
+    a.tiles_per_row = cdiv(a.Wo, 16);
+    a.ntiles = c->N * a.Ho * a.tiles_per_row;
+    const int ncc = a.Co8 > 32 ? 2 : 1;
+    int wgs = cdiv(a.ntiles, 4);
+    if (wgs > 768) wgs = 768;
+    const dim3 grid(wgs, 2);
+    if (ncc == 2) hipLaunchKernelGGL(thin_dgrad_k4s2_kernel<2>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(thin_dgrad_k4s2_kernel<1>, grid, dim3(256), 0, st, a);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
 // internal entry (also used by distill.hip): `batch` independent problems, strides in elements
 int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const void* w, void* dst, const gcc_epilogue_t* ep,
                        int batch, long src_bstride, long wgt_bstride, long dst_bstride, hipStream_t st) {
@@ -802,6 +1095,14 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
                 }
             }
         }
+    }
+    if (batch == 1 && dgrad && thin_dgrad_shape(c) && !(ep && ep->stats_partial)) {
+        const int rc2 = launch_thin_dgrad(c, src, w, dst, ep, st);
+        if (rc2 >= 0) return rc2;
+    }
+    if (batch == 1 && !dgrad && thin_shape(c) && !(ep && (ep->stats_partial || ep->act == GCC_ACT_TANH))) {
+        const int rc2 = launch_thin(c, src, w, dst, ep, st);
+        if (rc2 >= 0) return rc2;
     }
     IgemmParams p;
     p.src = (const bf16_t*)src; p.wgt = (const bf16_t*)w; p.dst = (bf16_t*)dst;

@@ -262,28 +262,41 @@ __global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __re
 }
 
 // irregular widths (Ci % 8 != 0: 3- and 6-channel first layers): dW[co][tap][ci] (+)= sum_z slab[z][co][tap][cip]
-// same shape as the vector fold: 64 outputs x 4 split lanes per workgroup
+// OL outputs x SL split lanes per workgroup.  The image layers have few outputs and hundreds of slabs: with 16 split
+// lanes and the slab loop unrolled (independent loads in flight) the fold is no longer a chain of dependent loads
+// (36 us for 6 -> 128 at 256 x 256, twice the MFMA kernel it follows, before).
+template <int OL, int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splits,
                                                            int Co, int taps, int Ci, int Cip, int accumulate, int Cop,
                                                            int row_split, int col_split) {
-    __shared__ float sh[4][64];
+    static_assert(OL * SL == 256, "one workgroup");
+    __shared__ float sh[SL][OL];
     const size_t total = (size_t)Co * taps * Ci;
     const size_t slab = (size_t)Cop * taps * Cip;
-    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
+    const int o = threadIdx.x % OL, sl = threadIdx.x / OL;
+    for (size_t base = (size_t)blockIdx.x * OL; base < total; base += (size_t)gridDim.x * OL) {
         const size_t i = base + o;
         float s = 0.f;
         if (i < total) {
             const int c = (int)(i % Ci);
             const size_t rt = i / Ci;
             const int tap = (int)(rt % taps), r = (int)(rt / taps);
-            const size_t src = ((size_t)seg_to_phys(r, Co, row_split) * taps + tap) * Cip + seg_to_phys(c, Ci, col_split);
-            for (int z = sl; z < splits; z += 4) s += slabs[z * slab + src];
+            const float* src = slabs + ((size_t)seg_to_phys(r, Co, row_split) * taps + tap) * Cip + seg_to_phys(c, Ci, col_split);
+            int z = sl;
+            for (; z + 7 * SL < splits; z += 8 * SL) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = src[(size_t)(z + u * SL) * slab];
+#pragma unroll
+                for (int u = 0; u < 8; u++) s += v[u];
+            }
+            for (; z < splits; z += SL) s += src[(size_t)z * slab];
         }
         sh[sl][o] = s;
         __syncthreads();
         if (sl == 0 && i < total) {
-            s += sh[1][o] + sh[2][o] + sh[3][o];
+#pragma unroll
+            for (int q = 1; q < SL; q++) s += sh[q][o];
             dw[i] = accumulate ? dw[i] + s : s;
         }
         __syncthreads();
@@ -389,6 +402,7 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
     p.batch = batch; p.x_bstride = x_bstride; p.dy_bstride = dy_bstride;
     const bool seg = rows_l > 0;      // c holds physical sizes, dw is [rows_l][taps][cols_l]
     const bool regular = !seg && (c->Ci & 7) == 0 && (((uintptr_t)dw) & 15) == 0;
+    big = big && regular;              // concatenated / unaligned gradients keep the 128 x 128 tiling (same split plan)
     p.direct = (splits == 1 && regular) ? 1 : 0;
     p.accumulate = accumulate; p.dw = dw;
     const int tcol = big ? 256 : 128;
@@ -400,7 +414,7 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
         hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WCfg<true>::LDS_BYTES);
         attr_set = true;
     }
-    if (big && regular)
+    if (big)
         hipLaunchKernelGGL(wgrad_kernel<true>, dim3(p.col_tiles * p.co_tiles, batch, splits), dim3(WCfg<true>::NT), WCfg<true>::LDS_BYTES, st, p);
     else
         hipLaunchKernelGGL(wgrad_kernel<false>, dim3(p.col_tiles * p.co_tiles, batch, splits), dim3(WCfg<false>::NT), WCfg<false>::LDS_BYTES, st, p);
@@ -414,18 +428,18 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
         hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits, n4,
                            accumulate);
     } else {
-        int blocks = (int)((total + 63) / 64);
+        const size_t outs = seg ? (size_t)rows_l * c->KH * c->KW * cols_l : total;
+        const bool deep = splits >= 32;           // many slabs, few outputs: 16 outputs x 16 split lanes
+        int blocks = (int)((outs + (deep ? 15 : 63)) / (deep ? 16 : 64));
         if (blocks > 4096) blocks = 4096;
-        if (seg) {
-            const size_t tl = (size_t)rows_l * c->KH * c->KW * cols_l;
-            blocks = (int)((tl + 63) / 64);
-            if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits, rows_l,
-                               c->KH * c->KW, cols_l, p.Cip, accumulate, c->Co, row_split, col_split);
-        } else {
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits,
-                               batch * c->Co, c->KH * c->KW, c->Ci, p.Cip, accumulate, batch * c->Co, 0, 0);
-        }
+        const int rows = seg ? rows_l : batch * c->Co, cols = seg ? cols_l : c->Ci, cop = seg ? c->Co : batch * c->Co;
+        const int rsp = seg ? row_split : 0, csp = seg ? col_split : 0;
+        if (deep)
+            hipLaunchKernelGGL((wgrad_reduce_kernel<16, 16>), dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits, rows,
+                               c->KH * c->KW, cols, p.Cip, accumulate, cop, rsp, csp);
+        else
+            hipLaunchKernelGGL((wgrad_reduce_kernel<64, 4>), dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits, rows,
+                               c->KH * c->KW, cols, p.Cip, accumulate, cop, rsp, csp);
     }
     GCC_CHECK_LAUNCH();
     return GCC_OK;

@@ -26,6 +26,13 @@ SHAPES = [
     ('tG.u4 adj 512->1024 k4s2 @16', 16, 16, 16, 512, 1024, 4, 2, 1),
     ('sG.d2 64->128 k4s2 @64', 16, 64, 64, 64, 128, 4, 2, 1),
     ('sG.d3 128->256 k4s2 @32', 16, 32, 32, 128, 256, 4, 2, 1),
+    # thin first / last layers (<= 8 channels on one side): HBM-bound
+    ('thin sG.d0 3->32 k4s2 @256', 16, 256, 256, 3, 32, 4, 2, 1),
+    ('thin tG.d0 3->64 k4s2 @256', 16, 256, 256, 3, 64, 4, 2, 1),
+    ('thin sG.u0 adj 3->64 k4s2 @256', 16, 256, 256, 3, 64, 4, 2, 1),
+    ('thin tG.u0 adj 3->128 k4s2 @256', 16, 256, 256, 3, 128, 4, 2, 1),
+    ('thin D.L1 6->128 k4s2 @256', 16, 256, 256, 6, 128, 4, 2, 1),
+    ('thin D.L5 1024->1 k4s1 @31', 16, 31, 31, 1024, 1, 4, 1, 1),
     # K scan on the D.L2 geometry (M = 65536, N = 256): nk = 16 .. 128 k-steps per workgroup
     ('Kscan 64->256 k4s2 @128', 16, 128, 128, 64, 256, 4, 2, 1),
     ('Kscan 128->256 k4s2 @128', 16, 128, 128, 128, 256, 4, 2, 1),

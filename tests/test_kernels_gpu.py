@@ -67,6 +67,11 @@ CONV_CASES = [
     (2, 22, 22, 16, 3, 7, 1, 0),       # MobileResnet head: 7x7 to 3 channels
     (2, 16, 16, 16, 32, 3, 2, 1),      # MobileResnet down conv k3 s2; its dgrad is ConvTranspose(k3,s2,p1,output_padding=1)
     (1, 16, 16, 128, 64, 3, 2, 1),
+    (3, 37, 29, 6, 72, 4, 2, 1),       # thin-input kernel: ragged pixel tiles, 72 = 2 x 32 + 8 channels
+    (2, 18, 18, 3, 40, 3, 1, 1),       # thin-input kernel: 9 taps (padded to 12), 40 channels
+    (1, 64, 64, 5, 200, 4, 2, 1),      # thin-input kernel: two 128-channel columns
+    (3, 20, 28, 5, 56, 4, 2, 1),       # thin-output data gradient: ragged pair tiles (Wo = 14), 56 channels in
+    (2, 36, 36, 3, 40, 4, 2, 1),       # thin-output data gradient: two pair tiles per row, 40 channels in
     (4, 33, 33, 264, 520, 4, 1, 1),    # wgrad 256x256 tiles: ragged columns (4224) and output channels (520), 4 pixel splits
 ]
 
@@ -151,6 +156,26 @@ def test_conv_transpose_as_dgrad_with_stats_and_tanh():
     dw = torch.zeros_like(m)
     ops.conv_wgrad(dyd, xd, dw, 4, 2, 1)
     close(dw.cpu(), wr.grad, tol=5e-3, floor=1e-4, what='convT wgrad')
+
+
+@pytest.mark.parametrize('Cin,h,w', [(128, 16, 16), (64, 10, 24), (24, 6, 6), (40, 20, 9)])
+def test_conv_transpose_to_image(Cin, h, w):
+    """the generators' last layer: ConvTranspose2d(Cin -> 3, k4 s2 p1) + bias + tanh on the thin-output kernel"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    N, Cout = 2, 3
+    x = rb(torch.randn(N, Cin, h, w, generator=g))
+    wgt = rb(torch.randn(Cin, Cout, 4, 4, generator=g) * 0.1)
+    b = torch.randn(Cout, generator=g) * 0.1
+    y_ref = F.conv_transpose2d(x, wgt, None, stride=2, padding=1)
+    _, wtp = ops.pack_weights(master_cl(wgt))
+    xd = to_dev(x)
+    y = ops.conv_dgrad(xd, wtp, Cout, 2 * h, 2 * w, 4, 2, 1)
+    close(to_cpu(y), y_ref, what='convT -> image')
+    y2 = ops.conv_dgrad(xd, wtp, Cout, 2 * h, 2 * w, 4, 2, 1, bias=b.to(DEV), act=ops.ACT_TANH)
+    close(to_cpu(y2), torch.tanh(y_ref + b[None, :, None, None]), what='convT -> image + bias + tanh')
+    base = torch.empty(0, dtype=torch.bfloat16, device=DEV).set_(y2.untyped_storage()).view(N, 2 * h, 2 * w, 8)
+    assert float(base[..., Cout:].float().abs().max()) == 0.0, 'padding channels must stay zero'
 
 
 def test_conv_stats_with_bias_on_partial_tiles():
