@@ -78,6 +78,7 @@ PROTOTYPES = {
     'gcc_nchw_f32_to_nhwc_bf16': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'gcc_nhwc_bf16_to_nchw_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'gcc_nhwc_copy': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _Z, _P]),
+    'gcc_nhwc_pack_pair': (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _Z, _P]),
     'gcc_nhwc_add': (_I, [_P, _I, _I, _P, _I, _I, _I, _Z, _P]),
     'gcc_bn_finalize': (_I, [_P, _I, _I, C.c_double, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     'gcc_in_finalize': (_I, [_P, _I, _I, _I, C.c_double, _F, _P, _P, _P, _P, _P]),

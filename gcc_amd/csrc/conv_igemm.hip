@@ -682,27 +682,33 @@ struct HeadArgs {
     bf16_t* g;
     int N, H, W, Ho, Wo, KH, KW, stride, pad;
 };
+// 16 lanes per output (one per tap, taps <= 16), each summing its tap's split-K partials, then a 16-lane shuffle sum:
+// one thread per output walked taps x ksplit dependent loads (21 us for 14400 outputs)
 __global__ __launch_bounds__(256) void head_tapsum_kernel(const HeadArgs a) {
     const size_t total = (size_t)a.N * a.Ho * a.Wo;
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
-        const int ox = (int)(q % a.Wo);
-        const size_t t = q / a.Wo;
-        const int oy = (int)(t % a.Ho);
-        const size_t n = t / a.Ho;
+    const int tap = threadIdx.x & 15;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    for (size_t q0 = (size_t)blockIdx.x * 16; q0 < total; q0 += (size_t)gridDim.x * 16) {
+        const size_t q = q0 + (threadIdx.x >> 4);
         float acc = 0.f;
-        for (int kh = 0; kh < a.KH; kh++) {
-            const int iy = oy * a.stride + kh - a.pad;
-            if ((unsigned)iy >= (unsigned)a.H) continue;
-            for (int kw = 0; kw < a.KW; kw++) {
-                const int ix = ox * a.stride + kw - a.pad;
-                if ((unsigned)ix >= (unsigned)a.W) continue;
+        if (q < total && kh < a.KH) {
+            const int ox = (int)(q % a.Wo);
+            const size_t t = q / a.Wo;
+            const int oy = (int)(t % a.Ho);
+            const size_t n = t / a.Ho;
+            const int iy = oy * a.stride + kh - a.pad, ix = ox * a.stride + kw - a.pad;
+            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
                 const size_t row = (n * a.H + iy) * (size_t)a.W + ix;
-                for (int s = 0; s < a.ksplit; s++) acc += a.partial[((size_t)s * a.rows_max + row) * a.Cpad + kh * a.KW + kw];
+                for (int s = 0; s < a.ksplit; s++) acc += a.partial[((size_t)s * a.rows_max + row) * a.Cpad + tap];
             }
         }
-        float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        o[0] = apply_act(acc + (a.bias ? a.bias[0] : 0.f), a.act, a.slope);
-        *(i32x4*)(a.dst + q * a.ldd + a.doff) = pack8(o);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 16);
+        if (tap == 0 && q < total) {
+            float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            o[0] = apply_act(acc + (a.bias ? a.bias[0] : 0.f), a.act, a.slope);
+            *(i32x4*)(a.dst + q * a.ldd + a.doff) = pack8(o);
+        }
     }
 }
 // G[pixel][tap*8 + 0] = dy[n][oy][ox] with oy*s + kh - pad == iy (if such an output exists), zeros elsewhere
@@ -1089,7 +1095,7 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
                     a.dst = (bf16_t*)dst; a.ldd = c->ldy; a.doff = c->yoff;
                     a.N = c->N; a.H = c->H; a.W = c->W; a.Ho = Ho; a.Wo = Wo; a.KH = c->KH; a.KW = c->KW; a.stride = c->stride; a.pad = c->pad;
                     const size_t outs = (size_t)c->N * Ho * Wo;
-                    hipLaunchKernelGGL(head_tapsum_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, st, a);
+                    hipLaunchKernelGGL(head_tapsum_kernel, dim3((unsigned)(outs + 15 > 16 * 4096 ? 4096 : (outs + 15) / 16)), dim3(256), 0, st, a);
                     GCC_CHECK_LAUNCH();
                     return GCC_OK;
                 }

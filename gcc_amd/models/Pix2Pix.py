@@ -376,7 +376,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         self.finish_G_update()
         N, _, H, W = self._A.shape
         c = self.G._ctx(N, H, W)
-        ops.nhwc_copy(self._A, 0, c.x_in, 0, 3)
+        ops.nhwc_copy(self._A, 0, c.x_in, 0, 3, cfill=8)
         if self.resnet:
             self._gctx = self.G.forward(c, train=self.netG.training)
         else:
@@ -398,8 +398,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
     # -- helpers ------------------------------------------------------------------------------
     def _pack_pair(self, ctx, second):
         """ctx.x_in = cat(real_A, second) along channels (3 + 3, zero-filled to 8)"""
-        ops.nhwc_copy(self._A, 0, ctx.x_in, 0, 3)
-        ops.nhwc_copy(second, 0, ctx.x_in, 3, 3, cfill=5)
+        ops.nhwc_pack_pair(self._A, second, ctx.x_in, 3, 3)
 
     def _d_forward(self, tag, second):
         N, _, H, W = self._A.shape

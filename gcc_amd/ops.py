@@ -361,6 +361,14 @@ def nhwc_copy(src, soff, dst, doff, Cc, cfill=None):
     check(lib().gcc_nhwc_copy(sp, lds, soff, dp, ldd, doff, Cc, cfill if cfill else Cc, N * H * W, stream()), 'gcc_nhwc_copy')
 
 
+def nhwc_pack_pair(a, b, dst, Ca, Cb, doff=0):
+    """dst[:, doff : doff + Ca + Cb] = cat(a[:, :Ca], b[:, :Cb]), zero-filled to the 8-wide group (Ca + Cb <= 8)"""
+    ap, N, _, H, W, lda = geom(a)
+    bp, _, _, _, _, ldb = geom(b)
+    dp, _, _, _, _, ldd = geom(dst)
+    check(lib().gcc_nhwc_pack_pair(ap, lda, 0, bp, ldb, 0, dp, ldd, doff, Ca, Cb, N * H * W, stream()), 'gcc_nhwc_pack_pair')
+
+
 def nhwc_add(src, soff, dst, doff, Cc):
     sp, N, _, H, W, lds = geom(src)
     dp, _, _, _, _, ldd = geom(dst)

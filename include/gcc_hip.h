@@ -131,6 +131,11 @@ int gcc_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int N, int C, int H, 
  * required; [C, Cfill) zero-filled in dst). */
 int gcc_nhwc_copy(const void* src, int lds, int soff, void* dst, int ldd, int doff, int C, int Cfill,
                   size_t pixels, gcc_stream_t stream);
+/* channel concatenation of two thin tensors into one 8-wide group: dst[.., doff + c] = a[.., aoff + c] (c < Ca), then
+ * b[.., boff + c] (c < Cb), zeros up to 8 (Ca + Cb <= 8).  Replaces torch.cat((real_A, fake_B), 1) at
+ * models/Pix2Pix.py:466-470, 483 (the discriminator's conditional input). */
+int gcc_nhwc_pack_pair(const void* a, int lda, int aoff, const void* b, int ldb, int boff, void* dst, int ldd, int doff,
+                       int Ca, int Cb, size_t pixels, gcc_stream_t stream);
 /* dst[.., doff+c] += src[.., soff+c]  (gradient fan-in of fake_B: models/Pix2Pix.py:516-550) */
 int gcc_nhwc_add(const void* src, int lds, int soff, void* dst, int ldd, int doff, int C, size_t pixels,
                  gcc_stream_t stream);
