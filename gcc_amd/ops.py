@@ -693,7 +693,7 @@ def distill_bwd(f, t, wg, wc, df, ws, squared=False):
 
 class AdamPlan:
     """Device-side descriptor/work lists of one optimizer (built once; pointers must stay valid)."""
-    CHUNK = 1 << 16
+    CHUNK = 1 << 12      # elements per 256-thread workgroup: 16 per thread, enough workgroups to fill the chip for 10 M-parameter groups
 
     def __init__(self, params, grads, device, l1=None):
         self.params = list(params)
