@@ -72,6 +72,25 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// division by a launch-constant divisor: one multiply-high and a shift (exact for 0 <= n < 2^31)
+struct FastDiv {
+    uint32_t mul, shr;
+    int d;
+};
+static FastDiv make_fastdiv(int d) {
+    FastDiv f; f.d = d;
+    if (d == 1) { f.mul = 0; f.shr = 0; return f; }
+    int lg = 0;
+    while ((1ll << lg) < d) lg++;
+    const int p = 31 + lg;
+    f.mul = (uint32_t)((((unsigned long long)1 << p) + d - 1) / d);
+    f.shr = p - 32;
+    return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
+    return f.d == 1 ? n : (int)(__umulhi((uint32_t)n, f.mul) >> f.shr);
+}
+
 __host__ __device__ static inline int ceil8(int v) { return (v + 7) & ~7; }
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

@@ -778,6 +778,7 @@ struct ThinArgs {
     int ldx, xoff, ldy, yoff, Co;
     uint32_t x_bytes;
     int total;            // N * Ho * Wo
+    FastDiv dHoWo, dWo;
 };
 
 template <int NJ>      // 32-channel groups per workgroup column
@@ -826,9 +827,9 @@ __global__ __launch_bounds__(256) void thin_fprop_kernel(const ThinArgs a) {
     auto fetch = [&](int tile, i32x4* xb) {
         const int q = tile * 16 + i;
         const bool qv = q < a.total;
-        const int n = q / (a.Ho * a.Wo);
-        const int r = q - n * (a.Ho * a.Wo);
-        const int oy = r / a.Wo;
+        const int n = fdiv(qv ? q : 0, a.dHoWo);
+        const int r = (qv ? q : 0) - n * (a.Ho * a.Wo);
+        const int oy = fdiv(r, a.dWo);
         const int ox = r - oy * a.Wo;
 #pragma unroll
         for (int kc = 0; kc < 4; kc++) {
@@ -866,13 +867,15 @@ __global__ __launch_bounds__(256) void thin_fprop_kernel(const ThinArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const float v0 = acc[t][0][e] + bv[t][e], v1 = acc[t][1][e] + bv[t][4 + e];
-                o[e] = v0 > 0.f ? v0 : v0 * neg;
-                o[4 + e] = v1 > 0.f ? v1 : v1 * neg;
+                o[e] = fmaxf(v0, v0 * neg);             // neg in [0, 1]: v for v > 0, v * neg below
+                o[4 + e] = fmaxf(v1, v1 * neg);
             }
             const int co = co_base + 32 * t + 8 * g;
+            if (a.Co & 7) {                                 // padding channels of the 8-wide group stay zero
 #pragma unroll
-            for (int e = 0; e < 8; e++)
-                if (co + e >= a.Co) o[e] = 0.f;           // padding channels of the 8-wide group stay zero
+                for (int e = 0; e < 8; e++)
+                    if (co + e >= a.Co) o[e] = 0.f;
+            }
             *(i32x4*)(stage + i * ROWB + t * 64 + g * 16) = pack8(o);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -930,6 +933,7 @@ static int launch_thin(const gcc_conv_t* c, const void* x, const void* w, void* 
     const size_t xb = (size_t)c->N * c->H * c->W * c->ldx * 2, outs = (size_t)c->N * a.Ho * a.Wo;
     if (xb >= OOB || outs >= (size_t)1 << 30) return -1;
     a.x_bytes = (uint32_t)xb; a.total = (int)outs;
+    a.dHoWo = make_fastdiv(a.Ho * a.Wo); a.dWo = make_fastdiv(a.Wo);
     const int ntiles = (a.total + 15) / 16;
     // persistent waves: weights are fetched once per wave, so no more workgroups than fill the chip twice
     // persistent waves: three workgroups per CU (the 128-channel form's 50 KB of LDS and 133 VGPRs allow exactly that;
@@ -961,6 +965,7 @@ struct ThinDgradArgs {
     int N, H, W, Ho, Wo, ldy, yoff, ldx, xoff, Ci, Co8;
     uint32_t dy_bytes, wt_bytes;
     int tiles_per_row, ntiles;        // per row parity: N * (H/2) * tiles_per_row
+    FastDiv dTpr, dHh;
 };
 
 template <int NCC>      // 32-channel chunks of Co
@@ -992,9 +997,9 @@ __global__ __launch_bounds__(256) void thin_dgrad_k4s2_kernel(const ThinDgradArg
 
     const int nw = gridDim.x * 4;
     for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += nw) {
-        const int jt = tile % a.tiles_per_row;
-        const int nr = tile / a.tiles_per_row;           // n * (H/2) + r
-        const int r = nr % (a.H >> 1), n = nr / (a.H >> 1);
+        const int nr = fdiv(tile, a.dTpr);               // n * (H/2) + r
+        const int jt = tile - nr * a.tiles_per_row;
+        const int n = fdiv(nr, a.dHh), r = nr - n * (a.H >> 1);
         const int j = jt * 16 + i;
         i32x4 yb[NK];
 #pragma unroll
@@ -1046,6 +1051,7 @@ static int launch_thin_dgrad(const gcc_conv_t* c, const void* dy, const void* wt
     a.dy_bytes = (uint32_t)yb; a.wt_bytes = (uint32_t)wb;
     a.tiles_per_row = cdiv(a.Wo, 16);
     a.ntiles = c->N * a.Ho * a.tiles_per_row;
+    a.dTpr = make_fastdiv(a.tiles_per_row); a.dHh = make_fastdiv(a.Ho);
     const int ncc = a.Co8 > 32 ? 2 : 1;
     int wgs = cdiv(a.ntiles, 4);
     if (wgs > 768) wgs = 768;
@@ -1106,7 +1112,8 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
         const int rc2 = launch_thin_dgrad(c, src, w, dst, ep, st);
         if (rc2 >= 0) return rc2;
     }
-    if (batch == 1 && !dgrad && thin_shape(c) && !(ep && (ep->stats_partial || ep->act == GCC_ACT_TANH))) {
+    if (batch == 1 && !dgrad && thin_shape(c) &&
+        !(ep && (ep->stats_partial || ep->act == GCC_ACT_TANH || (ep->act == GCC_ACT_LRELU && (ep->slope < 0.f || ep->slope > 1.f))))) {
         const int rc2 = launch_thin(c, src, w, dst, ep, st);
         if (rc2 >= 0) return rc2;
     }

@@ -234,6 +234,24 @@ def test_layout_roundtrip_and_copy():
     close(to_cpu(ab), rb(torch.cat([a, a], 1)), tol=0, floor=0, what='copy slice')
     ops.nhwc_add(f, 0, ab, 3, 3)
     close(to_cpu(ab[:, 3:6]), rb(rb(a) + rb(a)), tol=0, floor=0, what='add slice')
+    # the discriminator's conditional input: cat(A, B) as one 16-byte pack, also into the second group of a wider buffer
+    fa, fb = to_dev(a), to_dev(b)
+    pk = ops.new_act(2, 6, 16, 16, DEV)
+    base = torch.empty(0, dtype=torch.bfloat16, device=DEV).set_(pk.untyped_storage()).view(2, 16, 16, 8)
+    base.fill_(1.0)
+    ops.nhwc_pack_pair(fa, fb, pk, 3, 3)
+    close(to_cpu(pk), rb(torch.cat([a, b], 1)), tol=0, floor=0, what='pack pair')
+    assert float(base[..., 6:].float().abs().max()) == 0.0, 'pack pair zero-fills the group'
+    wide = ops.new_act(2, 16, 16, 16, DEV)
+    ops.nhwc_pack_pair(fb, fa, wide, 3, 2, doff=8)
+    close(to_cpu(wide[:, 8:13]), rb(torch.cat([b, a[:, :2]], 1)), tol=0, floor=0, what='pack pair at offset 8')
+    assert float(wide[:, :8].float().abs().max()) == 0.0 and float(wide[:, 13:].float().abs().max()) == 0.0
+    whole = ops.new_act(2, 3, 16, 16, DEV)
+    basew = torch.empty(0, dtype=torch.bfloat16, device=DEV).set_(whole.untyped_storage()).view(2, 16, 16, 8)
+    basew.fill_(1.0)
+    ops.nhwc_copy(fa, 0, whole, 0, 3, cfill=8)
+    close(to_cpu(whole), rb(a), tol=0, floor=0, what='copy whole group')
+    assert float(basew[..., 3:].float().abs().max()) == 0.0
     x = torch.randn(2, 64, 4, 4, generator=g)
     d1, d2 = to_dev(x), to_dev(x)
     ops.nhwc_add(d1, 0, d2, 0, 64)
