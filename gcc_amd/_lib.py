@@ -67,6 +67,7 @@ PROTOTYPES = {
     'gcc_strerror': (C.c_char_p, [_I]),
     'gcc_version': (_I, []),
     'gcc_conv_stat_tiles': (_I, [C.POINTER(conv_t), _I]),
+    'gcc_conv_route': (_I, [C.POINTER(conv_t), _I, C.POINTER(epilogue_t)]),
     'gcc_conv_workspace': (_Z, [C.POINTER(conv_t), _I]),
     'gcc_conv_fprop': (_I, [C.POINTER(conv_t), _P, _P, _P, C.POINTER(epilogue_t), _P]),
     'gcc_conv_dgrad': (_I, [C.POINTER(conv_t), _P, _P, _P, C.POINTER(epilogue_t), _P]),

@@ -1188,6 +1188,20 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
     return GCC_OK;
 }
 
+// which kernel family a fprop / dgrad call with this geometry and epilogue runs on (same predicates as the dispatch in
+// gcc_internal_igemm): 0 igemm_kernel, 1 thin_fprop / thin_dgrad, 2 the single-output-channel head route
+extern "C" int gcc_conv_route(const gcc_conv_t* c, int dgrad, const gcc_epilogue_t* ep) {
+    if (check_conv(c)) return -1;
+    if (dgrad && thin_dgrad_shape(c) && !(ep && ep->stats_partial)) return 1;
+    if (!dgrad && thin_shape(c) &&
+        !(ep && (ep->stats_partial || ep->act == GCC_ACT_TANH || (ep->act == GCC_ACT_LRELU && (ep->slope < 0.f || ep->slope > 1.f)))))
+        return 1;
+    if (!dgrad && head_shape(c) && ep && ep->workspace && !ep->stats_partial && (((uintptr_t)ep->workspace) & 15) == 0 &&
+        head_fprop_workspace(c, nullptr) <= ep->workspace_bytes)
+        return 2;
+    return 0;
+}
+
 extern "C" size_t gcc_conv_workspace(const gcc_conv_t* c, int dgrad) {
     if (check_conv(c)) return 0;
     if (head_shape(c) && !dgrad) return head_fprop_workspace(c, nullptr);

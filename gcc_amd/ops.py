@@ -89,6 +89,9 @@ class _Profile:
 
 
 PROFILE = _Profile()
+# gcc_conv_route() -> label of the bracketed launch
+_ROUTE_KIND = {0: 'igemm_kernel (conv fprop/dgrad)', 1: 'thin_fprop / thin_dgrad (image layers)', 2: 'head route (igemm 128x16 + tap sum)',
+               -1: 'igemm_kernel (conv fprop/dgrad)'}
 
 
 def lib():
@@ -270,7 +273,7 @@ def conv_fprop(x, w, Co, k, stride, pad, out=None, bias=None, act=ACT_NONE, slop
     e0 = PROFILE.begin() if PROFILE.active else None
     check(lib().gcc_conv_fprop(C.byref(d), xp, w.data_ptr(), yp, C.byref(ep), stream()), 'gcc_conv_fprop')
     if e0 is not None:
-        PROFILE.end('igemm_kernel (conv fprop/dgrad)', 2.0 * N * Ho * Wo * Co * k * k * Ci, e0,
+        PROFILE.end(_ROUTE_KIND[lib().gcc_conv_route(C.byref(d), 0, C.byref(ep))], 2.0 * N * Ho * Wo * Co * k * k * Ci, e0,
                     shape=('fprop', N, Ho, Wo, Ci, Co, k, stride))
     return (out, stats) if want_stats else out
 
@@ -291,7 +294,7 @@ def conv_dgrad(dy, wt, Ci, H, W, k, stride, pad, out=None, bias=None, act=ACT_NO
     e0 = PROFILE.begin() if PROFILE.active else None
     check(lib().gcc_conv_dgrad(C.byref(d), yp, wt.data_ptr(), xp, C.byref(ep), stream()), 'gcc_conv_dgrad')
     if e0 is not None:
-        PROFILE.end('igemm_kernel (conv fprop/dgrad)', 2.0 * N * Ho * Wo * Co * k * k * Ci, e0,
+        PROFILE.end(_ROUTE_KIND[lib().gcc_conv_route(C.byref(d), 1, C.byref(ep))], 2.0 * N * Ho * Wo * Co * k * k * Ci, e0,
                     shape=('dgrad', N, Ho, Wo, Ci, Co, k, stride))
     return (out, stats) if want_stats else out
 

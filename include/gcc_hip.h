@@ -77,6 +77,10 @@ size_t gcc_conv_workspace(const gcc_conv_t* c, int dgrad);
 /* number of partial-statistics rows a fprop/dgrad launch writes (one per 128-pixel tile) */
 int gcc_conv_stat_tiles(const gcc_conv_t* c, int dgrad);
 
+/* kernel family a fprop / dgrad call runs on: 0 igemm_kernel, 1 the thin image-layer kernels (<= 8 channels on the
+ * image side), 2 the single-output-channel head route; < 0 for an invalid geometry.  Introspection for profilers. */
+int gcc_conv_route(const gcc_conv_t* c, int dgrad, const gcc_epilogue_t* ep);
+
 /* y = conv(x, W) (+bias, act).  Replaces aten::convolution at models/Pix2Pix.py:31-32, 280-300,
  * 320-343, 407-409 (F.conv2d / nn.Conv2d.forward).  x: [N,H,W,ldx]  w: W packing  y: [N,Ho,Wo,ldy] */
 int gcc_conv_fprop(const gcc_conv_t* c, const void* x, const void* w, void* y,

@@ -38,6 +38,31 @@ def test_library_exports_every_declared_symbol():
     assert b'workspace' in _lib.load().gcc_strerror(-3)
 
 
+def test_conv_route_predicates():
+    """gcc_conv_route is host logic only: which kernel family each layer shape of the headline config runs on"""
+    from gcc_amd import _lib
+    lib = _lib.load()
+    conv = lambda N, H, W, Ci, Co, k, s, p: _lib.conv_t(N, H, W, Ci, Co, k, k, s, p, (Ci + 7) // 8 * 8, 0, (Co + 7) // 8 * 8, 0)
+    none = _lib.epilogue_t(None, 0, 0.2, None, None, 0)
+    d_l1 = conv(16, 256, 256, 6, 128, 4, 2, 1)
+    assert lib.gcc_conv_route(ctypes.byref(d_l1), 0, ctypes.byref(none)) == 1          # thin fprop
+    assert lib.gcc_conv_route(ctypes.byref(d_l1), 1, ctypes.byref(none)) == 0          # 128 channels in: implicit GEMM
+    g_u0 = conv(16, 256, 256, 3, 64, 4, 2, 1)
+    assert lib.gcc_conv_route(ctypes.byref(g_u0), 1, ctypes.byref(none)) == 1          # ConvTranspose 64 -> 3: pair-tiled kernel
+    with_stats = _lib.epilogue_t(None, 0, 0.2, ctypes.c_void_p(4096), None, 0)
+    assert lib.gcc_conv_route(ctypes.byref(d_l1), 0, ctypes.byref(with_stats)) == 0    # fused BN statistics: implicit GEMM
+    d_l2 = conv(16, 128, 128, 128, 256, 4, 2, 1)
+    assert lib.gcc_conv_route(ctypes.byref(d_l2), 0, ctypes.byref(none)) == 0
+    d_l5 = conv(16, 31, 31, 1024, 1, 4, 1, 1)
+    need = lib.gcc_conv_workspace(ctypes.byref(d_l5), 0)
+    assert need > 0
+    ws = _lib.epilogue_t(None, 0, 0.2, None, ctypes.c_void_p(1 << 20), need)
+    assert lib.gcc_conv_route(ctypes.byref(d_l5), 0, ctypes.byref(ws)) == 2            # head route
+    assert lib.gcc_conv_route(ctypes.byref(d_l5), 0, ctypes.byref(none)) == 0          # no workspace: implicit GEMM
+    bad = conv(16, 31, 31, 0, 1, 4, 1, 1)
+    assert lib.gcc_conv_route(ctypes.byref(bad), 0, ctypes.byref(none)) < 0
+
+
 def test_struct_layouts_match_header():
     from gcc_amd import _lib
     assert ctypes.sizeof(_lib.conv_t) == 13 * 4
