@@ -38,23 +38,34 @@ __device__ __forceinline__ i32x4 pack8(const float* f) {
     return v;
 }
 
+// `act` is a launch constant: the slope selection below is scalar (loop-invariant) work and the only branch is the uniform
+// tanh test.  (A per-element `switch` compiled to a chain of scalar branches per element: the streaming kernels were bound by
+// instruction issue, not by HBM -- bnact_fwd ran 5 us behind a plain copy of the same bytes.)
+__device__ __forceinline__ float act_neg_slope(int act, float slope) {
+    return act == GCC_ACT_LRELU ? slope : (act == GCC_ACT_RELU ? 0.f : 1.f);
+}
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
-    switch (act) {
-        case GCC_ACT_LRELU: return v > 0.f ? v : v * slope;
-        case GCC_ACT_RELU: return v > 0.f ? v : 0.f;
-        case GCC_ACT_TANH: return tanhf(v);
-        default: return v;
+    if (act == GCC_ACT_TANH) return tanhf(v);
+    const float neg = act_neg_slope(act, slope);
+    return v > 0.f ? v : v * neg;
+}
+// eight channels at once: the tanh test leaves the element loop
+__device__ __forceinline__ void apply_act8(const float* v, float* o, int act, float slope) {
+    if (act == GCC_ACT_TANH) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = tanhf(v[j]);
+    } else {
+        const float neg = act_neg_slope(act, slope);
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = v[j] > 0.f ? v[j] : v[j] * neg;
     }
 }
 // derivative of the activation evaluated on its OUTPUT y (the reference's in-place activations
 // differentiate through the result: leaky_relu_backward(self_is_result), threshold_backward).
 __device__ __forceinline__ float act_grad_from_out(float y, int act, float slope) {
-    switch (act) {
-        case GCC_ACT_LRELU: return y > 0.f ? 1.f : slope;
-        case GCC_ACT_RELU: return y > 0.f ? 1.f : 0.f;
-        case GCC_ACT_TANH: return 1.f - y * y;
-        default: return 1.f;
-    }
+    const float neg = act_neg_slope(act, slope);
+    const float lin = y > 0.f ? 1.f : neg, th = 1.f - y * y;
+    return act == GCC_ACT_TANH ? th : lin;
 }
 
 // counter-based RNG for dropout: splitmix64 of (seed, index) -> uniform [0,1)

@@ -168,22 +168,26 @@ __global__ __launch_bounds__(256) void bnact_fwd_kernel(const FwdArgs a) {
         const i32x4 raw = *(const i32x4*)(xg + pix * a.ldx + a.xoff + c0);
         float v[8], o1[8], o2[8];
         unpack8(raw, v);
+        // stage by stage over the 8 channels, the launch-constant options tested once per stage (not per element)
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            float z = v[j] * sc[j] + sf[j];
-            if (a.p.drop_p > 0.f) {
+        for (int j = 0; j < 8; j++) v[j] = v[j] * sc[j] + sf[j];
+        if (a.p.drop_p > 0.f) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
                 const float u = rng_uniform(a.p.seed, pix * (size_t)a.C + c0 + j);
-                z = u >= a.p.drop_p ? z * keep_scale : 0.f;
+                v[j] = u >= a.p.drop_p ? v[j] * keep_scale : 0.f;
             }
-            if (!a.p.gate_after_act) {
-                z *= gm[j];
-                o1[j] = apply_act(z, a.p.act, a.p.slope);
-            } else {
-                o1[j] = apply_act(z, a.p.act, a.p.slope) * gm[j];
-                z *= gm[j];
-            }
-            o2[j] = apply_act(z, a.p.act2, a.p.slope);
         }
+        if (!a.p.gate_after_act) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] *= gm[j];
+            apply_act8(v, o1, a.p.act, a.p.slope);
+        } else {
+            apply_act8(v, o1, a.p.act, a.p.slope);
+#pragma unroll
+            for (int j = 0; j < 8; j++) { o1[j] *= gm[j]; v[j] *= gm[j]; }
+        }
+        if (y2g) apply_act8(v, o2, a.p.act2, a.p.slope);
         if (rg) {
             float rv[8];
             unpack8(*(const i32x4*)(rg + pix * a.ldres + c0), rv);
