@@ -49,7 +49,18 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     const float neg = act_neg_slope(act, slope);
     return v > 0.f ? v : v * neg;
 }
-// eight channels at once: the tanh test leaves the element loop
+// N channels at once: the tanh test leaves the element loop
+template <int N>
+__device__ __forceinline__ void apply_actN(const float* v, float* o, int act, float slope) {
+    if (act == GCC_ACT_TANH) {
+#pragma unroll
+        for (int j = 0; j < N; j++) o[j] = tanhf(v[j]);
+    } else {
+        const float neg = act_neg_slope(act, slope);
+#pragma unroll
+        for (int j = 0; j < N; j++) o[j] = v[j] > 0.f ? v[j] : v[j] * neg;
+    }
+}
 __device__ __forceinline__ void apply_act8(const float* v, float* o, int act, float slope) {
     if (act == GCC_ACT_TANH) {
 #pragma unroll

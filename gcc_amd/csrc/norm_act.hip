@@ -164,8 +164,7 @@ __global__ __launch_bounds__(256) void bnact_fwd_kernel(const FwdArgs a) {
         }
     }
     const float keep_scale = a.p.drop_p > 0.f ? 1.f / (1.f - a.p.drop_p) : 1.f;
-    for (size_t pix = (size_t)blockIdx.x * a.L.PPB + pl; pix < a.pixels; pix += (size_t)gridDim.x * a.L.PPB) {
-        const i32x4 raw = *(const i32x4*)(xg + pix * a.ldx + a.xoff + c0);
+    auto one = [&](size_t pix, const i32x4& raw, const i32x4& rres) {
         float v[8], o1[8], o2[8];
         unpack8(raw, v);
         // stage by stage over the 8 channels, the launch-constant options tested once per stage (not per element)
@@ -190,12 +189,26 @@ __global__ __launch_bounds__(256) void bnact_fwd_kernel(const FwdArgs a) {
         if (y2g) apply_act8(v, o2, a.p.act2, a.p.slope);
         if (rg) {
             float rv[8];
-            unpack8(*(const i32x4*)(rg + pix * a.ldres + c0), rv);
+            unpack8(rres, rv);
 #pragma unroll
             for (int j = 0; j < 8; j++) o1[j] += rv[j];
         }
         if (yg) *(i32x4*)(yg + pix * a.ldy + a.yoff + c0) = pack8(o1);
         if (y2g) *(i32x4*)(y2g + pix * a.ldy2 + a.y2off + c0) = pack8(o2);
+    };
+    // two pixels per trip: both loads are issued before either is used (the kernel is a pure stream; with one 16-byte load
+    // in flight per thread the bytes in flight per CU, not HBM, set its rate)
+    const size_t step = (size_t)gridDim.x * a.L.PPB;
+    const i32x4 z4 = {0, 0, 0, 0};
+    for (size_t pix = (size_t)blockIdx.x * a.L.PPB + pl; pix < a.pixels; pix += 2 * step) {
+        const size_t p1 = pix + step;
+        const bool has1 = p1 < a.pixels;
+        const i32x4 r0 = *(const i32x4*)(xg + pix * a.ldx + a.xoff + c0);
+        const i32x4 r1 = has1 ? *(const i32x4*)(xg + p1 * a.ldx + a.xoff + c0) : z4;
+        const i32x4 q0 = rg ? *(const i32x4*)(rg + pix * a.ldres + c0) : z4;
+        const i32x4 q1 = (rg && has1) ? *(const i32x4*)(rg + p1 * a.ldres + c0) : z4;
+        one(pix, r0, q0);
+        if (has1) one(p1, r1, q1);
     }
 }
 
@@ -295,49 +308,92 @@ __global__ __launch_bounds__(NTH) void bnact_bwd_reduce_kernel(const BwdArgs a0)
                 rg1 = ldraw<V>(a.g1 + nx * a.ldg1 + a.g1off + c0);
                 if (a.g2) rg2 = ldraw<V>(a.g2 + nx * a.ldg2 + a.g2off + c0);
             }
+            // stage by stage over the V channels: launch-constant options are tested once per stage, not per element
+            float df[V], zd[V], g[V];
 #pragma unroll
             for (int j = 0; j < V; j++) {
-                float df = 1.f;
+                df[j] = 1.f;
                 if constexpr (DROP) {
                     const float u = rng_uniform(a.p.seed, pix * (size_t)a.C + c0 + j);
-                    df = u >= a.p.drop_p ? keep_scale : 0.f;
+                    df[j] = u >= a.p.drop_p ? keep_scale : 0.f;
                 }
-                float zd = 0.f;
-                if constexpr (GATE || DROP) zd = (xv[j] * sc[j] + sf[j]) * df;
-                float g;
-                if constexpr (GATE) {
-                    float ga;
-                    if (!a.p.gate_after_act) {
-                        const float yo = a.y ? yv[j] : apply_act(zd * gm[j], a.p.act, a.p.slope);
-                        g = g1v[j] * act_grad_from_out(yo, a.p.act, a.p.slope);
-                        if (a.g2) g += g2v[j] * act_grad_from_out(yo, a.p.act2, a.p.slope);
-                        ga = g * zd;
-                        g *= gm[j];
+                zd[j] = 0.f;
+                if constexpr (GATE || DROP) zd[j] = (xv[j] * sc[j] + sf[j]) * df[j];
+            }
+            if constexpr (GATE) {
+                if (!a.p.gate_after_act) {
+                    float yo[V];
+                    if (a.y) {
+#pragma unroll
+                        for (int j = 0; j < V; j++) yo[j] = yv[j];
                     } else {
-                        const float ao = apply_act(zd, a.p.act, a.p.slope);
-                        ga = g1v[j] * ao;
-                        g = g1v[j] * gm[j] * act_grad_from_out(ao, a.p.act, a.p.slope);
+                        float t[V];
+#pragma unroll
+                        for (int j = 0; j < V; j++) t[j] = zd[j] * gm[j];
+                        apply_actN<V>(t, yo, a.p.act, a.p.slope);
                     }
-                    s2[j] += ga;
+#pragma unroll
+                    for (int j = 0; j < V; j++) g[j] = g1v[j] * act_grad_from_out(yo[j], a.p.act, a.p.slope);
+                    if (a.g2) {
+#pragma unroll
+                        for (int j = 0; j < V; j++) g[j] += g2v[j] * act_grad_from_out(yo[j], a.p.act2, a.p.slope);
+                    }
+#pragma unroll
+                    for (int j = 0; j < V; j++) { s2[j] += g[j] * zd[j]; g[j] *= gm[j]; }
                 } else {
-                    // no gate: the saved output y gives the activation derivative; without it, re-derive the
-                    // activation input (rare path: outputs that had a residual added are not usable as y)
-                    float yo;
-                    if (a.y) yo = yv[j];
-                    else if (DROP) yo = apply_act(zd, a.p.act, a.p.slope);
-                    else if (a.p.bn) yo = apply_act(xv[j] * sc[j] + sf[j], a.p.act, a.p.slope);   // the forward's own form
-                    else yo = xv[j];
-                    g = g1v[j] * act_grad_from_out(yo, a.p.act, a.p.slope);
-                    if (a.g2) g += g2v[j] * act_grad_from_out(yo, a.p.act2, a.p.slope);
+                    float ao[V];
+                    apply_actN<V>(zd, ao, a.p.act, a.p.slope);
+#pragma unroll
+                    for (int j = 0; j < V; j++) {
+                        s2[j] += g1v[j] * ao[j];
+                        g[j] = g1v[j] * gm[j] * act_grad_from_out(ao[j], a.p.act, a.p.slope);
+                    }
                 }
-                float d = g * df;
-                if (!a.p.bn) d *= act_grad_from_out(xv[j], a.in_act, a.in_slope);
+            } else {
+                // no gate: the saved output y gives the activation derivative; without it, re-derive the
+                // activation input (outputs that had a residual added are not usable as y)
+                float yo[V];
+                if (a.y) {
+#pragma unroll
+                    for (int j = 0; j < V; j++) yo[j] = yv[j];
+                } else if (DROP) {
+                    apply_actN<V>(zd, yo, a.p.act, a.p.slope);
+                } else if (a.p.bn) {
+                    float t[V];
+#pragma unroll
+                    for (int j = 0; j < V; j++) t[j] = xv[j] * sc[j] + sf[j];     // the forward's own form
+                    apply_actN<V>(t, yo, a.p.act, a.p.slope);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < V; j++) yo[j] = xv[j];
+                }
+#pragma unroll
+                for (int j = 0; j < V; j++) g[j] = g1v[j] * act_grad_from_out(yo[j], a.p.act, a.p.slope);
+                if (a.g2) {
+#pragma unroll
+                    for (int j = 0; j < V; j++) g[j] += g2v[j] * act_grad_from_out(yo[j], a.p.act2, a.p.slope);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < V; j++) dz[j] = g[j] * df[j];
+            if (!a.p.bn) {
+#pragma unroll
+                for (int j = 0; j < V; j++) dz[j] *= act_grad_from_out(xv[j], a.in_act, a.in_slope);
+            }
+            if (evs != 0.f) {
+                if constexpr (GATE || DROP) {
+#pragma unroll
+                    for (int j = 0; j < V; j++) dz[j] *= sc[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < V; j++) dz[j] *= rs[j] * (a.p.gamma ? a.p.gamma[c0 + j < a.C ? c0 + j : 0] : 1.f);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < V; j++) {
                 const float xh = (xv[j] - mu[j]) * rs[j];
-                if constexpr (GATE || DROP) { if (evs != 0.f) d *= sc[j]; }
-                else { if (evs != 0.f) d *= rs[j] * (a.p.gamma ? a.p.gamma[c0 + j < a.C ? c0 + j : 0] : 1.f); }
-                dz[j] = d;
-                s0[j] += d;
-                s1[j] += d * xh;
+                s0[j] += dz[j];
+                s1[j] += dz[j] * xh;
             }
             stv<V>(a.dx + pix * a.lddx + a.dxoff + c0, dz);
         }
