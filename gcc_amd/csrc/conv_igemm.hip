@@ -122,7 +122,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
             const bool live = !p.stats || (m0 + pl < M);
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = live ? apply_act(acc[i][j][r] + bv[r], p.act, p.slope) : 0.f;
+            for (int r = 0; r < 4; r++) v[r] = acc[i][j][r] + bv[r];
+            apply_actN<4>(v, v, p.act, p.slope);
+            if (!live) v[0] = v[1] = v[2] = v[3] = 0.f;
             i32x2 pk;
             pk[0] = (int)pack2bf(v[0], v[1]);
             pk[1] = (int)pack2bf(v[2], v[3]);
