@@ -38,3 +38,10 @@ for g, n in gaps:
     by[n[:60]][0] += g; by[n[:60]][1] += 1
 for n, (g, c) in sorted(by.items(), key=lambda x: -x[1][0])[:12]:
     print('  %7.1f us over %4d gaps before %s' % (g / 1e3, c, n))
+cnt = defaultdict(lambda: [0, 0])
+for s_, e_, q_, n_ in ev:
+    k = n_[:70]
+    cnt[k][0] += 1; cnt[k][1] += e_ - s_
+print('launches in the window: %d' % len(ev))
+for k, (c, t) in sorted(cnt.items(), key=lambda x: -x[1][0])[:int(sys.argv[3]) if len(sys.argv) > 3 else 0]:
+    print('  %5d x %7.1f us  %s' % (c, t / c / 1e3, k))
