@@ -508,17 +508,32 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams 
         const int m = (int)(q / CH);
         const int c0 = (int)(q - (size_t)m * CH) * 8;
         float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int s = 0; s < p.ksplit; s++) {
-            const float* r = base + ((size_t)s * p.rows_max + m) * p.Cpad + c0;
-            const f32x4 a = *(const f32x4*)r, b = *(const f32x4*)(r + 4);
+        const float* r0 = base + (size_t)m * p.Cpad + c0;
+        const size_t sstride = (size_t)p.rows_max * p.Cpad;
+        int sl = 0;
+        for (; sl + 3 < p.ksplit; sl += 4) {            // four slices (8 loads) in flight
+            f32x4 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { a[u] = *(const f32x4*)(r0 + (sl + u) * sstride); b[u] = *(const f32x4*)(r0 + (sl + u) * sstride + 4); }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                v[0] += a[u][0]; v[1] += a[u][1]; v[2] += a[u][2]; v[3] += a[u][3];
+                v[4] += b[u][0]; v[5] += b[u][1]; v[6] += b[u][2]; v[7] += b[u][3];
+            }
+        }
+        for (; sl < p.ksplit; sl++) {
+            const f32x4 a = *(const f32x4*)(r0 + sl * sstride), b = *(const f32x4*)(r0 + sl * sstride + 4);
             v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
             v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
         }
+        if (p.bias) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const bool ok = c0 + j < p.Cout;
-            const float bv = (p.bias && ok) ? p.bias[c0 + j] : 0.f;
-            v[j] = ok ? apply_act(v[j] + bv, p.act, p.slope) : 0.f;
+            for (int j = 0; j < 8; j++) v[j] += c0 + j < p.Cout ? p.bias[c0 + j] : 0.f;
+        }
+        apply_act8(v, v, p.act, p.slope);
+        if (c0 + 8 > p.Cout) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (c0 + j >= p.Cout) v[j] = 0.f;
         }
         const int n = m / (Hg * Wg);
         const int r = m - n * (Hg * Wg);

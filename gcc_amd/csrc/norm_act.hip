@@ -61,8 +61,16 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     }
     sh[0][pl][cl] = s; sh[1][pl][cl] = ss;
     __syncthreads();
+    // two-level fold of the 32 tile lanes (a single thread walking 31 dependent LDS reads cost ~1 us per launch)
+    if (pl < 8) {
+        s = (s + sh[0][pl + 8][cl]) + (sh[0][pl + 16][cl] + sh[0][pl + 24][cl]);
+        ss = (ss + sh[1][pl + 8][cl]) + (sh[1][pl + 16][cl] + sh[1][pl + 24][cl]);
+    }
+    __syncthreads();
+    if (pl < 8) { sh[0][pl][cl] = s; sh[1][pl][cl] = ss; }
+    __syncthreads();
     if (pl == 0 && c < C) {
-        for (int q = 1; q < 32; q++) { s += sh[0][q][cl]; ss += sh[1][q][cl]; }
+        for (int q = 1; q < 8; q++) { s += sh[0][q][cl]; ss += sh[1][q][cl]; }
         const double m = s / count;
         double var = ss / count - m * m;
         if (var < 0.0) var = 0.0;
@@ -451,8 +459,18 @@ __global__ __launch_bounds__(1024) void bnact_bwd_finalize_kernel(const BwdArgs 
     }
     for (int k = 0; k < 3; k++) sh[k][pl][cl] = t[k];
     __syncthreads();
+    if (pl < 8) {                       // two-level fold of the 32 row lanes
+#pragma unroll
+        for (int k = 0; k < 3; k++) t[k] = (t[k] + sh[k][pl + 8][cl]) + (sh[k][pl + 16][cl] + sh[k][pl + 24][cl]);
+    }
+    __syncthreads();
+    if (pl < 8) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) sh[k][pl][cl] = t[k];
+    }
+    __syncthreads();
     if (pl == 0 && c < a.C8) {
-        for (int q = 1; q < 32; q++)
+        for (int q = 1; q < 8; q++)
             for (int k = 0; k < 3; k++) t[k] += sh[k][q][cl];
         if (c < a.C) {
             if (a.p.dbeta) a.p.dbeta[c] += (float)t[0];
