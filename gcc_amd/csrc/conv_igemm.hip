@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams 
 // per-channel sum / sum of squares of an NHWC bf16 tensor -> stats[0][2][C] (one 8-channel chunk per block)
 __global__ __launch_bounds__(256) void channel_stats_kernel(const bf16_t* __restrict__ x, int ld, int off, int C, size_t pixels,
                                                             float* __restrict__ stats) {
-    __shared__ float red[2][256][9];
+    __shared__ float red[4][16];
     const int c0 = blockIdx.x * 8;
     float s[8], ss[8];
 #pragma unroll
@@ -557,13 +557,18 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const bf16_t* __rest
 #pragma unroll
         for (int j = 0; j < 8; j++) { s[j] += v[j]; ss[j] += v[j] * v[j]; }
     }
+    // wave shuffle sums, then the four waves through LDS (16 threads walking 256 LDS entries each cost ~5 us)
 #pragma unroll
-    for (int j = 0; j < 8; j++) { red[0][threadIdx.x][j] = s[j]; red[1][threadIdx.x][j] = ss[j]; }
+    for (int j = 0; j < 8; j++) { s[j] = wave_sum(s[j]); ss[j] = wave_sum(ss[j]); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) { red[wave][j] = s[j]; red[wave][8 + j] = ss[j]; }
+    }
     __syncthreads();
     if (threadIdx.x < 16) {
         const int j = threadIdx.x & 7, w = threadIdx.x >> 3;
-        float t = 0.f;
-        for (int q = 0; q < 256; q++) t += red[w][q][j];
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
         if (c0 + j < C) stats[(size_t)w * C + c0 + j] = t;
     }
 }

@@ -243,6 +243,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __re
     }
 }
 
+// few slabs (<= 8: the usual case, large dW): one thread per float4 output, every slab load and the accumulate load in
+// flight at once, no LDS exchange and no barrier
+__global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                                int splits, size_t n4, int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 v[8];
+#pragma unroll
+        for (int z = 0; z < 8; z++)
+            if (z < splits) v[z] = ((const f32x4*)slabs)[(size_t)z * n4 + i];
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (accumulate) s = ((const f32x4*)dw)[i];
+#pragma unroll
+        for (int z = 0; z < 8; z++)
+            if (z < splits) { s[0] += v[z][0]; s[1] += v[z][1]; s[2] += v[z][2]; s[3] += v[z][3]; }
+        ((f32x4*)dw)[i] = s;
+    }
+}
+
 // irregular widths (Ci % 8 != 0: 3- and 6-channel first layers): dW[co][tap][ci] (+)= sum_z slab[z][co][tap][cip]
 // OL outputs x SL split lanes per workgroup.  The image layers have few outputs and hundreds of slabs: with 16 split
 // lanes and the slab loop unrolled (independent loads in flight) the fold is no longer a chain of dependent loads
@@ -405,10 +423,17 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
     const size_t total = (size_t)batch * c->Co * c->KH * c->KW * c->Ci;
     if (regular) {
         const size_t n4 = total / 4;
-        int blocks = (int)((n4 + 63) / 64);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits, n4,
-                           accumulate);
+        if (splits <= 8) {
+            int blocks = (int)((n4 + 255) / 256);
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits, n4,
+                               accumulate);
+        } else {
+            int blocks = (int)((n4 + 63) / 64);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, splits, n4,
+                               accumulate);
+        }
     } else {
         const size_t outs = seg ? (size_t)rows_l * c->KH * c->KW * cols_l : total;
         const bool deep = splits >= 32;           // many slabs, few outputs: 16 outputs x 16 split lanes

@@ -190,8 +190,7 @@ __global__ __launch_bounds__(1024) void gan_loss_kernel(int mode, int real, int 
     const float inv = 1.f / (float)pixels;
     const float gw = gweight * (gweight_dev ? gweight_dev[0] : 1.f);
     float acc = 0.f;
-    for (size_t i = threadIdx.x; i < pixels; i += blockDim.x) {
-        const float x = bf2f(pred[i * ld + off]);
+    auto one = [&](size_t i, float x, float prev) {
         float l, d;
         if (mode == 0) {          // hinge
             if (ford) {
@@ -212,10 +211,24 @@ __global__ __launch_bounds__(1024) void gan_loss_kernel(int mode, int real, int 
         }
         acc += l;
         if (dpred) {
-            float o[8] = {gw * d * inv, 0, 0, 0, 0, 0, 0, 0};
-            if (dpred_accumulate) o[0] += bf2f(dpred[i * ld + off]);
+            float o[8] = {gw * d * inv + prev, 0, 0, 0, 0, 0, 0, 0};
             *(i32x4*)(dpred + i * ld + off) = pack8(o);
         }
+    };
+    // single workgroup (the map is ~10^4 values): four elements per thread in flight, the trip is a latency chain otherwise
+    const size_t bd = blockDim.x;
+    const bool rd = dpred && dpred_accumulate;
+    for (size_t i0 = threadIdx.x; i0 < pixels; i0 += 4 * bd) {
+        float x[4], pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const size_t i = i0 + u * bd;
+            x[u] = i < pixels ? bf2f(pred[i * ld + off]) : 0.f;
+            pv[u] = (rd && i < pixels) ? bf2f(dpred[i * ld + off]) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i0 + u * bd < pixels) one(i0 + u * bd, x[u], pv[u]);
     }
     const float t = block_sum256(acc, sh);
     if (threadIdx.x == 0) loss[0] = (accumulate ? loss[0] : 0.f) + weight * t * inv;

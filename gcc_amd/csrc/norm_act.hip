@@ -54,7 +54,18 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     }
     double s = 0.0, ss = 0.0;
     if (c < C) {
-        for (int t = pl; t < tiles; t += 32) {
+        int t = pl;
+        for (; t + 96 < tiles; t += 128) {          // four tile rows (8 loads) in flight per thread
+            float a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                a[u] = part[((size_t)(t + 32 * u) * 2 + 0) * C + c];
+                b[u] = part[((size_t)(t + 32 * u) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { s += (double)a[u]; ss += (double)b[u]; }
+        }
+        for (; t < tiles; t += 32) {
             s += (double)part[((size_t)t * 2 + 0) * C + c];
             ss += (double)part[((size_t)t * 2 + 1) * C + c];
         }
