@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams 
 
 // per-channel sum / sum of squares of an NHWC bf16 tensor -> stats[0][2][C] (one 8-channel chunk per block)
 __global__ __launch_bounds__(256) void channel_stats_kernel(const bf16_t* __restrict__ x, int ld, int off, int C, size_t pixels,
-                                                            float* __restrict__ stats) {
+                                                            float* __restrict__ stats, int tiles) {
     __shared__ float red[4][16];
     const int c0 = blockIdx.x * 8;
     float s[8], ss[8];
@@ -570,6 +570,11 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const bf16_t* __rest
         const int j = threadIdx.x & 7, w = threadIdx.x >> 3;
         const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
         if (c0 + j < C) stats[(size_t)w * C + c0 + j] = t;
+    }
+    // rows of the other tiles of the [tiles][2][C] table: zeros (the whole tensor's sums sit in row 0)
+    for (int q = threadIdx.x; q < (tiles - 1) * 16; q += 256) {
+        const int row = 1 + (q >> 4), w = (q >> 3) & 1, j = q & 7;
+        if (c0 + j < C) stats[((size_t)row * 2 + w) * C + c0 + j] = 0.f;
     }
 }
 
@@ -1199,12 +1204,9 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
     if (rc) return rc;
     if (p.ksplit > 1 && stats_out) {
         const int tiles = p.mtiles_max * phases;
-        if (tiles > 1 &&
-            hipMemsetAsync(stats_out + (size_t)2 * p.Cout, 0, (size_t)(tiles - 1) * 2 * p.Cout * sizeof(float), st) != hipSuccess)
-            return GCC_ERR_LAUNCH;
         const size_t pixels = (size_t)p.N * p.Hd * p.Wd;
         hipLaunchKernelGGL(channel_stats_kernel, dim3(ceil8(p.Cout) / 8), dim3(256), 0, st, p.dst, p.ldd, p.doff, p.Cout,
-                           pixels, stats_out);
+                           pixels, stats_out, tiles);
         GCC_CHECK_LAUNCH();
     }
     return GCC_OK;
