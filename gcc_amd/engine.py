@@ -463,11 +463,16 @@ class PatchGANEngine:
         return self._gbufs(c.N, c.H, c.W).layer[-1]
 
     # ---------------------------------------------------------------------------------------
-    def forward(self, c, train=True):
-        """input already in c.x_in; returns c.pred"""
+    def forward(self, c, train=True, defer_running=False, refresh=True):
+        """input already in c.x_in; returns c.pred.
+        defer_running: this pass runs ahead of its place in the reference's order (on another stream): its BatchNorm
+        layers compute their coefficients but leave running_mean / running_var alone; apply_deferred_running(c) replays
+        the finalize with the running update where the pass belongs (the EMA updates of two passes do not commute).
+        refresh=False: the gate masks are current (refresh_masks() was called since alpha last changed)."""
         L = self.L
-        if self.masked:
+        if self.masked and refresh:
             self.refresh_masks()
+        c.deferred = []
         self.conv[0].forward(c.x_in, c.a0, act=ACT_LRELU)
         if self.masked:
             ops.bnact_fwd(c.a0, c.g0, gate=self.mask[0], gate_after_act=True)
@@ -480,12 +485,25 @@ class PatchGANEngine:
             else:
                 _, stats = self.conv[li].forward(src, c.c[li], want_stats=True)
                 n = c.N * c.hs[li][0] * c.hs[li][1]
-                self.bn[li].finalize(stats, n, c.st[li], train)
+                if defer_running and train:
+                    bn = self.bn[li].bn
+                    ops.bn_finalize(stats, n, bn.weight.data, bn.bias.data, None, None, c.st[li], eps=bn.eps, momentum=bn.momentum)
+                    c.deferred.append((li, stats, n))
+                else:
+                    self.bn[li].finalize(stats, n, c.st[li], train)
                 ops.bnact_fwd(c.c[li], c.y[li], scale=c.st[li].scale, shift=c.st[li].shift, gate=self.mask[li], act=ACT_LRELU)
             src = c.y[li]
         self.conv[L - 1].forward(src, c.pred)
         c.train = train
         return c.pred
+
+    def apply_deferred_running(self, c):
+        """the running-statistics updates a defer_running pass left out, on the current stream (which has joined the
+        stream that pass ran on): the same finalize over the same partial sums, now with the EMA update"""
+        for li, stats, n in getattr(c, 'deferred', []):
+            stats.record_stream(torch.cuda.current_stream())
+            self.bn[li].finalize(stats, n, c.st[li], True)
+        c.deferred = []
 
     def backward(self, c, has_pred_grad=True, g_feat=None, wgrad=True, agrad=False, need_dx=True):
         """dL/dpred must be in grad_pred_buffer(c) when has_pred_grad; g_feat = optional [g(y1), g(y3)].

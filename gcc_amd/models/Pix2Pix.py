@@ -400,11 +400,40 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         """ctx.x_in = cat(real_A, second) along channels (3 + 3, zero-filled to 8)"""
         ops.nhwc_pack_pair(self._A, second, ctx.x_in, 3, 3)
 
-    def _d_forward(self, tag, second):
+    def _d_forward(self, tag, second, refresh=True):
         N, _, H, W = self._A.shape
         ctx = self.D.new_ctx(N, H, W, tag)
         self._pack_pair(ctx, second)
-        self.D.forward(ctx, train=True)
+        self.D.forward(ctx, train=True, refresh=refresh)
+        return ctx
+
+    def _start_real_pass(self, tag):
+        """D(real_A, real_B) does not depend on the generator: start it on the auxiliary stream before the generator's
+        forward (the student's stream is the iteration's critical path: ~460 mostly small launches, while the other
+        streams idle half the time).  The pass keeps its place in the reference's order for everything that is order
+        dependent: its BatchNorm running-statistics updates are applied in _take_real_pass(), after D(fake)'s."""
+        self._early = getattr(self, '_early', {})
+        aux = self._aux_stream() if self.teacher_model is not None else False
+        if not aux:
+            return
+        main = torch.cuda.current_stream()
+        self.D.refresh_masks() if self.D.masked else None
+        aux.wait_stream(main)
+        with torch.cuda.stream(aux):
+            N, _, H, W = self._A.shape
+            ctx = self.D.new_ctx(N, H, W, tag)
+            self._pack_pair(ctx, self._B)
+            self.D.forward(ctx, train=True, defer_running=True, refresh=False)
+        self._early[tag] = (ctx, aux)
+
+    def _take_real_pass(self, tag):
+        """the context of D(real) -- from the auxiliary stream if it was started early, else computed here"""
+        got = getattr(self, '_early', {}).pop(tag, None)
+        if got is None:
+            return self._d_forward(tag, self._B)
+        ctx, aux = got
+        torch.cuda.current_stream().wait_stream(aux)
+        self.D.apply_deferred_running(ctx)
         return ctx
 
     def _allreduce(self, optimizer):
@@ -413,8 +442,9 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
     # -- D step (models/Pix2Pix.py:464-477) --------------------------------------------------------
     def backward_D(self):
         mode = self.opt.gan_mode
-        cf = self._d_forward('d_fake', self._fake)
-        cr = self._d_forward('d_real', self._B)
+        early = 'd_real' in getattr(self, '_early', {})
+        cf = self._d_forward('d_fake', self._fake, refresh=not early)
+        cr = self._take_real_pass('d_real')
         gp = self.D.grad_pred_buffer(cf)
         ops.gan_loss(mode, cf.pred, False, True, self._l('D_fake'), dpred=gp, grad_weight=0.5)
         self.D.backward(cf, wgrad=True, need_dx=False)
@@ -500,6 +530,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             # the reference clones; here the teacher's activation buffers of this iteration are
             # simply not overwritten before the student consumes them (separate contexts)
             self.target_distillation_features = T.get_distillation_features()
+        self._start_real_pass('d_real')
         self.forward()
         self.optimizer_D.zero_grad()
         self.backward_D()
@@ -533,8 +564,9 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
     def get_D_arch_diff(self, isTeacher=False):
         """three hinge terms on one fake / real pair; the |.| difference (EMA'd for the teacher)"""
         mode = self.opt.gan_mode
-        cf = self._d_forward('a_fake', self._fake)
-        cr = self._d_forward('a_real', self._B)
+        early = 'a_real' in getattr(self, '_early', {})
+        cf = self._d_forward('a_fake', self._fake, refresh=not early)
+        cr = self._take_real_pass('a_real')
         ops.gan_loss(mode, cf.pred, False, True, self._l('D_arch_fake'))
         ops.gan_loss(mode, cf.pred, True, False, self._l('D_arch_fake_real'))
         ops.gan_loss(mode, cr.pred, True, True, self._l('D_arch_real'))
@@ -579,6 +611,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
                 T.set_input(self.input)
                 T.forward()
                 T.get_D_arch_diff(isTeacher=True)
+            self._start_real_pass('a_real')
             self.forward()
         else:
             self.forward()

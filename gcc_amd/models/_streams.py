@@ -43,6 +43,16 @@ class TeacherStreamMixin:
             fn()
         return ts
 
+    def _aux_stream(self):
+        """second stream of the student: work that does not depend on the generator's output (the discriminator's pass
+        over the real pair) runs here next to the generator's forward.  GCC_EARLY_DREAL=0 turns it off."""
+        if getattr(self, 'serialize_streams', False) or not torch.cuda.is_available():
+            return False
+        if getattr(self, '_astream', None) is None:
+            on = os.environ.get('GCC_EARLY_DREAL', '1') != '0' and os.environ.get('GCC_CONCURRENT_TEACHER', '1') != '0'
+            self._astream = torch.cuda.Stream(device=self.device) if on else False
+        return self._astream
+
     @staticmethod
     def _join(ts):
         if ts:

@@ -45,3 +45,13 @@ for s_, e_, q_, n_ in ev:
 print('launches in the window: %d' % len(ev))
 for k, (c, t) in sorted(cnt.items(), key=lambda x: -x[1][0])[:int(sys.argv[3]) if len(sys.argv) > 3 else 0]:
     print('  %5d x %7.1f us  %s' % (c, t / c / 1e3, k))
+# per queue: gaps between consecutive kernels of the same queue (dispatch latency when short, dependency waits when long)
+byq = defaultdict(list)
+for s_, e_, q_, n_ in ev:
+    byq[q_].append((s_, e_, n_))
+for q_, lst in sorted(byq.items()):
+    lst.sort()
+    short = [b[0] - a[1] for a, b in zip(lst, lst[1:]) if 0 <= b[0] - a[1] < 30000]
+    long_ = [b[0] - a[1] for a, b in zip(lst, lst[1:]) if b[0] - a[1] >= 30000]
+    print('  queue %s: %d kernels; %d back-to-back gaps (< 30 us) totalling %.2f ms (avg %.1f us); %d longer waits totalling %.2f ms'
+          % (q_, len(lst), len(short), sum(short) / 1e6, (sum(short) / max(len(short), 1)) / 1e3, len(long_), sum(long_) / 1e6))
