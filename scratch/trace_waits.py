@@ -30,3 +30,23 @@ for t, q, w, pa, nb in sorted(out):
                 busy[qq] += o
     others = ' '.join('q%s:%.0f%%' % (k, 100.0 * v / w) for k, v in sorted(busy.items()))
     print('t=%7.2f ms  queue %s waits %7.1f us  after %-46s before %-46s | meanwhile %s' % ((t - cut) / 1e6, q, w / 1e3, pa, nb, others))
+# time per kernel name on the busiest queue
+tot = defaultdict(lambda: [0, 0])
+bq = max(byq, key=lambda k: sum(e[1] - e[0] for e in byq[k]))
+for s, e, q, n in byq[bq]:
+    tot[n[:72]][0] += e - s; tot[n[:72]][1] += 1
+print('busiest queue %s: %d kernels, busy %.2f ms of %.2f ms' % (bq, len(byq[bq]), sum(v[0] for v in tot.values()) / 1e6, win))
+for n, (t, c) in sorted(tot.items(), key=lambda x: -x[1][0])[:22]:
+    print('  %7.1f us  %4d x %6.1f us  %s' % (t / 1e3, c, t / c / 1e3, n))
+# gap histogram of the busiest queue
+lst = sorted(byq[bq])
+gaps = [(b[0] - a[1], a[3][:40], b[3][:40]) for a, b in zip(lst, lst[1:])]
+for lo, hi in ((0, 3e3), (3e3, 10e3), (10e3, 30e3), (30e3, 150e3), (150e3, 1e12)):
+    g = [x for x in gaps if lo <= x[0] < hi]
+    print('  gaps %5.0f-%-7.0f us: %4d totalling %7.1f us' % (lo / 1e3, min(hi, 1e9) / 1e3, len(g), sum(x[0] for x in g) / 1e3))
+mid = defaultdict(lambda: [0, 0])
+for w, pa, nb in gaps:
+    if 10e3 <= w < 150e3:
+        mid[(pa, nb)][0] += w; mid[(pa, nb)][1] += 1
+for (pa, nb), (w, c) in sorted(mid.items(), key=lambda x: -x[1][0])[:14]:
+    print('  %7.1f us in %3d gaps  after %-40s before %s' % (w / 1e3, c, pa, nb))
