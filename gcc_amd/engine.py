@@ -167,6 +167,41 @@ def _get(module, dotted):
     return m
 
 
+def refresh_gate_masks(obj):
+    """mask_i = (sign(alpha_i - tau) + 1) / 2 for every gated layer of `obj` (obj.gate / obj.mask / obj.tau).  Once the arch
+    optimizer has re-homed the alphas into its flat buffer they are neighbours in one storage: one launch over the whole
+    span (the masks become views of one buffer at the same offsets) instead of one launch per layer -- these launches sit
+    on the student's critical chain, 4 per discriminator pass.  The alphas' addresses are re-checked on every call."""
+    gates = [(i, g) for i, g in enumerate(obj.gate) if g is not None]
+    if not gates:
+        return
+    alphas = [g.alpha.data for _, g in gates]
+    key = tuple(a.data_ptr() for a in alphas)
+    if getattr(obj, '_mask_key', None) != key:
+        obj._mask_key = key
+        obj._mask_span = None
+        a0 = alphas[0]
+        base = a0.untyped_storage().data_ptr()
+        same = len(alphas) > 1 and all(a.dtype == torch.float32 and a.is_contiguous() and
+                                       a.untyped_storage().data_ptr() == base for a in alphas)
+        lo = min(a.storage_offset() for a in alphas)
+        hi = max(a.storage_offset() + a.numel() for a in alphas)
+        if same and lo % 4 == 0 and hi - lo <= 2 * sum(a.numel() for a in alphas) + 64:
+            obj._alpha_span = torch.empty(0, dtype=torch.float32, device=a0.device).set_(a0.untyped_storage(), lo, (hi - lo,), (1,))
+            obj._mask_span = torch.ones(hi - lo, dtype=torch.float32, device=a0.device)
+            for (i, _), a in zip(gates, alphas):
+                o = a.storage_offset() - lo
+                obj.mask[i] = obj._mask_span[o:o + a.numel()]
+        else:
+            for (i, _), a in zip(gates, alphas):
+                obj.mask[i] = torch.ones(a.numel(), dtype=torch.float32, device=a.device)
+    if obj._mask_span is not None:
+        ops.gate_mask(obj._alpha_span, obj.tau, obj._mask_span)
+    else:
+        for (i, _), a in zip(gates, alphas):
+            ops.gate_mask(a, obj.tau, obj.mask[i])
+
+
 # ------------------------------------------------------------------------------------------------
 # U-Net generator
 # ------------------------------------------------------------------------------------------------
@@ -410,9 +445,7 @@ class PatchGANEngine:
         self._pack.run()
 
     def refresh_masks(self):
-        for i in range(self.L):
-            if self.gate[i] is not None:
-                ops.gate_mask(self.gate[i].alpha.data, self.tau, self.mask[i])
+        refresh_gate_masks(self)
 
     def _sizes(self, H, W):
         hs = []
@@ -1039,9 +1072,7 @@ class SaganDiscriminatorEngine:
         self._pack.run()
 
     def refresh_masks(self):
-        for i in range(4):
-            if self.gate[i] is not None:
-                ops.gate_mask(self.gate[i].alpha.data, self.tau, self.mask[i])
+        refresh_gate_masks(self)
 
     def new_ctx(self, N, tag):
         key = (N, tag)
@@ -1313,9 +1344,7 @@ class SRDiscriminatorEngine:
         self._pack.run()
 
     def refresh_masks(self):
-        for i in range(self.L):
-            if self.gate[i] is not None:
-                ops.gate_mask(self.gate[i].alpha.data, self.tau, self.mask[i])
+        refresh_gate_masks(self)
 
     def _sizes(self, H, W):
         out = []
