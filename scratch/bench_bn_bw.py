@@ -35,5 +35,7 @@ for N, C, H in ((16, 64, 128), (16, 128, 128), (16, 256, 64), (16, 512, 32), (16
     t_copy = timeit(lambda: yb.copy_(xb))
     t_fwd = timeit(lambda: ops.bnact_fwd(x, y, scale=sc, shift=sh, act=ops.ACT_LRELU))
     t_bwd = timeit(lambda: ops.bnact_bwd(x, None, g, dx, bn=bn, gamma=gamma, beta=beta, act=ops.ACT_LRELU, dgamma=dgamma, dbeta=dbeta))
+    gate = torch.ones(C, device=dev); dalpha = torch.zeros(C, device=dev)
+    t_bwdg = timeit(lambda: ops.bnact_bwd(x, None, g, dx, bn=bn, gamma=gamma, beta=beta, gate=gate, act=ops.ACT_LRELU, act2=ops.ACT_LRELU, dgamma=dgamma, dbeta=dbeta, dalpha=dalpha))
     print('N%d C%4d %3dx%-3d %5.1f MB | copy %5.1f us (%.1f TB/s) | bnact_fwd %5.1f us (%.1f TB/s) | bnact_bwd %6.1f us (3 launches; 14 B/elem alg. -> %.1f TB/s)'
-          % (N, C, H, H, mb, t_copy, 2 * mb / t_copy, t_fwd, 2 * mb / t_fwd, t_bwd, 7 * mb / t_bwd), flush=True)
+          % (N, C, H, H, mb, t_copy, 2 * mb / t_copy, t_fwd, 2 * mb / t_fwd, t_bwd, 7 * mb / t_bwd) + ' | gated bwd %6.1f us' % t_bwdg, flush=True)

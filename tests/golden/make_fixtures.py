@@ -969,6 +969,85 @@ def fixture_checkpoint():
     print('checkpoint ok: %d bytes' % len(blob))
 
 
+def fixture_checkpoint_other():
+    """checkpoint files written by the reference's save_models of the other three model classes (student networks at the
+    widths of their *_gcc fixtures, recipe weights), and the image each reference model produces from one in eval mode"""
+    import tempfile
+    import torch.optim as optim
+
+    def dump(model, tag, fwd):
+        with tempfile.TemporaryDirectory() as d:
+            model.save_models(5, d, fid=7.25)
+            blob = open(os.path.join(d, 'model_5.pth'), 'rb').read()
+        open(os.path.join(HERE, 'ref_checkpoint_%s.pth' % tag), 'wb').write(blob)
+        model.model_eval()
+        with torch.no_grad():
+            out = fwd(model)
+        np.savez_compressed(os.path.join(HERE, 'ref_checkpoint_%s.npz' % tag), **{k: v.numpy() for k, v in out.items()})
+        print('checkpoint %s ok: %d bytes' % (tag, len(blob)))
+
+    # CycleGAN: two generators, two masked discriminators
+    from models import get_model_class
+    opt = parse([a for a in CYCLE_ARGV if a not in ('--online_distillation',)])
+    model = get_model_class(opt)(opt)
+    for n, sd in ((model.netG_A, 1101), (model.netG_B, 1102), (model.netD_A, 1103), (model.netD_B, 1104)):
+        load_recipe(n, sd)
+    g = torch.Generator().manual_seed(1105)
+    A, B = torch.rand(1, 3, 64, 64, generator=g) * 2 - 1, torch.rand(1, 3, 64, 64, generator=g) * 2 - 1
+
+    def fwd_cycle(m):
+        m.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
+        m.forward()
+        return {'A': A, 'B': B, 'fake_B': m.fake_B, 'fake_A': m.fake_A}
+    dump(model, 'cyclegan', fwd_cycle)
+
+    # SAGAN (torch >= 2 rejects the reference's integer beta: SURVEY.md hazard H7)
+    real_adam = optim.Adam
+
+    class FloatBetasAdam(real_adam):
+        def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), **kw):
+            super().__init__(params, lr=lr, betas=(float(betas[0]), float(betas[1])), **kw)
+    torch.optim.Adam = FloatBetasAdam
+    try:
+        opt = parse(['--dataroot', './database/celeb/', '--model', 'sagan', '--gpu_ids', '-1', '--ngf', '8', '--ndf', '8',
+                     '--darts_discriminator', '--threshold', '0.1'])
+        model = get_model_class(opt)(opt)
+    finally:
+        torch.optim.Adam = real_adam
+    load_recipe(model.netG, 1111)
+    load_recipe(model.netD, 1112)
+    z = torch.randn(4, opt.z_dim, generator=torch.Generator().manual_seed(1113))
+
+    def fwd_sagan(m):
+        m.set_input({'z': z, 'real_img': torch.zeros(4, 3, 64, 64), 'img_path': ['p'] * 4})
+        m.forward()
+        return {'z': z, 'fake_img': m.fake_img}
+    dump(model, 'sagan', fwd_sagan)
+
+    # SRGAN
+    import torchvision.models.vgg as tvgg
+    tvgg.vgg19 = vgg19_standin
+    from options import options as ref_options
+    if not any('--generator_only' in a.option_strings for a in ref_options.parser._actions):
+        ref_options.parser.add_argument('--generator_only', action='store_true')
+    import models.GANLoss as ref_ganloss
+    ref_ganloss.vgg19 = vgg19_standin
+    opt = parse(['--dataroot', './database/sr/', '--model', 'srgan', '--gpu_ids', '-1', '--ngf', '8', '--ndf', '8',
+                 '--darts_discriminator'])
+    model = get_model_class(opt)(opt)
+    load_recipe(model.netG, 1121)
+    load_recipe(model.netD, 1122)
+    srgan_condition(model.netG.state_dict())
+    srgan_condition(model.netD.state_dict())
+    lr = torch.rand(2, 3, 12, 12, generator=torch.Generator().manual_seed(1123))
+
+    def fwd_srgan(m):
+        m.set_input({'lr': lr, 'hr': torch.zeros(2, 3, 48, 48), 'lr_names': ['a'] * 2, 'hr_names': ['b'] * 2})
+        m.forward()
+        return {'lr': lr, 'fake_hr': m.fake_hr}
+    dump(model, 'srgan', fwd_srgan)
+
+
 def fixture_metric():
     """evaluation arithmetic of the reference on seeded inputs: calculate_frechet_distance (scipy sqrtm) for a
     well-conditioned and a rank-deficient pair, np.mean / np.cov statistics, fast_hist + per_class_iu, y-channel
@@ -1081,6 +1160,6 @@ if __name__ == '__main__':
     only = sys.argv[1:]            # e.g. "make_fixtures.py cyclegan cyclegan_pretrain"; none = all
     import_reference()
     for fn in (fixture_options, fixture_ops, fixture_eval_d8, fixture_gcc_d6, fixture_pretrain_d6, fixture_prune_d8,
-               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan, fixture_srgan, fixture_prune_search_gan, fixture_checkpoint, fixture_metric, fixture_pipeline, fixture_srgan_content):
+               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan, fixture_srgan, fixture_prune_search_gan, fixture_checkpoint, fixture_checkpoint_other, fixture_metric, fixture_pipeline, fixture_srgan_content):
         if not only or fn.__name__[len('fixture_'):] in only:
             fn()
