@@ -981,7 +981,7 @@ extern "C" int gcc_bnact_fwd(const gcc_bnact_t* p, const void* x, int ldx, int x
     a.res = (const bf16_t*)p->residual; a.ldres = p->ld_residual;
     if (a.res && (a.ldres & 7)) return GCC_ERR_BAD_ARG;
     if (!make_layout(C, &a.L)) return GCC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bnact_fwd_kernel, dim3(stream_blocks(pixels, a.L, 6), a.groups), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bnact_fwd_kernel, dim3(stream_blocks(pixels, a.L, 2), a.groups), dim3(256), 0, (hipStream_t)stream, a);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }
@@ -1064,7 +1064,7 @@ extern "C" int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_s
     hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3((a.C8 + 31) / 32, groups), dim3(1024), 0, st, a, blocks);
     GCC_CHECK_LAUNCH();
     if (p->bn && !p->bn_eval) {
-        hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(stream_blocks(pixels, a.L, 6), groups), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(stream_blocks(pixels, a.L, 2), groups), dim3(256), 0, st, a);
         GCC_CHECK_LAUNCH();
     }
     return GCC_OK;
