@@ -132,7 +132,7 @@ def cpu_baseline(iters=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
