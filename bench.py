@@ -73,7 +73,13 @@ def synthetic(batch, rank, device, size=256):
         g = torch.Generator().manual_seed(seed)
         a = torch.rand(batch, 3, size, size, generator=g) * 2 - 1
         b = torch.rand(batch, 3, size, size, generator=g) * 2 - 1
-        return {'A': a.to(device), 'B': b.to(device), 'A_paths': [''] * batch, 'B_paths': [''] * batch}
+        d = {'A': a.to(device), 'B': b.to(device), 'A_paths': [''] * batch, 'B_paths': [''] * batch}
+        # resident in HBM before the timed region: the 'ready' event (gcc_amd.models._streams: what a prefetching loader hands
+        # over with a device batch) tells set_input that no producer kernel is pending
+        torch.cuda.synchronize()
+        d['ready'] = torch.cuda.Event()
+        d['ready'].record()
+        return d
     return pair(1234 + rank), pair(4321 + rank)
 
 
@@ -93,9 +99,9 @@ def one_step(model, train, val):
     model.optimizer_netD_arch()
 
 
-def cpu_baseline(iters=16):
-    """oracle on the host cores: N=1, full-size networks; a bounded sample of about 10 s (16 iterations at ~0.6 s, fewer if
-    the host is slower: at most 30 s)"""
+def cpu_baseline(iters=16, batch=1, budget=30.0):
+    """oracle on the host cores: `batch` images per iteration (N=1 and N=4), full-size networks; a bounded sample
+    (N=1: 16 iterations at ~0.6 s, fewer if the host is slower; at most `budget` seconds)"""
     from oracle import gcc_oracle as O
     try:
         ncores = len(os.sched_getaffinity(0))
@@ -106,8 +112,7 @@ def cpu_baseline(iters=16):
     opt = O.Opt(ngf=32, ndf=128, teacher_ngf=64, teacher_ndf=128, num_downs=8, no_dropout=False, direction='BtoA')
     m = O.build_gcc_pair(opt, seed=0)
     g = torch.Generator().manual_seed(1234)
-    A, B = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1, torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
-    vA, vB = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1, torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    A, B, vA, vB = (torch.rand(batch, 3, 256, 256, generator=g) * 2 - 1 for _ in range(4))
 
     def it():
         m.set_input(A, B)
@@ -118,15 +123,41 @@ def cpu_baseline(iters=16):
     t0 = time.time()
     it()
     first = time.time() - t0
-    log('cpu_baseline: warm-up iteration %.1f s on %d threads' % (first, ncores))
-    iters = max(1, min(iters, int(30.0 / max(first, 1e-3))))
+    log('cpu_baseline: N=%d warm-up iteration %.1f s on %d threads' % (batch, first, ncores))
+    iters = max(1, min(iters, int(budget / max(first, 1e-3))))
     t0 = time.time()
     for _ in range(iters):
         it()
     dt = (time.time() - t0) / iters
-    return {'value': round(1.0 / dt, 4), 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': 'N=1 256x256, same GCC iteration (student ngf32/ndf128 + teacher ngf64/ndf128), fp32, '
-                      '1 warm-up + %d timed iterations, %.2f s/iteration' % (iters, dt)}
+    return {'value': round(batch / dt, 4), 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'N=%d 256x256, same GCC iteration (student ngf32/ndf128 + teacher ngf64/ndf128), fp32, '
+                      '1 warm-up + %d timed iterations, %.2f s/iteration' % (batch, iters, dt)}
+
+
+def generator_block(tag_stats, batch):
+    """north_star's sub-figure: MFMA utilisation of the generator forward + backward at batch 16.  From the bracketed step:
+    conv_* = the generator's fprop / dgrad / wgrad launches alone (algorithmic FLOP / sum of their durations); pass_* = the
+    same FLOP over the wall time of the whole G.forward + G.backward passes, BatchNorm / activation / dropout kernels
+    included.  SURVEY 8(d): 9.25 (student) / 36.19 (teacher) GFLOP per image fwd + bwd; the step also holds the arch step's
+    generator forward (3.10 / 12.10), counted in `measured`."""
+    out = {}
+    for who, gflop in (('student_G', 9.25), ('teacher_G', 36.19)):
+        parts = [tag_stats.get(who + '.fwd'), tag_stats.get(who + '.bwd')]
+        if not all(parts):
+            continue
+        flop = sum(p['flop'] for p in parts)
+        conv_s = sum(p['conv_s'] for p in parts)
+        span_s = sum(p.get('span_s', 0.0) for p in parts)
+        out[who] = {'survey_gflop_per_image_fwd_bwd': gflop, 'measured_gflop_per_image': round(flop / batch / 1e9, 2),
+                    'conv_launches': sum(p['conv_launches'] for p in parts), 'conv_ms': round(conv_s * 1e3, 3),
+                    'conv_tflops': round(flop / conv_s / 1e12, 1), 'conv_mfma_frac': round(flop / conv_s / PEAK_BF16, 4),
+                    'pass_ms': round(span_s * 1e3, 3), 'pass_tflops': round(flop / span_s / 1e12, 1),
+                    'pass_mfma_frac': round(flop / span_s / PEAK_BF16, 4)}
+    if len(out) == 2:
+        tot = {k: sum(tag_stats[w + p][k] for w in ('student_G', 'teacher_G') for p in ('.fwd', '.bwd')) for k in ('flop', 'conv_s', 'span_s')}
+        out['both'] = {'conv_mfma_frac': round(tot['flop'] / tot['conv_s'] / PEAK_BF16, 4),
+                       'pass_mfma_frac': round(tot['flop'] / tot['span_s'] / PEAK_BF16, 4), 'target': 0.40}
+    return out
 
 
 def main():
@@ -150,6 +181,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
     model, opt = build(args.batch)
+    model.G.profile_tag, model.teacher_model.G.profile_tag = 'student_G', 'teacher_G'
     device = model.device
     torch.cuda.set_device(device)
     train, val = synthetic(args.batch, rank, device)
@@ -187,6 +219,7 @@ def main():
     if not args.no_roofline:
         roof = ops.PROFILE.stop()
         if roof is not None:
+            roof['generator'] = generator_block(ops.PROFILE.tag_stats, args.batch)
             # HBM bytes per igemm launch from the PMC counters: collected in their own rocprofv3 passes (--pmc FETCH_SIZE,
             # --pmc WRITE_SIZE; scratch/pmc_traffic.py applies the gfx950 corrections) and committed under profiles/
             import glob
@@ -219,8 +252,11 @@ def main():
     }
     if roof is not None:
         out['roofline'] = roof
+    out['rccl_ranks'] = world
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
+        n4 = cpu_baseline(iters=4, batch=4, budget=20.0)          # SURVEY 8(d) / BASELINE.md: N=1 and N=4
+        out['cpu_baseline']['n4'] = {k: n4[k] for k in ('value', 'unit', 'sample')}
     print(json.dumps(out))
 
 

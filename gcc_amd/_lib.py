@@ -57,6 +57,10 @@ class adam_chunk_t(C.Structure):
     _fields_ = [('tensor', C.c_int), ('pad_', C.c_int), ('offset', C.c_int64)]
 
 
+# gcc_set_option ids (enum in include/gcc_hip.h)
+(OPT_IGEMM_BIG, OPT_IGEMM_BIG_MIN, OPT_IGEMM_BIG_NK, OPT_IGEMM_GLDS, OPT_IGEMM_HEAD, OPT_IGEMM_THIN, OPT_WGRAD_BIG,
+ OPT_BN_SWEEPS, OPT_BN_MAXBLK, OPT_BN_REDUCE_THREADS, OPT_BN_REDUCE_CAP, OPT_INORM_LPP) = range(12)
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -66,6 +70,10 @@ _Z = C.c_size_t
 PROTOTYPES = {
     'gcc_strerror': (C.c_char_p, [_I]),
     'gcc_version': (_I, []),
+    'gcc_set_option': (_I, [_I, _I]),
+    'gcc_get_option': (_I, [_I]),
+    'gcc_conv_set_plan': (_I, [_I, _I, _I]),
+    'gcc_conv_tile': (_I, [C.POINTER(conv_t), _I]),
     'gcc_conv_stat_tiles': (_I, [C.POINTER(conv_t), _I]),
     'gcc_conv_route': (_I, [C.POINTER(conv_t), _I, C.POINTER(epilogue_t)]),
     'gcc_conv_workspace': (_Z, [C.POINTER(conv_t), _I]),
@@ -114,6 +122,7 @@ PROTOTYPES = {
     'gcc_confusion_hist': (_I, [_P, _P, _Z, _I, _P, _P]),
     'gcc_psnr_workspace': (_Z, []),
     'gcc_psnr_y_sse': (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _Z, _P]),
+    'gcc_ssim_y_sum': (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _Z, _P]),
     'gcc_activation_stats_workspace': (_Z, [_I, _I]),
     'gcc_activation_stats': (_I, [_P, _I, _I, _I, _P, _P, _P, _Z, _P]),
     'gcc_frechet_workspace': (_Z, [_I]),

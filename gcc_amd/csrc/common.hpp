@@ -113,6 +113,9 @@ __device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
     return f.d == 1 ? n : (int)(__umulhi((uint32_t)n, f.mul) >> f.shr);
 }
 
+// process-wide tuning options (include/gcc_hip.h: gcc_set_option); defined in misc.hip
+int gcc_opt(int id);
+
 __host__ __device__ static inline int ceil8(int v) { return (v + 7) & ~7; }
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

@@ -11,6 +11,7 @@
 // 4 consecutive output channels of one pixel; the epilogue (bias, activation, bf16 rounding,
 // optional BatchNorm partial sums) goes through LDS and leaves as coalesced 16-byte NHWC stores.
 #include <stdlib.h>
+#include <mutex>
 #include "common.hpp"
 
 // named (not anonymous) namespace: hipcc fails to emit the host stub of a kernel template with internal
@@ -592,26 +593,18 @@ static SplitPlan plan_ksplit(long blocks, int nk) {
     return sp;
 }
 
-static int g_use_glds = -1;
-static bool use_glds() {
-    if (g_use_glds < 0) {
-        const char* e = getenv("GCC_IGEMM_GLDS");
-        g_use_glds = e ? (atoi(e) != 0) : 1;
-    }
-    return g_use_glds != 0;
-}
+static bool use_glds() { return gcc_opt(GCC_OPT_IGEMM_GLDS) != 0; }
 
 template <int BP, int BC>
 int launch(const IgemmParams& p, int phases, int batch, hipStream_t st) {
     using C = Cfg<BP, BC>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;       // one-time kernel attribute (idempotent; once per instantiation)
+    std::call_once(attr_once, [] {
         hipFuncSetAttribute((const void*)igemm_kernel<BP, BC, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         hipFuncSetAttribute((const void*)igemm_kernel<BP, BC, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if constexpr (BP == 128)
             hipFuncSetAttribute((const void*)igemm_kernel<BP, BC, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        attr_set = true;
-    }
+    });
     dim3 grid(p.mtiles_max * p.ntiles, p.ksplit > 1 ? p.ksplit : batch, phases);
     const bool ut = (p.Ct % BK) == 0;
     bool launched = false;
@@ -640,7 +633,6 @@ int launch(const IgemmParams& p, int phases, int batch, hipStream_t st) {
 
 // Tile choice (shared by the launcher, gcc_conv_stat_tiles and gcc_conv_workspace).
 struct TilePlan { int BP, BC, ntiles, mtiles; };
-static int g_big_tiles = -1, g_big_min = 200, g_big_nk = 24;
 static TilePlan select_tile(size_t max_rows, int Cout, int phases, int nk, int batch) {
     TilePlan t;
     t.BP = 128;
@@ -648,14 +640,9 @@ static TilePlan select_tile(size_t max_rows, int Cout, int phases, int nk, int b
     else if (Cout > 32) { t.BC = 64; t.ntiles = 1; }
     else if (Cout > 16) { t.BC = 32; t.ntiles = 1; }
     else { t.BC = 16; t.ntiles = 1; }
-    if (g_big_tiles < 0) {
-        const char* e = getenv("GCC_IGEMM_BIG");
-        g_big_tiles = e ? atoi(e) : 2;
-        const char* m = getenv("GCC_IGEMM_BIG_MIN");      // test hook: minimum number of 256-pixel tiles
-        if (m) g_big_min = atoi(m);
-        const char* k = getenv("GCC_IGEMM_BIG_NK");       // tuning hook: minimum K depth (in 64-steps) for 256-pixel tiles
-        if (k) g_big_nk = atoi(k);
-    }
+    // the plan (gcc_conv_set_plan): which tile families are allowed, minimum number of 256-pixel tiles, minimum K depth
+    const int g_big_tiles = gcc_opt(GCC_OPT_IGEMM_BIG), g_big_min = gcc_opt(GCC_OPT_IGEMM_BIG_MIN),
+              g_big_nk = gcc_opt(GCC_OPT_IGEMM_BIG_NK);
     // 256-pixel tiles (one 8-wave workgroup per CU) when they still fill the chip and the K loop is
     // long enough to amortise the un-overlapped prologue / epilogue of a lone workgroup
     if (g_big_tiles && use_glds() && batch == 1 && Cout >= 128 && nk >= g_big_nk) {
@@ -760,11 +747,7 @@ __global__ __launch_bounds__(256) void head_gather_kernel(const HeadArgs a) {
     }
 }
 
-static bool head_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("GCC_IGEMM_HEAD"); v = e ? atoi(e) : 1; }
-    return v != 0;
-}
+static bool head_enabled() { return gcc_opt(GCC_OPT_IGEMM_HEAD) != 0; }
 // rows of the tap matrix / bytes of the gathered dy matrix
 static size_t head_rows(const gcc_conv_t* c) { return (size_t)c->N * c->H * c->W; }
 static bool head_shape(const gcc_conv_t* c) {
@@ -942,11 +925,7 @@ __global__ __launch_bounds__(256) void thin_fprop_kernel(const ThinArgs a) {
     }
 }
 
-static bool thin_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("GCC_IGEMM_THIN"); v = e ? atoi(e) : 1; }
-    return v != 0;
-}
+static bool thin_enabled() { return gcc_opt(GCC_OPT_IGEMM_THIN) != 0; }
 static bool thin_shape(const gcc_conv_t* c) {
     return ceil8(c->Ci) == 8 && c->KH * c->KW <= 16 && c->Co >= 16 && (size_t)c->Co * c->KH * c->KW * 16 < OOB && thin_enabled();
 }
@@ -1237,6 +1216,13 @@ extern "C" size_t gcc_conv_workspace(const gcc_conv_t* c, int dgrad) {
     const SplitPlan sp = plan_ksplit((long)tp.mtiles * tp.ntiles * phases, nk);
     if (sp.ksplit <= 1) return 0;
     return (size_t)phases * sp.ksplit * max_rows * tp.ntiles * tp.BC * sizeof(float);
+}
+
+extern "C" int gcc_conv_tile(const gcc_conv_t* c, int dgrad) {
+    if (check_conv(c)) return 0;
+    const int phases = dgrad ? c->stride * c->stride : 1;
+    const TilePlan tp = select_tile(conv_max_rows(c, dgrad), dgrad ? c->Ci : c->Co, phases, conv_nk(c, dgrad), 1);
+    return tp.BP * 1000 + tp.BC;
 }
 
 extern "C" int gcc_conv_stat_tiles(const gcc_conv_t* c, int dgrad) {

@@ -10,6 +10,7 @@
 // 8 waves of 128 x 64 for large outputs (WCfg).
 // Split-K over pixels: every split writes an fp32 slab, gcc_wgrad_reduce folds the slabs into the
 // fp32 master-layout gradient (deterministic; no float atomics).
+#include <mutex>
 #include "common.hpp"
 
 namespace {
@@ -309,8 +310,7 @@ int plan_splits(const gcc_conv_t* c, int batch, int* ksteps_per_split, bool* big
     const int ksteps = (int)((M + TP - 1) / TP);
     const int ncols = c->KH * c->KW * ceil8(c->Ci);
     // 256 x 256 tiles (one workgroup per CU): large regular outputs only, where at most ~8 pixel splits fill the chip
-    static int big_mode = -1;
-    if (big_mode < 0) { const char* e = getenv("GCC_WGRAD_BIG"); big_mode = e ? atoi(e) : 1; }
+    const int big_mode = gcc_opt(GCC_OPT_WGRAD_BIG);
     const int tiles_big = cdiv(ncols, 256) * cdiv(c->Co, 256);
     bool big = big_mode && batch == 1 && (c->Ci & 7) == 0 && c->Co >= 256 && ncols >= 256 && tiles_big >= 32 && ksteps >= 64;
     int splits;
@@ -408,12 +408,11 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
     const int tcol = big ? 256 : 128;
     p.col_tiles = cdiv(p.ncols, tcol); p.co_tiles = cdiv(c->Co, tcol);
     p.dHW = make_fastdiv(Ho * Wo); p.dW = make_fastdiv(Wo); p.dCip = make_fastdiv(p.Cip); p.dKW = make_fastdiv(c->KW);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
         hipFuncSetAttribute((const void*)wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WCfg<false>::LDS_BYTES);
         hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WCfg<true>::LDS_BYTES);
-        attr_set = true;
-    }
+    });
     if (big)
         hipLaunchKernelGGL(wgrad_kernel<true>, dim3(p.col_tiles * p.co_tiles, batch, splits), dim3(WCfg<true>::NT), WCfg<true>::LDS_BYTES, st, p);
     else

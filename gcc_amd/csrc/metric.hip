@@ -88,6 +88,36 @@ __global__ __launch_bounds__(256) void psnr_sse_kernel(const float* __restrict__
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+// SSIM on the luminance channel (skimage.metrics.structural_similarity defaults: 7 x 7 uniform window, K1 = .01, K2 = .03,
+// sample covariance NP / (NP - 1), mean of S over the window centres that keep the whole window inside the image), on the
+// 4-pixel-cropped y-channel image of models/SRGAN.py:653-661.  One thread per window centre, 49 taps in f64.
+__global__ __launch_bounds__(256) void ssim_y_kernel(const float* __restrict__ fake, const float* __restrict__ real, int N, int H,
+                                                     int W, double data_range, double* partial) {
+    __shared__ double sh[4];
+    const int h = H - 8, w = W - 8, hv = h - 6, wv = w - 6;       // y image, valid window centres
+    const size_t per = (size_t)hv * wv, total = per * N, plane = (size_t)H * W;
+    const double C1 = (0.01 * data_range) * (0.01 * data_range), C2 = (0.03 * data_range) * (0.03 * data_range);
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t n = i / per, r = i - n * per;
+        const size_t y0 = r / wv + 4, x0 = r % wv + 4;                // top-left tap in the uncropped image
+        const float* f = fake + n * 3 * plane;
+        const float* g = real + n * 3 * plane;
+        double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+        for (int dy = 0; dy < 7; dy++)
+            for (int dx = 0; dx < 7; dx++) {
+                const size_t o = (y0 + dy) * W + x0 + dx;
+                const double a = (double)luma(g, plane, o), b = (double)luma(f, plane, o);   // X = real, Y = fake (:660)
+                sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+            }
+        const double ux = sx / 49.0, uy = sy / 49.0, cn = 49.0 / 48.0;
+        const double vx = cn * (sxx / 49.0 - ux * ux), vy = cn * (syy / 49.0 - uy * uy), vxy = cn * (sxy / 49.0 - ux * uy);
+        acc += ((2.0 * ux * uy + C1) * (2.0 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2));
+    }
+    const double s = block_sum_f64(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double* partial, int n, double scale, double* out, int accumulate) {
     __shared__ double sh[4];
     double acc = 0.0;
@@ -257,6 +287,19 @@ extern "C" int gcc_psnr_y_sse(const float* fake, const float* real, int N, int H
     hipLaunchKernelGGL(psnr_sse_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, fake, real, N, H, W, (double*)ws);
     GCC_CHECK_LAUNCH();
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, nb, 1.0, sse, accumulate);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+extern "C" int gcc_ssim_y_sum(const float* fake, const float* real, int N, int H, int W, double* ssim_sum, int accumulate, void* ws,
+                             size_t ws_bytes, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!fake || !real || !ssim_sum || !ws || N <= 0 || H < 8 + 7 || W < 8 + 7) return GCC_ERR_BAD_ARG;
+    if (ws_bytes < gcc_psnr_workspace()) return GCC_ERR_WORKSPACE;
+    const int nb = nblk((size_t)N * (H - 14) * (W - 14), 1024);
+    hipLaunchKernelGGL(ssim_y_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, fake, real, N, H, W, 255.0, (double*)ws);
+    GCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, nb, 1.0, ssim_sum, accumulate);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

@@ -1,4 +1,7 @@
 // Layout packing, weight packing, losses, distillation loss glue and multi-tensor Adam.
+#include <atomic>
+#include <mutex>
+#include <stdlib.h>
 #include "common.hpp"
 
 int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const void* w, void* dst, const gcc_epilogue_t* ep,
@@ -372,7 +375,48 @@ extern "C" const char* gcc_strerror(int code) {
     }
 }
 extern "C" int gcc_version(void) {
-    GCC_ENTER(); return 100; }
+    GCC_ENTER(); return 200; }
+
+// ---- tuning options (the library's only process-wide state) --------------------------------------------------------
+namespace {
+struct OptDef { const char* env; int def; };
+const OptDef kOptDef[GCC_OPT_COUNT_] = {
+    {"GCC_IGEMM_BIG", 2}, {"GCC_IGEMM_BIG_MIN", 200}, {"GCC_IGEMM_BIG_NK", 24}, {"GCC_IGEMM_GLDS", 1}, {"GCC_IGEMM_HEAD", 1},
+    {"GCC_IGEMM_THIN", 1}, {"GCC_WGRAD_BIG", 1}, {"GCC_BN_SWEEPS", 0}, {"GCC_BN_MAXBLK", 2048}, {"GCC_BN_REDUCE_THREADS", 256},
+    {"GCC_BN_REDUCE_CAP", 1024}, {"GCC_INORM_LPP", 0},
+};
+std::atomic<int> g_opt[GCC_OPT_COUNT_];
+int g_opt_default[GCC_OPT_COUNT_];
+std::once_flag g_opt_once;
+void opt_init() {
+    for (int i = 0; i < GCC_OPT_COUNT_; i++) {
+        const char* e = getenv(kOptDef[i].env);
+        int v = e ? atoi(e) : kOptDef[i].def;
+        if (v < 0) v = kOptDef[i].def;
+        g_opt_default[i] = v;
+        g_opt[i].store(v, std::memory_order_relaxed);
+    }
+}
+}  // namespace
+int gcc_opt(int id) {
+    std::call_once(g_opt_once, opt_init);
+    return g_opt[id].load(std::memory_order_relaxed);
+}
+extern "C" int gcc_get_option(int id) {
+    if (id < 0 || id >= GCC_OPT_COUNT_) return GCC_ERR_BAD_ARG;
+    return gcc_opt(id);
+}
+extern "C" int gcc_set_option(int id, int value) {
+    if (id < 0 || id >= GCC_OPT_COUNT_) return GCC_ERR_BAD_ARG;
+    std::call_once(g_opt_once, opt_init);
+    return g_opt[id].exchange(value < 0 ? g_opt_default[id] : value, std::memory_order_relaxed);
+}
+extern "C" int gcc_conv_set_plan(int big, int big_min, int big_nk) {
+    gcc_set_option(GCC_OPT_IGEMM_BIG, big);
+    gcc_set_option(GCC_OPT_IGEMM_BIG_MIN, big_min);
+    gcc_set_option(GCC_OPT_IGEMM_BIG_NK, big_nk);
+    return GCC_OK;
+}
 
 extern "C" int gcc_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int N, int C, int H, int W, int ld, int off, int Cfill,
                                          gcc_stream_t stream) {

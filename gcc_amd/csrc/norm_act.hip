@@ -25,11 +25,7 @@ static bool make_layout(int C, Layout* L, int V = 8) {
     return true;
 }
 static int stream_blocks(size_t pixels, const Layout& L, int sweeps_per_block) {
-    static int sw = -1, cap = 2048;
-    if (sw < 0) {
-        const char* e = getenv("GCC_BN_SWEEPS"); sw = e ? atoi(e) : 0;
-        const char* m = getenv("GCC_BN_MAXBLK"); if (m) cap = atoi(m);
-    }
+    const int sw = gcc_opt(GCC_OPT_BN_SWEEPS), cap = gcc_opt(GCC_OPT_BN_MAXBLK);
     if (sw > 0) sweeps_per_block = sw;
     size_t b = (pixels + (size_t)L.PPB * sweeps_per_block - 1) / ((size_t)L.PPB * sweeps_per_block);
     if (b < 1) b = 1;
@@ -792,8 +788,7 @@ __global__ __launch_bounds__(NTH) void inorm_bwd_fused_kernel(const InFusedArgs 
 
 template <bool BWD>
 void inorm_launch(const InFusedArgs& a, int N, hipStream_t st) {
-    static int lpp_env = -1;
-    if (lpp_env < 0) { const char* e = getenv("GCC_INORM_LPP"); lpp_env = e ? atoi(e) : 0; }
+    const int lpp_env = gcc_opt(GCC_OPT_INORM_LPP);
     const int lpp = lpp_env ? lpp_env : 2;
     const int slabs = ((a.C + 7) / 8 + lpp - 1) / lpp;
     const dim3 grid(slabs, N);
@@ -987,9 +982,7 @@ extern "C" int gcc_bnact_fwd(const gcc_bnact_t* p, const void* x, int ldx, int x
 }
 
 static int reduce_threads() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("GCC_BN_REDUCE_THREADS"); v = (e && atoi(e) == 1024) ? 1024 : 256; }
-    return v;
+    return gcc_opt(GCC_OPT_BN_REDUCE_THREADS) == 1024 ? 1024 : 256;
 }
 static int bwd_blocks(size_t pixels, const Layout& L) {
     // (L is the 8-channel, 256-thread layout.)  256-thread reduce workgroups sweep PPB/2 pixels at a time: ~16 sweeps
@@ -998,8 +991,7 @@ static int bwd_blocks(size_t pixels, const Layout& L) {
     const size_t per = small ? (size_t)L.PPB * 8 : (size_t)L.PPB * 8 * 4;
     size_t b = (pixels + per - 1) / per;
     if (b < 1) b = 1;
-    static int capv = -1;
-    if (capv < 0) { const char* e = getenv("GCC_BN_REDUCE_CAP"); capv = e ? atoi(e) : 1024; }
+    const int capv = gcc_opt(GCC_OPT_BN_REDUCE_CAP);
     const size_t cap = small ? (size_t)capv : 256;
     if (b > cap) b = cap;
     return (int)b;

@@ -261,12 +261,40 @@ class _GpuFileLoader:
             out[k] = torch.stack(v) if torch.is_tensor(v[0]) else list(v)
         return out
 
+    def rank_order(self):
+        """this rank's share of the epoch: ONE permutation (rank 0's draw, broadcast) dealt round-robin, truncated so that
+        every rank sees the same number of items -- an epoch is one pass over the dataset for the whole job, which keeps
+        the per-epoch LR / EMA-beta / arch-LR schedules those of the reference"""
+        from .. import dist as gdist
+        order = self.order()
+        w = gdist.world_size()
+        if w > 1:
+            import torch.distributed as dist
+            box = [order]
+            dist.broadcast_object_list(box, src=0)
+            order = box[0]
+            order = order[:len(order) // w * w][gdist.rank()::w]
+        return order
+
+    def _produce(self, fn):
+        """run the GPU part of a batch on the loader's own stream and hand the batch over with a 'ready' event (the
+        models' set_input orders every consuming stream behind it): the online teacher's stream does not have to wait
+        for the student's queue, and the batch is never read before its producer finished"""
+        if getattr(self, '_stream', None) is None:
+            self._stream = torch.cuda.Stream()
+        with torch.cuda.stream(self._stream):
+            batch = fn()
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+        batch['ready'] = ev
+        return batch
+
     def __iter__(self):
         from concurrent.futures import ThreadPoolExecutor
-        order, bs = self.order(), int(self.opt.batch_size)
+        order, bs = self.rank_order(), int(self.opt.batch_size)
         with ThreadPoolExecutor(max(1, self.threads)) as pool:
             for b in range(0, len(order), bs):
-                yield self.collate([self.item(i, pool) for i in order[b:b + bs]])
+                yield self._produce(lambda: self.collate([self.item(i, pool) for i in order[b:b + bs]]))
 
 
 class AlignedGpuDataLoader(_GpuFileLoader):
@@ -282,14 +310,21 @@ class AlignedGpuDataLoader(_GpuFileLoader):
     def __len__(self):
         return len(self.paths)
 
+    LOOKAHEAD = 4          # batches decoded ahead of the GPU (bounded: a whole epoch of decoded images does not fit in host memory)
+
     def __iter__(self):
+        from collections import deque
         from concurrent.futures import ThreadPoolExecutor
-        order, bs = self.order(), int(self.opt.batch_size)
+        order, bs = self.rank_order(), int(self.opt.batch_size)
         with ThreadPoolExecutor(max(1, self.threads)) as pool:
-            futs = [pool.submit(self.decode, self.paths[i]) for i in order]        # decode ahead of the GPU
+            window, nxt = deque(), 0
             for b in range(0, len(order), bs):
-                idx = order[b:b + bs]
-                yield self.pipe.batch([f.result() for f in futs[b:b + bs]], [self.paths[i] for i in idx])
+                while nxt < len(order) and nxt < b + (self.LOOKAHEAD + 1) * bs:
+                    window.append(pool.submit(self.decode, self.paths[order[nxt]]))
+                    nxt += 1
+                imgs = [window.popleft().result() for _ in order[b:b + bs]]
+                paths = [self.paths[i] for i in order[b:b + bs]]
+                yield self._produce(lambda: self.pipe.batch(imgs, paths))
 
 
 class UnalignedGpuDataLoader(_GpuFileLoader):

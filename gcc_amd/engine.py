@@ -311,6 +311,13 @@ class UnetEngine:
     # ---------------------------------------------------------------------------------------
     def forward(self, N, H, W, train=True):
         """x must already sit in ctx.x_in (use ctx(N,H,W).x_in); returns ctx (ctx.out = tanh image)."""
+        tag = getattr(self, 'profile_tag', None)
+        if tag and ops.PROFILE.active:             # bench.py's roofline.generator block
+            with ops.PROFILE.span(tag + '.fwd'):
+                return self._forward(N, H, W, train)
+        return self._forward(N, H, W, train)
+
+    def _forward(self, N, H, W, train=True):
         c = self._ctx(N, H, W)
         D, wd, uw = self.D, self.width, self.uwidth
         c.train = train
@@ -343,6 +350,13 @@ class UnetEngine:
     def backward(self, c, g_feat=None, wgrad=True):
         """c.g_out holds dL/d(out).  g_feat: optional list of 4 gradients w.r.t. features(c).
         Accumulates parameter gradients (wgrad) ; nothing is returned (the input image needs none)."""
+        tag = getattr(self, 'profile_tag', None)
+        if tag and ops.PROFILE.active:
+            with ops.PROFILE.span(tag + '.bwd'):
+                return self._backward(c, g_feat, wgrad)
+        return self._backward(c, g_feat, wgrad)
+
+    def _backward(self, c, g_feat=None, wgrad=True):
         D, wd, uw, N = self.D, self.width, self.uwidth, c.N
         if g_feat is None:
             g_feat = [None] * 4

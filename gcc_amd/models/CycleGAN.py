@@ -113,6 +113,8 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
             for cfg, lst in ((cfg_AtoB, self.transform_A_convs), (cfg_BtoA, self.transform_B_convs)):
                 s = opt.ngf * 4 if cfg is None else cfg[2]
                 lst += [nn.Conv2d(s, opt.teacher_ngf * 4, 1, 1, 0, bias=False).to(dev) for _ in range(4)]
+                for t in lst:
+                    gdist.broadcast_module(t)      # default-initialised from each rank's RNG: replicas must start equal
         masked = bool(opt.darts_discriminator)
         if masked:
             self.loss_names += ['D_arch_diff_A', 'D_arch_A', 'D_arch_diff_B', 'D_arch_B', 'teacher_netD_A_arch_diff',
@@ -205,6 +207,7 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
     # ---------------------------------------------------------------------------------------
     def set_input(self, input):
         self.input = input
+        self._note_input(input)
         AtoB = self.opt.direction == 'AtoB'
         self.real_A = input['A' if AtoB else 'B'].to(self.device, torch.float32).contiguous()
         self.real_B = input['B' if AtoB else 'A'].to(self.device, torch.float32).contiguous()

@@ -286,6 +286,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
                 g_l1 += [opt.lambda_scale if (opt.lambda_scale > 0.0 and not opt.lambda_weight > 0.0) else 0.0, 0.0]
         for t in self.transform_convs:
             t.to(dev)
+            gdist.broadcast_module(t)              # default-initialised from each rank's RNG: replicas must start equal
             g_params.append(t.weight)
             g_l1.append(0.0)
         self.optimizer_G = HipAdam(g_params, lr=opt.lr, betas=(0.5, 0.999), l1=g_l1)
@@ -360,6 +361,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
     # ---------------------------------------------------------------------------------------
     def set_input(self, input):
         self.input = input
+        self._note_input(input)
         AtoB = self.opt.direction == 'AtoB'
         self.real_A = input['A' if AtoB else 'B'].to(self.device, torch.float32).contiguous()
         self.real_B = input['B' if AtoB else 'A'].to(self.device, torch.float32).contiguous()

@@ -165,6 +165,8 @@ class SAGANModel(TeacherStreamMixin, nn.Module):
             t_w = [opt.teacher_ngf * 4, opt.teacher_ngf]
             s_w = [opt.ngf * 4, opt.ngf] if filter_cfgs is None else [filter_cfgs[1], filter_cfgs[3]]
             self.transform_convs = [nn.Conv2d(s, t, 1, 1, 0, bias=False).to(dev) for s, t in zip(s_w, t_w)]
+            for t in self.transform_convs:
+                gdist.broadcast_module(t)          # default-initialised from each rank's RNG: replicas must start equal
         if masked:
             self.loss_names += ['D_arch_diff', 'D_arch', 'teacher_D_arch_diff']
             self.netD = MaskDiscriminator(ndf=opt.ndf)            # H6: --threshold is not forwarded
@@ -237,6 +239,7 @@ class SAGANModel(TeacherStreamMixin, nn.Module):
     # ---------------------------------------------------------------------------------------
     def set_input(self, input):
         self.input = input
+        self._note_input(input)
         self.z = input['z'].to(self.device, torch.float32).contiguous()
         self.real_img = input['real_img'].to(self.device, torch.float32).contiguous()
         self.image_paths = [input.get('img_path'), input.get('img_path')]

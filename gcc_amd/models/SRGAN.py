@@ -190,6 +190,8 @@ class SRGAN(TeacherStreamMixin, nn.Module):
         self.transform_convs = []
         if self.distill:
             self.transform_convs = [nn.Conv2d(opt.ngf, opt.teacher_ngf, 1, 1, 0, bias=False).to(dev) for _ in range(4)]
+            for t in self.transform_convs:
+                gdist.broadcast_module(t)          # default-initialised from each rank's RNG: replicas must start equal
         if masked:
             self.loss_names += ['D_arch_diff', 'D_arch', 'teacher_D_arch_diff']
             self.netD = MaskDiscriminator(n_channels=opt.ndf, threshold=opt.threshold)
@@ -292,6 +294,7 @@ class SRGAN(TeacherStreamMixin, nn.Module):
 
     def set_input(self, input):
         self.input = input
+        self._note_input(input)
         self.real_lr = input['lr'].to(self.device, torch.float32).contiguous()
         self._real_hr_nchw = input['hr'].to(self.device, torch.float32).contiguous()
         self.image_paths = [input.get('lr_names'), input.get('hr_names')]
@@ -608,6 +611,19 @@ class SRGAN(TeacherStreamMixin, nn.Module):
                                ops.stream()), 'gcc_psnr_y_sse')
         mse = float(sse.item()) / (N * (H - 8) * (W - 8))
         return 10.0 * math.log10(255.0 ** 2 / mse) if mse > 0 else float('inf')
+
+    def get_current_ssim(self):
+        """models/SRGAN.py:659-661: skimage's structural_similarity(real_y, fake_y, data_range=255.) on the same cropped
+        luminance images (7 x 7 uniform window, sample covariance, K1 .01 / K2 .03, 3-pixel border of the SSIM map dropped);
+        skimage is un-pinned and absent from the build image: restated from its published definition, parity unpinned"""
+        fake, real = self.fake_hr.float().contiguous(), self.real_hr.float().contiguous()
+        N, _, H, W = fake.shape
+        L = ops.lib()
+        acc = torch.zeros(1, dtype=torch.float64, device=fake.device)
+        ws = torch.empty(L.gcc_psnr_workspace(), dtype=torch.uint8, device=fake.device)
+        check(L.gcc_ssim_y_sum(fake.data_ptr(), real.data_ptr(), N, H, W, acc.data_ptr(), 0, ws.data_ptr(), ws.numel(),
+                               ops.stream()), 'gcc_ssim_y_sum')
+        return float(acc.item()) / (N * (H - 14) * (W - 14))
 
     def init_distillation(self):
         if self.distill:

@@ -25,12 +25,38 @@ class TeacherStreamMixin:
         self._teacher_free = torch.cuda.Event()
         self._teacher_free.record(torch.cuda.current_stream())
 
+    def _note_input(self, input):
+        """set_input(): order this stream -- and, through _release_teacher_stream, the teacher's -- behind whatever produced
+        a device-resident batch.  A batch dict may carry 'ready' (a torch.cuda.Event recorded by its producer after the last
+        kernel that wrote its tensors: gcc_amd.data's loaders and bench.py set it); without one, device tensors are assumed
+        to have been produced on the stream set_input is called on, and an event recorded here stands for them (the
+        teacher then also waits for everything else already enqueued on this stream).  Host tensors need nothing: the
+        H2D copy is issued on the consuming stream itself.  The tensors are marked as used on this stream so that the
+        caching allocator does not hand their memory to the producer's stream while the copies below are still pending."""
+        ev = input.get('ready') if hasattr(input, 'get') else None
+        dev = [v for v in input.values() if torch.is_tensor(v) and v.is_cuda] if hasattr(input, 'values') else []
+        if dev:
+            cur = torch.cuda.current_stream()
+            if ev is not None:
+                cur.wait_event(ev)
+            else:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+            for t in dev:
+                t.record_stream(cur)
+        self._input_ready = ev if dev else None
+
     def _release_teacher_stream(self, ts):
         ev = getattr(self, '_teacher_free', None)
         if ev is not None:
             ts.wait_event(ev)
         else:
             ts.wait_stream(torch.cuda.current_stream())
+        # the batch the teacher is about to read (set_input on its own stream) must exist: ADVICE r1, race on a
+        # device-resident batch written by main-stream kernels after _teacher_free was recorded
+        ready = getattr(self, '_input_ready', None)
+        if ready is not None:
+            ts.wait_event(ready)
 
     def _run_teacher(self, fn):
         """run fn() (teacher work) on the teacher's stream if there is one; returns the stream (or False)"""

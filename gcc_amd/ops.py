@@ -28,6 +28,8 @@ class _Profile:
         """steps: stop bracketing launches after this many step_done() calls (keeps the event
         overhead -- about 6% when every launch of a step is bracketed -- out of most of the timed region)"""
         self.records = []
+        self.spans = []
+        self.tag = None
         self.active = True
         self.steps_left = steps
         self.steps_seen = 0
@@ -48,14 +50,25 @@ class _Profile:
     def end(self, kind, flops, e0, shape=None):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.records.append((kind, flops, e0, e1, shape))
+        self.records.append((kind, flops, e0, e1, shape, self.tag))
+
+    def span(self, name):
+        """context manager: wall duration of a whole engine pass (every kernel in it, MFMA or not) under `name`; conv
+        launches inside are attributed to `name` too (PROFILE.tag)"""
+        return _Span(self, name)
 
     def stop(self, peak=2.5e15):
         self.active = False
         torch.cuda.synchronize()
         agg, shapes = {}, {}
-        for kind, flops, e0, e1, shape in self.records:
+        tags = {}
+        for kind, flops, e0, e1, shape, tag in self.records:
             sec = e0.elapsed_time(e1) * 1e-3
+            if tag is not None:
+                t = tags.setdefault(tag, [0.0, 0.0, 0])
+                t[0] += flops
+                t[1] += sec
+                t[2] += 1
             a = agg.setdefault(kind, [0.0, 0.0, 0])
             a[0] += flops
             a[1] += sec
@@ -65,6 +78,12 @@ class _Profile:
             b[1] += sec
             b[2] += 1
         self.records = []
+        self.tag_stats = {k: {'flop': v[0], 'conv_s': v[1], 'conv_launches': v[2]} for k, v in tags.items()}
+        for name, e0, e1 in getattr(self, 'spans', []):
+            t = self.tag_stats.setdefault(name, {'flop': 0.0, 'conv_s': 0.0, 'conv_launches': 0})
+            t['span_s'] = t.get('span_s', 0.0) + e0.elapsed_time(e1) * 1e-3
+            t['spans'] = t.get('spans', 0) + 1
+        self.spans = []
         if os.environ.get('GCC_PROFILE_SHAPES') == '1':      # per-geometry table on stderr (tuning aid)
             import sys
             for (kind, shape), (fl, sec, n) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:40]:
@@ -86,6 +105,27 @@ class _Profile:
                        'algorithmic_gflop_per_launch': round(fl / n / 1e9, 3)}
         out['per_kernel'] = per
         return out
+
+
+class _Span:
+    def __init__(self, prof, name):
+        self.prof, self.name = prof, name
+
+    def __enter__(self):
+        if self.prof.active:
+            self.prev = self.prof.tag
+            self.prof.tag = self.name
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if getattr(self, 'e0', None) is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.prof.spans.append((self.name, self.e0, e1))
+            self.prof.tag = self.prev
+        return False
 
 
 PROFILE = _Profile()

@@ -4,11 +4,12 @@
         --online_distillation --darts_discriminator --lambda_content 50 --lambda_gram 1e4 ...
     (data parallel: python -m torch.distributed.run --nproc-per-node 8 -m gcc_amd.train ...)
 
-Data loading is outside the accelerated path: if the reference's own
-``data`` package is importable (run from a checkout of it) its loaders are used unchanged --
-they only have to yield the batch dict {'A','B','A_paths','B_paths'}; otherwise
-``--dataroot synthetic[:N]`` yields seeded U[-1,1) pairs of that shape.  Evaluation (FID / mIoU,
-reference metric/) needs third-party weights and stays with the reference's test.py.
+Batches come from gcc_amd.data (host decode + the GPU transform chain of SURVEY.md 8(f).4) or, with
+``--dataroot synthetic[:N]``, from seeded U[-1,1) pairs of the same shape.  Any iterable of the reference's
+batch dicts ({'A','B','A_paths','B_paths'} ...) can be passed to main(datasets=...) instead.
+The per-epoch evaluation of the reference's loop (train.py:14-73, 160-165) needs third-party evaluator networks
+(Inception / DRN weights): main(evaluate=fn) takes the callable that produces the metric(s) -- gcc_amd.metric supplies
+the arithmetic downstream of those networks -- and keeps the reference's best-checkpoint bookkeeping around it.
 """
 import copy
 import os
@@ -49,13 +50,10 @@ def make_datasets(opt):
         n = int(root.split(':')[1]) if ':' in root else 8
         r = gdist.rank()
         return SyntheticPairs(opt, n, 1234 + r), SyntheticPairs(opt, n, 4321 + r)
-    if os.environ.get('GCC_HOST_DATALOADER') != '1':
-        # host decode + GPU transforms (gcc_amd.data); two loaders over the same phase, as create_split_dataset builds
-        # them (data/__init__.py:59-66)
-        from .data import create_dataset
-        return create_dataset(opt), create_dataset(opt)
-    from data import create_split_dataset      # the reference's loaders (data/__init__.py:52-58)
-    return create_split_dataset(opt)
+    # host decode + GPU transforms (gcc_amd.data); two loaders over the same phase, as create_split_dataset builds
+    # them (data/__init__.py:59-66)
+    from .data import create_dataset
+    return create_dataset(opt), create_dataset(opt)
 
 
 def attach_teacher(model, opt, model_class):
@@ -74,7 +72,42 @@ def attach_teacher(model, opt, model_class):
     return teacher
 
 
-def main(argv=None):
+class BestRecord:
+    """utils/best_information.py:1-33 -- best value and epoch per metric slot.  Larger is better for the SRGAN scores and the
+    cityscapes mIoU, smaller for every FID; ties count as an improvement (the reference compares with <= / >=)."""
+
+    def __init__(self, opt):
+        self.higher = opt.model == 'srgan' or 'cityscapes' in str(opt.dataroot)
+        self.value, self.epoch = {}, {}
+
+    def update(self, metric, epoch, index=0):
+        best = self.value.get(index, 0.0 if self.higher else float('inf'))
+        if (best <= metric) if self.higher else (best >= metric):
+            self.value[index], self.epoch[index] = metric, epoch
+            return True
+        return False
+
+    def report(self, logger, last):
+        last = list(last) if isinstance(last, (list, tuple)) else [last]
+        logger.info(' | '.join('slot %d: best epoch %d %.2f / last %.2f' % (i, self.epoch.get(i, 0), self.value.get(i, float('nan')), v)
+                               for i, v in enumerate(last)))
+
+
+def run_evaluation(model, opt, logger, epoch, best, evaluate, ckpt_dir):
+    """train.py:14-73: evaluate(model, opt) returns [(metric value, direction tag), ...] in the reference's slot order
+    (pix2pix: one mIoU or FID tagged opt.direction; cyclegan: AtoB, BtoA FIDs; sagan: one FID; srgan: 4 PSNR then 4 SSIM
+    tagged with the test-set names); a new best in a slot saves model_best_<tag>.pth on rank 0."""
+    model.model_eval()
+    scores = evaluate(model, copy.deepcopy(opt))
+    model.model_train()
+    for i, (value, tag) in enumerate(scores):
+        logger.info('evaluation slot %d (%s): %.2f' % (i, tag, value))
+        if best.update(value, epoch, index=i):
+            model.save_models(epoch, ckpt_dir, fid=value, isbest=True, direction=tag)
+    return [v for v, _ in scores]
+
+
+def main(argv=None, datasets=None, evaluate=None):
     gdist.init_from_env()
     opt = options.parse(argv)
     opt.isTrain = True
@@ -90,9 +123,10 @@ def main(argv=None):
         attach_teacher(model, opt, model_class)
     if opt.initial_path is not None:
         model.load_models(opt.initial_path, load_discriminator=False)
-    train_set, val_set = make_datasets(opt)
+    train_set, val_set = datasets if datasets is not None else make_datasets(opt)
     logger.info('The number of training images = %d' % len(train_set))
     total_iters = 0
+    best, last_scores = BestRecord(opt), None
     for epoch in range(opt.epoch_count, opt.n_epochs + opt.n_epochs_decay + 1):
         model.model_train()
         logger.info('\nEpoch:%d' % epoch)
@@ -113,12 +147,19 @@ def main(argv=None):
                 losses = model.get_current_losses()
                 msg = '(epoch: %d, iters: %d, time: %.3f) ' % (epoch, epoch_iter, (time.time() - t0) / opt.batch_size)
                 logger.info(msg + ' '.join('%s: %.3f' % kv for kv in losses.items()))
-        if epoch % opt.save_epoch_freq == 0 and epoch == opt.n_epochs + opt.n_epochs_decay:
-            model.save_models(epoch, os.path.join(exp, 'checkpoints'))
+        if epoch % opt.save_epoch_freq == 0:            # train.py:160-165
+            if evaluate is not None:
+                last_scores = run_evaluation(model, opt, logger, epoch, best, evaluate, os.path.join(exp, 'checkpoints'))
+            logger.info('saving the model at the end of epoch %d, iters %d' % (epoch, total_iters))
+            if epoch == opt.n_epochs + opt.n_epochs_decay:
+                model.save_models(epoch, os.path.join(exp, 'checkpoints'))
         model.print_sparse_info(logger)
         logger.info('End of epoch %d / %d \t Time Taken: %d sec' % (epoch, opt.n_epochs + opt.n_epochs_decay,
                                                                     time.time() - t_epoch))
         model.update_learning_rate(epoch)
+    if last_scores is not None:
+        best.report(logger, last_scores)
+    return model
 
 
 if __name__ == '__main__':

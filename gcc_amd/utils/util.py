@@ -62,67 +62,21 @@ def get_scheduler(optimizer, opt):
     raise NotImplementedError('learning rate policy [%s] is not implemented' % opt.lr_policy)
 
 
-def tensor2imgs(image_tensor, imtype=None, normalize=True, tile=False):
-    """utils/util.py:45-76: [-1, 1] (or [0, 1]) image tensors -> uint8 HWC numpy images (a 4-D batch gives [N, H, W, C]).
-    The value path of the evaluators: clip((x + 1) / 2 * 255) truncated to uint8."""
+def tensor2imgs(image_tensor, imtype=None, normalize=True):
+    """The evaluators' value path (reference utils/util.py:45-76): float image tensor(s) -> uint8 images, channels last;
+    a 4-D batch gives [N, H, W, C], a list gives a list.  normalize: [-1, 1] input, (x + 1) / 2 * 255 in fp32, clipped
+    to [0, 255] and truncated; otherwise [0, 1] input scaled by 255."""
     import numpy as np
-    imtype = np.uint8 if imtype is None else imtype
-    if isinstance(image_tensor, list):
+    if isinstance(image_tensor, (list, tuple)):
         return [tensor2imgs(t, imtype, normalize) for t in image_tensor]
-    if tile:
-        raise NotImplementedError('tiled visualisation is outside the evaluation path')
-    if image_tensor.dim() == 4:
-        return np.concatenate([tensor2imgs(t)[None] for t in image_tensor], axis=0)
-    if image_tensor.dim() == 2:
-        image_tensor = image_tensor.unsqueeze(0)
-    image_numpy = image_tensor.detach().cpu().float().numpy()
-    if normalize:
-        image_numpy = (np.transpose(image_numpy, (1, 2, 0)) + 1) / 2.0 * 255.0
-    else:
-        image_numpy = np.transpose(image_numpy, (1, 2, 0)) * 255.0
-    image_numpy = np.clip(image_numpy, 0, 255)
-    if image_numpy.shape[2] == 1:
-        image_numpy = image_numpy[:, :, 0]
-    return image_numpy.astype(imtype)
-
-
-def tensor2im(input_image, imtype=None):
-    """utils/util.py:78-95: first image of an NCHW tensor in [-1, 1] -> HWC array, (x + 1) / 2 * 255 truncated to uint8
-    (no clipping, as there)"""
-    import numpy as np
-    import torch
-    imtype = np.uint8 if imtype is None else imtype
-    if isinstance(input_image, np.ndarray):
-        return input_image.astype(imtype)
-    if not isinstance(input_image, torch.Tensor):
-        return input_image
-    image_numpy = input_image.data[0].cpu().float().numpy()
-    return ((np.transpose(image_numpy, (1, 2, 0)) + 1) / 2.0 * 255.0).astype(imtype)
-
-
-def save_image(image_numpy, image_path, aspect_ratio=1.0):
-    """utils/util.py:153-168"""
-    from PIL import Image
-    image_pil = Image.fromarray(image_numpy)
-    h, w, _ = image_numpy.shape
-    if aspect_ratio > 1.0:
-        image_pil = image_pil.resize((h, int(w * aspect_ratio)), Image.BICUBIC)
-    if aspect_ratio < 1.0:
-        image_pil = image_pil.resize((int(h / aspect_ratio), w), Image.BICUBIC)
-    image_pil.save(image_path)
-
-
-def save_images(visuals, img_path, save_image_dir, direction='AtoB', aspect_ratio=1.0, width=256):
-    """utils/util.py:208-235: the input image under its partner's name, every generated image under <label>/"""
-    imageA_path = img_path[0][0] if direction == 'AtoB' else img_path[1][0]
-    imageB_path = img_path[1][0] if direction == 'AtoB' else img_path[0][0]
-    imageA_name = (imageA_path.split('/')[-1].split('\\\\')[-1]).split('.')[0]
-    imageB_name = (imageB_path.split('/')[-1].split('\\\\')[-1]).split('.')[0]
-    for label, im_data in visuals.items():
-        if label == 'real_A' or label == 'real_img':
-            save_image(tensor2im(im_data), os.path.join(save_image_dir, imageB_name + '.png'), aspect_ratio)
-        if label in ('fake_B', 'fake_A', 'fake_hr', 'fake_img'):
-            image_name = '%s_%s.png' % (imageB_name if label == 'fake_A' else imageA_name, label)
-            save_path = os.path.join(save_image_dir, label)
-            mkdirs(save_path)
-            save_image(tensor2im(im_data), os.path.join(save_path, image_name), aspect_ratio=aspect_ratio)
+    x = image_tensor.detach().float().cpu()
+    if x.dim() == 2:
+        x = x[None]
+    batched = x.dim() == 4
+    if not batched:
+        x = x[None]
+    x = ((x + 1.0) / 2.0 * 255.0) if normalize else (x * 255.0)
+    out = x.clamp(0.0, 255.0).permute(0, 2, 3, 1).numpy().astype(np.uint8 if imtype is None else imtype)
+    if out.shape[-1] == 1:
+        out = out[..., 0]
+    return out if batched else out[0]

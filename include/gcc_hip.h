@@ -5,7 +5,9 @@
  * models/Pix2Pix.py.  Each entry point below names the reference call site(s) whose ATen operator
  * it replaces (paths relative to the reference root).  Conventions:
  *   - plain C, no torch types; every pointer is a DEVICE pointer owned by the caller (activations,
- *     weights, workspaces); the library allocates nothing and keeps no global state;
+ *     weights, workspaces); the library allocates nothing.  Its only process-wide state is the table of
+ *     tuning options below (gcc_set_option / gcc_conv_set_plan: atomics, defaults read once from GCC_*
+ *     environment variables) and the one-time hipFuncSetAttribute of the kernels that use > 64 KB of LDS;
  *   - every kernel is enqueued on the caller's `stream` and never synchronises;
  *   - return value: 0 = GCC_OK, negative = error (see gcc_strerror); no exceptions, no abort;
  *   - activations are NHWC bf16 (a PyTorch channels_last tensor): element (n,h,w,c) lives at
@@ -40,6 +42,37 @@ enum { GCC_ACT_NONE = 0, GCC_ACT_LRELU = 1, GCC_ACT_RELU = 2, GCC_ACT_TANH = 3 }
 
 const char* gcc_strerror(int code);
 int gcc_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tuning options: which tile shape / kernel family a geometry is routed to.  Every option only selects
+ * between kernels that compute the same result (the parity tests run each conv case under every plan).
+ * Defaults come from the environment variable of the same name (GCC_<NAME>) when it is set at first use.
+ * gcc_set_option(id, value): value < 0 restores the default; returns the previous value (>= 0) or
+ * GCC_ERR_BAD_ARG.  Options are process-wide atomics: set them before launching, not concurrently with
+ * launches whose workspace was sized under another plan (gcc_conv_workspace / gcc_conv_stat_tiles depend
+ * on the plan).
+ * ------------------------------------------------------------------------------------------- */
+enum {
+    GCC_OPT_IGEMM_BIG = 0,      /* 0: 128-pixel tiles only; 1: + 256x128; 2 (default): + 256x256 */
+    GCC_OPT_IGEMM_BIG_MIN,      /* minimum number of 256-pixel tiles of a launch (default 200) */
+    GCC_OPT_IGEMM_BIG_NK,       /* minimum K depth in 64-steps for 256-pixel tiles (default 24) */
+    GCC_OPT_IGEMM_GLDS,         /* 1 (default): LDS-DMA staging; 0: register-staged 128-pixel tiles */
+    GCC_OPT_IGEMM_HEAD,         /* 1 (default): single-output-channel head route */
+    GCC_OPT_IGEMM_THIN,         /* 1 (default): thin image-layer kernels */
+    GCC_OPT_WGRAD_BIG,          /* 1 (default): 256x256 weight-gradient tiles on the large layers */
+    GCC_OPT_BN_SWEEPS,          /* 0 (default): per-kernel choice of sweeps per streaming workgroup */
+    GCC_OPT_BN_MAXBLK,          /* cap on streaming workgroups (default 2048) */
+    GCC_OPT_BN_REDUCE_THREADS,  /* 256 (default) or 1024 threads per BatchNorm-backward reduce workgroup */
+    GCC_OPT_BN_REDUCE_CAP,      /* cap on those workgroups (default 1024) */
+    GCC_OPT_INORM_LPP,          /* 0 (default): automatic lanes per pixel of the one-launch InstanceNorm */
+    GCC_OPT_COUNT_
+};
+int gcc_set_option(int id, int value);
+int gcc_get_option(int id);
+/* the fprop / dgrad tile plan in one call (each argument < 0: restore that default).  Tests select
+ * {big=0}, {big=1, big_min=1, big_nk=1} and {big=2, big_min=1, big_nk=1} to run every geometry on the
+ * 128xBC, 256x128 and 256x256 tiles. */
+int gcc_conv_set_plan(int big, int big_min, int big_nk);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution geometry.  One descriptor serves Conv2d and ConvTranspose2d: a ConvTranspose2d
@@ -80,6 +113,9 @@ int gcc_conv_stat_tiles(const gcc_conv_t* c, int dgrad);
 /* kernel family a fprop / dgrad call runs on: 0 igemm_kernel, 1 the thin image-layer kernels (<= 8 channels on the
  * image side), 2 the single-output-channel head route; < 0 for an invalid geometry.  Introspection for profilers. */
 int gcc_conv_route(const gcc_conv_t* c, int dgrad, const gcc_epilogue_t* ep);
+/* tile the current plan picks for a geometry on the igemm_kernel route: BP * 1000 + BC (e.g. 256256 = 256 pixels x
+ * 256 channels); 0 for an invalid geometry.  Introspection for tests and profilers. */
+int gcc_conv_tile(const gcc_conv_t* c, int dgrad);
 
 /* y = conv(x, W) (+bias, act).  Replaces aten::convolution at models/Pix2Pix.py:31-32, 280-300,
  * 320-343, 407-409 (F.conv2d / nn.Conv2d.forward).  x: [N,H,W,ldx]  w: W packing  y: [N,Ho,Wo,ldy] */
@@ -380,6 +416,10 @@ int gcc_clamp_f32(float* p, float lo, float hi, size_t n, gcc_stream_t stream);
  * gcc_psnr_y_sse: sum of squared luminance differences of two NCHW fp32 images in [-1, 1] with the 4-pixel border
  *   cropped (models/SRGAN.py:653-657: convert_image(..., 'y-channel'), data/sr_dataset.py:36-37, 58-62); PSNR =
  *   10 log10(255^2 N (H-8)(W-8) / sse).  f64 accumulation in a fixed order.
+ * gcc_ssim_y_sum: sum over the N images and over all window centres of the SSIM map of the same luminance images
+ *   (models/SRGAN.py:659-661, skimage.metrics.structural_similarity(real_y, fake_y, data_range=255.) with its defaults: 7 x 7
+ *   uniform window, K1 = .01, K2 = .03, sample covariance, border of 3 cropped); SSIM = sum / (N (H-14)(W-14)).  f64.
+ *   Workspace as gcc_psnr_workspace().  (skimage is an un-pinned dependency that the build image lacks: parity unpinned.)
  * gcc_activation_stats: mu = mean(act, 0), sigma = np.cov(act, rowvar=False) in f64 (metric/fid_score.py:327-328) of
  *   activations [n][d] (fp32 or f64, row major).
  * gcc_frechet_distance: metric/fid_score.py:219-284; out[0] = |mu1-mu2|^2 + tr(s1) + tr(s2) - 2 tr(sqrtm(s1 s2)) with
@@ -391,6 +431,8 @@ int gcc_argmax_channels(const float* scores, int N, int C, size_t HW, int* pred,
 int gcc_confusion_hist(const int* pred, const int* label, size_t count, int n, long long* hist, gcc_stream_t stream);
 size_t gcc_psnr_workspace(void);
 int gcc_psnr_y_sse(const float* fake, const float* real, int N, int H, int W, double* sse, int accumulate, void* ws,
+                   size_t ws_bytes, gcc_stream_t stream);
+int gcc_ssim_y_sum(const float* fake, const float* real, int N, int H, int W, double* ssim_sum, int accumulate, void* ws,
                    size_t ws_bytes, gcc_stream_t stream);
 size_t gcc_activation_stats_workspace(int n, int d);
 int gcc_activation_stats(const void* act, int is_f64, int n, int d, double* mu, double* sigma, void* ws, size_t ws_bytes,

@@ -4,7 +4,9 @@ and bench.py's cpu_baseline leg may import this; the product path never does).
 Pinned against the reference's own functions run in the build container (tests/golden/make_fixtures.py::fixture_metric
 -> tests/golden/metric.npz): calculate_frechet_distance (scipy.linalg.sqrtm), fast_hist, per_class_iu, convert_image.
 skimage is absent from the image: peak_signal_noise_ratio is restated from its published definition,
-10 log10(data_range^2 / mean((a - b)^2)) in float64."""
+10 log10(data_range^2 / mean((a - b)^2)) in float64, and structural_similarity from the definition its documentation gives
+(Wang et al. 2004 with a uniform 7 x 7 window, sample covariance, K1 = 0.01, K2 = 0.03, the mean taken over the SSIM map
+with a border of (7 - 1) / 2 pixels cropped): PARITY UNPINNED for these two formulas (no skimage here to check against)."""
 import numpy as np
 from scipy import linalg
 
@@ -47,6 +49,23 @@ def y_channel(img):
     x = np.float32(255.) * np.transpose(x, (0, 2, 3, 1))[:, 4:-4, 4:-4, :]
     w = np.array([65.481, 128.553, 24.966], dtype=np.float32)
     return (x @ w) / np.float32(255.) + np.float32(16.)
+
+
+def ssim_y(fake, real, data_range=255.):
+    """models/SRGAN.py:659-661 with skimage.metrics.structural_similarity(real_y, fake_y, data_range=255.) restated
+    (defaults: win_size 7, uniform filter, use_sample_covariance, K1 .01, K2 .03); mean over the batch"""
+    from scipy.ndimage import uniform_filter
+    X, Y = y_channel(real).astype(np.float64), y_channel(fake).astype(np.float64)
+    out = []
+    for x, y in zip(X, Y):
+        ux, uy = uniform_filter(x, 7), uniform_filter(y, 7)
+        uxx, uyy, uxy = uniform_filter(x * x, 7), uniform_filter(y * y, 7), uniform_filter(x * y, 7)
+        cn = 49. / 48.
+        vx, vy, vxy = cn * (uxx - ux * ux), cn * (uyy - uy * uy), cn * (uxy - ux * uy)
+        C1, C2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+        S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+        out.append(S[3:-3, 3:-3].mean())
+    return float(np.mean(out))
 
 
 def psnr_y(fake, real):

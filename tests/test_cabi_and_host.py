@@ -63,6 +63,36 @@ def test_conv_route_predicates():
     assert lib.gcc_conv_route(ctypes.byref(bad), 0, ctypes.byref(none)) < 0
 
 
+def test_tile_plan_options_are_host_state_only():
+    """gcc_conv_set_plan / gcc_set_option: the tile plan is explicit, per-call selectable host state (no cached getenv);
+    the headline shapes land on the 256-pixel tiles under the default plan"""
+    from gcc_amd import _lib
+    lib = _lib.load()
+    conv = lambda N, H, W, Ci, Co, k, s, p: _lib.conv_t(N, H, W, Ci, Co, k, k, s, p, (Ci + 7) // 8 * 8, 0, (Co + 7) // 8 * 8, 0)
+    lib.gcc_conv_set_plan(-1, -1, -1)
+    assert [lib.gcc_get_option(i) for i in range(3)] == [2, 200, 24] or os.environ.get('GCC_IGEMM_BIG') is not None
+    l2, l3, l4 = conv(16, 128, 128, 128, 256, 4, 2, 1), conv(16, 64, 64, 256, 512, 4, 2, 1), conv(16, 32, 32, 512, 1024, 4, 1, 1)
+    small = conv(2, 32, 32, 128, 256, 4, 2, 1)
+    try:
+        assert lib.gcc_conv_tile(ctypes.byref(l2), 0) == 256256
+        assert lib.gcc_conv_tile(ctypes.byref(l3), 0) == 256128 and lib.gcc_conv_tile(ctypes.byref(l3), 1) == 256256
+        assert lib.gcc_conv_tile(ctypes.byref(l4), 0) == 256256
+        assert lib.gcc_conv_tile(ctypes.byref(small), 0) == 128128
+        lib.gcc_conv_set_plan(2, 1, 1)
+        assert lib.gcc_conv_tile(ctypes.byref(small), 0) == 256256
+        lib.gcc_conv_set_plan(1, 1, 1)
+        assert lib.gcc_conv_tile(ctypes.byref(small), 0) == 256128 and lib.gcc_conv_tile(ctypes.byref(l2), 0) == 256128
+        lib.gcc_conv_set_plan(0, -1, -1)
+        assert lib.gcc_conv_tile(ctypes.byref(l4), 0) == 128128
+        prev = lib.gcc_set_option(_lib.OPT_WGRAD_BIG, 0)
+        assert prev == 1 and lib.gcc_get_option(_lib.OPT_WGRAD_BIG) == 0
+        assert lib.gcc_set_option(99, 1) < 0 and lib.gcc_get_option(-1) < 0
+    finally:
+        lib.gcc_conv_set_plan(-1, -1, -1)
+        lib.gcc_set_option(_lib.OPT_WGRAD_BIG, -1)
+    assert lib.gcc_conv_tile(ctypes.byref(small), 0) == 128128 and lib.gcc_get_option(_lib.OPT_WGRAD_BIG) == 1
+
+
 def test_struct_layouts_match_header():
     from gcc_amd import _lib
     assert ctypes.sizeof(_lib.conv_t) == 13 * 4

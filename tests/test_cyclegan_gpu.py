@@ -76,6 +76,10 @@ def test_cyclegan_two_iterations_vs_reference_golden(golden_dir):
     assert list(model.netD_A.state_dict().keys()) == [str(k) for k in z['D_keys']]
     assert list(teacher.netD_A.state_dict().keys()) == [str(k) for k in z['TD_keys']]
     assert opt.gan_mode == str(z['gan_mode']) and model.loss_names == [str(k) for k in z['loss_names']]
+    from tests import _updates
+    init = _updates.snapshot({'sG_A': model.netG_A, 'sG_B': model.netG_B, 'sD_A': model.netD_A, 'sD_B': model.netD_B,
+                              'tG_A': teacher.netG_A, 'tG_B': teacher.netG_B, 'tD_A': teacher.netD_A, 'tD_B': teacher.netD_B})
+    agree = _updates.MovementAgreement()
     for it in range(2):
         model.set_input(_data(z, 'it%d.A' % it, 'it%d.B' % it))
         model.optimize_parameters()
@@ -138,6 +142,10 @@ def test_cyclegan_two_iterations_vs_reference_golden(golden_dir):
                 tol = 2.2 * opt.lr * 2 + 1e-6
             err = float(np.abs(g - ref).max())
             assert err <= tol, (tag, name, err, tol)
+            if not (name.endswith('running_mean') or name.endswith('running_var')):
+                agree.add(tag[:2] + ('.alpha' if name.endswith('alpha') else ''), init[tag][name], g, ref.reshape(-1),
+                          (opt.arch_lr if name.endswith('alpha') else opt.lr) * 2)
+    agree.check()
 
 
 def test_cyclegan_gradients_vs_oracle(golden_dir):

@@ -47,6 +47,9 @@ def _worker(rank, world, port, q):
     for name, mod in (('sG', model.netG), ('sD', model.netD), ('tG', teacher.netG), ('tD', teacher.netD)):
         out[name] = torch.cat([v.detach().float().cpu().reshape(-1) for k, v in mod.state_dict().items()
                                if k.endswith('weight') or k.endswith('bias') or k.endswith('alpha')]).numpy()
+    # everything optimizer_G owns, the 1x1 distillation transform convs included (they live outside netG / netD)
+    out['flatG'] = model.optimizer_G.flat.values.detach().float().cpu().numpy()
+    out['T'] = torch.cat([t.weight.detach().float().cpu().reshape(-1) for t in model.transform_convs]).numpy()
     out['losses'] = dict(model.get_current_losses())
     q.put(out)
     dist.barrier()
@@ -68,7 +71,7 @@ def test_two_ranks_stay_identical():
     a, b = res
     import numpy as np
     assert np.array_equal(a['w0'], b['w0']), 'replicas did not start from the same weights'
-    for k in ('sG', 'sD', 'tG', 'tD'):
+    for k in ('sG', 'sD', 'tG', 'tD', 'T', 'flatG'):
         assert np.array_equal(a[k], b[k]), 'replicas diverged in %s: gradients were not exchanged identically' % k
         assert np.isfinite(a[k]).all()
     assert a['losses'] == b['losses']          # logged losses are rank-averaged

@@ -60,9 +60,9 @@ CONV_CASES = [
     (2, 4, 4, 512, 512, 4, 2, 1),      # U-Net bottleneck, K = 8192: split-K path (fprop and dgrad)
     (4, 12, 12, 1024, 1, 4, 1, 1),     # PatchGAN head, Cout = 1, K = 16384: split-K path
     (16, 2, 2, 256, 384, 4, 2, 1),     # split-K with an N tail (384 = 3 x 128)
-    (2, 32, 32, 128, 128, 4, 2, 1),    # 256x128 tile candidates (forced by GCC_IGEMM_BIG_MIN=1 in the second test pass)
+    (2, 32, 32, 128, 128, 4, 2, 1),    # 256x128 tile candidates (the tile256x128 / tile256x256 plans below force them)
     (2, 16, 16, 256, 384, 4, 1, 1),    # 256-pixel tiles with M and N tails, fprop and dgrad
-    (3, 20, 20, 128, 512, 4, 2, 1),    # 256x256 tiles (GCC_IGEMM_BIG=2), ragged M
+    (3, 20, 20, 128, 512, 4, 2, 1),    # 256x256 tiles, ragged M
     (2, 22, 22, 3, 16, 7, 1, 0),       # MobileResnet stem: 7x7 on the reflect-padded image
     (2, 22, 22, 16, 3, 7, 1, 0),       # MobileResnet head: 7x7 to 3 channels
     (2, 16, 16, 16, 32, 3, 2, 1),      # MobileResnet down conv k3 s2; its dgrad is ConvTranspose(k3,s2,p1,output_padding=1)
@@ -76,10 +76,39 @@ CONV_CASES = [
 ]
 
 
+# fprop / dgrad tile plans (include/gcc_hip.h gcc_conv_set_plan): every geometry runs on every tile family it can be
+# routed to -- the default plan picks the 256-pixel tiles only for chip-filling grids, which small test cases never are
+PLANS = {'default': (-1, -1, -1), 'tile128': (0, -1, -1), 'tile256x128': (1, 1, 1), 'tile256x256': (2, 1, 1)}
+
+
+def _tiles(case):
+    import ctypes as C
+    from gcc_amd import _lib
+    N, H, W, Ci, Co, k, s, p = case
+    d = _lib.conv_t(N, H, W, Ci, Co, k, k, s, p, (Ci + 7) & ~7, 0, (Co + 7) & ~7, 0)
+    return (_lib.load().gcc_conv_tile(C.byref(d), 0), _lib.load().gcc_conv_tile(C.byref(d), 1))
+
+
+@pytest.fixture
+def conv_plan(request):
+    from gcc_amd import _lib
+    lib = _lib.load()
+    lib.gcc_conv_set_plan(-1, -1, -1)
+    yield lambda name: lib.gcc_conv_set_plan(*PLANS[name])
+    lib.gcc_conv_set_plan(-1, -1, -1)
+
+
+@pytest.mark.parametrize('plan', list(PLANS))
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv_fprop_dgrad_wgrad(case):
+def test_conv_fprop_dgrad_wgrad(case, plan, conv_plan):
     ops = _ops()
     N, H, W, Ci, Co, k, s, p = case
+    base_tiles = _tiles(case)
+    conv_plan(plan)
+    tiles = _tiles(case)
+    if plan != 'default' and tiles == base_tiles:
+        pytest.skip('plan %s routes this geometry to the default tiles %s' % (plan, tiles))
+    print('plan %s: fprop tile %d, dgrad tile %d' % (plan, tiles[0], tiles[1]))
     g = torch.Generator().manual_seed(hash(case) % 1000)
     x = rb(torch.randn(N, Ci, H, W, generator=g))
     w = rb(torch.randn(Co, Ci, k, k, generator=g) * 0.1)
@@ -123,6 +152,54 @@ def test_conv_fprop_dgrad_wgrad(case):
     close(dw.cpu(), wr.grad, tol=5e-3, floor=1e-4, what='wgrad')
     ops.conv_wgrad(xd, dyd, dw, k, s, p, accumulate=True)
     close(dw.cpu(), 2 * wr.grad, tol=5e-3, floor=1e-4, what='wgrad accumulate')
+
+
+# True shapes of the headline configuration (BASELINE.json configs[1]: N = 16 per GPU, ndf 128, teacher ngf 64, 256 x 256) under
+# the DEFAULT plan: what bench.py actually launches (igemm 256x256 / 256x128 tiles, the 256x256 weight-gradient tiles).
+TRUE_SHAPES = {
+    # name: (N, H, W, Ci, Co, k, s, p)          reference layer
+    'patchgan_L2': (16, 128, 128, 128, 256, 4, 2, 1),     # models/Pix2Pix.py:287-300, n = 1
+    'patchgan_L3': (16, 64, 64, 256, 512, 4, 2, 1),       # n = 2
+    'patchgan_L4': (16, 32, 32, 512, 1024, 4, 1, 1),      # stride-1 layer -> 31 x 31
+    'teacherG_d2': (16, 64, 64, 128, 256, 4, 2, 1),       # U-Net ngf 64 down conv at depth 2 (models/Pix2Pix.py:31-32)
+    'teacherG_u2': (16, 64, 64, 128, 512, 4, 2, 1),       # ConvTranspose2d(512 -> 128) of depth 2 as its adjoint conv (:40-56)
+}
+
+
+@pytest.mark.parametrize('name', list(TRUE_SHAPES))
+def test_conv_true_shapes_default_plan(name):
+    ops = _ops()
+    from gcc_amd import _lib
+    _lib.load().gcc_conv_set_plan(-1, -1, -1)
+    case = TRUE_SHAPES[name]
+    N, H, W, Ci, Co, k, s, p = case
+    tiles = _tiles(case)
+    print('%s: fprop tile %d, dgrad tile %d' % (name, tiles[0], tiles[1]))
+    if name.startswith('patchgan'):
+        assert tiles[0] // 1000 == 256 and tiles[1] // 1000 == 256, 'the PatchGAN layers run on the 256-pixel tiles'
+    g = torch.Generator().manual_seed(len(name))
+    x = rb(torch.randn(N, Ci, H, W, generator=g))
+    w = rb(torch.randn(Co, Ci, k, k, generator=g) * 0.02)
+    with torch.no_grad():
+        y_ref = F.conv2d(x, w, None, stride=s, padding=p)
+        dy = rb(torch.randn(y_ref.shape, generator=g))
+        dx_ref = torch.nn.grad.conv2d_input(x.shape, w, dy, stride=s, padding=p)
+        dw_ref = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride=s, padding=p)
+    xd = to_dev(x)
+    m = master_cl(w)
+    wp, wtp = ops.pack_weights(m)
+    y, stats = ops.conv_fprop(xd, wp, Co, k, s, p, want_stats=True)
+    yg = to_cpu(y)
+    close(yg, y_ref, what=name + ' fprop')
+    st = stats.sum(0).cpu()
+    close(st[0], yg.sum((0, 2, 3)), tol=1e-3, floor=1e-2, what=name + ' stats sum')
+    close(st[1], (yg * yg).sum((0, 2, 3)), tol=1e-3, floor=1e-2, what=name + ' stats sumsq')
+    dyd = to_dev(dy)
+    dx = ops.conv_dgrad(dyd, wtp, Ci, H, W, k, s, p)
+    close(to_cpu(dx), dx_ref, what=name + ' dgrad')
+    dw = torch.zeros_like(m)
+    ops.conv_wgrad(xd, dyd, dw, k, s, p, accumulate=False)
+    close(dw.cpu(), dw_ref, tol=5e-3, floor=1e-4, what=name + ' wgrad')
 
 
 def test_conv_transpose_as_dgrad_with_stats_and_tanh():

@@ -101,3 +101,14 @@ def test_psnr_y_kernel(golden_dir):
     assert abs(sse.item() - 2 * ref_sse) <= 1e-5 * ref_sse
     psnr = 10 * np.log10(255. ** 2 / (sse.item() / 2 / (N * (H - 8) * (W - 8))))
     assert abs(psnr - M.psnr_y(z['psnr.fake'], z['psnr.real'])) < 1e-4
+    # SSIM on the same luminance images (skimage's definition restated in the oracle: unpinned, like PSNR)
+    acc = torch.zeros(1, dtype=torch.float64, device=dev)
+    check(L.gcc_ssim_y_sum(fake.data_ptr(), real.data_ptr(), N, H, W, acc.data_ptr(), 0, ws.data_ptr(), ws.numel(), ops.stream()),
+          'gcc_ssim_y_sum')
+    ssim = acc.item() / (N * (H - 14) * (W - 14))
+    ref = M.ssim_y(z['psnr.fake'], z['psnr.real'])
+    assert 0.0 < ref < 1.0 and abs(ssim - ref) < 1e-9, (ssim, ref)
+    same = torch.zeros(1, dtype=torch.float64, device=dev)
+    check(L.gcc_ssim_y_sum(real.data_ptr(), real.data_ptr(), N, H, W, same.data_ptr(), 0, ws.data_ptr(), ws.numel(), ops.stream()),
+          'gcc_ssim_y_sum')
+    assert abs(same.item() / (N * (H - 14) * (W - 14)) - 1.0) < 1e-12

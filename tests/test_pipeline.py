@@ -254,33 +254,38 @@ def test_sr_and_sa_pipelines_bit_exact():
 
 
 @pytest.mark.gpu
-def test_evaluation_loop_writes_images(tmp_path):
-    """python -m gcc_amd.test: checkpoint -> model (cfg from the file) -> val split -> PNGs where the reference puts them;
-    the saved fake image equals the model's eval output through the reference's tensor2im arithmetic"""
-    from PIL import Image
-    from gcc_amd import test as gtest
-    from gcc_amd.models import get_model_class
-    from gcc_amd.options import options
-    rng = np.random.RandomState(9)
-    d = tmp_path / 'data' / 'val'
-    d.mkdir(parents=True)
-    for i in range(2):
-        Image.fromarray((rng.rand(256, 512, 3) * 255).astype(np.uint8)).save(str(d / ('v%d.png' % i)))
-    base = ['--dataroot', str(tmp_path / 'data'), '--model', 'pix2pix', '--gpu_ids', '0', '--ngf', '8', '--ndf', '8',
-            '--checkpoints_dir', str(tmp_path / 'ckpt'), '--name', 'ev', '--direction', 'AtoB']
-    opt = options.parse(base)
-    opt.isTrain = True
-    src = get_model_class(opt)(opt)
-    src.save_models(3, str(tmp_path / 'ckpt' / 'ev' / 'checkpoints'), fid=1.0)
-    model = gtest.main(base + ['--pretrain_path', str(tmp_path / 'ckpt' / 'ev' / 'checkpoints' / 'model_3.pth')])
-    res = tmp_path / 'ckpt' / 'ev' / 'test_results'
-    assert sorted(os.listdir(str(res))) == ['fake_B', 'v0.png', 'v1.png']
-    assert sorted(os.listdir(str(res / 'fake_B'))) == ['v0_fake_B.png', 'v1_fake_B.png']
-    saved = np.array(Image.open(str(res / 'fake_B' / 'v1_fake_B.png')))
-    fake = model.fake_B[0].cpu().float().numpy()                      # the last image the loop processed
-    assert np.array_equal(saved, ((np.transpose(fake, (1, 2, 0)) + 1) / 2.0 * 255.0).astype(np.uint8))
-    real = np.array(Image.open(str(res / 'v1.png')))
-    assert real.shape == (256, 256, 3)
+def test_train_loop_evaluation_and_best_checkpoint(tmp_path):
+    """the per-epoch evaluation + best-checkpoint branch of the reference's loop (train.py:14-73, 160-165): the evaluator
+    networks are external, so the metric comes from a callable; a new best saves model_best_<direction>.pth with the
+    metric in the file, the last epoch saves model_<epoch>.pth, and the tensor2imgs value path feeds the evaluator"""
+    from gcc_amd import train
+    from gcc_amd.utils import util
+    seen = []
+
+    def evaluate(model, opt):
+        g = torch.Generator().manual_seed(5)
+        model.set_input({'A': torch.rand(1, 3, 64, 64, generator=g) * 2 - 1, 'B': torch.rand(1, 3, 64, 64, generator=g) * 2 - 1,
+                         'A_paths': ['a'], 'B_paths': ['b']})
+        assert not model.netG.training
+        model.forward()
+        imgs = util.tensor2imgs(model.fake_B)
+        assert imgs.shape == (1, 64, 64, 3) and imgs.dtype == np.uint8
+        fake = model.fake_B.cpu().numpy()
+        assert np.array_equal(imgs, np.clip((np.transpose(fake, (0, 2, 3, 1)) + 1) / 2.0 * 255.0, 0, 255).astype(np.uint8))
+        seen.append(len(seen))
+        return [([30.0, 20.0, 25.0][len(seen) - 1], opt.direction)]          # an FID: smaller is better
+    argv = ['--dataroot', 'synthetic:2', '--model', 'pix2pix', '--gpu_ids', '0', '--ngf', '8', '--ndf', '8', '--teacher_ngf', '16',
+            '--num_downs', '6', '--crop_size', '64', '--batch_size', '2', '--online_distillation', '--darts_discriminator',
+            '--n_epochs', '2', '--n_epochs_decay', '1', '--save_epoch_freq', '1', '--checkpoints_dir', str(tmp_path / 'ckpt'),
+            '--name', 'ev', '--print_freq', '2', '--direction', 'AtoB']
+    train.main(argv, evaluate=evaluate)
+    assert seen == [0, 1, 2]
+    ck = tmp_path / 'ckpt' / 'ev' / 'checkpoints'
+    assert sorted(os.listdir(str(ck))) == ['model_3.pth', 'model_best_AtoB.pth']
+    best = torch.load(str(ck / 'model_best_AtoB.pth'), map_location='cpu')
+    assert best['fid'] == 20.0 and best['epoch'] == 2
+    log = (tmp_path / 'ckpt' / 'ev' / 'logger.log').read_text()
+    assert 'best epoch 2 20.00 / last 25.00' in log and 'End of epoch 3' in log
 
 
 @pytest.mark.gpu

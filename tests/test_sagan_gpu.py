@@ -175,6 +175,9 @@ def test_sagan_two_iterations_vs_reference_golden(golden_dir):
     assert e.max() <= 2e-2 and e.mean() <= 3e-3
     model.netG.load_state_dict(sd0)
     model.model_train()
+    from tests import _updates
+    init = _updates.snapshot({'sG': model.netG, 'sD': model.netD, 'tG': teacher.netG, 'tD': teacher.netD})
+    agree = _updates.MovementAgreement()
     # the same two iterations on the oracle with bf16 storage emulated: the reference's arithmetic plus the rounding
     # points of the HIP path.  Behind sign-like Adam steps (beta1 = 0) the fp32 reference and any bf16 pipeline drift
     # apart (iteration 1: G_GAN 1.667 emulated vs 1.478 fp32), while the HIP path must stay on the emulated trajectory.
@@ -265,6 +268,12 @@ def test_sagan_two_iterations_vs_reference_golden(golden_dir):
                 tol = 2.2 * lr * sum(((1 - 0.9 ** t) / 0.1) ** 0.5 for t in range(1, n_upd + 1)) + 1e-6
             err = float(np.abs(g - ref).max())
             assert err <= tol, (tag, name, err, tol)
+            if name.endswith('alpha'):
+                agree.add(tag + '.alpha', init[tag][name], g, ref.reshape(-1), opt.arch_lr * 2)
+            elif not (name.endswith('running_mean') or name.endswith('running_var') or name.endswith('weight_u')
+                      or name.endswith('weight_v')):
+                agree.add(tag, init[tag][name], g, ref.reshape(-1), lr * n_upd)
+    agree.check()
 
 
 def test_sagan_gradients_vs_oracle(golden_dir):

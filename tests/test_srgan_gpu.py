@@ -158,7 +158,20 @@ def test_srgan_two_iterations_vs_reference_golden(golden_dir):
     e = (model.fake_hr.cpu() - torch.from_numpy(z['eval.fake_hr'])).abs()
     print('eval fake_hr: max %.4g mean %.4g' % (e.max(), e.mean()))
     assert e.max() <= 3e-2 and e.mean() <= 4e-3
+    # evaluator surface (metric/test_metric.py:105-111): PSNR / SSIM of the eval image against a target, vs the oracle's
+    # restatement of skimage on the same two images
+    from oracle import metric_oracle as M
+    g_hr = torch.Generator().manual_seed(8)
+    hr = (model.fake_hr.cpu() + 0.05 * torch.randn(model.fake_hr.shape, generator=g_hr)).clamp(-1, 1)
+    model.set_input({'lr': torch.from_numpy(z['eval.lr']), 'hr': hr, 'lr_names': ['a'] * 2, 'hr_names': ['b'] * 2})
+    model.forward()
+    f_np, r_np = model.fake_hr.cpu().numpy(), model.real_hr.cpu().numpy()
+    assert abs(model.get_current_psnr() - M.psnr_y(f_np, r_np)) < 1e-3
+    assert abs(model.get_current_ssim() - M.ssim_y(f_np, r_np)) < 1e-6
     model.model_train()
+    from tests import _updates
+    init = _updates.snapshot({'sG': model.netG, 'sD': model.netD, 'tG': teacher.netG, 'tD': teacher.netD})
+    agree = _updates.MovementAgreement()
     emu = []
     O.EMULATE_BF16 = True
     try:
@@ -225,6 +238,10 @@ def test_srgan_two_iterations_vs_reference_golden(golden_dir):
                 tol = 2.2 * opt.lr * 2 + 1e-6
             err = float(np.abs(g - ref).max())
             assert err <= tol, (tag, name, err, tol)
+            if not (name.endswith('running_mean') or name.endswith('running_var')):
+                agree.add(tag + ('.alpha' if name.endswith('alpha') else ''), init[tag][name], g, ref.reshape(-1),
+                          (opt.arch_lr if name.endswith('alpha') else opt.lr) * 2)
+    agree.check()
 
 
 def test_srgan_gradients_vs_oracle(golden_dir):
