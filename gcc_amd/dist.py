@@ -83,6 +83,78 @@ def all_reduce_grads(optimizer, async_op=False):
     return None
 
 
+class GradReducer:
+    """Bucketed gradient all-reduce of one optimizer, overlapped with the backward pass that produces the gradients.
+
+    The optimizer's flat gradient buffer is laid out in backward-completion order (engine.FlatParams(layout=...)): segment i
+    = the parameters whose gradients are complete once the engine reports segment i.  Adjacent segments are coalesced into
+    buckets of at least `bucket_bytes` (xGMI is point to point: a ring step moves bucket / world bytes per link, so buckets
+    of a few tens of MB keep every link busy while staying well below the gradient of a whole network); when the last
+    segment of a bucket is reported, its slice is all-reduced asynchronously (RCCL's own stream, ordered behind the stream
+    the weight-gradient kernels of that segment were enqueued on) while the backward pass continues.  finish() makes the
+    current stream wait for every bucket (and reduces whatever was never reported) -- call it before the Adam step.
+    Sum over ranks; the 1/world factor is applied inside the Adam kernel."""
+
+    def __init__(self, optimizer, bucket_bytes=32 << 20):
+        self.opt = optimizer
+        self.flat = optimizer.flat
+        segs = self.flat.segments
+        self.buckets, self.bucket_of = [], []
+        b0 = 0
+        for i, (b, e) in enumerate(segs):
+            self.bucket_of.append(len(self.buckets))
+            if (e - segs[b0][0]) * 4 >= bucket_bytes or i == len(segs) - 1:
+                self.buckets.append((segs[b0][0], e, i))        # [begin, end) elements, last segment index
+                b0 = i + 1
+        self.handles = []
+        self.launched = [False] * len(self.buckets)
+        self.enabled = True
+
+    def begin(self):
+        """a new backward pass starts writing these gradients"""
+        self.handles, self.launched = [], [False] * len(self.buckets)
+
+    def segment_done(self, i, stream=None):
+        """the kernels that complete segment i's gradients have been enqueued; `stream`: the stream they were enqueued on
+        (default: the current stream)"""
+        if not (self.enabled and is_dist()):
+            return
+        k = self.bucket_of[i]
+        b, e, last = self.buckets[k]
+        if i != last or self.launched[k]:
+            return
+        self.opt.set_grad_scale(1.0 / world_size())
+        self.launched[k] = True
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                self.handles.append(dist.all_reduce(self.flat.grads[b:e], op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self.handles.append(dist.all_reduce(self.flat.grads[b:e], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        if not is_dist():
+            return
+        self.opt.set_grad_scale(1.0 / world_size())
+        for k, (b, e, _) in enumerate(self.buckets):
+            if not self.launched[k]:
+                self.launched[k] = True
+                self.handles.append(dist.all_reduce(self.flat.grads[b:e], op=dist.ReduceOp.SUM, async_op=True))
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+
+    def wait(self):                 # the handle protocol of all_reduce_grads(async_op=True)
+        self.finish()
+
+
+def all_reduce_sum(t):
+    """sum over ranks of a small fp32 device vector, in place (the teacher's arch-difference terms: every replica must
+    feed the same value into its EMA; the caller folds 1/world into its next kernel)"""
+    if is_dist():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def mean_dict(d, device):
     if not is_dist():
         return d

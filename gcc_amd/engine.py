@@ -31,12 +31,26 @@ class FlatParams:
     every tensor's logical shape and strides (conv weights stay channels_last).  One fill zeroes all
     gradients, one all-reduce exchanges them, one multi-tensor Adam launch updates them."""
 
-    def __init__(self, params, device):
+    def __init__(self, params, device, layout=None):
+        """layout: optional storage order -- a list of lists of parameters (every parameter exactly once), each inner
+        list one *segment*; segments are laid down back to back in the order given, which the data-parallel path chooses
+        as the order in which the backward pass completes the gradients, so that a finished run of segments is one
+        contiguous slice of `grads` (dist.GradReducer: bucketed all-reduce overlapped with the rest of the backward).
+        self.segments = [(begin, end)] element ranges.  The parameter list itself (optimizer order) is unchanged."""
         self.params = [p for p in params]
-        offs, total = [], 0
-        for p in self.params:
-            offs.append(total)
-            total += (p.numel() + 3) & ~3
+        if layout is None:
+            layout = [self.params]
+        placed = [p for seg in layout for p in seg]
+        assert len(placed) == len(self.params) and {id(p) for p in placed} == {id(p) for p in self.params}, \
+            'layout must hold every parameter exactly once'
+        where, total, self.segments = {}, 0, []
+        for seg in layout:
+            b = total
+            for p in seg:
+                where[id(p)] = total
+                total += (p.numel() + 3) & ~3
+            self.segments.append((b, total))
+        offs = [where[id(p)] for p in self.params]
         self.total = total
         self.values = torch.zeros(max(total, 4), dtype=torch.float32, device=device)
         self.grads = torch.zeros(max(total, 4), dtype=torch.float32, device=device)
@@ -249,6 +263,37 @@ class UnetEngine:
     def convs(self):
         return [c for c in self.down + self.up if c is not None]
 
+    @staticmethod
+    def grad_segments(module, num_downs):
+        """parameters grouped in the order _backward() completes their gradients (one segment per layer: conv weight / bias
+        with the BatchNorm behind it): up[0], up[1] .. up[D-1], down[D-1] .. down[0].  Same name scheme as __init__."""
+        D = num_downs
+        prefix = lambda d: 'model' if d == 0 else 'model.model.1' + '.model.3' * (d - 1)
+        par = lambda name: [p for p in _get(module, name).parameters()]
+        segs = []
+        for d in range(D):
+            p = prefix(d)
+            seg = par(p + ('.model.3' if d in (0, D - 1) else '.model.5'))
+            if d > 0:
+                seg = par(p + ('.model.4' if d == D - 1 else '.model.6')) + seg
+            segs.append(seg)
+        for d in range(D - 1, -1, -1):
+            p = prefix(d)
+            seg = par(p + ('.model.0' if d == 0 else '.model.1'))
+            if 0 < d < D - 1:
+                seg = par(p + '.model.2') + seg
+            segs.append(seg)
+        return segs
+
+    def _seg_done(self, i):
+        """segment i of grad_segments() is complete once everything enqueued so far (main stream + weight-gradient side
+        stream) has run: report it to the data-parallel reducer, ordered behind the side stream"""
+        r = getattr(self, 'reducer', None)
+        if r is not None:
+            r.segment_done(self.seg_base + i, ops.SideStream.get(self.device).stream if OVERLAP_WGRAD else None)
+
+    seg_base = 0          # index of this engine's first segment in the optimizer's layout (transform convs come first)
+
     def repack(self):
         if getattr(self, '_pack', None) is None:
             self._pack = ops.PackPlan(self.convs(), self.device)
@@ -364,6 +409,7 @@ class UnetEngine:
         ops.bnact_bwd(c.out, None, c.g_out, c.g_out, in_act=ACT_TANH)
         if wgrad:
             self.up[0].backward_weight(c.rcat[1], c.g_out)
+            self._seg_done(0)
         self.up[0].backward_data(c.g_out, c.g_rcat[1])
         for d in range(1, D):
             if d == 2 and g_feat[3] is not None:
@@ -381,11 +427,13 @@ class UnetEngine:
             src = c.e[D - 1] if d == D - 1 else c.rcat[d + 1]
             if wgrad:
                 self.up[d].backward_weight(src, c.g_t[d])
+                self._seg_done(d)
             self.up[d].backward_data(c.g_t[d], c.g_e_last if d == D - 1 else c.g_rcat[d + 1])
         # innermost down conv (+ fused ReLU)
         ops.bnact_bwd(c.e[D - 1], None, c.g_e_last, c.g_e_last, in_act=ACT_RELU)
         if wgrad:
             self.down[D - 1].backward_weight(c.lin[D - 1], c.g_e_last)
+            self._seg_done(D)
         self.down[D - 1].backward_data(c.g_e_last, c.g_lin[D - 1])
         for d in range(D - 2, -1, -1):
             # e[d] feeds lin[d+1] (LeakyReLU) and rcat[d+1][:w] (ReLU)
@@ -403,6 +451,7 @@ class UnetEngine:
                 ops.bnact_bwd(c.e[0], c.lin[1], c.g_lin[1], c.g_e[0], g2=g2, act=ACT_LRELU, act2=ACT_RELU)
             if wgrad:
                 self.down[d].backward_weight(c.lin[d] if d > 0 else c.x_in, c.g_e[d])
+                self._seg_done(2 * D - 1 - d)
             if d > 0:
                 self.down[d].backward_data(c.g_e[d], c.g_lin[d])
         ops.SideStream.get(self.device).join()
@@ -452,6 +501,23 @@ class PatchGANEngine:
 
     def convs(self):
         return self.conv
+
+    def grad_segments(self):
+        """weight-optimizer parameters in the order backward() completes their gradients: the last conv first, then each
+        layer's BatchNorm + conv down to the first conv (alphas belong to the arch optimizer)"""
+        segs = []
+        for li in range(self.L - 1, -1, -1):
+            seg = []
+            if self.bn[li] is not None:
+                seg += list(self.bn[li].bn.parameters())
+            seg += [p for p in (self.conv[li].weight, self.conv[li].bias) if p is not None]
+            segs.append(seg)
+        return segs
+
+    def _seg_done(self, i):
+        r = getattr(self, 'reducer', None)
+        if r is not None and getattr(self, 'reduce_now', False):
+            r.segment_done(i, ops.SideStream.get(self.device).stream if OVERLAP_WGRAD else None)
 
     def repack(self):
         if getattr(self, '_pack', None) is None:
@@ -564,6 +630,7 @@ class PatchGANEngine:
         if has_pred_grad:
             if wgrad:
                 self.conv[L - 1].backward_weight(c.y[L - 2], G.layer[L - 1])
+                self._seg_done(0)
             self.conv[L - 1].backward_data(G.layer[L - 1], G.layer[L - 2])
         for li in range(L - 2, 0, -1):
             g1, g2 = G.layer[li], feat_of.get(li)
@@ -582,12 +649,14 @@ class PatchGANEngine:
             src = c.g0 if li == 1 else c.y[li - 1]
             if wgrad:
                 self.conv[li].backward_weight(src, G.layer[li])
+                self._seg_done(L - 1 - li)
             self.conv[li].backward_data(G.layer[li], G.layer[li - 1])
         gate = self.gate[0]
         ops.bnact_bwd(c.a0, None, G.layer[0], G.layer[0], gate=self.mask[0], gate_after_act=True, in_act=ACT_LRELU,
                       dalpha=gate.alpha.grad if (agrad and gate is not None) else None)
         if wgrad:
             self.conv[0].backward_weight(c.x_in, G.layer[0])
+            self._seg_done(L - 1)
         dx = None
         if need_dx:
             self.conv[0].backward_data(G.layer[0], G.x_in)

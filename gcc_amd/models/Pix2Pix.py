@@ -190,14 +190,15 @@ class HipAdam(torch.optim.Optimizer):
     """torch.optim.Optimizer facade (so LambdaLR/StepLR schedulers work unchanged) whose step() is
     one multi-tensor gcc_adam_step launch over a FlatParams group."""
 
-    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, l1=None, dup=()):
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, l1=None, dup=(), layout=None):
         """dup: parameters (members of params) the reference lists twice in this optimizer (SAGAN, SURVEY.md hazard
         H5): torch's Adam then applies two sequential updates per step to them, with the same gradient and the step
         counter advancing twice -- reproduced by a second plan over those tensors that is stepped twice."""
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         dev = params[0].device
-        self.flat = engine.FlatParams(params, dev)
+        self.flat = engine.FlatParams(params, dev, layout=layout)
+        self.reducer = None         # dist.GradReducer under data parallelism (Pix2PixModel sets it)
         l1 = list(l1) if l1 is not None else [0.0] * len(params)
         dup_ids = {id(p) for p in dup}
         once = [i for i, p in enumerate(params) if id(p) not in dup_ids]
@@ -289,14 +290,20 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             gdist.broadcast_module(t)              # default-initialised from each rank's RNG: replicas must start equal
             g_params.append(t.weight)
             g_l1.append(0.0)
-        self.optimizer_G = HipAdam(g_params, lr=opt.lr, betas=(0.5, 0.999), l1=g_l1)
+        # storage order of the flat gradient buffers = backward-completion order (transform convs, then the U-Net layer by
+        # layer; the PatchGAN from its last conv down): data parallelism all-reduces finished runs while the backward continues
+        g_layout = d_layout = None
+        if not self.resnet:
+            g_layout = ([[t.weight for t in self.transform_convs]] if self.transform_convs else []) + \
+                engine.UnetEngine.grad_segments(self.netG, opt.num_downs)
+        self.optimizer_G = HipAdam(g_params, lr=opt.lr, betas=(0.5, 0.999), l1=g_l1, layout=g_layout)
         w_params, a_params = [], []
         for m in self.netD.modules():
             if isinstance(m, (nn.Conv2d, nn.BatchNorm2d)):
                 w_params += list(m.parameters())
             elif isinstance(m, DifferentiableOP):
                 a_params += list(m.parameters())
-        self.optimizer_D = HipAdam(w_params, lr=opt.lr, betas=(0.5, 0.999))
+        self.optimizer_D = HipAdam(w_params, lr=opt.lr, betas=(0.5, 0.999), layout=self._d_layout())
         if opt.darts_discriminator:
             self.optimizer_arch = HipAdam(a_params, lr=opt.arch_lr)
             if opt.arch_lr_step:
@@ -314,6 +321,12 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             # the last two hooked features are concat buffers (skip | up path): their channel dimension is split
             t_split = [0, 0, self.G.width[3], self.G.width[1]]
         self.D = engine.PatchGANEngine(self.netD, bool(opt.darts_discriminator), opt.threshold, dev)
+        if gdist.world_size() > 1 and os.environ.get('GCC_DP_BUCKETS', '1') != '0':
+            mb = int(os.environ.get('GCC_DP_BUCKET_MB', '32'))
+            if g_layout is not None:
+                self.optimizer_G.reducer = self.G.reducer = gdist.GradReducer(self.optimizer_G, mb << 20)
+                self.G.seg_base = 1 if self.transform_convs else 0
+            self.optimizer_D.reducer = self.D.reducer = gdist.GradReducer(self.optimizer_D, mb << 20)
         self.T = [engine.ConvOp(t.weight, None, 1, 1, 0, False, col_split=sp)
                   for t, sp in zip(self.transform_convs, t_split)]
         self.refresh_weights()
@@ -438,8 +451,25 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         self.D.apply_deferred_running(ctx)
         return ctx
 
+    def _d_layout(self):
+        """PatchGAN weight parameters in backward-completion order (engine.PatchGANEngine.grad_segments, by module index)"""
+        mods = [m for m in self.netD.model.children() if isinstance(m, (nn.Conv2d, nn.BatchNorm2d))]
+        segs, cur = [], []
+        for m in mods:                       # forward order: conv, [bn], conv, [bn] ... -> one segment per conv (+ its bn)
+            if isinstance(m, nn.Conv2d) and cur:
+                segs.append(cur)
+                cur = []
+            cur = (list(m.parameters()) + cur) if isinstance(m, nn.BatchNorm2d) else cur + list(m.parameters())
+        segs.append(cur)
+        return segs[::-1]
+
     def _allreduce(self, optimizer):
-        gdist.all_reduce_grads(optimizer)
+        """gradient exchange before an optimizer step: buckets the backward pass already launched are waited for, the rest
+        is reduced here"""
+        if getattr(optimizer, 'reducer', None) is not None:
+            optimizer.reducer.finish()
+        else:
+            gdist.all_reduce_grads(optimizer)
 
     # -- D step (models/Pix2Pix.py:464-477) --------------------------------------------------------
     def backward_D(self):
@@ -448,10 +478,14 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         cf = self._d_forward('d_fake', self._fake, refresh=not early)
         cr = self._take_real_pass('d_real')
         gp = self.D.grad_pred_buffer(cf)
+        if self.optimizer_D.reducer is not None:
+            self.optimizer_D.reducer.begin()
         ops.gan_loss(mode, cf.pred, False, True, self._l('D_fake'), dpred=gp, grad_weight=0.5)
         self.D.backward(cf, wgrad=True, need_dx=False)
         ops.gan_loss(mode, cr.pred, True, True, self._l('D_real'), dpred=gp, grad_weight=0.5)
+        self.D.reduce_now = True             # the second pass completes the gradients: its finished layers are exchanged
         self.D.backward(cr, wgrad=True, need_dx=False)
+        self.D.reduce_now = False
 
     # -- G step (models/Pix2Pix.py:513-552) --------------------------------------------------------
     def backward_G(self, ts=None):
@@ -466,6 +500,8 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         ops.l1_loss(self._fake, self._B, self._l('G_L1'), weight=opt.lambda_L1, da=gc.g_out)
         ops.nhwc_add(dx, 3, gc.g_out, 0, 3)
         g_feat = None
+        if self.optimizer_G.reducer is not None:
+            self.optimizer_G.reducer.begin()
         if ts:
             torch.cuda.current_stream().wait_stream(ts)
         if self.distill:
@@ -496,6 +532,8 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
                 self.T[i].backward_data(dtf[i], gbuf)
                 g_feat.append(gbuf)
             ops.SideStream.get(self.device).join()
+            if self.optimizer_G.reducer is not None:
+                self.optimizer_G.reducer.segment_done(0)          # the transform convs' gradients (main stream: joined)
             dx2 = T.D.backward(ct, has_pred_grad=False, g_feat=[dtf[4], dtf[5]], wgrad=False, need_dx=True)
             ops.nhwc_add(dx2, 3, gc.g_out, 0, 3)
             self._mark_teacher_free()
@@ -545,7 +583,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             # online teacher under data parallelism: its generator is not read again before the arch
             # step, so its (largest, 218 MB) gradient bucket is reduced while the student's whole
             # iteration runs; finish_G_update() applies it.  Same arithmetic, later in stream order.
-            self._pending_G = gdist.all_reduce_grads(self.optimizer_G, async_op=True)
+            self._pending_G = self.optimizer_G.reducer or gdist.all_reduce_grads(self.optimizer_G, async_op=True)
             return
         self._allreduce(self.optimizer_G)
         self._apply_G_update()
@@ -573,9 +611,19 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         ops.gan_loss(mode, cf.pred, True, False, self._l('D_arch_fake_real'))
         ops.gan_loss(mode, cr.pred, True, True, self._l('D_arch_real'))
         out = self._l('teacher_D_arch_diff' if isTeacher else 'D_arch_diff')
+        w = 1.0
+        if isTeacher and self._world > 1:
+            # the teacher's difference feeds an EMA that every replica must hold identically -> the two hinge
+            # means are summed over ranks (in place: the teacher logs neither) and the 1/world goes into the scalar op
+            i = self._slot['D_arch_fake']
+            assert self._slot['D_arch_fake_real'] == i + 1
+            gdist.all_reduce_sum(self._lossvec[i:i + 2])
+            w = 1.0 / gdist.world_size()
         if isTeacher and self._ema_started:
             b = float(self.opt.ema_beta)
-            ops.scalar_op(1, self._l('D_arch_fake_real'), self._l('D_arch_fake'), out, c=out, k0=b, k1=1.0 - b)
+            ops.scalar_op(1, self._l('D_arch_fake_real'), self._l('D_arch_fake'), out, c=out, k0=b * w, k1=1.0 - b)
+        elif w != 1.0:
+            ops.scalar_op(1, self._l('D_arch_fake_real'), self._l('D_arch_fake'), out, c=out, k0=w, k1=0.0)
         else:
             ops.scalar_op(0, self._l('D_arch_fake_real'), self._l('D_arch_fake'), out)
         self._ema_started = True

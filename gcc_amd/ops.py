@@ -73,7 +73,7 @@ class _Profile:
             a[0] += flops
             a[1] += sec
             a[2] += 1
-            b = shapes.setdefault((kind.split(' ')[0], shape), [0.0, 0.0, 0])
+            b = shapes.setdefault((kind.split(' ')[0], shape, tag or ''), [0.0, 0.0, 0])
             b[0] += flops
             b[1] += sec
             b[2] += 1
@@ -86,9 +86,9 @@ class _Profile:
         self.spans = []
         if os.environ.get('GCC_PROFILE_SHAPES') == '1':      # per-geometry table on stderr (tuning aid)
             import sys
-            for (kind, shape), (fl, sec, n) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:40]:
-                print('%-14s %-44s n=%4d  total %7.3f ms  avg %7.1f us  %7.1f TFLOP/s' % (kind, shape, n, sec * 1e3, sec / n * 1e6,
-                                                                                         fl / sec / 1e12), file=sys.stderr)
+            for (kind, shape, tag), (fl, sec, n) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('GCC_PROFILE_TOP', '200'))]:
+                print('%-14s %-44s %-14s n=%4d  total %7.3f ms  avg %7.1f us  %7.1f TFLOP/s' % (
+                    kind, shape, tag, n, sec * 1e3, sec / n * 1e6, fl / sec / 1e12), file=sys.stderr)
         if not agg:
             return None
         dom = max(agg, key=lambda k: agg[k][1])

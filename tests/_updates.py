@@ -17,6 +17,17 @@ import torch
 from tests.golden.recipe import sample_idx
 
 
+def _report(line):
+    """stdout (shown by pytest on failure) and, when GCC_TEST_REPORT names a file, appended there: the measured agreement
+    of passing runs is evidence too"""
+    import os
+    print(line)
+    path = os.environ.get('GCC_TEST_REPORT')
+    if path:
+        with open(path, 'a') as fh:
+            fh.write('%s | %s\n' % (os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0], line))
+
+
 def sampled(t):
     g = t.detach().float().cpu().reshape(-1)
     return g[sample_idx(g.numel())].numpy().copy()
@@ -42,13 +53,13 @@ class MovementAgreement:
         a[2] += int((d_hip[sel] != 0).sum())
         a[3] += int(d_ref.size)
 
-    def check(self, min_agree=0.9, min_moved=0.99, min_selected=0.2):
+    def check(self, min_agree=0.9, min_moved=0.99, min_selected=0.1):
         assert self.acc, 'no tensors were compared'
         for tag, (n, agree, moved, total) in sorted(self.acc.items()):
-            print('update agreement %-6s: %6d of %6d sampled elements moved clearly in the reference; same direction %.4f, '
-                  'moved at all %.4f' % (tag, n, total, agree / max(n, 1), moved / max(n, 1)))
+            _report('update agreement %-9s: %6d of %6d sampled elements moved clearly in the reference; same direction %.4f, '
+                    'moved at all %.4f' % (tag, n, total, agree / max(n, 1), moved / max(n, 1)))
         for tag, (n, agree, moved, total) in self.acc.items():
-            assert n >= min_selected * total, (tag, 'too few clearly moved elements', n, total)
+            assert n >= max(8, min_selected * total), (tag, 'too few clearly moved elements', n, total)
             assert moved >= min_moved * n, (tag, 'weights did not move', moved, n)
             assert agree >= min_agree * n, (tag, 'update direction disagrees with the reference', agree, n)
 
@@ -68,7 +79,7 @@ def sign_check(tag, before, after, g32, g16, acc):
 def sign_report(acc, min_frac=0.99, min_selected=0.02):
     assert acc
     for tag, (n, ok, total) in sorted(acc.items()):
-        print('update sign %-6s: %8d of %8d elements above the bf16 floor; step opposite to the oracle gradient on %.4f' % (
+        _report('update sign %-6s: %8d of %8d elements above the bf16 floor; step opposite to the oracle gradient on %.4f' % (
             tag, n, total, ok / max(n, 1)))
     for tag, (n, ok, total) in acc.items():
         assert n >= min_selected * total, (tag, 'too few elements above the floor', n, total)

@@ -93,6 +93,40 @@ def test_tile_plan_options_are_host_state_only():
     assert lib.gcc_conv_tile(ctypes.byref(small), 0) == 128128 and lib.gcc_get_option(_lib.OPT_WGRAD_BIG) == 1
 
 
+def test_gradient_layout_follows_backward_completion_order():
+    """data parallelism: the flat gradient buffers are laid out in the order the backward pass completes the gradients
+    (engine.UnetEngine.grad_segments / Pix2PixModel._d_layout), every parameter exactly once, and dist.GradReducer
+    coalesces adjacent segments into buckets that tile the buffer"""
+    from gcc_amd import dist as gdist
+    from gcc_amd import engine
+    from gcc_amd.models.Pix2Pix import MaskNLayerDiscriminator, Pix2PixModel, UnetGenertor
+    g = UnetGenertor(3, 3, 8, ngf=8)
+    names = {id(p): n for n, p in g.named_parameters()}
+    segs = engine.UnetEngine.grad_segments(g, 8)
+    assert len(segs) == 16 and sorted(names[id(p)] for s in segs for p in s) == sorted(names.values())
+    assert [names[id(p)] for p in segs[0]] == ['model.model.3.weight', 'model.model.3.bias']        # outermost up conv first
+    assert [names[id(p)] for p in segs[-1]] == ['model.model.0.weight']                              # outermost down conv last
+    assert names[id(segs[8][0])].endswith('model.3.model.1.weight') and len(segs[8]) == 1             # innermost down conv
+    holder = type('H', (), {})()
+    holder.netD = MaskNLayerDiscriminator(input_nc=6, ndf=8)
+    dn = {id(p): n for n, p in holder.netD.named_parameters()}
+    dsegs = Pix2PixModel._d_layout(holder)
+    assert [[dn[id(p)] for p in s] for s in dsegs] == [['model.15.weight', 'model.15.bias'], ['model.12.weight', 'model.12.bias', 'model.11.weight'],
+                                                      ['model.8.weight', 'model.8.bias', 'model.7.weight'],
+                                                      ['model.4.weight', 'model.4.bias', 'model.3.weight'], ['model.0.weight', 'model.0.bias']]
+    params = list(g.parameters())
+    before = [p.detach().clone() for p in params]
+    flat = engine.FlatParams(params, 'cpu', layout=segs)
+    assert all(torch.equal(p.detach(), b) for p, b in zip(params, before)), 're-homing keeps the values'
+    assert flat.segments[0][0] == 0 and flat.segments[-1][1] == flat.total
+    assert all(a[1] == b[0] for a, b in zip(flat.segments, flat.segments[1:]))
+    assert segs[0][0].data_ptr() == flat.values.data_ptr()                                       # first segment sits at offset 0
+    red = gdist.GradReducer(type('O', (), {'flat': flat, 'set_grad_scale': lambda self, s: None})(), bucket_bytes=64 << 10)
+    assert red.buckets[0][0] == 0 and red.buckets[-1][1] == flat.total and len(red.buckets) >= 3
+    assert all(a[1] == b[0] for a, b in zip(red.buckets, red.buckets[1:]))
+    assert [b[2] for b in red.buckets] == sorted(b[2] for b in red.buckets) and red.buckets[-1][2] == 15
+
+
 def test_struct_layouts_match_header():
     from gcc_amd import _lib
     assert ctypes.sizeof(_lib.conv_t) == 13 * 4

@@ -23,6 +23,21 @@ def _free_port():
     return p
 
 
+def _collect(q, procs, n, timeout=1200):
+    """n results from the workers' queue; fails as soon as a worker has died instead of waiting out the timeout"""
+    import queue
+    import time
+    out, t0 = [], time.time()
+    while len(out) < n:
+        try:
+            out.append(q.get(timeout=5))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, 'a worker process died (exit codes %s): see its traceback above' % dead
+            assert time.time() - t0 < timeout, 'workers timed out'
+    return out
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -64,7 +79,7 @@ def test_two_ranks_stay_identical():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=1200) for _ in range(2)], key=lambda d: d['rank'])
+    res = sorted(_collect(q, procs, 2), key=lambda d: d['rank'])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -120,7 +135,7 @@ def test_rccl_single_rank_with_teacher_stream():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
     p.start()
-    res = q.get(timeout=1200)
+    res = _collect(q, [p], 1)[0]
     p.join(120)
     assert p.exitcode == 0
     assert res['got'] == res['ref'], (res['got'], res['ref'])
