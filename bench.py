@@ -134,6 +134,38 @@ def cpu_baseline(iters=16, batch=1, budget=30.0):
                       '1 warm-up + %d timed iterations, %.2f s/iteration' % (batch, iters, dt)}
 
 
+def allreduce_table(model, device, reps=5):
+    """after the timed region: every gradient bucket of the step all-reduced alone (blocking, `reps` times, max over ranks)
+    -- what the exchange costs when nothing overlaps it, so that a scaling curve can be read against it"""
+    import torch.distributed as dist
+    rows, total_ms, total_mb = [], 0.0, 0.0
+    T = model.teacher_model
+    for name, opt_ in (('teacher_D', T.optimizer_D), ('teacher_G', T.optimizer_G), ('student_D', model.optimizer_D),
+                       ('student_G', model.optimizer_G), ('alpha', model.optimizer_arch)):
+        red = getattr(opt_, 'reducer', None)
+        spans = [(b, e) for b, e, _ in red.buckets] if red is not None else [(0, opt_.flat.grads.numel())]
+        for i, (b, e) in enumerate(spans):
+            buf = opt_.flat.grads[b:e].clone()
+            dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                dist.all_reduce(buf)
+            e1.record()
+            torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms, mb = float(t.item()), (e - b) * 4 / 1e6
+            rows.append({'bucket': '%s[%d]' % (name, i), 'MB': round(mb, 2), 'ms': round(ms, 3),
+                         'algbw_GBps': round(mb / ms, 1) if ms > 0 else None})
+            total_ms += ms
+            total_mb += mb
+    return {'buckets': rows, 'total_MB_fp32': round(total_mb, 1), 'total_ms_unoverlapped': round(total_ms, 3),
+            'note': 'each bucket alone after the timed region; in the step they overlap the backward pass (dist.GradReducer)'}
+
+
 def generator_block(tag_stats, batch):
     """north_star's sub-figure: MFMA utilisation of the generator forward + backward at batch 16.  From the bracketed step:
     conv_* = the generator's fprop / dgrad / wgrad launches alone (algorithmic FLOP / sum of their durations); pass_* = the
@@ -233,6 +265,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     losses = model.get_current_losses()
+    comm = allreduce_table(model, device) if world > 1 else None
     if rank != 0:
         return
     imgs = world * args.batch * args.steps
@@ -253,6 +286,8 @@ def main():
     if roof is not None:
         out['roofline'] = roof
     out['rccl_ranks'] = world
+    if comm is not None:
+        out['allreduce'] = comm
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
         n4 = cpu_baseline(iters=4, batch=4, budget=20.0)          # SURVEY 8(d) / BASELINE.md: N=1 and N=4

@@ -38,13 +38,13 @@ def _collect(q, procs, n, timeout=1200):
     return out
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend='gloo', iters=1):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+                      LOCAL_RANK=str(rank) if backend == 'nccl' else '0', HSA_ENABLE_IPC_MODE_LEGACY='0')
     import torch.distributed as dist
     from gcc_amd import dist as gdist
-    gdist.init_from_env(backend='gloo')
+    gdist.init_from_env(backend=backend)
     from tests.test_pix2pix_gpu import GCC_ARGV, build_model
     torch.manual_seed(100 + rank)            # different initial weights per rank: the broadcast must fix that
     model, teacher, opt = build_model(GCC_ARGV, teacher_ndf=16)
@@ -52,11 +52,14 @@ def _worker(rank, world, port, q):
     sd0 = model.netG.state_dict()['model.model.0.weight'].float().cpu().clone()
     g = torch.Generator().manual_seed(7 + rank)     # different data per rank
     A, B = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1, torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
-    model.set_input({'A': A, 'B': B, 'A_paths': [''], 'B_paths': ['']})
-    model.optimize_parameters()
-    model.set_input({'A': B, 'B': A, 'A_paths': [''], 'B_paths': ['']})
-    model.clipping_mask_alpha()
-    model.optimizer_netD_arch()
+    for _ in range(iters):
+        model.set_input({'A': A, 'B': B, 'A_paths': [''], 'B_paths': ['']})
+        model.optimize_parameters()
+        model.set_input({'A': B, 'B': A, 'A_paths': [''], 'B_paths': ['']})
+        model.clipping_mask_alpha()
+        model.optimizer_netD_arch()
+    model.finish_G_update()
+    teacher.finish_G_update()
     torch.cuda.synchronize()
     out = {'rank': rank, 'w0': sd0.numpy()}
     for name, mod in (('sG', model.netG), ('sD', model.netD), ('tG', teacher.netG), ('tD', teacher.netD)):
@@ -90,6 +93,29 @@ def test_two_ranks_stay_identical():
         assert np.array_equal(a[k], b[k]), 'replicas diverged in %s: gradients were not exchanged identically' % k
         assert np.isfinite(a[k]).all()
     assert a['losses'] == b['losses']          # logged losses are rank-averaged
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: one RCCL rank per device')
+def test_two_rccl_ranks_two_devices():
+    """the production backend on real devices (skipped on the one-GPU test box; the first box with two GPUs runs it): two
+    RCCL ranks, one GPU each, two whole iterations on different shards -- bucketed all-reduces launched during the
+    backward, the asynchronous teacher-generator exchange, the summed teacher arch difference -- replicas bit-identical"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 'nccl', 2)) for r in range(2)]
+    for p in procs:
+        p.start()
+    a, b = sorted(_collect(q, procs, 2), key=lambda d: d['rank'])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    import numpy as np
+    for k in ('sG', 'sD', 'tG', 'tD', 'T', 'flatG'):
+        assert np.array_equal(a[k], b[k]), 'replicas diverged in %s' % k
+        assert np.isfinite(a[k]).all()
+    assert a['losses'] == b['losses']
 
 
 def _rccl_worker(port, q):
