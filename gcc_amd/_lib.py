@@ -59,7 +59,8 @@ class adam_chunk_t(C.Structure):
 
 # gcc_set_option ids (enum in include/gcc_hip.h)
 (OPT_IGEMM_BIG, OPT_IGEMM_BIG_MIN, OPT_IGEMM_BIG_NK, OPT_IGEMM_GLDS, OPT_IGEMM_HEAD, OPT_IGEMM_THIN, OPT_WGRAD_BIG,
- OPT_BN_SWEEPS, OPT_BN_MAXBLK, OPT_BN_REDUCE_THREADS, OPT_BN_REDUCE_CAP, OPT_INORM_LPP) = range(12)
+ OPT_BN_SWEEPS, OPT_BN_MAXBLK, OPT_BN_REDUCE_THREADS, OPT_BN_REDUCE_CAP, OPT_INORM_LPP, OPT_WGRAD_WGS_BIG,
+ OPT_WGRAD_WGS) = range(14)
 
 _P = C.c_void_p
 _I = C.c_int

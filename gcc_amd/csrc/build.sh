@@ -9,7 +9,7 @@ mkdir -p build
 if [ "${GCC_BUILD_FORCE:-0}" = "1" ]; then rm -f build/*.o $OUT; fi
 pids=()
 for f in conv_igemm conv_wgrad norm_act misc dwconv spectral attention srgan metric; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.hpp -nt build/$f.o ] || [ ../../include/gcc_hip.h -nt build/$f.o ]; then
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.hpp -nt build/$f.o ] || [ igemm_common.hpp -nt build/$f.o ] || [ ../../include/gcc_hip.h -nt build/$f.o ]; then
     rm -f build/$f.o
     hipcc $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)

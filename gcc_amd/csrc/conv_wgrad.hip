@@ -315,14 +315,16 @@ int plan_splits(const gcc_conv_t* c, int batch, int* ksteps_per_split, bool* big
     bool big = big_mode && batch == 1 && (c->Ci & 7) == 0 && c->Co >= 256 && ncols >= 256 && tiles_big >= 32 && ksteps >= 64;
     int splits;
     if (big) {
-        splits = tiles_big >= 200 ? 1 : cdiv(256, tiles_big);
+        const int target = gcc_opt(GCC_OPT_WGRAD_WGS_BIG);
+        splits = tiles_big >= (target * 25) / 32 ? 1 : cdiv(target, tiles_big);
         const int max_splits = ksteps / 16 > 0 ? ksteps / 16 : 1;
         if (splits > max_splits) splits = max_splits;
     } else {
         const int tiles = cdiv(ncols, 128) * cdiv(c->Co, 128) * batch;
         // enough tiles to fill the chip (2 workgroups per CU resident): no split, dW written directly;
         // otherwise split the pixel range so that ~512 workgroups exist, >= 8 k-steps (512 pixels) each
-        splits = tiles >= 192 ? 1 : cdiv(512, tiles);
+        const int target = gcc_opt(GCC_OPT_WGRAD_WGS);
+        splits = tiles >= (target * 3) / 8 ? 1 : cdiv(target, tiles);
         const int max_splits = ksteps / 8 > 0 ? ksteps / 8 : 1;
         if (splits > max_splits) splits = max_splits;
     }

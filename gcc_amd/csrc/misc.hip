@@ -381,9 +381,9 @@ extern "C" int gcc_version(void) {
 namespace {
 struct OptDef { const char* env; int def; };
 const OptDef kOptDef[GCC_OPT_COUNT_] = {
-    {"GCC_IGEMM_BIG", 2}, {"GCC_IGEMM_BIG_MIN", 200}, {"GCC_IGEMM_BIG_NK", 24}, {"GCC_IGEMM_GLDS", 1}, {"GCC_IGEMM_HEAD", 1},
+    {"GCC_IGEMM_BIG", 2}, {"GCC_IGEMM_BIG_MIN", 120}, {"GCC_IGEMM_BIG_NK", 24}, {"GCC_IGEMM_GLDS", 1}, {"GCC_IGEMM_HEAD", 1},
     {"GCC_IGEMM_THIN", 1}, {"GCC_WGRAD_BIG", 1}, {"GCC_BN_SWEEPS", 0}, {"GCC_BN_MAXBLK", 2048}, {"GCC_BN_REDUCE_THREADS", 256},
-    {"GCC_BN_REDUCE_CAP", 1024}, {"GCC_INORM_LPP", 0},
+    {"GCC_BN_REDUCE_CAP", 1024}, {"GCC_INORM_LPP", 0}, {"GCC_WGRAD_WGS_BIG", 256}, {"GCC_WGRAD_WGS", 512},
 };
 std::atomic<int> g_opt[GCC_OPT_COUNT_];
 int g_opt_default[GCC_OPT_COUNT_];

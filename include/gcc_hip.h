@@ -54,7 +54,8 @@ int gcc_version(void);
  * ------------------------------------------------------------------------------------------- */
 enum {
     GCC_OPT_IGEMM_BIG = 0,      /* 0: 128-pixel tiles only; 1: + 256x128; 2 (default): + 256x256 */
-    GCC_OPT_IGEMM_BIG_MIN,      /* minimum number of 256-pixel tiles of a launch (default 200) */
+    GCC_OPT_IGEMM_BIG_MIN,      /* minimum number of 256-pixel tiles of a launch (default 120: half a chip of one-per-CU workgroups; the rest of the
+                                   CUs run the other streams' kernels -- measured +2.7 % on the step against 200, profiles/r02_e) */
     GCC_OPT_IGEMM_BIG_NK,       /* minimum K depth in 64-steps for 256-pixel tiles (default 24) */
     GCC_OPT_IGEMM_GLDS,         /* 1 (default): LDS-DMA staging; 0: register-staged 128-pixel tiles */
     GCC_OPT_IGEMM_HEAD,         /* 1 (default): single-output-channel head route */
@@ -65,6 +66,8 @@ enum {
     GCC_OPT_BN_REDUCE_THREADS,  /* 256 (default) or 1024 threads per BatchNorm-backward reduce workgroup */
     GCC_OPT_BN_REDUCE_CAP,      /* cap on those workgroups (default 1024) */
     GCC_OPT_INORM_LPP,          /* 0 (default): automatic lanes per pixel of the one-launch InstanceNorm */
+    GCC_OPT_WGRAD_WGS_BIG,      /* workgroups a split 256x256 weight-gradient launch aims at (default 256) */
+    GCC_OPT_WGRAD_WGS,          /* ... a split 128x128 weight-gradient launch (default 512) */
     GCC_OPT_COUNT_
 };
 int gcc_set_option(int id, int value);

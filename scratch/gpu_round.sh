@@ -33,6 +33,17 @@ graph)
   timeout 600 python scratch/probe_graph_pix2pix.py > $out/graph_probe.txt 2>&1; tail -8 $out/graph_probe.txt;;
 dp)
   timeout 900 python -m pytest tests/test_dp_gpu.py -q -m gpu -x 2>&1 | tail -15;;
+pmc)
+  i=0
+  for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i+1))
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --serialize-streams > $GRAFT_REPO_ROOT/$out/pmc$i.log 2>&1)
+    f=$(find $out/pmc$i -name '*counter_collection.csv' | head -1); cp $f $out/pmc${i}_counters.csv 2>/dev/null
+    rm -rf $out/pmc$i
+  done
+  python scratch/pmc_mfma.py $out/pmc_mfma_lds.json $out/pmc1_counters.csv $out/pmc2_counters.csv
+  python scratch/pmc_traffic.py $out/pmc3_counters.csv $out/pmc4_counters.csv $out/igemm_hbm_traffic.json
+  rm -f $out/pmc*_counters.csv;;
 counters)
   rocprofv3 -L > $out/counters_list.txt 2>&1; grep -c . $out/counters_list.txt;;
 esac
