@@ -423,6 +423,12 @@ struct SplitPlan { int ksplit, kper; };
 // split only launches that cannot fill the chip and have a long K loop
 static SplitPlan plan_ksplit(long blocks, int nk) {
     SplitPlan sp = {1, nk};
+    if (const int f = gcc_opt(GCC_OPT_IGEMM_FORCE_KSPLIT)) {          // tuning hook
+        const int s = f > nk ? nk : f;
+        sp.kper = (nk + s - 1) / s;
+        sp.ksplit = (nk + sp.kper - 1) / sp.kper;
+        return sp;
+    }
     if (blocks >= 128 || nk < 16) return sp;
     int s = (int)((1024 + blocks - 1) / blocks);
     if (s > nk / 4) s = nk / 4;
@@ -480,6 +486,9 @@ static TilePlan select_tile(size_t max_rows, int Cout, int phases, int nk, int b
     else if (Cout > 32) { t.BC = 64; t.ntiles = 1; }
     else if (Cout > 16) { t.BC = 32; t.ntiles = 1; }
     else { t.BC = 16; t.ntiles = 1; }
+    if (const int f = gcc_opt(GCC_OPT_IGEMM_FORCE_BC)) {               // tuning hook
+        if (f == 16 || f == 32 || f == 64 || f == 128) { t.BC = f; t.ntiles = cdiv(Cout, f); }
+    }
     // the plan (gcc_conv_set_plan): which tile families are allowed, minimum number of 256-pixel tiles, minimum K depth
     const int g_big_tiles = gcc_opt(GCC_OPT_IGEMM_BIG), g_big_min = gcc_opt(GCC_OPT_IGEMM_BIG_MIN),
               g_big_nk = gcc_opt(GCC_OPT_IGEMM_BIG_NK);

@@ -68,6 +68,8 @@ enum {
     GCC_OPT_INORM_LPP,          /* 0 (default): automatic lanes per pixel of the one-launch InstanceNorm */
     GCC_OPT_WGRAD_WGS_BIG,      /* workgroups a split 256x256 weight-gradient launch aims at (default 256) */
     GCC_OPT_WGRAD_WGS,          /* ... a split 128x128 weight-gradient launch (default 512) */
+    GCC_OPT_IGEMM_FORCE_BC,     /* tuning: 0 (default) automatic; 16 / 32 / 64 / 128: channel width of the 128-pixel tiles */
+    GCC_OPT_IGEMM_FORCE_KSPLIT, /* tuning: 0 (default) automatic; n >= 1: K slices of a 128-pixel-tile launch (1 = never split) */
     GCC_OPT_COUNT_
 };
 int gcc_set_option(int id, int value);

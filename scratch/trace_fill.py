@@ -1,0 +1,57 @@
+"""Chip fill over time from a rocprofv3 kernel trace of bench.py (production schedule): every running kernel contributes
+fill = min(1, workgroups / 256 CUs) (a launch with fewer workgroups than CUs cannot use the whole chip; one with more is taken
+as chip-filling), summed over the concurrently running kernels and clipped at 1.  Prints the time-weighted histogram of the
+summed fill over the last iteration(s) and, for the low-fill time, which kernels were running.
+usage: python scratch/trace_fill.py <kernel_trace.csv> [window_ms]"""
+import csv
+import sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+win = float(sys.argv[2]) if len(sys.argv) > 2 else 36.0
+
+
+def wgs(r):
+    n = 1
+    for a, b in (('Grid_Size_X', 'Workgroup_Size_X'), ('Grid_Size_Y', 'Workgroup_Size_Y'), ('Grid_Size_Z', 'Workgroup_Size_Z')):
+        g, w = int(r.get(a, 1) or 1), int(r.get(b, 1) or 1)
+        n *= max(1, (g + w - 1) // max(w, 1))
+    return n
+
+
+ev = []
+for r in rows:
+    ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), min(1.0, wgs(r) / 256.0), r['Kernel_Name'].split('(')[0][-48:], r.get('Queue_Id', '0')))
+t1 = max(e[1] for e in ev)
+cut = t1 - win * 1e6
+ev = [e for e in ev if e[0] >= cut]
+pts = []
+for i, (s, e, f, n, q) in enumerate(ev):
+    pts.append((s, 1, i))
+    pts.append((e, -1, i))
+pts.sort()
+active = set()
+hist = defaultdict(float)
+low_by = defaultdict(float)
+prev = pts[0][0]
+for t, kind, i in pts:
+    dt = t - prev
+    if dt > 0:
+        fill = min(1.0, sum(ev[j][2] for j in active))
+        b = 'idle' if not active else ('<0.25' if fill < 0.25 else '<0.5' if fill < 0.5 else '<1' if fill < 1.0 else 'full')
+        hist[b] += dt
+        if active and fill < 0.5:
+            for j in active:
+                low_by[(ev[j][3], ev[j][4])] += dt
+    prev = t
+    if kind == 1:
+        active.add(i)
+    else:
+        active.discard(i)
+tot = sum(hist.values())
+print('window %.2f ms' % (tot / 1e6))
+for b in ('idle', '<0.25', '<0.5', '<1', 'full'):
+    print('  summed fill %-6s %7.2f ms  %5.1f %%' % (b, hist[b] / 1e6, 100.0 * hist[b] / tot))
+print('kernels running while the summed fill is below 0.5 (time, queue):')
+for (n, q), t in sorted(low_by.items(), key=lambda x: -x[1])[:25]:
+    print('  %7.2f ms  q%s  %s' % (t / 1e6, q, n))
