@@ -84,11 +84,11 @@ def synthetic(batch, rank, device, size=256):
 
 
 def serialize_streams(model, engine, flag):
-    """the production schedule runs three HIP streams (student, online teacher, weight gradients): kernels of different
-    streams share the CUs, so a launch's wall duration there includes its neighbours'.  The roofline block wants the
-    kernel's own duration: the profiled steps run with everything on one stream."""
-    engine.OVERLAP_WGRAD = not flag
-    model.serialize_streams = flag
+    """the production schedule runs four HIP streams (student, online teacher, auxiliary, weight gradients): kernels of
+    different streams share the CUs, so a launch's wall duration there includes its neighbours'.  The roofline block wants
+    the kernel's own duration: the profiled step runs with everything on one stream -- and with the tile plan the library
+    uses when a launch has the chip to itself (models/_streams.py set_stream_schedule)."""
+    model.set_stream_schedule(not flag)
 
 
 def one_step(model, train, val):

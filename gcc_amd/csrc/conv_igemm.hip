@@ -328,6 +328,49 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
         }
     }
 
+    if constexpr (BP == 256 && BC == 256) {
+        if (p.pair) {
+            // Two workgroups own this tile, one per K half (in-launch split-K hand-off, cdna_hip_programming.md Guideline 16,
+            // recipe R1): write-through (sc1) slab stores, every storing wave drains, one lane publishes the flag; the other
+            // half polls that one word, one agent-scope acquire, sc1 slab loads.  a + b == b + a: the result does not
+            // depend on which half arrives first.
+            typedef __attribute__((address_space(1))) unsigned int gu32;
+            const int tile_id = (int)(blockIdx.z * gridDim.x + blockIdx.x);
+            gu32* fl = (gu32*)(p.pair_flags + 2 * tile_id);
+            int* sh = (int*)smem;                           // the loop's LDS is free: every wave passed its last barrier
+            if (tid == 0) sh[0] = (int)__hip_atomic_fetch_add(fl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int ticket = sh[0];
+            __syncthreads();
+            const __amdgpu_buffer_rsrc_t rs_slab =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(p.pair_slab + (size_t)tile_id * (BP * BC)), 0, BP * BC * 4, 0x00020000);
+            if (ticket == 0) {
+#pragma unroll
+                for (int i = 0; i < C::CB; i++)
+#pragma unroll
+                    for (int j = 0; j < C::PB; j++)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, acc[i][j]), rs_slab,
+                                                               ((i * C::PB + j) * NT + tid) * 16, 0, 16);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(fl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            if (tid == 0) {
+                while (__hip_atomic_load(fl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < C::CB; i++)
+#pragma unroll
+                for (int j = 0; j < C::PB; j++) {
+                    const f32x4 o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_slab, ((i * C::PB + j) * NT + tid) * 16, 0, 16));
+                    acc[i][j] += o;
+                }
+        }
+    }
     igemm_epilogue<C, BP, BC>(p, acc, smem, tid, lr, lq, wc, wp, m0, n0, M, Hg, Wg, ostr, py, px, mt, ks_idx, dstp);
 }
 
@@ -421,7 +464,7 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const bf16_t* __rest
 
 struct SplitPlan { int ksplit, kper; };
 // split only launches that cannot fill the chip and have a long K loop
-static SplitPlan plan_ksplit(long blocks, int nk) {
+static SplitPlan plan_ksplit(long blocks, int nk, int max_slices = 1 << 30) {
     SplitPlan sp = {1, nk};
     if (const int f = gcc_opt(GCC_OPT_IGEMM_FORCE_KSPLIT)) {          // tuning hook
         const int s = f > nk ? nk : f;
@@ -432,6 +475,7 @@ static SplitPlan plan_ksplit(long blocks, int nk) {
     if (blocks >= 128 || nk < 16) return sp;
     int s = (int)((1024 + blocks - 1) / blocks);
     if (s > nk / 4) s = nk / 4;
+    if (s > max_slices) s = max_slices;
     if (s < 2) return sp;
     sp.kper = (nk + s - 1) / s;
     sp.ksplit = (nk + sp.kper - 1) / sp.kper;
@@ -467,7 +511,7 @@ int launch(const IgemmParams& p, int phases, int batch, hipStream_t st) {
             hipLaunchKernelGGL((igemm_kernel<BP, BC, true, false>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
     }
     GCC_CHECK_LAUNCH();
-    if (p.ksplit > 1 && !p.raw_partial) {
+    if (p.ksplit > 1 && !p.raw_partial && !p.pair) {
         const size_t total = (size_t)p.rows_max * (ceil8(p.Cout) / 8);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 1024) blocks = 1024;
@@ -478,14 +522,32 @@ int launch(const IgemmParams& p, int phases, int batch, hipStream_t st) {
 }
 
 // Tile choice (shared by the launcher, gcc_conv_stat_tiles and gcc_conv_workspace).
-struct TilePlan { int BP, BC, ntiles, mtiles; };
+struct TilePlan { int BP, BC, ntiles, mtiles, max_slices, pair; };
 static TilePlan select_tile(size_t max_rows, int Cout, int phases, int nk, int batch) {
     TilePlan t;
     t.BP = 128;
+    t.max_slices = 1 << 30;
+    t.pair = 0;
     if (Cout > 64) { t.BC = 128; t.ntiles = cdiv(Cout, 128); }
     else if (Cout > 32) { t.BC = 64; t.ntiles = 1; }
     else if (Cout > 16) { t.BC = 32; t.ntiles = 1; }
     else { t.BC = 16; t.ntiles = 1; }
+    if (gcc_opt(GCC_OPT_IGEMM_NARROW) && batch == 1 && t.BC > 32) {
+        // Mid-size layers (the U-Nets at 32 x 32 .. 8 x 8): 128 x 128 tiles leave most CUs without a workgroup.  Measured
+        // per shape inside the step (profiles/r02_j, r02_m):  (a) K loop of <= 64 steps: the widest tile that still gives
+        // every CU a workgroup, un-split (one kernel instead of partials + fold + statistics);  (b) longer loops on >= 8
+        // M tiles: 64-channel tiles, K split at most 8 ways by plan_ksplit (the 128-wide plan splits 16-32 ways there:
+        // tens of MB of fp32 partials).  Smaller launches keep the 128-wide tile with its deep K split: they stream their
+        // weights cold from HBM and want every CU loading.
+        const long mt = (long)((max_rows + 127) / 128) * phases;
+        if (nk <= 64) {
+            int bc = t.BC;
+            while (bc > 32 && mt * cdiv(Cout, bc) < 256) bc >>= 1;
+            if (mt * cdiv(Cout, bc) >= 256) { t.BC = bc; t.ntiles = cdiv(Cout, bc); }
+        } else if (mt >= 8 && mt * cdiv(Cout, t.BC) < 128) {
+            t.BC = 64; t.ntiles = cdiv(Cout, 64); t.max_slices = 8;
+        }
+    }
     if (const int f = gcc_opt(GCC_OPT_IGEMM_FORCE_BC)) {               // tuning hook
         if (f == 16 || f == 32 || f == 64 || f == 128) { t.BC = f; t.ntiles = cdiv(Cout, f); }
     }
@@ -498,6 +560,8 @@ static TilePlan select_tile(size_t max_rows, int Cout, int phases, int nk, int b
         const long m256 = (long)((max_rows + 255) / 256);
         if (g_big_tiles >= 2 && Cout % 256 == 0 && m256 * (Cout / 256) * phases >= g_big_min) {
             t.BP = 256; t.BC = 256; t.ntiles = Cout / 256;
+            // fewer than ~3/4 of a chip of one-per-CU workgroups and a long loop: two workgroups per tile, one per K half
+            t.pair = (gcc_opt(GCC_OPT_IGEMM_PAIR) && m256 * (Cout / 256) * phases < 192 && nk >= 48) ? 1 : 0;
         } else if (m256 * cdiv(Cout, 128) * phases >= g_big_min) {
             t.BP = 256; t.BC = 128; t.ntiles = cdiv(Cout, 128);
         }
@@ -505,6 +569,8 @@ static TilePlan select_tile(size_t max_rows, int Cout, int phases, int nk, int b
     t.mtiles = (int)((max_rows + t.BP - 1) / t.BP);
     return t;
 }
+constexpr size_t PAIR_FLAG_BYTES = 4096;          // ticket / ready words of up to 512 tiles, a block of its own at the workspace's start
+static size_t pair_workspace(size_t tiles) { return tiles > 512 ? ~(size_t)0 : PAIR_FLAG_BYTES + tiles * (size_t)(256 * 256 * 4); }
 static int conv_nk(const gcc_conv_t* c, int dgrad) {
     const int taps_max = dgrad ? cdiv(c->KH, c->stride) * cdiv(c->KW, c->stride) : c->KH * c->KW;
     return cdiv(taps_max * ceil8(dgrad ? c->Co : c->Ci), BK);
@@ -1010,9 +1076,19 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
     p.mtiles_max = tp.mtiles;
     // ---- split-K decision (needs caller workspace; without it the launch simply is not split) ------
     p.ksplit = 1; p.kper = 0; p.partial = nullptr; p.rows_max = (int)max_rows; p.Cpad = p.ntiles * BC; p.raw_partial = 0;
+    p.pair = 0; p.pair_slab = nullptr; p.pair_flags = nullptr;
+    if (tp.pair && batch == 1 && ep && ep->workspace && (((uintptr_t)ep->workspace) & 15) == 0) {
+        const size_t tiles = (size_t)tp.mtiles * tp.ntiles * phases;
+        if (pair_workspace(tiles) <= ep->workspace_bytes) {
+            p.pair = 1; p.ksplit = 2; p.kper = cdiv(conv_nk(c, dgrad), 2);
+            p.pair_flags = (unsigned int*)ep->workspace;
+            p.pair_slab = (float*)((char*)ep->workspace + PAIR_FLAG_BYTES);
+            if (hipMemsetAsync(ep->workspace, 0, PAIR_FLAG_BYTES, st) != hipSuccess) return GCC_ERR_LAUNCH;
+        }
+    }
     float* stats_out = p.stats;
     if (batch == 1 && tp.BP == 128 && ep && ep->workspace) {
-        const SplitPlan sp = plan_ksplit((long)p.mtiles_max * p.ntiles * phases, conv_nk(c, dgrad));
+        const SplitPlan sp = plan_ksplit((long)p.mtiles_max * p.ntiles * phases, conv_nk(c, dgrad), tp.max_slices);
         const size_t need = (size_t)phases * sp.ksplit * max_rows * p.Cpad * sizeof(float);
         if (sp.ksplit > 1 && need <= ep->workspace_bytes && (((uintptr_t)ep->workspace) & 15) == 0) {
             p.ksplit = sp.ksplit; p.kper = sp.kper; p.partial = (float*)ep->workspace;
@@ -1030,7 +1106,7 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
         }
     }
     if (rc) return rc;
-    if (p.ksplit > 1 && stats_out) {
+    if (p.ksplit > 1 && stats_out && !p.pair) {
         const int tiles = p.mtiles_max * phases;
         const size_t pixels = (size_t)p.N * p.Hd * p.Wd;
         hipLaunchKernelGGL(channel_stats_kernel, dim3(ceil8(p.Cout) / 8), dim3(256), 0, st, p.dst, p.ldd, p.doff, p.Cout,
@@ -1061,8 +1137,9 @@ extern "C" size_t gcc_conv_workspace(const gcc_conv_t* c, int dgrad) {
     const size_t max_rows = conv_max_rows(c, dgrad);
     const int nk = conv_nk(c, dgrad);
     const TilePlan tp = select_tile(max_rows, dgrad ? c->Ci : c->Co, phases, nk, 1);
+    if (tp.pair) return pair_workspace((size_t)tp.mtiles * tp.ntiles * phases);
     if (tp.BP != 128) return 0;
-    const SplitPlan sp = plan_ksplit((long)tp.mtiles * tp.ntiles * phases, nk);
+    const SplitPlan sp = plan_ksplit((long)tp.mtiles * tp.ntiles * phases, nk, tp.max_slices);
     if (sp.ksplit <= 1) return 0;
     return (size_t)phases * sp.ksplit * max_rows * tp.ntiles * tp.BC * sizeof(float);
 }

@@ -34,6 +34,11 @@ struct IgemmParams {
     float* partial;
     int rows_max, Cpad;
     int raw_partial;     // leave the fp32 partial tiles to the caller (no splitk_epilogue_kernel)
+    // pair split (256 x 256 tiles that cannot fill the chip): blockIdx.y = K half; the half that finishes first parks its
+    // accumulators in `pair_slab` (register order) and signals, the other adds them and runs the epilogue
+    int pair;
+    float* pair_slab;            // [tiles][256 * 256] fp32
+    unsigned int* pair_flags;    // [tiles][2]: ticket, ready -- zeroed by the launcher before every launch
 };
 
 constexpr int BK = 64;   // k per step

@@ -12,6 +12,15 @@ import torch
 
 
 class TeacherStreamMixin:
+    def set_stream_schedule(self, concurrent):
+        """concurrent=True: the production schedule (student, online teacher, auxiliary and weight-gradient streams).
+        False: every launch on one stream -- and the library's tile plan for launches that have the chip to themselves
+        (GCC_OPT_IGEMM_PAIR: half-chip 256x256-tile launches split their K loop over two workgroups per tile)."""
+        from .. import _lib, engine, ops
+        self.serialize_streams = not concurrent
+        engine.OVERLAP_WGRAD = bool(concurrent) and os.environ.get('GCC_OVERLAP_WGRAD', '1') != '0'
+        ops.lib().gcc_set_option(_lib.OPT_IGEMM_PAIR, 0 if concurrent else 1)
+
     def _teacher_stream(self):
         if getattr(self, 'serialize_streams', False):
             return False

@@ -70,6 +70,14 @@ enum {
     GCC_OPT_WGRAD_WGS,          /* ... a split 128x128 weight-gradient launch (default 512) */
     GCC_OPT_IGEMM_FORCE_BC,     /* tuning: 0 (default) automatic; 16 / 32 / 64 / 128: channel width of the 128-pixel tiles */
     GCC_OPT_IGEMM_FORCE_KSPLIT, /* tuning: 0 (default) automatic; n >= 1: K slices of a 128-pixel-tile launch (1 = never split) */
+    GCC_OPT_IGEMM_NARROW,       /* 1 (default): 128-pixel tiles narrow to 64 / 32 channels until the launch has >= 256 workgroups, and
+                                   K is split only for loops of >= 48 steps (0: the round-1 plan) */
+    GCC_OPT_IGEMM_PAIR,         /* 1: a 256x256-tile launch of < 192 tiles with >= 48 K steps runs two workgroups per tile (one per K
+                                   half, combined inside the launch through the caller's workspace) and fills the chip by itself: the
+                                   plan for a launch that has the chip to itself (single-stream schedules; measured 0.317 against
+                                   0.281 of the bf16 peak over the step's igemm launches).  0 (default): one workgroup per tile --
+                                   less CU time per launch, the free CUs run the other streams' kernels (the multi-stream
+                                   production schedule: +1 % on the step).  gcc_amd's models switch it with their schedule. */
     GCC_OPT_COUNT_
 };
 int gcc_set_option(int id, int value);
@@ -109,7 +117,8 @@ typedef struct {
     size_t workspace_bytes;
 } gcc_epilogue_t;
 
-/* split-K scratch a fprop (dgrad=0) / dgrad (dgrad=1) launch can use; 0 when it would not split */
+/* scratch a fprop (dgrad=0) / dgrad (dgrad=1) launch can use: split-K partial tiles of small grids, or the hand-off slabs of a
+ * pair-split 256x256-tile launch; 0 when the launch needs none.  Without it the launch simply runs un-split. */
 size_t gcc_conv_workspace(const gcc_conv_t* c, int dgrad);
 
 /* number of partial-statistics rows a fprop/dgrad launch writes (one per 128-pixel tile) */

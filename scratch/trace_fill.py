@@ -19,9 +19,16 @@ def wgs(r):
     return n
 
 
+def short(n):
+    import re
+    n = n.replace('(anonymous namespace)::', '').replace('void ', '')
+    m = re.match(r'([A-Za-z_0-9:]+(<[^(]*>)?)', n)
+    return (m.group(1) if m else n)[:56]
+
+
 ev = []
 for r in rows:
-    ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), min(1.0, wgs(r) / 256.0), r['Kernel_Name'].split('(')[0][-48:], r.get('Queue_Id', '0')))
+    ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), min(1.0, wgs(r) / 256.0), short(r['Kernel_Name']), r.get('Queue_Id', '0')))
 t1 = max(e[1] for e in ev)
 cut = t1 - win * 1e6
 ev = [e for e in ev if e[0] >= cut]
@@ -55,3 +62,10 @@ for b in ('idle', '<0.25', '<0.5', '<1', 'full'):
 print('kernels running while the summed fill is below 0.5 (time, queue):')
 for (n, q), t in sorted(low_by.items(), key=lambda x: -x[1])[:25]:
     print('  %7.2f ms  q%s  %s' % (t / 1e6, q, n))
+
+cnt = defaultdict(int)
+for s_, e_, f_, n_, q_ in ev:
+    cnt[n_] += 1
+print('launches in the window: %d (%.0f per 18 ms)' % (len(ev), len(ev) * 18.0 / win))
+for n_, c_ in sorted(cnt.items(), key=lambda x: -x[1])[:40]:
+    print('  %5d  %s' % (c_, n_))
