@@ -190,6 +190,13 @@ def refresh_gate_masks(obj):
     if not gates:
         return
     alphas = [g.alpha.data for _, g in gates]
+    if getattr(obj, 'mask_cache', False):
+        # the owner promises to set mask_dirty whenever it changes an alpha through the library (arch optimizer step,
+        # clip_alpha, weight reload); writes made with torch operators show up in the tensors' version counters
+        stamp = tuple(g.alpha._version for _, g in gates) + tuple(a.data_ptr() for a in alphas)
+        if not getattr(obj, 'mask_dirty', True) and getattr(obj, '_mask_stamp', None) == stamp:
+            return
+        obj._mask_stamp, obj.mask_dirty = stamp, False
     key = tuple(a.data_ptr() for a in alphas)
     if getattr(obj, '_mask_key', None) != key:
         obj._mask_key = key

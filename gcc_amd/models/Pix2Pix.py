@@ -321,6 +321,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             # the last two hooked features are concat buffers (skip | up path): their channel dimension is split
             t_split = [0, 0, self.G.width[3], self.G.width[1]]
         self.D = engine.PatchGANEngine(self.netD, bool(opt.darts_discriminator), opt.threshold, dev)
+        self.D.mask_cache = True          # gate masks are recomputed only after alpha changed (arch step, clip, reload)
         if gdist.world_size() > 1 and os.environ.get('GCC_DP_BUCKETS', '1') != '0':
             mb = int(os.environ.get('GCC_DP_BUCKET_MB', '32'))
             if g_layout is not None:
@@ -357,6 +358,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         """re-derive the bf16 weight packings from the fp32 masters (after init / load / Adam)"""
         self.G.repack()
         self.D.repack()
+        self.D.mask_dirty = True
         for t in self.T:
             t.repack()
 
@@ -672,11 +674,13 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         self.backward_D_arch(ts)
         self._allreduce(self.optimizer_arch)
         self.optimizer_arch.step()
+        self.D.mask_dirty = True
 
     def clipping_mask_alpha(self):
         for m in self.netD.modules():
             if isinstance(m, DifferentiableOP):
                 m.clip_alpha()
+        self.D.mask_dirty = True
 
     # -- bookkeeping surface ----------------------------------------------------------------------
     def print_sparse_info(self, logger):
