@@ -312,7 +312,8 @@ int plan_splits(const gcc_conv_t* c, int batch, int* ksteps_per_split, bool* big
     // 256 x 256 tiles (one workgroup per CU): large regular outputs only, where at most ~8 pixel splits fill the chip
     const int big_mode = gcc_opt(GCC_OPT_WGRAD_BIG);
     const int tiles_big = cdiv(ncols, 256) * cdiv(c->Co, 256);
-    bool big = big_mode && batch == 1 && (c->Ci & 7) == 0 && c->Co >= 256 && ncols >= 256 && tiles_big >= 32 && ksteps >= 64;
+    bool big = big_mode && batch == 1 && (c->Ci & 7) == 0 && c->Co >= 256 && ncols >= 256 && tiles_big >= gcc_opt(GCC_OPT_WGRAD_BIG_MIN_TILES) &&
+               ksteps >= 64;
     int splits;
     if (big) {
         const int target = gcc_opt(GCC_OPT_WGRAD_WGS_BIG);

@@ -78,6 +78,7 @@ enum {
                                    0.281 of the bf16 peak over the step's igemm launches).  0 (default): one workgroup per tile --
                                    less CU time per launch, the free CUs run the other streams' kernels (the multi-stream
                                    production schedule: +1 % on the step).  gcc_amd's models switch it with their schedule. */
+    GCC_OPT_WGRAD_BIG_MIN_TILES,/* minimum number of 256x256 output tiles for the big weight-gradient tiling (default 32) */
     GCC_OPT_COUNT_
 };
 int gcc_set_option(int id, int value);

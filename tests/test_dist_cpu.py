@@ -51,7 +51,47 @@ def _worker(rank, world, port, q):
     ok_bcast = all(torch.equal(gathered[0], gg) for gg in gathered)
     md = gdist.mean_dict({'a': float(rank), 'b': 2.0}, 'cpu')
     ok_mean = abs(md['a'] - (world - 1) / 2) < 1e-12 and md['b'] == 2.0
-    q.put((rank, ok_grad, ok_bcast, ok_mean, (b, e)))
+    # bucketed reducer over a flat gradient buffer in backward-completion order (U-Net module tree on CPU): segments reported
+    # one by one launch their bucket's asynchronous all-reduce; after finish() the buffer holds the sum over ranks, exactly
+    # what one all-reduce of the whole buffer gives, and unreported segments are swept up by finish()
+    from gcc_amd import engine
+    from gcc_amd.models.Pix2Pix import UnetGenertor
+    torch.manual_seed(3)
+    net = UnetGenertor(3, 3, 6, ngf=4)
+    segs = engine.UnetEngine.grad_segments(net, 6)
+    flatp = engine.FlatParams(list(net.parameters()), 'cpu', layout=segs)
+
+    class _Opt:
+        flat = flatp
+
+        def set_grad_scale(self, s):
+            self.scale = s
+    opt_ = _Opt()
+    red = gdist.GradReducer(opt_, bucket_bytes=4 << 10)
+    gen = torch.Generator().manual_seed(100 + rank)
+    flatp.grads.copy_(torch.randn(flatp.grads.shape, generator=gen))
+    want = flatp.grads.clone()
+    dist.all_reduce(want)
+    red.begin()
+    for i in range(len(segs) - 3):               # the last three segments are never reported
+        red.segment_done(i)
+    launched_early = sum(red.launched)
+    red.finish()
+    ok_buckets = (torch.equal(flatp.grads, want) and len(red.buckets) >= 3 and 0 < launched_early < len(red.buckets)
+                  and abs(opt_.scale - 1.0 / world) < 1e-12 and all(red.launched))
+    # a second pass reuses the reducer
+    flatp.grads.copy_(torch.randn(flatp.grads.shape, generator=gen))
+    want = flatp.grads.clone()
+    dist.all_reduce(want)
+    red.begin()
+    for i in range(len(segs)):
+        red.segment_done(i)
+    red.finish()
+    ok_buckets = ok_buckets and torch.equal(flatp.grads, want)
+    t2 = torch.tensor([1.0 + rank, 2.0], dtype=torch.float32)
+    gdist.all_reduce_sum(t2)
+    ok_buckets = ok_buckets and t2.tolist() == [3.0, 4.0]
+    q.put((rank, ok_grad, ok_bcast, ok_mean and ok_buckets, (b, e)))
     dist.barrier()
     dist.destroy_process_group()
 
