@@ -225,6 +225,52 @@ class HipAdam(torch.optim.Optimizer):
             self.plan_dup.step(g['lr'], g['betas'], g['eps'])
 
 
+# host-enqueue scheduling: alternate the chunks of two generators (GCC_INTERLEAVE=0: teacher first, then the student)
+# GCC_INTERLEAVE: 0 (default) the teacher's whole iteration is enqueued first, then the student's; 1 alternate chunk by chunk;
+# n >= 2 alternate the first n chunks only.  Measured (profiles/r02_ab_tables.md): every interleaving is 3.5-6 % SLOWER -- the
+# teacher's iteration is the critical path (its end gates the student's backward_G) and both networks' discriminator passes
+# fill the chip, so work given to the student early only delays the teacher.
+INTERLEAVE = int(os.environ.get('GCC_INTERLEAVE', '0'))
+
+
+def _step(gen, stream):
+    """one chunk of `gen` with `stream` current (None: the current stream); False when the generator is exhausted"""
+    try:
+        if stream:
+            with torch.cuda.stream(stream):
+                next(gen)
+        else:
+            next(gen)
+        return True
+    except StopIteration:
+        return False
+
+
+def _drain(gen, stream):
+    if stream:
+        with torch.cuda.stream(stream):
+            for _ in gen:
+                pass
+    else:
+        for _ in gen:
+            pass
+
+
+def _alternate(tgen, ts, sgen):
+    """teacher chunk, student chunk, ... until both are exhausted (tgen may be None)"""
+    t_alive, s_alive = tgen is not None, sgen is not None
+    n = 0
+    while t_alive or s_alive:
+        if t_alive:
+            t_alive = _step(tgen, ts)
+        n += 1
+        if INTERLEAVE >= 2 and n >= INTERLEAVE and t_alive:
+            _drain(tgen, ts)
+            t_alive = False
+        if s_alive:
+            s_alive = _step(sgen, None)
+
+
 # ------------------------------------------------------------------------------------------------
 class Pix2PixModel(TeacherStreamMixin, nn.Module):
 
@@ -475,15 +521,24 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
 
     # -- D step (models/Pix2Pix.py:464-477) --------------------------------------------------------
     def backward_D(self):
+        for _ in self._backward_D_steps():
+            pass
+
+    def _backward_D_steps(self):
+        """backward_D in host-enqueue chunks (one discriminator pass each): the iteration's scheduler alternates the
+        chunks of the student with those of the online teacher, so that both streams have work queued at the same time"""
         mode = self.opt.gan_mode
         early = 'd_real' in getattr(self, '_early', {})
         cf = self._d_forward('d_fake', self._fake, refresh=not early)
+        yield
         cr = self._take_real_pass('d_real')
         gp = self.D.grad_pred_buffer(cf)
         if self.optimizer_D.reducer is not None:
             self.optimizer_D.reducer.begin()
         ops.gan_loss(mode, cf.pred, False, True, self._l('D_fake'), dpred=gp, grad_weight=0.5)
+        yield
         self.D.backward(cf, wgrad=True, need_dx=False)
+        yield
         ops.gan_loss(mode, cr.pred, True, True, self._l('D_real'), dpred=gp, grad_weight=0.5)
         self.D.reduce_now = True             # the second pass completes the gradients: its finished layers are exchanged
         self.D.backward(cr, wgrad=True, need_dx=False)
@@ -493,14 +548,26 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
     def backward_G(self, ts=None):
         """ts: the online teacher's stream -- joined only where its features are first read (the student's own GAN / L1
         terms and the discriminator's data gradient do not depend on it)"""
+        for _ in self._backward_G_head_steps():
+            pass
+        self._backward_G_tail(ts)
+
+    def _backward_G_head_steps(self):
+        """the part of backward_G that does not read the teacher: D(fake) with the updated discriminator, the GAN / L1
+        terms and the discriminator's data gradient"""
         opt, mode = self.opt, self.opt.gan_mode
         gc = self._gctx
         cg = self._d_forward('g_fake', self._fake)
         self._dctx_g = cg
         ops.gan_loss(mode, cg.pred, True, False, self._l('G_GAN'), dpred=self.D.grad_pred_buffer(cg))
+        yield
         dx = self.D.backward(cg, wgrad=False, need_dx=True)
         ops.l1_loss(self._fake, self._B, self._l('G_L1'), weight=opt.lambda_L1, da=gc.g_out)
         ops.nhwc_add(dx, 3, gc.g_out, 0, 3)
+
+    def _backward_G_tail(self, ts=None):
+        opt = self.opt
+        gc = self._gctx
         g_feat = None
         if self.optimizer_G.reducer is not None:
             self.optimizer_G.reducer.begin()
@@ -555,36 +622,62 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
 
     # -- one iteration (models/Pix2Pix.py:565-583) ----------------------------------------------------
     def optimize_parameters(self):
+        """models/Pix2Pix.py:565-583.  The online teacher's whole iteration (its own stream) is enqueued first, then the
+        student's forward + discriminator step + the teacher-independent head of backward_G; both are generators of
+        host-enqueue chunks so that the order can be chosen (GCC_INTERLEAVE, see above: teacher first is the fastest)."""
         self.finish_G_update()
-        ts = None
+        ts, tgen = None, None
         if self.opt.online_distillation:
             T = self.teacher_model
             T._defer_G_update = True
             ts = self._teacher_stream()
             if ts:
                 self._release_teacher_stream(ts)                 # after the last launch that reads the teacher's buffers
-                with torch.cuda.stream(ts):
-                    T.set_input(self.input)
-                    T.optimize_parameters()
-            else:
-                T.set_input(self.input)
-                T.optimize_parameters()
+            tgen = T._iteration_steps(self.input)
+            if not ts or not INTERLEAVE:
+                _drain(tgen, ts)
+                tgen = None
+        sgen = self._pre_join_steps()
+        _alternate(tgen, ts, sgen)
+        if self.opt.online_distillation:
             # the reference clones; here the teacher's activation buffers of this iteration are
             # simply not overwritten before the student consumes them (separate contexts)
-            self.target_distillation_features = T.get_distillation_features()
-        self._start_real_pass('d_real')
-        self.forward()
-        self.optimizer_D.zero_grad()
-        self.backward_D()
-        self._allreduce(self.optimizer_D)
-        self.optimizer_D.step()
-        self.D.repack()
-        self.optimizer_G.zero_grad()
-        self.backward_G(ts)
+            self.target_distillation_features = self.teacher_model.get_distillation_features()
+        self._backward_G_tail(ts)
         if self._defer_G_update and self._world > 1:
             # online teacher under data parallelism: its generator is not read again before the arch
             # step, so its (largest, 218 MB) gradient bucket is reduced while the student's whole
             # iteration runs; finish_G_update() applies it.  Same arithmetic, later in stream order.
+            self._pending_G = self.optimizer_G.reducer or gdist.all_reduce_grads(self.optimizer_G, async_op=True)
+            return
+        self._allreduce(self.optimizer_G)
+        self._apply_G_update()
+
+    def _pre_join_steps(self):
+        """the student's iteration up to the point where the teacher's features are first read"""
+        self._start_real_pass('d_real')
+        yield
+        self.forward()
+        yield
+        self.optimizer_D.zero_grad()
+        yield from self._backward_D_steps()
+        self._allreduce(self.optimizer_D)
+        self.optimizer_D.step()
+        self.D.repack()
+        self.optimizer_G.zero_grad()
+        yield
+        yield from self._backward_G_head_steps()
+
+    def _iteration_steps(self, input):
+        """set_input + optimize_parameters of a model without a teacher of its own (the online teacher), as host-enqueue
+        chunks for the student's scheduler"""
+        self.set_input(input)
+        self.finish_G_update()
+        yield
+        yield from self._pre_join_steps()
+        yield
+        self._backward_G_tail(None)
+        if self._defer_G_update and self._world > 1:
             self._pending_G = self.optimizer_G.reducer or gdist.all_reduce_grads(self.optimizer_G, async_op=True)
             return
         self._allreduce(self.optimizer_G)
@@ -656,17 +749,30 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
     def optimizer_netD_arch(self):
         T = self.teacher_model
         ts = self._teacher_stream()
+
+        def teacher_part():
+            T.finish_G_update()
+            T.set_input(self.input)
+            yield
+            T.forward()
+            yield
+            T.get_D_arch_diff(isTeacher=True)
+
+        def student_part():
+            if ts:
+                self._start_real_pass('a_real')
+                yield
+            self.forward()
+
         if ts:
             self._release_teacher_stream(ts)
-            with torch.cuda.stream(ts):
-                T.finish_G_update()
-                T.set_input(self.input)
-                T.forward()
-                T.get_D_arch_diff(isTeacher=True)
-            self._start_real_pass('a_real')
-            self.forward()
+            tgen = teacher_part()
+            if not INTERLEAVE:
+                _drain(tgen, ts)
+                tgen = None
+            _alternate(tgen, ts, student_part())
         else:
-            self.forward()
+            _drain(student_part(), None)
             T.finish_G_update()
             T.set_input(self.input)
             T.forward()

@@ -27,6 +27,7 @@ profdefault)
   python scratch/trace_waits.py $f > $out/trace_waits_default.txt 2>&1
   python scratch/trace_summary.py $f > $out/trace_summary_default.txt 2>&1
   python scratch/trace_fill.py $f > $out/trace_fill_default.txt 2>&1
+  python scratch/trace_timeline.py $f 22 100 > $out/trace_timeline_default.txt 2>&1
   rm -f $f;;
 shapes)
   GCC_PROFILE_SHAPES=1 timeout 600 python bench.py --steps 3 --warmup 3 --no-cpu-baseline > $out/shapes.json 2> $out/shapes.txt; grep -c . $out/shapes.txt;;
