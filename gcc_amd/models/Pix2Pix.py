@@ -231,6 +231,11 @@ class HipAdam(torch.optim.Optimizer):
 # teacher's iteration is the critical path (its end gates the student's backward_G) and both networks' discriminator passes
 # fill the chip, so work given to the student early only delays the teacher.
 INTERLEAVE = int(os.environ.get('GCC_INTERLEAVE', '0'))
+TEACHER_EARLY_DREAL = os.environ.get('GCC_TEACHER_EARLY_DREAL', '0') == '1'      # measured: -7 % (a fifth busy queue); off
+# the student joins the teacher's stream where the teacher's features and discriminator are final (after the head of the
+# teacher's backward_G), not at the end of the teacher's iteration: the teacher's generator backward + Adam + repack
+# (small and HBM-bound kernels) then run beside the student's distillation passes instead of in front of them
+EARLY_JOIN = os.environ.get('GCC_EARLY_JOIN', '1') != '0'
 
 
 def _step(gen, stream):
@@ -476,7 +481,9 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         streams idle half the time).  The pass keeps its place in the reference's order for everything that is order
         dependent: its BatchNorm running-statistics updates are applied in _take_real_pass(), after D(fake)'s."""
         self._early = getattr(self, '_early', {})
-        aux = self._aux_stream() if self.teacher_model is not None else False
+        # the student always; the online teacher only with GCC_TEACHER_EARLY_DREAL=1 (measured: 833 against 893 images/s)
+        is_teacher = self.teacher_model is None
+        aux = self._aux_stream() if (not is_teacher or (TEACHER_EARLY_DREAL and getattr(self, '_is_online_teacher', False))) else False
         if not aux:
             return
         main = torch.cuda.current_stream()
@@ -572,7 +579,11 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         if self.optimizer_G.reducer is not None:
             self.optimizer_G.reducer.begin()
         if ts:
-            torch.cuda.current_stream().wait_stream(ts)
+            ev = getattr(self.teacher_model, '_head_done', None) if EARLY_JOIN else None
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+            else:
+                torch.cuda.current_stream().wait_stream(ts)
         if self.distill:
             T = self.teacher_model
             # teacher D (train mode, frozen) on the student's fake: features for the last two terms (:531-533)
@@ -630,6 +641,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         if self.opt.online_distillation:
             T = self.teacher_model
             T._defer_G_update = True
+            T._is_online_teacher = True
             ts = self._teacher_stream()
             if ts:
                 self._release_teacher_stream(ts)                 # after the last launch that reads the teacher's buffers
@@ -675,6 +687,10 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         self.finish_G_update()
         yield
         yield from self._pre_join_steps()
+        # everything a student reads from this model is final here: the generator's features (forward), the discriminator's
+        # weights (its Adam step + repack) and features (the D(fake) pass of backward_G's head)
+        self._head_done = torch.cuda.Event()
+        self._head_done.record(torch.cuda.current_stream())
         yield
         self._backward_G_tail(None)
         if self._defer_G_update and self._world > 1:

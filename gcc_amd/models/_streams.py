@@ -18,6 +18,8 @@ class TeacherStreamMixin:
         (GCC_OPT_IGEMM_PAIR: half-chip 256x256-tile launches split their K loop over two workgroups per tile)."""
         from .. import _lib, engine, ops
         self.serialize_streams = not concurrent
+        if getattr(self, 'teacher_model', None) is not None:
+            self.teacher_model.serialize_streams = not concurrent
         engine.OVERLAP_WGRAD = bool(concurrent) and os.environ.get('GCC_OVERLAP_WGRAD', '1') != '0'
         ops.lib().gcc_set_option(_lib.OPT_IGEMM_PAIR, 0 if concurrent else 1)
 

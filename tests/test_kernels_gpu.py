@@ -78,7 +78,8 @@ CONV_CASES = [
 
 # fprop / dgrad tile plans (include/gcc_hip.h gcc_conv_set_plan): every geometry runs on every tile family it can be
 # routed to -- the default plan picks the 256-pixel tiles only for chip-filling grids, which small test cases never are
-PLANS = {'default': (-1, -1, -1), 'tile128': (0, -1, -1), 'tile256x128': (1, 1, 1), 'tile256x256': (2, 1, 1)}
+PLANS = {'default': (-1, -1, -1), 'tile128': (0, -1, -1), 'tile256x128': (1, 1, 1), 'tile256x256': (2, 1, 1),
+         'tile256x256_pair': (2, 1, 1)}        # + GCC_OPT_IGEMM_PAIR: two workgroups per tile, K halves combined inside the launch
 
 
 def _tiles(case):
@@ -94,8 +95,14 @@ def conv_plan(request):
     from gcc_amd import _lib
     lib = _lib.load()
     lib.gcc_conv_set_plan(-1, -1, -1)
-    yield lambda name: lib.gcc_conv_set_plan(*PLANS[name])
+    lib.gcc_set_option(_lib.OPT_IGEMM_PAIR, -1)
+
+    def choose(name):
+        lib.gcc_conv_set_plan(*PLANS[name])
+        lib.gcc_set_option(_lib.OPT_IGEMM_PAIR, 1 if name.endswith('_pair') else -1)
+    yield choose
     lib.gcc_conv_set_plan(-1, -1, -1)
+    lib.gcc_set_option(_lib.OPT_IGEMM_PAIR, -1)
 
 
 @pytest.mark.parametrize('plan', list(PLANS))
@@ -108,6 +115,8 @@ def test_conv_fprop_dgrad_wgrad(case, plan, conv_plan):
     tiles = _tiles(case)
     if plan != 'default' and tiles == base_tiles:
         pytest.skip('plan %s routes this geometry to the default tiles %s' % (plan, tiles))
+    if plan.endswith('_pair') and 256256 not in tiles:
+        pytest.skip('no 256x256 tiles for this geometry: nothing to pair')
     print('plan %s: fprop tile %d, dgrad tile %d' % (plan, tiles[0], tiles[1]))
     g = torch.Generator().manual_seed(hash(case) % 1000)
     x = rb(torch.randn(N, Ci, H, W, generator=g))
@@ -166,11 +175,24 @@ TRUE_SHAPES = {
 }
 
 
+@pytest.mark.parametrize('pair', [0, 1])
 @pytest.mark.parametrize('name', list(TRUE_SHAPES))
-def test_conv_true_shapes_default_plan(name):
+def test_conv_true_shapes_default_plan(name, pair):
+    """pair = 1: the single-stream plan (what bench.py's bracketed roofline step and --serialize-streams run): half-chip 256x256
+    launches (PatchGAN L3 forward, L4 data gradient) split K over two workgroups per tile"""
     ops = _ops()
     from gcc_amd import _lib
+    if pair and name not in ('patchgan_L3', 'patchgan_L4'):
+        pytest.skip('no half-chip 256x256 launch in this layer')
     _lib.load().gcc_conv_set_plan(-1, -1, -1)
+    _lib.load().gcc_set_option(_lib.OPT_IGEMM_PAIR, pair)
+    try:
+        _true_shape_case(ops, name)
+    finally:
+        _lib.load().gcc_set_option(_lib.OPT_IGEMM_PAIR, -1)
+
+
+def _true_shape_case(ops, name):
     case = TRUE_SHAPES[name]
     N, H, W, Ci, Co, k, s, p = case
     tiles = _tiles(case)
