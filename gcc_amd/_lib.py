@@ -30,6 +30,12 @@ class bnact_t(C.Structure):
                 ('seed', C.c_uint64), ('groups', C.c_int), ('ld_residual', C.c_int), ('residual', C.c_void_p)]
 
 
+class bn_t(C.Structure):
+    _fields_ = [('gamma', C.c_void_p), ('beta', C.c_void_p), ('eps', C.c_float), ('momentum', C.c_float), ('count', C.c_double),
+                ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p),
+                ('scale', C.c_void_p), ('shift', C.c_void_p)]
+
+
 class bnact_bwd_t(C.Structure):
     _fields_ = [('bn', C.c_int), ('bn_eval', C.c_int), ('mean', C.c_void_p), ('rstd', C.c_void_p),
                 ('gamma', C.c_void_p), ('beta', C.c_void_p), ('gate', C.c_void_p), ('gate_after_act', C.c_int),
@@ -60,7 +66,7 @@ class adam_chunk_t(C.Structure):
 # gcc_set_option ids (enum in include/gcc_hip.h)
 (OPT_IGEMM_BIG, OPT_IGEMM_BIG_MIN, OPT_IGEMM_BIG_NK, OPT_IGEMM_GLDS, OPT_IGEMM_HEAD, OPT_IGEMM_THIN, OPT_WGRAD_BIG,
  OPT_BN_SWEEPS, OPT_BN_MAXBLK, OPT_BN_REDUCE_THREADS, OPT_BN_REDUCE_CAP, OPT_INORM_LPP, OPT_WGRAD_WGS_BIG,
- OPT_WGRAD_WGS, OPT_IGEMM_FORCE_BC, OPT_IGEMM_FORCE_KSPLIT, OPT_IGEMM_NARROW, OPT_IGEMM_PAIR, OPT_WGRAD_BIG_MIN_TILES) = range(19)
+ OPT_WGRAD_WGS, OPT_IGEMM_FORCE_BC, OPT_IGEMM_FORCE_KSPLIT, OPT_IGEMM_NARROW, OPT_IGEMM_PAIR, OPT_WGRAD_BIG_MIN_TILES, OPT_FUSE_BN) = range(20)
 
 _P = C.c_void_p
 _I = C.c_int
@@ -102,6 +108,8 @@ PROTOTYPES = {
     'gcc_dwconv3x3_reflect_wgrad': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
     'gcc_bn_eval_coeffs': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     'gcc_bnact_fwd': (_I, [C.POINTER(bnact_t), _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _Z, _P]),
+    'gcc_conv_bn_act_workspace': (_Z, [C.POINTER(conv_t), _I]),
+    'gcc_conv_bn_act': (_I, [C.POINTER(conv_t), _I, _P, _P, _P, C.POINTER(bn_t), C.POINTER(bnact_t), _P, _I, _I, _P, _I, _I, _P, _Z, _P]),
     'gcc_bnact_bwd_workspace': (_Z, [_I, _Z]),
     'gcc_bnact_bwd': (_I, [C.POINTER(bnact_bwd_t), _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I,
                            _I, _Z, _P, _Z, _P]),

@@ -1130,6 +1130,227 @@ extern "C" int gcc_conv_route(const gcc_conv_t* c, int dgrad, const gcc_epilogue
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv + BatchNorm(training) + activation in one call (include/gcc_hip.h gcc_conv_bn_act)
+namespace gcc_igemm {
+struct FoldBnArgs {
+    IgemmParams p;                 // geometry of the split launch (partial, ksplit, rows_max, Cpad, dst = raw output)
+    gcc_bn_t bn;
+    int act, act2; float slope, drop_p; uint64_t seed;
+    bf16_t* y; int ldy, yoff;
+    bf16_t* y2; int ldy2, y2off;
+    int phases;
+};
+// one workgroup per 8 output channels, every row of them: fold the K slices (bf16-rounded raw output, kept for the backward
+// pass), f64 statistics of the rounded values, finalize (as bn_finalize_kernel), normalise + dropout + activation(s) (as
+// bnact_fwd_kernel: same affine form, same dropout counter pix * C + channel, so the backward pass regenerates the mask)
+__global__ __launch_bounds__(256) void splitk_bn_act_kernel(const FoldBnArgs a) {
+    __shared__ double red[4][16];
+    __shared__ float coef[16];
+    const IgemmParams& p = a.p;
+    const int c0 = blockIdx.x * 8;
+    const int C = p.Cout;
+    const size_t sstride = (size_t)p.rows_max * p.Cpad;
+    double s[8], ss[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] = ss[j] = 0.0;
+    for (int z = 0; z < a.phases; z++) {
+        int py = 0, px = 0, Hg, Wg, ostr = 1;
+        if (!p.dgrad) { Hg = p.Hd; Wg = p.Wd; }
+        else {
+            const int st = p.stride;
+            py = z / st; px = z % st; ostr = st;
+            Hg = (p.Hd - py + st - 1) / st; Wg = (p.Wd - px + st - 1) / st;
+        }
+        const int M = p.N * Hg * Wg;
+        const float* base = p.partial + (size_t)z * p.ksplit * sstride;
+        for (int m = threadIdx.x; m < M; m += 256) {
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const float* r0 = base + (size_t)m * p.Cpad + c0;
+            for (int sl = 0; sl < p.ksplit; sl++) {
+                const f32x4 u = *(const f32x4*)(r0 + sl * sstride), w = *(const f32x4*)(r0 + sl * sstride + 4);
+                v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+                v[4] += w[0]; v[5] += w[1]; v[6] += w[2]; v[7] += w[3];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (c0 + j >= C) v[j] = 0.f;
+            const i32x4 pk = pack8(v);
+            float r[8];
+            unpack8(pk, r);
+#pragma unroll
+            for (int j = 0; j < 8; j++) { s[j] += (double)r[j]; ss[j] += (double)r[j] * (double)r[j]; }
+            const int n = m / (Hg * Wg);
+            const int rr = m - n * (Hg * Wg);
+            const int oy = rr / Wg, ox = rr - oy * Wg;
+            const size_t pix = (size_t)(n * p.Hd + oy * ostr + py) * p.Wd + (ox * ostr + px);
+            *(i32x4*)(p.dst + pix * p.ldd + p.doff + c0) = pk;
+        }
+    }
+    // block reduction: wave shuffles, then the four waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s[j] += __shfl_xor(s[j], o, 64); ss[j] += __shfl_xor(ss[j], o, 64); }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) { red[wave][j] = s[j]; red[wave][8 + j] = ss[j]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int j = threadIdx.x, c = c0 + j;
+        float sc = 1.f, sf = 0.f;
+        if (c < C) {
+            const double sum = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+            const double sq = (red[0][8 + j] + red[1][8 + j]) + (red[2][8 + j] + red[3][8 + j]);
+            const double mean = sum / a.bn.count;
+            double var = sq / a.bn.count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float r = (float)(1.0 / sqrt(var + (double)a.bn.eps));
+            const float g = a.bn.gamma ? a.bn.gamma[c] : 1.f, b = a.bn.beta ? a.bn.beta[c] : 0.f;
+            if (a.bn.mean) a.bn.mean[c] = (float)mean;
+            if (a.bn.rstd) a.bn.rstd[c] = r;
+            sc = g * r;
+            sf = b - (float)mean * g * r;
+            a.bn.scale[c] = sc;
+            a.bn.shift[c] = sf;
+            if (a.bn.running_mean) a.bn.running_mean[c] = (1.f - a.bn.momentum) * a.bn.running_mean[c] + a.bn.momentum * (float)mean;
+            if (a.bn.running_var) {
+                const double unb = a.bn.count > 1.0 ? var * a.bn.count / (a.bn.count - 1.0) : var;
+                a.bn.running_var[c] = (1.f - a.bn.momentum) * a.bn.running_var[c] + a.bn.momentum * (float)unb;
+            }
+        }
+        coef[j] = sc; coef[8 + j] = sf;
+    }
+    __syncthreads();
+    float sc[8], sf[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { sc[j] = coef[j]; sf[j] = coef[8 + j]; }
+    const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const size_t pixels = (size_t)p.N * p.Hd * p.Wd;
+    // second pass over the raw output: every thread re-reads exactly the pixels it wrote itself
+    for (int z = 0; z < a.phases; z++) {
+        int py = 0, px = 0, Hg, Wg, ostr = 1;
+        if (!p.dgrad) { Hg = p.Hd; Wg = p.Wd; }
+        else {
+            const int st = p.stride;
+            py = z / st; px = z % st; ostr = st;
+            Hg = (p.Hd - py + st - 1) / st; Wg = (p.Wd - px + st - 1) / st;
+        }
+        const int M = p.N * Hg * Wg;
+        for (int m = threadIdx.x; m < M; m += 256) {
+            const int n = m / (Hg * Wg);
+            const int rr = m - n * (Hg * Wg);
+            const int oy = rr / Wg, ox = rr - oy * Wg;
+            const size_t pix = (size_t)(n * p.Hd + oy * ostr + py) * p.Wd + (ox * ostr + px);
+            float v[8], o1[8], o2[8];
+            unpack8(*(const i32x4*)(p.dst + pix * p.ldd + p.doff + c0), v);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = v[j] * sc[j] + sf[j];
+            if (a.drop_p > 0.f) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float u = rng_uniform(a.seed, pix * (size_t)C + c0 + j);
+                    v[j] = u >= a.drop_p ? v[j] * keep_scale : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (c0 + j >= C) v[j] = 0.f;       // pad channels stay exact zeros
+            apply_act8(v, o1, a.act, a.slope);
+            if (a.y) *(i32x4*)(a.y + pix * a.ldy + a.yoff + c0) = pack8(o1);
+            if (a.y2) {
+                apply_act8(v, o2, a.act2, a.slope);
+                *(i32x4*)(a.y2 + pix * a.ldy2 + a.y2off + c0) = pack8(o2);
+            }
+        }
+    }
+    (void)pixels;
+}
+constexpr size_t FOLD_BN_MAX_ROWS = 4096;      // rows (all phases) a 256-thread workgroup walks twice
+}  // namespace gcc_igemm
+
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+extern "C" size_t gcc_conv_workspace(const gcc_conv_t* c, int dgrad);
+extern "C" int gcc_conv_stat_tiles(const gcc_conv_t* c, int dgrad);
+extern "C" size_t gcc_conv_bn_act_workspace(const gcc_conv_t* c, int dgrad) {
+    if (check_conv(c)) return 0;
+    const int Cout = dgrad ? c->Ci : c->Co;
+    return al256(gcc_conv_workspace(c, dgrad)) + al256((size_t)gcc_conv_stat_tiles(c, dgrad) * 2 * Cout * sizeof(float));
+}
+
+extern "C" int gcc_conv_bn_act(const gcc_conv_t* c, int dgrad, const void* x, const void* w, void* y_raw, const gcc_bn_t* bn,
+                               const gcc_bnact_t* act, void* y, int ldy, int yoff, void* y2, int ldy2, int y2off, void* ws,
+                               size_t ws_bytes, gcc_stream_t stream) {
+    GCC_ENTER();
+    int rc = check_conv(c);
+    if (rc) return rc;
+    if (!x || !w || !y_raw || !bn || !act || (!y && !y2) || !bn->scale || !bn->shift || bn->count <= 0 || !ws) return GCC_ERR_BAD_ARG;
+    if ((y && ((ldy & 7) || (yoff & 7))) || (y2 && ((ldy2 & 7) || (y2off & 7)))) return GCC_ERR_BAD_ARG;
+    if (ws_bytes < gcc_conv_bn_act_workspace(c, dgrad) || (((uintptr_t)ws) & 15)) return GCC_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int Cout = dgrad ? c->Ci : c->Co;
+    const int phases = dgrad ? c->stride * c->stride : 1;
+    const size_t split_bytes = al256(gcc_conv_workspace(c, dgrad));
+    float* stats = (float*)((char*)ws + split_bytes);
+    const int Ho = gcc_conv_out(c->H, c->KH, c->stride, c->pad), Wo = gcc_conv_out(c->W, c->KW, c->stride, c->pad);
+    const size_t out_pixels = dgrad ? (size_t)c->N * c->H * c->W : (size_t)c->N * Ho * Wo;
+    const int out_ld = dgrad ? c->ldx : c->ldy, out_off = dgrad ? c->xoff : c->yoff;
+    // which plan would the conv take?  (same predicates as gcc_internal_igemm)
+    const size_t max_rows = conv_max_rows(c, dgrad);
+    const int nk = conv_nk(c, dgrad);
+    const TilePlan tp = select_tile(max_rows, Cout, phases, nk, 1);
+    const SplitPlan sp = tp.BP == 128 ? plan_ksplit((long)tp.mtiles * tp.ntiles * phases, nk, tp.max_slices) : SplitPlan{1, nk};
+    const bool routed = (dgrad && thin_dgrad_shape(c)) || (!dgrad && thin_shape(c)) || head_shape(c);
+    if (!routed && sp.ksplit > 1 && max_rows * phases <= FOLD_BN_MAX_ROWS && gcc_opt(GCC_OPT_FUSE_BN)) {
+        // split launch with raw partial tiles, then the fused fold + statistics + finalize + normalise kernel
+        FoldBnArgs a;
+        IgemmParams& p = a.p;
+        p.src = (const bf16_t*)x; p.wgt = (const bf16_t*)w; p.dst = (bf16_t*)y_raw; p.bias = nullptr; p.stats = nullptr;
+        p.act = GCC_ACT_NONE; p.slope = 0.f;
+        p.N = c->N; p.KH = c->KH; p.KW = c->KW; p.stride = c->stride; p.pad = c->pad; p.dgrad = dgrad;
+        if (!dgrad) {
+            p.Hs = c->H; p.Ws = c->W; p.lds_ = c->ldx; p.soff = c->xoff; p.Hd = Ho; p.Wd = Wo; p.ldd = c->ldy; p.doff = c->yoff;
+            p.Ct = ceil8(c->Ci); p.Cout = c->Co;
+        } else {
+            p.Hs = Ho; p.Ws = Wo; p.lds_ = c->ldy; p.soff = c->yoff; p.Hd = c->H; p.Wd = c->W; p.ldd = c->ldx; p.doff = c->xoff;
+            p.Ct = ceil8(c->Co); p.Cout = c->Ci;
+            if (c->KH < c->stride || c->KW < c->stride) return GCC_ERR_UNSUPPORTED;
+        }
+        p.ldw = c->KH * c->KW * p.Ct;
+        const size_t sb = (size_t)p.N * p.Hs * p.Ws * p.lds_ * 2, wb = (size_t)p.Cout * p.ldw * 2;
+        if (sb >= OOB || wb >= OOB) return GCC_ERR_UNSUPPORTED;
+        p.src_bytes = (uint32_t)sb; p.wgt_bytes = (uint32_t)wb;
+        p.src_bstride = p.wgt_bstride = p.dst_bstride = 0;
+        p.ntiles = tp.ntiles; p.mtiles_max = tp.mtiles;
+        p.ksplit = sp.ksplit; p.kper = sp.kper; p.partial = (float*)ws; p.rows_max = (int)max_rows; p.Cpad = tp.ntiles * tp.BC;
+        p.raw_partial = 1; p.pair = 0; p.pair_slab = nullptr; p.pair_flags = nullptr;
+        if ((size_t)phases * sp.ksplit * max_rows * p.Cpad * sizeof(float) > split_bytes) return GCC_ERR_WORKSPACE;
+        switch (tp.BC) {
+            case 128: rc = launch<128, 128>(p, phases, 1, st); break;
+            case 64: rc = launch<128, 64>(p, phases, 1, st); break;
+            case 32: rc = launch<128, 32>(p, phases, 1, st); break;
+            default: rc = launch<128, 16>(p, phases, 1, st); break;
+        }
+        if (rc) return rc;
+        a.bn = *bn; a.act = act->act; a.act2 = act->act2; a.slope = act->slope; a.drop_p = act->drop_p; a.seed = act->seed;
+        a.y = (bf16_t*)y; a.ldy = ldy; a.yoff = yoff; a.y2 = (bf16_t*)y2; a.ldy2 = ldy2; a.y2off = y2off; a.phases = phases;
+        hipLaunchKernelGGL(splitk_bn_act_kernel, dim3(ceil8(Cout) / 8), dim3(256), 0, st, a);
+        GCC_CHECK_LAUNCH();
+        return GCC_OK;
+    }
+    // ordinary path: conv with statistics in its epilogue, finalize, normalise -- one call, three to five launches
+    gcc_epilogue_t ep = {nullptr, GCC_ACT_NONE, 0.f, stats, split_bytes ? ws : nullptr, split_bytes};
+    rc = gcc_internal_igemm(c, dgrad, x, w, y_raw, &ep, 1, 0, 0, 0, st);
+    if (rc) return rc;
+    rc = gcc_bn_finalize(stats, gcc_conv_stat_tiles(c, dgrad), Cout, bn->count, bn->gamma, bn->beta, bn->eps, bn->momentum,
+                         bn->running_mean, bn->running_var, bn->mean, bn->rstd, bn->scale, bn->shift, stream);
+    if (rc) return rc;
+    gcc_bnact_t q = *act;
+    q.scale = bn->scale; q.shift = bn->shift; q.gate = nullptr; q.gate_after_act = 0; q.groups = 1; q.residual = nullptr; q.ld_residual = 0;
+    return gcc_bnact_fwd(&q, y_raw, out_ld, out_off, y, ldy, yoff, y2, ldy2, y2off, Cout, out_pixels, stream);
+}
+
 extern "C" size_t gcc_conv_workspace(const gcc_conv_t* c, int dgrad) {
     if (check_conv(c)) return 0;
     if (head_shape(c) && !dgrad) return head_fprop_workspace(c, nullptr);

@@ -21,6 +21,8 @@ from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH
 LRELU = 0.2
 # run weight-gradient kernels on a side stream, concurrently with the data-gradient / BN chain
 OVERLAP_WGRAD = os.environ.get('GCC_OVERLAP_WGRAD', '1') != '0'
+# U-Net layers as one C call (gcc_conv_bn_act): conv + BatchNorm statistics + finalize + normalise / activation
+FUSE_CONV_BN = os.environ.get('GCC_FUSE_CONV_BN', '1') != '0'
 
 
 # ------------------------------------------------------------------------------------------------
@@ -120,6 +122,13 @@ class ConvOp:
         N, _, H, W = out.shape
         return ops.conv_dgrad(x, self.wt, self.cols_k, H, W, self.k, self.stride, self.pad, out=out, bias=b, act=act,
                               slope=LRELU, want_stats=want_stats)
+
+    def forward_bn_act(self, x, raw, bnop, st, count, y, y2=None, act=ACT_NONE, act2=ACT_NONE, drop_p=0.0, seed=0):
+        """conv + BatchNorm (training statistics) + activation [+ dropout, + second activated copy] as one C call"""
+        w, dgrad = (self.wt, True) if self.transposed else (self.w, False)
+        ops.conv_bn_act(dgrad, x, w, raw, self.k, self.stride, self.pad, bnop.bn, st, count, y, y2, act=act, act2=act2,
+                        slope=LRELU, drop_p=drop_p, seed=seed)
+        bnop.pending_batches += 1
 
     # -- gradient w.r.t. the layer input ------------------------------------------------------
     def backward_data(self, dy, out):
@@ -378,9 +387,15 @@ class UnetEngine:
         # ---- down path
         self.down[0].forward(c.x_in, c.e[0])
         ops.bnact_fwd(c.e[0], c.lin[1], ops.cslice(c.rcat[1], 0, wd[0]), act=ACT_LRELU, act2=ACT_RELU)
+        # (bench.py's bracketed roofline step times every igemm launch on its own: the layers run as separate calls there)
+        fused = train and FUSE_CONV_BN and not ops.PROFILE.active
         for d in range(1, D - 1):
-            _, stats = self.down[d].forward(c.lin[d], c.e[d], want_stats=True)
             n = N * c.hs[d][0] * c.hs[d][1]
+            if fused and self.down[d].bias is None and not (self.down[d].row_split or self.down[d].col_split):
+                self.down[d].forward_bn_act(c.lin[d], c.e[d], self.down_bn[d], c.st_down[d], n, c.lin[d + 1],
+                                            ops.cslice(c.rcat[d + 1], 0, wd[d]), act=ACT_LRELU, act2=ACT_RELU)
+                continue
+            _, stats = self.down[d].forward(c.lin[d], c.e[d], want_stats=True)
             self.down_bn[d].finalize(stats, n, c.st_down[d], train)
             ops.bnact_fwd(c.e[d], c.lin[d + 1], ops.cslice(c.rcat[d + 1], 0, wd[d]), scale=c.st_down[d].scale,
                           shift=c.st_down[d].shift, act=ACT_LRELU, act2=ACT_RELU)
@@ -388,10 +403,16 @@ class UnetEngine:
         # ---- up path
         src = c.e[D - 1]
         for d in range(D - 1, 0, -1):
-            _, stats = self.up[d].forward(src, c.t[d], want_stats=True)
             hh, ww = c.hs[d - 1]
-            self.up_bn[d].finalize(stats, N * hh * ww, c.st_up[d], train)
             drop = 0.5 if (train and d in self.drop_depths) else 0.0
+            if fused and self.up[d].bias is None and not (self.up[d].row_split or self.up[d].col_split):
+                self.up[d].forward_bn_act(src, c.t[d], self.up_bn[d], c.st_up[d], N * hh * ww,
+                                          ops.cslice(c.rcat[d], self.uoff[d], uw[d]), act=ACT_RELU, drop_p=drop,
+                                          seed=c.iter_seed * 64 + d)
+                src = c.rcat[d]
+                continue
+            _, stats = self.up[d].forward(src, c.t[d], want_stats=True)
+            self.up_bn[d].finalize(stats, N * hh * ww, c.st_up[d], train)
             ops.bnact_fwd(c.t[d], ops.cslice(c.rcat[d], self.uoff[d], uw[d]), scale=c.st_up[d].scale,
                           shift=c.st_up[d].shift, act=ACT_RELU, drop_p=drop, seed=c.iter_seed * 64 + d)
             src = c.rcat[d]

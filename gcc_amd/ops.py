@@ -339,6 +339,41 @@ def conv_dgrad(dy, wt, Ci, H, W, k, stride, pad, out=None, bias=None, act=ACT_NO
     return (out, stats) if want_stats else out
 
 
+def conv_bn_act(dgrad, src, w, raw, k, stride, pad, bn_module, st, count, y, y2=None, act=ACT_NONE, act2=ACT_NONE, slope=0.2,
+                drop_p=0.0, seed=0):
+    """conv (dgrad=False: raw = conv(src); True: raw = conv_backward_data(src) == ConvTranspose2d forward) + BatchNorm with the
+    batch statistics of raw (running statistics of `bn_module` updated, mean / rstd / scale / shift into the BNState `st`) +
+    y = act(drop(bn(raw))) [+ y2 = act2(..)] in one C call (gcc_conv_bn_act)"""
+    sp, N, Cs, Hs, Ws, lds = geom(src)
+    rp, _, Cr, Hr, Wr, ldr = geom(raw)
+    if not dgrad:
+        d = conv_desc(N, Hs, Ws, Cs, Cr, k, stride, pad, lds, ldr)
+        flops = 2.0 * N * Hr * Wr * Cr * k * k * Cs
+    else:
+        assert Hs == (Hr + 2 * pad - k) // stride + 1 and Ws == (Wr + 2 * pad - k) // stride + 1
+        d = conv_desc(N, Hr, Wr, Cr, Cs, k, stride, pad, ldr, lds)
+        flops = 2.0 * N * Hs * Ws * Cs * k * k * Cr
+    need = lib().gcc_conv_bn_act_workspace(C.byref(d), int(dgrad))
+    ws = workspace(need, src.device, 'convbn')
+    bn = _lib.bn_t(bn_module.weight.data_ptr(), bn_module.bias.data_ptr(), bn_module.eps, bn_module.momentum, float(count),
+                   bn_module.running_mean.data_ptr(), bn_module.running_var.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
+                   st.scale.data_ptr(), st.shift.data_ptr())
+    yp, ldy = (None, 0)
+    if y is not None:
+        yp, _, _, _, _, ldy = geom(y)
+    y2p, ldy2 = (None, 0)
+    if y2 is not None:
+        y2p, _, _, _, _, ldy2 = geom(y2)
+    a = _lib.bnact_t(None, None, None, 0, act, slope, act2, drop_p, seed, 1, 0, None)
+    e0 = PROFILE.begin() if PROFILE.active else None
+    check(lib().gcc_conv_bn_act(C.byref(d), int(dgrad), sp, w.data_ptr(), rp, C.byref(bn), C.byref(a), yp, ldy, 0, y2p, ldy2, 0,
+                                ws.data_ptr(), ws.numel(), stream()), 'gcc_conv_bn_act')
+    if e0 is not None:
+        PROFILE.end('conv + BatchNorm + activation (one call)', flops, e0,
+                    shape=('dgrad+bn' if dgrad else 'fprop+bn', N, Hs if dgrad else Hr, Ws if dgrad else Wr, Cr if dgrad else Cs,
+                           Cs if dgrad else Cr, k, stride))
+
+
 def conv_wgrad(x, dy, dw, k, stride, pad, accumulate=False):
     """dw: fp32 [Co, Ci, k, k] channels_last gradient buffer (physical [Co][taps][Ci])."""
     xp, N, Ci, H, W, ldx = geom(x)

@@ -79,6 +79,7 @@ enum {
                                    less CU time per launch, the free CUs run the other streams' kernels (the multi-stream
                                    production schedule: +1 % on the step).  gcc_amd's models switch it with their schedule. */
     GCC_OPT_WGRAD_BIG_MIN_TILES,/* minimum number of 256x256 output tiles for the big weight-gradient tiling (default 32) */
+    GCC_OPT_FUSE_BN,            /* 1 (default): gcc_conv_bn_act folds split-K partials, statistics, finalize and normalise in one kernel */
     GCC_OPT_COUNT_
 };
 int gcc_set_option(int id, int value);
@@ -249,6 +250,28 @@ typedef struct {
  * concat buffer).  x/y/y2 are NHWC bf16 with their own ld/off. */
 int gcc_bnact_fwd(const gcc_bnact_t* p, const void* x, int ldx, int xoff, void* y, int ldy, int yoff,
                   void* y2, int ldy2, int y2off, int C, size_t pixels, gcc_stream_t stream);
+
+/* Conv2d / ConvTranspose2d + BatchNorm2d(training statistics) + activation (+ dropout, + a second activated copy) as ONE call:
+ * the U-Net layer `conv -> BatchNorm2d -> LeakyReLU/ReLU[/Dropout]` of models/Pix2Pix.py:31-36, 40-64 (conv = fprop for
+ * dgrad == 0, backward-data / ConvTranspose forward for dgrad == 1, as gcc_conv_fprop / gcc_conv_dgrad; bias-free).
+ *   y_raw (the conv's own output, kept for the backward pass), then batch statistics of its bf16-rounded values, mean / rstd /
+ *   scale / shift and the running-statistics update as gcc_bn_finalize, then y = act(drop(bn(y_raw))) and, if y2 != NULL,
+ *   y2 = act2(drop(bn(y_raw))) as gcc_bnact_fwd (`act`: its scale / shift / gate / residual / groups fields are ignored).
+ * Layers whose grid is split over K (the U-Net's <= 16x16 layers: a handful of output rows, thousands of K) run two launches --
+ * the fp32 partial tiles, then one kernel that folds them, takes the statistics (f64), finalises and normalises: a workgroup
+ * per 8 output channels owns every row of them -- instead of five (partials, fold, channel statistics, finalize, normalise);
+ * every other layer runs the ordinary three kernels inside this one call.  ws: gcc_conv_bn_act_workspace() bytes. */
+typedef struct {
+    const float* gamma; const float* beta;          /* [C] */
+    float eps, momentum;
+    double count;                                   /* N * H * W of the conv output */
+    float* running_mean; float* running_var;        /* [C] or NULL */
+    float* mean; float* rstd; float* scale; float* shift;   /* [C] outputs (saved for the backward pass) */
+} gcc_bn_t;
+size_t gcc_conv_bn_act_workspace(const gcc_conv_t* c, int dgrad);
+int gcc_conv_bn_act(const gcc_conv_t* c, int dgrad, const void* x, const void* w, void* y_raw, const gcc_bn_t* bn,
+                    const gcc_bnact_t* act, void* y, int ldy, int yoff, void* y2, int ldy2, int y2off, void* ws,
+                    size_t ws_bytes, gcc_stream_t stream);
 
 /* Backward of y = act(gate(bn(x))) [dropout] given up to two upstream gradients:
  *   g  = g1 * act'(y)  +  g2 * act2'(y)     (g2 from the skip/concat path, may be NULL)

@@ -227,6 +227,89 @@ def _true_shape_case(ops, name):
     close(dw.cpu(), dw_ref, tol=5e-3, floor=1e-4, what=name + ' wgrad')
 
 
+@pytest.mark.parametrize('case', [
+    # N, H, W, Ci, Co, transposed, drop      (k4 s2 p1: the U-Net layers)
+    (16, 8, 8, 256, 256, False, 0.0),        # student d5: 4x4 out, K = 4096: split K -> the fused fold kernel
+    (16, 4, 4, 512, 512, False, 0.0),        # teacher d6
+    (16, 2, 2, 256, 512, True, 0.5),         # student u6 (ConvT 512 -> 256, 2x2 -> 4x4) with dropout
+    (16, 8, 8, 256, 512, True, 0.5),         # u4-like: 4 phases x 256 rows
+    (3, 6, 10, 40, 72, False, 0.0),          # ragged sizes, channels not multiples of 64
+    (16, 32, 32, 128, 256, False, 0.0),      # un-split layer: the ordinary three kernels inside the one call
+    (2, 16, 16, 64, 128, True, 0.0),
+])
+@pytest.mark.parametrize('fuse', [1, 0])
+def test_conv_bn_act_one_call(case, fuse):
+    """gcc_conv_bn_act against conv -> BatchNorm2d(train) -> activation in fp32 torch on the bf16-rounded conv output: raw output,
+    batch statistics, running statistics, both activated copies; dropout: the mask is the one gcc_bnact_bwd regenerates
+    (checked through the backward of the same layer), rate ~ 0.5"""
+    ops = _ops()
+    from gcc_amd import _lib
+    import torch.nn as nn
+    N, H, W, Ci, Co, transposed, drop = case
+    g = torch.Generator().manual_seed(N * 100 + H + Ci)
+    lib = _lib.load()
+    lib.gcc_set_option(_lib.OPT_FUSE_BN, fuse)
+    try:
+        bn = nn.BatchNorm2d(Co if not transposed else Ci).to(DEV)
+        Cn = bn.num_features
+        with torch.no_grad():
+            bn.weight.copy_(1 + 0.1 * torch.randn(Cn, generator=g))
+            bn.bias.copy_(torch.randn(Cn, generator=g))
+        rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+        if not transposed:
+            x = rb(torch.randn(N, Ci, H, W, generator=g))
+            wgt = rb(torch.randn(Co, Ci, 4, 4, generator=g) * 0.05)
+            ref_raw = F.conv2d(x, wgt, None, stride=2, padding=1)
+            wp, _ = ops.pack_weights(master_cl(wgt))
+            src, wpk = to_dev(x), wp
+        else:                                   # ConvTranspose2d(Co -> Ci): adjoint conv Ci -> Co, forward = dgrad
+            x = rb(torch.randn(N, Co, H // 2, W // 2, generator=g))
+            wgt = rb(torch.randn(Co, Ci, 4, 4, generator=g) * 0.05)
+            ref_raw = F.conv_transpose2d(x, wgt, None, stride=2, padding=1)
+            _, wtp = ops.pack_weights(master_cl(wgt))
+            src, wpk = to_dev(x), wtp
+        raw = ops.new_act(*ref_raw.shape, DEV)
+        y = ops.new_act(*ref_raw.shape, DEV)
+        y2 = ops.new_act(*ref_raw.shape, DEV)
+        st = ops.BNState(Cn, DEV)
+        count = ref_raw.shape[0] * ref_raw.shape[2] * ref_raw.shape[3]
+        seed = 1234567
+        ops.conv_bn_act(transposed, src, wpk, raw, 4, 2, 1, bn, st, count, y, y2, act=ops.ACT_LRELU if not transposed else ops.ACT_RELU,
+                        act2=ops.ACT_RELU, drop_p=drop, seed=seed)
+        torch.cuda.synchronize()
+        rawg = to_cpu(raw)
+        close(rawg, ref_raw, what='raw conv output')
+        mean = rawg.mean((0, 2, 3))
+        var = rawg.var((0, 2, 3), unbiased=False)
+        close(st.mean.cpu(), mean, tol=1e-4, floor=1e-5, what='batch mean')
+        close(st.rstd.cpu(), 1.0 / torch.sqrt(var + bn.eps), tol=1e-4, floor=1e-5, what='rstd')
+        close(bn.running_mean.cpu(), 0.9 * rm0.cpu() + 0.1 * mean, tol=1e-4, floor=1e-5, what='running mean')
+        close(bn.running_var.cpu(), 0.9 * rv0.cpu() + 0.1 * var * count / (count - 1), tol=1e-4, floor=1e-5, what='running var')
+        z = (rawg - mean[None, :, None, None]) / torch.sqrt(var + bn.eps)[None, :, None, None] * bn.weight.detach().cpu()[None, :, None, None] \
+            + bn.bias.detach().cpu()[None, :, None, None]
+        yg, y2g = to_cpu(y), to_cpu(y2)
+        act1 = (lambda t: F.leaky_relu(t, 0.2)) if not transposed else torch.relu
+        if drop == 0.0:
+            close(yg, act1(z), what='activated output')
+            close(y2g, torch.relu(z), what='second activated output')
+        else:
+            # the mask the backward pass regenerates from (seed, pixel, channel): a bare dropout backward of ones
+            gup = to_dev(torch.ones(ref_raw.shape))
+            dxb = ops.new_act(*ref_raw.shape, DEV)
+            ops.bnact_bwd(raw, None, gup, dxb, bn=None, act=ops.ACT_NONE, drop_p=drop, seed=seed)
+            mask = to_cpu(dxb) != 0
+            assert abs(float(mask.float().mean()) - (1.0 - drop)) < 0.03, float(mask.float().mean())
+            zd = torch.where(mask, z / (1.0 - drop), torch.zeros(()))
+            close(yg, act1(zd), what='activated output under the regenerated dropout mask')
+            close(y2g, torch.relu(zd), what='second activated output under the regenerated dropout mask')
+        if ref_raw.shape[1] % 8:
+            ld = y.stride(3)
+            full = torch.as_strided(y, (ref_raw.shape[0], ld, ref_raw.shape[2], ref_raw.shape[3]), y.stride())
+            assert float(full[:, ref_raw.shape[1]:].float().abs().max()) == 0.0
+    finally:
+        lib.gcc_set_option(_lib.OPT_FUSE_BN, -1)
+
+
 def test_conv_transpose_as_dgrad_with_stats_and_tanh():
     """ConvTranspose2d(k4,s2,p1) forward == gcc_conv_dgrad of the adjoint conv; weight layout
     [Cin_T, Cout_T, k, k] channels_last is the adjoint conv's [Co][tap][Ci]."""
