@@ -66,6 +66,15 @@ for (n, q), t in sorted(low_by.items(), key=lambda x: -x[1])[:25]:
 cnt = defaultdict(int)
 for s_, e_, f_, n_, q_ in ev:
     cnt[n_] += 1
-print('launches in the window: %d (%.0f per 18 ms)' % (len(ev), len(ev) * 18.0 / win))
+# exact per-iteration census: everything launched between the last two arch_coeffs launches (one per GCC iteration)
+marks = sorted(e[0] for e in ev if e[3].startswith('arch_coeffs'))
+if len(marks) >= 2:
+    a_, b_ = marks[-2], marks[-1]
+    one = [e for e in ev if a_ <= e[0] < b_]
+    print('launches per iteration (between the last two arch_coeffs launches, %.2f ms apart): %d' % ((b_ - a_) / 1e6, len(one)))
+    cnt = defaultdict(int)
+    for s_, e_, f_, n_, q_ in one:
+        cnt[n_] += 1
+print('launches in the window: %d' % len(ev))
 for n_, c_ in sorted(cnt.items(), key=lambda x: -x[1])[:40]:
     print('  %5d  %s' % (c_, n_))
