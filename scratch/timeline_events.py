@@ -1,0 +1,79 @@
+"""Phase timeline of the production schedule WITHOUT a profiler: HIP events at the phase boundaries of both networks (recorded on
+whatever stream the phase runs on), a few iterations, times relative to the start of the student's optimize_parameters.
+The profiler's kernel trace slows the host enough to change the overlap; this does not (about 20 events per iteration)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from gcc_amd.models import Pix2Pix as P  # noqa: E402
+
+model, opt = bench.build(16)
+dev = model.device
+torch.cuda.set_device(dev)
+train, val = bench.synthetic(16, 0, dev)
+T = model.teacher_model
+marks = []
+
+
+def mark(name):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record(torch.cuda.current_stream())
+    marks.append((name, e))
+
+
+def wrap_gen(obj, attr, name):
+    orig = getattr(obj, attr)
+
+    def g(*a, **k):
+        mark(name + ' begin')
+        yield from orig(*a, **k)
+        mark(name + ' end')
+    setattr(obj, attr, g)
+
+
+def wrap_fn(obj, attr, name):
+    orig = getattr(obj, attr)
+
+    def f(*a, **k):
+        mark(name + ' begin')
+        r = orig(*a, **k)
+        mark(name + ' end')
+        return r
+    setattr(obj, attr, f)
+
+
+wrap_gen(T, '_iteration_steps', 'T.iteration')
+wrap_gen(T, '_pre_join_steps', 'T.pre-join (G fwd, D step, head)')
+wrap_fn(T, '_backward_G_tail', 'T.G backward')
+wrap_gen(model, '_pre_join_steps', 'S.pre-join (G fwd, D step, head)')
+wrap_fn(model, '_backward_G_tail', 'S.tail (T.D on fake, distill, G backward)')
+wrap_fn(model, '_apply_G_update', 'S.adam G + repack')
+wrap_fn(model, 'optimizer_netD_arch', 'S.arch step')
+wrap_fn(model, 'backward_D_arch', 'S.arch backward (incl. its 2 D forwards)')
+orig_diff = T.get_D_arch_diff
+
+
+def tdiff(*a, **k):
+    r = orig_diff(*a, **k)
+    mark('T.arch forward + diff end')
+    return r
+T.get_D_arch_diff = tdiff
+
+for _ in range(6):
+    bench.one_step(model, train, val)
+torch.cuda.synchronize()
+for it in range(3):
+    marks.clear()
+    t0 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    bench.one_step(model, train, val)
+    t1 = torch.cuda.Event(enable_timing=True)
+    t1.record()
+    torch.cuda.synchronize()
+    print('--- iteration %d: %.2f ms (main-stream events)' % (it, t0.elapsed_time(t1)))
+    for name, e in marks:
+        print('  %7.2f ms  %s' % (t0.elapsed_time(e), name))
