@@ -54,6 +54,21 @@ wrap_fn(model, '_backward_G_tail', 'S.tail (T.D on fake, distill, G backward)')
 wrap_fn(model, '_apply_G_update', 'S.adam G + repack')
 wrap_fn(model, 'optimizer_netD_arch', 'S.arch step')
 wrap_fn(model, 'backward_D_arch', 'S.arch backward (incl. its 2 D forwards)')
+orig_free = model._mark_teacher_free
+
+
+def free_():
+    orig_free()
+    mark('S: teacher free (main stream)')
+model._mark_teacher_free = free_
+orig_rel = model._release_teacher_stream
+
+
+def rel_(ts):
+    orig_rel(ts)
+    with torch.cuda.stream(ts):
+        mark('T stream released (after its waits)')
+model._release_teacher_stream = rel_
 orig_diff = T.get_D_arch_diff
 
 
