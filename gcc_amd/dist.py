@@ -126,7 +126,8 @@ class GradReducer:
         self.opt.set_grad_scale(1.0 / world_size())
         self.launched[k] = True
         if stream is not None:
-            with torch.cuda.stream(stream):
+            from . import ops
+            with ops.on_stream(stream):
                 self.handles.append(dist.all_reduce(self.flat.grads[b:e], op=dist.ReduceOp.SUM, async_op=True))
         else:
             self.handles.append(dist.all_reduce(self.flat.grads[b:e], op=dist.ReduceOp.SUM, async_op=True))

@@ -142,7 +142,7 @@ class ConvOp:
         if OVERLAP_WGRAD:
             side = ops.SideStream.get(x.device)
             side.fork()
-            with torch.cuda.stream(side.stream):
+            with ops.on_stream(side.stream):
                 self._backward_weight(x, dy)
         else:
             self._backward_weight(x, dy)
@@ -642,7 +642,7 @@ class PatchGANEngine:
         """the running-statistics updates a defer_running pass left out, on the current stream (which has joined the
         stream that pass ran on): the same finalize over the same partial sums, now with the EMA update"""
         for li, stats, n in getattr(c, 'deferred', []):
-            stats.record_stream(torch.cuda.current_stream())
+            stats.record_stream(ops.current_stream())
             self.bn[li].finalize(stats, n, c.st[li], True)
         c.deferred = []
 
@@ -715,7 +715,7 @@ class DWOp:
         if OVERLAP_WGRAD:
             side = ops.SideStream.get(x.device)
             side.fork()
-            with torch.cuda.stream(side.stream):
+            with ops.on_stream(side.stream):
                 run()
         else:
             run()
@@ -1003,7 +1003,7 @@ class SNConvOp:
         if OVERLAP_WGRAD:
             side = ops.SideStream.get(x.device)
             side.fork()
-            with torch.cuda.stream(side.stream):
+            with ops.on_stream(side.stream):
                 run()
         else:
             run()

@@ -242,7 +242,7 @@ def _step(gen, stream):
     """one chunk of `gen` with `stream` current (None: the current stream); False when the generator is exhausted"""
     try:
         if stream:
-            with torch.cuda.stream(stream):
+            with ops.on_stream(stream):
                 next(gen)
         else:
             next(gen)
@@ -253,7 +253,7 @@ def _step(gen, stream):
 
 def _drain(gen, stream):
     if stream:
-        with torch.cuda.stream(stream):
+        with ops.on_stream(stream):
             for _ in gen:
                 pass
     else:
@@ -486,10 +486,10 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         aux = self._aux_stream() if (not is_teacher or (TEACHER_EARLY_DREAL and getattr(self, '_is_online_teacher', False))) else False
         if not aux:
             return
-        main = torch.cuda.current_stream()
+        main = ops.current_stream()
         self.D.refresh_masks() if self.D.masked else None
         aux.wait_stream(main)
-        with torch.cuda.stream(aux):
+        with ops.on_stream(aux):
             N, _, H, W = self._A.shape
             ctx = self.D.new_ctx(N, H, W, tag)
             self._pack_pair(ctx, self._B)
@@ -502,7 +502,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         if got is None:
             return self._d_forward(tag, self._B)
         ctx, aux = got
-        torch.cuda.current_stream().wait_stream(aux)
+        ops.current_stream().wait_stream(aux)
         self.D.apply_deferred_running(ctx)
         return ctx
 
@@ -581,9 +581,9 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         if ts:
             ev = getattr(self.teacher_model, '_head_done', None) if EARLY_JOIN else None
             if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
+                ops.current_stream().wait_event(ev)
             else:
-                torch.cuda.current_stream().wait_stream(ts)
+                ops.current_stream().wait_stream(ts)
         if self.distill:
             T = self.teacher_model
             # teacher D (train mode, frozen) on the student's fake: features for the last two terms (:531-533)
@@ -690,7 +690,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         # everything a student reads from this model is final here: the generator's features (forward), the discriminator's
         # weights (its Adam step + repack) and features (the D(fake) pass of backward_G's head)
         self._head_done = torch.cuda.Event()
-        self._head_done.record(torch.cuda.current_stream())
+        self._head_done.record(ops.current_stream())
         yield
         self._backward_G_tail(None)
         if self._defer_G_update and self._world > 1:
@@ -747,7 +747,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             T.get_D_arch_diff(isTeacher=True)
         cf, cr = self.get_D_arch_diff(isTeacher=False)
         if ts:
-            torch.cuda.current_stream().wait_stream(ts)          # the teacher's difference was computed on its stream
+            ops.current_stream().wait_stream(ts)          # the teacher's difference was computed on its stream
         ops.scalar_op(2, T._l('teacher_D_arch_diff'), T._l('teacher_D_arch_diff'), self._l('teacher_D_arch_diff'), k0=0.0)
         self._mark_teacher_free()
         # loss_D_arch = |d_S - d_T| + (L_real + L_fake)/2 ; coefficients of the three hinge gradients

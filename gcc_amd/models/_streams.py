@@ -10,13 +10,15 @@ import os
 
 import torch
 
+from .. import ops
+
 
 class TeacherStreamMixin:
     def set_stream_schedule(self, concurrent):
         """concurrent=True: the production schedule (student, online teacher, auxiliary and weight-gradient streams).
         False: every launch on one stream -- and the library's tile plan for launches that have the chip to themselves
         (GCC_OPT_IGEMM_PAIR: half-chip 256x256-tile launches split their K loop over two workgroups per tile)."""
-        from .. import _lib, engine, ops
+        from .. import _lib, engine
         self.serialize_streams = not concurrent
         if getattr(self, 'teacher_model', None) is not None:
             self.teacher_model.serialize_streams = not concurrent
@@ -34,7 +36,7 @@ class TeacherStreamMixin:
     def _mark_teacher_free(self):
         """main stream: no later launch reads the teacher's buffers -- its stream may move on from here"""
         self._teacher_free = torch.cuda.Event()
-        self._teacher_free.record(torch.cuda.current_stream())
+        self._teacher_free.record(ops.current_stream())
 
     def _note_input(self, input):
         """set_input(): order this stream -- and, through _release_teacher_stream, the teacher's -- behind whatever produced
@@ -47,7 +49,7 @@ class TeacherStreamMixin:
         ev = input.get('ready') if hasattr(input, 'get') else None
         dev = [v for v in input.values() if torch.is_tensor(v) and v.is_cuda] if hasattr(input, 'values') else []
         if dev:
-            cur = torch.cuda.current_stream()
+            cur = ops.current_stream()
             if ev is not None:
                 cur.wait_event(ev)
             else:
@@ -62,7 +64,7 @@ class TeacherStreamMixin:
         if ev is not None:
             ts.wait_event(ev)
         else:
-            ts.wait_stream(torch.cuda.current_stream())
+            ts.wait_stream(ops.current_stream())
         # the batch the teacher is about to read (set_input on its own stream) must exist: ADVICE r1, race on a
         # device-resident batch written by main-stream kernels after _teacher_free was recorded
         ready = getattr(self, '_input_ready', None)
@@ -74,7 +76,7 @@ class TeacherStreamMixin:
         ts = self._teacher_stream()
         if ts:
             self._release_teacher_stream(ts)
-            with torch.cuda.stream(ts):
+            with ops.on_stream(ts):
                 fn()
         else:
             fn()
@@ -93,4 +95,4 @@ class TeacherStreamMixin:
     @staticmethod
     def _join(ts):
         if ts:
-            torch.cuda.current_stream().wait_stream(ts)
+            ops.current_stream().wait_stream(ts)

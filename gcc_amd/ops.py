@@ -155,6 +155,42 @@ def stream():
     return torch._C._cuda_getCurrentRawStream(_dev_index)
 
 
+_stream_objs = {}
+
+
+def current_stream():
+    """torch.cuda.Stream object of the current stream.  torch.cuda.current_stream() takes ~8 us of host time (device-index
+    resolution, availability checks); this is a dict lookup on the raw handle -- the hot path asks a few hundred times per
+    iteration (event records / waits, side-stream forks)."""
+    raw = stream()
+    s = _stream_objs.get(raw)
+    if s is None:
+        s = _stream_objs[raw] = torch.cuda.current_stream()
+    return s
+
+
+class on_stream:
+    """`with on_stream(s)`: torch.cuda.stream(s) for the one device of this process, without its per-entry device and
+    current-stream queries (~20 us of host time per block)"""
+    __slots__ = ('s', 'prev')
+
+    def __init__(self, s):
+        self.s = s
+
+    def __enter__(self):
+        s = self.s
+        if s:
+            self.prev = current_stream()
+            torch._C._cuda_setStream(stream_id=s.stream_id, device_index=s.device_index, device_type=s.device_type)
+        return s
+
+    def __exit__(self, *exc):
+        if self.s:
+            p = self.prev
+            torch._C._cuda_setStream(stream_id=p.stream_id, device_index=p.device_index, device_type=p.device_type)
+        return False
+
+
 def ceil8(v):
     return (v + 7) & ~7
 
@@ -162,7 +198,7 @@ def ceil8(v):
 def workspace(nbytes, device, slot='default'):
     """Grow-only scratch buffer per (device, slot, stream): all users of one buffer are ordered on one stream (the online
     teacher may run on its own stream next to the student's)."""
-    key = (str(device), slot, stream())
+    key = (device, slot, stream())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -178,28 +214,28 @@ class SideStream:
     def __init__(self, device):
         self.stream = torch.cuda.Stream(device=device)
         self.dirty = False
+        self.ev_fork, self.ev_join = torch.cuda.Event(), torch.cuda.Event()     # re-recorded: a wait holds the record it saw
 
     @classmethod
     def get(cls, device):
         """the side stream that belongs to the CURRENT stream of `device`"""
-        key = (str(device), stream())
-        if key not in cls._inst:
-            cls._inst[key] = SideStream(device)
-        return cls._inst[key]
+        key = (device, stream())
+        inst = cls._inst.get(key)
+        if inst is None:
+            inst = cls._inst[key] = SideStream(device)
+        return inst
 
     def fork(self):
         """everything enqueued on the main stream so far happens-before later side-stream work"""
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self.stream.wait_event(ev)
+        self.ev_fork.record(current_stream())
+        self.stream.wait_event(self.ev_fork)
         self.dirty = True
 
     def join(self):
         """the main stream waits for all side-stream work enqueued so far"""
         if self.dirty:
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-            torch.cuda.current_stream().wait_event(ev)
+            self.ev_join.record(self.stream)
+            current_stream().wait_event(self.ev_join)
             self.dirty = False
 
 
