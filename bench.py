@@ -29,6 +29,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # this pool's driver supports dmabuf IPC only (RCCL needs it)
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
