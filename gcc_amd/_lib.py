@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgcc_hip.so')
+LIB_PATH = os.environ.get('GCC_HIP_LIB') or os.path.join(_HERE, 'libgcc_hip.so')     # GCC_HIP_LIB: another build of the same ABI (A/B runs)
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 

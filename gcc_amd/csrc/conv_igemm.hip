@@ -17,12 +17,29 @@
 
 // named (not anonymous) namespace: hipcc fails to emit the host stub of a kernel template with internal
 // linkage whose body holds lambdas inside an `if constexpr` branch
+// GCC_IGEMM_ROT=1: the k loop rotated by half a step (see the loop).  Measured and NOT the default (profiles/r03_l_clock_probe.txt,
+// same box, in-kernel clock stamps): the 256x256 loop takes 4 % fewer cycles per k-step (2828 -> 2720) and a launch that is not
+// power-limited gains them (half-chip L4 dgrad 315.7 -> 304.0 us, zero-filled L4 fprop 166.5 -> 160.6 us), but on random data at
+// full chip the clock falls from 2.07 to 2.02 GHz and the launch time does not move (191.5 -> 191.0 us), the short-K and the
+// 128-pixel-tile launches get slower (L2 fprop 62.4 -> 64.0 us; the kernel spills 94 VGPRs), and the step loses 0.4 %
+// (897.7 against 901.6 images/s, igemm 769 against 789 TFLOP/s).
+#ifndef GCC_IGEMM_ROT
+#define GCC_IGEMM_ROT 0
+#endif
+
 namespace gcc_igemm {
 
 // GLDS = true : tiles are staged global -> LDS directly (buffer_load ... lds, 1 KiB per wave-instruction,
 //               XOR swizzle applied on the per-lane SOURCE address, zero fill by the descriptor range
 //               check), one barrier per k-step: no staging VGPRs, no ds_write traffic.
 // GLDS = false: register-staged variant (kept for A/B measurement).
+#ifdef GCC_CLOCK_PROBE
+// Diagnostic build only (scratch/probe_clock.py; never part of libgcc_hip.so): the shader clock the chip holds inside the
+// main loop = d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, 'DVFS give-back' item 6), one stamp pair per
+// workgroup around the k loop.
+__device__ unsigned long long g_clock_probe[4096][4];
+#endif
+
 template <int BP, int BC, bool GLDS, bool UT>
 __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams p) {
     using C = Cfg<BP, BC>;
@@ -287,9 +304,76 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
                 load_tap();
             }
         };
+#ifdef GCC_CLOCK_PROBE
+        const unsigned long long pt0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();
+#endif
         load_tap();
         issue(0);
         next_step();
+#if GCC_IGEMM_ROT
+        // The k loop rotated by half a step: the barrier sits between the two 32-deep k-slices of a stage, so that the
+        // fragment reads that follow it (slice 0 of the NEXT stage) run under the MFMAs of slice 1 instead of in front of
+        // the step's first MFMA -- with the barrier at the top of the step both waves of a SIMD wait for their first twelve
+        // ds_read_b128 at the same time and the matrix pipe idles (in-kernel clock stamps, profiles/r03_l_*: 72 % busy).
+        //   A: MFMAs of slice 0 | reads of slice 1 (stage s)         -> nobody reads stage s any more
+        //   B: my DMA of stage s^1 landed; barrier                     -> everybody's has, stage s is free
+        //   C: DMA of step kt+2 into stage s
+        //   D: MFMAs of slice 1 | reads of slice 0 of stage s^1
+        // A DMA issued at C is waited for at B of the next step: one full step in flight, as before.
+        bf16x8 f0w[C::CB], f0a[C::PB], f1w[C::CB], f1a[C::PB];
+        auto read_slice = [&](int stage, int ks, bf16x8 (&fw)[C::CB], bf16x8 (&fa)[C::PB]) {
+            const char* a = sA + stage * (BP * BK * 2);
+            const char* w = sW + stage * (BC * BK * 2);
+#pragma unroll
+            for (int i = 0; i < C::CB; i++) {
+                const int row = wc * C::TC + i * 16 + lr;
+                fw[i] = *(const bf16x8*)(w + row * 128 + (((ks * 4 + lq) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < C::PB; j++) {
+                const int row = wp * C::TP + j * 16 + lr;
+                fa[j] = *(const bf16x8*)(a + row * 128 + (((ks * 4 + lq) ^ (row & 7)) << 4));
+            }
+        };
+        auto mfma_slice = [&](const bf16x8 (&fw)[C::CB], const bf16x8 (&fa)[C::PB]) {
+#pragma unroll
+            for (int i = 0; i < C::CB; i++)
+#pragma unroll
+                for (int j = 0; j < C::PB; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        };
+        constexpr int R_READS = C::CB + C::PB, R_MFMAS = C::CB * C::PB;
+        constexpr int R_MPR = R_MFMAS / R_READS > 0 ? R_MFMAS / R_READS : 1;
+        auto pin = [&]() {                          // one fragment read per R_MPR MFMAs, then the remaining MFMAs
+#pragma unroll
+            for (int r = 0; r < R_READS; r++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, R_MPR, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, R_MFMAS - R_READS * R_MPR > 0 ? R_MFMAS - R_READS * R_MPR : 0, 0);
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        issue(1);                                   // past the end of K the offsets are out of range: zero fill, unused
+        next_step();
+        read_slice(0, 0, f0w, f0a);
+        for (int kt = 0; kt < nk; kt++) {
+            const int cur = kt & 1;
+            read_slice(cur, 1, f1w, f1a);
+            mfma_slice(f0w, f0a);
+            pin();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            issue(cur);
+            next_step();                            // (rare) tap change: its VALU work hides under the MFMAs below
+            __builtin_amdgcn_sched_barrier(0);
+            read_slice(cur ^ 1, 0, f0w, f0a);       // the last step reads a stage nobody uses
+            mfma_slice(f1w, f1a);
+            pin();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#else
         for (int kt = 0; kt < nk; kt++) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -299,6 +383,17 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#endif
+#ifdef GCC_CLOCK_PROBE
+        {
+            const unsigned long long pt1 = __builtin_amdgcn_s_memtime(), pr1 = __builtin_amdgcn_s_memrealtime();
+            const unsigned b = blockIdx.z * gridDim.x + blockIdx.x;
+            if (tid == 0 && b < 4096) {
+                g_clock_probe[b][0] = pt1 - pt0; g_clock_probe[b][1] = pr1 - pr0; g_clock_probe[b][2] = (unsigned long long)nk;
+                g_clock_probe[b][3] = 1;
+            }
+        }
+#endif
     } else if constexpr (GLDS) {
         // one barrier per k-step: [tile kt landed for every wave AND everyone left tile kt-1] ->
         // issue tile kt+1 into the buffer tile kt-1 occupied -> compute tile kt while it flies
@@ -1115,6 +1210,17 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
     }
     return GCC_OK;
 }
+
+#ifdef GCC_CLOCK_PROBE
+extern "C" int gcc_probe_read(unsigned long long* dst, int clear) {
+    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(gcc_igemm::g_clock_probe), sizeof(unsigned long long) * 4096 * 4);
+    if (e == hipSuccess && clear) {
+        void* sym = nullptr;
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(gcc_igemm::g_clock_probe)) == hipSuccess) e = hipMemset(sym, 0, sizeof(unsigned long long) * 4096 * 4);
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
 
 // which kernel family a fprop / dgrad call with this geometry and epilogue runs on (same predicates as the dispatch in
 // gcc_internal_igemm): 0 igemm_kernel, 1 thin_fprop / thin_dgrad, 2 the single-output-channel head route
