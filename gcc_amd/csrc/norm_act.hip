@@ -990,6 +990,16 @@ static int bwd_blocks(size_t pixels, const Layout& L) {
     const bool small = reduce_threads() == 256;
     const size_t per = small ? (size_t)L.PPB * 8 : (size_t)L.PPB * 8 * 4;
     size_t b = (pixels + per - 1) / per;
+    if (small && b < 512) {
+        // Tensors that cannot fill the chip at 16 sweeps per workgroup (the U-Net's <= 32x32 layers): a sweep is one dependent
+        // round trip to memory (~1 us with two pixels in flight per thread), so 16 of them made a 15-29 us kernel out of a few
+        // hundred KB -- on the generators' backward chain, which runs alone.  Down to 2 sweeps, up to 512 workgroups.
+        const size_t lane_pixels = (size_t)L.PPB / 2 > 0 ? (size_t)L.PPB / 2 : 1;      // pixels per sweep of the 4-channel layout
+        size_t sweeps = (pixels + lane_pixels * 512 - 1) / (lane_pixels * 512);
+        if (sweeps < 2) sweeps = 2;
+        if (sweeps > 16) sweeps = 16;
+        b = (pixels + lane_pixels * sweeps - 1) / (lane_pixels * sweeps);
+    }
     if (b < 1) b = 1;
     const int capv = gcc_opt(GCC_OPT_BN_REDUCE_CAP);
     const size_t cap = small ? (size_t)capv : 256;
