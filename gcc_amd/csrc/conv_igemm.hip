@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const bf16_t* __rest
 #pragma unroll
         for (int j = 0; j < 8; j++) { s[j] += v[j]; ss[j] += v[j] * v[j]; }
     }
-    // wave shuffle sums, then the four waves through LDS (16 threads walking 256 LDS entries each cost ~5 us)
+    // wave shuffle sums, then the waves through LDS (16 threads walking 256 LDS entries each cost ~5 us)
 #pragma unroll
     for (int j = 0; j < 8; j++) { s[j] = wave_sum(s[j]); ss[j] = wave_sum(ss[j]); }
     const int wave = threadIdx.x >> 6;
@@ -1250,8 +1250,12 @@ struct FoldBnArgs {
 // one workgroup per 8 output channels, every row of them: fold the K slices (bf16-rounded raw output, kept for the backward
 // pass), f64 statistics of the rounded values, finalize (as bn_finalize_kernel), normalise + dropout + activation(s) (as
 // bnact_fwd_kernel: same affine form, same dropout counter pix * C + channel, so the backward pass regenerates the mask)
-__global__ __launch_bounds__(256) void splitk_bn_act_kernel(const FoldBnArgs a) {
-    __shared__ double red[4][16];
+// NT = 1024: the grid is C/8 workgroups (32-64 on these layers) and the walk over rows x K slices is a chain of dependent
+// round trips -- 256 threads took 50 us on a 16x16 layer (4096 rows x 8 slices); four times the threads and four slices'
+// loads in flight per thread (same summation order) bring the kernel back under the launches it replaces.
+template <int NT>
+__global__ __launch_bounds__(NT) void splitk_bn_act_kernel(const FoldBnArgs a) {
+    __shared__ double red[NT / 64][16];
     __shared__ float coef[16];
     const IgemmParams& p = a.p;
     const int c0 = blockIdx.x * 8;
@@ -1270,10 +1274,24 @@ __global__ __launch_bounds__(256) void splitk_bn_act_kernel(const FoldBnArgs a) 
         }
         const int M = p.N * Hg * Wg;
         const float* base = p.partial + (size_t)z * p.ksplit * sstride;
-        for (int m = threadIdx.x; m < M; m += 256) {
+        for (int m = threadIdx.x; m < M; m += NT) {
             float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             const float* r0 = base + (size_t)m * p.Cpad + c0;
-            for (int sl = 0; sl < p.ksplit; sl++) {
+            int sl = 0;
+            for (; sl + 4 <= p.ksplit; sl += 4) {
+                f32x4 u[4], w[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    u[q] = *(const f32x4*)(r0 + (sl + q) * sstride);
+                    w[q] = *(const f32x4*)(r0 + (sl + q) * sstride + 4);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    v[0] += u[q][0]; v[1] += u[q][1]; v[2] += u[q][2]; v[3] += u[q][3];
+                    v[4] += w[q][0]; v[5] += w[q][1]; v[6] += w[q][2]; v[7] += w[q][3];
+                }
+            }
+            for (; sl < p.ksplit; sl++) {
                 const f32x4 u = *(const f32x4*)(r0 + sl * sstride), w = *(const f32x4*)(r0 + sl * sstride + 4);
                 v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
                 v[4] += w[0]; v[5] += w[1]; v[6] += w[2]; v[7] += w[3];
@@ -1292,7 +1310,7 @@ __global__ __launch_bounds__(256) void splitk_bn_act_kernel(const FoldBnArgs a) 
             *(i32x4*)(p.dst + pix * p.ldd + p.doff + c0) = pk;
         }
     }
-    // block reduction: wave shuffles, then the four waves through LDS
+    // block reduction: wave shuffles, then the waves through LDS
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -1308,8 +1326,9 @@ __global__ __launch_bounds__(256) void splitk_bn_act_kernel(const FoldBnArgs a) 
         const int j = threadIdx.x, c = c0 + j;
         float sc = 1.f, sf = 0.f;
         if (c < C) {
-            const double sum = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
-            const double sq = (red[0][8 + j] + red[1][8 + j]) + (red[2][8 + j] + red[3][8 + j]);
+            double sum = 0.0, sq = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < NT / 64; wv++) { sum += red[wv][j]; sq += red[wv][8 + j]; }
             const double mean = sum / a.bn.count;
             double var = sq / a.bn.count - mean * mean;
             if (var < 0.0) var = 0.0;
@@ -1345,7 +1364,7 @@ __global__ __launch_bounds__(256) void splitk_bn_act_kernel(const FoldBnArgs a) 
             Hg = (p.Hd - py + st - 1) / st; Wg = (p.Wd - px + st - 1) / st;
         }
         const int M = p.N * Hg * Wg;
-        for (int m = threadIdx.x; m < M; m += 256) {
+        for (int m = threadIdx.x; m < M; m += NT) {
             const int n = m / (Hg * Wg);
             const int rr = m - n * (Hg * Wg);
             const int oy = rr / Wg, ox = rr - oy * Wg;
@@ -1441,7 +1460,7 @@ extern "C" int gcc_conv_bn_act(const gcc_conv_t* c, int dgrad, const void* x, co
         if (rc) return rc;
         a.bn = *bn; a.act = act->act; a.act2 = act->act2; a.slope = act->slope; a.drop_p = act->drop_p; a.seed = act->seed;
         a.y = (bf16_t*)y; a.ldy = ldy; a.yoff = yoff; a.y2 = (bf16_t*)y2; a.ldy2 = ldy2; a.y2off = y2off; a.phases = phases;
-        hipLaunchKernelGGL(splitk_bn_act_kernel, dim3(ceil8(Cout) / 8), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(splitk_bn_act_kernel<1024>, dim3(ceil8(Cout) / 8), dim3(1024), 0, st, a);
         GCC_CHECK_LAUNCH();
         return GCC_OK;
     }
