@@ -538,6 +538,125 @@ __global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(const BwdArgs a0) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// BatchNorm (training statistics, no gate) + activation backward of a SMALL tensor in one launch: a workgroup owns every
+// pixel of 8 channels, so the two sums need no grid-wide step.  Each thread keeps the raw x and the fp32 dz of its <= 8
+// pixels in registers between the statistics and dx = A dz + B x + K -- nothing is re-read, dz is never rounded to bf16.
+// For the U-Net's <= 16x16 layers (pixels <= 4096 at N=16) the three-launch pipeline above is a chain of three ~5-7 us
+// kernels on the generators' backward pass, which runs with nothing else to fill the chip; this is one of ~7 us.
+constexpr int SMALL_NT = 512, SMALL_RPT = 8;
+constexpr size_t SMALL_MAX_PIXELS = (size_t)SMALL_NT * SMALL_RPT;
+template <bool DROP>
+__global__ __launch_bounds__(SMALL_NT) void bnact_bwd_small_kernel(const BwdArgs a) {
+    __shared__ double red[SMALL_NT / 64][16];
+    __shared__ float coef[24];
+    const int c0 = blockIdx.x * 8;
+    const int pixels = (int)a.pixels;
+    const bool NOY = !a.y;
+    float mu[8], rs[8], sc[8], sf[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int c = c0 + j;
+        const bool v = c < a.C;
+        mu[j] = v ? a.p.mean[c] : 0.f;
+        rs[j] = v ? a.p.rstd[c] : 0.f;
+        const float g = (v && a.p.gamma) ? a.p.gamma[c] : 1.f;
+        const float b = (v && a.p.beta) ? a.p.beta[c] : 0.f;
+        sc[j] = g * rs[j];
+        sf[j] = b - mu[j] * sc[j];
+    }
+    const float keep_scale = a.p.drop_p > 0.f ? 1.f / (1.f - a.p.drop_p) : 1.f;
+    i32x4 rx[SMALL_RPT], rg1[SMALL_RPT], rg2[SMALL_RPT], ry[SMALL_RPT];
+#pragma unroll
+    for (int r = 0; r < SMALL_RPT; r++) {               // every load of the thread in flight at once
+        const int pix = threadIdx.x + r * SMALL_NT;
+        rx[r] = rg1[r] = rg2[r] = ry[r] = i32x4{0, 0, 0, 0};
+        if (pix < pixels) {
+            rx[r] = *(const i32x4*)(a.x + (size_t)pix * a.ldx + a.xoff + c0);
+            rg1[r] = *(const i32x4*)(a.g1 + (size_t)pix * a.ldg1 + a.g1off + c0);
+            if (a.g2) rg2[r] = *(const i32x4*)(a.g2 + (size_t)pix * a.ldg2 + a.g2off + c0);
+            if (a.y) ry[r] = *(const i32x4*)(a.y + (size_t)pix * a.ldy + a.yoff + c0);
+        }
+    }
+    float dz[SMALL_RPT][8];
+    float s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s0[j] = s1[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < SMALL_RPT; r++) {
+        const int pix = threadIdx.x + r * SMALL_NT;
+        float xv[8], g1v[8], g2v[8], yo[8], df[8], zd[8];
+        unpack8(rx[r], xv);
+        unpack8(rg1[r], g1v);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {                   // the reduce kernel's own forms, stage by stage
+            df[j] = 1.f;
+            if constexpr (DROP) {
+                const float u = rng_uniform(a.p.seed, (size_t)pix * (size_t)a.C + c0 + j);
+                df[j] = u >= a.p.drop_p ? keep_scale : 0.f;
+            }
+            zd[j] = (xv[j] * sc[j] + sf[j]) * df[j];
+        }
+        if (!NOY) unpack8(ry[r], yo);
+        else apply_actN<8>(zd, yo, a.p.act, a.p.slope);
+        float g[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) g[j] = g1v[j] * act_grad_from_out(yo[j], a.p.act, a.p.slope);
+        if (a.g2) {
+            unpack8(rg2[r], g2v);
+#pragma unroll
+            for (int j = 0; j < 8; j++) g[j] += g2v[j] * act_grad_from_out(yo[j], a.p.act2, a.p.slope);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float d = pix < pixels ? g[j] * df[j] : 0.f;
+            dz[r][j] = d;
+            s0[j] += d;
+            s1[j] += d * ((xv[j] - mu[j]) * rs[j]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { s0[j] = wave_sum(s0[j]); s1[j] = wave_sum(s1[j]); }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) { red[wave][j] = (double)s0[j]; red[wave][8 + j] = (double)s1[j]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int j = threadIdx.x, c = c0 + j;
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < SMALL_NT / 64; w++) { t0 += red[w][j]; t1 += red[w][8 + j]; }
+        float A = 0.f, B = 0.f, K = 0.f;
+        if (c < a.C) {
+            if (a.p.dbeta) a.p.dbeta[c] += (float)t0;
+            if (a.p.dgamma) a.p.dgamma[c] += (float)t1;
+            const float inv = 1.f / (float)a.pixels;
+            const float r_ = a.p.rstd[c], m_ = a.p.mean[c];
+            const float gr = (a.p.gamma ? a.p.gamma[c] : 1.f) * r_;
+            const float k0 = (float)t0 * inv, k1 = (float)t1 * inv;
+            A = gr; B = -gr * r_ * k1; K = -gr * k0 + gr * r_ * k1 * m_;     // bnact_bwd_finalize_kernel's coefficients
+        }
+        coef[j] = A; coef[8 + j] = B; coef[16 + j] = K;
+    }
+    __syncthreads();
+    float A[8], B[8], K[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { A[j] = coef[j]; B[j] = coef[8 + j]; K[j] = coef[16 + j]; }
+#pragma unroll
+    for (int r = 0; r < SMALL_RPT; r++) {
+        const int pix = threadIdx.x + r * SMALL_NT;
+        if (pix < pixels) {
+            float xv[8], o[8];
+            unpack8(rx[r], xv);
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = A[j] * dz[r][j] + B[j] * xv[j] + K[j];
+            *(i32x4*)(a.dx + (size_t)pix * a.lddx + a.dxoff + c0) = pack8(o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // InstanceNorm2d(affine=False) of small planes in ONE launch: a workgroup owns the [HW][8 channels] slab of one image, so
 // statistics and normalisation need no grid-wide step.  Pass 1 sums the slab, pass 2 re-reads it (from L2: a slab is
 // HW * 16 bytes) and writes.  At batch 1 (CycleGAN) the three-launch pipeline above is launch-latency bound: three
@@ -1045,6 +1164,12 @@ extern "C" int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_s
     hipStream_t st = (hipStream_t)stream;
     const bool gate = p->gate != nullptr || p->dalpha != nullptr || p->gate_after_act;
     const bool drop = p->drop_p > 0.f;
+    if (p->bn && !p->bn_eval && !gate && groups == 1 && pixels <= SMALL_MAX_PIXELS && gcc_opt(GCC_OPT_BN_BWD_SMALL)) {
+        if (drop) hipLaunchKernelGGL(bnact_bwd_small_kernel<true>, dim3(a.C8 / 8), dim3(SMALL_NT), 0, st, a);
+        else hipLaunchKernelGGL(bnact_bwd_small_kernel<false>, dim3(a.C8 / 8), dim3(SMALL_NT), 0, st, a);
+        GCC_CHECK_LAUNCH();
+        return GCC_OK;
+    }
     {
         BwdArgs r = a;                      // the reduce pass runs 4 channels per thread
         if (!make_layout(C, &r.L, 4)) return GCC_ERR_UNSUPPORTED;

@@ -40,6 +40,8 @@ pts.sort()
 active = set()
 hist = defaultdict(float)
 low_by = defaultdict(float)
+mid_by = defaultdict(float)
+alone_by = defaultdict(float)
 prev = pts[0][0]
 for t, kind, i in pts:
     dt = t - prev
@@ -50,6 +52,12 @@ for t, kind, i in pts:
         if active and fill < 0.5:
             for j in active:
                 low_by[(ev[j][3], ev[j][4])] += dt
+        elif active and fill < 1.0:
+            for j in active:
+                mid_by[(ev[j][3], ev[j][4])] += dt
+        if len(active) == 1:
+            for j in active:
+                alone_by[(ev[j][3], ev[j][4], ev[j][2] >= 1.0)] += dt
     prev = t
     if kind == 1:
         active.add(i)
@@ -61,6 +69,13 @@ for b in ('idle', '<0.25', '<0.5', '<1', 'full'):
     print('  summed fill %-6s %7.2f ms  %5.1f %%' % (b, hist[b] / 1e6, 100.0 * hist[b] / tot))
 print('kernels running while the summed fill is below 0.5 (time, queue):')
 for (n, q), t in sorted(low_by.items(), key=lambda x: -x[1])[:25]:
+    print('  %7.2f ms  q%s  %s' % (t / 1e6, q, n))
+print('kernels running while the summed fill is in [0.5, 1) (time, queue):')
+for (n, q), t in sorted(mid_by.items(), key=lambda x: -x[1])[:20]:
+    print('  %7.2f ms  q%s  %s' % (t / 1e6, q, n))
+print('time with exactly ONE kernel running: %.2f ms of which chip-filling launches %.2f ms; the others:' % (
+    sum(alone_by.values()) / 1e6, sum(t for (n, q, f), t in alone_by.items() if f) / 1e6))
+for (n, q, f), t in sorted(((k, v) for k, v in alone_by.items() if not k[2]), key=lambda x: -x[1])[:20]:
     print('  %7.2f ms  q%s  %s' % (t / 1e6, q, n))
 
 cnt = defaultdict(int)

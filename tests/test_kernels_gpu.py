@@ -531,6 +531,57 @@ def test_bn_act_gate_forward_backward(C, gate, after, drop):
         close(dalpha.cpu(), ar.grad, tol=1e-2, floor=1e-3, what='dalpha')
 
 
+@pytest.mark.parametrize('C,N,H,W,drop,noy,two', [(20, 3, 5, 7, 0.0, False, True), (256, 16, 16, 16, 0.0, True, True),
+                                                  (64, 16, 8, 8, 0.5, True, False), (512, 16, 2, 2, 0.5, False, True),
+                                                  (32, 5, 29, 29, 0.0, True, True)])
+def test_bn_backward_small_tensor_one_launch(C, N, H, W, drop, noy, two):
+    """gcc_bnact_bwd of <= 4096 pixels (the U-Net's <= 16x16 layers at N=16) runs as ONE kernel (GCC_OPT_BN_BWD_SMALL): against
+    fp32 torch autograd and against the three-launch pipeline on the same inputs (dropout mask regenerated from the same
+    counter; y given or recomputed from x; one or two incoming gradients).  The last case (4205 pixels) is above the limit and
+    must take the three-launch path under both settings."""
+    ops = _ops()
+    from gcc_amd import _lib
+    g = torch.Generator().manual_seed(C + H)
+    x = rb(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), torch.randn(C, generator=g)
+    xd = to_dev(x)
+    st = ops.BNState(C, DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    stats = torch.stack([x.sum((0, 2, 3)), (x * x).sum((0, 2, 3))])[None].contiguous().to(DEV)
+    ops.bn_finalize(stats, N * H * W, gamma.to(DEV), beta.to(DEV), rm, rv, st)
+    y, y2 = ops.new_act(N, C, H, W, DEV), ops.new_act(N, C, H, W, DEV)
+    ops.bnact_fwd(xd, y, y2, scale=st.scale, shift=st.shift, act=ops.ACT_LRELU, act2=ops.ACT_RELU, drop_p=drop, seed=77)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    if drop > 0:
+        keep = (to_cpu(y) != 0).float()
+        z = z * keep / (1 - drop)
+    g1 = rb(torch.randn(N, C, H, W, generator=g))
+    g2 = rb(torch.randn(N, C, H, W, generator=g)) if two else None
+    loss = (F.leaky_relu(z, 0.2) * g1).sum() + ((F.relu(z) * g2).sum() if two else 0.0)
+    loss.backward()
+    res = {}
+    for small in (1, 0):
+        prev = ops.lib().gcc_set_option(_lib.OPT_BN_BWD_SMALL, small)
+        try:
+            dgamma, dbeta = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+            dx = ops.new_act(N, C, H, W, DEV)
+            ops.bnact_bwd(xd, None if noy else y, to_dev(g1), dx, g2=to_dev(g2) if two else None, bn=st, gamma=gamma.to(DEV),
+                          beta=beta.to(DEV), act=ops.ACT_LRELU, act2=ops.ACT_RELU, drop_p=drop, seed=77, dgamma=dgamma, dbeta=dbeta)
+            res[small] = (to_cpu(dx), dgamma.cpu(), dbeta.cpu())
+        finally:
+            ops.lib().gcc_set_option(_lib.OPT_BN_BWD_SMALL, prev)
+        close(res[small][0], xr.grad, tol=2e-2, what='dx (one launch: %d)' % small)
+        close(res[small][1], gr.grad, tol=1e-2, floor=1e-3, what='dgamma (one launch: %d)' % small)
+        close(res[small][2], br.grad, tol=1e-2, floor=1e-3, what='dbeta (one launch: %d)' % small)
+    # the two paths against each other: same sums up to their order, dz unrounded in the one-launch kernel
+    close(res[1][0], res[0][0], tol=1e-2, what='dx, one launch against three')
+    close(res[1][1], res[0][1], tol=1e-4, floor=1e-4, what='dgamma, one launch against three')
+    if N * H * W > 4096:
+        assert torch.equal(res[1][0], res[0][0])
+
+
 def test_channel_sum():
     ops = _ops()
     x = rb(torch.randn(3, 40, 7, 5))
