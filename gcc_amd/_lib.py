@@ -153,6 +153,12 @@ PROTOTYPES = {
     'gcc_fill_f32': (_I, [_P, _F, _Z, _P]),
     'gcc_clamp_f32': (_I, [_P, _F, _F, _Z, _P]),
     'gcc_scalar_op': (_I, [_I, _P, _P, _P, _F, _F, _P, _P]),
+    'gcc_comm_unique_id': (_I, [_P]),
+    'gcc_comm_init': (_I, [C.POINTER(C.c_void_p), _I, _I, _P]),
+    'gcc_comm_allreduce_sum_f32': (_I, [_P, _P, _Z, _P]),
+    'gcc_comm_rank': (_I, [_P]),
+    'gcc_comm_world': (_I, [_P]),
+    'gcc_comm_destroy': (_I, [_P]),
 }
 
 _lib = None

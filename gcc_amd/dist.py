@@ -148,6 +148,42 @@ class GradReducer:
         self.finish()
 
 
+class NativeComm:
+    """The C ABI's own communicator (include/gcc_hip.h: gcc_comm_*), for hosts without a process group: RCCL directly, the id
+    made by rank 0 (`NativeComm.unique_id()`) and handed to the other ranks by whatever channel the host has.  gcc_amd's
+    model classes use torch.distributed (GradReducer above); this wrapper is the binding example of INTEGRATION.md and what
+    the tests drive."""
+
+    def __init__(self, rank, world, unique_id):
+        import ctypes as C
+        from . import _lib
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        _lib.check(self._lib.gcc_comm_init(C.byref(self._h), int(rank), int(world), bytes(unique_id)), 'gcc_comm_init')
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _lib
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().gcc_comm_unique_id(buf), 'gcc_comm_unique_id')
+        return bytes(buf)
+
+    def all_reduce_sum_(self, flat, stream=None):
+        """in place, fp32, enqueued on `stream` (raw handle; default: the current stream)"""
+        from . import _lib, ops
+        assert flat.dtype == torch.float32 and flat.is_contiguous() and flat.is_cuda
+        _lib.check(self._lib.gcc_comm_allreduce_sum_f32(self._h, flat.data_ptr(), flat.numel(),
+                                                        ops.stream() if stream is None else stream), 'gcc_comm_allreduce_sum_f32')
+        return flat
+
+    def close(self):
+        if self._h:
+            self._lib.gcc_comm_destroy(self._h)
+            self._h = None
+
+
 def all_reduce_sum(t):
     """sum over ranks of a small fp32 device vector, in place (the teacher's arch-difference terms: every replica must
     feed the same value into its EMA; the caller folds 1/world into its next kernel)"""

@@ -7,7 +7,8 @@
  *   - plain C, no torch types; every pointer is a DEVICE pointer owned by the caller (activations,
  *     weights, workspaces); the library allocates nothing.  Its only process-wide state is the table of
  *     tuning options below (gcc_set_option / gcc_conv_set_plan: atomics, defaults read once from GCC_*
- *     environment variables) and the one-time hipFuncSetAttribute of the kernels that use > 64 KB of LDS;
+ *     environment variables), the one-time hipFuncSetAttribute of the kernels that use > 64 KB of LDS, and the RCCL entry
+ *     points resolved on the first gcc_comm_* call (communicators themselves are explicit objects the caller owns);
  *   - every kernel is enqueued on the caller's `stream` and never synchronises;
  *   - return value: 0 = GCC_OK, negative = error (see gcc_strerror); no exceptions, no abort;
  *   - activations are NHWC bf16 (a PyTorch channels_last tensor): element (n,h,w,c) lives at
@@ -499,6 +500,23 @@ int gcc_crop_flip_normalize(const void* src, int H, int W, size_t pitch, int x0,
  * low-resolution input, data/sr_dataset.py:52-56), form 1 convert_image '[-1, 1]' = 2 (v / 255) - 1 (:49-50), form 2 v / 255 */
 int gcc_crop_convert(const void* src, int H, int W, size_t pitch, int x0, int y0, int crop_h, int crop_w, int flip, int form,
                      const float* mean3, const float* std3, float* nchw, void* nhwc_bf16, int ld, gcc_stream_t stream);
+
+/* ---- gradient exchange ---------------------------------------------------------------------------------
+ * The reference trains on one device (models/Pix2Pix.py:356); the data-parallel path sums the five optimizers' flat fp32
+ * gradient buffers over ranks before each `optimizer.step()` (train.py has no counterpart: this is the exchange a
+ * multi-GPU launch of it needs).  An explicit communicator over RCCL, one per process (one process per GPU), created from an
+ * id that rank 0 makes and the host distributes by its own means.  gcc_amd's Python host uses torch.distributed (the same
+ * RCCL) instead; these entry points serve a host without one.  RCCL is loaded on first use (GCC_ERR_UNSUPPORTED if absent). */
+#define GCC_COMM_ID_BYTES 128
+typedef struct gcc_comm gcc_comm_t;
+int gcc_comm_unique_id(void* id /* [GCC_COMM_ID_BYTES], host */);
+int gcc_comm_init(gcc_comm_t** comm, int rank, int world, const void* id);   /* collective; binds to the current device */
+/* in-place sum over ranks of count fp32 values, ordered on `stream` like a kernel; the caller applies 1 / world in its
+ * optimizer step (gcc_adam_tensor_t.grad_scale) and picks the bucket size (one call per bucket) */
+int gcc_comm_allreduce_sum_f32(gcc_comm_t* comm, float* buf, size_t count, gcc_stream_t stream);
+int gcc_comm_rank(const gcc_comm_t* comm);
+int gcc_comm_world(const gcc_comm_t* comm);
+int gcc_comm_destroy(gcc_comm_t* comm);
 
 #ifdef __cplusplus
 }

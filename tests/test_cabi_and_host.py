@@ -38,6 +38,26 @@ def test_library_exports_every_declared_symbol():
     assert b'workspace' in _lib.load().gcc_strerror(-3)
 
 
+def test_comm_entry_points_without_a_gpu():
+    """gcc_comm_*: the id comes from RCCL (resolved at run time, no load-time dependency), argument errors are codes"""
+    from gcc_amd import _lib
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(128)
+    assert lib.gcc_comm_unique_id(buf) == 0
+    assert any(bytes(buf))
+    assert lib.gcc_comm_unique_id(None) == -1
+    h = ctypes.c_void_p()
+    assert lib.gcc_comm_init(ctypes.byref(h), 2, 2, bytes(buf)) == -1          # rank out of range
+    assert lib.gcc_comm_init(ctypes.byref(h), 0, 0, bytes(buf)) == -1
+    assert lib.gcc_comm_init(None, 0, 1, bytes(buf)) == -1
+    assert lib.gcc_comm_allreduce_sum_f32(None, None, 0, None) == -1
+    assert lib.gcc_comm_destroy(None) == -1
+    assert lib.gcc_comm_rank(None) == -1 and lib.gcc_comm_world(None) == -1
+    import subprocess
+    out = subprocess.run(['readelf', '-d', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert 'rccl' not in out, 'libgcc_hip.so must not depend on RCCL at load time'
+
+
 def test_conv_route_predicates():
     """gcc_conv_route is host logic only: which kernel family each layer shape of the headline config runs on"""
     from gcc_amd import _lib

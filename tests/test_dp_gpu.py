@@ -118,6 +118,63 @@ def test_two_rccl_ranks_two_devices():
     assert a['losses'] == b['losses']
 
 
+def _native_worker(rank, world, uid, q):
+    sys.path.insert(0, ROOT)
+    os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    import torch as th
+    from gcc_amd import dist as gdist
+    from gcc_amd import ops
+    th.cuda.set_device(rank)
+    ops.set_device_index(rank)
+    comm = gdist.NativeComm(rank, world, uid)
+    g = th.Generator().manual_seed(3 + rank)
+    host = th.randn(1 << 20, generator=g)
+    buf = host.to('cuda:%d' % rank)
+    side = th.cuda.Stream()
+    with th.cuda.stream(side):                  # ordered on the caller's stream like a kernel
+        buf.mul_(2.0)
+        comm.all_reduce_sum_(buf)
+        buf.mul_(0.5)
+    th.cuda.synchronize()
+    q.put({'rank': rank, 'sum': buf.cpu().numpy(), 'own': host.numpy()})
+    comm.close()
+
+
+@pytest.mark.timeout(900)
+def test_native_comm_single_rank():
+    """include/gcc_hip.h gcc_comm_*: communicator of one rank on this box's GPU -- init, an all-reduce enqueued between two
+    kernels of a side stream, destroy; the sum over one rank is the buffer itself"""
+    from gcc_amd import dist as gdist
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_native_worker, args=(0, 1, gdist.NativeComm.unique_id(), q))
+    p.start()
+    res = _collect(q, [p], 1)[0]
+    p.join(120)
+    assert p.exitcode == 0
+    import numpy as np
+    assert np.array_equal(res['sum'], res['own'] * np.float32(2.0) * np.float32(0.5))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: one RCCL rank per device')
+def test_native_comm_two_ranks_two_devices():
+    from gcc_amd import dist as gdist
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    uid = gdist.NativeComm.unique_id()
+    procs = [ctx.Process(target=_native_worker, args=(r, 2, uid, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    a, b = sorted(_collect(q, procs, 2), key=lambda d: d['rank'])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    import numpy as np
+    want = (a['own'] * np.float32(2.0) + b['own'] * np.float32(2.0)) * np.float32(0.5)
+    assert np.array_equal(a['sum'], b['sum']) and np.allclose(a['sum'], want, rtol=0, atol=1e-6)
+
+
 def _rccl_worker(port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
