@@ -287,6 +287,8 @@ def main():
         'loss_check': {k: round(v, 4) for k, v in losses.items()},
     }
     if roof is not None:
+        if 'conv_roofline' in roof:       # north_star: throughput as a fraction of the conv roofline
+            roof['conv_roofline']['frac_of_step'] = round(roof['conv_roofline']['bound_ms'] / (1000.0 * dt / args.steps), 4)
         out['roofline'] = roof
     out['rccl_ranks'] = world
     if comm is not None:

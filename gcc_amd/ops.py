@@ -57,13 +57,24 @@ class _Profile:
         launches inside are attributed to `name` too (PROFILE.tag)"""
         return _Span(self, name)
 
-    def stop(self, peak=2.5e15):
+    def stop(self, peak=2.5e15, hbm=8.0e12):
         self.active = False
         torch.cuda.synchronize()
         agg, shapes = {}, {}
         tags = {}
+        roof_s, roof_meas_s, roof_n = 0.0, 0.0, 0
         for kind, flops, e0, e1, shape, tag in self.records:
             sec = e0.elapsed_time(e1) * 1e-3
+            if shape is not None and len(shape) == 8 and shape[0] in ('fprop', 'dgrad', 'wgrad'):
+                # SURVEY.md 8(d) 'conv roofline': per layer max(FLOP / MFMA peak, minimum bytes / HBM bandwidth), summed --
+                # minimum bytes = every operand once (bf16 activations and weights; the fp32 weight gradient of a wgrad)
+                op, n_, ho, wo, ci, co, k_, st_ = shape
+                small, big = n_ * ho * wo * co, n_ * (ho * st_) * (wo * st_) * ci      # conv output side / input side
+                wts = co * ci * k_ * k_
+                nbytes = 2.0 * (small + big) + (4.0 if op == 'wgrad' else 2.0) * wts
+                roof_s += max(flops / peak, nbytes / hbm)
+                roof_meas_s += sec
+                roof_n += 1
             if tag is not None:
                 t = tags.setdefault(tag, [0.0, 0.0, 0])
                 t[0] += flops
@@ -104,6 +115,11 @@ class _Profile:
                        'avg_launch_us': round(1e6 * sec / n, 2),
                        'algorithmic_gflop_per_launch': round(fl / n / 1e9, 3)}
         out['per_kernel'] = per
+        if roof_n:
+            out['conv_roofline'] = {'layers': roof_n, 'bound_ms': round(roof_s * 1e3, 3), 'measured_ms': round(roof_meas_s * 1e3, 3),
+                                    'frac': round(roof_s / roof_meas_s, 4),
+                                    'definition': 'sum over the conv launches of one iteration of max(FLOP / 2.5 PFLOP/s, '
+                                                  'minimum operand bytes / 8 TB/s) over the sum of their measured durations'}
         return out
 
 
@@ -447,7 +463,8 @@ def conv_wgrad_seg(x, dy, dw, rows, cols, row_split, col_split, k, stride, pad, 
     check(lib().gcc_conv_wgrad_seg(C.byref(d), xp, yp, dw.data_ptr(), rows, cols, row_split, col_split, int(accumulate),
                                    ws.data_ptr(), ws.numel(), stream()), 'gcc_conv_wgrad_seg')
     if e0 is not None:
-        PROFILE.end('wgrad_kernel (+ slab reduce)', 2.0 * N * Ho * Wo * rows * k * k * cols, e0)
+        PROFILE.end('wgrad_kernel (+ slab reduce)', 2.0 * N * Ho * Wo * rows * k * k * cols, e0,
+                    shape=('wgrad', N, Ho, Wo, cols, rows, k, stride))
     return dw
 
 
