@@ -627,9 +627,11 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
 
     def _dws(self, i, N, C, HW):
         key = ('w', i, N, C, HW)
-        if key not in self._dist_ws:
-            self._dist_ws[key] = torch.empty(ops.distill_workspace_bytes(N, C, HW), dtype=torch.uint8, device=self.device)
-        return self._dist_ws[key]
+        need = ops.distill_workspace_bytes(N, C, HW)       # depends on the weight-gradient split plan (tuning options)
+        buf = self._dist_ws.get(key)
+        if buf is None or buf.numel() < need:
+            buf = self._dist_ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return buf
 
     # -- one iteration (models/Pix2Pix.py:565-583) ----------------------------------------------------
     def optimize_parameters(self):

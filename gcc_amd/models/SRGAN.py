@@ -288,9 +288,11 @@ class SRGAN(TeacherStreamMixin, nn.Module):
 
     def _dws(self, i, N, C, HW):
         key = ('ws', i, N, C, HW)
-        if key not in self._bufs:
-            self._bufs[key] = torch.empty(ops.distill_workspace_bytes(N, C, HW), dtype=torch.uint8, device=self.device)
-        return self._bufs[key]
+        need = ops.distill_workspace_bytes(N, C, HW)       # depends on the weight-gradient split plan (tuning options)
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < need:
+            buf = self._bufs[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return buf
 
     def set_input(self, input):
         self.input = input

@@ -24,6 +24,19 @@ class TeacherStreamMixin:
             self.teacher_model.serialize_streams = not concurrent
         engine.OVERLAP_WGRAD = bool(concurrent) and os.environ.get('GCC_OVERLAP_WGRAD', '1') != '0'
         ops.lib().gcc_set_option(_lib.OPT_IGEMM_PAIR, 0 if concurrent else 1)
+        self._apply_wgrad_plan(concurrent)
+
+    @staticmethod
+    def _apply_wgrad_plan(concurrent):
+        """Workgroup targets of the split weight-gradient launches.  The library's defaults (256 / 512) are for a launch that
+        has the chip to itself; on the weight-gradient side stream of the production schedule half of that is faster end to
+        end (+0.6 %, profiles/r02_ab_tables.md r03w / r03x): half-chip launches beside the main stream's chain, half the fp32
+        slab traffic -- although the same launches alone run at 365 instead of 538 TFLOP/s.  An explicit GCC_WGRAD_WGS* wins."""
+        from .. import _lib
+        lib = ops.lib()
+        for opt_id, env, side in ((_lib.OPT_WGRAD_WGS_BIG, 'GCC_WGRAD_WGS_BIG', 128), (_lib.OPT_WGRAD_WGS, 'GCC_WGRAD_WGS', 256)):
+            if env not in os.environ:
+                lib.gcc_set_option(opt_id, side if concurrent else -1)
 
     def _teacher_stream(self):
         if getattr(self, 'serialize_streams', False):
@@ -31,6 +44,8 @@ class TeacherStreamMixin:
         if getattr(self, '_tstream', None) is None:
             on = os.environ.get('GCC_CONCURRENT_TEACHER', '1') != '0'
             self._tstream = torch.cuda.Stream(device=self.device) if on else False
+            if on:
+                self._apply_wgrad_plan(True)
         return self._tstream
 
     def _mark_teacher_free(self):
