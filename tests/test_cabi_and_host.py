@@ -58,6 +58,27 @@ def test_comm_entry_points_without_a_gpu():
     assert 'rccl' not in out, 'libgcc_hip.so must not depend on RCCL at load time'
 
 
+def test_weight_gradient_plan_follows_the_schedule(monkeypatch):
+    """models/_streams.py: the concurrent schedule halves the workgroup targets of split weight-gradient launches, the
+    single-stream schedule restores the library's defaults, an explicit GCC_WGRAD_WGS* environment variable wins"""
+    from gcc_amd import _lib
+    from gcc_amd.models._streams import TeacherStreamMixin as M
+    lib = _lib.load()
+    monkeypatch.delenv('GCC_WGRAD_WGS_BIG', raising=False)
+    monkeypatch.delenv('GCC_WGRAD_WGS', raising=False)
+    try:
+        M._apply_wgrad_plan(True)
+        assert (lib.gcc_get_option(_lib.OPT_WGRAD_WGS_BIG), lib.gcc_get_option(_lib.OPT_WGRAD_WGS)) == (128, 256)
+        M._apply_wgrad_plan(False)
+        assert (lib.gcc_get_option(_lib.OPT_WGRAD_WGS_BIG), lib.gcc_get_option(_lib.OPT_WGRAD_WGS)) == (256, 512)
+        monkeypatch.setenv('GCC_WGRAD_WGS', '512')
+        M._apply_wgrad_plan(True)
+        assert (lib.gcc_get_option(_lib.OPT_WGRAD_WGS_BIG), lib.gcc_get_option(_lib.OPT_WGRAD_WGS)) == (128, 512)
+    finally:
+        lib.gcc_set_option(_lib.OPT_WGRAD_WGS_BIG, -1)
+        lib.gcc_set_option(_lib.OPT_WGRAD_WGS, -1)
+
+
 def test_conv_route_predicates():
     """gcc_conv_route is host logic only: which kernel family each layer shape of the headline config runs on"""
     from gcc_amd import _lib
