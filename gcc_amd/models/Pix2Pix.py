@@ -801,9 +801,13 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         self.D.mask_dirty = True
 
     def clipping_mask_alpha(self):
-        for m in self.netD.modules():
-            if isinstance(m, DifferentiableOP):
-                m.clip_alpha()
+        flat = getattr(getattr(self, 'optimizer_arch', None), 'flat', None)
+        if flat is not None:
+            ops.clamp_(flat.values, 0.0, 1.0)          # every alpha lives in the arch optimizer's flat buffer: one launch
+        else:
+            for m in self.netD.modules():
+                if isinstance(m, DifferentiableOP):
+                    m.clip_alpha()
         self.D.mask_dirty = True
 
     # -- bookkeeping surface ----------------------------------------------------------------------
