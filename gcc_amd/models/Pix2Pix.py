@@ -703,9 +703,14 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
 
     def _apply_G_update(self):
         self.optimizer_G.step()          # L1_sparsity() (:554-563) is fused into the Adam kernel
-        self.G.repack()
-        for t in self.T:
-            t.repack()
+        if self.T and isinstance(self.G, engine.UnetEngine):     # generator + transform convs: one repack launch (on the iteration's critical chain)
+            if getattr(self, '_g_pack', None) is None:
+                self._g_pack = ops.PackPlan(list(self.G.convs()) + list(self.T), self.device)
+            self._g_pack.run()
+        else:
+            self.G.repack()
+            for t in self.T:
+                t.repack()
 
     def finish_G_update(self):
         if self._pending_G is not None:
