@@ -969,6 +969,52 @@ __global__ __launch_bounds__(1024) void channel_sum_finalize_kernel(const float*
     }
 }
 
+// small tensors (the batch-1 models' bias gradients: <= 128 x 128 pixels): one launch -- a workgroup owns every pixel of 8
+// channels, four pixels' loads in flight per thread, wave shuffles + LDS in double.  The two-launch pipeline above costs those
+// launch-bound models two host enqueues and two dependent launches per convolution bias.
+constexpr int SUM_SMALL_NT = 512;
+constexpr size_t SUM_SMALL_MAX_PIXELS = 16384;
+__global__ __launch_bounds__(SUM_SMALL_NT) void channel_sum_small_kernel(const SumArgs a, float* out, int accumulate) {
+    __shared__ double red[SUM_SMALL_NT / 64][8];
+    const int c0 = blockIdx.x * 8;
+    const int pixels = (int)a.pixels;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int pix = threadIdx.x;
+    for (; pix + 3 * SUM_SMALL_NT < pixels; pix += 4 * SUM_SMALL_NT) {
+        i32x4 r[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) r[q] = *(const i32x4*)(a.x + (size_t)(pix + q * SUM_SMALL_NT) * a.ld + a.off + c0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float v[8];
+            unpack8(r[q], v);
+#pragma unroll
+            for (int j = 0; j < 8; j++) s[j] += v[j];
+        }
+    }
+    for (; pix < pixels; pix += SUM_SMALL_NT) {
+        float v[8];
+        unpack8(*(const i32x4*)(a.x + (size_t)pix * a.ld + a.off + c0), v);
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] += v[j];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] = wave_sum(s[j]);
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) red[wave][j] = (double)s[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && c0 + (int)threadIdx.x < a.C) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < SUM_SMALL_NT / 64; w++) t += red[w][threadIdx.x];
+        const int c = c0 + threadIdx.x;
+        out[c] = accumulate ? out[c] + (float)t : (float)t;
+    }
+}
+
 // per-channel sum / sum of squares in the conv-epilogue partial format: out[group][block][2][C]
 struct StatArgs { const bf16_t* x; int ld, off; int C; size_t pixels; Layout L; float* out; int nblocks; };
 __global__ __launch_bounds__(256) void channel_stats_g_kernel(const StatArgs a) {
@@ -1222,6 +1268,11 @@ extern "C" int gcc_channel_sum(const void* x, int ld, int off, int C, size_t pix
     if (!make_layout(C, &a.L)) return GCC_ERR_UNSUPPORTED;
     const int blocks = bwd_blocks(pixels, a.L);
     hipStream_t st = (hipStream_t)stream;
+    if (pixels <= SUM_SMALL_MAX_PIXELS && gcc_opt(GCC_OPT_BN_BWD_SMALL)) {
+        hipLaunchKernelGGL(channel_sum_small_kernel, dim3(a.C8 / 8), dim3(SUM_SMALL_NT), 0, st, a, out, accumulate);
+        GCC_CHECK_LAUNCH();
+        return GCC_OK;
+    }
     hipLaunchKernelGGL(channel_sum_kernel, dim3(blocks), dim3(256), 0, st, a);
     GCC_CHECK_LAUNCH();
     hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, (const float*)ws, blocks, C,

@@ -582,12 +582,24 @@ def test_bn_backward_small_tensor_one_launch(C, N, H, W, drop, noy, two):
         assert torch.equal(res[1][0], res[0][0])
 
 
-def test_channel_sum():
+@pytest.mark.parametrize('N,C,H,W', [(3, 40, 7, 5), (1, 24, 128, 128), (1, 64, 129, 128), (2, 8, 64, 100), (16, 256, 1, 1)])
+def test_channel_sum(N, C, H, W):
+    """bias gradients: the one-launch kernel (<= 16384 pixels) and the two-launch pipeline, plain and accumulating"""
     ops = _ops()
-    x = rb(torch.randn(3, 40, 7, 5))
-    out = torch.zeros(40, device=DEV)
-    ops.channel_sum(to_dev(x), out)
-    close(out.cpu(), x.sum((0, 2, 3)), tol=1e-4, floor=1e-4, what='channel sum')
+    from gcc_amd import _lib
+    x = rb(torch.randn(N, C, H, W, generator=torch.Generator().manual_seed(C + H)))
+    want = x.double().sum((0, 2, 3)).float()
+    xd = to_dev(x)
+    for small in (1, 0):
+        prev = ops.lib().gcc_set_option(_lib.OPT_BN_BWD_SMALL, small)
+        try:
+            out = torch.zeros(C, device=DEV)
+            ops.channel_sum(xd, out)
+            close(out.cpu(), want, tol=1e-4, floor=2e-3, what='channel sum (one launch: %d)' % small)
+            ops.channel_sum(xd, out, accumulate=True)
+            close(out.cpu(), 2 * want, tol=1e-4, floor=4e-3, what='accumulated channel sum (one launch: %d)' % small)
+        finally:
+            ops.lib().gcc_set_option(_lib.OPT_BN_BWD_SMALL, prev)
 
 
 @pytest.mark.parametrize('mode', ['hinge', 'lsgan', 'vanilla', 'wgangp'])
