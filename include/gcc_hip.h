@@ -81,7 +81,8 @@ enum {
                                    production schedule: +1 % on the step).  gcc_amd's models switch it with their schedule. */
     GCC_OPT_WGRAD_BIG_MIN_TILES,/* minimum number of 256x256 output tiles for the big weight-gradient tiling (default 32) */
     GCC_OPT_FUSE_BN,            /* 1 (default): gcc_conv_bn_act folds split-K partials, statistics, finalize and normalise in one kernel */
-    GCC_OPT_BN_BWD_SMALL,       /* 1 (default): gcc_bnact_bwd of <= 4096 pixels (training BatchNorm, no gate) runs as one kernel instead of three */
+    GCC_OPT_BN_BWD_SMALL,       /* 1 (default): gcc_bnact_bwd of <= 4096 pixels (training BatchNorm, no gate) runs as one kernel instead of
+                                   three, gcc_channel_sum of <= 16384 pixels as one instead of two */
     GCC_OPT_COUNT_
 };
 int gcc_set_option(int id, int value);
