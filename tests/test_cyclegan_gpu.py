@@ -5,6 +5,7 @@ through two generators with the recipe's random weights, which amplify the first
 bf16 storage emulated is 0.098-0.112 max / 0.0176 mean away from the fp32 reference on rec_A / rec_B of this input,
 so their bar is 0.16 max / 0.025 mean."""
 import copy
+from collections import OrderedDict
 import os
 import random
 
@@ -273,3 +274,93 @@ def test_cyclegan_pretrain_l1_sparsity_and_pool(golden_dir):
         imgs[:, 0, 0, 0] = torch.arange(2, dtype=torch.float32, device=DEV).bfloat16() + 10 * step
         got = pool.query(imgs, out)[:, 0, 0, 0].float().cpu().tolist()
         assert got == z['pool.returned'][step].tolist(), (step, got)
+
+
+FULL_CYCLE_ARGV = ['--dataroot', './database/horse2zebra/', '--model', 'cyclegan', '--gpu_ids', '0', '--ngf', '24', '--ndf', '64',
+                   '--teacher_ngf', '64', '--online_distillation', '--darts_discriminator', '--lambda_content', '0.01',
+                   '--lambda_gram', '10', '--arch_lr', '1e-4', '--arch_lr_step']
+
+
+def test_cyclegan_full_width_iteration_vs_oracle():
+    """BASELINE.json configs[2] at its real widths (student ngf 24 / masked D ndf 64, teacher ngf 64 / ndf 64, 256 x 256, batch
+    1): one whole iteration + arch step of the HIP path against the oracle on the same recipe weights -- the tile plans and
+    kernel routes these widths select differ from the ngf-8 fixtures'.  Generated images and every logged loss; the
+    bf16-emulating oracle gives the floor the image tolerances are set against (printed)."""
+    from oracle import gcc_oracle as O
+    from tests.golden.recipe import recipe_state_dict, recipe_transform
+    model, teacher, opt = build_cyclegan(FULL_CYCLE_ARGV, teacher_ndf=64)
+    seeds = {'sG_A': 701, 'sG_B': 702, 'sD_A': 703, 'sD_B': 704, 'tG_A': 705, 'tG_B': 706, 'tD_A': 707, 'tD_B': 708}
+    nets = {'sG_A': model.netG_A, 'sG_B': model.netG_B, 'sD_A': model.netD_A, 'sD_B': model.netD_B,
+            'tG_A': teacher.netG_A, 'tG_B': teacher.netG_B, 'tD_A': teacher.netD_A, 'tD_B': teacher.netD_B}
+    sds = {}
+    for tag, net in nets.items():
+        sds[tag] = recipe_state_dict(OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items()), seeds[tag])
+        net.load_state_dict(sds[tag])
+    Ts = {}
+    with torch.no_grad():
+        for w, convs, base in (('A', model.transform_A_convs, 720), ('B', model.transform_B_convs, 730)):
+            Ts[w] = [recipe_transform(t.weight.shape[0], t.weight.shape[1], base + i) for i, t in enumerate(convs)]
+            for t, v in zip(convs, Ts[w]):
+                t.weight.copy_(v.to(DEV))
+    model.refresh_weights()
+    teacher.refresh_weights()
+    model.model_train()
+    g = torch.Generator().manual_seed(91)
+    A, B, vA, vB = (torch.rand(1, 3, 256, 256, generator=g) * 2 - 1 for _ in range(4))
+    model.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
+    model.optimize_parameters()
+    got_img = {n: getattr(model, n).cpu() for n in ('fake_A', 'fake_B', 'rec_A', 'rec_B')}
+    got_timg = {n: getattr(teacher, n).cpu() for n in ('fake_A', 'fake_B')}
+    model.set_input({'A': vA, 'B': vB, 'A_paths': ['a'], 'B_paths': ['b']})
+    model.clipping_mask_alpha()
+    model.optimizer_netD_arch()
+    got, tgot = model.get_current_losses(), teacher.get_current_losses()
+
+    def run_oracle(emulate):
+        O.EMULATE_BF16 = emulate
+        try:
+            oopt = O.Opt(ngf=24, ndf=64, teacher_ngf=64, teacher_ndf=64, direction=opt.direction, gan_mode=opt.gan_mode,
+                         lambda_L1=opt.lambda_L1, lambda_A=opt.lambda_A, lambda_B=opt.lambda_B,
+                         lambda_identity=opt.lambda_identity, lambda_content=0.01, lambda_gram=10.0)
+            cp = lambda tag: copy.deepcopy(sds[tag])
+            ot = O.CycleGANOracle(oopt, {'A': cp('tG_A'), 'B': cp('tG_B')}, {'A': cp('tD_A'), 'B': cp('tD_B')}, masked=False)
+            om = O.CycleGANOracle(oopt, {'A': cp('sG_A'), 'B': cp('sG_B')}, {'A': cp('sD_A'), 'B': cp('sD_B')},
+                                  {w: [t.clone() for t in Ts[w]] for w in 'AB'}, masked=True, teacher=ot)
+            om.set_input(A, B)
+            om.optimize_parameters()
+            imgs = {n: getattr(om, n).detach().clone() for n in ('fake_A', 'fake_B', 'rec_A', 'rec_B')}
+            timgs = {n: getattr(ot, n).detach().clone() for n in ('fake_A', 'fake_B')}
+            om.set_input(vA, vB)
+            om.clipping_mask_alpha()
+            om.optimizer_netD_arch()
+            return imgs, timgs, dict(om.losses), dict(ot.losses)
+        finally:
+            O.EMULATE_BF16 = False
+    ref_img, ref_timg, ref_l, ref_tl = run_oracle(False)
+    emu_img, emu_timg, _, _ = run_oracle(True)
+    bad = []
+    for n in got_img:
+        e, floor = (got_img[n] - ref_img[n]).abs(), (emu_img[n] - ref_img[n]).abs()
+        print('%s: max %.4g mean %.4g   (bf16-emulating oracle against fp32: max %.4g mean %.4g)' % (n, e.max(), e.mean(), floor.max(), floor.mean()))
+        k = 4.0 if n.startswith('rec') else 1.0
+        # the fixture tolerances, or 1.5x what bf16 storage alone does to this image at these widths
+        if not (e.max() <= max(4e-2 * k, 1.5 * float(floor.max())) and e.mean() <= max(6.25e-3 * k, 1.5 * float(floor.mean()))):
+            bad.append((n, float(e.max()), float(e.mean())))
+    for n in got_timg:
+        e, floor = (got_timg[n] - ref_timg[n]).abs(), (emu_timg[n] - ref_timg[n]).abs()
+        print('teacher %s: max %.4g mean %.4g   (bf16-emulating oracle against fp32: max %.4g mean %.4g)' % (n, e.max(), e.mean(), floor.max(), floor.mean()))
+        if not (e.max() <= max(4e-2, 1.5 * float(floor.max())) and e.mean() <= max(6e-3, 1.5 * float(floor.mean()))):
+            bad.append(('teacher ' + n, float(e.max()), float(e.mean())))
+    assert len(set(ref_l) & set(got)) >= 10, (sorted(ref_l), sorted(got))
+    for k, v in ref_l.items():
+        if k not in got:
+            continue
+        print('S %-24s got %.5g ref %.5g' % (k, got[k], v))
+        if not abs(got[k] - v) <= 3e-2 * max(1.0, abs(v)):
+            bad.append((k, got[k], v))
+    for k, v in ref_tl.items():
+        if k in tgot:
+            print('T %-24s got %.5g ref %.5g' % (k, tgot[k], v))
+            if not abs(tgot[k] - v) <= 3e-2 * max(1.0, abs(v)):
+                bad.append(('teacher ' + k, tgot[k], v))
+    assert not bad, bad
