@@ -347,3 +347,90 @@ def test_sagan_gradients_vs_oracle(golden_dir):
         if t == 'alpha':
             check((t, k), sd[k].grad)
     assert not bad, bad
+
+
+FULL_SAGAN_ARGV = ['--dataroot', './database/celeb/', '--model', 'sagan', '--gpu_ids', '0', '--ngf', '48', '--ndf', '64',
+                   '--teacher_ngf', '64', '--online_distillation', '--darts_discriminator', '--threshold', '0.1',
+                   '--lambda_L1', '1', '--lambda_content', '1', '--lambda_gram', '1', '--arch_lr', '1e-4', '--batch_size', '64']
+
+
+def test_sagan_full_width_iteration_vs_oracle():
+    """BASELINE.json configs[3] at its real widths (student ngf 48 / masked D ndf 64, teacher ngf 64 / ndf 64, 64 x 64, batch
+    64, z 128): one iteration + arch step of the HIP path against the oracle on the same recipe weights.  The generated
+    images against the fp32 oracle (before any update acts); the loss scalars against the bf16-emulating oracle, the
+    trajectory the HIP path must stay on behind the sign-like Adam steps (beta1 = 0) -- the fp32 values are printed beside."""
+    from collections import OrderedDict
+    from gcc_amd.options import options
+    from gcc_amd.models import get_model_class
+    from oracle import gcc_oracle as O
+    from tests.golden.recipe import recipe_state_dict, recipe_transform
+    opt = options.parse(FULL_SAGAN_ARGV)
+    opt.isTrain = True
+    opt.teacher_ndf = 64
+    cls = get_model_class(opt)
+    model = cls(opt)
+    topt = copy.deepcopy(opt)
+    topt.ngf, topt.ndf = opt.teacher_ngf, opt.teacher_ndf
+    topt.darts_discriminator = topt.online_distillation = False
+    teacher = cls(topt)
+    teacher.model_train()
+    model.teacher_model = teacher
+    model.init_distillation()
+    teacher.init_distillation()
+    sds = {}
+    for tag, net, seed in (('sG', model.netG, 811), ('sD', model.netD, 812), ('tG', teacher.netG, 813), ('tD', teacher.netD, 814)):
+        sds[tag] = recipe_state_dict(OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items()), seed)
+        net.load_state_dict(sds[tag])
+    Ts = [recipe_transform(t.weight.shape[0], t.weight.shape[1], 820 + i) for i, t in enumerate(model.transform_convs)]
+    with torch.no_grad():
+        for t, v in zip(model.transform_convs, Ts):
+            t.weight.copy_(v.to(DEV))
+    model.refresh_weights()
+    teacher.refresh_weights()
+    model.model_train()
+    g = torch.Generator().manual_seed(93)
+    N = 64
+    zz, vz = torch.randn(N, opt.z_dim, generator=g), torch.randn(N, opt.z_dim, generator=g)
+    real, vreal = torch.rand(N, 3, 64, 64, generator=g) * 2 - 1, torch.rand(N, 3, 64, 64, generator=g) * 2 - 1
+    model.set_input({'z': zz, 'real_img': real, 'img_path': ['p'] * N})
+    model.optimize_parameters()
+    fake, tfake = model.fake_img.cpu(), teacher.fake_img.cpu()
+    model.set_input({'z': vz, 'real_img': vreal, 'img_path': ['p'] * N})
+    model.clipping_mask_alpha()
+    model.optimizer_netD_arch()
+    got, tgot = model.get_current_losses(), teacher.get_current_losses()
+
+    def run_oracle(emulate):
+        O.EMULATE_BF16 = emulate
+        try:
+            oopt = O.Opt(ngf=48, ndf=64, teacher_ngf=64, teacher_ndf=64, gan_mode=opt.gan_mode, lr=opt.lr, lambda_L1=1.0,
+                         lambda_content=1.0, lambda_gram=1.0)
+            ot = O.SAGANOracle(oopt, copy.deepcopy(sds['tG']), copy.deepcopy(sds['tD']), masked=False)
+            om = O.SAGANOracle(oopt, copy.deepcopy(sds['sG']), copy.deepcopy(sds['sD']), [t.clone() for t in Ts], masked=True,
+                               teacher=ot)
+            om.set_input(zz, real)
+            om.optimize_parameters()
+            imgs = (om.fake_img.detach().clone(), ot.fake_img.detach().clone())
+            om.set_input(vz, vreal)
+            om.clipping_mask_alpha()
+            om.optimizer_netD_arch()
+            return imgs, dict(om.losses), dict(ot.losses)
+        finally:
+            O.EMULATE_BF16 = False
+    (ref_fake, ref_tfake), ref_l, ref_tl = run_oracle(False)
+    (emu_fake, emu_tfake), emu_l, emu_tl = run_oracle(True)
+    bad = []
+    for what, a, r, e_ in (('fake_img', fake, ref_fake, emu_fake), ('teacher fake_img', tfake, ref_tfake, emu_tfake)):
+        e, floor = (a - r).abs(), (e_ - r).abs()
+        print('%s: max %.4g mean %.4g   (bf16-emulating oracle against fp32: max %.4g mean %.4g)' % (what, e.max(), e.mean(), floor.max(), floor.mean()))
+        if not (e.max() <= max(2e-2, 1.5 * float(floor.max())) and e.mean() <= max(3e-3, 1.5 * float(floor.mean()))):
+            bad.append((what, float(e.max()), float(e.mean())))
+    assert len(set(emu_l) & set(got)) >= 8, (sorted(emu_l), sorted(got))
+    for tag, gl, el, rl in (('S', got, emu_l, ref_l), ('T', tgot, emu_tl, ref_tl)):
+        for k, v in el.items():
+            if k not in gl:
+                continue
+            print('%s %-24s got %.5g  bf16-emulating oracle %.5g  fp32 oracle %.5g' % (tag, k, gl[k], v, rl[k]))
+            if not abs(gl[k] - v) <= 3e-2 * max(1.0, abs(v)):
+                bad.append((tag, k, gl[k], v))
+    assert not bad, bad
