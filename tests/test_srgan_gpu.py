@@ -461,3 +461,91 @@ def test_srgan_content_pretraining_vs_reference_golden(golden_dir):
         else:
             # three Adam steps: each moves a weight by at most ~lr (beta1 0.9 bias-corrected: the first steps are sign-like)
             assert np.abs(g - ref).max() <= 2.2 * lr * 3 + 1e-6, (name, float(np.abs(g - ref).max()))
+
+
+FULL_SRGAN_ARGV = ['--dataroot', './database/sr/', '--model', 'srgan', '--gpu_ids', '0', '--ngf', '24', '--ndf', '64',
+                   '--teacher_ngf', '64', '--online_distillation', '--darts_discriminator', '--lambda_content', '1',
+                   '--lambda_gram', '1', '--lambda_L1', '0.5', '--lambda_SR_content', '0.5', '--arch_lr', '1e-4',
+                   '--image_size', '96', '--batch_size', '16']
+
+
+def test_srgan_full_width_iteration_vs_oracle():
+    """BASELINE.json configs[4] at its real widths (SRResNet ngf 24, teacher 64, D ndf 64, the real VGG19[:36] widths with
+    conditioned random weights, 24 x 24 -> 96 x 96, batch 16): one iteration + arch step of the HIP path against the oracle on
+    the same weights -- every logged loss (content = MSE of the super-resolved image, perceptual = VGG feature MSE, the GAN, distillation
+    and arch terms) within 3e-2 of the fp32 or the bf16-emulating oracle."""
+    from collections import OrderedDict
+    from gcc_amd.options import options
+    from gcc_amd.models import get_model_class
+    from oracle import gcc_oracle as O
+    from tests.golden.recipe import recipe_state_dict, recipe_transform, srgan_condition
+    os.environ['GCC_VGG19_RANDOM'] = '1'
+    opt = options.parse(FULL_SRGAN_ARGV)
+    opt.isTrain = True
+    opt.teacher_ndf = 64
+    cls = get_model_class(opt)
+    model = cls(opt)
+    topt = copy.deepcopy(opt)
+    topt.ngf, topt.ndf = opt.teacher_ngf, opt.teacher_ndf
+    topt.darts_discriminator = topt.online_distillation = False
+    teacher = cls(topt)
+    teacher.model_train()
+    model.teacher_model = teacher
+    model.init_distillation()
+    teacher.init_distillation()
+    sds = {}
+    for tag, nets, seed in (('sG', [model.netG], 921), ('sD', [model.netD], 922), ('tG', [teacher.netG], 923), ('tD', [teacher.netD], 924),
+                            ('V', [model.truncated_vgg19, teacher.truncated_vgg19], 925)):
+        sds[tag] = recipe_state_dict(OrderedDict((k, tuple(v.shape)) for k, v in nets[0].state_dict().items()), seed)
+        srgan_condition(sds[tag])
+        for net in nets:
+            net.load_state_dict(sds[tag])
+    Ts = [recipe_transform(t.weight.shape[0], t.weight.shape[1], 930 + i) for i, t in enumerate(model.transform_convs)]
+    with torch.no_grad():
+        for t, v in zip(model.transform_convs, Ts):
+            t.weight.copy_(v.to(DEV))
+    for m in (model, teacher):
+        m.refresh_weights()
+        m.V.repack()
+    model.model_train()
+    g = torch.Generator().manual_seed(95)
+    N = 16
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    lr, vlr = ((torch.rand(N, 3, 24, 24, generator=g) - mean) / std for _ in range(2))
+    hr, vhr = (torch.rand(N, 3, 96, 96, generator=g) * 2 - 1 for _ in range(2))
+    model.set_input({'lr': lr, 'hr': hr, 'lr_names': ['a'] * N, 'hr_names': ['b'] * N})
+    model.optimize_parameters()
+    model.set_input({'lr': vlr, 'hr': vhr, 'lr_names': ['a'] * N, 'hr_names': ['b'] * N})
+    model.clipping_mask_alpha()
+    model.optimizer_netD_arch()
+    got, tgot = model.get_current_losses(), teacher.get_current_losses()
+
+    def run_oracle(emulate):
+        O.EMULATE_BF16 = emulate
+        try:
+            oopt = O.Opt(ngf=24, ndf=64, teacher_ngf=64, teacher_ndf=64, gan_mode=opt.gan_mode, lr=opt.lr, threshold=opt.threshold,
+                         lambda_L1=0.5, lambda_content=1.0, lambda_gram=1.0, lambda_SR_content=0.5)
+            cp = lambda tag: copy.deepcopy(sds[tag])
+            ot = O.SRGANOracle(oopt, cp('tG'), cp('tD'), cp('V'), masked=False)
+            om = O.SRGANOracle(oopt, cp('sG'), cp('sD'), cp('V'), [t.clone() for t in Ts], masked=True, teacher=ot)
+            om.set_input(lr, hr)
+            om.optimize_parameters()
+            om.set_input(vlr, vhr)
+            om.clipping_mask_alpha()
+            om.optimizer_netD_arch()
+            return dict(om.losses), dict(ot.losses)
+        finally:
+            O.EMULATE_BF16 = False
+    ref_l, ref_tl = run_oracle(False)
+    emu_l, emu_tl = run_oracle(True)
+    bad = []
+    assert len(set(ref_l) & set(got)) >= 8, (sorted(ref_l), sorted(got))
+    for tag, gl, rl, el in (('S', got, ref_l, emu_l), ('T', tgot, ref_tl, emu_tl)):
+        for k, v in rl.items():
+            if k not in gl:
+                continue
+            print('%s %-24s got %.5g  fp32 oracle %.5g  bf16-emulating oracle %.5g' % (tag, k, gl[k], v, el[k]))
+            if not (abs(gl[k] - v) <= 3e-2 * max(1.0, abs(v)) or abs(gl[k] - el[k]) <= 3e-2 * max(1.0, abs(el[k]))):
+                bad.append((tag, k, gl[k], v, el[k]))
+    assert not bad, bad
