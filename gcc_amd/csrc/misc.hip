@@ -124,9 +124,43 @@ __global__ void pack_wt_kernel(const float* __restrict__ m, int rows, int taps, 
 // multi-tensor form: one launch repacks every conv of an optimizer group (device work list)
 __global__ __launch_bounds__(256) void pack_multi_kernel(const gcc_pack_desc_t* __restrict__ descs,
                                                          const gcc_pack_item_t* __restrict__ items) {
-    __shared__ float t[32][33];
+    __shared__ float t[64][65];
     const gcc_pack_item_t it = items[blockIdx.x];
     const gcc_pack_desc_t d = descs[it.tensor];
+    if (it.kind == 2) {
+        // W and Wt of one 64 x 64 tile (rows b*64.., columns c*64..) of tap a, unsplit tensors with cols % 4 == 0: the fp32
+        // master is read once for both packings (kinds 0 + 1 read it twice and wrote Wt in 64-byte pieces: the launch ran at a
+        // third of its HBM time), 128-byte row pieces in and out, zero rows / columns up to the padded sizes.
+        const int tap = it.a, r0 = it.b * 64, c0 = it.c * 64;
+        const int cq = threadIdx.x & 15, rr = threadIdx.x >> 4;
+        bf16_t* w = (bf16_t*)d.w;
+        bf16_t* wt = (bf16_t*)d.wt;
+#pragma unroll
+        for (int pass = 0; pass < 4; pass++) {
+            const int lr = rr + 16 * pass, r = r0 + lr, c = c0 + cq * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < d.rows && c < d.cols) v = *(const f32x4*)(d.master + ((size_t)r * d.taps + tap) * d.cols + c);
+            t[lr][cq * 4 + 0] = v[0]; t[lr][cq * 4 + 1] = v[1]; t[lr][cq * 4 + 2] = v[2]; t[lr][cq * 4 + 3] = v[3];
+            if (w && r < d.rowsp && c < d.colsp) {
+                i32x2 o;
+                o[0] = (int)pack2bf(v[0], v[1]); o[1] = (int)pack2bf(v[2], v[3]);
+                *(i32x2*)(w + ((size_t)r * d.taps + tap) * d.colsp + c) = o;
+            }
+        }
+        __syncthreads();
+        if (wt) {
+#pragma unroll
+            for (int pass = 0; pass < 4; pass++) {
+                const int lc = rr + 16 * pass, c = c0 + lc, r = r0 + cq * 4;
+                if (c < d.colsp && r < d.rowsp) {
+                    i32x2 o;
+                    o[0] = (int)pack2bf(t[cq * 4 + 0][lc], t[cq * 4 + 1][lc]); o[1] = (int)pack2bf(t[cq * 4 + 2][lc], t[cq * 4 + 3][lc]);
+                    *(i32x2*)(wt + ((size_t)c * d.taps + tap) * d.rowsp + r) = o;
+                }
+            }
+        }
+        return;
+    }
     if (it.kind == 0) {                 // W: [rowsp][taps][colsp], linear chunk of 2048 elements
         const size_t total = (size_t)d.rowsp * d.taps * d.colsp;
         const size_t beg = (size_t)it.a * 2048;

@@ -304,6 +304,9 @@ def pack_weights_into(master, w, wt):
                                  wt.data_ptr() if wt is not None else None, stream()), 'gcc_pack_weights')
 
 
+FUSED_PACK = os.environ.get('GCC_FUSED_PACK', '1') != '0'
+
+
 class PackPlan:
     """One launch that refreshes the bf16 W / Wt packings of a list of convs (engine.ConvOp) from their
     fp32 masters.  Pointers must stay valid (flat parameter storage, persistent packings)."""
@@ -317,6 +320,13 @@ class PackPlan:
             colsp, rowsp = c.cols_p, c.rows_p
             D[i] = _lib.pack_desc_t(c.weight.data_ptr(), c.w.data_ptr(), c.wt.data_ptr(), rows, taps, cols, colsp, rowsp,
                                     c.row_split, c.col_split, 0)
+            if (FUSED_PACK and not c.row_split and not c.col_split and cols % 4 == 0 and c.weight.data_ptr() % 16 == 0
+                    and c.w is not None and c.wt is not None):
+                for tap in range(taps):             # kind 2: both packings of a 64 x 64 tile from one read of the master
+                    for rb in range((rowsp + 63) // 64):
+                        for cb in range((colsp + 63) // 64):
+                            items.append((i, 2, tap, rb, cb))
+                continue
             for a in range((rowsp * taps * colsp + 2047) // 2048):
                 items.append((i, 0, a, 0, 0))
             for tap in range(taps):

@@ -166,7 +166,8 @@ int gcc_pack_weights(const float* master, int rows, int taps, int cols, void* w,
                      gcc_stream_t stream);
 
 /* multi-tensor form: DEVICE arrays built once per optimizer group.  kind 0: W chunk `a` (2048 output
- * elements); kind 1: one 32x32 tile (row block b, column block c) of tap `a` for Wt. */
+ * elements); kind 1: one 32x32 tile (row block b, column block c) of tap `a` for Wt; kind 2 (unsplit tensors with
+ * cols % 4 == 0 and a 16-byte aligned master): W and Wt of one 64x64 tile of tap `a` from a single read of the master. */
 /* rows / cols are the master's logical sizes; row_split / col_split (0 = none) say that the dimension is
  * a concatenation whose first part has that many channels: each part is padded to 8 channels in the
  * packings (W = [rowsp][taps][colsp], Wt = [colsp][taps][rowsp], rowsp/colsp = padded physical sizes),

@@ -403,6 +403,43 @@ def test_conv_channel_slices():
     assert float(big_out[:, :16].float().abs().max()) == 0.0 and float(big_out[:, 32:].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('fused', [1, 0])
+def test_pack_plan_matches_single_tensor_packing(fused, monkeypatch):
+    """ops.PackPlan (one launch for a list of convs; with GCC_FUSED_PACK the W and Wt of a 64x64 tile come from one read of the
+    master) against gcc_pack_weights per tensor and against the definition: widths that are / are not multiples of 64, 8, 4;
+    a padded row count; a concatenated column dimension (keeps the two-kind path either way)"""
+    ops = _ops()
+    from gcc_amd import engine
+    monkeypatch.setattr(ops, 'FUSED_PACK', bool(fused))
+    g = torch.Generator().manual_seed(4)
+    convs = []
+    for rows, cols, k, csplit in ((64, 32, 4, 0), (130, 68, 3, 0), (256, 512, 4, 0), (24, 8, 1, 0), (3, 64, 4, 0), (40, 6, 3, 0),
+                                  (32, 20, 4, 12), (200, 128, 1, 0)):
+        w = (torch.randn(rows, cols, k, k, generator=g) * 0.1).to(DEV).contiguous(memory_format=torch.channels_last)
+        convs.append(engine.ConvOp(w, None, k, 1, 0, False, col_split=csplit))
+    plan = ops.PackPlan(convs, DEV)
+    kinds = set(int(v) for v in plan.d_items.cpu()[:, 1])
+    assert kinds == ({0, 1, 2} if fused else {0, 1})
+    plan.run()
+    torch.cuda.synchronize()
+    for c in convs:
+        m = c.weight.detach().float().cpu()                  # [rows, cols, k, k]
+        rows, cols, k = c.rows, c.cols, c.k
+        ref = m.permute(0, 2, 3, 1).reshape(rows, k * k, cols).to(torch.bfloat16)
+        if not c.col_split:
+            w1, wt1 = ops.pack_weights(c.weight)
+            assert torch.equal(c.w.cpu()[:rows], w1.cpu()) and torch.equal(c.wt.cpu()[:cols], wt1.cpu()), (rows, cols, k)
+            assert torch.equal(c.w.cpu()[:rows, :, :cols], ref)
+            assert torch.equal(c.wt.cpu()[:cols, :, :rows], ref.permute(2, 1, 0))
+            wz, wtz = c.w.cpu().float(), c.wt.cpu().float()                     # padding rows / columns are zeros
+            assert not wz[rows:].any() and not wz[:, :, cols:].any() and not wtz[cols:].any() and not wtz[:, :, rows:].any()
+        else:
+            s0 = c.col_split
+            p0 = (s0 + 7) // 8 * 8
+            assert torch.equal(c.w.cpu()[:rows, :, :s0], ref[:, :, :s0])
+            assert torch.equal(c.w.cpu()[:rows, :, p0:p0 + cols - s0], ref[:, :, s0:])
+
+
 def test_layout_roundtrip_and_copy():
     ops = _ops()
     g = torch.Generator().manual_seed(2)
