@@ -138,23 +138,24 @@ class ConvOp:
         return ops.conv_fprop(dy, self.w, self.rows_k, self.k, self.stride, self.pad, out=out)
 
     # -- gradient w.r.t. the weight (accumulates into weight.grad) and bias -------------------------
-    def backward_weight(self, x, dy):
+    def backward_weight(self, x, dy, bias_done=False):
+        """bias_done: the bias gradient (channel sums of dy) was already accumulated by the kernel that produced dy"""
         if OVERLAP_WGRAD:
             side = ops.SideStream.get(x.device)
             side.fork()
             with ops.on_stream(side.stream):
-                self._backward_weight(x, dy)
+                self._backward_weight(x, dy, bias_done)
         else:
-            self._backward_weight(x, dy)
+            self._backward_weight(x, dy, bias_done)
 
-    def _backward_weight(self, x, dy):
+    def _backward_weight(self, x, dy, bias_done=False):
         cx, cdy = (x, dy) if not self.transposed else (dy, x)      # (conv input, conv output-gradient) of the adjoint pair
         if self.row_split or self.col_split:
             ops.conv_wgrad_seg(cx, cdy, self.weight.grad, self.rows, self.cols, self.row_split, self.col_split, self.k,
                                self.stride, self.pad, accumulate=True)
         else:
             ops.conv_wgrad(cx, cdy, self.weight.grad, self.k, self.stride, self.pad, accumulate=True)
-        if self.bias is not None:
+        if self.bias is not None and not bias_done:
             ops.channel_sum(dy, self.bias.grad, accumulate=True)
 
 
@@ -680,10 +681,14 @@ class PatchGANEngine:
                 self._seg_done(L - 1 - li)
             self.conv[li].backward_data(G.layer[li], G.layer[li - 1])
         gate = self.gate[0]
+        # the first conv's bias gradient is the channel sum of dz, which this pass forms anyway (its 'dbeta' sum): no separate
+        # read of the [N, ndf, H/2, W/2] gradient by gcc_channel_sum (67 MB per discriminator pass at ndf 128, 256 x 256, N = 16)
+        b0 = self.conv[0].bias
         ops.bnact_bwd(c.a0, None, G.layer[0], G.layer[0], gate=self.mask[0], gate_after_act=True, in_act=ACT_LRELU,
-                      dalpha=gate.alpha.grad if (agrad and gate is not None) else None)
+                      dalpha=gate.alpha.grad if (agrad and gate is not None) else None,
+                      dbeta=b0.grad if (wgrad and b0 is not None) else None)
         if wgrad:
-            self.conv[0].backward_weight(c.x_in, G.layer[0])
+            self.conv[0].backward_weight(c.x_in, G.layer[0], bias_done=True)
             self._seg_done(L - 1)
         dx = None
         if need_dx:
