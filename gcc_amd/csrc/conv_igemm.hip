@@ -1051,7 +1051,104 @@ __global__ __launch_bounds__(256) void thin_dgrad_k4s2_kernel(const ThinDgradArg
     }
 }
 
+// The wide case (65 .. 128 channels in: the first PatchGAN layer's data gradient at ndf 128, the teacher generator's last
+// ConvTranspose): the texture-path form above requests every dy byte three times per output pixel and loses to the implicit
+// GEMM there.  Here a workgroup stages the two dy rows (r, r + 1) that the output rows 2r + 1 and 2r + 2 touch ONCE, by
+// LDS-DMA ([2][Wo][256 B], the sixteen 16-byte chunks of a pixel XOR-swizzled with the pixel index on the source side, zero
+// rows / channels by the descriptor range check), and every MFMA operand of both output rows is a conflict-free
+// ds_read_b128 out of them; the weight fragments of the row parity being computed live in registers (24 x 16 B per lane,
+// loaded straight from the packing).  64 KB of LDS: two workgroups per CU, one staging while the other computes.
+constexpr int THIN_WIDE_RB = 256;                 // bytes per staged pixel (128 channels)
+__global__ __launch_bounds__(256) void thin_dgrad_wide_kernel(const ThinDgradArgs a) {
+    constexpr int NCC = 4, NK = 6 * NCC;
+    extern __shared__ __attribute__((aligned(16))) char ylds[];          // [2 rows][Wo][THIN_WIDE_RB]
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.x / (a.Ho + 1);
+    const int r = (int)(blockIdx.x % (a.Ho + 1)) - 1;                     // dy rows r and r + 1
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+    // stage: piece q = 1 KiB = 4 pixels; lane L lands at byte q * 1024 + L * 16, which must hold chunk (slot ^ (pixel & 15))
+    const int pieces = 2 * a.Wo / 4;
+    for (int q = wave; q < pieces; q += 4) {
+        const int o = q * 1024 + lane * 16;
+        const int u = o / (a.Wo * THIN_WIDE_RB);
+        const int within = o - u * (a.Wo * THIN_WIDE_RB);
+        const int px = within / THIN_WIDE_RB, slot = (within % THIN_WIDE_RB) >> 4;
+        const int co = ((slot ^ (px & 15)) << 3);
+        const int oy = r + u;
+        const bool ok = (unsigned)oy < (unsigned)a.Ho && co < a.Co8;
+        const uint32_t off = ok ? (uint32_t)((((n * a.Ho + oy) * a.Wo + px) * a.ldy + a.yoff + co) * 2) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, LDS_PTR(void, ylds + q * 1024), 16, off, 0, 0, 0);
+    }
+    const int ci0 = (g & 1) * 4, pxo = g >> 1;
+    float bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) bv[e] = (a.bias && ci0 + e < a.Ci) ? a.bias[ci0 + e] : 0.f;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        const int py = pass == 0 ? 1 : 0;                     // output row 2r + 1 (parity 1 of r), then 2r + 2 (parity 0 of r + 1)
+        const int iy = pass == 0 ? 2 * r + 1 : 2 * r + 2;
+        // weight fragments of this row parity (operand f = (u, b, cc) as in thin_dgrad_k4s2_kernel)
+        bf16x8 wf[NK];
+#pragma unroll
+        for (int f = 0; f < NK; f++) {
+            const int u = f / (3 * NCC), b = (f / NCC) % 3 - 1, cc = f % NCC;
+            const int px = i >> 3, ci = i & 7;
+            const int kh = py == 0 ? (u == 0 ? 1 : 3) : (u == 0 ? 0 : 2);
+            const int kw = px == 0 ? (b == 0 ? 1 : (b < 0 ? 3 : -1)) : (b > 0 ? 0 : (b == 0 ? 2 : -1));
+            const int co = 32 * cc + 8 * g;
+            const uint32_t off = (kw >= 0 && ci < a.Ci && co < a.Co8) ? (uint32_t)((((ci * 16 + kh * 4 + kw) * a.Co8) + co) * 2) : OOB;
+            wf[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));
+        }
+        if (pass == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if ((unsigned)iy >= (unsigned)a.H) continue;           // workgroup-uniform: the rows above / below the image
+        for (int jt = wave; jt < a.tiles_per_row; jt += 4) {
+            const int j = jt * 16 + i;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < NK; f += 2) {
+                bf16x8 yb[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int ff = f + h;
+                    const int u = ff / (3 * NCC), b = (ff / NCC) % 3 - 1, cc = ff % NCC;
+                    // both parities: u == 0 reads dy row r + 1 (staged row 1), u == 1 reads dy row r (staged row 0)
+                    const int ox = j + b;
+                    const int chunk = 4 * cc + g;
+                    const bool ok = (unsigned)ox < (unsigned)a.Wo;
+                    const int oxc = ok ? ox : 0;
+                    const bf16x8 v = *(const bf16x8*)(ylds + ((1 - u) * a.Wo + oxc) * THIN_WIDE_RB + ((chunk ^ (oxc & 15)) << 4));
+                    yb[h] = ok ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f], yb[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f + 1], yb[1], acc1, 0, 0, 0);
+            }
+            const int ix = 2 * j + pxo;
+            if (ix < a.W) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    o[e] = apply_act(acc0[e] + acc1[e] + bv[e], a.act, a.slope);
+                    if (ci0 + e >= a.Ci) o[e] = 0.f;
+                }
+                i32x2 v = {(int)pack2bf(o[0], o[1]), (int)pack2bf(o[2], o[3])};
+                *(i32x2*)(a.dx + ((size_t)(n * a.H + iy) * a.W + ix) * a.ldx + a.xoff + ci0) = v;
+            }
+        }
+    }
+}
+
+static bool thin_dgrad_wide_shape(const gcc_conv_t* c) {
+    return ceil8(c->Ci) == 8 && c->KH == 4 && c->KW == 4 && c->stride == 2 && c->pad == 1 && !(c->H & 1) && !(c->W & 1) &&
+           c->Co > 64 && c->Co <= 128 && ((c->W / 2) & 3) == 0 && (size_t)(c->W / 2) * THIN_WIDE_RB * 2 <= 80 * 1024 &&
+           gcc_opt(GCC_OPT_IGEMM_THIN) >= 1 && gcc_opt(GCC_OPT_IGEMM_THIN) != 2;
+}
 static bool thin_dgrad_shape(const gcc_conv_t* c) {
+    if (thin_dgrad_wide_shape(c)) return true;
     return ceil8(c->Ci) == 8 && c->KH == 4 && c->KW == 4 && c->stride == 2 && c->pad == 1 && !(c->H & 1) && !(c->W & 1) &&
            c->Co >= 16 && c->Co <= 64 && thin_enabled();
 }
@@ -1068,6 +1165,16 @@ static int launch_thin_dgrad(const gcc_conv_t* c, const void* dy, const void* wt
     a.tiles_per_row = cdiv(a.Wo, 16);
     a.ntiles = c->N * a.Ho * a.tiles_per_row;
     a.dTpr = make_fastdiv(a.tiles_per_row); a.dHh = make_fastdiv(a.Ho);
+    if (thin_dgrad_wide_shape(c)) {
+        const size_t lds = (size_t)2 * a.Wo * THIN_WIDE_RB;
+        static std::once_flag wide_once;
+        std::call_once(wide_once, [] {
+            (void)hipFuncSetAttribute((const void*)thin_dgrad_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        });
+        hipLaunchKernelGGL(thin_dgrad_wide_kernel, dim3(c->N * (a.Ho + 1)), dim3(256), lds, st, a);
+        GCC_CHECK_LAUNCH();
+        return GCC_OK;
+    }
     const int ncc = a.Co8 > 32 ? 2 : 1;
     int wgs = cdiv(a.ntiles, 4);
     if (wgs > 768) wgs = 768;

@@ -60,7 +60,7 @@ enum {
     GCC_OPT_IGEMM_BIG_NK,       /* minimum K depth in 64-steps for 256-pixel tiles (default 24) */
     GCC_OPT_IGEMM_GLDS,         /* 1 (default): LDS-DMA staging; 0: register-staged 128-pixel tiles */
     GCC_OPT_IGEMM_HEAD,         /* 1 (default): single-output-channel head route */
-    GCC_OPT_IGEMM_THIN,         /* 1 (default): thin image-layer kernels */
+    GCC_OPT_IGEMM_THIN,         /* 1 (default): thin image-layer kernels; 2: without the LDS-staged wide (65..128 channel) data-gradient form; 0: none */
     GCC_OPT_WGRAD_BIG,          /* 1 (default): 256x256 weight-gradient tiles on the large layers */
     GCC_OPT_BN_SWEEPS,          /* 0 (default): per-kernel choice of sweeps per streaming workgroup */
     GCC_OPT_BN_MAXBLK,          /* cap on streaming workgroups (default 2048) */

@@ -4,6 +4,8 @@ bits) accumulated in fp32 -> |err| <= 1.2e-2 * max|ref| (+ tiny absolute floor);
 outputs exact."""
 import math
 
+import ctypes as C
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -341,6 +343,39 @@ def test_conv_transpose_as_dgrad_with_stats_and_tanh():
     dw = torch.zeros_like(m)
     ops.conv_wgrad(dyd, xd, dw, 4, 2, 1)
     close(dw.cpu(), wr.grad, tol=5e-3, floor=1e-4, what='convT wgrad')
+
+
+@pytest.mark.parametrize('Cin,h,w,Cout', [(128, 128, 128, 6), (128, 64, 32, 3), (96, 12, 20, 3), (72, 8, 8, 6)])
+def test_data_gradient_to_image_wide(Cin, h, w, Cout):
+    """65 .. 128 channels into <= 8 (the first PatchGAN layer's data gradient at ndf 128 -- the true 256 x 256 shape at N = 2 --
+    and the teacher generator's last ConvTranspose): the LDS-staged thin kernel, the texture-path / implicit-GEMM route
+    (GCC_OPT_IGEMM_THIN = 2) on the same inputs, and fp32 torch"""
+    ops = _ops()
+    from gcc_amd import _lib
+    g = torch.Generator().manual_seed(Cin + h)
+    N = 2
+    x = rb(torch.randn(N, Cin, h, w, generator=g))
+    wgt = rb(torch.randn(Cin, Cout, 4, 4, generator=g) * 0.05)
+    b = torch.randn(Cout, generator=g) * 0.1
+    y_ref = F.conv_transpose2d(x, wgt, None, stride=2, padding=1)
+    _, wtp = ops.pack_weights(master_cl(wgt))
+    xd = to_dev(x)
+    d = ops.conv_desc(N, 2 * h, 2 * w, Cout, Cin, 4, 2, 1, 8, xd.stride(3))
+    outs = {}
+    for thin in (1, 2):
+        prev = ops.lib().gcc_set_option(_lib.OPT_IGEMM_THIN, thin)
+        try:
+            assert ops.lib().gcc_conv_route(C.byref(d), 1, None) == (1 if (thin == 1 or Cin <= 64) else 0)
+            y = ops.conv_dgrad(xd, wtp, Cout, 2 * h, 2 * w, 4, 2, 1)
+            close(to_cpu(y), y_ref, what='data gradient -> image (THIN=%d)' % thin)
+            y2 = ops.conv_dgrad(xd, wtp, Cout, 2 * h, 2 * w, 4, 2, 1, bias=b.to(DEV), act=ops.ACT_TANH)
+            close(to_cpu(y2), torch.tanh(y_ref + b[None, :, None, None]), what='+ bias + tanh (THIN=%d)' % thin)
+            base = torch.empty(0, dtype=torch.bfloat16, device=DEV).set_(y2.untyped_storage()).view(N, 2 * h, 2 * w, 8)
+            assert float(base[..., Cout:].float().abs().max()) == 0.0, 'padding channels must stay zero'
+            outs[thin] = to_cpu(y)
+        finally:
+            ops.lib().gcc_set_option(_lib.OPT_IGEMM_THIN, prev)
+    close(outs[1], outs[2], tol=1e-2, what='staged kernel against the implicit GEMM')
 
 
 @pytest.mark.parametrize('Cin,h,w', [(128, 16, 16), (64, 10, 24), (24, 6, 6), (40, 20, 9)])
