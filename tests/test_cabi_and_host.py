@@ -87,7 +87,13 @@ def test_conv_route_predicates():
     none = _lib.epilogue_t(None, 0, 0.2, None, None, 0)
     d_l1 = conv(16, 256, 256, 6, 128, 4, 2, 1)
     assert lib.gcc_conv_route(ctypes.byref(d_l1), 0, ctypes.byref(none)) == 1          # thin fprop
-    assert lib.gcc_conv_route(ctypes.byref(d_l1), 1, ctypes.byref(none)) == 0          # 128 channels in: implicit GEMM
+    assert lib.gcc_conv_route(ctypes.byref(d_l1), 1, ctypes.byref(none)) == 1          # 128 channels in: the LDS-staged thin kernel
+    prev = lib.gcc_set_option(_lib.OPT_IGEMM_THIN, 2)
+    try:
+        assert lib.gcc_conv_route(ctypes.byref(d_l1), 1, ctypes.byref(none)) == 0      # ... or the implicit GEMM without it
+        assert lib.gcc_conv_route(ctypes.byref(d_l1), 0, ctypes.byref(none)) == 1
+    finally:
+        lib.gcc_set_option(_lib.OPT_IGEMM_THIN, prev)
     g_u0 = conv(16, 256, 256, 3, 64, 4, 2, 1)
     assert lib.gcc_conv_route(ctypes.byref(g_u0), 1, ctypes.byref(none)) == 1          # ConvTranspose 64 -> 3: pair-tiled kernel
     with_stats = _lib.epilogue_t(None, 0, 0.2, ctypes.c_void_p(4096), None, 0)
