@@ -1053,98 +1053,124 @@ __global__ __launch_bounds__(256) void thin_dgrad_k4s2_kernel(const ThinDgradArg
 
 // The wide case (65 .. 128 channels in: the first PatchGAN layer's data gradient at ndf 128, the teacher generator's last
 // ConvTranspose): the texture-path form above requests every dy byte three times per output pixel and loses to the implicit
-// GEMM there.  Here a workgroup stages the two dy rows (r, r + 1) that the output rows 2r + 1 and 2r + 2 touch ONCE, by
-// LDS-DMA ([2][Wo][256 B], the sixteen 16-byte chunks of a pixel XOR-swizzled with the pixel index on the source side, zero
-// rows / channels by the descriptor range check), and every MFMA operand of both output rows is a conflict-free
-// ds_read_b128 out of them; the weight fragments of the row parity being computed live in registers (24 x 16 B per lane,
-// loaded straight from the packing).  64 KB of LDS: two workgroups per CU, one staging while the other computes.
+// GEMM there.  Here the dy rows are staged ONCE by LDS-DMA ([Wo][256 B] per row, the sixteen 16-byte chunks of a pixel
+// XOR-swizzled with the pixel index on the source side, zero rows / channels by the descriptor range check), and every MFMA
+// operand of the two output rows a row pair (r, r + 1) feeds is a conflict-free ds_read_b128 out of them.
 constexpr int THIN_WIDE_RB = 256;                 // bytes per staged pixel (128 channels)
-__global__ __launch_bounds__(256) void thin_dgrad_wide_kernel(const ThinDgradArgs a) {
-    constexpr int NCC = 4, NK = 6 * NCC;
-    extern __shared__ __attribute__((aligned(16))) char ylds[];          // [2 rows][Wo][THIN_WIDE_RB]
+// One 8-wave workgroup per CU walks `rows_per_wg` consecutive r of one image with a ring of three staged dy rows: row r + 2
+// flies (LDS-DMA) while the output rows of r are computed; the weight fragments of both row parities sit in LDS in fragment
+// order (48 KB, filled once per workgroup).  Two waves per SIMD hide the ds_read latency (with the weights in registers --
+// 192 VGPRs, one wave per SIMD -- every ds_read -> MFMA pair ran exposed: 55 us); dy is read from L2 / HBM about once.
+constexpr int THIN_WIDE_NT = 512;
+__global__ __launch_bounds__(THIN_WIDE_NT) void thin_dgrad_wide_kernel(const ThinDgradArgs a, int rows_per_wg, int wgs_per_image) {
+    constexpr int NCC = 4, NK = 6 * NCC, NW = THIN_WIDE_NT / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem_w[];
+    char* wlds = smem_w;                                                 // [2 parities][NK][1 KiB] weight fragments
+    char* ylds = smem_w + 2 * NK * 1024;                                 // [3 ring slots][Wo + 4][THIN_WIDE_RB]
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = blockIdx.x / (a.Ho + 1);
-    const int r = (int)(blockIdx.x % (a.Ho + 1)) - 1;                     // dy rows r and r + 1
+    const int n = blockIdx.x / wgs_per_image, wb = blockIdx.x % wgs_per_image;
+    const int r_first = wb == 0 ? -1 : wb * rows_per_wg;                 // r = -1: output row 0 (dy rows -1 (zeros) and 0)
+    int r_last = (wb + 1) * rows_per_wg - 1;
+    if (r_last > a.Ho - 1) r_last = a.Ho - 1;
+    if (r_first > r_last) return;
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
-    // stage: piece q = 1 KiB = 4 pixels; lane L lands at byte q * 1024 + L * 16, which must hold chunk (slot ^ (pixel & 15))
-    const int pieces = 2 * a.Wo / 4;
-    for (int q = wave; q < pieces; q += 4) {
-        const int o = q * 1024 + lane * 16;
-        const int u = o / (a.Wo * THIN_WIDE_RB);
-        const int within = o - u * (a.Wo * THIN_WIDE_RB);
-        const int px = within / THIN_WIDE_RB, slot = (within % THIN_WIDE_RB) >> 4;
-        const int co = ((slot ^ (px & 15)) << 3);
-        const int oy = r + u;
-        const bool ok = (unsigned)oy < (unsigned)a.Ho && co < a.Co8;
-        const uint32_t off = ok ? (uint32_t)((((n * a.Ho + oy) * a.Wo + px) * a.ldy + a.yoff + co) * 2) : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, LDS_PTR(void, ylds + q * 1024), 16, off, 0, 0, 0);
+    // a staged row holds pixels -2 .. Wo + 1 (two zero pixels on each side: the taps at ox = -1 and ox = Wo read zeros instead
+    // of being predicated); staged pixel p' = ox + 2.  dy row y -> ring slot (y + 1) % 3.  Lane L of piece q lands at
+    // q * 1024 + L * 16, which must hold chunk slot ^ (p' & 15) of pixel p'.
+    const int row_bytes = (a.Wo + 4) * THIN_WIDE_RB;
+    const int pieces = row_bytes / 1024;                                 // 1 KiB = 4 pixels per wave instruction
+    auto stage_row = [&](int y) {
+        char* base = ylds + ((y + 1) % 3) * row_bytes;
+        const bool row_ok = (unsigned)y < (unsigned)a.Ho;
+        for (int q = wave; q < pieces; q += NW) {
+            const int o = q * 1024 + lane * 16;
+            const int pp = o / THIN_WIDE_RB, slot = (o % THIN_WIDE_RB) >> 4;
+            const int co = ((slot ^ (pp & 15)) << 3);
+            const int ox = pp - 2;
+            const bool ok = row_ok && (unsigned)ox < (unsigned)a.Wo && co < a.Co8;
+            const uint32_t off = ok ? (uint32_t)((((n * a.Ho + y) * a.Wo + ox) * a.ldy + a.yoff + co) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, LDS_PTR(void, base + q * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    stage_row(r_first);
+    stage_row(r_first + 1);
+    // weight fragments (operand f = (u, b, cc) as in thin_dgrad_k4s2_kernel), parity py = f2 / NK
+    for (int f2 = wave; f2 < 2 * NK; f2 += NW) {
+        const int py = f2 / NK, f = f2 - py * NK;
+        const int u = f / (3 * NCC), b = (f / NCC) % 3 - 1, cc = f % NCC;
+        const int px = i >> 3, ci = i & 7;
+        const int kh = py == 0 ? (u == 0 ? 1 : 3) : (u == 0 ? 0 : 2);
+        const int kw = px == 0 ? (b == 0 ? 1 : (b < 0 ? 3 : -1)) : (b > 0 ? 0 : (b == 0 ? 2 : -1));
+        const int co = 32 * cc + 8 * g;
+        const uint32_t off = (kw >= 0 && ci < a.Ci && co < a.Co8) ? (uint32_t)((((ci * 16 + kh * 4 + kw) * a.Co8) + co) * 2) : OOB;
+        *(i32x4*)(wlds + (f2 * 64 + lane) * 16) = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0);
     }
+    // per-lane byte offsets of the 12 (b, cc) operands inside a staged row, for tile 0; a tile adds 16 pixels = 4096 bytes
+    // (16 pixels keep p' & 15, so the swizzle term is tile-independent)
+    int yoffs[3][NCC];
+#pragma unroll
+    for (int bb = 0; bb < 3; bb++)
+#pragma unroll
+        for (int cc = 0; cc < NCC; cc++) {
+            const int pp = i + (bb - 1) + 2;
+            yoffs[bb][cc] = pp * THIN_WIDE_RB + (((4 * cc + g) ^ (pp & 15)) << 4);
+        }
     const int ci0 = (g & 1) * 4, pxo = g >> 1;
     float bv[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) bv[e] = (a.bias && ci0 + e < a.Ci) ? a.bias[ci0 + e] : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 #pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
-        const int py = pass == 0 ? 1 : 0;                     // output row 2r + 1 (parity 1 of r), then 2r + 2 (parity 0 of r + 1)
-        const int iy = pass == 0 ? 2 * r + 1 : 2 * r + 2;
-        // weight fragments of this row parity (operand f = (u, b, cc) as in thin_dgrad_k4s2_kernel)
-        bf16x8 wf[NK];
+    for (int r = r_first; r <= r_last; r++) {
+        if (r < r_last) stage_row(r + 2);                      // into the slot of row r - 1, which nobody reads any more
+        const char* row_u0 = ylds + ((r + 2) % 3) * row_bytes;   // u == 0: dy row r + 1 (both parities)
+        const char* row_u1 = ylds + ((r + 1) % 3) * row_bytes;   // u == 1: dy row r
 #pragma unroll
-        for (int f = 0; f < NK; f++) {
-            const int u = f / (3 * NCC), b = (f / NCC) % 3 - 1, cc = f % NCC;
-            const int px = i >> 3, ci = i & 7;
-            const int kh = py == 0 ? (u == 0 ? 1 : 3) : (u == 0 ? 0 : 2);
-            const int kw = px == 0 ? (b == 0 ? 1 : (b < 0 ? 3 : -1)) : (b > 0 ? 0 : (b == 0 ? 2 : -1));
-            const int co = 32 * cc + 8 * g;
-            const uint32_t off = (kw >= 0 && ci < a.Ci && co < a.Co8) ? (uint32_t)((((ci * 16 + kh * 4 + kw) * a.Co8) + co) * 2) : OOB;
-            wf[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));
-        }
-        if (pass == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        if ((unsigned)iy >= (unsigned)a.H) continue;           // workgroup-uniform: the rows above / below the image
-        for (int jt = wave; jt < a.tiles_per_row; jt += 4) {
-            const int j = jt * 16 + i;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int pass = 0; pass < 2; pass++) {
+            const int py = pass == 0 ? 1 : 0;                   // output row 2r + 1 (parity 1 of r), then 2r + 2 (parity 0 of r + 1)
+            const int iy = pass == 0 ? 2 * r + 1 : 2 * r + 2;
+            if ((unsigned)iy >= (unsigned)a.H) continue;        // workgroup-uniform: the rows above / below the image
+            const char* wp = wlds + (py * NK * 64 + lane) * 16;
+            for (int jt = wave; jt < a.tiles_per_row; jt += NW) {
+                const char* t0 = row_u0 + jt * (16 * THIN_WIDE_RB);
+                const char* t1 = row_u1 + jt * (16 * THIN_WIDE_RB);
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int f = 0; f < NK; f += 2) {
-                bf16x8 yb[2];
+                for (int f = 0; f < NK; f += 2) {
+                    bf16x8 yb[2];
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int ff = f + h;
-                    const int u = ff / (3 * NCC), b = (ff / NCC) % 3 - 1, cc = ff % NCC;
-                    // both parities: u == 0 reads dy row r + 1 (staged row 1), u == 1 reads dy row r (staged row 0)
-                    const int ox = j + b;
-                    const int chunk = 4 * cc + g;
-                    const bool ok = (unsigned)ox < (unsigned)a.Wo;
-                    const int oxc = ok ? ox : 0;
-                    const bf16x8 v = *(const bf16x8*)(ylds + ((1 - u) * a.Wo + oxc) * THIN_WIDE_RB + ((chunk ^ (oxc & 15)) << 4));
-                    yb[h] = ok ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int h = 0; h < 2; h++) {
+                        const int ff = f + h;
+                        const int u = ff / (3 * NCC), bb = (ff / NCC) % 3, cc = ff % NCC;
+                        yb[h] = *(const bf16x8*)((u == 0 ? t0 : t1) + yoffs[bb][cc]);
+                    }
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(wp + f * 1024), yb[0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(wp + (f + 1) * 1024), yb[1], acc1, 0, 0, 0);
                 }
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f], yb[0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f + 1], yb[1], acc1, 0, 0, 0);
-            }
-            const int ix = 2 * j + pxo;
-            if (ix < a.W) {
-                float o[4];
+                const int ix = 2 * (jt * 16 + i) + pxo;
+                if (ix < a.W) {
+                    float o[4];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    o[e] = apply_act(acc0[e] + acc1[e] + bv[e], a.act, a.slope);
-                    if (ci0 + e >= a.Ci) o[e] = 0.f;
+                    for (int e = 0; e < 4; e++) {
+                        o[e] = apply_act(acc0[e] + acc1[e] + bv[e], a.act, a.slope);
+                        if (ci0 + e >= a.Ci) o[e] = 0.f;
+                    }
+                    i32x2 v = {(int)pack2bf(o[0], o[1]), (int)pack2bf(o[2], o[3])};
+                    *(i32x2*)(a.dx + ((size_t)(n * a.H + iy) * a.W + ix) * a.ldx + a.xoff + ci0) = v;
                 }
-                i32x2 v = {(int)pack2bf(o[0], o[1]), (int)pack2bf(o[2], o[3])};
-                *(i32x2*)(a.dx + ((size_t)(n * a.H + iy) * a.W + ix) * a.ldx + a.xoff + ci0) = v;
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // row r + 2 has landed (and this wave's stores have left)
+        __syncthreads();                                          // everybody is done with rows r, r + 1
     }
 }
 
 static bool thin_dgrad_wide_shape(const gcc_conv_t* c) {
     return ceil8(c->Ci) == 8 && c->KH == 4 && c->KW == 4 && c->stride == 2 && c->pad == 1 && !(c->H & 1) && !(c->W & 1) &&
-           c->Co > 64 && c->Co <= 128 && ((c->W / 2) & 3) == 0 && (size_t)(c->W / 2) * THIN_WIDE_RB * 2 <= 80 * 1024 &&
+           c->Co > 64 && c->Co <= 128 && ((c->W / 2) & 3) == 0 && (size_t)(c->W / 2 + 4) * THIN_WIDE_RB * 3 + 48 * 1024 <= 156 * 1024 &&
            gcc_opt(GCC_OPT_IGEMM_THIN) >= 1 && gcc_opt(GCC_OPT_IGEMM_THIN) != 2;
 }
 static bool thin_dgrad_shape(const gcc_conv_t* c) {
@@ -1166,12 +1192,18 @@ static int launch_thin_dgrad(const gcc_conv_t* c, const void* dy, const void* wt
     a.ntiles = c->N * a.Ho * a.tiles_per_row;
     a.dTpr = make_fastdiv(a.tiles_per_row); a.dHh = make_fastdiv(a.Ho);
     if (thin_dgrad_wide_shape(c)) {
-        const size_t lds = (size_t)2 * a.Wo * THIN_WIDE_RB;
+        const size_t lds = (size_t)3 * (a.Wo + 4) * THIN_WIDE_RB + 48 * 1024;
         static std::once_flag wide_once;
         std::call_once(wide_once, [] {
-            (void)hipFuncSetAttribute((const void*)thin_dgrad_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)thin_dgrad_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
         });
-        hipLaunchKernelGGL(thin_dgrad_wide_kernel, dim3(c->N * (a.Ho + 1)), dim3(256), lds, st, a);
+        // one workgroup per CU (a 3-row ring is 96 KB at Wo = 128): as many workgroups per image as give the chip one round
+        int wpi = 256 / c->N;
+        if (wpi < 1) wpi = 1;
+        if (wpi > a.Ho) wpi = a.Ho;
+        const int rows_per_wg = cdiv(a.Ho, wpi);
+        wpi = cdiv(a.Ho, rows_per_wg);
+        hipLaunchKernelGGL(thin_dgrad_wide_kernel, dim3(c->N * wpi), dim3(THIN_WIDE_NT), lds, st, a, rows_per_wg, wpi);
         GCC_CHECK_LAUNCH();
         return GCC_OK;
     }

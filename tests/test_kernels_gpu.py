@@ -345,16 +345,16 @@ def test_conv_transpose_as_dgrad_with_stats_and_tanh():
     close(dw.cpu(), wr.grad, tol=5e-3, floor=1e-4, what='convT wgrad')
 
 
-@pytest.mark.parametrize('Cin,h,w,Cout', [(128, 128, 128, 6), (128, 64, 32, 3), (96, 12, 20, 3), (72, 8, 8, 6)])
-def test_data_gradient_to_image_wide(Cin, h, w, Cout):
+@pytest.mark.parametrize('Cin,h,w,Cout,N', [(128, 128, 128, 6, 2), (128, 64, 32, 3, 2), (96, 12, 20, 3, 2), (72, 8, 8, 6, 2),
+                                             (128, 16, 16, 6, 40), (128, 9, 12, 3, 100), (128, 32, 32, 6, 16)])
+def test_data_gradient_to_image_wide(Cin, h, w, Cout, N):
     """65 .. 128 channels into <= 8 (the first PatchGAN layer's data gradient at ndf 128 -- the true 256 x 256 shape at N = 2 --
     and the teacher generator's last ConvTranspose): the LDS-staged thin kernel, the texture-path / implicit-GEMM route
     (GCC_OPT_IGEMM_THIN = 2) on the same inputs, and fp32 torch"""
     ops = _ops()
     from gcc_amd import _lib
     g = torch.Generator().manual_seed(Cin + h)
-    N = 2
-    x = rb(torch.randn(N, Cin, h, w, generator=g))
+    x = rb(torch.randn(N, Cin, h, w, generator=g))          # N > 256 / rows: a workgroup walks several row pairs (3-row ring)
     wgt = rb(torch.randn(Cin, Cout, 4, 4, generator=g) * 0.05)
     b = torch.randn(Cout, generator=g) * 0.1
     y_ref = F.conv_transpose2d(x, wgt, None, stride=2, padding=1)
