@@ -377,8 +377,16 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
         for (int kt = 0; kt < nk; kt++) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            issue((kt + 1) & 1);                    // past the end of K the offsets are out of range: zero fill, unused
-            next_step();                            // (rare) tap change: its VALU work hides under the MFMAs below
+            if (!(p.debug & 2)) {
+                issue((kt + 1) & 1);                // past the end of K the offsets are out of range: zero fill, unused
+                if (!(p.debug & 4)) next_step();    // (rare) tap change: its VALU work hides under the MFMAs below
+                else {
+#pragma unroll
+                    for (int i = 0; i < AI; i++) cur_a[i] -= BK * 2;
+#pragma unroll
+                    for (int i = 0; i < W_N; i++) cur_w[i] -= BK * 2;
+                }
+            }
             compute(kt & 1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1311,6 +1319,7 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
     // ---- split-K decision (needs caller workspace; without it the launch simply is not split) ------
     p.ksplit = 1; p.kper = 0; p.partial = nullptr; p.rows_max = (int)max_rows; p.Cpad = p.ntiles * BC; p.raw_partial = 0;
     p.pair = 0; p.pair_slab = nullptr; p.pair_flags = nullptr;
+    p.debug = gcc_opt(GCC_OPT_DEBUG);
     if (tp.pair && batch == 1 && ep && ep->workspace && (((uintptr_t)ep->workspace) & 15) == 0) {
         const size_t tiles = (size_t)tp.mtiles * tp.ntiles * phases;
         if (pair_workspace(tiles) <= ep->workspace_bytes) {

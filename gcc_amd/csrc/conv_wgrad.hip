@@ -33,6 +33,8 @@ struct WgradParams {
     int direct;                      // 1: no split -> write (accumulate) straight into dW, no slab / fold pass
     int accumulate;
     float* dw;
+    int rowmode;                     // how issue_loads finds a piece's pixels: 0 every lane decomposes its pixel every step, 1 LDS pixel table
+    int debug;                       // GCC_OPT_DEBUG ablations (timing diagnostics only; results are wrong)
 };
 
 constexpr int TP = 64;          // pixels per step
@@ -54,7 +56,10 @@ struct WCfg {
     static constexpr int WCOL = BIG ? 128 : 64;         // columns per wave
     static constexpr int FI = WCOL / 16;                // column fragments per wave (4 or 8)
     static constexpr int FJ = 4;                        // output-channel fragments per wave (64 channels)
-    static constexpr int LDS_BYTES = 4 * TILE_BYTES;
+    // pixel table (rowmode 1): two chunks of CH k-steps x 64 pixels x {gather base, validity mask}
+    static constexpr int CH = BIG ? 16 : 8;
+    static constexpr int TBL_BYTES = 2 * CH * TP * 8;
+    static constexpr int LDS_BYTES = 4 * TILE_BYTES + TBL_BYTES;
 };
 
 // Both panels are [64 pixels][TCOL channels] images filled by LDS-DMA (buffer_load ... lds: one wave instruction lays
@@ -63,6 +68,22 @@ struct WCfg {
 // a half-wave touches per transposing read fall on 8 distinct bank groups.
 __device__ __forceinline__ int phys_col_bytes(int row, int col_bytes) {          // col_bytes: logical byte offset in the row
     return ((((col_bytes >> 5) ^ (row & 7)) << 5) | (col_bytes & 31));
+}
+
+// LDS-DMA (buffer_load_dwordx4 ... lds: 1 KiB per wave, lane l lands at lds_base + 16 l) issued from inline assembly.  Through
+// the builtin hipcc (ROCm 7.2) counts the DMA as a pending LDS write and, in front of the ds_read_b64_tr_b16 fragment reads
+// (an intrinsic it has no alias information for), emitted `s_waitcnt vmcnt(0)`: every k-step waited for the loads it had just
+// issued before touching the OTHER stage -- the prefetch never overlapped the MFMAs (L4 weight gradient 314 us with loads from
+// fixed, cache-hot addresses against 201 us without loads, profiles/r3f_wgrad_scalar.txt).  An asm statement is opaque to that
+// bookkeeping (cdna_hip_programming.md 5.7 item 1); the loop's own `s_waitcnt vmcnt(0)` + barrier in front of the stage's first
+// read is what orders the data.  M0 (the DMA's LDS base) is written in the same statement that uses it; nothing else in this
+// kernel depends on M0 (no LDS-DMA builtin is left).
+__device__ __forceinline__ void lds_dma16(const i32x4& rsrc, uint32_t lds_base, uint32_t voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ i32x4 make_rsrc(const void* ptr, uint32_t bytes) {
+    const uint64_t a = (uint64_t)ptr;
+    return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
 }
 
 template <int RS>
@@ -78,7 +99,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int ks, int colbase,
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool BIG>
+template <bool BIG, bool TABLE>
 __global__ __launch_bounds__(WCfg<BIG>::NT) void wgrad_kernel(const WgradParams p) {
     using C = WCfg<BIG>;
     constexpr int RS = C::RS, TILE_BYTES = C::TILE_BYTES, FI = C::FI, FJ = C::FJ;
@@ -101,8 +122,9 @@ __global__ __launch_bounds__(WCfg<BIG>::NT) void wgrad_kernel(const WgradParams 
     if (k_end > ksteps_total) k_end = ksteps_total;
 
     const int bidx = blockIdx.y;
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)bidx * p.x_bstride), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + (size_t)bidx * p.dy_bstride), 0, p.dy_bytes, 0x00020000);
+    const i32x4 rs_x = make_rsrc(p.x + (size_t)bidx * p.x_bstride, p.x_bytes);
+    const i32x4 rs_y = make_rsrc(p.dy + (size_t)bidx * p.dy_bstride, p.dy_bytes);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
 
     // LDS-DMA pieces of this wave: piece i (0..3) of a panel covers pixel rows RPP * (4 * wave + i) + rsub.  The physical
     // 16-byte chunk pch of a row holds the logical chunk whose 32-byte window is XORed with (row & 7); a lane meets at
@@ -110,6 +132,9 @@ __global__ __launch_bounds__(WCfg<BIG>::NT) void wgrad_kernel(const WgradParams 
     const int rsub = lane / C::CPR, pch = lane % C::CPR;
     int q_tap_dy[4], q_tap_dx[4], q_cx[4], q_coy[4];
     bool q_colok[4], q_cook[4];
+    // rowmode 1: byte offsets relative to the table's gather base / the step's first dy row, and the mask bits a lane needs
+    int cxl[4], cyl[4];
+    uint32_t xbits[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int r7 = (C::RPP * (4 * wave + i) + rsub) & 7;
@@ -123,27 +148,73 @@ __global__ __launch_bounds__(WCfg<BIG>::NT) void wgrad_kernel(const WgradParams 
         q_tap_dy[i] = kh - p.pad; q_tap_dx[i] = kw - p.pad;
         q_coy[i] = co0 + lch * 8;
         q_cook[i] = q_coy[i] < ((p.Co + 7) & ~7);
+        cxl[i] = ((kh * p.W + kw) * p.ldx + q_cx[i]) * 2;
+        // a lane with no dy channels to load: an offset beyond 2 GB, which the descriptor's range check answers with zeros
+        cyl[i] = q_cook[i] ? ((C::RPP * (4 * wave + i) + rsub) * p.ldy + p.yoff + q_coy[i]) * 2 : (int)0x80000000u;
+        // bit 15 is never set in a table mask: a lane with no x columns to load can never match
+        xbits[i] = q_colok[i] ? (0x80000000u | (1u << (kh & 15)) | (1u << (16 + (kw & 15)))) : 0x80008000u;
     }
 
-    auto issue_loads = [&](int kstep, int stage) {
+    // A piece's pixels are m = kstep * 64 + RPP * (4 * wave + i) + rsub.  Decomposing m every step (two divisions by launch
+    // constants, the gather address, bounds) cost ~110 vector + ~230 scalar instructions per wave and k-step beside 32 or 64
+    // MFMAs, against 34 + 31 in igemm_kernel, whose offsets advance by a constant (rocprofv3 SQ_INSTS_*, profiles/r3h_pmc.txt);
+    // neither pipe is free beside an MFMA stream: the L4 weight gradient took 245 us with this arithmetic and cache-hot loads
+    // against 178 us with neither (profiles/r3c_ablate.txt), whether the arithmetic ran in front of the step's MFMAs, pinned
+    // between them, or on the scalar unit.  rowmode 1: every pixel of the workgroup's range is decomposed ONCE, by one thread,
+    // into an LDS table entry {byte offset of x[n][oy*s - pad][ox*s - pad], mask: bit kh = row oy*s - pad + kh inside the image,
+    // bit 16 + kw = column inside, bit 31 = pixel exists}; a lane's step is one 8-byte LDS read, an add and a mask test per
+    // piece.  The table is a ring of two chunks of CH steps, the next-but-one chunk is rebuilt once per CH steps.
+    char* tbl = smem + 4 * TILE_BYTES;
+    const int nk = k_end - k_begin;
+    auto build_chunk = [&](int c) {
+        for (int e = tid; e < C::CH * TP; e += C::NT) {
+            const int step = c * C::CH + (e >> 6);
+            const int m = (k_begin + step) * TP + (e & 63);
+            i32x2 ent = {0, 0};
+            if (step < nk && m < p.M) {
+                const int n = fdiv(m, p.dHW);
+                const int r = m - n * (p.Ho * p.Wo);
+                const int oy = fdiv(r, p.dW);
+                const int ox = r - oy * p.Wo;
+                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+                uint32_t mask = 0x80000000u;
+                for (int k = 0; k < p.KH; k++) mask |= ((unsigned)(iy0 + k) < (unsigned)p.H) ? (1u << k) : 0u;
+                for (int k = 0; k < p.KW; k++) mask |= ((unsigned)(ix0 + k) < (unsigned)p.W) ? (1u << (16 + k)) : 0u;
+                ent[0] = (((n * p.H + iy0) * p.W + ix0) * p.ldx + p.xoff) * 2;
+                ent[1] = (int)mask;
+            }
+            *(i32x2*)(tbl + ((c & 1) * (C::CH * TP) + e) * 8) = ent;
+        }
+    };
+    const int tl = (C::RPP * 4 * wave + rsub) * 8;       // this lane's first entry inside a step's 64
+    auto issue_loads = [&](int kstep, int stage) {       // kstep relative to k_begin
+        const char* te = tbl + (kstep & (2 * C::CH - 1)) * (TP * 8) + tl;
+        const int sby = (k_begin + kstep) * TP * p.ldy * 2;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int row = C::RPP * (4 * wave + i) + rsub;
-            const int m = kstep * TP + row;
-            const bool mv = m < p.M;
-            const int n = fdiv(m, p.dHW);
-            const int r = m - n * (p.Ho * p.Wo);
-            const int oy = fdiv(r, p.dW);
-            const int ox = r - oy * p.Wo;
-            const int iy = oy * p.stride + q_tap_dy[i], ix = ox * p.stride + q_tap_dx[i];
-            const bool okx = mv && q_colok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const uint32_t offx = okx ? (uint32_t)((((n * p.H + iy) * p.W + ix) * p.ldx + p.xoff + q_cx[i]) * 2) : OOB;
-            const bool oky = mv && q_cook[i];
-            const uint32_t offy = oky ? (uint32_t)((m * p.ldy + p.yoff + q_coy[i]) * 2) : OOB;
-            char* dx = sX + stage * TILE_BYTES + (4 * wave + i) * 1024;
-            char* dy = sY + stage * TILE_BYTES + (4 * wave + i) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(void, dx), 16, offx, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, LDS_PTR(void, dy), 16, offy, 0, 0, 0);
+            uint32_t offx, offy;
+            if constexpr (!TABLE) {
+                const int row = C::RPP * (4 * wave + i) + rsub;
+                const int m = (k_begin + kstep) * TP + row;
+                const bool mv = m < p.M;
+                const int n = fdiv(m, p.dHW);
+                const int r = m - n * (p.Ho * p.Wo);
+                const int oy = fdiv(r, p.dW);
+                const int ox = r - oy * p.Wo;
+                const int iy = oy * p.stride + q_tap_dy[i], ix = ox * p.stride + q_tap_dx[i];
+                const bool okx = mv && q_colok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                offx = okx ? (uint32_t)((((n * p.H + iy) * p.W + ix) * p.ldx + p.xoff + q_cx[i]) * 2) : OOB;
+                const bool oky = mv && q_cook[i];
+                offy = oky ? (uint32_t)((m * p.ldy + p.yoff + q_coy[i]) * 2) : OOB;
+            } else {
+                const i32x2 ent = *(const i32x2*)(te + i * (C::RPP * 8));
+                const uint32_t mask = (uint32_t)ent[1];
+                offx = (mask & xbits[i]) == xbits[i] ? (uint32_t)(ent[0] + cxl[i]) : OOB;
+                offy = (int)mask < 0 ? (uint32_t)(sby + cyl[i]) : OOB;
+            }
+            const uint32_t dx = lds0 + stage * TILE_BYTES + (4 * wave + i) * 1024;
+            lds_dma16(rs_x, dx, offx);
+            lds_dma16(rs_y, dx + 2 * TILE_BYTES, offy);
         }
     };
 
@@ -153,16 +224,24 @@ __global__ __launch_bounds__(WCfg<BIG>::NT) void wgrad_kernel(const WgradParams 
 #pragma unroll
         for (int j = 0; j < FJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = k_end - k_begin;
     if (nk > 0) {
+        if constexpr (TABLE) {
+            build_chunk(0);
+            build_chunk(1);
+            __syncthreads();
+        }
         // one barrier per step: [tile kt landed for every wave AND everyone left tile kt-1] -> issue tile kt+1 into the
         // stage tile kt-1 occupied -> compute tile kt while it flies
-        issue_loads(k_begin, 0);
+        issue_loads(0, 0);
         for (int kt = 0; kt < nk; kt++) {
             const int cur = kt & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (kt + 1 < nk) issue_loads(k_begin + kt + 1, cur ^ 1);
+            if (kt + 1 < nk && !(p.debug & 2)) issue_loads((p.debug & 4) ? 0 : kt + 1, cur ^ 1);
+            // chunk (kt+1)/CH - 1 was last read a step ago (behind this step's barrier); its slot takes chunk (kt+1)/CH + 1
+            if constexpr (TABLE) {
+                if (((kt + 1) & (C::CH - 1)) == 0) build_chunk(((kt + 1) / C::CH) + 1);
+            }
             const char* tx = sX + cur * TILE_BYTES;
             const char* ty = sY + cur * TILE_BYTES;
             // both k-slices in registers; the transposing reads of slice 1 are issued under the MFMAs of slice 0
@@ -408,18 +487,29 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
     big = big && regular;              // concatenated / unaligned gradients keep the 128 x 128 tiling (same split plan)
     p.direct = (splits == 1 && regular) ? 1 : 0;
     p.accumulate = accumulate; p.dw = dw;
+    p.debug = gcc_opt(GCC_OPT_DEBUG);
+    {
+        p.rowmode = (gcc_opt(GCC_OPT_WGRAD_ROW_TABLE) && c->KH <= 15 && c->KW <= 15) ? 1 : 0;
+    }
     const int tcol = big ? 256 : 128;
     p.col_tiles = cdiv(p.ncols, tcol); p.co_tiles = cdiv(c->Co, tcol);
     p.dHW = make_fastdiv(Ho * Wo); p.dW = make_fastdiv(Wo); p.dCip = make_fastdiv(p.Cip); p.dKW = make_fastdiv(c->KW);
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
-        hipFuncSetAttribute((const void*)wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WCfg<false>::LDS_BYTES);
-        hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WCfg<true>::LDS_BYTES);
+        hipFuncSetAttribute((const void*)wgrad_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WCfg<false>::LDS_BYTES);
+        hipFuncSetAttribute((const void*)wgrad_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WCfg<true>::LDS_BYTES);
+        hipFuncSetAttribute((const void*)wgrad_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WCfg<false>::LDS_BYTES);
+        hipFuncSetAttribute((const void*)wgrad_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WCfg<true>::LDS_BYTES);
     });
-    if (big)
-        hipLaunchKernelGGL(wgrad_kernel<true>, dim3(p.col_tiles * p.co_tiles, batch, splits), dim3(WCfg<true>::NT), WCfg<true>::LDS_BYTES, st, p);
+    const dim3 grid(p.col_tiles * p.co_tiles, batch, splits);
+    if (big && p.rowmode)
+        hipLaunchKernelGGL((wgrad_kernel<true, true>), grid, dim3(WCfg<true>::NT), WCfg<true>::LDS_BYTES, st, p);
+    else if (big)
+        hipLaunchKernelGGL((wgrad_kernel<true, false>), grid, dim3(WCfg<true>::NT), WCfg<true>::LDS_BYTES, st, p);
+    else if (p.rowmode)
+        hipLaunchKernelGGL((wgrad_kernel<false, true>), grid, dim3(WCfg<false>::NT), WCfg<false>::LDS_BYTES, st, p);
     else
-        hipLaunchKernelGGL(wgrad_kernel<false>, dim3(p.col_tiles * p.co_tiles, batch, splits), dim3(WCfg<false>::NT), WCfg<false>::LDS_BYTES, st, p);
+        hipLaunchKernelGGL((wgrad_kernel<false, false>), grid, dim3(WCfg<false>::NT), WCfg<false>::LDS_BYTES, st, p);
     GCC_CHECK_LAUNCH();
     if (p.direct) return GCC_OK;
     const size_t total = (size_t)batch * c->Co * c->KH * c->KW * c->Ci;

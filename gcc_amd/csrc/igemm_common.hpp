@@ -39,6 +39,7 @@ struct IgemmParams {
     int pair;
     float* pair_slab;            // [tiles][256 * 256] fp32
     unsigned int* pair_flags;    // [tiles][2]: ticket, ready -- zeroed by the launcher before every launch
+    int debug = 0;               // GCC_OPT_DEBUG ablations (timing diagnostics only)
 };
 
 constexpr int BK = 64;   // k per step

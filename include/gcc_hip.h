@@ -83,6 +83,15 @@ enum {
     GCC_OPT_FUSE_BN,            /* 1 (default): gcc_conv_bn_act folds split-K partials, statistics, finalize and normalise in one kernel */
     GCC_OPT_BN_BWD_SMALL,       /* 1 (default): gcc_bnact_bwd of <= 4096 pixels (training BatchNorm, no gate) runs as one kernel instead of
                                    three, gcc_channel_sum of <= 16384 pixels as one instead of two */
+    GCC_OPT_WGRAD_ROW_TABLE,    /* 1 (default): the weight-gradient kernel decomposes each pixel of a workgroup's range once, into an LDS table
+                                   (gather base + validity mask), instead of in every lane at every k-step (0: the round-2 form;
+                                   kernels taller or wider than 15 taps always take that form) */
+    GCC_OPT_IGEMM_HALO,         /* 1 (default): k4 s2 p1 convolutions whose geometry fits (channels per tap a multiple of 64, 256 output channels
+                                   per tile, output rows that tile 256 pixels) stage each 64-channel slice of the input neighbourhood of a
+                                   256-pixel tile ONCE in LDS and serve the taps that share it from there (conv_halo.hip); 0: the gather
+                                   kernel re-stages the pixels for every tap */
+    GCC_OPT_DEBUG,              /* 0 (default).  Diagnostic ablations for timing only -- RESULTS ARE WRONG when set: bit 1 (2) the main loops issue
+                                   no staging loads after the first step, bit 2 (4) they re-load the first step's addresses */
     GCC_OPT_COUNT_
 };
 int gcc_set_option(int id, int value);
