@@ -281,11 +281,11 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
             for (int i = 0; i < W_N; i++) cur_w[i] = (kval && w_ok[i]) ? (uint32_t)(w_off[i] + wt_off) : OOB;
             left = (p.Ct - cc) / BK;
         };
-        auto issue = [&](int stage) {
+        auto issue = [&](int stage, bool pixels = true) {
 #pragma unroll
             for (int i = 0; i < AI; i++) {
                 char* dst = sA + stage * (BP * BK * 2) + (wave * AI + i) * 1024;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, LDS_PTR(void, dst), 16, cur_a[i], 0, 0, 0);
+                if (pixels) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, LDS_PTR(void, dst), 16, cur_a[i], 0, 0, 0);
                 cur_a[i] += BK * 2;
             }
             if (WPW > 0 || wave < C::WI) {
@@ -378,7 +378,7 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (!(p.debug & 2)) {
-                issue((kt + 1) & 1);                // past the end of K the offsets are out of range: zero fill, unused
+                issue((kt + 1) & 1, !(p.debug & 8) || (kt & 3) == 0);    // past the end of K the offsets are out of range: zero fill, unused
                 if (!(p.debug & 4)) next_step();    // (rare) tap change: its VALU work hides under the MFMAs below
                 else {
 #pragma unroll
@@ -1313,6 +1313,15 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
     const int phases = dgrad ? c->stride * c->stride : 1;
     if (dgrad && (c->KH < c->stride || c->KW < c->stride)) return GCC_ERR_UNSUPPORTED;
     const TilePlan tp = select_tile(max_rows, p.Cout, phases, conv_nk(c, dgrad), batch);
+    if (batch == 1) {
+        // k4 s2 p1 layers whose geometry fits: the tile's input neighbourhood staged once per 64 channels (conv_halo.hip).  With
+        // statistics the tile rows must be the ones gcc_conv_stat_tiles() promised (the 256-pixel plan's).
+        const HaloPlan h = halo_plan(c, dgrad);
+        if (h.ok && h.wgs >= gcc_opt(GCC_OPT_IGEMM_BIG_MIN) && (!p.stats || (tp.BP == 256 && !dgrad))) {
+            const int rc2 = launch_halo(c, dgrad, h, src, w, dst, ep, st);
+            if (rc2 >= 0) return rc2;
+        }
+    }
     const int BC = tp.BC;
     p.ntiles = tp.ntiles;
     p.mtiles_max = tp.mtiles;

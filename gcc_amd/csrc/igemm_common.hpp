@@ -43,6 +43,12 @@ struct IgemmParams {
 };
 
 constexpr int BK = 64;   // k per step
+
+// conv_halo.hip: k4 s2 p1 convolutions with the tile's input neighbourhood resident in LDS
+struct HaloPlan { int ok, mode, TR, TW, lgTW, HR, HW, HWp, npieces, tiles_x, tiles_y, ntiles, phases; size_t lds; long wgs; };
+HaloPlan halo_plan(const gcc_conv_t* c, int dgrad);
+int launch_halo(const gcc_conv_t* c, int dgrad, const HaloPlan& h, const void* src, const void* w, void* dst, const gcc_epilogue_t* ep,
+                hipStream_t st);
 constexpr uint32_t OOB = 0x7FFFFFF0u;
 
 // BP pixels x BC channels per workgroup.  BP = 128: 4 waves (2 workgroups per CU); BP = 256: 8 waves,

@@ -23,7 +23,9 @@ class TeacherStreamMixin:
         if getattr(self, 'teacher_model', None) is not None:
             self.teacher_model.serialize_streams = not concurrent
         engine.OVERLAP_WGRAD = bool(concurrent) and os.environ.get('GCC_OVERLAP_WGRAD', '1') != '0'
-        ops.lib().gcc_set_option(_lib.OPT_IGEMM_PAIR, 0 if concurrent else 1)
+        # GCC_PAIR_CONCURRENT=1: keep the pair split in the multi-stream schedule too (A/B hook)
+        pair_conc = 1 if os.environ.get('GCC_PAIR_CONCURRENT', '0') == '1' else 0
+        ops.lib().gcc_set_option(_lib.OPT_IGEMM_PAIR, pair_conc if concurrent else 1)
         self._apply_wgrad_plan(concurrent)
 
     @staticmethod
