@@ -18,6 +18,13 @@
 // input channels (L2's data gradient) a 256-column tile holds BOTH px phases (columns 0..127: px = 0, 128..255: px = 1; mode 2):
 // the two phases' output pixels are neighbours in x, so the tile's 256 "channels" are 512 contiguous bytes of dx.
 //
+// Stride 1 (k4 s1 p1: PatchGAN L4, 512 -> 1024 on 32 x 32 -> 31 x 31; template parameter S1): all 16 taps share one staged
+// neighbourhood, (TR + 3) x (TW + 3) pixels of a 64-channel slice serve 16 k-steps (pixel staging 1/11th of igemm_kernel's; the
+// forward's positions live on the padded H x W grid, the tile rows / columns past Ho, Wo are computed and dropped).  With a
+// 16 x 16 tile and an LDS pitch of 20 rows the two stages of the slice and of the weights are exactly the CU's 160 KiB.  The
+// pitch is 4 mod 8, so a row shift by an odd number of sub-grid rows flips bit 2 of row & 7 -- the swizzled chunk index moves by
+// 4, i.e. the address by 64 bytes, exactly like the second 32-deep k-slice does: still a compile-time XOR on one base address.
+//
 // Tile 256 pixels x 256 columns x 64 k, 8 waves (2 along columns x 4 along pixels, 128 x 64 per wave), one workgroup per CU;
 // main loop, fragment order and epilogue are igemm_kernel<256, 256>'s.  Geometry must fit exactly (launcher: halo_plan).
 #include <mutex>
@@ -28,7 +35,8 @@ namespace gcc_igemm {
 
 struct HaloParams {
     const bf16_t* src; const bf16_t* wgt; bf16_t* dst; const float* bias; float* stats;
-    int mode;                      // 0 fprop, 1 dgrad (one phase per z), 2 dgrad, both px phases in the tile's columns
+    int mode;                      // k4 s2 p1: 0 fprop, 1 dgrad (one phase per z), 2 dgrad, both px phases in the tile's columns;
+                                   // k4 s1 p1: 3 fprop, 4 dgrad
     int N, Hs, Ws, lds_, soff;     // gather source (x / dy)
     int Hd, Wd, ldd, doff;         // destination
     int Ct, Cout, ldw;             // source channels per tap (multiple of 64), GEMM columns, weight row stride (elements)
@@ -40,6 +48,7 @@ struct HaloParams {
     int tiles_x, tiles_y;          // tiles per image
     int ntiles;                    // column tiles
     int nchunks;                   // Ct / 64
+    int PH, PW;                    // positions that exist (mode 3: Ho x Wo of the padded H x W grid; otherwise the whole grid)
 };
 
 constexpr int HB = 256, HC = 256;
@@ -47,9 +56,11 @@ using HCfg = Cfg<HB, HC>;
 constexpr int HALO_W_BYTES = HC * BK * 2;          // one weight stage: [256][64] bf16
 constexpr int HALO_MAX_PIECES = 48;                // 6 per wave
 
+template <bool S1>
 __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
     using C = HCfg;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int T = S1 ? 16 : 4;                   // k-steps (taps) a staged slice serves
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     char* sW = smem;                                 // weights [2][256][128 B]
     char* sH = smem + 2 * HALO_W_BYTES;              // staged sub-grid slices [2][npieces * 8][128 B]
     const int hbuf = p.npieces * 1024;
@@ -70,18 +81,25 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
     const int py = p.mode == 0 ? 0 : (p.mode == 1 ? (int)blockIdx.z >> 1 : (int)blockIdx.z);
     const int pxz = p.mode == 1 ? (int)blockIdx.z & 1 : 0;
 
-    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, p.wgt_bytes, 0x00020000);
+    // LDS-DMA from inline assembly (common.hpp lds_dma16): invisible to hipcc's wait-count insertion, which otherwise drains the
+    // prefetch in front of the fragment reads of the stride-1 form; the loop's own vmcnt(0) + barrier order the data
+    const i32x4 rs_src = make_rsrc(p.src, p.src_bytes);
+    const i32x4 rs_wgt = make_rsrc(p.wgt, p.wgt_bytes);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
 
     // ---- staged sub-grid: this wave's pieces q = wave + 8 t; a lane's pixel of piece q is LDS row 8 q + (lane >> 3) ------------
     // physical 16-byte chunk lane & 7 of a row holds logical chunk (lane & 7) ^ (row & 7), and row & 7 == lane >> 3
     const int chunk = (lane & 7) ^ (lane >> 3);
     const int sstep = p.mode == 0 ? 2 : 1;           // source pixels per position step
+    const float inv_pitch = 1.0f / (float)p.HWp;
     const int img_base = img * p.Hs * p.Ws;
     // stage `s` of the K loop: mode 0: s = (u * 2 + v) * nchunks + ch; modes 1, 2: s = ch
     auto issue_halo = [&](int s, int t, int buf) {
         int oy_s, ox_s, ch;
-        if (p.mode == 0) {
+        if constexpr (S1) {
+            ch = s;
+            oy_s = ox_s = p.mode == 3 ? -1 : -2;
+        } else if (p.mode == 0) {
             const int uv = s / p.nchunks;
             ch = s - uv * p.nchunks;
             oy_s = (uv >> 1) - 1; ox_s = (uv & 1) - 1;
@@ -91,15 +109,20 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
         }
         const int q = wave + 8 * t;
         if (q < p.npieces) {                          // wave-uniform
-            // a sub-grid row occupies HWp (a multiple of 8) LDS rows: the piece's sub-grid row and first column are wave-uniform
-            const int ppr = p.HWp >> 3;
-            const int Yl = q / ppr;
-            const int Xl = (q - Yl * ppr) * 8 + (lane >> 3);
+            int Yl, Xl;
+            if constexpr (S1) {                       // pitch 20: a piece's 8 rows may straddle two sub-grid rows
+                const int row = q * 8 + (lane >> 3);
+                Yl = (int)(((float)row + 0.5f) * inv_pitch);
+                Xl = row - Yl * p.HWp;
+            } else {                                  // pitch a multiple of 8: the piece's sub-grid row and first column are wave-uniform
+                const int ppr = p.HWp >> 3;
+                Yl = q / ppr;
+                Xl = (q - Yl * ppr) * 8 + (lane >> 3);
+            }
             const int y = sstep * (Y0 + Yl) + oy_s, x = sstep * (X0 + Xl) + ox_s;
-            const bool ok = Xl < p.HW && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+            const bool ok = Yl < p.HR && Xl < p.HW && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
             const uint32_t off = ok ? (uint32_t)((((img_base + y * p.Ws + x) * p.lds_ + p.soff + ch * BK) << 1) + chunk * 16) : OOB;
-            char* dst = sH + buf * hbuf + q * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, LDS_PTR(void, dst), 16, off, 0, 0, 0);
+            lds_dma16(rs_src, lds0 + 2 * HALO_W_BYTES + buf * hbuf + q * 1024, off);
         }
     };
 
@@ -109,9 +132,12 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
     const int w_row0 = (p.mode == 2 ? (wr0 & 127) : n0 + wr0) * p.ldw * 2 + chunk * 16;
     const int px_w = p.mode == 2 ? (wave >> 2) : pxz;      // column half of the rows this wave stages (mode 2)
     auto issue_w = [&](int kt, int buf) {
-        const int s = kt >> 2, j = kt & 3, ja = j >> 1, jb = j & 1;
+        const int s = kt / T, j = kt - s * T, ja = j >> 1, jb = j & 1;
         int kh, kw, ch;
-        if (p.mode == 0) {
+        if constexpr (S1) {
+            ch = s;
+            kh = j >> 2; kw = j & 3;
+        } else if (p.mode == 0) {
             const int uv = s / p.nchunks;
             ch = s - uv * p.nchunks;
             kh = 2 * ja + (uv >> 1); kw = 2 * jb + (uv & 1);
@@ -123,8 +149,7 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t off = (uint32_t)(w_row0 + tapoff + i * (16 * p.ldw));
-            char* dst = sW + buf * HALO_W_BYTES + (wave * 4 + i) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, LDS_PTR(void, dst), 16, off, 0, 0, 0);
+            lds_dma16(rs_wgt, lds0 + buf * HALO_W_BYTES + (wave * 4 + i) * 1024, off);
         }
     };
 
@@ -134,6 +159,8 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
     // consecutive LDS rows.  With the pitch a multiple of 8, a fragment's row & 7 is (lr + shx) & 7 whatever the fragment and the
     // row shift: one address register per column shift shx (0, 1 or 2), everything else is a scalar byte offset.
     const int prow0 = ((wp * C::TP) >> p.lgTW) * p.HWp + ((wp * C::TP) & (p.TW - 1)) + lr;
+    // (S1, pitch 4 mod 8, TW == 16: fragment jj sits jj sub-grid rows below fragment 0, whose tile row wp * 4 is even, so its
+    // row & 7 is (lr + shx) & 7 with bit 2 flipped when jj + shy is odd -- the XOR in afrag below.)
     int abase[3];
 #pragma unroll
     for (int sx = 0; sx < 3; sx++) abase[sx] = (prow0 + sx) * 128 + ((lq ^ ((lr + sx) & 7)) << 4);
@@ -156,15 +183,26 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
     // take that one's registers -- and the four pixel fragments into registers of their own, one per two weight fragments
     // (128 accumulators + 48 + 16 fragment registers instead of 128 + 96: igemm_kernel<256, 256> sits at the 256-register
     // limit with the second slice held apart, and this kernel has more address arithmetic alive).
+    // (fragment addresses are formed as 32-bit LDS addresses: XOR arithmetic through a generic pointer made hipcc emit
+    // flat_load_dwordx4, whose waits cover the vector-memory counter too -- the prefetch was drained in front of the MFMAs)
+    typedef __attribute__((address_space(3))) const bf16x8* lds_frag_ptr;
     auto compute = [&](int wbuf, int hb, int shy, int shx) {
-        const char* a = sH + (hb * hbuf + shy * p.HWp * 128) + abase[shx];
+        uint32_t a = lds0 + 2 * HALO_W_BYTES + hb * hbuf + shy * p.HWp * 128;
+        if constexpr (S1) {          // shy, shx are run-time (wave-uniform) here: the 16-tap loop is not unrolled
+            const int t = prow0 + shx;
+            a += (t << 7) + ((lq ^ (t & 7)) << 4);
+            a ^= (shy & 1) * 64;     // odd row shift: chunk index ^ 4 (pitch 4 mod 8)
+        } else {
+            a += abase[shx];
+        }
         const char* w = sW + wbuf * HALO_W_BYTES;
         auto wfrag = [&](int ks, int i) {
             const int row = wc * C::TC + i * 16 + lr;
             return *(const bf16x8*)(w + row * 128 + (((ks * 4 + lq) ^ (row & 7)) << 4));
         };
         auto afrag = [&](int ks, int j) {             // slice 1 = chunk ^ 4: the address differs in bit 6
-            return *(const bf16x8*)((const char*)((uintptr_t)(a + pstep[j]) ^ (uintptr_t)(ks * 64)));
+            const int flip = S1 ? ((ks + j) & 1) : ks;     // fragment j sits j sub-grid rows further down (S1)
+            return *(lds_frag_ptr)(uintptr_t)((a + pstep[j]) ^ (uint32_t)(flip * 64));
         };
         bf16x8 fw0[C::CB], fa0[C::PB], fw1[C::CB], fa1[C::PB];
 #pragma unroll
@@ -200,26 +238,45 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
     // one barrier per k-step, as in igemm_kernel: [everything issued a step ago has landed for every wave AND everyone left the
     // buffers of step kt - 1] -> issue the weights of step kt + 1 and (in the first three steps of a stage) a third of the next
     // stage's sub-grid slice -> multiply step kt.  A slice is complete a full k-step before its first read.
-    const int nstages = p.mode == 0 ? 4 * p.nchunks : p.nchunks;
-    const int nk = 4 * nstages;
+    const int nstages = (!S1 && p.mode == 0) ? 4 * p.nchunks : p.nchunks;
+    const int nk = T * nstages;
 #pragma unroll
     for (int t = 0; t < 6; t++) issue_halo(0, t, 0);
     issue_w(0, 0);
-    for (int s = 0; s < nstages; s++) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int kt = 4 * s + j;
+    if constexpr (S1) {
+        auto step = [&](int s, int j, int wbuf) {                 // wbuf is a literal at both call sites
+            const int kt = T * s + j;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (kt + 1 < nk) issue_w(kt + 1, (kt + 1) & 1);
-            if (j < 3 && s + 1 < nstages) {
-                issue_halo(s + 1, 2 * j, (s + 1) & 1);
-                issue_halo(s + 1, 2 * j + 1, (s + 1) & 1);
+            if (kt + 1 < nk) issue_w(kt + 1, wbuf ^ 1);
+            if (j < 6 && s + 1 < nstages) issue_halo(s + 1, j, (s + 1) & 1);
+            const int kh = j >> 2, kw = j & 3;
+            compute(wbuf, s & 1, p.mode == 3 ? kh : 3 - kh, p.mode == 3 ? kw : 3 - kw);
+        };
+        for (int s = 0; s < nstages; s++) {
+#pragma unroll 1
+            for (int j = 0; j < T; j += 2) {
+                step(s, j, 0);
+                step(s, j + 1, 1);
             }
-            const int ja = j >> 1, jb = j & 1;
-            const int shy = p.mode == 0 ? ja : 1 - ja;
-            const int shx = p.mode == 0 ? jb : (p.mode == 1 ? 1 - jb : px_c + 1 - jb);
-            compute(kt & 1, s & 1, shy, shx);
+        }
+    } else {
+        for (int s = 0; s < nstages; s++) {
+#pragma unroll
+            for (int j = 0; j < T; j++) {
+                const int kt = T * s + j;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (kt + 1 < nk) issue_w(kt + 1, (kt + 1) & 1);
+                if (j < 3 && s + 1 < nstages) {
+                    issue_halo(s + 1, 2 * j, (s + 1) & 1);
+                    issue_halo(s + 1, 2 * j + 1, (s + 1) & 1);
+                }
+                const int ja = j >> 1, jb = j & 1;
+                const int shy = p.mode == 0 ? ja : 1 - ja;
+                const int shx = p.mode == 0 ? jb : (p.mode == 1 ? 1 - jb : px_c + 1 - jb);
+                compute(kt & 1, s & 1, shy, shx);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -244,6 +301,9 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
 #pragma unroll
             for (int r = 0; r < 4; r++) v[r] = acc[i][j][r] + bv[r];
             apply_actN<4>(v, v, p.act, p.slope);
+            if constexpr (S1) {       // positions past the output keep exact zeros (the statistics below sum every row of the tile)
+                if (Y0 + (pl >> p.lgTW) >= p.PH || X0 + (pl & (p.TW - 1)) >= p.PW) v[0] = v[1] = v[2] = v[3] = 0.f;
+            }
             i32x2 pk;
             pk[0] = (int)pack2bf(v[0], v[1]);
             pk[1] = (int)pack2bf(v[2], v[3]);
@@ -257,7 +317,11 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
         const int row = q / CPR, cch = q - row * CPR;
         const int yl = row >> p.lgTW, xl = row & (p.TW - 1);
         int oy, ox, ch;
-        if (p.mode == 0) { oy = Y0 + yl; ox = X0 + xl; ch = n0 + cch * 8; }
+        if constexpr (S1) {
+            oy = Y0 + yl; ox = X0 + xl; ch = n0 + cch * 8;
+            if (oy >= p.PH || ox >= p.PW) continue;
+        }
+        else if (p.mode == 0) { oy = Y0 + yl; ox = X0 + xl; ch = n0 + cch * 8; }
         else if (p.mode == 1) { oy = 2 * (Y0 + yl) + py; ox = 2 * (X0 + xl) + pxz; ch = n0 + cch * 8; }
         else { oy = 2 * (Y0 + yl) + py; ox = 2 * (X0 + xl) + (cch >> 4); ch = (cch & 15) * 8; }
         const size_t o = ((size_t)(img * p.Hd + oy) * p.Wd + ox) * p.ldd + p.doff + ch;
@@ -288,29 +352,40 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
 HaloPlan halo_plan(const gcc_conv_t* c, int dgrad) {
     HaloPlan h = {};
     if (!gcc_opt(GCC_OPT_IGEMM_HALO)) return h;
-    if (c->KH != 4 || c->KW != 4 || c->stride != 2 || c->pad != 1 || (c->H & 1) || (c->W & 1)) return h;
-    const int Ho = c->H / 2, Wo = c->W / 2;
+    if (c->KH != 4 || c->KW != 4 || c->pad != 1) return h;
     const int Ct = dgrad ? c->Co : c->Ci, Cout = dgrad ? c->Ci : c->Co;
     if (Ct % BK || Ct < BK) return h;
-    if (!dgrad) { if (Cout % HC) return h; h.mode = 0; }
-    else if (Cout == 128) h.mode = 2;
-    else if (Cout % HC == 0) h.mode = 1;
-    else return h;
-    int tw = 256;
-    while (tw > Wo) tw >>= 1;
-    if (tw < 16 || Wo % tw) return h;
-    const int tr = 256 / tw;
-    if (Ho % tr) return h;
-    h.TW = tw; h.TR = tr;
+    int gh, gw;                                   // position grid
+    if (c->stride == 2) {
+        if ((c->H & 1) || (c->W & 1)) return h;
+        gh = c->H / 2; gw = c->W / 2;
+        if (!dgrad) { if (Cout % HC) return h; h.mode = 0; }
+        else if (Cout == 128) h.mode = 2;
+        else if (Cout % HC == 0) h.mode = 1;
+        else return h;
+        int tw = 256;
+        while (tw > gw) tw >>= 1;
+        if (tw < 16 || gw % tw) return h;
+        h.TW = tw; h.TR = 256 / tw;
+        h.HR = h.TR + 1; h.HW = tw + (h.mode == 2 ? 2 : 1);
+        h.HWp = (h.HW + 7) & ~7;
+        h.phases = h.mode == 0 ? 1 : (h.mode == 1 ? 4 : 2);
+    } else if (c->stride == 1) {
+        if (gcc_opt(GCC_OPT_IGEMM_HALO) < 2) return h;            // 2 (default): the stride-1 form too
+        if (Cout % HC) return h;
+        gh = c->H; gw = c->W;                     // forward: the padded grid (Ho = H - 1 rows exist)
+        h.mode = dgrad ? 4 : 3;
+        h.TW = 16; h.TR = 16;
+        h.HR = 19; h.HW = 19; h.HWp = 20;
+        h.phases = 1;
+    } else return h;
+    if (gw % h.TW || gh % h.TR) return h;
     h.lgTW = 0;
-    while ((1 << h.lgTW) < tw) h.lgTW++;
-    h.HR = tr + 1; h.HW = tw + (h.mode == 2 ? 2 : 1);
-    h.HWp = (h.HW + 7) & ~7;
-    h.npieces = h.HR * h.HWp / 8;
+    while ((1 << h.lgTW) < h.TW) h.lgTW++;
+    h.npieces = (h.HR * h.HWp + 7) / 8;
     if (h.npieces > HALO_MAX_PIECES) return h;
-    h.tiles_x = Wo / tw; h.tiles_y = Ho / tr;
+    h.tiles_x = gw / h.TW; h.tiles_y = gh / h.TR;
     h.ntiles = h.mode == 2 ? 1 : Cout / HC;
-    h.phases = h.mode == 0 ? 1 : (h.mode == 1 ? 4 : 2);
     const size_t loop = 2 * (size_t)HALO_W_BYTES + 2 * (size_t)h.npieces * 1024;
     const size_t epi = (size_t)HCfg::LDS_BYTES_EPI;
     h.lds = loop > epi ? loop : epi;
@@ -323,7 +398,7 @@ HaloPlan halo_plan(const gcc_conv_t* c, int dgrad) {
 int launch_halo(const gcc_conv_t* c, int dgrad, const HaloPlan& h, const void* src, const void* w, void* dst, const gcc_epilogue_t* ep,
                 hipStream_t st) {
     HaloParams p;
-    const int Ho = c->H / 2, Wo = c->W / 2;
+    const int Ho = gcc_conv_out(c->H, 4, c->stride, 1), Wo = gcc_conv_out(c->W, 4, c->stride, 1);
     p.src = (const bf16_t*)src; p.wgt = (const bf16_t*)w; p.dst = (bf16_t*)dst;
     p.bias = ep ? ep->bias : nullptr; p.stats = ep ? ep->stats_partial : nullptr;
     p.act = ep ? ep->act : GCC_ACT_NONE; p.slope = ep ? ep->slope : 0.f;
@@ -342,12 +417,15 @@ int launch_halo(const gcc_conv_t* c, int dgrad, const HaloPlan& h, const void* s
     p.src_bytes = (uint32_t)sb; p.wgt_bytes = (uint32_t)wb;
     p.TR = h.TR; p.TW = h.TW; p.lgTW = h.lgTW; p.HR = h.HR; p.HW = h.HW; p.HWp = h.HWp; p.npieces = h.npieces;
     p.tiles_x = h.tiles_x; p.tiles_y = h.tiles_y; p.ntiles = h.ntiles; p.nchunks = p.Ct / BK;
+    p.PH = h.mode == 3 ? Ho : h.tiles_y * h.TR; p.PW = h.mode == 3 ? Wo : h.tiles_x * h.TW;
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute((const void*)igemm_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)igemm_halo_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)igemm_halo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const dim3 grid((unsigned)(c->N * h.tiles_x * h.tiles_y * h.ntiles), 1, h.phases);
-    hipLaunchKernelGGL(igemm_halo_kernel, grid, dim3(512), h.lds, st, p);
+    if (h.mode >= 3) hipLaunchKernelGGL(igemm_halo_kernel<true>, grid, dim3(512), h.lds, st, p);
+    else hipLaunchKernelGGL(igemm_halo_kernel<false>, grid, dim3(512), h.lds, st, p);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

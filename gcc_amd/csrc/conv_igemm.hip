@@ -626,6 +626,15 @@ int launch(const IgemmParams& p, int phases, int batch, hipStream_t st) {
 
 // Tile choice (shared by the launcher, gcc_conv_stat_tiles and gcc_conv_workspace).
 struct TilePlan { int BP, BC, ntiles, mtiles, max_slices, pair; };
+// does a launch take the LDS-resident-neighbourhood kernel (conv_halo.hip)?  With statistics its tile rows must be the ones
+// gcc_conv_stat_tiles() promised: the stride-2 form keeps the 256-pixel plan's rows, the stride-1 form has its own (and
+// gcc_conv_stat_tiles reports them).
+static bool halo_routed(const HaloPlan& h, int dgrad, bool with_stats, int plan_bp) {
+    if (!h.ok || h.wgs < gcc_opt(GCC_OPT_IGEMM_BIG_MIN)) return false;
+    if (!with_stats) return true;
+    if (dgrad) return false;
+    return h.mode == 3 || plan_bp == 256;
+}
 static TilePlan select_tile(size_t max_rows, int Cout, int phases, int nk, int batch) {
     TilePlan t;
     t.BP = 128;
@@ -1317,7 +1326,7 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
         // k4 s2 p1 layers whose geometry fits: the tile's input neighbourhood staged once per 64 channels (conv_halo.hip).  With
         // statistics the tile rows must be the ones gcc_conv_stat_tiles() promised (the 256-pixel plan's).
         const HaloPlan h = halo_plan(c, dgrad);
-        if (h.ok && h.wgs >= gcc_opt(GCC_OPT_IGEMM_BIG_MIN) && (!p.stats || (tp.BP == 256 && !dgrad))) {
+        if (halo_routed(h, dgrad, p.stats != nullptr, tp.BP)) {
             const int rc2 = launch_halo(c, dgrad, h, src, w, dst, ep, st);
             if (rc2 >= 0) return rc2;
         }
@@ -1659,6 +1668,8 @@ extern "C" int gcc_conv_stat_tiles(const gcc_conv_t* c, int dgrad) {
     if (check_conv(c)) return 0;
     const int phases = dgrad ? c->stride * c->stride : 1;
     const TilePlan tp = select_tile(conv_max_rows(c, dgrad), dgrad ? c->Ci : c->Co, phases, conv_nk(c, dgrad), 1);
+    const HaloPlan h = halo_plan(c, dgrad);
+    if (halo_routed(h, dgrad, true, tp.BP)) return c->N * h.tiles_x * h.tiles_y;
     return tp.mtiles * phases;
 }
 

@@ -70,22 +70,6 @@ __device__ __forceinline__ int phys_col_bytes(int row, int col_bytes) {         
     return ((((col_bytes >> 5) ^ (row & 7)) << 5) | (col_bytes & 31));
 }
 
-// LDS-DMA (buffer_load_dwordx4 ... lds: 1 KiB per wave, lane l lands at lds_base + 16 l) issued from inline assembly.  Through
-// the builtin hipcc (ROCm 7.2) counts the DMA as a pending LDS write and, in front of the ds_read_b64_tr_b16 fragment reads
-// (an intrinsic it has no alias information for), emitted `s_waitcnt vmcnt(0)`: every k-step waited for the loads it had just
-// issued before touching the OTHER stage -- the prefetch never overlapped the MFMAs (L4 weight gradient 314 us with loads from
-// fixed, cache-hot addresses against 201 us without loads, profiles/r3f_wgrad_scalar.txt).  An asm statement is opaque to that
-// bookkeeping (cdna_hip_programming.md 5.7 item 1); the loop's own `s_waitcnt vmcnt(0)` + barrier in front of the stage's first
-// read is what orders the data.  M0 (the DMA's LDS base) is written in the same statement that uses it; nothing else in this
-// kernel depends on M0 (no LDS-DMA builtin is left).
-__device__ __forceinline__ void lds_dma16(const i32x4& rsrc, uint32_t lds_base, uint32_t voff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
-}
-__device__ __forceinline__ i32x4 make_rsrc(const void* ptr, uint32_t bytes) {
-    const uint64_t a = (uint64_t)ptr;
-    return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
-}
-
 template <int RS>
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int ks, int colbase, int lane) {
     // 16x16x32 operand from a [pixel][channel] image: lane (g = lane>>4, i = lane&15) ends up with
