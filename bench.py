@@ -11,14 +11,19 @@ for BASELINE.json configs[1]: student U-Net ngf 32 + selective-activation PatchG
 teacher ngf 64 / ndf 128, hinge GAN loss, lambda_L1 100, content 50, gram 1e4, bf16 MFMA compute.
 Inputs are resident in HBM before the timed region.  One JSON line is printed by rank 0.
 
-roofline: the dominant kernel is the implicit-GEMM convolution (igemm_kernel, conv fprop / dgrad /
-ConvTranspose).  Every launch of it inside the first step of the timed region is bracketed by HIP
+roofline: the dominant kernel family is the implicit-GEMM convolution (igemm_kernel / igemm_halo_kernel: conv fprop /
+dgrad / ConvTranspose).  Every launch of it inside the first step of the timed region is bracketed by HIP
 events on the launch stream (bracketing all steps costs ~6% throughput); achieved = sum of algorithmic FLOPs
 (2*M*Cout*taps*Cin, padding excluded) / sum of measured durations; peak = 2.5 PFLOP/s dense bf16 MFMA
-(MI355X_MICROARCH.md).  That step runs with the three production streams (student, online teacher, weight
-gradients) folded onto one, so that a launch's duration is the kernel's own and not its neighbours' share of the CUs;
-the other steps of the timed region run the production schedule (profiles/: rocprofv3 summaries of
-`bench.py --serialize-streams`, which agree with these durations, and of the default command).
+(MI355X_MICROARCH.md).  That step runs with the production streams (student, online teacher, auxiliary, weight
+gradients) folded onto one, so that a launch's duration is the kernel's own and not its neighbours' share of the CUs,
+under the tile plan the production schedule uses (`roofline.frac`); one more such step AFTER the timed region runs the
+plan for launches that have the chip to themselves (pair split, full-chip weight-gradient splits:
+`roofline.frac_alone_plan`).  The other
+steps of the timed region run the production schedule (profiles/: rocprofv3 summaries of `bench.py
+--serialize-streams`, which agree with these durations, and of the default command).
+other_configs: after the timed region and outside `value`, one short run each of BASELINE.json configs 3-5 (CycleGAN,
+SAGAN, SRGAN at their reference widths, synthetic batches, 10 warm-up + 30 timed iterations).
 cpu_baseline: the oracle (CPU restatement pinned to the reference) timed on this host's cores on a
 bounded sample (N=1, same architecture, 1 warm-up + 16 timed iterations, about 10 s), rank 0 at --gpus 1 only.
 """
@@ -84,12 +89,12 @@ def synthetic(batch, rank, device, size=256):
     return pair(1234 + rank), pair(4321 + rank)
 
 
-def serialize_streams(model, engine, flag):
+def serialize_streams(model, engine, flag, plan=None):
     """the production schedule runs four HIP streams (student, online teacher, auxiliary, weight gradients): kernels of
     different streams share the CUs, so a launch's wall duration there includes its neighbours'.  The roofline block wants
-    the kernel's own duration: the profiled step runs with everything on one stream -- and with the tile plan the library
-    uses when a launch has the chip to itself (models/_streams.py set_stream_schedule)."""
-    model.set_stream_schedule(not flag)
+    the kernel's own duration: the profiled steps run with everything on one stream, under the tile plan named by `plan`
+    (models/_streams.py set_stream_schedule: 'production' or 'alone')."""
+    model.set_stream_schedule(not flag, plan)
 
 
 def one_step(model, train, val):
@@ -193,6 +198,63 @@ def generator_block(tag_stats, batch):
     return out
 
 
+OTHER_ARGV = {
+    'cyclegan': (1, ['--dataroot', 'synthetic', '--model', 'cyclegan', '--ngf', '24', '--ndf', '64', '--teacher_ngf', '64',
+                     '--lambda_content', '0.01', '--lambda_gram', '10']),
+    'sagan': (64, ['--dataroot', 'synthetic', '--model', 'sagan', '--ngf', '48', '--ndf', '64', '--teacher_ngf', '64',
+                   '--crop_size', '64', '--gan_mode', 'hinge']),
+    'srgan': (16, ['--dataroot', 'synthetic', '--model', 'srgan', '--ngf', '24', '--teacher_ngf', '64', '--image_size', '96']),
+}
+
+
+def other_configs(warmup=10, steps=30):
+    """BASELINE.json configs 3-5 on synthetic batches at the reference scripts' widths (distillation + architecture step on):
+    CycleGAN 256x256 batch 1, SAGAN 64x64 batch 64, SRGAN x4 24 -> 96 crops batch 16 (options/options.py:196-203).  Outside
+    `value`; launch-bound today, so launches per step are printed beside the time."""
+    from gcc_amd import ops
+    from gcc_amd.models import get_model_class
+    from gcc_amd.options import options
+    from gcc_amd.train import SyntheticPairs, attach_teacher
+    os.environ.setdefault('GCC_VGG19_RANDOM', '1')       # torchvision's VGG19 weights cannot be downloaded here
+    out = {}
+    for which, (batch, argv) in OTHER_ARGV.items():
+        try:
+            opt = options.parse(argv + ['--gpu_ids', '0', '--online_distillation', '--darts_discriminator', '--batch_size', str(batch)])
+            opt.isTrain = True
+            if getattr(opt, 'teacher_ndf', None) is None:
+                opt.teacher_ndf = opt.ndf
+            cls = get_model_class(opt)
+            model = cls(opt)
+            attach_teacher(model, opt, cls)
+            model.model_train()
+            data = list(SyntheticPairs(opt, 4, 7))
+
+            def step(i):
+                model.set_input(data[i % 4])
+                model.optimize_parameters()
+                model.set_input(data[(i + 1) % 4])
+                model.clipping_mask_alpha()
+                model.optimizer_netD_arch()
+            for i in range(warmup):
+                step(i)
+            torch.cuda.synchronize()
+            ops.lib().gcc_launch_count(1)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(i)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            launches = ops.lib().gcc_launch_count(1) / steps
+            out[which] = {'batch': batch, 'ms_per_step': round(ms, 3), 'images_per_s': round(batch / ms * 1e3, 1),
+                          'launches_per_step': round(launches)}
+            del model, data
+            torch.cuda.empty_cache()
+        except Exception as e:      # the headline line must not be lost to a side measurement
+            out[which] = {'error': '%s: %s' % (type(e).__name__, e)}
+        log('other_configs %s: %s' % (which, out[which]))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -201,6 +263,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true')
     ap.add_argument('--serialize-streams', action='store_true',
                     help='run every step on one HIP stream (as the profiled steps do): for rocprofv3 runs whose per-kernel '
                          'average must be the kernel\'s own duration')
@@ -231,38 +294,69 @@ def main():
         torch.distributed.barrier()
     from gcc_amd import engine
     n_prof = 0 if args.no_roofline else min(args.steps, 1)
-    if n_prof:
-        ops.PROFILE.start(steps=n_prof)   # HIP events bracket the igemm launches of the first timed step (195 launches)
     if args.serialize_streams:
         serialize_streams(model, engine, True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    roofs = []
+    launches_per_step = None
     for i in range(args.steps):
-        if n_prof and i == 0:
-            serialize_streams(model, engine, True)      # profiled steps: one stream, a launch's duration is its own
-        if n_prof and i == n_prof:
+        if i < n_prof:
+            # profiled step: one stream, a launch's duration is its own; the tile plan is the production schedule's
+            torch.cuda.synchronize()
+            serialize_streams(model, engine, True, 'production')
+            ops.PROFILE.start(steps=1)          # HIP events bracket the MFMA-kernel launches of this step
+        elif i == n_prof and n_prof:
             torch.cuda.synchronize()
             serialize_streams(model, engine, args.serialize_streams)
+        if i == n_prof:
+            ops.lib().gcc_launch_count(1)
         one_step(model, train, val)
-        ops.PROFILE.step_done()
+        if i == n_prof:
+            launches_per_step = int(ops.lib().gcc_launch_count(0))
+        if i < n_prof:
+            ops.PROFILE.step_done()
+            r = ops.PROFILE.stop()
+            if i == 0 and r is not None:
+                r['generator'] = generator_block(ops.PROFILE.tag_stats, args.batch)
+            roofs.append(r)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     log('timed region: %.3f s (%.1f ms/step)' % (dt, 1000 * dt / args.steps))
+    if n_prof:
+        # after the timed region: one more single-stream step under the plan for launches that have the chip to themselves
+        serialize_streams(model, engine, True, 'alone')
+        one_step(model, train, val)                  # the split plan changes workspace sizes: one untimed step first
+        ops.PROFILE.start(steps=1)
+        one_step(model, train, val)
+        ops.PROFILE.step_done()
+        roofs.append(ops.PROFILE.stop())
+        serialize_streams(model, engine, args.serialize_streams)
     roof = None
-    if not args.no_roofline:
-        roof = ops.PROFILE.stop()
-        if roof is not None:
-            roof['generator'] = generator_block(ops.PROFILE.tag_stats, args.batch)
-            # HBM bytes per igemm launch from the PMC counters: collected in their own rocprofv3 passes (--pmc FETCH_SIZE,
-            # --pmc WRITE_SIZE; scratch/pmc_traffic.py applies the gfx950 corrections) and committed under profiles/
-            import glob
-            files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_igemm_hbm_traffic.json')))
-            if files:
-                with open(files[-1]) as fh:
-                    roof['traffic'] = round(json.load(fh)['hbm_bytes_per_launch_corrected'])
-                roof['traffic_source'] = 'profiles/' + os.path.basename(files[-1]) + ' (bytes per launch, rocprofv3 PMC passes)'
+    if roofs and roofs[0] is not None:
+        roof = roofs[0]
+        roof['plan'] = 'production tile plan (no pair split, half-chip weight-gradient splits), one stream'
+        if len(roofs) > 1 and roofs[1] is not None:
+            alone = roofs[1]
+            roof['frac_alone_plan'] = alone['frac']
+            roof['achieved_alone_plan'] = alone['achieved']
+            roof['alone_plan'] = {'plan': 'pair split of half-chip 256x256 launches, full-chip weight-gradient splits, one stream',
+                                  'per_kernel': alone['per_kernel'], 'conv_roofline_frac': alone.get('conv_roofline', {}).get('frac')}
+        roof['steps_bracketed'] = 1
+        # HBM bytes per launch of the igemm family from the PMC counters: collected in their own rocprofv3 passes (--pmc
+        # FETCH_SIZE, --pmc WRITE_SIZE; scratch/pmc_traffic.py applies the gfx950 corrections) and committed under profiles/
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_igemm_hbm_traffic.json')))
+        if files:
+            with open(files[-1]) as fh:
+                tj = json.load(fh)
+            roof['traffic'] = round(tj['hbm_bytes_per_launch_corrected'])
+            roof['traffic_source'] = 'profiles/%s (bytes per launch, rocprofv3 PMC passes of tree %s)' % (
+                os.path.basename(files[-1]), tj.get('git_head', 'of round 2'))
+            if 'per_family' in tj:
+                roof['traffic_per_family'] = tj['per_family']
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -281,10 +375,12 @@ def main():
                                'optimizer_netD_arch), student ngf32 / masked PatchGAN ndf128, teacher ngf64 / ndf128, '
                                'filter_cfgs=None (no pretrained checkpoint to prune)',
                    'batch_per_gpu': args.batch, 'global_batch': world * args.batch, 'image': '256x256',
-                   'parallelism': 'dp%d' % world},
+                   'parallelism': 'dp%d' % world,
+                   'dropout': 'on (counter RNG; the oracle / golden iterations run --no_dropout)'},
         'step_tflops': round(FLOP_PER_IMG * args.batch * args.steps / dt / 1e12, 2),
         'step_mfma_frac': round(FLOP_PER_IMG * args.batch * args.steps / dt / PEAK_BF16, 4),
         'loss_check': {k: round(v, 4) for k, v in losses.items()},
+        'launches_per_step': launches_per_step,
     }
     if roof is not None:
         if 'conv_roofline' in roof:       # north_star: throughput as a fraction of the conv roofline
@@ -297,6 +393,10 @@ def main():
         out['cpu_baseline'] = cpu_baseline()
         n4 = cpu_baseline(iters=4, batch=4, budget=20.0)          # SURVEY 8(d) / BASELINE.md: N=1 and N=4
         out['cpu_baseline']['n4'] = {k: n4[k] for k in ('value', 'unit', 'sample')}
+    if world == 1 and not args.no_other_configs:
+        del model
+        torch.cuda.empty_cache()
+        out['other_configs'] = other_configs()
     print(json.dumps(out))
 
 

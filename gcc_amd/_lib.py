@@ -78,6 +78,7 @@ _Z = C.c_size_t
 PROTOTYPES = {
     'gcc_strerror': (C.c_char_p, [_I]),
     'gcc_version': (_I, []),
+    'gcc_launch_count': (C.c_longlong, [_I]),
     'gcc_set_option': (_I, [_I, _I]),
     'gcc_get_option': (_I, [_I]),
     'gcc_conv_set_plan': (_I, [_I, _I, _I]),

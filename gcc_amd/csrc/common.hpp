@@ -115,6 +115,14 @@ __device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
 
 // process-wide tuning options (include/gcc_hip.h: gcc_set_option); defined in misc.hip
 int gcc_opt(int id);
+// every kernel launch of the library is counted (gcc_launch_count: bench.py reports launches per step)
+void gcc_count_launch();
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                         \
+    do {                                                                                                          \
+        gcc_count_launch();                                                                                       \
+        hipLaunchKernelGGLInternal((kernelName), (numBlocks), (numThreads), (memPerBlock), (streamId), __VA_ARGS__); \
+    } while (0)
 
 __host__ __device__ static inline int ceil8(int v) { return (v + 7) & ~7; }
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

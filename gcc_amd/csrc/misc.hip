@@ -438,6 +438,11 @@ int gcc_opt(int id) {
     std::call_once(g_opt_once, opt_init);
     return g_opt[id].load(std::memory_order_relaxed);
 }
+namespace { std::atomic<long long> g_launches{0}; }
+void gcc_count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
+extern "C" long long gcc_launch_count(int reset) {
+    return reset ? g_launches.exchange(0, std::memory_order_relaxed) : g_launches.load(std::memory_order_relaxed);
+}
 extern "C" int gcc_get_option(int id) {
     if (id < 0 || id >= GCC_OPT_COUNT_) return GCC_ERR_BAD_ARG;
     return gcc_opt(id);

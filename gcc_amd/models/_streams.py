@@ -14,19 +14,24 @@ from .. import ops
 
 
 class TeacherStreamMixin:
-    def set_stream_schedule(self, concurrent):
+    def set_stream_schedule(self, concurrent, plan=None):
         """concurrent=True: the production schedule (student, online teacher, auxiliary and weight-gradient streams).
-        False: every launch on one stream -- and the library's tile plan for launches that have the chip to themselves
-        (GCC_OPT_IGEMM_PAIR: half-chip 256x256-tile launches split their K loop over two workgroups per tile)."""
+        False: every launch on one stream.  plan: the library's tile plan -- 'production' (what the multi-stream schedule runs:
+        no pair split, half-chip weight-gradient splits) or 'alone' (for launches that have the chip to themselves:
+        GCC_OPT_IGEMM_PAIR, full-chip weight-gradient splits); default: 'production' with concurrent streams, 'alone' without.
+        bench.py times one single-stream step under each plan (a launch's duration is then the kernel's own)."""
         from .. import _lib, engine
         self.serialize_streams = not concurrent
         if getattr(self, 'teacher_model', None) is not None:
             self.teacher_model.serialize_streams = not concurrent
         engine.OVERLAP_WGRAD = bool(concurrent) and os.environ.get('GCC_OVERLAP_WGRAD', '1') != '0'
-        # GCC_PAIR_CONCURRENT=1: keep the pair split in the multi-stream schedule too (A/B hook)
-        pair_conc = 1 if os.environ.get('GCC_PAIR_CONCURRENT', '0') == '1' else 0
-        ops.lib().gcc_set_option(_lib.OPT_IGEMM_PAIR, pair_conc if concurrent else 1)
-        self._apply_wgrad_plan(concurrent)
+        if plan is None:
+            plan = 'production' if concurrent else 'alone'
+        assert plan in ('production', 'alone')
+        # GCC_PAIR_CONCURRENT=1: keep the pair split in the production plan too (A/B hook)
+        pair_prod = 1 if os.environ.get('GCC_PAIR_CONCURRENT', '0') == '1' else 0
+        ops.lib().gcc_set_option(_lib.OPT_IGEMM_PAIR, pair_prod if plan == 'production' else 1)
+        self._apply_wgrad_plan(plan == 'production')
 
     @staticmethod
     def _apply_wgrad_plan(concurrent):

@@ -62,6 +62,7 @@ class _Profile:
         torch.cuda.synchronize()
         agg, shapes = {}, {}
         tags = {}
+        alg_bytes = {}
         roof_s, roof_meas_s, roof_n = 0.0, 0.0, 0
         for kind, flops, e0, e1, shape, tag in self.records:
             sec = e0.elapsed_time(e1) * 1e-3
@@ -72,6 +73,7 @@ class _Profile:
                 small, big = n_ * ho * wo * co, n_ * (ho * st_) * (wo * st_) * ci      # conv output side / input side
                 wts = co * ci * k_ * k_
                 nbytes = 2.0 * (small + big) + (4.0 if op == 'wgrad' else 2.0) * wts
+                alg_bytes[kind] = alg_bytes.get(kind, 0.0) + nbytes
                 roof_s += max(flops / peak, nbytes / hbm)
                 roof_meas_s += sec
                 roof_n += 1
@@ -113,7 +115,9 @@ class _Profile:
                        'unit': 'TFLOP/s', 'frac': round(fl / sec / peak, 4), 'traffic': None, 'launches': n,
                        'steps_bracketed': getattr(self, 'steps_seen', None),
                        'avg_launch_us': round(1e6 * sec / n, 2),
-                       'algorithmic_gflop_per_launch': round(fl / n / 1e9, 3)}
+                       'algorithmic_gflop_per_launch': round(fl / n / 1e9, 3),
+                       # every operand once (bf16 input + output + weights of the launch): what `traffic` is to be read against
+                       'algorithmic_bytes_per_launch': round(alg_bytes.get(kind, 0.0) / n)}
         out['per_kernel'] = per
         if roof_n:
             out['conv_roofline'] = {'layers': roof_n, 'bound_ms': round(roof_s * 1e3, 3), 'measured_ms': round(roof_meas_s * 1e3, 3),

@@ -43,6 +43,8 @@ enum { GCC_ACT_NONE = 0, GCC_ACT_LRELU = 1, GCC_ACT_RELU = 2, GCC_ACT_TANH = 3 }
 
 const char* gcc_strerror(int code);
 int gcc_version(void);
+/* kernel launches the library has made in this process so far (reset != 0: return the count and start again from zero) */
+long long gcc_launch_count(int reset);
 
 /* ---------------------------------------------------------------------------------------------
  * Tuning options: which tile shape / kernel family a geometry is routed to.  Every option only selects

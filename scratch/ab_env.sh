@@ -8,7 +8,7 @@ for rep in 1 2; do
   for cfg in "$@"; do
     i=$((i+1))
     [ "$cfg" = "-" ] && envs="" || envs="$cfg"
-    env $envs GCC_PROFILE_SHAPES=1 timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline > $out/v${i}_r$rep.json 2> $out/v${i}_r$rep.txt
+    env $envs GCC_PROFILE_SHAPES=1 timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs > $out/v${i}_r$rep.json 2> $out/v${i}_r$rep.txt
     python - <<PY
 import json
 try:

@@ -16,12 +16,12 @@ tests)
 bench)
   timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench exit $?"; cat $out/bench.json | head -c 3000;;
 prof)
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof_serialized -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --serialize-streams > $GRAFT_REPO_ROOT/$out/prof_serialized.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof_serialized -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --serialize-streams > $GRAFT_REPO_ROOT/$out/prof_serialized.log 2>&1)
   find $out/prof_serialized -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $out/kernel_stats_serialized.csv
   find $out/prof_serialized -name '*kernel_trace.csv' -delete
   head -25 $out/kernel_stats_serialized.csv;;
 profdefault)
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof_default -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $GRAFT_REPO_ROOT/$out/prof_default.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof_default -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-roofline > $GRAFT_REPO_ROOT/$out/prof_default.log 2>&1)
   find $out/prof_default -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $out/kernel_stats_default.csv
   f=$(find $out/prof_default -name '*kernel_trace.csv' | head -1)
   python scratch/trace_waits.py $f > $out/trace_waits_default.txt 2>&1
@@ -30,7 +30,7 @@ profdefault)
   python scratch/trace_timeline.py $f 22 100 > $out/trace_timeline_default.txt 2>&1
   rm -f $f;;
 shapes)
-  GCC_PROFILE_SHAPES=1 timeout 600 python bench.py --steps 3 --warmup 3 --no-cpu-baseline > $out/shapes.json 2> $out/shapes.txt; grep -c . $out/shapes.txt;;
+  GCC_PROFILE_SHAPES=1 timeout 600 python bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-other-configs > $out/shapes.json 2> $out/shapes.txt; grep -c . $out/shapes.txt;;
 graph)
   timeout 600 python scratch/probe_graph_pix2pix.py > $out/graph_probe.txt 2>&1; tail -8 $out/graph_probe.txt;;
 dp)
@@ -39,12 +39,12 @@ pmc)
   i=0
   for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
-    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --serialize-streams > $GRAFT_REPO_ROOT/$out/pmc$i.log 2>&1)
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-roofline --serialize-streams > $GRAFT_REPO_ROOT/$out/pmc$i.log 2>&1)
     f=$(find $out/pmc$i -name '*counter_collection.csv' | head -1); cp $f $out/pmc${i}_counters.csv 2>/dev/null
     rm -rf $out/pmc$i
   done
   python scratch/pmc_mfma.py $out/pmc_mfma_lds.json $out/pmc1_counters.csv $out/pmc2_counters.csv
-  python scratch/pmc_traffic.py $out/pmc3_counters.csv $out/pmc4_counters.csv $out/igemm_hbm_traffic.json
+  python scratch/pmc_traffic.py $out/pmc3_counters.csv $out/pmc4_counters.csv $out/igemm_hbm_traffic.json "${GCC_GIT_HEAD:-unknown}"
   rm -f $out/pmc*_counters.csv;;
 counters)
   rocprofv3 -L > $out/counters_list.txt 2>&1; grep -c . $out/counters_list.txt;;

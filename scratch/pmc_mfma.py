@@ -15,7 +15,7 @@ from collections import defaultdict
 
 
 def family(name):
-    m = re.search(r'(igemm_kernel<[^>]*>|wgrad_kernel<[^>]*>|thin_fprop_kernel<\d+>|thin_dgrad_k4s2_kernel<\d+>)', name)
+    m = re.search(r'(igemm_halo_kernel<\w+>|igemm_kernel<[^>]*>|wgrad_kernel<[^>]*>|thin_fprop_kernel<\d+>|thin_dgrad_k4s2_kernel<\d+>)', name)
     if m:
         return m.group(1)
     m = re.search(r'([A-Za-z_0-9]+)(<[^(]*)?\(', name)
