@@ -109,6 +109,23 @@ def test_gcc_two_iterations_vs_reference_golden(golden_dir):
     init = _updates.snapshot(nets)
     agree = _updates.MovementAgreement()
     worst = {}
+    # the same two iterations on the oracle with bf16 storage emulated at the points the HIP path rounds: the second bar a
+    # logged scalar may meet (the bar the model tests of the other families use), instead of a looser tolerance
+    from oracle import gcc_oracle as O
+    from tests.test_oracle_golden import build_gcc_oracle
+    emu = []
+    O.EMULATE_BF16 = True
+    try:
+        om, ot, _ = build_gcc_oracle(z)
+        for it in range(2):
+            om.set_input(torch.from_numpy(z['it%d.A' % it]), torch.from_numpy(z['it%d.B' % it]))
+            om.optimize_parameters()
+            om.set_input(torch.from_numpy(z['it%d.vA' % it]), torch.from_numpy(z['it%d.vB' % it]))
+            om.clipping_mask_alpha()
+            om.optimizer_netD_arch()
+            emu.append((dict(om.losses), dict(ot.losses)))
+    finally:
+        O.EMULATE_BF16 = False
     for it in range(2):
         data = {'A': torch.from_numpy(z['it%d.A' % it]), 'B': torch.from_numpy(z['it%d.B' % it]), 'A_paths': ['a'], 'B_paths': ['b']}
         model.set_input(data)
@@ -148,12 +165,14 @@ def test_gcc_two_iterations_vs_reference_golden(golden_dir):
                 ref = float(z[k])
                 got = losses[name] if '.loss.' in k else tl[name]
                 err = abs(got - ref) / max(1.0, abs(ref))
-                print('it%d %s %s: got %.5g ref %.5g' % (it, 'S' if '.loss.' in k else 'T', name, got, ref))
-                # the arch terms are differences of two O(1) hinge means over a 2x1x6x6 PatchGAN map (72 values: one value
-                # crossing the hinge moves a mean by 1.4%); behind the first Adam steps (iteration 1) their realisation depends
-                # on the summation order of the BatchNorm reductions (seen: 3.0% / 4.2% with 1024- / 256-thread reduce blocks)
-                tol = 8e-2 if (it >= 1 and 'arch' in name) else 3e-2
-                assert err <= tol, (it, k, got, ref)
+                e16 = emu[it][0 if '.loss.' in k else 1].get(name)
+                err16 = abs(got - e16) / max(1.0, abs(e16)) if e16 is not None else float('inf')
+                print('it%d %s %s: got %.5g ref %.5g bf16-emulating oracle %s' % (it, 'S' if '.loss.' in k else 'T', name, got, ref,
+                                                                                 '%.5g' % e16 if e16 is not None else '-'))
+                # 3e-2 of the reference's value, or of the bf16-emulating oracle's (the arch terms are differences of two O(1)
+                # hinge means over a 2x1x6x6 PatchGAN map: one of 72 values crossing the hinge moves a mean by 1.4 %, and behind
+                # the first Adam steps which side it falls on is a matter of bf16 storage, not of the arithmetic)
+                assert min(err, err16) <= 3e-2, (it, k, got, ref, e16)
     lr = opt.lr
     for prefix, mod, steps in (('final.sG.', model.netG, 2), ('final.tG.', teacher.netG, 2), ('final.sD.', model.netD, 2),
                                ('final.tD.', teacher.netD, 2)):
@@ -190,8 +209,9 @@ def test_gradients_vs_oracle(golden_dir):
     oracle's autograd gradient for the same weights and inputs -- both the fp32 oracle and the oracle
     with bf16 storage emulated (oracle.EMULATE_BF16), which measures how far bf16 storage alone moves
     each gradient on this tiny, badly conditioned problem (N=2, BatchNorm over as few as 8 samples).
-    Bar per tensor (relative L2): within 6e-2 of the emulated oracle, or no farther from the fp32
-    oracle than 1.5x the measured bf16-storage deviation + 2e-2.  gan_mode lsgan: the hinge loss is
+    Bar per tensor (relative L2): within 6e-2 of the emulated oracle AND no farther from the fp32
+    oracle than 1.5x the measured bf16-storage deviation + 2e-2 (either of the two where bf16 storage
+    alone moves the gradient by 5 % or more).  gan_mode lsgan: the hinge loss is
     piecewise linear, so on a 2x1x6x6 PatchGAN map a single pred value rounding across the hinge
     (seen: 1 of 72) moves the whole gradient by >10% and would only measure that."""
     from tests.test_oracle_golden import build_gcc_oracle
@@ -307,7 +327,10 @@ def _gradient_check(model, teacher, build_oracle, A, B, vA, vB, skip=None, gan_m
             return
         r32, r16, floor = _rel(g, g32[key]), _rel(g, g16[key]), _rel(g16[key], g32[key])
         print('%-5s %-56s vs fp32 %.4f  vs bf16-emulated %.4f  (emulated vs fp32 %.4f)' % (key[0], key[1], r32, r16, floor))
-        if not (r16 <= 6e-2 or r32 <= 1.5 * floor + 2e-2):
+        # well-conditioned tensors (bf16 storage alone moves the gradient by < 5 %) must meet BOTH bars; where storage rounding
+        # alone moves it further, either
+        ok16, ok32 = r16 <= 6e-2, r32 <= 1.5 * floor + 2e-2
+        if not ((ok16 and ok32) if floor < 5e-2 else (ok16 or ok32)):
             bad.append((key, r32, r16, floor))
     for tag, mod in (('tD', teacher.netD), ('tG', teacher.netG), ('sD', model.netD), ('sG', model.netG)):
         sd = mod.state_dict(keep_vars=True)
@@ -392,12 +415,14 @@ FULL_ARGV = ['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gp
              '--arch_lr', '1e-4', '--arch_lr_step']
 
 
-@pytest.mark.parametrize('plan', ['default', 'tile256'])
-def test_full_config_iteration_vs_oracle(plan):
+@pytest.mark.parametrize('plan,batch', [('default', 2), ('tile256', 2), ('default', 16)])
+def test_full_config_iteration_vs_oracle(plan, batch):
     """BASELINE.json configs[1] at its real widths (student ngf 32 / masked PatchGAN ndf 128, teacher ngf 64 / ndf 128, 8 downs,
-    256 x 256; N = 2 so that the CPU oracle finishes in seconds): one whole GCC iteration + arch step of the HIP path against
-    the oracle on the same recipe weights.  'tile256' forces every eligible conv onto the 256-pixel igemm tiles the N = 16
-    bench grid selects by itself.  Tolerances as everywhere: image max-abs 2e-2 / mean-abs 3e-3, loss scalars 3e-2."""
+    256 x 256): one whole GCC iteration + arch step of the HIP path against the oracle on the same recipe weights.  N = 2 keeps
+    the CPU oracle to seconds; 'tile256' forces every eligible conv onto the 256-pixel igemm tiles the N = 16 bench grid selects
+    by itself; ('default', 16) IS the bench's batch -- the exact launch set bench.py times (the LDS-resident-neighbourhood
+    kernels of conv_halo.hip included, which need the N = 16 grids), --no_dropout.  Tolerances as everywhere: image max-abs
+    2e-2 / mean-abs 3e-3, loss scalars 3e-2."""
     import copy
     from gcc_amd import _lib
     from oracle import gcc_oracle as O
@@ -423,11 +448,11 @@ def test_full_config_iteration_vs_oracle(plan):
         om = O.Pix2PixOracle(oopt, copy.deepcopy(sds['sG']), copy.deepcopy(sds['sD']), [t.clone() for t in Ts], masked=True,
                              teacher=ot)
         g = torch.Generator().manual_seed(77)
-        A, B, vA, vB = (torch.rand(2, 3, 256, 256, generator=g) * 2 - 1 for _ in range(4))
-        model.set_input({'A': A, 'B': B, 'A_paths': ['a'] * 2, 'B_paths': ['b'] * 2})
+        A, B, vA, vB = (torch.rand(batch, 3, 256, 256, generator=g) * 2 - 1 for _ in range(4))
+        model.set_input({'A': A, 'B': B, 'A_paths': ['a'] * batch, 'B_paths': ['b'] * batch})
         model.optimize_parameters()
         fake, tfake = model.fake_B.cpu(), teacher.fake_B.cpu()
-        model.set_input({'A': vA, 'B': vB, 'A_paths': ['a'] * 2, 'B_paths': ['b'] * 2})
+        model.set_input({'A': vA, 'B': vB, 'A_paths': ['a'] * batch, 'B_paths': ['b'] * batch})
         model.clipping_mask_alpha()
         model.optimizer_netD_arch()
         got, tgot = model.get_current_losses(), teacher.get_current_losses()

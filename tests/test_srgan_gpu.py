@@ -469,18 +469,24 @@ FULL_SRGAN_ARGV = ['--dataroot', './database/sr/', '--model', 'srgan', '--gpu_id
                    '--image_size', '96', '--batch_size', '16']
 
 
-def test_srgan_full_width_iteration_vs_oracle():
+@pytest.mark.parametrize('hr_size,N', [(96, 16), (384, 2)])
+def test_srgan_full_width_iteration_vs_oracle(hr_size, N):
     """BASELINE.json configs[4] at its real widths (SRResNet ngf 24, teacher 64, D ndf 64, the real VGG19[:36] widths with
-    conditioned random weights, 24 x 24 -> 96 x 96, batch 16): one iteration + arch step of the HIP path against the oracle on
-    the same weights -- every logged loss (content = MSE of the super-resolved image, perceptual = VGG feature MSE, the GAN, distillation
-    and arch terms) within 3e-2 of the fp32 or the bf16-emulating oracle."""
+    conditioned random weights): one iteration + arch step of the HIP path against the oracle on the same weights -- every
+    logged loss (content = MSE of the super-resolved image, perceptual = VGG feature MSE, the GAN, distillation and arch terms)
+    within 3e-2 of the fp32 or the bf16-emulating oracle.  (96, 16): the reference's training crop, 24 x 24 -> 96 x 96, batch 16
+    (options/options.py:196-203); (384, 2): BASELINE.json's literal size, x4 96 -> 384 (models/SRGAN.py:139-245), N = 2 so
+    that the CPU oracle finishes in seconds."""
     from collections import OrderedDict
     from gcc_amd.options import options
     from gcc_amd.models import get_model_class
     from oracle import gcc_oracle as O
     from tests.golden.recipe import recipe_state_dict, recipe_transform, srgan_condition
     os.environ['GCC_VGG19_RANDOM'] = '1'
-    opt = options.parse(FULL_SRGAN_ARGV)
+    argv = list(FULL_SRGAN_ARGV)
+    argv[argv.index('--image_size') + 1] = str(hr_size)
+    argv[argv.index('--batch_size') + 1] = str(N)
+    opt = options.parse(argv)
     opt.isTrain = True
     opt.teacher_ndf = 64
     cls = get_model_class(opt)
@@ -509,11 +515,10 @@ def test_srgan_full_width_iteration_vs_oracle():
         m.V.repack()
     model.model_train()
     g = torch.Generator().manual_seed(95)
-    N = 16
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
-    lr, vlr = ((torch.rand(N, 3, 24, 24, generator=g) - mean) / std for _ in range(2))
-    hr, vhr = (torch.rand(N, 3, 96, 96, generator=g) * 2 - 1 for _ in range(2))
+    lr, vlr = ((torch.rand(N, 3, hr_size // 4, hr_size // 4, generator=g) - mean) / std for _ in range(2))
+    hr, vhr = (torch.rand(N, 3, hr_size, hr_size, generator=g) * 2 - 1 for _ in range(2))
     model.set_input({'lr': lr, 'hr': hr, 'lr_names': ['a'] * N, 'hr_names': ['b'] * N})
     model.optimize_parameters()
     model.set_input({'lr': vlr, 'hr': vhr, 'lr_names': ['a'] * N, 'hr_names': ['b'] * N})
