@@ -142,34 +142,49 @@ def cpu_baseline(iters=16, batch=1, budget=30.0):
 
 def allreduce_table(model, device, reps=5):
     """after the timed region: every gradient bucket of the step all-reduced alone (blocking, `reps` times, max over ranks)
-    -- what the exchange costs when nothing overlaps it, so that a scaling curve can be read against it"""
+    -- what the exchange costs when nothing overlaps it, so that a scaling curve can be read against it -- through both
+    routes: torch.distributed (ProcessGroupNCCL's stream) and the C ABI's communicator (gcc_comm_allreduce_sum_f32 on the
+    caller's stream; RCCL backends only)."""
     import torch.distributed as dist
-    rows, total_ms, total_mb = [], 0.0, 0.0
+    from gcc_amd import dist as gdist
     T = model.teacher_model
+    groups = []
     for name, opt_ in (('teacher_D', T.optimizer_D), ('teacher_G', T.optimizer_G), ('student_D', model.optimizer_D),
                        ('student_G', model.optimizer_G), ('alpha', model.optimizer_arch)):
         red = getattr(opt_, 'reducer', None)
         spans = [(b, e) for b, e, _ in red.buckets] if red is not None else [(0, opt_.flat.grads.numel())]
-        for i, (b, e) in enumerate(spans):
+        groups += [('%s[%d]' % (name, i), opt_, b, e) for i, (b, e) in enumerate(spans)]
+
+    def table(reduce_fn):
+        rows, total_ms, total_mb = [], 0.0, 0.0
+        for label, opt_, b, e in groups:
             buf = opt_.flat.grads[b:e].clone()
-            dist.all_reduce(buf)
+            reduce_fn(buf)
             torch.cuda.synchronize()
             dist.barrier()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                dist.all_reduce(buf)
+                reduce_fn(buf)
             e1.record()
             torch.cuda.synchronize()
             t = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ms, mb = float(t.item()), (e - b) * 4 / 1e6
-            rows.append({'bucket': '%s[%d]' % (name, i), 'MB': round(mb, 2), 'ms': round(ms, 3),
-                         'algbw_GBps': round(mb / ms, 1) if ms > 0 else None})
+            rows.append({'bucket': label, 'MB': round(mb, 2), 'ms': round(ms, 3), 'algbw_GBps': round(mb / ms, 1) if ms > 0 else None})
             total_ms += ms
             total_mb += mb
-    return {'buckets': rows, 'total_MB_fp32': round(total_mb, 1), 'total_ms_unoverlapped': round(total_ms, 3),
-            'note': 'each bucket alone after the timed region; in the step they overlap the backward pass (dist.GradReducer)'}
+        return {'buckets': rows, 'total_MB_fp32': round(total_mb, 1), 'total_ms_unoverlapped': round(total_ms, 3)}
+    out = {'route': gdist.comm_route(), 'bucketed': getattr(model.optimizer_D, 'reducer', None) is not None,
+           'note': 'each bucket alone after the timed region; in the step they overlap the backward pass (dist.GradReducer)',
+           'torch': table(lambda buf: dist.all_reduce(buf))}
+    if dist.get_backend() == 'nccl':
+        try:
+            comm = gdist.native_comm()
+            out['native'] = table(lambda buf: comm.all_reduce_sum_(buf))
+        except Exception as e:
+            out['native'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    return out
 
 
 def generator_block(tag_stats, batch):

@@ -83,6 +83,88 @@ def all_reduce_grads(optimizer, async_op=False):
     return None
 
 
+def comm_route():
+    """GCC_DP_COMM=native: the bucket all-reduces are enqueued through the C ABI's own communicator (gcc_comm_allreduce_sum_f32,
+    csrc/comm.hip: RCCL on the CALLER's stream -- the weight-gradient side stream -- so the step stays on its four hardware
+    queues); default 'torch': torch.distributed's all_reduce(async_op=True), which runs on ProcessGroupNCCL's own stream."""
+    return 'native' if os.environ.get('GCC_DP_COMM', 'torch') == 'native' else 'torch'
+
+
+_native = None
+
+
+def native_comm():
+    """one gcc_comm communicator per process over the ranks of the process group (or of one rank without a group): the
+    RCCL id is made by rank 0 and handed round through the group"""
+    global _native
+    if _native is None:
+        if is_dist() and world_size() > 1:
+            box = [NativeComm.unique_id() if rank() == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            _native = NativeComm(rank(), world_size(), box[0])
+        else:
+            _native = NativeComm(0, 1, NativeComm.unique_id())
+    return _native
+
+
+_selfcheck = {}
+
+
+def bucket_selfcheck(device):
+    """Does a collective issued the way GradReducer issues it -- under ops.on_stream(side stream), right behind the kernels that
+    produce its input -- wait for those kernels?  The ordering rests on the communication library picking up the stream that
+    ops.on_stream makes current (a slip there leaves replicas bit-identical and wrong).  Checked once per process
+    and route on the real backend: a side stream runs ~ms of kernels and then writes rank + 1 into a zeroed buffer, the
+    all-reduce follows at once; every element must come back as world * (world + 1) / 2.  False (with a warning) makes the
+    model classes fall back to one flat all-reduce per optimizer on the main stream."""
+    route = comm_route()
+    key = (str(device), route)
+    if key in _selfcheck:
+        return _selfcheck[key]
+    ok = True
+    if is_dist() and torch.cuda.is_available():
+        from . import ops
+        w = world_size()
+        buf = torch.zeros(1 << 20, dtype=torch.float32, device=device)
+        junk = torch.empty(64 << 20, dtype=torch.float32, device=device)
+        torch.cuda.synchronize(device)
+        side = ops.SideStream.get(device).stream
+        with ops.on_stream(side):
+            for i in range(8):
+                junk.fill_(float(i))                      # ~2 ms of work in front of the write the collective must see
+            buf.fill_(float(rank() + 1))
+            if route == 'native':
+                native_comm().all_reduce_sum_(buf, stream=side.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                torch.cuda.current_stream(device).wait_event(ev)
+            else:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True).wait()
+        ops.current_stream().wait_stream(side)
+        torch.cuda.synchronize(device)
+        want = w * (w + 1) / 2.0
+        flag = torch.tensor([1.0 if bool((buf == want).all()) else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item() == 1.0)
+        if not ok and rank() == 0:
+            import sys
+            print('[gcc_amd.dist] bucketed all-reduce self-check FAILED on route %r: falling back to one flat all-reduce per '
+                  'optimizer' % route, file=sys.stderr, flush=True)
+    _selfcheck[key] = ok
+    return ok
+
+
+def buckets_enabled(device):
+    """bucketed, overlapped gradient exchange (GradReducer) for this process?  GCC_DP_BUCKETS=0 turns it off; otherwise it
+    is on when the process group has more than one rank (GCC_DP_FORCE_BUCKETS=1: also with one rank -- the one-GPU test box)
+    and the self-check above passes."""
+    if os.environ.get('GCC_DP_BUCKETS', '1') == '0' or not is_dist():
+        return False
+    if world_size() <= 1 and os.environ.get('GCC_DP_FORCE_BUCKETS') != '1':
+        return False
+    return bucket_selfcheck(device)
+
+
 class GradReducer:
     """Bucketed gradient all-reduce of one optimizer, overlapped with the backward pass that produces the gradients.
 
@@ -109,6 +191,24 @@ class GradReducer:
         self.handles = []
         self.launched = [False] * len(self.buckets)
         self.enabled = True
+        self.route = comm_route()
+        self.native = native_comm() if self.route == 'native' else None
+
+    def _reduce(self, b, e, stream=None):
+        """enqueue the all-reduce of grads[b:e]: behind everything enqueued so far on `stream` (a torch.cuda.Stream; default:
+        the current stream).  torch route: a work handle; native route: an event recorded behind the collective."""
+        from . import ops
+        if self.route == 'native':
+            st = stream if stream is not None else ops.current_stream()
+            self.native.all_reduce_sum_(self.flat.grads[b:e], stream=st.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self.handles.append(ev)
+        elif stream is not None:
+            with ops.on_stream(stream):
+                self.handles.append(dist.all_reduce(self.flat.grads[b:e], op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self.handles.append(dist.all_reduce(self.flat.grads[b:e], op=dist.ReduceOp.SUM, async_op=True))
 
     def begin(self):
         """a new backward pass starts writing these gradients"""
@@ -125,12 +225,7 @@ class GradReducer:
             return
         self.opt.set_grad_scale(1.0 / world_size())
         self.launched[k] = True
-        if stream is not None:
-            from . import ops
-            with ops.on_stream(stream):
-                self.handles.append(dist.all_reduce(self.flat.grads[b:e], op=dist.ReduceOp.SUM, async_op=True))
-        else:
-            self.handles.append(dist.all_reduce(self.flat.grads[b:e], op=dist.ReduceOp.SUM, async_op=True))
+        self._reduce(b, e, stream)
 
     def finish(self):
         if not is_dist():
@@ -139,9 +234,15 @@ class GradReducer:
         for k, (b, e, _) in enumerate(self.buckets):
             if not self.launched[k]:
                 self.launched[k] = True
-                self.handles.append(dist.all_reduce(self.flat.grads[b:e], op=dist.ReduceOp.SUM, async_op=True))
-        for h in self.handles:
-            h.wait()
+                self._reduce(b, e)
+        if self.route == 'native':
+            from . import ops
+            cur = ops.current_stream()
+            for ev in self.handles:
+                cur.wait_event(ev)
+        else:
+            for h in self.handles:
+                h.wait()
         self.handles = []
 
     def wait(self):                 # the handle protocol of all_reduce_grads(async_op=True)
@@ -179,9 +280,15 @@ class NativeComm:
         return flat
 
     def close(self):
-        if self._h:
+        if getattr(self, '_h', None):
             self._lib.gcc_comm_destroy(self._h)
             self._h = None
+
+    def __del__(self):          # a dropped handle must not leak the communicator
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def all_reduce_sum(t):

@@ -373,7 +373,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             t_split = [0, 0, self.G.width[3], self.G.width[1]]
         self.D = engine.PatchGANEngine(self.netD, bool(opt.darts_discriminator), opt.threshold, dev)
         self.D.mask_cache = True          # gate masks are recomputed only after alpha changed (arch step, clip, reload)
-        if gdist.world_size() > 1 and os.environ.get('GCC_DP_BUCKETS', '1') != '0':
+        if gdist.buckets_enabled(dev):
             mb = int(os.environ.get('GCC_DP_BUCKET_MB', '32'))
             if g_layout is not None:
                 self.optimizer_G.reducer = self.G.reducer = gdist.GradReducer(self.optimizer_G, mb << 20)

@@ -167,12 +167,38 @@ def set_device_index(idx):
     _dev_index = idx
 
 
+# torch's private fast paths for "which stream is current" / "make this stream current" (torch 2.10: _cuda_getCurrentRawStream,
+# _cuda_setStream), each behind a guard: if a torch upgrade removes or re-signs one, the public API takes over (torch.cuda.
+# current_stream().cuda_stream, torch.cuda.set_stream) -- slower on the host (~8 / ~20 us per call), never differently ordered.
+# tests/test_kernels_gpu.py::test_stream_helpers_order_work asserts the ordering through whichever path is active.
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_SET_STREAM = getattr(torch._C, '_cuda_setStream', None)
+if os.environ.get('GCC_PUBLIC_STREAM_API') == '1':          # test hook: exercise the fallbacks
+    _RAW_STREAM = _SET_STREAM = None
+
+
+def _set_current(s):
+    global _SET_STREAM
+    if _SET_STREAM is not None:
+        try:
+            _SET_STREAM(stream_id=s.stream_id, device_index=s.device_index, device_type=s.device_type)
+            return
+        except (TypeError, AttributeError):
+            _SET_STREAM = None
+    torch.cuda.set_stream(s)
+
+
 def stream():
     """raw hipStream_t of the current stream (the direct C call: this runs once per launch on the host's hot path)"""
-    global _dev_index
+    global _dev_index, _RAW_STREAM
     if _dev_index is None:
         _dev_index = torch.cuda.current_device()
-    return torch._C._cuda_getCurrentRawStream(_dev_index)
+    if _RAW_STREAM is not None:
+        try:
+            return _RAW_STREAM(_dev_index)
+        except (TypeError, AttributeError):
+            _RAW_STREAM = None
+    return torch.cuda.current_stream(_dev_index).cuda_stream
 
 
 _stream_objs = {}
@@ -201,13 +227,12 @@ class on_stream:
         s = self.s
         if s:
             self.prev = current_stream()
-            torch._C._cuda_setStream(stream_id=s.stream_id, device_index=s.device_index, device_type=s.device_type)
+            _set_current(s)
         return s
 
     def __exit__(self, *exc):
         if self.s:
-            p = self.prev
-            torch._C._cuda_setStream(stream_id=p.stream_id, device_index=p.device_index, device_type=p.device_type)
+            _set_current(self.prev)
         return False
 
 

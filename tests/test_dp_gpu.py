@@ -38,10 +38,11 @@ def _collect(q, procs, n, timeout=1200):
     return out
 
 
-def _worker(rank, world, port, q, backend='gloo', iters=1):
+def _worker(rank, world, port, q, backend='gloo', iters=1, buckets='1'):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank) if backend == 'nccl' else '0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+                      LOCAL_RANK=str(rank) if backend == 'nccl' else '0', HSA_ENABLE_IPC_MODE_LEGACY='0',
+                      GCC_DP_BUCKETS=buckets)
     import torch.distributed as dist
     from gcc_amd import dist as gdist
     gdist.init_from_env(backend=backend)
@@ -61,7 +62,7 @@ def _worker(rank, world, port, q, backend='gloo', iters=1):
     model.finish_G_update()
     teacher.finish_G_update()
     torch.cuda.synchronize()
-    out = {'rank': rank, 'w0': sd0.numpy()}
+    out = {'rank': rank, 'w0': sd0.numpy(), 'bucketed': model.optimizer_D.reducer is not None}
     for name, mod in (('sG', model.netG), ('sD', model.netD), ('tG', teacher.netG), ('tD', teacher.netD)):
         out[name] = torch.cat([v.detach().float().cpu().reshape(-1) for k, v in mod.state_dict().items()
                                if k.endswith('weight') or k.endswith('bias') or k.endswith('alpha')]).numpy()
@@ -74,25 +75,38 @@ def _worker(rank, world, port, q, backend='gloo', iters=1):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(1500)       # the spawned ranks import torch afresh: minutes on a cold box, seconds otherwise
-def test_two_ranks_stay_identical():
+def _two_ranks(buckets):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 'gloo', 1, buckets)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(_collect(q, procs, 2), key=lambda d: d['rank'])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    a, b = res
+    return res
+
+
+@pytest.mark.timeout(1500)       # the spawned ranks import torch afresh: minutes on a cold box, seconds otherwise
+def test_two_ranks_stay_identical():
     import numpy as np
+    a, b = _two_ranks('1')
+    assert a['bucketed'] and b['bucketed'], 'the bucketed reducer (and its self-check) should be on'
     assert np.array_equal(a['w0'], b['w0']), 'replicas did not start from the same weights'
     for k in ('sG', 'sD', 'tG', 'tD', 'T', 'flatG'):
         assert np.array_equal(a[k], b[k]), 'replicas diverged in %s: gradients were not exchanged identically' % k
         assert np.isfinite(a[k]).all()
     assert a['losses'] == b['losses']          # logged losses are rank-averaged
+    # the bucketed, overlapped exchange against the plain flat all-reduce per optimizer on the same shards -- a
+    # missed ordering between the weight-gradient kernels and a bucket's all-reduce would leave the replicas identical to
+    # each other and different from this
+    c, d = _two_ranks('0')
+    assert not c['bucketed']
+    for k in ('sG', 'sD', 'tG', 'tD', 'T', 'flatG'):
+        assert np.array_equal(a[k], c[k]), 'bucketed and flat gradient exchange disagree in %s' % k
+    assert a['losses'] == c['losses']
 
 
 @pytest.mark.timeout(1500)
@@ -175,10 +189,11 @@ def test_native_comm_two_ranks_two_devices():
     assert np.array_equal(a['sum'], b['sum']) and np.allclose(a['sum'], want, rtol=0, atol=1e-6)
 
 
-def _rccl_worker(port, q):
+def _rccl_worker(port, q, route='torch'):
     sys.path.insert(0, ROOT)
+    # GCC_DP_FORCE_BUCKETS: the bucketed reducer (and its self-check) also with the one rank this box can give RCCL
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
-                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', GCC_DP_FORCE_BUCKETS='1', GCC_DP_COMM=route)
     import torch.distributed as dist
     from tests.test_pix2pix_gpu import GCC_ARGV, build_model
 
@@ -200,27 +215,31 @@ def _rccl_worker(port, q):
             torch.cuda.synchronize()
             out.append(dict(model.get_current_losses()))
         w = torch.cat([p.detach().float().reshape(-1) for p in list(model.netG.parameters()) + list(teacher.netG.parameters())]).cpu()
-        return out, w
-    ref_losses, ref_w = run(False)
+        return out, w, (model.optimizer_D.reducer is not None and model.optimizer_D.reducer.route)
+    ref_losses, ref_w, _ = run(False)
     torch.cuda.set_device(0)
     dist.init_process_group(backend='nccl', rank=0, world_size=1)
-    losses, w = run(True)
+    losses, w, bucket_route = run(True)
     dist.barrier()
     dist.destroy_process_group()
-    q.put({'ref': ref_losses, 'got': losses, 'same_weights': bool(torch.equal(ref_w, w))})
+    q.put({'ref': ref_losses, 'got': losses, 'same_weights': bool(torch.equal(ref_w, w)), 'bucket_route': bucket_route})
 
 
 @pytest.mark.timeout(1500)
-def test_rccl_single_rank_with_teacher_stream():
-    """the nccl (= RCCL) backend itself, one rank: the bucket all-reduces issued from the main and the teacher stream, the
-    asynchronous teacher-generator bucket and its late wait -- results must equal the run without a process group"""
+@pytest.mark.parametrize('route', ['torch', 'native'])
+def test_rccl_single_rank_with_teacher_stream(route):
+    """the nccl (= RCCL) backend itself, one rank: the BUCKETED all-reduces issued from the weight-gradient side streams of the
+    main and the teacher stream (after the self-check of that ordering on this backend), the asynchronous teacher-generator
+    bucket and its late wait -- through torch.distributed and through the C ABI's own communicator (GCC_DP_COMM=native:
+    gcc_comm_allreduce_sum_f32 on the side stream itself) -- results must equal the run without a process group"""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q, route))
     p.start()
     res = _collect(q, [p], 1)[0]
     p.join(120)
     assert p.exitcode == 0
+    assert res['bucket_route'] == route, res['bucket_route']
     assert res['got'] == res['ref'], (res['got'], res['ref'])
     assert res['same_weights']
 

@@ -892,3 +892,84 @@ def test_instance_norm_one_launch(C, H, W, relu, res):
         assert float(y.permute(0, 2, 3, 1).reshape(-1)[:0].sum()) == 0.0
         base = y.as_strided((N, H, W, ops.ceil8(C)), (H * W * ops.ceil8(C), W * ops.ceil8(C), ops.ceil8(C), 1))
         assert float(base[..., C:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('public_api', [False, True])
+def test_stream_helpers_order_work(public_api):
+    """ops.stream / ops.current_stream / ops.on_stream (torch's private raw-stream calls behind a guard, the public API as
+    their fallback): inside `with on_stream(s)` the library's launches go to s -- a kernel enqueued there behind a long fill
+    sees the fill's result -- and the previous stream is current again afterwards; record / wait through the same helpers
+    orders a second stream behind it.  public_api=True forces the fallbacks a torch upgrade would leave us with."""
+    ops = _ops()
+    saved = ops._RAW_STREAM, ops._SET_STREAM
+    if public_api:
+        ops._RAW_STREAM = ops._SET_STREAM = None
+    try:
+        main_raw = ops.stream()
+        assert main_raw == torch.cuda.current_stream().cuda_stream
+        side, other = torch.cuda.Stream(), torch.cuda.Stream()
+        big = torch.zeros(64 << 20, dtype=torch.float32, device=DEV)
+        src = ops.new_act(1, 8, 64, 64, DEV)
+        dst = ops.new_act(1, 8, 64, 64, DEV)
+        torch.cuda.synchronize()
+        with ops.on_stream(side):
+            assert ops.stream() == side.cuda_stream and ops.current_stream().cuda_stream == side.cuda_stream
+            for i in range(4):
+                big.fill_(float(i))                      # ~1 ms in front of the write below
+            src.fill_(3.0)
+            ops.nhwc_copy(src, 0, dst, 0, 8)             # a library launch: must run on `side`, behind the fill
+            ev = torch.cuda.Event()
+            ev.record(ops.current_stream())
+        assert ops.stream() == main_raw                   # restored
+        with ops.on_stream(other):
+            ops.current_stream().wait_event(ev)
+            out = ops.new_act(1, 8, 64, 64, DEV)
+            ops.nhwc_copy(dst, 0, out, 0, 8)
+        torch.cuda.synchronize()
+        assert float(out.float().min()) == 3.0 and float(out.float().max()) == 3.0
+    finally:
+        ops._RAW_STREAM, ops._SET_STREAM = saved
+
+
+HALO_CASES = [  # N, H, W, Ci, Co, stride: the PatchGAN layers conv_halo.hip serves at the bench's batch, and a smaller grid of each form
+    (16, 128, 128, 128, 256, 2), (16, 64, 64, 256, 512, 2), (16, 32, 32, 512, 1024, 1), (8, 64, 64, 128, 256, 2),
+    (4, 64, 64, 64, 512, 1)]
+
+
+@pytest.mark.parametrize('N,H,W,Ci,Co,stride', HALO_CASES)
+def test_halo_conv_vs_torch_and_gather_kernel(N, H, W, Ci, Co, stride):
+    """igemm_halo_kernel (tile neighbourhood resident in LDS; k4 s2 p1 forward / data gradient per phase / both px phases of a
+    128-channel data gradient, k4 s1 p1 forward on the padded grid / data gradient) against fp32 torch on the same bf16
+    operands, against igemm_kernel (GCC_OPT_IGEMM_HALO = 0: same sums in another order), and its BatchNorm partial sums
+    against the sums of its own rounded output."""
+    ops = _ops()
+    from gcc_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(N + H + Co)
+    k, p = 4, 1
+    Ho, Wo = (H + 2 - k) // stride + 1, (W + 2 - k) // stride + 1
+    x = rb(torch.randn(N, Ci, H, W, generator=g))
+    dy = rb(torch.randn(N, Co, Ho, Wo, generator=g))
+    m = rb(torch.randn(Co, Ci, k, k, generator=g) * 0.05)
+    w, wt = ops.pack_weights(m.to(DEV).contiguous(memory_format=torch.channels_last))
+    ref_y = F.conv2d(x, m, stride=stride, padding=p)
+    ref_dx = torch.nn.grad.conv2d_input((N, Ci, H, W), m, dy, stride=stride, padding=p)
+    res = {}
+    prev = lib.gcc_get_option(_lib.OPT_IGEMM_HALO)
+    try:
+        for halo in (0, 2):
+            lib.gcc_set_option(_lib.OPT_IGEMM_HALO, halo)
+            y, st = ops.conv_fprop(to_dev(x), w, Co, k, stride, p, want_stats=True)
+            dx = ops.conv_dgrad(to_dev(dy), wt, Ci, H, W, k, stride, p)
+            res[halo] = (to_cpu(y), to_cpu(dx), st.double().sum(0).cpu())
+    finally:
+        lib.gcc_set_option(_lib.OPT_IGEMM_HALO, prev)
+    y0, dx0, _ = res[0]
+    y2, dx2, st2 = res[2]
+    close(y2, ref_y, what='halo fprop vs torch')
+    close(dx2, ref_dx, what='halo dgrad vs torch')
+    close(y2, y0, tol=1.2e-2, what='halo fprop vs gather kernel')
+    close(dx2, dx0, tol=1.2e-2, what='halo dgrad vs gather kernel')
+    yd = y2.double()
+    want = torch.stack([yd.sum((0, 2, 3)), (yd * yd).sum((0, 2, 3))])
+    assert float((st2 - want).abs().max() / want.abs().max()) <= 1e-5
