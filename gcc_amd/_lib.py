@@ -160,6 +160,7 @@ PROTOTYPES = {
     'gcc_comm_rank': (_I, [_P]),
     'gcc_comm_world': (_I, [_P]),
     'gcc_comm_destroy': (_I, [_P]),
+    'gcc_comm_last_error': (C.c_char_p, []),
 }
 
 _lib = None

@@ -8,11 +8,23 @@
 // never call.
 #include <dlfcn.h>
 #include <string.h>
-#include <rccl/rccl.h>
 
 #include <mutex>
 
 #include "common.hpp"
+
+// The handful of RCCL / NCCL ABI items this file touches, declared here instead of through <rccl/rccl.h>: the library is
+// resolved with dlopen precisely so that hosts without it can build and load libgcc_hip.so -- a compile-time dependency on
+// the rccl development headers would take that back.  Values are NCCL's public, ABI-stable ones (nccl.h).
+typedef struct ncclComm* ncclComm_t;
+constexpr int NCCL_UNIQUE_ID_BYTES = 128;
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef int ncclResult_t;      // ncclSuccess == 0
+typedef int ncclDataType_t;    // ncclFloat32 == 7
+typedef int ncclRedOp_t;       // ncclSum == 0
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclFloat = 7;
+constexpr ncclRedOp_t ncclSum = 0;
 
 namespace {
 struct RcclApi {
@@ -20,8 +32,11 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     ncclResult_t (*CommDestroy)(ncclComm_t);
+    const char* (*GetErrorString)(ncclResult_t);
     bool ok;
 };
+thread_local ncclResult_t t_last_error = ncclSuccess;      // what RCCL answered to this thread's last failing call
+inline bool rccl_ok(ncclResult_t r) { if (r != ncclSuccess) t_last_error = r; return r == ncclSuccess; }
 RcclApi g_rccl;
 std::once_flag g_rccl_once;
 
@@ -36,6 +51,7 @@ const RcclApi& rccl() {
         g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
         g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
         g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+        g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
         g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.AllReduce && g_rccl.CommDestroy;
     });
     return g_rccl;
@@ -55,7 +71,7 @@ extern "C" int gcc_comm_unique_id(void* id) {
     const RcclApi& r = rccl();
     if (!r.ok) return GCC_ERR_UNSUPPORTED;
     ncclUniqueId u;
-    if (r.GetUniqueId(&u) != ncclSuccess) return GCC_ERR_LAUNCH;
+    if (!rccl_ok(r.GetUniqueId(&u))) return GCC_ERR_LAUNCH;
     memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
     return GCC_OK;
 }
@@ -72,7 +88,7 @@ extern "C" int gcc_comm_init(gcc_comm_t** out, int rank, int world, const void* 
     if (!c) return GCC_ERR_LAUNCH;
     c->rank = rank; c->world = world; c->device = -1;
     (void)hipGetDevice(&c->device);
-    if (r.CommInitRank(&c->comm, world, u, rank) != ncclSuccess) { delete c; return GCC_ERR_LAUNCH; }
+    if (!rccl_ok(r.CommInitRank(&c->comm, world, u, rank))) { delete c; return GCC_ERR_LAUNCH; }
     *out = c;
     return GCC_OK;
 }
@@ -85,7 +101,7 @@ extern "C" int gcc_comm_allreduce_sum_f32(gcc_comm_t* c, float* buf, size_t coun
     if (!c || !buf || count == 0) return GCC_ERR_BAD_ARG;
     const RcclApi& r = rccl();
     if (!r.ok) return GCC_ERR_UNSUPPORTED;
-    if (r.AllReduce(buf, buf, count, ncclFloat, ncclSum, c->comm, (hipStream_t)stream) != ncclSuccess) return GCC_ERR_LAUNCH;
+    if (!rccl_ok(r.AllReduce(buf, buf, count, ncclFloat, ncclSum, c->comm, (hipStream_t)stream))) return GCC_ERR_LAUNCH;
     return GCC_OK;
 }
 
@@ -97,7 +113,14 @@ extern "C" int gcc_comm_destroy(gcc_comm_t* c) {
     if (!c) return GCC_ERR_BAD_ARG;
     const RcclApi& r = rccl();
     int rc = GCC_OK;
-    if (r.ok && r.CommDestroy(c->comm) != ncclSuccess) rc = GCC_ERR_LAUNCH;
+    if (r.ok && !rccl_ok(r.CommDestroy(c->comm))) rc = GCC_ERR_LAUNCH;
     delete c;
     return rc;
+}
+
+// RCCL's own words for the calling thread's last failing gcc_comm_* call ("" when none failed, or without the library)
+extern "C" const char* gcc_comm_last_error(void) {
+    const RcclApi& r = rccl();
+    if (t_last_error == ncclSuccess || !r.ok || !r.GetErrorString) return "";
+    return r.GetErrorString(t_last_error);
 }

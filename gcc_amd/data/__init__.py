@@ -268,11 +268,16 @@ class _GpuFileLoader:
         from .. import dist as gdist
         order = self.order()
         w = gdist.world_size()
-        if w > 1:
+        # only TRAINING loaders are dealt over the ranks: an evaluation loader (serial order, or a non-train phase) is walked
+        # whole by whoever iterates it -- no collective inside, so one rank may evaluate alone
+        shard = bool(getattr(self.opt, 'isTrain', False)) and not self.opt.serial_batches and \
+            getattr(self.opt, 'phase', 'train') == 'train'
+        if w > 1 and shard:
             import torch.distributed as dist
             box = [order]
             dist.broadcast_object_list(box, src=0)
             order = box[0]
+            assert len(order) >= w, 'dataset of %d items cannot be dealt over %d ranks' % (len(order), w)
             order = order[:len(order) // w * w][gdist.rank()::w]
         return order
 

@@ -260,7 +260,10 @@ class NativeComm:
         from . import _lib
         self._lib = _lib.load()
         self._h = C.c_void_p()
-        _lib.check(self._lib.gcc_comm_init(C.byref(self._h), int(rank), int(world), bytes(unique_id)), 'gcc_comm_init')
+        rc = self._lib.gcc_comm_init(C.byref(self._h), int(rank), int(world), bytes(unique_id))
+        if rc:
+            why = self._lib.gcc_comm_last_error()
+            raise _lib.GccError('gcc_comm_init: %s%s' % (self._lib.gcc_strerror(rc).decode(), (' (RCCL: %s)' % why.decode()) if why else ''))
         self.rank, self.world = rank, world
 
     @staticmethod

@@ -13,14 +13,44 @@ import torch
 from .. import ops
 
 
+# the tile plan is process-wide state of libgcc_hip.so (gcc_set_option); every model instance keeps the plan it wants and
+# re-applies it at the head of its own phases when another instance (or a test) has changed the library's since
+_applied_plan = None
+
+
 class TeacherStreamMixin:
+    def _ensure_plan(self):
+        """make the library's pair-split / weight-gradient split options the ones THIS model's schedule asked for (no-op when
+        they already are: a tuple compare per phase).  Explicit GCC_WGRAD_WGS* environment values win, as before."""
+        global _applied_plan
+        plan = getattr(self, '_plan', None)
+        if plan is None or plan == _applied_plan:
+            return
+        from .. import _lib
+        lib = ops.lib()
+        pair, wgs_big, wgs = plan
+        lib.gcc_set_option(_lib.OPT_IGEMM_PAIR, pair)
+        if 'GCC_WGRAD_WGS_BIG' not in os.environ:
+            lib.gcc_set_option(_lib.OPT_WGRAD_WGS_BIG, wgs_big)
+        if 'GCC_WGRAD_WGS' not in os.environ:
+            lib.gcc_set_option(_lib.OPT_WGRAD_WGS, wgs)
+        _applied_plan = plan
+
+    def restore_library_plan(self):
+        """give the library its default plan back (model teardown / tests that go on to call the kernels directly)"""
+        global _applied_plan
+        self._plan = (-1, -1, -1)
+        self._ensure_plan()
+        self._plan = None
+        _applied_plan = None
+
     def set_stream_schedule(self, concurrent, plan=None):
         """concurrent=True: the production schedule (student, online teacher, auxiliary and weight-gradient streams).
         False: every launch on one stream.  plan: the library's tile plan -- 'production' (what the multi-stream schedule runs:
         no pair split, half-chip weight-gradient splits) or 'alone' (for launches that have the chip to themselves:
         GCC_OPT_IGEMM_PAIR, full-chip weight-gradient splits); default: 'production' with concurrent streams, 'alone' without.
         bench.py times one single-stream step under each plan (a launch's duration is then the kernel's own)."""
-        from .. import _lib, engine
+        from .. import engine
         self.serialize_streams = not concurrent
         if getattr(self, 'teacher_model', None) is not None:
             self.teacher_model.serialize_streams = not concurrent
@@ -30,29 +60,24 @@ class TeacherStreamMixin:
         assert plan in ('production', 'alone')
         # GCC_PAIR_CONCURRENT=1: keep the pair split in the production plan too (A/B hook)
         pair_prod = 1 if os.environ.get('GCC_PAIR_CONCURRENT', '0') == '1' else 0
-        ops.lib().gcc_set_option(_lib.OPT_IGEMM_PAIR, pair_prod if plan == 'production' else 1)
-        self._apply_wgrad_plan(plan == 'production')
-
-    @staticmethod
-    def _apply_wgrad_plan(concurrent):
-        """Workgroup targets of the split weight-gradient launches.  The library's defaults (256 / 512) are for a launch that
-        has the chip to itself; on the weight-gradient side stream of the production schedule half of that is faster end to
-        end (+0.6 %, profiles/r02_ab_tables.md r03w / r03x): half-chip launches beside the main stream's chain, half the fp32
-        slab traffic -- although the same launches alone run at 365 instead of 538 TFLOP/s.  An explicit GCC_WGRAD_WGS* wins."""
-        from .. import _lib
-        lib = ops.lib()
-        for opt_id, env, side in ((_lib.OPT_WGRAD_WGS_BIG, 'GCC_WGRAD_WGS_BIG', 128), (_lib.OPT_WGRAD_WGS, 'GCC_WGRAD_WGS', 256)):
-            if env not in os.environ:
-                lib.gcc_set_option(opt_id, side if concurrent else -1)
+        # Workgroup targets of the split weight-gradient launches: the library's defaults (256 / 512) are for a launch that has
+        # the chip to itself; on the weight-gradient side stream of the production schedule half of that is faster end to end
+        # (+0.6 %, profiles/r02_ab_tables.md r03w / r03x; re-measured with this round's kernels: profiles/r3l_ab_plans.txt)
+        self._plan = (pair_prod, 128, 256) if plan == 'production' else (1, -1, -1)
+        if getattr(self, 'teacher_model', None) is not None:
+            self.teacher_model._plan = self._plan
+        self._ensure_plan()
 
     def _teacher_stream(self):
+        self._ensure_plan()
         if getattr(self, 'serialize_streams', False):
             return False
         if getattr(self, '_tstream', None) is None:
             on = os.environ.get('GCC_CONCURRENT_TEACHER', '1') != '0'
             self._tstream = torch.cuda.Stream(device=self.device) if on else False
-            if on:
-                self._apply_wgrad_plan(True)
+            if on and getattr(self, '_plan', None) is None:
+                self._plan = (1 if os.environ.get('GCC_PAIR_CONCURRENT', '0') == '1' else 0, 128, 256)
+                self._ensure_plan()
         return self._tstream
 
     def _mark_teacher_free(self):

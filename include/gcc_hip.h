@@ -530,6 +530,9 @@ int gcc_comm_allreduce_sum_f32(gcc_comm_t* comm, float* buf, size_t count, gcc_s
 int gcc_comm_rank(const gcc_comm_t* comm);
 int gcc_comm_world(const gcc_comm_t* comm);
 int gcc_comm_destroy(gcc_comm_t* comm);
+/* RCCL's own message for the calling thread's last failing gcc_comm_* call ("" if none failed): a GCC_ERR_LAUNCH from this
+ * group otherwise hides which ncclResult it was */
+const char* gcc_comm_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -59,22 +59,44 @@ def test_comm_entry_points_without_a_gpu():
 
 
 def test_weight_gradient_plan_follows_the_schedule(monkeypatch):
-    """models/_streams.py: the concurrent schedule halves the workgroup targets of split weight-gradient launches, the
-    single-stream schedule restores the library's defaults, an explicit GCC_WGRAD_WGS* environment variable wins"""
+    """models/_streams.py: every model instance keeps the tile plan its schedule asked for and re-applies it at the head of
+    its phases: the production plan halves the workgroup targets of split weight-gradient launches and leaves the pair split
+    off, the alone plan restores the library's defaults with the pair split on, an explicit GCC_WGRAD_WGS* environment
+    variable wins, and two instances with different plans each get their own when their turn comes"""
     from gcc_amd import _lib
+    from gcc_amd.models import _streams
     from gcc_amd.models._streams import TeacherStreamMixin as M
     lib = _lib.load()
     monkeypatch.delenv('GCC_WGRAD_WGS_BIG', raising=False)
     monkeypatch.delenv('GCC_WGRAD_WGS', raising=False)
+    monkeypatch.delenv('GCC_PAIR_CONCURRENT', raising=False)
+
+    class Fake(M):
+        device = None
+        serialize_streams = True
+    state = lambda: (lib.gcc_get_option(_lib.OPT_IGEMM_PAIR), lib.gcc_get_option(_lib.OPT_WGRAD_WGS_BIG),
+                     lib.gcc_get_option(_lib.OPT_WGRAD_WGS))
+    a, b = Fake(), Fake()
     try:
-        M._apply_wgrad_plan(True)
-        assert (lib.gcc_get_option(_lib.OPT_WGRAD_WGS_BIG), lib.gcc_get_option(_lib.OPT_WGRAD_WGS)) == (128, 256)
-        M._apply_wgrad_plan(False)
-        assert (lib.gcc_get_option(_lib.OPT_WGRAD_WGS_BIG), lib.gcc_get_option(_lib.OPT_WGRAD_WGS)) == (256, 512)
+        a.set_stream_schedule(True)
+        assert state() == (0, 128, 256)
+        b.set_stream_schedule(False)
+        assert state() == (1, 256, 512)
+        a._ensure_plan()                         # head of a's next phase (_teacher_stream): its own plan again, whatever b left
+        assert state() == (0, 128, 256)
+        b._ensure_plan()
+        assert state() == (1, 256, 512)
+        a.set_stream_schedule(False, plan='production')      # one stream under the production plan (bench.py's bracketed step)
+        assert state() == (0, 128, 256)
         monkeypatch.setenv('GCC_WGRAD_WGS', '512')
-        M._apply_wgrad_plan(True)
-        assert (lib.gcc_get_option(_lib.OPT_WGRAD_WGS_BIG), lib.gcc_get_option(_lib.OPT_WGRAD_WGS)) == (128, 512)
+        lib.gcc_set_option(_lib.OPT_WGRAD_WGS, 512)
+        b.set_stream_schedule(True)
+        a.set_stream_schedule(True)
+        assert state() == (0, 128, 512)
     finally:
+        a.restore_library_plan()
+        assert _streams._applied_plan is None
+        lib.gcc_set_option(_lib.OPT_IGEMM_PAIR, -1)
         lib.gcc_set_option(_lib.OPT_WGRAD_WGS_BIG, -1)
         lib.gcc_set_option(_lib.OPT_WGRAD_WGS, -1)
 
