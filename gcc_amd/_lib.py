@@ -67,7 +67,7 @@ class adam_chunk_t(C.Structure):
 (OPT_IGEMM_BIG, OPT_IGEMM_BIG_MIN, OPT_IGEMM_BIG_NK, OPT_IGEMM_GLDS, OPT_IGEMM_HEAD, OPT_IGEMM_THIN, OPT_WGRAD_BIG,
  OPT_BN_SWEEPS, OPT_BN_MAXBLK, OPT_BN_REDUCE_THREADS, OPT_BN_REDUCE_CAP, OPT_INORM_LPP, OPT_WGRAD_WGS_BIG,
  OPT_WGRAD_WGS, OPT_IGEMM_FORCE_BC, OPT_IGEMM_FORCE_KSPLIT, OPT_IGEMM_NARROW, OPT_IGEMM_PAIR, OPT_WGRAD_BIG_MIN_TILES, OPT_FUSE_BN,
- OPT_BN_BWD_SMALL, OPT_WGRAD_ROW_TABLE, OPT_IGEMM_HALO, OPT_DEBUG) = range(24)
+ OPT_BN_BWD_SMALL, OPT_WGRAD_ROW_TABLE, OPT_IGEMM_HALO, OPT_FUSE_BN_PARTIAL_KB, OPT_DEBUG) = range(25)
 
 _P = C.c_void_p
 _I = C.c_int

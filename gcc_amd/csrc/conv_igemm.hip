@@ -1591,7 +1591,19 @@ extern "C" int gcc_conv_bn_act(const gcc_conv_t* c, int dgrad, const void* x, co
     const size_t max_rows = conv_max_rows(c, dgrad);
     const int nk = conv_nk(c, dgrad);
     const TilePlan tp = select_tile(max_rows, Cout, phases, nk, 1);
-    const SplitPlan sp = tp.BP == 128 ? plan_ksplit((long)tp.mtiles * tp.ntiles * phases, nk, tp.max_slices) : SplitPlan{1, nk};
+    SplitPlan sp = tp.BP == 128 ? plan_ksplit((long)tp.mtiles * tp.ntiles * phases, nk, tp.max_slices) : SplitPlan{1, nk};
+    // The K split is sized to fill the chip with the partial-tile launch, but every slice is one more fp32 copy of the output
+    // that splitk_bn_act_kernel -- C / 8 workgroups -- has to read back: the student's 16x16 -> 8x8 layer wrote and folded 16
+    // slices = 16.8 MB for a 0.5 MB output, 59 us of fold behind 11 us of MFMA work (profiles/r3z_unet_student_chain.txt).
+    // Cap the slices at GCC_OPT_FUSE_BN_PARTIAL_KB of partial tiles (default 4 MB), never below four (fewer leave the partial-tile
+    // launch with a handful of workgroups: student forward 628 -> 569 us, teacher 836 -> 796 with 8 MB: profiles/r3z_*).
+    if (sp.ksplit > 4 && max_rows * phases <= FOLD_BN_MAX_ROWS) {
+        const size_t per_slice = (size_t)phases * max_rows * tp.ntiles * tp.BC * sizeof(float);
+        const size_t cap = (size_t)gcc_opt(GCC_OPT_FUSE_BN_PARTIAL_KB) * 1024;
+        int ks = sp.ksplit;
+        while (ks > 4 && per_slice * ks > cap) ks = (ks + 1) / 2;
+        if (ks != sp.ksplit) { sp.kper = cdiv(nk, ks); sp.ksplit = cdiv(nk, sp.kper); }
+    }
     const bool routed = (dgrad && thin_dgrad_shape(c)) || (!dgrad && thin_shape(c)) || head_shape(c);
     if (!routed && sp.ksplit > 1 && max_rows * phases <= FOLD_BN_MAX_ROWS && gcc_opt(GCC_OPT_FUSE_BN)) {
         // split launch with raw partial tiles, then the fused fold + statistics + finalize + normalise kernel

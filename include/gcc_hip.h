@@ -92,6 +92,8 @@ enum {
                                    per tile, output rows that tile 256 pixels) stage each 64-channel slice of the input neighbourhood of a
                                    256-pixel tile ONCE in LDS and serve the taps that share it from there (conv_halo.hip); 0: the gather
                                    kernel re-stages the pixels for every tap */
+    GCC_OPT_FUSE_BN_PARTIAL_KB, /* gcc_conv_bn_act: cap (KB of fp32 partial tiles, default 4096) on the K split of the layers whose fold + statistics +
+                                   normalise run as one kernel: every slice is another copy of the output that kernel reads back */
     GCC_OPT_DEBUG,              /* 0 (default).  Diagnostic ablations for timing only -- RESULTS ARE WRONG when set: bit 1 (2) the main loops issue
                                    no staging loads after the first step, bit 2 (4) they re-load the first step's addresses */
     GCC_OPT_COUNT_
