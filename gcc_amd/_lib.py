@@ -67,7 +67,8 @@ class adam_chunk_t(C.Structure):
 (OPT_IGEMM_BIG, OPT_IGEMM_BIG_MIN, OPT_IGEMM_BIG_NK, OPT_IGEMM_GLDS, OPT_IGEMM_HEAD, OPT_IGEMM_THIN, OPT_WGRAD_BIG,
  OPT_BN_SWEEPS, OPT_BN_MAXBLK, OPT_BN_REDUCE_THREADS, OPT_BN_REDUCE_CAP, OPT_INORM_LPP, OPT_WGRAD_WGS_BIG,
  OPT_WGRAD_WGS, OPT_IGEMM_FORCE_BC, OPT_IGEMM_FORCE_KSPLIT, OPT_IGEMM_NARROW, OPT_IGEMM_PAIR, OPT_WGRAD_BIG_MIN_TILES, OPT_FUSE_BN,
- OPT_BN_BWD_SMALL, OPT_WGRAD_ROW_TABLE, OPT_IGEMM_HALO, OPT_FUSE_BN_PARTIAL_KB, OPT_DEBUG) = range(25)
+ OPT_BN_BWD_SMALL, OPT_WGRAD_ROW_TABLE, OPT_IGEMM_HALO, OPT_FUSE_BN_PARTIAL_KB, OPT_INORM_GRID,
+ OPT_DEBUG) = range(26)
 
 _P = C.c_void_p
 _I = C.c_int
@@ -100,8 +101,8 @@ PROTOTYPES = {
     'gcc_nhwc_add': (_I, [_P, _I, _I, _P, _I, _I, _I, _Z, _P]),
     'gcc_bn_finalize': (_I, [_P, _I, _I, C.c_double, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     'gcc_in_finalize': (_I, [_P, _I, _I, _I, C.c_double, _F, _P, _P, _P, _P, _P]),
-    'gcc_inorm_fwd': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P]),
-    'gcc_inorm_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
+    'gcc_inorm_fwd': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
+    'gcc_inorm_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
     'gcc_channel_stats_tiles': (_I, [_Z, _I]),
     'gcc_channel_stats': (_I, [_P, _I, _I, _I, _Z, _I, _P, _P]),
     'gcc_reflect_pad': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -5,6 +5,7 @@
 // float atomics).
 #include "common.hpp"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -905,8 +906,363 @@ __global__ __launch_bounds__(NTH) void inorm_bwd_fused_kernel(const InFusedArgs 
     }
 }
 
+// The same one-launch InstanceNorm with the plane of an image split over S workgroups (round 3: at batch 1 the slab kernels
+// above put 6-16 workgroups on 256 CUs -- `rocprofv3` of a CycleGAN iteration: 592 forward launches of 18 us and 296 backward
+// launches of 37 us on average, 21.7 of the iteration's 56 ms of kernel time).  A workgroup owns `rows` whole pixels (all
+// channels: contiguous memory) and writes its per-channel partial sums; the image's workgroups meet at an in-launch barrier,
+// the counter form of the hand-off in cdna_hip_programming.md (Guideline 16) with write-through (sc1) stores and sc1 loads
+// instead of fences.  The last workgroup of an image to arrive folds the S partials (S * V * 4 <= 64 KB) and publishes the
+// totals; every workgroup then normalises its own rows, which it has just read.  Residency comes from the grid size alone:
+// <= 128 workgroups of 256 threads per launch, so that the four streams of a training step cannot fill the chip's 256 x 4
+// slots with waiting workgroups; the spin is bounded all the same.  An image's arrival word is zero before and after every
+// launch (the last arriver re-arms it; the host allocates it zeroed); its epoch word counts the launches and is never reset.
+struct InGridArgs {
+    InFusedArgs a;
+    float* partial;        // [N * CG][S][V]
+    double* totals;        // [N * CG][V]
+    unsigned* cnt;         // [N * CG][4]: arrivals, epoch
+    int S, rows;           // workgroups per (image, channel group), pixels per workgroup
+    int CG, CHg;           // channel groups per image, 16-byte chunks per group (all of them when the image has < 16)
+    int CH, CHP, sh;       // chunks per pixel; the power of two above CHg, its log2
+    int V;                 // CHg * 16 partial values per workgroup: [chunk][stat 0 / 1][8 channels]
+    unsigned long long* clk;   // GCC_OPT_DEBUG bit 5 (32): [S][8] s_memrealtime stamps of image 0, group 0 (100 MHz)
+};
+
+// A lane keeps its first PPT pixels (16 bytes each, per tensor) in registers from the statistics pass to the normalising pass:
+// every load of a pass is in flight at once, and the second pass loads nothing but the residual.  (With four loads in flight
+// and a second read of x, s_memrealtime stamps of the 64 x 64 x 256 plane read: 2 us statistics, 4 us hand-off, 6 us
+// normalising; the backward 8 + 4 + 8.)  Rows beyond PPT * (256 / CHP) per workgroup stream through the loops behind.
 template <bool BWD>
-void inorm_launch(const InFusedArgs& a, int N, hipStream_t st) {
+__global__ __launch_bounds__(256, 4) void inorm_grid_kernel(const InGridArgs ga) {   // <= 128 VGPRs: four workgroups per CU, the residency the barrier counts on
+    constexpr int PPT = BWD ? 4 : 8;
+    __shared__ double smem_d[2048 + 256 + 1];       // one array (a second __shared__ object costs a vmcnt(0), guide 5.4)
+    float* red = (float*)smem_d;                    // [4 waves][64 lanes][16] per-wave sums; later the forward's coefficients
+    double* tot = smem_d + 2048;                    // [V <= 256] totals of the (image, channel group)
+    const InFusedArgs& a = ga.a;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ch = t & (ga.CHP - 1), pl = t >> ga.sh, PL = 256 >> ga.sh;      // ch: chunk inside the group
+    const int s = blockIdx.x, cg = blockIdx.y;
+    const size_t g = blockIdx.z;
+    const size_t dom = g * ga.CG + cg;              // the barrier domain: S workgroups
+    const bool live = ch < ga.CHg && cg * ga.CHg + ch < ga.CH;
+    const int c0 = (cg * ga.CHg + ch) * 8;
+    const int p0 = s * ga.rows, p1 = min(p0 + ga.rows, a.HW);
+    const bf16_t* xg = a.x + g * (size_t)a.HW * a.ldx + c0;
+    const bf16_t* yg = (BWD && a.y) ? a.y + g * (size_t)a.HW * a.ldy + c0 : nullptr;
+    const bf16_t* ag = a.aux ? a.aux + g * (size_t)a.HW * a.ldaux + c0 : nullptr;     // fwd: residual; bwd: incoming gradient
+    bf16_t* og = a.out + g * (size_t)a.HW * a.ldout + c0;
+    float mu[8], rs[8];
+    if (BWD) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const bool ok = live && c0 + j < a.C;
+            mu[j] = ok ? a.mean[g * a.C + c0 + j] : 0.f;
+            rs[j] = ok ? a.rstd[g * a.C + c0 + j] : 0.f;
+        }
+    }
+    // the image's epoch word: stable until every workgroup of this launch has arrived (all of them read it first)
+    typedef __attribute__((address_space(1))) unsigned int gu32;
+    gu32* cnt = (gu32*)ga.cnt + dom * 4;            // [0] arrivals, [1] epoch: bumped when the totals are ready
+#define IN_STAMP(k) do { if (ga.clk && t == 0 && dom == 0) ga.clk[s * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    IN_STAMP(0);
+    unsigned epoch = 0;
+    if (t == 0 && ga.S > 1) epoch = __hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float v[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[0][j] = v[1][j] = 0.f;
+    auto accum = [&](const i32x4& rx, const i32x4& rgr, const i32x4& ry) {
+        float xv[8];
+        unpack8(rx, xv);
+        if (!BWD) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { v[0][j] += xv[j]; v[1][j] += xv[j] * xv[j]; }
+        } else {
+            float gv[8], yv[8];
+            unpack8(rgr, gv);
+            if (yg) unpack8(ry, yv);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float xh = (xv[j] - mu[j]) * rs[j];
+                const float yo = yg ? yv[j] : apply_act(xh, a.act, a.slope);
+                const float d = gv[j] * act_grad_from_out(yo, a.act, a.slope);
+                v[0][j] += d; v[1][j] += d * xh;
+            }
+        }
+    };
+    const i32x4 zero4 = {0, 0, 0, 0};
+    i32x4 cx[PPT], cgr[BWD ? PPT : 1];               // the saved output y is read again in the second pass: 128 VGPRs hold no more
+    const int pfirst = p0 + pl;                     // this lane's pixels: pfirst + u * PL
+    const int pstream = pfirst + PPT * PL;          // the first one that is not held in registers
+    if (live) {
+        i32x4 cy[BWD ? PPT : 1];
+#pragma unroll
+        for (int u = 0; u < PPT; u++) {
+            const int p = pfirst + u * PL;
+            const bool ok = p < p1;
+            cx[u] = ok ? *(const i32x4*)(xg + (size_t)p * a.ldx) : zero4;
+            if (BWD) {
+                cgr[u] = ok ? *(const i32x4*)(ag + (size_t)p * a.ldaux) : zero4;      // zero gradient: no contribution
+                cy[u] = (ok && yg) ? *(const i32x4*)(yg + (size_t)p * a.ldy) : zero4;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PPT; u++) accum(cx[u], cgr[BWD ? u : 0], cy[BWD ? u : 0]);
+        for (int p = pstream; p < p1; p += PL) {
+            i32x4 rx = *(const i32x4*)(xg + (size_t)p * a.ldx), rgr = rx, ry = rx;
+            if (BWD) {
+                rgr = *(const i32x4*)(ag + (size_t)p * a.ldaux);
+                if (yg) ry = *(const i32x4*)(yg + (size_t)p * a.ldy);
+            }
+            accum(rx, rgr, ry);
+        }
+    }
+    // lanes of a wave that hold the same chunk (CHP < 64), then the waves through LDS
+    for (int o = 32; o >= ga.CHP; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[k][j] += __shfl_xor(v[k][j], o, 64);
+    }
+    if (ga.sh >= 6 || (lane >> ga.sh) == 0) {
+        float* dst = red + (wave * 64 + (ga.sh >= 6 ? lane : ch)) * 16;
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) dst[k * 8 + j] = v[k][j];
+    }
+    __syncthreads();
+    const bool alone = ga.S == 1;
+    // The partials travel between workgroups on other XCDs (private L2s): write-through (sc1) stores and sc1 loads, every one of
+    // them, instead of an agent-scope release / acquire pair (the fences write back and invalidate the whole L2, which holds the
+    // producer convolution's output).  The LAST workgroup of an image to arrive folds the S partials (<= 64 KB, its 256 lanes keep
+    // 32 loads in flight each) and publishes V totals; the others wait for its epoch bump and read those V values only.
+    const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(ga.partial + dom * ga.S * (size_t)ga.V), 0, ga.S * ga.V * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_tot = __builtin_amdgcn_make_buffer_rsrc((void*)(ga.totals + dom * (size_t)ga.V), 0, ga.V * 8, 0x00020000);
+    for (int i = t; i < ga.V; i += 256) {
+        const int chunk = i >> 4, r = i & 15;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+            if ((((w << 6) ^ chunk) & (ga.CHP - 1) & ~63) == 0) sum += red[(w * 64 + (chunk & 63)) * 16 + r];
+        if (alone) tot[i] = (double)sum;
+        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sum), rs_part, (s * ga.V + i) * 4, 0, 16);
+    }
+    IN_STAMP(1);
+    if (!alone) {
+        int* sh_ticket = (int*)(smem_d + 2048 + 256);   // behind tot
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) *sh_ticket = (int)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const bool last = *sh_ticket == ga.S - 1;
+        IN_STAMP(2);
+        if (last) {
+            // everyone has arrived and nobody reads the arrival word again: re-arm it for the next launch on this stream
+            if (t == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // q slices: with V < 256 the idle lanes take other partials of the same value; folded through LDS below
+            const int nslice = ga.V >= 256 ? 1 : 256 / ga.V;
+            double* part = smem_d;                  // [nslice][V] doubles <= 2 KB: `red` is dead
+            __syncthreads();
+            for (int i0 = 0; i0 < ga.V; i0 += 256) {
+                const int sl = ga.V >= 256 ? 0 : t / ga.V;
+                const int i = ga.V >= 256 ? i0 + t : t - sl * ga.V;
+                if (sl < nslice && i < ga.V) {
+                    double sum = 0.0;
+                    int q = sl;
+                    constexpr int FB = BWD ? 16 : 32;       // loads in flight per lane (the backward holds more state)
+                    for (; q + (FB - 1) * nslice < ga.S; q += FB * nslice) {
+                        float f[FB];
+#pragma unroll
+                        for (int u = 0; u < FB; u++)
+                            f[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_part, ((q + u * nslice) * ga.V + i) * 4, 0, 16));
+#pragma unroll
+                        for (int u = 0; u < FB; u += 4) sum += ((double)f[u] + (double)f[u + 1]) + ((double)f[u + 2] + (double)f[u + 3]);
+                    }
+                    for (; q + 7 * nslice < ga.S; q += 8 * nslice) {
+                        float f[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++)
+                            f[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_part, ((q + u * nslice) * ga.V + i) * 4, 0, 16));
+#pragma unroll
+                        for (int u = 0; u < 8; u += 4) sum += ((double)f[u] + (double)f[u + 1]) + ((double)f[u + 2] + (double)f[u + 3]);
+                    }
+                    for (; q < ga.S; q += nslice)
+                        sum += (double)__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_part, (q * ga.V + i) * 4, 0, 16));
+                    if (nslice == 1) tot[i] = sum;
+                    else part[sl * ga.V + i] = sum;
+                }
+            }
+            __syncthreads();
+            if (nslice > 1) {
+                for (int i = t; i < ga.V; i += 256) {
+                    double sum = 0.0;
+                    for (int sl = 0; sl < nslice; sl++) sum += part[sl * ga.V + i];
+                    tot[i] = sum;
+                }
+                __syncthreads();
+            }
+            for (int i = t; i < ga.V; i += 256) {
+                const i32x2 bits = __builtin_bit_cast(i32x2, tot[i]);
+                __builtin_amdgcn_raw_buffer_store_b64(bits, rs_tot, i * 8, 0, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(cnt + 1, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            IN_STAMP(3);
+        } else {
+            if (t == 0) {
+                for (int spin = 0; spin < (1 << 24); spin++) {
+                    if (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            IN_STAMP(3);
+            __syncthreads();
+            for (int i = t; i < ga.V; i += 256)
+                tot[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_tot, i * 8, 0, 16));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+    }
+    IN_STAMP(4);
+    const double inv_hw = 1.0 / (double)a.HW;
+    if (!BWD) {
+        __syncthreads();          // `red` is read above by other threads until here; it now receives the coefficients
+        for (int cl = t; cl < ga.CHg * 8; cl += 256) {
+            const int chunk = cl >> 3, j = cl & 7;
+            const double m = tot[chunk * 16 + j] * inv_hw;
+            double var = tot[chunk * 16 + 8 + j] * inv_hw - m * m;
+            if (var < 0.0) var = 0.0;
+            const float r = (float)(1.0 / sqrt(var + (double)a.eps));
+            const float sh = 0.f - (float)m * r;
+            red[chunk * 16 + j] = r; red[chunk * 16 + 8 + j] = sh;
+            const int c = cg * ga.CHg * 8 + cl;
+            if (s == 0 && c < a.C) {
+                const size_t o = g * a.C + c;
+                a.mean[o] = (float)m; a.rstd[o] = r; a.scale[o] = r; a.shift[o] = sh;
+            }
+        }
+        __syncthreads();
+        if (!live) return;
+        float sc[8], sf[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { sc[j] = red[ch * 16 + j]; sf[j] = red[ch * 16 + 8 + j]; }
+        auto emit = [&](int p, const i32x4& rx, const i32x4& rr) {
+            float f[8], o[8];
+            unpack8(rx, f);
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = f[j] * sc[j] + sf[j];
+            apply_act8(o, o, a.act, a.slope);
+            if (ag) {
+                float rv[8];
+                unpack8(rr, rv);
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j] += rv[j];
+            }
+            *(i32x4*)(og + (size_t)p * a.ldout) = pack8(o);
+        };
+        if (ag) {
+            i32x4 rr[PPT];
+#pragma unroll
+            for (int u = 0; u < PPT; u++) {
+                const int p = pfirst + u * PL;
+                rr[u] = p < p1 ? *(const i32x4*)(ag + (size_t)p * a.ldaux) : zero4;
+            }
+#pragma unroll
+            for (int u = 0; u < PPT; u++)
+                if (pfirst + u * PL < p1) emit(pfirst + u * PL, cx[u], rr[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < PPT; u++)
+                if (pfirst + u * PL < p1) emit(pfirst + u * PL, cx[u], zero4);
+        }
+        for (int p = pstream; p < p1; p += PL) {
+            const i32x4 rx = *(const i32x4*)(xg + (size_t)p * a.ldx);
+            const i32x4 rr = ag ? *(const i32x4*)(ag + (size_t)p * a.ldaux) : rx;
+            emit(p, rx, rr);
+        }
+        IN_STAMP(5);
+    } else {
+        if (!live) return;
+        float A[8], B[8], K[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float k0 = (float)(tot[ch * 16 + j] * inv_hw), k1 = (float)(tot[ch * 16 + 8 + j] * inv_hw);
+            A[j] = rs[j]; B[j] = -rs[j] * rs[j] * k1; K[j] = -rs[j] * k0 + rs[j] * rs[j] * k1 * mu[j];
+        }
+        auto emit = [&](int p, const i32x4& rx, const i32x4& rgr, const i32x4& ry) {
+            float xv[8], yv[8], gv[8], o[8];
+            unpack8(rx, xv); unpack8(rgr, gv);
+            if (yg) unpack8(ry, yv);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float yo = yg ? yv[j] : apply_act((xv[j] - mu[j]) * rs[j], a.act, a.slope);
+                const float d = gv[j] * act_grad_from_out(yo, a.act, a.slope);
+                o[j] = A[j] * d + B[j] * xv[j] + K[j];
+            }
+            *(i32x4*)(og + (size_t)p * a.ldout) = pack8(o);
+        };
+        i32x4 cy[PPT];
+#pragma unroll
+        for (int u = 0; u < PPT; u++) {
+            const int p = pfirst + u * PL;
+            cy[u] = (p < p1 && yg) ? *(const i32x4*)(yg + (size_t)p * a.ldy) : zero4;
+        }
+#pragma unroll
+        for (int u = 0; u < PPT; u++)
+            if (pfirst + u * PL < p1) emit(pfirst + u * PL, cx[u], cgr[BWD ? u : 0], cy[u]);
+        for (int p = pstream; p < p1; p += PL) {
+            const i32x4 rx = *(const i32x4*)(xg + (size_t)p * a.ldx);
+            const i32x4 rgr = *(const i32x4*)(ag + (size_t)p * a.ldaux);
+            const i32x4 ry = yg ? *(const i32x4*)(yg + (size_t)p * a.ldy) : rx;
+            emit(p, rx, rgr, ry);
+        }
+        IN_STAMP(5);
+    }
+#undef IN_STAMP
+}
+
+constexpr size_t INORM_WS_HEADER = 4096;           // [N * CG <= 256][4] counter words in front of the totals and the partials
+// plan of the grid form; false: this geometry stays with the slab kernels
+static bool inorm_grid_plan(int C, int HW, int N, int px, size_t ws_bytes, InGridArgs* ga) {
+    const int CH = (C + 7) / 8;
+    if (CH > 256 || N > 64) return false;
+    const int CHg = CH >= 16 ? 8 : CH;              // 64-channel groups (128-byte segments of a pixel) once an image has 128 channels
+    const int CG = (CH + CHg - 1) / CHg;
+    if (N * CG > 256) return false;
+    int CHP = 1, sh = 0;
+    while (CHP < CHg) { CHP <<= 1; sh++; }
+    const int PL = 256 / CHP, V = CHg * 16;
+    // as many CUs as the caps below allow: the passes are bound by the vector ALU of the CUs that take part and by the latency of
+    // a lane's loads, not by memory; px pixels per lane = what the kernel keeps in registers (forward 8, backward 4: measured
+    // best of 2 / 4 / 8 -- more workgroups shorten the passes and lengthen the hand-off, ~40 ns per arrival on one counter)
+    long S = (HW + px * PL - 1) / (px * PL);
+    S = std::min<long>(S, 256 / (N * CG));                    // residency: <= 256 workgroups of <= 128 VGPRs per launch
+    S = std::min<long>(S, std::max(1, 32768 / V));            // the S partials the last arriver folds: <= 128 KB
+    S = std::max<long>(S, 1);
+    int rows = (int)((HW + S - 1) / S);
+    rows = ((rows + PL - 1) / PL) * PL;
+    S = (HW + rows - 1) / rows;
+    if (S > 1 && ws_bytes < INORM_WS_HEADER + (size_t)N * CG * V * sizeof(double) + (size_t)N * CG * S * V * sizeof(float)) return false;
+    ga->S = (int)S; ga->rows = rows; ga->CG = CG; ga->CHg = CHg; ga->CH = CH; ga->CHP = CHP; ga->sh = sh; ga->V = V;
+    return true;
+}
+
+template <bool BWD>
+void inorm_launch(const InFusedArgs& a, int N, hipStream_t st, void* ws, size_t ws_bytes) {
+    InGridArgs ga;
+    if (ws && ws_bytes >= INORM_WS_HEADER + 16384 && gcc_opt(GCC_OPT_INORM_GRID) && inorm_grid_plan(a.C, a.HW, N, BWD ? 4 : 8, ws_bytes, &ga)) {
+        ga.a = a;
+        ga.cnt = (unsigned*)ws;
+        ga.totals = (double*)((char*)ws + INORM_WS_HEADER);
+        ga.partial = (float*)((char*)ws + INORM_WS_HEADER + (size_t)N * ga.CG * ga.V * sizeof(double));
+        ga.clk = (gcc_opt(GCC_OPT_DEBUG) & 32) ? (unsigned long long*)((char*)ws + ws_bytes - 16384) : nullptr;
+        hipLaunchKernelGGL((inorm_grid_kernel<BWD>), dim3(ga.S, ga.CG, N), dim3(256), 0, st, ga);
+        return;
+    }
     const int lpp_env = gcc_opt(GCC_OPT_INORM_LPP);
     const int lpp = lpp_env ? lpp_env : 2;
     const int slabs = ((a.C + 7) / 8 + lpp - 1) / lpp;
@@ -1078,7 +1434,7 @@ extern "C" int gcc_in_finalize(const float* stats_partial, int tiles_per_group, 
 
 extern "C" int gcc_inorm_fwd(const void* x, int ldx, void* y, int ldy, const void* residual, int ldr, int C, int HW, int N,
                              int act, float slope, float eps, float* mean, float* rstd, float* scale, float* shift,
-                             gcc_stream_t stream) {
+                             void* workspace, size_t workspace_bytes, gcc_stream_t stream) {
     GCC_ENTER();
     if (!x || !y || !mean || !rstd || !scale || !shift || C <= 0 || HW <= 0 || N <= 0 || (ldx & 7) || (ldy & 7) ||
         (residual && (ldr & 7)))
@@ -1086,13 +1442,14 @@ extern "C" int gcc_inorm_fwd(const void* x, int ldx, void* y, int ldy, const voi
     InFusedArgs a = {};
     a.x = (const bf16_t*)x; a.ldx = ldx; a.out = (bf16_t*)y; a.ldout = ldy; a.aux = (const bf16_t*)residual; a.ldaux = ldr;
     a.C = C; a.HW = HW; a.act = act; a.slope = slope; a.eps = eps; a.mean = mean; a.rstd = rstd; a.scale = scale; a.shift = shift;
-    inorm_launch<false>(a, N, (hipStream_t)stream);
+    inorm_launch<false>(a, N, (hipStream_t)stream, workspace, workspace_bytes);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }
 
 extern "C" int gcc_inorm_bwd(const void* x, int ldx, const void* y, int ldy, const void* g, int ldg, void* dx, int lddx, int C,
-                             int HW, int N, int act, float slope, const float* mean, const float* rstd, gcc_stream_t stream) {
+                             int HW, int N, int act, float slope, const float* mean, const float* rstd, void* workspace,
+                             size_t workspace_bytes, gcc_stream_t stream) {
     GCC_ENTER();
     if (!x || !g || !dx || !mean || !rstd || C <= 0 || HW <= 0 || N <= 0 || (ldx & 7) || (ldg & 7) || (lddx & 7) ||
         (y && (ldy & 7)))
@@ -1101,7 +1458,7 @@ extern "C" int gcc_inorm_bwd(const void* x, int ldx, const void* y, int ldy, con
     a.x = (const bf16_t*)x; a.ldx = ldx; a.y = (const bf16_t*)y; a.ldy = ldy; a.aux = (const bf16_t*)g; a.ldaux = ldg;
     a.out = (bf16_t*)dx; a.ldout = lddx; a.C = C; a.HW = HW; a.act = act; a.slope = slope;
     a.mean = (float*)mean; a.rstd = (float*)rstd;
-    inorm_launch<true>(a, N, (hipStream_t)stream);
+    inorm_launch<true>(a, N, (hipStream_t)stream, workspace, workspace_bytes);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

@@ -628,7 +628,18 @@ def in_finalize(stats, count, st, eps=1e-5):
                                 st.scale.data_ptr(), st.shift.data_ptr(), stream()), 'gcc_in_finalize')
 
 
-INORM_FUSED_MAX_HW = int(os.environ.get('GCC_INORM_FUSED_MAX_HW', '4096'))   # planes up to 64 x 64: one-launch InstanceNorm
+INORM_FUSED_MAX_HW = int(os.environ.get('GCC_INORM_FUSED_MAX_HW', str(1 << 20)))   # planes above this take the three-pass route
+INORM_WS_BYTES = 4096 + (3 << 19)      # include/gcc_hip.h: GCC_INORM_WORKSPACE_BYTES
+_inorm_ws = {}
+
+
+def inorm_workspace(device):
+    """zero-filled once, one per stream (gcc_inorm_fwd's workspace contract: its in-launch barrier counts in it)"""
+    key = (device, stream())
+    ws = _inorm_ws.get(key)
+    if ws is None:
+        ws = _inorm_ws[key] = torch.zeros(INORM_WS_BYTES, dtype=torch.uint8, device=device)
+    return ws
 
 
 def inorm_fwd(x, y, st, act=ACT_NONE, slope=0.2, residual=None, eps=1e-5):
@@ -638,8 +649,9 @@ def inorm_fwd(x, y, st, act=ACT_NONE, slope=0.2, residual=None, eps=1e-5):
     rp, ldr = (None, 0)
     if residual is not None:
         rp, _, _, _, _, ldr = geom(residual)
+    ws = inorm_workspace(x.device)
     check(lib().gcc_inorm_fwd(xp, ldx, yp, ldy, rp, ldr, Cc, H * W, N, act, slope, eps, st.mean.data_ptr(), st.rstd.data_ptr(),
-                              st.scale.data_ptr(), st.shift.data_ptr(), stream()), 'gcc_inorm_fwd')
+                              st.scale.data_ptr(), st.shift.data_ptr(), ws.data_ptr(), ws.numel(), stream()), 'gcc_inorm_fwd')
 
 
 def inorm_bwd(x, y, g, dx, st, act=ACT_NONE, slope=0.2):
@@ -649,8 +661,9 @@ def inorm_bwd(x, y, g, dx, st, act=ACT_NONE, slope=0.2):
         yp, _, _, _, _, ldy = geom(y)
     gp, _, _, _, _, ldg = geom(g)
     dxp, _, _, _, _, lddx = geom(dx)
+    ws = inorm_workspace(x.device)
     check(lib().gcc_inorm_bwd(xp, ldx, yp, ldy, gp, ldg, dxp, lddx, Cc, H * W, N, act, slope, st.mean.data_ptr(),
-                              st.rstd.data_ptr(), stream()), 'gcc_inorm_bwd')
+                              st.rstd.data_ptr(), ws.data_ptr(), ws.numel(), stream()), 'gcc_inorm_bwd')
 
 
 def bnact_fwd(x, y, y2=None, scale=None, shift=None, gate=None, gate_after_act=False, act=ACT_NONE, slope=0.2,

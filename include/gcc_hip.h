@@ -94,6 +94,7 @@ enum {
                                    kernel re-stages the pixels for every tap */
     GCC_OPT_FUSE_BN_PARTIAL_KB, /* gcc_conv_bn_act: cap (KB of fp32 partial tiles, default 4096) on the K split of the layers whose fold + statistics +
                                    normalise run as one kernel: every slice is another copy of the output that kernel reads back */
+    GCC_OPT_INORM_GRID,         /* 1 (default): gcc_inorm_fwd / _bwd with a workspace split an image's plane over workgroups (in-launch barrier); 0: slab kernels */
     GCC_OPT_DEBUG,              /* 0 (default).  Diagnostic ablations for timing only -- RESULTS ARE WRONG when set: bit 1 (2) the main loops issue
                                    no staging loads after the first step, bit 2 (4) they re-load the first step's addresses */
     GCC_OPT_COUNT_
@@ -229,16 +230,20 @@ int gcc_bn_finalize(const float* stats_partial, int tiles, int C, double count, 
  * and channel mean / rstd from [groups][tiles_per_group][2][C] partial sums (conv epilogue or gcc_channel_stats) */
 int gcc_in_finalize(const float* stats_partial, int tiles_per_group, int groups, int C, double count, float eps,
                     float* mean, float* rstd, float* scale, float* shift, gcc_stream_t stream);
-/* The same InstanceNorm (+ activation, + residual added after it) in one launch for planes small enough that a workgroup
- * per (image, 8-channel slab) is the faster shape (batch 1: models/CycleGAN.py:77-138 at 64x64 / 128x128): statistics,
- * mean / rstd / scale / shift [N][C] written for the backward, y = act((x - mean) rstd) + residual. */
+/* The same InstanceNorm (+ activation, + residual added after it) in one launch: statistics, mean / rstd / scale / shift [N][C]
+ * written for the backward, y = act((x - mean) rstd) + residual (models/CycleGAN.py:77-138 at batch 1).  With a workspace the
+ * plane of an image is split over up to 256 / N workgroups (pixel ranges x 64-channel groups) that meet at an in-launch barrier; without one (NULL) a workgroup
+ * owns a whole (image, 16-channel slab).  Workspace contract: GCC_INORM_WORKSPACE_BYTES bytes, zero-filled once by the
+ * caller when it is allocated, used by ONE stream (calls on it are ordered); every call leaves its arrival words zero. */
+#define GCC_INORM_WORKSPACE_BYTES ((size_t)4096 + ((size_t)3 << 19))
 int gcc_inorm_fwd(const void* x, int ldx, void* y, int ldy, const void* residual, int ld_residual, int C, int HW, int N,
                   int act, float slope, float eps, float* mean, float* rstd, float* scale, float* shift,
-                  gcc_stream_t stream);
+                  void* workspace, size_t workspace_bytes, gcc_stream_t stream);
 /* its backward: dx = rstd (dz - mean(dz) - xhat mean(dz xhat)) with dz = g act'(y) (y NULL: the activation output is
  * recomputed from x); dx may alias g. */
 int gcc_inorm_bwd(const void* x, int ldx, const void* y, int ldy, const void* g, int ldg, void* dx, int lddx, int C, int HW,
-                  int N, int act, float slope, const float* mean, const float* rstd, gcc_stream_t stream);
+                  int N, int act, float slope, const float* mean, const float* rstd, void* workspace, size_t workspace_bytes,
+                  gcc_stream_t stream);
 int gcc_channel_stats_tiles(size_t pixels_per_group, int C);
 int gcc_channel_stats(const void* x, int ld, int off, int C, size_t pixels_per_group, int groups, float* stats,
                       gcc_stream_t stream);

@@ -854,11 +854,31 @@ def test_instance_norm_forward_backward(C, relu, res):
     close(to_cpu(dx), xr.grad, tol=2e-2, what='instance norm bwd')
 
 
+@pytest.mark.parametrize('grid', [1, 0])
 @pytest.mark.parametrize('C,H,W,relu,res', [(12, 8, 6, True, False), (8, 5, 7, False, True), (40, 64, 64, True, False),
-                                            (16, 64, 72, False, True), (24, 128, 128, True, False)])
-def test_instance_norm_one_launch(C, H, W, relu, res):
-    """gcc_inorm_fwd / gcc_inorm_bwd (one workgroup per image x 8-channel slab) against torch's instance_norm, and
-    against the three-launch pipeline they replace for small planes"""
+                                            (16, 64, 72, False, True), (24, 128, 128, True, False), (256, 64, 64, True, True),
+                                            (96, 64, 64, False, False), (512, 32, 31, True, False), (1032, 16, 16, True, False),
+                                            (64, 256, 256, True, False), (3, 33, 17, False, False)])
+def test_instance_norm_one_launch(C, H, W, relu, res, grid):
+    """gcc_inorm_fwd / gcc_inorm_bwd against torch's instance_norm, and against the three-launch pipeline they replace:
+    grid=1 the plane of an image split over workgroups that meet at an in-launch barrier (C = 1032 is beyond its plan and
+    stays with the slab kernel), grid=0 one workgroup per image x 16-channel slab.  Every call is made twice: the barrier's
+    counters must be back at zero after a launch."""
+    _run_instance_norm_one_launch(C, H, W, relu, res, grid)
+
+
+def _run_instance_norm_one_launch(C, H, W, relu, res, grid):
+    ops = _ops()
+    from gcc_amd import _lib
+    lib = _lib.load()
+    lib.gcc_set_option(_lib.OPT_INORM_GRID, grid)
+    try:
+        _instance_norm_one_launch_body(ops, C, H, W, relu, res)
+    finally:
+        lib.gcc_set_option(_lib.OPT_INORM_GRID, -1)
+
+
+def _instance_norm_one_launch_body(ops, C, H, W, relu, res):
     ops = _ops()
     g = torch.Generator().manual_seed(C + H)
     N = 2
@@ -875,13 +895,15 @@ def test_instance_norm_one_launch(C, H, W, relu, res):
     xd = to_dev(x)
     st = ops.INState(N, C, DEV)
     y = ops.new_act(N, C, H, W, DEV)
-    ops.inorm_fwd(xd, y, st, act=act, residual=to_dev(r) if res else None)
+    for _ in range(2):
+        ops.inorm_fwd(xd, y, st, act=act, residual=to_dev(r) if res else None)
     close(to_cpu(y), yref.detach(), what='one-launch instance norm fwd')
+    assert int(ops.inorm_workspace(xd.device)[:4096].view(torch.int32)[0::4].abs().sum()) == 0, 'arrival words not re-armed'
     close(st.mean.cpu(), x.mean((2, 3)), tol=1e-4, floor=1e-5, what='IN mean')
     close(st.rstd.cpu(), 1.0 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5), tol=1e-4, what='IN rstd')
     st3 = ops.INState(N, C, DEV)
     ops.in_finalize(ops.channel_stats(xd), H * W, st3)
-    assert torch.allclose(st.scale, st3.scale, rtol=2e-6, atol=1e-7) and torch.allclose(st.shift, st3.shift, rtol=2e-5, atol=1e-6)
+    assert torch.allclose(st.scale, st3.scale, rtol=4e-6, atol=1e-7) and torch.allclose(st.shift, st3.shift, rtol=4e-5, atol=2e-6)
     gd = to_dev(gy)
     dx = ops.new_act(N, C, H, W, DEV)
     ops.inorm_bwd(xd, None if res else y, gd, dx, st, act=act)
