@@ -622,8 +622,11 @@ class PatchGANEngine:
         for li in range(1, L - 1):
             if self.inorm[li]:
                 self.conv[li].forward(src, c.c[li])
-                ops.in_finalize(ops.channel_stats(c.c[li]), c.hs[li][0] * c.hs[li][1], c.st[li])
-                ops.bnact_fwd(c.c[li], c.y[li], scale=c.st[li].scale, shift=c.st[li].shift, act=ACT_LRELU, groups=c.N)
+                if c.hs[li][0] * c.hs[li][1] <= ops.INORM_FUSED_MAX_HW:      # statistics + normalisation in one launch
+                    ops.inorm_fwd(c.c[li], c.y[li], c.st[li], act=ACT_LRELU)
+                else:
+                    ops.in_finalize(ops.channel_stats(c.c[li]), c.hs[li][0] * c.hs[li][1], c.st[li])
+                    ops.bnact_fwd(c.c[li], c.y[li], scale=c.st[li].scale, shift=c.st[li].shift, act=ACT_LRELU, groups=c.N)
             else:
                 _, stats = self.conv[li].forward(src, c.c[li], want_stats=True)
                 n = c.N * c.hs[li][0] * c.hs[li][1]
@@ -668,7 +671,10 @@ class PatchGANEngine:
                 g1, g2 = g2, None
             gate = self.gate[li]
             if self.inorm[li]:
-                ops.bnact_bwd(c.c[li], c.y[li], g1, G.layer[li], g2=g2, bn=c.st[li], act=ACT_LRELU, act2=ACT_LRELU, groups=c.N)
+                if g2 is None and c.hs[li][0] * c.hs[li][1] <= ops.INORM_FUSED_MAX_HW:
+                    ops.inorm_bwd(c.c[li], c.y[li], g1, G.layer[li], c.st[li], act=ACT_LRELU)
+                else:
+                    ops.bnact_bwd(c.c[li], c.y[li], g1, G.layer[li], g2=g2, bn=c.st[li], act=ACT_LRELU, act2=ACT_LRELU, groups=c.N)
             else:
                 bn = self.bn[li].bn
                 ops.bnact_bwd(c.c[li], None, g1, G.layer[li], g2=g2, bn=c.st[li], gamma=bn.weight.data, beta=bn.bias.data,
