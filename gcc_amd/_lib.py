@@ -101,6 +101,20 @@ PROTOTYPES = {
     'gcc_nhwc_add': (_I, [_P, _I, _I, _P, _I, _I, _I, _Z, _P]),
     'gcc_bn_finalize': (_I, [_P, _I, _I, C.c_double, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     'gcc_in_finalize': (_I, [_P, _I, _I, _I, C.c_double, _F, _P, _P, _P, _P, _P]),
+    'gcc_write_i32': (_I, [_P, _P, _I, _P]),
+    'gcc_image_pool_query': (_I, [_P, _P, _P, _P, _I, _Z, _I, _P]),
+    'gcc_replay_begin': (_I, [_P]),
+    'gcc_replay_end': (_I, [_P, _I]),
+    'gcc_replay_run': (_I, [_P]),
+    'gcc_replay_tag_next': (_I, [_I]),
+    'gcc_replay_patch': (_I, [_P, _I, _I, _P, _Z]),
+    'gcc_replay_info': (C.c_longlong, [_P, _I]),
+    'gcc_replay_destroy': (_I, [_P]),
+    'gcc_event_create': (_I, [_P]),
+    'gcc_event_destroy': (_I, [_P]),
+    'gcc_event_record': (_I, [_P, _P]),
+    'gcc_stream_wait_event': (_I, [_P, _P]),
+    'gcc_adam_factors': (_I, [_F, _F, _I, _P]),
     'gcc_inorm_fwd': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
     'gcc_inorm_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
     'gcc_channel_stats_tiles': (_I, [_Z, _I]),
@@ -144,7 +158,7 @@ PROTOTYPES = {
     'gcc_l1_loss': (_I, [_P, _I, _I, _P, _I, _I, _I, _Z, _F, _P, _I, _P, _I, _I, _P, _Z, _P]),
     'gcc_mse_loss': (_I, [_P, _I, _I, _P, _I, _I, _I, _Z, _F, _P, _I, _P, _I, _I, _P, _Z, _P]),
     'gcc_loss_workspace': (_Z, [_Z, _I]),
-    'gcc_prelu': (_I, [_I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P]),
+    'gcc_prelu': (_I, [_I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _Z, _P]),
     'gcc_maxpool2x2': (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     'gcc_pool_linear_fwd': (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     'gcc_pool_linear_bwd': (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P]),

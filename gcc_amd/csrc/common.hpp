@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <tuple>
+#include <type_traits>
+#include <utility>
 #include "../../include/gcc_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -115,14 +118,43 @@ __device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
 
 // process-wide tuning options (include/gcc_hip.h: gcc_set_option); defined in misc.hip
 int gcc_opt(int id);
-// every kernel launch of the library is counted (gcc_launch_count: bench.py reports launches per step)
+// Every kernel launch of the library goes through gcc_launch: it is counted (gcc_launch_count: bench.py reports launches per
+// step) and, while the calling thread records (gcc_replay_begin, replay.hip), written down with its argument values so that
+// gcc_replay_run can issue it again without the host code in front of it.  The launch itself is hipLaunchKernel on the kernel's
+// host stub -- what `kernel<<<...>>>(...)` compiles to, minus the push / pop of the call configuration.
 void gcc_count_launch();
+struct GccLaunchRec {
+    const void* func; dim3 grid, block; unsigned shmem; hipStream_t stream;
+    int nargs; void* const* args; const unsigned* sizes;
+};
+bool gcc_replay_recording();
+void gcc_replay_record_kernel(const GccLaunchRec& rec);
+// the few non-kernel stream operations of the library, recorded the same way
+hipError_t gcc_memset_async(void* dst, int value, size_t bytes, hipStream_t st);
+hipError_t gcc_memcpy_d2d_async(void* dst, const void* src, size_t bytes, hipStream_t st);
+
+template <typename T> struct GccArgBox { T v; };
+template <typename Tuple, size_t... I>
+static inline void gcc_fill_arg_ptrs(Tuple& t, void** ptrs, unsigned* sizes, std::index_sequence<I...>) {
+    ((ptrs[I] = (void*)&std::get<I>(t).v, sizes[I] = (unsigned)sizeof(std::get<I>(t).v)), ...);
+}
+template <typename... P, typename... A>
+static inline void gcc_launch(void (*kernel)(P...), dim3 grid, dim3 block, unsigned shmem, hipStream_t st, A&&... a) {
+    static_assert(sizeof...(P) == sizeof...(A), "kernel launched with the wrong number of arguments");
+    gcc_count_launch();
+    // the arguments converted to the kernel's parameter types, one box each (hipLaunchKernel takes their addresses)
+    constexpr int NA = (int)sizeof...(P);
+    void* ptrs[NA > 0 ? NA : 1];
+    unsigned sizes[NA > 0 ? NA : 1];
+    auto boxes = std::tuple<GccArgBox<typename std::remove_cv<P>::type>...>{GccArgBox<typename std::remove_cv<P>::type>{static_cast<P>(a)}...};
+    gcc_fill_arg_ptrs(boxes, ptrs, sizes, std::make_index_sequence<sizeof...(P)>{});
+    if (__builtin_expect(gcc_replay_recording(), 0))
+        gcc_replay_record_kernel(GccLaunchRec{(const void*)kernel, grid, block, shmem, st, NA, ptrs, sizes});
+    (void)hipLaunchKernel((const void*)kernel, grid, block, ptrs, shmem, st);
+}
 #undef hipLaunchKernelGGL
-#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                         \
-    do {                                                                                                          \
-        gcc_count_launch();                                                                                       \
-        hipLaunchKernelGGLInternal((kernelName), (numBlocks), (numThreads), (memPerBlock), (streamId), __VA_ARGS__); \
-    } while (0)
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...) \
+    gcc_launch((kernelName), dim3(numBlocks), dim3(numThreads), (unsigned)(memPerBlock), (streamId), __VA_ARGS__)
 
 __host__ __device__ static inline int ceil8(int v) { return (v + 7) & ~7; }
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1344,7 +1344,7 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
             p.pair = 1; p.ksplit = 2; p.kper = cdiv(conv_nk(c, dgrad), 2);
             p.pair_flags = (unsigned int*)ep->workspace;
             p.pair_slab = (float*)((char*)ep->workspace + PAIR_FLAG_BYTES);
-            if (hipMemsetAsync(ep->workspace, 0, PAIR_FLAG_BYTES, st) != hipSuccess) return GCC_ERR_LAUNCH;
+            if (gcc_memset_async(ep->workspace, 0, PAIR_FLAG_BYTES, st) != hipSuccess) return GCC_ERR_LAUNCH;
         }
     }
     float* stats_out = p.stats;

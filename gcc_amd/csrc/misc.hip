@@ -3,6 +3,7 @@
 #include <mutex>
 #include <stdlib.h>
 #include "common.hpp"
+#include <algorithm>
 
 int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const void* w, void* dst, const gcc_epilogue_t* ep,
                        int batch, long src_bstride, long wgt_bstride, long dst_bstride, hipStream_t st);
@@ -727,7 +728,7 @@ extern "C" int gcc_distill_fwd(const void* f, int ldf, int foff, const void* t, 
     hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)(partial + RED_BLOCKS), b2,
                        (double)N * HW * C, 1.f, scal + 1, 0, squared ? 2 : 1);
     GCC_CHECK_LAUNCH();
-    if (hipMemcpyAsync(out2, scal, 2 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return GCC_ERR_LAUNCH;
+    if (gcc_memcpy_d2d_async(out2, scal, 2 * sizeof(float), st) != hipSuccess) return GCC_ERR_LAUNCH;
     return GCC_OK;
 }
 
@@ -755,14 +756,66 @@ extern "C" int gcc_distill_bwd(const void* f, int ldf, int foff, const void* t, 
     return GCC_OK;
 }
 
+// ---- image history of the CycleGAN discriminators (utils/image_pool.py:5-54) on the device ---------------------------------
+// The reference draws, per image, whether the discriminator sees the new fake or an older one from a 50-image history that the
+// new one then replaces.  The draws stay on the host (Python's `random`, the reference's order); what they decided travels as
+// two ints per image -- mode (0 pass through, 1 store and pass through, 2 swap with slot) and slot -- written by a launch that
+// takes them BY VALUE (gcc_write_i32: a recording patches that one argument per iteration), and one kernel moves the pixels.
+struct I32x16 { int v[16]; };
+__global__ void write_i32_kernel(int* dst, I32x16 vals, int n) {
+    if (threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+extern "C" int gcc_write_i32(int* dst, const int* values, int n, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!dst || !values || n < 1 || n > 16) return GCC_ERR_BAD_ARG;
+    I32x16 v = {};
+    for (int i = 0; i < n; i++) v.v[i] = values[i];
+    hipLaunchKernelGGL(write_i32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, v, n);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+__global__ __launch_bounds__(256) void image_pool_kernel(const i32x4* __restrict__ src, i32x4* __restrict__ out, i32x4* pool,
+                                                         const int* __restrict__ sel, size_t hw) {
+    const int n = blockIdx.y;
+    const int mode = sel[2 * n], slot = sel[2 * n + 1];
+    const i32x4* s = src + n * hw;
+    i32x4* o = out + n * hw;
+    i32x4* p = pool + (size_t)slot * hw;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (size_t)gridDim.x * 256) {
+        const i32x4 v = s[i];
+        if (mode == 0) { o[i] = v; }
+        else if (mode == 1) { p[i] = v; o[i] = v; }
+        else { const i32x4 old = p[i]; p[i] = v; o[i] = old; }
+    }
+}
+// images / out: [N][HW][8] bf16 (3 channels in one 16-byte group), pool: [slots][HW][8], sel: device [N][2] = (mode, slot)
+extern "C" int gcc_image_pool_query(const void* images, void* out, void* pool, const int* sel, int N, size_t HW, int slots,
+                                    gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!images || !out || !pool || !sel || N < 1 || HW == 0 || slots < 1) return GCC_ERR_BAD_ARG;
+    const int bx = (int)std::min<size_t>((HW + 255) / 256, 128);
+    hipLaunchKernelGGL(image_pool_kernel, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, (const i32x4*)images, (i32x4*)out,
+                       (i32x4*)pool, sel, HW);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+extern "C" int gcc_adam_factors(float beta1, float beta2, int step, float* out2) {
+    if (!out2 || step < 1) return GCC_ERR_BAD_ARG;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    out2[0] = (float)bc1; out2[1] = (float)sqrt(bc2);
+    return GCC_OK;
+}
+
 extern "C" int gcc_adam_step(const gcc_adam_tensor_t* tensors, const gcc_adam_chunk_t* chunks, int nchunks, int chunk_elems,
                              float lr, float beta1, float beta2, float eps, int step, gcc_stream_t stream) {
     GCC_ENTER();
     if (!tensors || !chunks || nchunks <= 0 || chunk_elems <= 0 || step < 1) return GCC_ERR_BAD_ARG;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    float f[2];
+    gcc_adam_factors(beta1, beta2, step, f);
     hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, tensors, chunks, chunk_elems, lr, beta1,
-                       beta2, eps, (float)bc1, (float)sqrt(bc2));
+                       beta2, eps, f[0], f[1]);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

@@ -194,7 +194,7 @@ extern "C" int gcc_spectral_power_iteration(const float* w_bar, float* u, float*
     const size_t n = (size_t)R * K;
     hipLaunchKernelGGL(sn_scale_kernel, dim3(nblocks(n)), dim3(256), 0, st, w_bar, (const float*)scal, w_eff, n);
     GCC_CHECK_LAUNCH();
-    if (hipMemcpyAsync(sigma_out, scal + 2, sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return GCC_ERR_LAUNCH;
+    if (gcc_memcpy_d2d_async(sigma_out, scal + 2, sizeof(float), st) != hipSuccess) return GCC_ERR_LAUNCH;
     return GCC_OK;
 }
 

@@ -21,6 +21,7 @@ __device__ __forceinline__ float block_sum256(float v, float* sh) {
 struct PreluArgs {
     const bf16_t* x; int ldx; bf16_t* y; int ldy; const float* slope; int C; int N, H, W, r;
     const bf16_t* dy; int lddy; bf16_t* dx; int lddx; float* dslope;
+    float* partial; unsigned* counter;        // backward with a workspace: per-block partial sums of dslope, arrival counter
 };
 
 template <bool BWD>
@@ -93,7 +94,33 @@ __global__ __launch_bounds__(256) void prelu_kernel(const PreluArgs a) {
     }
     if (BWD && a.dslope) {
         const float t = block_sum256(ds, sh);
-        if (threadIdx.x == 0) atomicAdd(a.dslope, t);
+        if (!a.partial) {                               // no workspace: the sum's order is the blocks' arrival order
+            if (threadIdx.x == 0) atomicAdd(a.dslope, t);
+            return;
+        }
+        // Deterministic form (round 3: an eager and a replayed iteration must agree to the bit, and so must two runs): every
+        // block leaves its partial (write-through store), the last one to arrive folds them in index order and adds the total
+        // to the gradient -- one block, one read-modify-write.  The counter is zero before and after the launch.
+        typedef __attribute__((address_space(1))) unsigned int gu32;
+        gu32* cnt = (gu32*)a.counter;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.partial, 0, gridDim.x * 4, 0x00020000);
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), rs, blockIdx.x * 4, 0, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            sh[0] = __uint_as_float(__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        __syncthreads();
+        const bool last = __float_as_uint(sh[0]) == gridDim.x - 1;
+        __syncthreads();
+        if (!last) return;
+        float acc = 0.f;
+        for (unsigned b = threadIdx.x; b < gridDim.x; b += 256)
+            acc += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, b * 4, 0, 16));
+        const float total = block_sum256(acc, sh);
+        if (threadIdx.x == 0) {
+            a.dslope[0] += total;
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -200,7 +227,8 @@ int grid_for(size_t items, int cap = 4096) {
 }  // namespace
 
 extern "C" int gcc_prelu(int backward, const void* x, int ldx, const float* slope, int C, int N, int H, int W, int shuffle,
-                         void* y, int ldy, const void* dy, int lddy, void* dx, int lddx, float* dslope, gcc_stream_t stream) {
+                         void* y, int ldy, const void* dy, int lddy, void* dx, int lddx, float* dslope, void* workspace,
+                         size_t workspace_bytes, gcc_stream_t stream) {
     GCC_ENTER();
     if (!x || !slope || C <= 0 || N <= 0 || H <= 0 || W <= 0 || (shuffle != 1 && shuffle != 2)) return GCC_ERR_BAD_ARG;
     if (backward ? (!dy || !dx) : !y) return GCC_ERR_BAD_ARG;
@@ -210,6 +238,11 @@ extern "C" int gcc_prelu(int backward, const void* x, int ldx, const float* slop
     a.x = (const bf16_t*)x; a.ldx = ldx; a.y = (bf16_t*)y; a.ldy = ldy; a.slope = slope; a.C = C; a.N = N; a.H = H; a.W = W;
     a.r = shuffle; a.dy = (const bf16_t*)dy; a.lddy = lddy; a.dx = (bf16_t*)dx; a.lddx = lddx; a.dslope = dslope;
     const size_t items = (size_t)N * H * W * ((C + 7) / 8);
+    a.partial = nullptr; a.counter = nullptr;
+    if (backward && dslope && workspace && workspace_bytes >= 256 + 4 * (size_t)grid_for(items)) {
+        a.counter = (unsigned*)workspace;
+        a.partial = (float*)((char*)workspace + 256);
+    }
     if (backward) hipLaunchKernelGGL(prelu_kernel<true>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(prelu_kernel<false>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, a);
     GCC_CHECK_LAUNCH();

@@ -129,6 +129,7 @@ class ConvOp:
         ops.conv_bn_act(dgrad, x, w, raw, self.k, self.stride, self.pad, bnop.bn, st, count, y, y2, act=act, act2=act2,
                         slope=LRELU, drop_p=drop_p, seed=seed)
         bnop.pending_batches += 1
+        ops.note_host(bnop)
 
     # -- gradient w.r.t. the layer input ------------------------------------------------------
     def backward_data(self, dy, out):
@@ -174,12 +175,16 @@ class BNOp:
             self.bn.num_batches_tracked += self.pending_batches
             self.pending_batches = 0
 
+    def replay_update(self, rec, tag):
+        self.pending_batches += 1          # one more training-mode application inside a replayed iteration
+
     def finalize(self, stats, count, st, train):
         bn = self.bn
         if train:
             ops.bn_finalize(stats, count, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, st,
                             eps=bn.eps, momentum=bn.momentum)
             self.pending_batches += 1
+            ops.note_host(self)
         else:
             ops.bn_eval_coeffs(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, st, eps=bn.eps)
 

@@ -51,31 +51,53 @@ class MaskNLayerDiscriminator(nn.Module):
 
 class ImagePool:
     """utils/image_pool.py:5-54 on device buffers: the history holds NHWC bf16 images; the random draws are Python's
-    ``random`` in the reference's order (uniform per image once full, randint on a swap)."""
+    ``random`` in the reference's order (uniform per image once full, randint on a swap).  What the draws decided goes to the
+    device as (mode, slot) per image, carried by a launch that takes them by value, and one kernel moves the pixels
+    (gcc_image_pool_query): the iteration's launch sequence does not depend on the draws, so it can be recorded and
+    replayed (gcc_amd.replay) with that one argument patched per iteration."""
 
     def __init__(self, pool_size):
         self.pool_size = pool_size
-        self.images = []
+        self.count = 0              # images held
+        self.store = None           # [pool_size, 3, H, W] NHWC bf16
+        self.sel = None             # device int32 [N][2]
+        self._n = 0
+
+    def _draw(self, N):
+        """(mode, slot) per image: 0 pass through, 1 store in `slot` and pass through, 2 swap with `slot`"""
+        sel = []
+        for _ in range(N):
+            if self.pool_size == 0:
+                sel += [0, 0]
+            elif self.count < self.pool_size:
+                sel += [1, self.count]
+                self.count += 1
+            elif random.uniform(0, 1) > 0.5:
+                sel += [2, random.randint(0, self.pool_size - 1)]
+            else:
+                sel += [0, 0]
+        return sel
 
     def query(self, images, out):
         """images: NHWC bf16 batch view [N,3,H,W]; out: batch buffer of the same geometry that receives the answer"""
-        N = images.shape[0]
-        for i in range(N):
-            src, dst = images[i:i + 1], out[i:i + 1]
-            if self.pool_size == 0:
-                ops.nhwc_copy(src, 0, dst, 0, 3)
-            elif len(self.images) < self.pool_size:
-                keep = ops.new_act(1, 3, images.shape[2], images.shape[3], images.device)
-                ops.nhwc_copy(src, 0, keep, 0, 3)
-                self.images.append(keep)
-                ops.nhwc_copy(src, 0, dst, 0, 3)
-            elif random.uniform(0, 1) > 0.5:
-                j = random.randint(0, self.pool_size - 1)
-                ops.nhwc_copy(self.images[j], 0, dst, 0, 3)
-                ops.nhwc_copy(src, 0, self.images[j], 0, 3)
-            else:
-                ops.nhwc_copy(src, 0, dst, 0, 3)
+        N, _, H, W = images.shape
+        assert N <= 8, 'the draws of a batch travel in one launch argument (16 ints)'
+        if self.store is None:
+            self.store = ops.new_act(max(self.pool_size, 1), 3, H, W, images.device)
+            self.sel = torch.zeros(16, dtype=torch.int32, device=images.device)
+        self._n = N
+        ops.note_dynamic(self)
+        ops.write_i32(self.sel, self._draw(N))
+        ops.image_pool_query(images, out, self.store, self.sel)
         return out
+
+    def replay_update(self, rec, tag):
+        """the draws of one more iteration into the recorded gcc_write_i32 launch (its by-value argument 1)"""
+        import ctypes as C
+        vals = (C.c_int * 16)(*self._draw(self._n))
+        n = ops.lib().gcc_replay_patch(rec, tag, 1, vals, 64)
+        if n != 1:
+            raise RuntimeError('gcc_replay_patch(image pool tag %d): %d launches patched' % (tag, n))
 
 
 class _Half:
@@ -88,6 +110,8 @@ class _Half:
 
 
 class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
+
+    teacher_thread = True         # launch-bound at its batch size: the teacher's step is enqueued by a second host thread (_streams.py)
 
     def __init__(self, opt, cfg_AtoB=None, cfg_BtoA=None):
         super().__init__()
@@ -382,10 +406,11 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
             def teacher_step():
                 T.set_input(self.input)
                 T.optimize_parameters()
+                # the reference clones; here the teacher's activation buffers are not overwritten before they are consumed
+                # (read by the student after _join: the step may be enqueued by the teacher's host thread)
+                self.target_distillation_A_features = T.get_distillation_features(AorB='A')
+                self.target_distillation_B_features = T.get_distillation_features(AorB='B')
             ts = self._run_teacher(teacher_step)
-            # the reference clones; here the teacher's activation buffers are not overwritten before they are consumed
-            self.target_distillation_A_features = T.get_distillation_features(AorB='A')
-            self.target_distillation_B_features = T.get_distillation_features(AorB='B')
         self.forward()
         self.optimizer_G.zero_grad()
         self.backward_G(ts)

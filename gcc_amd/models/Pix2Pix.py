@@ -488,7 +488,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             return
         main = ops.current_stream()
         self.D.refresh_masks() if self.D.masked else None
-        aux.wait_stream(main)
+        ops.wait_stream(aux, main)
         with ops.on_stream(aux):
             N, _, H, W = self._A.shape
             ctx = self.D.new_ctx(N, H, W, tag)
@@ -502,7 +502,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         if got is None:
             return self._d_forward(tag, self._B)
         ctx, aux = got
-        ops.current_stream().wait_stream(aux)
+        ops.wait_stream(ops.current_stream(), aux)
         self.D.apply_deferred_running(ctx)
         return ctx
 
@@ -581,9 +581,9 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         if ts:
             ev = getattr(self.teacher_model, '_head_done', None) if EARLY_JOIN else None
             if ev is not None:
-                ops.current_stream().wait_event(ev)
+                ops.wait_event(ops.current_stream(), ev)
             else:
-                ops.current_stream().wait_stream(ts)
+                ops.wait_stream(ops.current_stream(), ts)
         if self.distill:
             T = self.teacher_model
             # teacher D (train mode, frozen) on the student's fake: features for the last two terms (:531-533)
@@ -691,8 +691,9 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         yield from self._pre_join_steps()
         # everything a student reads from this model is final here: the generator's features (forward), the discriminator's
         # weights (its Adam step + repack) and features (the D(fake) pass of backward_G's head)
-        self._head_done = torch.cuda.Event()
-        self._head_done.record(ops.current_stream())
+        if getattr(self, '_head_done', None) is None:
+            self._head_done = ops.Event()
+        self._head_done.record()
         yield
         self._backward_G_tail(None)
         if self._defer_G_update and self._world > 1:
@@ -754,7 +755,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             T.get_D_arch_diff(isTeacher=True)
         cf, cr = self.get_D_arch_diff(isTeacher=False)
         if ts:
-            ops.current_stream().wait_stream(ts)          # the teacher's difference was computed on its stream
+            ops.wait_stream(ops.current_stream(), ts)          # the teacher's difference was computed on its stream
         ops.scalar_op(2, T._l('teacher_D_arch_diff'), T._l('teacher_D_arch_diff'), self._l('teacher_D_arch_diff'), k0=0.0)
         self._mark_teacher_free()
         # loss_D_arch = |d_S - d_T| + (L_real + L_fake)/2 ; coefficients of the three hinge gradients

@@ -141,6 +141,8 @@ def _is_dup(name):
 
 class SAGANModel(TeacherStreamMixin, nn.Module):
 
+    teacher_thread = True         # launch-bound at its batch size: the teacher's step is enqueued by a second host thread (_streams.py)
+
     def __init__(self, opt, filter_cfgs=None, channel_cfgs=None):
         super().__init__()
         self.opt = opt
@@ -352,8 +354,8 @@ class SAGANModel(TeacherStreamMixin, nn.Module):
             def teacher_step():
                 T.set_input(self.input)
                 T.optimize_parameters()
+                self.target_distillation_features = T.get_distillation_features()     # read after _join
             ts = self._run_teacher(teacher_step)
-            self.target_distillation_features = T.get_distillation_features()
         self.forward()
         self.optimizer_D.zero_grad()
         self.backward_D()

@@ -432,8 +432,8 @@ class SRGAN(TeacherStreamMixin, nn.Module):
             def teacher_step():
                 T.set_input(self.input)
                 T.optimize_parameters()
+                self.target_distillation_features = T.get_distillation_features()     # read after _join
             ts = self._run_teacher(teacher_step)
-            self.target_distillation_features = T.get_distillation_features()
         self.forward()
         self.optimizer_G.zero_grad()
         self.backward_G(ts)

@@ -5,8 +5,16 @@ enqueued on two streams; the student's stream joins the teacher's where the teac
 teacher's stream is released by an event recorded at the last main-stream launch that reads its buffers.  The many small
 layers of the two networks, which cannot fill 256 CUs alone, overlap; the arithmetic is unchanged.
 ``GCC_CONCURRENT_TEACHER=0`` (or ``model.serialize_streams = True``, used by bench.py's profiled steps) keeps everything
-on one stream."""
+on one stream.
+
+Host side (round 3): the launch-bound models (CycleGAN at batch 1: ~4 200 launches of 6.8 us of host time per iteration,
+host enqueue time = iteration time) hand the teacher's step to a second host thread.  ctypes releases the GIL inside every
+library call, so the ~4.3 us `hipLaunchKernel` halves of the two threads' launches overlap; the Python halves still take
+turns.  A model class opts in with ``teacher_thread = True`` (``GCC_TEACHER_THREAD=0/1`` overrides for every class); never
+under data parallelism (RCCL calls of one communicator from two threads)."""
 import os
+import queue
+import threading
 
 import torch
 
@@ -82,8 +90,10 @@ class TeacherStreamMixin:
 
     def _mark_teacher_free(self):
         """main stream: no later launch reads the teacher's buffers -- its stream may move on from here"""
-        self._teacher_free = torch.cuda.Event()
-        self._teacher_free.record(ops.current_stream())
+        ev = getattr(self, '_teacher_free', None)
+        if ev is None:
+            ev = self._teacher_free = ops.Event()      # re-recorded: the teacher's wait holds the record it saw
+        ev.record()
 
     def _note_input(self, input):
         """set_input(): order this stream -- and, through _release_teacher_stream, the teacher's -- behind whatever produced
@@ -98,9 +108,11 @@ class TeacherStreamMixin:
         if dev:
             cur = ops.current_stream()
             if ev is not None:
-                cur.wait_event(ev)
+                ops.wait_event(cur, ev)
             else:
-                ev = torch.cuda.Event()
+                ev = getattr(self, '_own_input_event', None)
+                if ev is None:
+                    ev = self._own_input_event = ops.Event()
                 ev.record(cur)
             for t in dev:
                 t.record_stream(cur)
@@ -109,22 +121,38 @@ class TeacherStreamMixin:
     def _release_teacher_stream(self, ts):
         ev = getattr(self, '_teacher_free', None)
         if ev is not None:
-            ts.wait_event(ev)
+            ops.wait_event(ts, ev)
         else:
-            ts.wait_stream(ops.current_stream())
+            ops.wait_stream(ts, ops.current_stream())
         # the batch the teacher is about to read (set_input on its own stream) must exist: ADVICE r1, race on a
         # device-resident batch written by main-stream kernels after _teacher_free was recorded
         ready = getattr(self, '_input_ready', None)
         if ready is not None:
-            ts.wait_event(ready)
+            ops.wait_event(ts, ready)
+
+    teacher_thread = False        # class default: enqueue the teacher's step from the calling thread
+
+    def _teacher_thread_on(self):
+        env = os.environ.get('GCC_TEACHER_THREAD')
+        on = self.teacher_thread if env is None else env == '1'
+        if ops.RECORDING:               # a recording is the calling thread's: everything is enqueued from it
+            return False
+        if on and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            on = False
+        return on
 
     def _run_teacher(self, fn):
-        """run fn() (teacher work) on the teacher's stream if there is one; returns the stream (or False)"""
+        """run fn() (teacher work) on the teacher's stream if there is one; returns the stream (or False).  With the
+        enqueue thread fn runs there: nothing it writes on the host (the teacher's contexts, target features) may be read
+        before _join(ts)."""
         ts = self._teacher_stream()
         if ts:
             self._release_teacher_stream(ts)
-            with ops.on_stream(ts):
-                fn()
+            if self._teacher_thread_on():
+                _EnqueueThread.get(self.device).submit(fn, ts)
+            else:
+                with ops.on_stream(ts):
+                    fn()
         else:
             fn()
         return ts
@@ -142,4 +170,57 @@ class TeacherStreamMixin:
     @staticmethod
     def _join(ts):
         if ts:
-            ops.current_stream().wait_stream(ts)
+            _EnqueueThread.drain()           # the teacher's launches must all be enqueued before the stream is waited for
+            ops.wait_stream(ops.current_stream(), ts)
+
+
+class _EnqueueThread:
+    """one worker per device that enqueues the teacher's launches on the teacher's stream; drain() returns once everything
+    submitted has been enqueued and re-raises what the step raised"""
+    _inst = {}
+
+    def __init__(self, device):
+        self.device = device
+        self.q = queue.SimpleQueue()
+        self.done = threading.Semaphore(0)
+        self.pending = 0
+        self.error = None
+        self.thread = threading.Thread(target=self._loop, name='gcc-teacher-enqueue', daemon=True)
+        self.thread.start()
+
+    @classmethod
+    def get(cls, device):
+        key = str(device)
+        inst = cls._inst.get(key)
+        if inst is None:
+            inst = cls._inst[key] = _EnqueueThread(device)
+        return inst
+
+    def _loop(self):
+        torch.cuda.set_device(self.device)
+        while True:
+            fn, ts = self.q.get()
+            try:
+                with ops.on_stream(ts):
+                    fn()
+            except BaseException as e:          # handed to the submitting thread at drain()
+                self.error = e
+            self.done.release()
+
+    def submit(self, fn, ts):
+        self._wait()                            # one step at a time: the steps of a model share its host state
+        self.pending += 1
+        self.q.put((fn, ts))
+
+    def _wait(self):
+        while self.pending:
+            self.done.acquire()
+            self.pending -= 1
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
+
+    @classmethod
+    def drain(cls):
+        for inst in cls._inst.values():
+            inst._wait()

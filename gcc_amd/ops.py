@@ -251,6 +251,70 @@ def workspace(nbytes, device, slot='default'):
     return buf
 
 
+class Event:
+    """An event of the library (gcc_event_*, hipEventDisableTiming): records and waits made through it are part of a launch
+    recording (gcc_amd.replay).  Never destroyed: a recording may hold its handle; a process creates a few dozen."""
+    __slots__ = ('h',)
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(lib().gcc_event_create(C.byref(h)), 'gcc_event_create')
+        self.h = h.value
+
+    def record(self, s=None):
+        """s: torch.cuda.Stream (default: the current stream)"""
+        check(lib().gcc_event_record(self.h, s.cuda_stream if s is not None else stream()), 'gcc_event_record')
+
+    def wait(self, s=None):
+        check(lib().gcc_stream_wait_event(s.cuda_stream if s is not None else stream(), self.h), 'gcc_stream_wait_event')
+
+
+def wait_event(s, ev):
+    """stream s waits for ev: an ops.Event, or a torch.cuda.Event handed in from outside (a data loader's 'ready')"""
+    if isinstance(ev, Event):
+        ev.wait(s)
+    else:
+        s.wait_event(ev)
+
+
+_pair_events = {}
+
+
+def wait_stream(s, other):
+    """stream s waits for everything enqueued on `other` so far (torch's Stream.wait_stream through the library's events)"""
+    key = (s.cuda_stream, other.cuda_stream)
+    ev = _pair_events.get(key)
+    if ev is None:
+        ev = _pair_events[key] = Event()
+    ev.record(other)
+    ev.wait(s)
+
+
+def note_host(obj):
+    """host-side bookkeeping of the iteration that no launch carries (BatchNorm's num_batches_tracked count): while
+    recording, obj.replay_update(recording, 0) is asked to repeat it for every replayed iteration"""
+    if RECORDING:
+        _dynamic.append((obj, 0))
+
+
+# True while gcc_amd.replay records an iteration: host-side shortcuts that would hide work from the recording thread (the
+# teacher's enqueue thread) are off, and launches that carry per-iteration scalars announce themselves (note_dynamic)
+RECORDING = False
+_dynamic = []          # while recording: (object, tag) in launch order; object.replay_update(recording, tag) runs before every replay
+_tag_counter = 0
+
+
+def note_dynamic(obj):
+    """call right before a launch whose BY-VALUE arguments change from iteration to iteration (Adam's bias corrections, the
+    image pool's draws): while recording, the launch is tagged and obj.replay_update(recording, tag) is asked to patch it
+    before every replay.  No-op otherwise."""
+    global _tag_counter
+    if RECORDING:
+        _tag_counter += 1
+        lib().gcc_replay_tag_next(_tag_counter)
+        _dynamic.append((obj, _tag_counter))
+
+
 class SideStream:
     """A second HIP stream per device: MFMA-bound weight-gradient kernels run on it while the
     HBM-bound BatchNorm / activation backward chain continues on the main stream."""
@@ -259,7 +323,7 @@ class SideStream:
     def __init__(self, device):
         self.stream = torch.cuda.Stream(device=device)
         self.dirty = False
-        self.ev_fork, self.ev_join = torch.cuda.Event(), torch.cuda.Event()     # re-recorded: a wait holds the record it saw
+        self.ev_fork, self.ev_join = Event(), Event()     # re-recorded: a wait holds the record it saw
 
     @classmethod
     def get(cls, device):
@@ -272,15 +336,15 @@ class SideStream:
 
     def fork(self):
         """everything enqueued on the main stream so far happens-before later side-stream work"""
-        self.ev_fork.record(current_stream())
-        self.stream.wait_event(self.ev_fork)
+        self.ev_fork.record()
+        self.ev_fork.wait(self.stream)
         self.dirty = True
 
     def join(self):
         """the main stream waits for all side-stream work enqueued so far"""
         if self.dirty:
             self.ev_join.record(self.stream)
-            current_stream().wait_event(self.ev_join)
+            self.ev_join.wait()
             self.dirty = False
 
 
@@ -631,6 +695,17 @@ def in_finalize(stats, count, st, eps=1e-5):
 INORM_FUSED_MAX_HW = int(os.environ.get('GCC_INORM_FUSED_MAX_HW', str(1 << 20)))   # planes above this take the three-pass route
 INORM_WS_BYTES = 4096 + (3 << 19)      # include/gcc_hip.h: GCC_INORM_WORKSPACE_BYTES
 _inorm_ws = {}
+_zero_ws = {}
+
+
+def zeroed_workspace(device, slot, nbytes):
+    """zero-filled once, one per (slot, stream): for kernels that count arrivals in their workspace and leave the counter
+    at zero (gcc_prelu's ordered slope-gradient sum)"""
+    key = (device, slot, stream())
+    ws = _zero_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _zero_ws[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    return ws
 
 
 def inorm_workspace(device):
@@ -811,15 +886,17 @@ def prelu_fwd(x, slope, y, shuffle=1):
     """y = prelu(x) (shuffle 1) or prelu(pixel_shuffle(x, 2)): x [N,4C,H,W] -> y [N,C,2H,2W]"""
     xp, N, Cx, H, W, ldx = geom(x)
     yp, _, Cy, _, _, ldy = geom(y)
-    check(lib().gcc_prelu(0, xp, ldx, slope.data_ptr(), Cy, N, H, W, shuffle, yp, ldy, None, 0, None, 0, None, stream()), 'gcc_prelu')
+    check(lib().gcc_prelu(0, xp, ldx, slope.data_ptr(), Cy, N, H, W, shuffle, yp, ldy, None, 0, None, 0, None, None, 0, stream()),
+          'gcc_prelu')
 
 
 def prelu_bwd(x, slope, dy, dx, dslope=None, shuffle=1):
     xp, N, Cx, H, W, ldx = geom(x)
     dyp, _, Cy, _, _, lddy = geom(dy)
     dxp, _, _, _, _, lddx = geom(dx)
+    ws = zeroed_workspace(x.device, 'prelu', 256 + 4 * 4096) if dslope is not None else None
     check(lib().gcc_prelu(1, xp, ldx, slope.data_ptr(), Cy, N, H, W, shuffle, None, 0, dyp, lddy, dxp, lddx, _p(dslope),
-                          stream()), 'gcc_prelu')
+                          _p(ws), ws.numel() if ws is not None else 0, stream()), 'gcc_prelu')
 
 
 def maxpool_fwd(x, y):
@@ -884,6 +961,7 @@ class AdamPlan:
         self.m = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in self.params]
         self.v = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in self.params]
         self.step_count = 0
+        self.last_hyper = None              # (lr, beta1, beta2, eps) of the last step
         self.device = device
         self.l1 = list(l1) if l1 is not None else [0.0] * len(self.params)
         self.grad_scale = 1.0
@@ -914,9 +992,43 @@ class AdamPlan:
 
     def step(self, lr, betas=(0.9, 0.999), eps=1e-8):
         self.step_count += 1
+        self.last_hyper = (float(lr), float(betas[0]), float(betas[1]), float(eps))
+        note_dynamic(self)
         check(lib().gcc_adam_step(self.d_tensors.data_ptr(), self.d_chunks.data_ptr(), self.nchunks, self.CHUNK,
                                   float(lr), float(betas[0]), float(betas[1]), float(eps), self.step_count, stream()),
               'gcc_adam_step')
+
+
+def _adam_replay_update(self, rec, tag):
+    """one more step of this plan inside a replayed iteration: the launch's bias_correction1 / sqrt(bias_correction2)
+    arguments (7 and 8 of adam_kernel, include/gcc_hip.h) for the new step count; lr / betas / eps are the recorded ones"""
+    self.step_count += 1
+    _, b1, b2, _ = self.last_hyper
+    f = (C.c_float * 2)()
+    check(lib().gcc_adam_factors(b1, b2, self.step_count, f), 'gcc_adam_factors')
+    for idx in (0, 1):
+        v = C.c_float(f[idx])
+        n = lib().gcc_replay_patch(rec, tag, 7 + idx, C.byref(v), 4)
+        if n != 1:
+            raise RuntimeError('gcc_replay_patch(adam tag %d): %d launches patched' % (tag, n))
+
+
+AdamPlan.replay_update = _adam_replay_update
+
+
+def write_i32(dst, values):
+    """dst (device int32) [0:len(values)] = values, carried by the launch itself (<= 16)"""
+    arr = (C.c_int * len(values))(*values)
+    check(lib().gcc_write_i32(dst.data_ptr(), arr, len(values), stream()), 'gcc_write_i32')
+
+
+def image_pool_query(images, out, pool, sel):
+    N, _, H, W = images.shape
+    ip, _, _, _, _, ldi = geom(images)
+    op_, _, _, _, _, ldo = geom(out)
+    assert ldi == 8 and ldo == 8 and pool.stride(1) == 1 and pool.shape[1] <= 8
+    check(lib().gcc_image_pool_query(ip, op_, pool.data_ptr(), sel.data_ptr(), N, H * W, pool.shape[0], stream()),
+          'gcc_image_pool_query')
 
 
 def fill(t, v):

@@ -429,12 +429,16 @@ int gcc_attention_bwd(const void* qkv, int ldq, int qoff, int koff, int voff, co
  * gcc_prelu: nn.PReLU() with its single learnable slope (device scalar), optionally fused with the nn.PixelShuffle(2)
  * in front of it (SubPixelConvolutionalBlock, :68-99): shuffle == 2 reads x [N][H][W][4C] and writes y [N][2H][2W][C],
  * y[n][2h+i][2w+j][c] = prelu(x[n][h][w][4c+2i+j]).  backward != 0: dx (layout of x) from dy (layout of y), and
- * dslope (+=, may be NULL: the distillation optimizer of the reference leaves the PReLU slopes out, :349-352).
+ * dslope (+=, may be NULL: the distillation optimizer of the reference leaves the PReLU slopes out, :349-352); with a
+ * workspace (GCC_PRELU_WORKSPACE_BYTES, zero-filled once by the caller, one per stream; its first word is zero again after
+ * every call) the sum behind dslope is formed in a fixed order -- bit-reproducible; without one (NULL) by atomic adds.
  * gcc_maxpool2x2: nn.MaxPool2d(2, 2) of the VGG stack; backward routes to the first maximum in scan order.
  * gcc_pool_linear_*: AdaptiveAvgPool2d((1,1)) + Linear(C, 1) of the discriminators (:245-262): pooled [N][C] fp32 is
  * kept for the backward pass, logit is bf16 [N][ldl] (one pixel per image, as gcc_gan_loss reads it). */
 int gcc_prelu(int backward, const void* x, int ldx, const float* slope, int C, int N, int H, int W, int shuffle,
-              void* y, int ldy, const void* dy, int lddy, void* dx, int lddx, float* dslope, gcc_stream_t stream);
+              void* y, int ldy, const void* dy, int lddy, void* dx, int lddx, float* dslope, void* workspace,
+              size_t workspace_bytes, gcc_stream_t stream);
+#define GCC_PRELU_WORKSPACE_BYTES ((size_t)256 + 4 * 4096)
 int gcc_maxpool2x2(int backward, const void* x, int ldx, void* y, int ldy, const void* dy, int lddy, void* dx, int lddx,
                    int N, int Ho, int Wo, int C, gcc_stream_t stream);
 int gcc_pool_linear_fwd(const void* x, int ldx, int N, int HW, int C, const float* w, const float* b, float* pooled,
@@ -540,6 +544,42 @@ int gcc_comm_destroy(gcc_comm_t* comm);
 /* RCCL's own message for the calling thread's last failing gcc_comm_* call ("" if none failed): a GCC_ERR_LAUNCH from this
  * group otherwise hides which ncclResult it was */
 const char* gcc_comm_last_error(void);
+
+/* CycleGAN's image history (utils/image_pool.py:5-54) on the device: gcc_write_i32 stores n <= 16 ints taken BY VALUE (the
+ * host's random draws: two per image, mode 0 pass through / 1 store and pass through / 2 swap with slot, and the slot);
+ * gcc_image_pool_query moves the pixels: images / out [N][HW][8] bf16, pool [slots][HW][8], sel device [N][2]. */
+int gcc_write_i32(int* dst, const int* values, int n, gcc_stream_t stream);
+int gcc_image_pool_query(const void* images, void* out, void* pool, const int* sel, int N, size_t HW, int slots,
+                         gcc_stream_t stream);
+
+/* ---- launch replay (gcc_amd/csrc/replay.hip) -------------------------------------------------------------------------
+ * The reference leaves the host side of an iteration to PyTorch's eager dispatcher (train.py:128-140 calls
+ * model.optimize_parameters() per batch); here an iteration is a few thousand launches of this library, and for the small
+ * models the HOST's launch rate is the bound.  gcc_replay_begin starts recording on the calling thread: every launch of
+ * the library made by that thread (and its memsets / copies, and gcc_event_record / gcc_stream_wait_event) still executes,
+ * and is written down with its argument values.  gcc_replay_end closes the recording; gcc_replay_run issues it again.
+ * Contract (as for a captured graph): all pointer arguments stay valid and keep their meaning -- inputs are fed through
+ * persistent buffers, the iteration's temporaries live in a pool that nothing else allocates from -- and scalars that change
+ * from iteration to iteration are patched: gcc_replay_tag_next(tag) marks the next launch the thread records,
+ * gcc_replay_patch overwrites one argument of every launch with that tag (gcc_adam_step's launch takes, in this order,
+ * tensors, chunks, chunk_elems, lr, beta1, beta2, eps, bias_correction1, sqrt(bias_correction2): gcc_adam_factors gives
+ * the last two for a step).  threads > 1 at gcc_replay_end: gcc_replay_run issues each HIP stream's launches from its own
+ * host thread (an event wait is issued only after the record it saw while recording).  Not re-entrant per handle. */
+typedef struct gcc_replay gcc_replay_t;
+int gcc_replay_begin(gcc_replay_t** out);
+int gcc_replay_end(gcc_replay_t* r, int threads);
+int gcc_replay_run(gcc_replay_t* r);
+int gcc_replay_tag_next(int tag);
+int gcc_replay_patch(gcc_replay_t* r, int tag, int arg_index, const void* value, size_t bytes);
+long long gcc_replay_info(const gcc_replay_t* r, int what);   /* 0 entries, 1 kernel launches, 2 streams, 3 threads, 4 argument bytes */
+int gcc_replay_destroy(gcc_replay_t* r);
+/* events of the library (hipEventDisableTiming), recorded / waited for through it so that a recording sees them */
+int gcc_event_create(void** event);
+int gcc_event_destroy(void* event);
+int gcc_event_record(void* event, gcc_stream_t stream);
+int gcc_stream_wait_event(gcc_stream_t stream, void* event);
+/* out[0] = 1 - beta1^step, out[1] = sqrt(1 - beta2^step) as gcc_adam_step passes them to its kernel */
+int gcc_adam_factors(float beta1, float beta2, int step, float* out2);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,111 @@
+"""Launch replay (gcc_amd.replay, gcc_replay_* of the C-ABI): an iteration recorded once and re-issued from native code -- on one
+thread and with one host thread per HIP stream -- leaves every parameter, optimizer moment and logged loss BIT-identical to the
+eager host path, over iterations whose Adam factors and image-pool draws differ from the recorded one."""
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+
+
+def _cyclegan():
+    from tests.conftest import GOLDEN
+    from tests.test_pix2pix_gpu import load
+    from tests.test_cyclegan_gpu import _build
+    z = load(GOLDEN, 'cyclegan_gcc.npz')
+    model, teacher, opt = _build(z)
+    g = torch.Generator().manual_seed(5)
+    data = [{'A': torch.rand(1, 3, 64, 64, generator=g) * 2 - 1, 'B': torch.rand(1, 3, 64, 64, generator=g) * 2 - 1,
+             'A_paths': ['a'], 'B_paths': ['b']} for _ in range(4)]
+    return model, teacher, opt, data
+
+
+def _sagan():
+    from tests.conftest import GOLDEN
+    from tests.test_pix2pix_gpu import load
+    from tests.test_sagan_gpu import _build
+    z = load(GOLDEN, 'sagan_gcc.npz')
+    model, teacher, opt = _build(z)
+    g = torch.Generator().manual_seed(6)
+    b = opt.batch_size
+    data = [{'z': torch.randn(b, opt.z_dim, generator=g), 'real_img': torch.rand(b, 3, 64, 64, generator=g) * 2 - 1, 'img_path': [''] * b}
+            for _ in range(4)]
+    return model, teacher, opt, data
+
+
+def _srgan():
+    from tests.conftest import GOLDEN
+    from tests.test_pix2pix_gpu import load
+    from tests.test_srgan_gpu import _build
+    z = load(GOLDEN, 'srgan_gcc.npz')
+    model, teacher, opt = _build(z)
+    g = torch.Generator().manual_seed(7)
+    data = [{'lr': torch.rand(2, 3, 24, 24, generator=g) * 2 - 1, 'hr': torch.rand(2, 3, 96, 96, generator=g) * 2 - 1,
+             'lr_names': ['a'] * 2, 'hr_names': ['b'] * 2} for _ in range(4)]
+    return model, teacher, opt, data
+
+
+def _state(model, teacher):
+    out = {}
+    for tag, m in (('s', model), ('t', teacher)):
+        for k, v in m.state_dict().items():
+            out['%s.%s' % (tag, k)] = v.detach().clone()
+        for name in dir(m):
+            o = getattr(m, name, None)
+            for pn in ('plan', 'plan_dup'):
+                p = getattr(o, pn, None) if name.startswith('optimizer') else None
+                if p is not None:
+                    for i, (a, b) in enumerate(zip(p.m, p.v)):
+                        out['%s.%s.%s.m%d' % (tag, name, pn, i)] = a.detach().clone()
+                        out['%s.%s.%s.v%d' % (tag, name, pn, i)] = b.detach().clone()
+    return out
+
+
+def _run(build, threads, enabled, iters=7):
+    from gcc_amd.replay import IterationReplay
+    random.seed(99)
+    torch.manual_seed(3)
+    model, teacher, opt, data = build()
+    rp = IterationReplay(model, opt, warmup=2, threads=threads, enabled=enabled)
+    modes = []
+    losses = []
+    for i in range(iters):
+        modes.append(rp.step(data[i % 4], data[(i + 1) % 4]))
+        losses.append(dict(model.get_current_losses()))
+    torch.cuda.synchronize()
+    info = rp.info()
+    st = _state(model, teacher)
+    rp.invalidate()
+    return modes, losses, st, info
+
+
+@pytest.mark.parametrize('which', ['cyclegan', 'sagan', 'srgan'])
+def test_replay_is_bit_identical_to_the_eager_iteration(which):
+    build = {'cyclegan': _cyclegan, 'sagan': _sagan, 'srgan': _srgan}[which]
+    m0, l0, s0, _ = _run(build, 1, False)
+    assert set(m0) == {'eager'}
+    for threads in (1, 4):
+        m1, l1, s1, info = _run(build, threads, True)
+        assert m1 == ['eager', 'eager', 'record'] + ['replay'] * 4, m1
+        assert info['launches'] > 100 and info['streams'] >= 2 and info['threads'] == min(threads, info['streams']), info
+        print(which, 'threads', threads, info)
+        assert l1 == l0, 'logged losses differ'
+        assert s0.keys() == s1.keys() and len(s0) > 20
+        bad = [k for k in s0 if not torch.equal(s0[k], s1[k])]
+        assert not bad, 'differ after replay: %s' % bad[:8]
+
+
+def test_replay_invalidate_and_shape_change():
+    """a changed batch shape or invalidate() drops the recording; the next steps run eagerly once and record again"""
+    from gcc_amd.replay import IterationReplay
+    random.seed(1)
+    model, teacher, opt, data = _srgan()
+    rp = IterationReplay(model, opt, warmup=1, threads=1, enabled=True)
+    modes = [rp.step(data[i % 4], data[(i + 1) % 4]) for i in range(4)]
+    assert modes == ['eager', 'record', 'replay', 'replay']
+    rp.invalidate()
+    modes = [rp.step(data[i % 4], data[(i + 1) % 4]) for i in range(3)]
+    assert modes == ['record', 'replay', 'replay'] or modes == ['eager', 'record', 'replay'], modes
+    torch.cuda.synchronize()
