@@ -228,7 +228,8 @@ OTHER_ARGV = {
 def other_configs(warmup=10, steps=30):
     """BASELINE.json configs 3-5 on synthetic batches at the reference scripts' widths (distillation + architecture step on):
     CycleGAN 256x256 batch 1, SAGAN 64x64 batch 64, SRGAN x4 24 -> 96 crops batch 16 (options/options.py:196-203).  Outside
-    `value`; launch-bound today, so launches per step are printed beside the time."""
+    `value`; launch-bound on the eager host path, so launches per step are printed beside the time, and
+    the replayed iteration's time beside both."""
     from gcc_amd import ops
     from gcc_amd.models import get_model_class
     from gcc_amd.options import options
@@ -265,6 +266,31 @@ def other_configs(warmup=10, steps=30):
             launches = ops.lib().gcc_launch_count(1) / steps
             out[which] = {'batch': batch, 'ms_per_step': round(ms, 3), 'images_per_s': round(batch / ms * 1e3, 1),
                           'launches_per_step': round(launches)}
+            # the same iteration recorded once and re-issued from native code (gcc_amd.replay; bit-identical results:
+            # tests/test_replay_gpu.py): the figure a launch-bound model trains at with GCC_REPLAY=1
+            try:
+                from gcc_amd.replay import IterationReplay
+                rp = IterationReplay(model, opt, warmup=1, enabled=True)
+                i = 0
+                while rp.rec is None and i < 4:
+                    rp.step(data[i % 4], data[(i + 1) % 4])
+                    i += 1
+                for j in range(5):
+                    rp.step(data[(i + j) % 4], data[(i + j + 1) % 4])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for j in range(steps):
+                    rp.step(data[j % 4], data[(j + 1) % 4])
+                torch.cuda.synchronize()
+                rms = (time.perf_counter() - t0) / steps * 1e3
+                info = rp.info() or {}
+                out[which]['replay'] = {'ms_per_step': round(rms, 3), 'images_per_s': round(batch / rms * 1e3, 1),
+                                        'entries': info.get('entries'), 'host_threads': info.get('threads'),
+                                        'streams': info.get('streams')}
+                rp.invalidate()
+                del rp
+            except Exception as e:
+                out[which]['replay'] = {'error': '%s: %s' % (type(e).__name__, e)}
             del model, data
             torch.cuda.empty_cache()
         except Exception as e:      # the headline line must not be lost to a side measurement

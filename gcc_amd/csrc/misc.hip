@@ -774,18 +774,19 @@ extern "C" int gcc_write_i32(int* dst, const int* values, int n, gcc_stream_t st
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }
+// one thread owns a pixel of EVERY image of the batch and walks the images in order: two images of a batch that draw the same
+// slot behave as in the reference's sequential loop (the second one receives the first one's pixels)
 __global__ __launch_bounds__(256) void image_pool_kernel(const i32x4* __restrict__ src, i32x4* __restrict__ out, i32x4* pool,
-                                                         const int* __restrict__ sel, size_t hw) {
-    const int n = blockIdx.y;
-    const int mode = sel[2 * n], slot = sel[2 * n + 1];
-    const i32x4* s = src + n * hw;
-    i32x4* o = out + n * hw;
-    i32x4* p = pool + (size_t)slot * hw;
+                                                         const int* __restrict__ sel, int N, size_t hw) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (size_t)gridDim.x * 256) {
-        const i32x4 v = s[i];
-        if (mode == 0) { o[i] = v; }
-        else if (mode == 1) { p[i] = v; o[i] = v; }
-        else { const i32x4 old = p[i]; p[i] = v; o[i] = old; }
+        for (int n = 0; n < N; n++) {
+            const int mode = sel[2 * n], slot = sel[2 * n + 1];
+            const i32x4 v = src[n * hw + i];
+            i32x4* p = pool + (size_t)slot * hw + i;
+            if (mode == 0) { out[n * hw + i] = v; }
+            else if (mode == 1) { *p = v; out[n * hw + i] = v; }
+            else { const i32x4 old = *p; *p = v; out[n * hw + i] = old; }
+        }
     }
 }
 // images / out: [N][HW][8] bf16 (3 channels in one 16-byte group), pool: [slots][HW][8], sel: device [N][2] = (mode, slot)
@@ -793,9 +794,9 @@ extern "C" int gcc_image_pool_query(const void* images, void* out, void* pool, c
                                     gcc_stream_t stream) {
     GCC_ENTER();
     if (!images || !out || !pool || !sel || N < 1 || HW == 0 || slots < 1) return GCC_ERR_BAD_ARG;
-    const int bx = (int)std::min<size_t>((HW + 255) / 256, 128);
-    hipLaunchKernelGGL(image_pool_kernel, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, (const i32x4*)images, (i32x4*)out,
-                       (i32x4*)pool, sel, HW);
+    const int bx = (int)std::min<size_t>((HW + 255) / 256, 512);
+    hipLaunchKernelGGL(image_pool_kernel, dim3(bx), dim3(256), 0, (hipStream_t)stream, (const i32x4*)images, (i32x4*)out,
+                       (i32x4*)pool, sel, N, HW);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

@@ -111,8 +111,6 @@ class _Half:
 
 class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
 
-    teacher_thread = True         # launch-bound at its batch size: the teacher's step is enqueued by a second host thread (_streams.py)
-
     def __init__(self, opt, cfg_AtoB=None, cfg_BtoA=None):
         super().__init__()
         self.opt = opt

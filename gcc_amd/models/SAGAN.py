@@ -141,8 +141,6 @@ def _is_dup(name):
 
 class SAGANModel(TeacherStreamMixin, nn.Module):
 
-    teacher_thread = True         # launch-bound at its batch size: the teacher's step is enqueued by a second host thread (_streams.py)
-
     def __init__(self, opt, filter_cfgs=None, channel_cfgs=None):
         super().__init__()
         self.opt = opt

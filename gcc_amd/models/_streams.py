@@ -7,11 +7,11 @@ layers of the two networks, which cannot fill 256 CUs alone, overlap; the arithm
 ``GCC_CONCURRENT_TEACHER=0`` (or ``model.serialize_streams = True``, used by bench.py's profiled steps) keeps everything
 on one stream.
 
-Host side (round 3): the launch-bound models (CycleGAN at batch 1: ~4 200 launches of 6.8 us of host time per iteration,
-host enqueue time = iteration time) hand the teacher's step to a second host thread.  ctypes releases the GIL inside every
-library call, so the ~4.3 us `hipLaunchKernel` halves of the two threads' launches overlap; the Python halves still take
-turns.  A model class opts in with ``teacher_thread = True`` (``GCC_TEACHER_THREAD=0/1`` overrides for every class); never
-under data parallelism (RCCL calls of one communicator from two threads)."""
+Host side (round 3): GCC_TEACHER_THREAD=1 hands the teacher's step to a second host thread.  ctypes releases the GIL inside
+every library call, so the ~4.3 us `hipLaunchKernel` halves of the two threads' launches overlap while the Python halves take
+turns: CycleGAN at batch 1 gains 9 % (34.7 -> 31.5 ms), SAGAN loses 15 % and SRGAN becomes erratic (14.7 / 35 ms) -- GIL
+ping-pong -- so it is off by default; the launch-bound models' answer is gcc_amd.replay (the iteration re-issued from native
+code).  Never under data parallelism (RCCL calls of one communicator from two threads)."""
 import os
 import queue
 import threading

@@ -253,7 +253,9 @@ def workspace(nbytes, device, slot='default'):
 
 class Event:
     """An event of the library (gcc_event_*, hipEventDisableTiming): records and waits made through it are part of a launch
-    recording (gcc_amd.replay).  Never destroyed: a recording may hold its handle; a process creates a few dozen."""
+    recording (gcc_amd.replay).  Never destroyed: a recording may hold its handle; a process creates a few dozen.
+    record / wait take a torch.cuda.Stream (default: the current stream); the *_raw forms take the hipStream_t itself (a
+    side-stream fork is two of these calls per weight-gradient launch: the property lookups count)."""
     __slots__ = ('h',)
 
     def __init__(self):
@@ -262,11 +264,20 @@ class Event:
         self.h = h.value
 
     def record(self, s=None):
-        """s: torch.cuda.Stream (default: the current stream)"""
-        check(lib().gcc_event_record(self.h, s.cuda_stream if s is not None else stream()), 'gcc_event_record')
+        if _lib.load().gcc_event_record(self.h, s.cuda_stream if s is not None else stream()):
+            raise RuntimeError('gcc_event_record failed')
 
     def wait(self, s=None):
-        check(lib().gcc_stream_wait_event(s.cuda_stream if s is not None else stream(), self.h), 'gcc_stream_wait_event')
+        if _lib.load().gcc_stream_wait_event(s.cuda_stream if s is not None else stream(), self.h):
+            raise RuntimeError('gcc_stream_wait_event failed')
+
+    def record_raw(self, raw):
+        if _lib.load().gcc_event_record(self.h, raw):
+            raise RuntimeError('gcc_event_record failed')
+
+    def wait_raw(self, raw):
+        if _lib.load().gcc_stream_wait_event(raw, self.h):
+            raise RuntimeError('gcc_stream_wait_event failed')
 
 
 def wait_event(s, ev):
@@ -322,6 +333,7 @@ class SideStream:
 
     def __init__(self, device):
         self.stream = torch.cuda.Stream(device=device)
+        self.raw = self.stream.cuda_stream
         self.dirty = False
         self.ev_fork, self.ev_join = Event(), Event()     # re-recorded: a wait holds the record it saw
 
@@ -336,15 +348,15 @@ class SideStream:
 
     def fork(self):
         """everything enqueued on the main stream so far happens-before later side-stream work"""
-        self.ev_fork.record()
-        self.ev_fork.wait(self.stream)
+        self.ev_fork.record_raw(stream())
+        self.ev_fork.wait_raw(self.raw)
         self.dirty = True
 
     def join(self):
         """the main stream waits for all side-stream work enqueued so far"""
         if self.dirty:
-            self.ev_join.record(self.stream)
-            self.ev_join.wait()
+            self.ev_join.record_raw(self.raw)
+            self.ev_join.wait_raw(stream())
             self.dirty = False
 
 

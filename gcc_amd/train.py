@@ -127,6 +127,12 @@ def main(argv=None, datasets=None, evaluate=None):
     logger.info('The number of training images = %d' % len(train_set))
     total_iters = 0
     best, last_scores = BestRecord(opt), None
+    # GCC_REPLAY=1: the iteration is recorded once per epoch and re-issued from native code (gcc_amd.replay: the launch-bound
+    # models -- CycleGAN at batch 1, SAGAN, SRGAN -- train at the GPU's pace instead of the Python host's); same results
+    replay = None
+    if os.environ.get('GCC_REPLAY', '0') == '1':
+        from .replay import IterationReplay
+        replay = IterationReplay(model, opt, enabled=True)
     for epoch in range(opt.epoch_count, opt.n_epochs + opt.n_epochs_decay + 1):
         model.model_train()
         logger.info('\nEpoch:%d' % epoch)
@@ -137,12 +143,16 @@ def main(argv=None, datasets=None, evaluate=None):
             t0 = time.time()
             total_iters += opt.batch_size
             epoch_iter += opt.batch_size
-            model.set_input(data)
-            model.optimize_parameters()
-            if opt.darts_discriminator and model.teacher_model is not None:
-                model.set_input(next(val_iter))
-                model.clipping_mask_alpha()
-                model.optimizer_netD_arch()
+            if replay is not None:
+                arch = opt.darts_discriminator and model.teacher_model is not None
+                replay.step(data, next(val_iter) if arch else None)
+            else:
+                model.set_input(data)
+                model.optimize_parameters()
+                if opt.darts_discriminator and model.teacher_model is not None:
+                    model.set_input(next(val_iter))
+                    model.clipping_mask_alpha()
+                    model.optimizer_netD_arch()
             if total_iters % opt.print_freq == 0:
                 losses = model.get_current_losses()
                 msg = '(epoch: %d, iters: %d, time: %.3f) ' % (epoch, epoch_iter, (time.time() - t0) / opt.batch_size)
@@ -157,6 +167,8 @@ def main(argv=None, datasets=None, evaluate=None):
         logger.info('End of epoch %d / %d \t Time Taken: %d sec' % (epoch, opt.n_epochs + opt.n_epochs_decay,
                                                                     time.time() - t_epoch))
         model.update_learning_rate(epoch)
+        if replay is not None:
+            replay.invalidate()          # learning rates (and the EMA beta) are launch arguments of the recording
     if last_scores is not None:
         best.report(logger, last_scores)
     return model

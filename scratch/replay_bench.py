@@ -13,7 +13,10 @@ os.environ.setdefault('GCC_VGG19_RANDOM', '1')
 which = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 batch, argv = bench.OTHER_ARGV[which]
-for label, enabled, threads in (('eager', False, 1), ('replay x1', True, 1), ('replay x2', True, 2), ('replay x4', True, 4)):
+modes = (('eager', False, 1), ('replay x1', True, 1), ('replay x2', True, 2), ('replay x4', True, 4))
+if len(sys.argv) > 3:
+    modes = [m for m in modes if m[0].replace(' ', '') in sys.argv[3].split(',')]
+for label, enabled, threads in modes:
     opt = options.parse(argv + ['--gpu_ids', '0', '--online_distillation', '--darts_discriminator', '--batch_size', str(batch)])
     opt.isTrain = True
     if getattr(opt, 'teacher_ndf', None) is None:
