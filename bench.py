@@ -246,7 +246,8 @@ def other_configs(warmup=10, steps=30):
             model = cls(opt)
             attach_teacher(model, opt, cls)
             model.model_train()
-            data = list(SyntheticPairs(opt, 4, 7))
+            # inputs resident in HBM before the timed region, as for the headline line
+            data = [{k: (v.to(model.device) if torch.is_tensor(v) else v) for k, v in d.items()} for d in SyntheticPairs(opt, 4, 7)]
 
             def step(i):
                 model.set_input(data[i % 4])

@@ -11,6 +11,7 @@
 // change between iterations are patched by tag (gcc_replay_tag_next / gcc_replay_patch: Adam's step-dependent factors).
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -282,6 +283,21 @@ extern "C" int gcc_replay_run(gcc_replay_t* r) {
     GCC_ENTER();
     if (!r || !r->closed) return GCC_ERR_BAD_ARG;
     if (r->nlanes <= 1) {
+        static const bool timing = getenv("GCC_REPLAY_TIMING") != nullptr;     // host time per entry kind, to stderr
+        if (timing) {
+            double t[5] = {0, 0, 0, 0, 0}; long n[5] = {0, 0, 0, 0, 0};
+            for (const Entry& x : r->e) {
+                timespec a, b;
+                clock_gettime(CLOCK_MONOTONIC, &a);
+                if (issue(r, x)) return GCC_ERR_LAUNCH;
+                clock_gettime(CLOCK_MONOTONIC, &b);
+                t[x.type] += (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3; n[x.type]++;
+            }
+            fprintf(stderr, "[gcc_replay] kernels %ld x %.2f us, memsets %ld x %.2f, copies %ld x %.2f, records %ld x %.2f, waits %ld x %.2f\n",
+                    n[0], n[0] ? t[0] / n[0] : 0., n[1], n[1] ? t[1] / n[1] : 0., n[2], n[2] ? t[2] / n[2] : 0., n[3], n[3] ? t[3] / n[3] : 0.,
+                    n[4], n[4] ? t[4] / n[4] : 0.);
+            return GCC_OK;
+        }
         for (const Entry& x : r->e)
             if (issue(r, x)) return GCC_ERR_LAUNCH;
         return GCC_OK;
