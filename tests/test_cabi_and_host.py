@@ -58,6 +58,36 @@ def test_comm_entry_points_without_a_gpu():
     assert 'rccl' not in out, 'libgcc_hip.so must not depend on RCCL at load time'
 
 
+def test_replay_recorder_lifecycle_without_a_gpu():
+    """gcc_replay_* host state (no launch is made): one recording per thread, an empty recording closes, reports and replays
+    as nothing; patching needs a closed recording and a positive tag; gcc_adam_factors is the arithmetic gcc_adam_step uses"""
+    import math
+    from gcc_amd import _lib
+    lib = _lib.load()
+    h, h2 = ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.gcc_replay_begin(ctypes.byref(h)) == 0 and h.value
+    assert lib.gcc_replay_begin(ctypes.byref(h2)) != 0           # this thread is already recording
+    assert lib.gcc_replay_tag_next(5) == 0
+    v = ctypes.c_float(1.0)
+    assert lib.gcc_replay_patch(h, 5, 0, ctypes.byref(v), 4) < 0  # still open
+    assert lib.gcc_replay_end(h, 4) == 0
+    assert lib.gcc_replay_end(h, 4) != 0                          # closed already
+    assert [lib.gcc_replay_info(h, i) for i in range(5)] == [0, 0, 0, 1, 0]
+    assert lib.gcc_replay_patch(h, 5, 0, ctypes.byref(v), 4) == 0 # nothing carries the tag
+    assert lib.gcc_replay_patch(h, 0, 0, ctypes.byref(v), 4) < 0
+    assert lib.gcc_replay_run(h) == 0
+    assert lib.gcc_replay_destroy(h) == 0
+    assert lib.gcc_replay_begin(ctypes.byref(h)) == 0             # a new recording may start
+    assert lib.gcc_replay_destroy(h) == 0                         # ... and be dropped unfinished
+    assert lib.gcc_replay_begin(ctypes.byref(h)) == 0 and lib.gcc_replay_end(h, 1) == 0 and lib.gcc_replay_destroy(h) == 0
+    f = (ctypes.c_float * 2)()
+    for step in (1, 2, 10, 1000):
+        assert lib.gcc_adam_factors(0.5, 0.999, step, f) == 0
+        b2 = float(np.float32(0.999))
+        assert f[0] == np.float32(1.0 - 0.5 ** step) and f[1] == np.float32(math.sqrt(1.0 - b2 ** step))
+    assert lib.gcc_adam_factors(0.5, 0.999, 0, f) != 0
+
+
 def test_weight_gradient_plan_follows_the_schedule(monkeypatch):
     """models/_streams.py: every model instance keeps the tile plan its schedule asked for and re-applies it at the head of
     its phases: the production plan halves the workgroup targets of split weight-gradient launches and leaves the pair split
