@@ -279,6 +279,8 @@ def _alternate(tgen, ts, sgen):
 # ------------------------------------------------------------------------------------------------
 class Pix2PixModel(TeacherStreamMixin, nn.Module):
 
+    replay_supported = False      # gcc_amd.replay: the U-Net's dropout seeds are by-value launch arguments of every iteration
+
     def __init__(self, opt, filter_cfgs=None, channel_cfgs=None):
         super().__init__()
         self.opt = opt
