@@ -916,6 +916,40 @@ def _instance_norm_one_launch_body(ops, C, H, W, relu, res):
         assert float(base[..., C:].abs().max()) == 0.0
 
 
+def test_instance_norm_grid_form_on_concurrent_streams():
+    """the grid form's in-launch barrier under the conditions of a training step: four streams launch it back to back on their
+    own tensors (each stream has its own workspace) while a fifth keeps the chip busy with large copies -- every launch completes
+    (residency comes from the grid size: <= 256 workgroups, four per CU) and every result equals the one computed alone"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(1, 256, 64, 64), (2, 96, 64, 64), (1, 64, 128, 128), (1, 128, 128, 128)]
+    xs = [to_dev(rb(torch.randn(*s_, generator=g))) for s_ in shapes]
+    gs = [to_dev(rb(torch.randn(*s_, generator=g))) for s_ in shapes]
+    ref = []
+    for x, gy in zip(xs, gs):
+        st = ops.INState(x.shape[0], x.shape[1], DEV)
+        y, dx = ops.new_act(*x.shape, DEV), ops.new_act(*x.shape, DEV)
+        ops.inorm_fwd(x, y, st, act=ops.ACT_RELU)
+        ops.inorm_bwd(x, y, gy, dx, st, act=ops.ACT_RELU)
+        ref.append((y.clone(), dx.clone()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in shapes]
+    noise = torch.cuda.Stream()
+    big_a, big_b = torch.empty(256 << 20, dtype=torch.uint8, device=DEV), torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+    outs = [(ops.new_act(*x.shape, DEV), ops.new_act(*x.shape, DEV), ops.INState(x.shape[0], x.shape[1], DEV)) for x in xs]
+    torch.cuda.synchronize()
+    for it in range(150):
+        with torch.cuda.stream(noise):
+            big_b.copy_(big_a)
+        for s_, x, gy, (y, dx, st) in zip(streams, xs, gs, outs):
+            with ops.on_stream(s_):
+                ops.inorm_fwd(x, y, st, act=ops.ACT_RELU)
+                ops.inorm_bwd(x, y, gy, dx, st, act=ops.ACT_RELU)
+    torch.cuda.synchronize()
+    for (y, dx, _), (ry, rdx) in zip(outs, ref):
+        assert torch.equal(y, ry) and torch.equal(dx, rdx)
+
+
 @pytest.mark.parametrize('public_api', [False, True])
 def test_stream_helpers_order_work(public_api):
     """ops.stream / ops.current_stream / ops.on_stream (torch's private raw-stream calls behind a guard, the public API as

@@ -109,3 +109,13 @@ def test_replay_invalidate_and_shape_change():
     modes = [rp.step(data[i % 4], data[(i + 1) % 4]) for i in range(3)]
     assert modes == ['record', 'replay', 'replay'] or modes == ['eager', 'record', 'replay'], modes
     torch.cuda.synchronize()
+
+
+def test_teacher_enqueue_thread_changes_nothing(monkeypatch):
+    """GCC_TEACHER_THREAD=1 (the teacher's step enqueued by a second host thread, models/_streams.py): same bits"""
+    m0, l0, s0, _ = _run(_cyclegan, 1, False, iters=3)
+    monkeypatch.setenv('GCC_TEACHER_THREAD', '1')
+    m1, l1, s1, _ = _run(_cyclegan, 1, False, iters=3)
+    assert l0 == l1
+    bad = [k for k in s0 if not torch.equal(s0[k], s1[k])]
+    assert not bad, bad[:8]
