@@ -908,19 +908,19 @@ __global__ __launch_bounds__(NTH) void inorm_bwd_fused_kernel(const InFusedArgs 
 
 // The same one-launch InstanceNorm with the plane of an image split over S workgroups (round 3: at batch 1 the slab kernels
 // above put 6-16 workgroups on 256 CUs -- `rocprofv3` of a CycleGAN iteration: 592 forward launches of 18 us and 296 backward
-// launches of 37 us on average, 21.7 of the iteration's 56 ms of kernel time).  A workgroup owns `rows` whole pixels (all
-// channels: contiguous memory) and writes its per-channel partial sums; the image's workgroups meet at an in-launch barrier,
-// the counter form of the hand-off in cdna_hip_programming.md (Guideline 16) with write-through (sc1) stores and sc1 loads
-// instead of fences.  The last workgroup of an image to arrive folds the S partials (S * V * 4 <= 64 KB) and publishes the
-// totals; every workgroup then normalises its own rows, which it has just read.  Residency comes from the grid size alone:
-// <= 128 workgroups of 256 threads per launch, so that the four streams of a training step cannot fill the chip's 256 x 4
-// slots with waiting workgroups; the spin is bounded all the same.  An image's arrival word is zero before and after every
-// launch (the last arriver re-arms it; the host allocates it zeroed); its epoch word counts the launches and is never reset.
+// launches of 37 us on average, 21.7 of the iteration's 56 ms of kernel time).  A workgroup owns `rows` whole pixels of a
+// 64-channel group (contiguous 128-byte segments) and writes its per-channel partial sums; the S workgroups of an (image,
+// channel group) domain exchange them inside the launch -- tagged write-through stores that every workgroup polls and folds
+// itself, see the hand-off below -- and every workgroup then normalises its own rows, which it still holds in registers.
+// Residency comes from the grid size alone: <= 256 workgroups of 256 threads at <= 128 VGPRs (four per CU), so that the four
+// streams of a training step cannot fill the chip with waiting workgroups; every spin is bounded all the same.  The workspace
+// is zero-filled once by the host; a domain's epoch word counts the launches that used it and is never reset.
 struct InGridArgs {
     InFusedArgs a;
-    float* partial;        // [N * CG][S][V]
-    double* totals;        // [N * CG][V]
-    unsigned* cnt;         // [N * CG][4]: arrivals, epoch
+    float* partial;        // [N * CG][S][V] (value, tag) pairs
+    float* level2;         // [N * CG][G][V] (double, tag, -) quads: the groups' sums when S > S1
+    int S1, G;             // workgroups whose partials one workgroup folds; groups of S1 per domain
+    unsigned* cnt;         // [N * CG][4]: word 1 = the domain's epoch
     int S, rows;           // workgroups per (image, channel group), pixels per workgroup
     int CG, CHg;           // channel groups per image, 16-byte chunks per group (all of them when the image has < 16)
     int CH, CHP, sh;       // chunks per pixel; the power of two above CHg, its log2
@@ -960,9 +960,9 @@ __global__ __launch_bounds__(256, 4) void inorm_grid_kernel(const InGridArgs ga)
             rs[j] = ok ? a.rstd[g * a.C + c0 + j] : 0.f;
         }
     }
-    // the image's epoch word: stable until every workgroup of this launch has arrived (all of them read it first)
+    // the domain's epoch word: stable until every workgroup of the domain has written its partial (all of them read it first)
     typedef __attribute__((address_space(1))) unsigned int gu32;
-    gu32* cnt = (gu32*)ga.cnt + dom * 4;            // [0] arrivals, [1] epoch: bumped when the totals are ready
+    gu32* cnt = (gu32*)ga.cnt + dom * 4;            // [1]: the domain's epoch (launches that used it)
 #define IN_STAMP(k) do { if (ga.clk && t == 0 && dom == 0) ga.clk[s * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     IN_STAMP(0);
     unsigned epoch = 0;
@@ -1032,13 +1032,22 @@ __global__ __launch_bounds__(256, 4) void inorm_grid_kernel(const InGridArgs ga)
     }
     __syncthreads();
     const bool alone = ga.S == 1;
-    // The partials travel between workgroups on other XCDs (private L2s): write-through (sc1) stores and sc1 loads, every one of
-    // them, instead of an agent-scope release / acquire pair (the fences write back and invalidate the whole L2, which holds the
-    // producer convolution's output).  The LAST workgroup of an image to arrive folds the S partials (<= 64 KB, its 256 lanes keep
-    // 32 loads in flight each) and publishes V totals; the others wait for its epoch bump and read those V values only.
+    // The hand-off, without a counter: every partial value leaves its workgroup as a (value, tag) pair in one 8-byte write-through
+    // (sc1) store, tag = (epoch of this domain + 1) << 8 | domain -- unique to this launch for every slot the domain's
+    // workgroups write, whatever earlier launches with other layouts left in the workspace (their tags carry a smaller epoch of
+    // this domain or another domain's byte).  Every workgroup then polls ALL S partials of its domain with sc1 loads until their
+    // tags match and folds them itself, in index order (S * V <= 4 K values: one or two round trips with all loads in flight).
+    // Two memory hops (store visible, load) instead of the five of a ticket / last-arriver-folds / totals / flag protocol.
+    // The domain's epoch word is bumped by its workgroup 0 once it has seen all S partials -- by then every workgroup of the
+    // domain has read the old value (it read it before it wrote its partial).  The workspace starts zero-filled; tag 0 never occurs.
     const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(ga.partial + dom * ga.S * (size_t)ga.V), 0, ga.S * ga.V * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_tot = __builtin_amdgcn_make_buffer_rsrc((void*)(ga.totals + dom * (size_t)ga.V), 0, ga.V * 8, 0x00020000);
+        (void*)(ga.partial + dom * ga.S * (size_t)ga.V * 2), 0, ga.S * ga.V * 8, 0x00020000);
+    if (!alone) {
+        int* sh_epoch = (int*)(smem_d + 2048 + 256);
+        if (t == 0) *sh_epoch = (int)epoch;
+    }
+    __syncthreads();
+    const unsigned tag = alone ? 0u : ((((unsigned)*(int*)(smem_d + 2048 + 256)) + 1u) << 8) | (unsigned)(dom & 0xff);
     for (int i = t; i < ga.V; i += 256) {
         const int chunk = i >> 4, r = i & 15;
         float sum = 0.f;
@@ -1046,84 +1055,81 @@ __global__ __launch_bounds__(256, 4) void inorm_grid_kernel(const InGridArgs ga)
         for (int w = 0; w < 4; w++)
             if ((((w << 6) ^ chunk) & (ga.CHP - 1) & ~63) == 0) sum += red[(w * 64 + (chunk & 63)) * 16 + r];
         if (alone) tot[i] = (double)sum;
-        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sum), rs_part, (s * ga.V + i) * 4, 0, 16);
+        else {
+            const i32x2 pr = {(int)__float_as_uint(sum), (int)tag};
+            __builtin_amdgcn_raw_buffer_store_b64(pr, rs_part, (s * ga.V + i) * 8, 0, 16);
+        }
     }
     IN_STAMP(1);
     if (!alone) {
-        int* sh_ticket = (int*)(smem_d + 2048 + 256);   // behind tot
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // lanes: value i = t % V of partial rows q0, q0 + nq, ... (nq = 256 / V rows walked in parallel)
+        const int nq = 256 / ga.V > 0 ? 256 / ga.V : 1;
+        const int i = t % ga.V, q0 = t / ga.V;
+        double* part = smem_d;                                       // [nq][V] doubles <= 2 KB: `red` is dead after the barrier
+        // level 1: the S1 workgroups of this workgroup's group (all S of the domain when S <= S1)
+        const int grp = s / ga.S1, g_lo = grp * ga.S1, g_hi = min(g_lo + ga.S1, ga.S);
         __syncthreads();
-        if (t == 0) *sh_ticket = (int)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const bool last = *sh_ticket == ga.S - 1;
-        IN_STAMP(2);
-        if (last) {
-            // everyone has arrived and nobody reads the arrival word again: re-arm it for the next launch on this stream
-            if (t == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // q slices: with V < 256 the idle lanes take other partials of the same value; folded through LDS below
-            const int nslice = ga.V >= 256 ? 1 : 256 / ga.V;
-            double* part = smem_d;                  // [nslice][V] doubles <= 2 KB: `red` is dead
-            __syncthreads();
-            for (int i0 = 0; i0 < ga.V; i0 += 256) {
-                const int sl = ga.V >= 256 ? 0 : t / ga.V;
-                const int i = ga.V >= 256 ? i0 + t : t - sl * ga.V;
-                if (sl < nslice && i < ga.V) {
-                    double sum = 0.0;
-                    int q = sl;
-                    constexpr int FB = BWD ? 16 : 32;       // loads in flight per lane (the backward holds more state)
-                    for (; q + (FB - 1) * nslice < ga.S; q += FB * nslice) {
-                        float f[FB];
+        double sum = 0.0;
+        if (q0 < nq) {
+            constexpr int FB = 8;
+            for (int qb = g_lo + q0; qb < g_hi; qb += FB * nq) {
+                i32x2 pr[FB];
+                unsigned pending = 0;
 #pragma unroll
-                        for (int u = 0; u < FB; u++)
-                            f[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_part, ((q + u * nslice) * ga.V + i) * 4, 0, 16));
+                for (int u = 0; u < FB; u++)
+                    if (qb + u * nq < g_hi) pending |= 1u << u;
+                for (int spin = 0; pending && spin < (1 << 20); spin++) {
 #pragma unroll
-                        for (int u = 0; u < FB; u += 4) sum += ((double)f[u] + (double)f[u + 1]) + ((double)f[u + 2] + (double)f[u + 3]);
-                    }
-                    for (; q + 7 * nslice < ga.S; q += 8 * nslice) {
-                        float f[8];
+                    for (int u = 0; u < FB; u++)
+                        if (pending & (1u << u)) pr[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_part, ((qb + u * nq) * ga.V + i) * 8, 0, 16);
 #pragma unroll
-                        for (int u = 0; u < 8; u++)
-                            f[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_part, ((q + u * nslice) * ga.V + i) * 4, 0, 16));
-#pragma unroll
-                        for (int u = 0; u < 8; u += 4) sum += ((double)f[u] + (double)f[u + 1]) + ((double)f[u + 2] + (double)f[u + 3]);
-                    }
-                    for (; q < ga.S; q += nslice)
-                        sum += (double)__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_part, (q * ga.V + i) * 4, 0, 16));
-                    if (nslice == 1) tot[i] = sum;
-                    else part[sl * ga.V + i] = sum;
+                    for (int u = 0; u < FB; u++)
+                        if ((pending & (1u << u)) && (unsigned)pr[u][1] == tag) pending &= ~(1u << u);
+                    if (pending) __builtin_amdgcn_s_sleep(1);
                 }
+#pragma unroll
+                for (int u = 0; u < FB; u++)
+                    if (qb + u * nq < g_hi) sum += (double)__uint_as_float((unsigned)pr[u][0]);
             }
-            __syncthreads();
-            if (nslice > 1) {
-                for (int i = t; i < ga.V; i += 256) {
-                    double sum = 0.0;
-                    for (int sl = 0; sl < nslice; sl++) sum += part[sl * ga.V + i];
-                    tot[i] = sum;
-                }
-                __syncthreads();
-            }
-            for (int i = t; i < ga.V; i += 256) {
-                const i32x2 bits = __builtin_bit_cast(i32x2, tot[i]);
-                __builtin_amdgcn_raw_buffer_store_b64(bits, rs_tot, i * 8, 0, 16);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (t == 0) __hip_atomic_store(cnt + 1, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            IN_STAMP(3);
-        } else {
-            if (t == 0) {
-                for (int spin = 0; spin < (1 << 24); spin++) {
-                    if (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            IN_STAMP(3);
-            __syncthreads();
-            for (int i = t; i < ga.V; i += 256)
-                tot[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_tot, i * 8, 0, 16));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            part[q0 * ga.V + i] = sum;
         }
+        __syncthreads();
+        for (int k = t; k < ga.V; k += 256) {
+            double tsum = 0.0;
+            for (int q = 0; q < nq; q++) tsum += part[q * ga.V + k];
+            tot[k] = tsum;
+        }
+        if (ga.G > 1) {
+            // level 2 (planes whose S partials are more than one workgroup should fold): the first workgroup of every group
+            // publishes the group's sums as (double, tag) in 16 bytes; everyone folds the G <= 8 of them
+            const __amdgpu_buffer_rsrc_t rs_l2 = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(ga.level2 + dom * ga.G * (size_t)ga.V * 4), 0, ga.G * ga.V * 16, 0x00020000);
+            __syncthreads();
+            if (s == g_lo) {
+                for (int k = t; k < ga.V; k += 256) {
+                    const i32x2 bits = __builtin_bit_cast(i32x2, tot[k]);
+                    const i32x4 v4 = {bits[0], bits[1], (int)tag, 0};
+                    __builtin_amdgcn_raw_buffer_store_b128(v4, rs_l2, (grp * ga.V + k) * 16, 0, 16);
+                }
+            }
+            for (int k = t; k < ga.V; k += 256) {
+                double tsum = 0.0;
+                for (int q = 0; q < ga.G; q++) {
+                    i32x4 v4 = {0, 0, 0, 0};
+                    for (int spin = 0; spin < (1 << 20); spin++) {
+                        v4 = __builtin_amdgcn_raw_buffer_load_b128(rs_l2, (q * ga.V + k) * 16, 0, 16);
+                        if ((unsigned)v4[2] == tag) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    const i32x2 bits = {v4[0], v4[1]};
+                    tsum += __builtin_bit_cast(double, bits);
+                }
+                tot[k] = tsum;
+            }
+        }
+        IN_STAMP(3);
+        if (s == 0 && t == 0) __hip_atomic_store(cnt + 1, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
     } else {
         __syncthreads();
     }
@@ -1241,12 +1247,16 @@ static bool inorm_grid_plan(int C, int HW, int N, int px, size_t ws_bytes, InGri
     // best of 2 / 4 / 8 -- more workgroups shorten the passes and lengthen the hand-off, ~40 ns per arrival on one counter)
     long S = (HW + px * PL - 1) / (px * PL);
     S = std::min<long>(S, 256 / (N * CG));                    // residency: <= 256 workgroups of <= 128 VGPRs per launch
-    S = std::min<long>(S, std::max(1, 32768 / V));            // the S partials the last arriver folds: <= 128 KB
     S = std::max<long>(S, 1);
     int rows = (int)((HW + S - 1) / S);
     rows = ((rows + PL - 1) / PL) * PL;
     S = (HW + rows - 1) / rows;
-    if (S > 1 && ws_bytes < INORM_WS_HEADER + (size_t)N * CG * V * sizeof(double) + (size_t)N * CG * S * V * sizeof(float)) return false;
+    // one workgroup folds at most 4 K (value, tag) pairs; beyond that the domain's workgroups meet in groups of S1 first
+    const int S1 = (int)std::min<long>(S, std::max(1, 4096 / V));
+    const int G = (int)((S + S1 - 1) / S1);
+    if (G > 8) return false;
+    if (S > 1 && ws_bytes < INORM_WS_HEADER + (size_t)N * CG * S * V * 8 + (size_t)N * CG * G * V * 16) return false;
+    ga->S1 = S1; ga->G = G;
     ga->S = (int)S; ga->rows = rows; ga->CG = CG; ga->CHg = CHg; ga->CH = CH; ga->CHP = CHP; ga->sh = sh; ga->V = V;
     return true;
 }
@@ -1257,8 +1267,8 @@ void inorm_launch(const InFusedArgs& a, int N, hipStream_t st, void* ws, size_t 
     if (ws && ws_bytes >= INORM_WS_HEADER + 16384 && gcc_opt(GCC_OPT_INORM_GRID) && inorm_grid_plan(a.C, a.HW, N, BWD ? 4 : 8, ws_bytes, &ga)) {
         ga.a = a;
         ga.cnt = (unsigned*)ws;
-        ga.totals = (double*)((char*)ws + INORM_WS_HEADER);
-        ga.partial = (float*)((char*)ws + INORM_WS_HEADER + (size_t)N * ga.CG * ga.V * sizeof(double));
+        ga.partial = (float*)((char*)ws + INORM_WS_HEADER);
+        ga.level2 = (float*)((char*)ws + INORM_WS_HEADER + (size_t)N * ga.CG * ga.S * ga.V * 8);
         ga.clk = (gcc_opt(GCC_OPT_DEBUG) & 32) ? (unsigned long long*)((char*)ws + ws_bytes - 16384) : nullptr;
         hipLaunchKernelGGL((inorm_grid_kernel<BWD>), dim3(ga.S, ga.CG, N), dim3(256), 0, st, ga);
         return;

@@ -234,7 +234,7 @@ int gcc_in_finalize(const float* stats_partial, int tiles_per_group, int groups,
  * written for the backward, y = act((x - mean) rstd) + residual (models/CycleGAN.py:77-138 at batch 1).  With a workspace the
  * plane of an image is split over up to 256 / N workgroups (pixel ranges x 64-channel groups) that meet at an in-launch barrier; without one (NULL) a workgroup
  * owns a whole (image, 16-channel slab).  Workspace contract: GCC_INORM_WORKSPACE_BYTES bytes, zero-filled once by the
- * caller when it is allocated, used by ONE stream (calls on it are ordered); every call leaves its arrival words zero. */
+ * caller when it is allocated, used by ONE stream (calls on it are ordered) and by nothing else. */
 #define GCC_INORM_WORKSPACE_BYTES ((size_t)4096 + ((size_t)3 << 19))
 int gcc_inorm_fwd(const void* x, int ldx, void* y, int ldy, const void* residual, int ld_residual, int C, int HW, int N,
                   int act, float slope, float eps, float* mean, float* rstd, float* scale, float* shift,

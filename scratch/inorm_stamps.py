@@ -19,7 +19,7 @@ for N, C, H, W in [(1, 256, 64, 64), (1, 512, 32, 32), (1, 64, 256, 256)]:
         c = clk[:S].double()
         t0 = c[:, 0].min()
         r = (c[:, :6] - t0) * 0.01      # us
-        print('%s %s: S=%d  start %.1f..%.1f | phase1 done %.1f..%.1f | ticket %.1f..%.1f | flag %.1f..%.1f | totals %.1f..%.1f | end %.1f..%.1f' % (
-            (N, C, H, W), 'bwd' if bwd else 'fwd', S, r[:, 0].min(), r[:, 0].max(), r[:, 1].min(), r[:, 1].max(), r[:, 2].min(), r[:, 2].max(),
-            r[:, 3].min(), r[:, 3].max(), r[:, 4].min(), r[:, 4].max(), r[:, 5].min(), r[:, 5].max()))
+        print('%s %s: S=%d  start %.1f..%.1f | statistics pass done %.1f..%.1f | partials exchanged and folded %.1f..%.1f | end %.1f..%.1f  (us from the first workgroup\'s start; min..max over the image-0 / group-0 domain)' % (
+            (N, C, H, W), 'bwd' if bwd else 'fwd', S, r[:, 0].min(), r[:, 0].max(), r[:, 1].min(), r[:, 1].max(), r[:, 3].min(), r[:, 3].max(),
+            r[:, 5].min(), r[:, 5].max()))
         ws[-16384:].zero_()

@@ -862,8 +862,8 @@ def test_instance_norm_forward_backward(C, relu, res):
 def test_instance_norm_one_launch(C, H, W, relu, res, grid):
     """gcc_inorm_fwd / gcc_inorm_bwd against torch's instance_norm, and against the three-launch pipeline they replace:
     grid=1 the plane of an image split over workgroups that meet at an in-launch barrier (C = 1032 is beyond its plan and
-    stays with the slab kernel), grid=0 one workgroup per image x 16-channel slab.  Every call is made twice: the barrier's
-    counters must be back at zero after a launch."""
+    stays with the slab kernel), grid=0 one workgroup per image x 16-channel slab.  Every call is made twice: the second
+    launch finds the first one's tagged partials in the workspace and must not take them for its own."""
     _run_instance_norm_one_launch(C, H, W, relu, res, grid)
 
 
@@ -898,7 +898,6 @@ def _instance_norm_one_launch_body(ops, C, H, W, relu, res):
     for _ in range(2):
         ops.inorm_fwd(xd, y, st, act=act, residual=to_dev(r) if res else None)
     close(to_cpu(y), yref.detach(), what='one-launch instance norm fwd')
-    assert int(ops.inorm_workspace(xd.device)[:4096].view(torch.int32)[0::4].abs().sum()) == 0, 'arrival words not re-armed'
     close(st.mean.cpu(), x.mean((2, 3)), tol=1e-4, floor=1e-5, what='IN mean')
     close(st.rstd.cpu(), 1.0 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5), tol=1e-4, what='IN rstd')
     st3 = ops.INState(N, C, DEV)
