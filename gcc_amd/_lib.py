@@ -117,6 +117,7 @@ PROTOTYPES = {
     'gcc_adam_factors': (_I, [_F, _F, _I, _P]),
     'gcc_inorm_fwd': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
     'gcc_inorm_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
+    'gcc_bn_bwd_one_launch': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _Z, _I, _F, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'gcc_channel_stats_tiles': (_I, [_Z, _I]),
     'gcc_channel_stats': (_I, [_P, _I, _I, _I, _Z, _I, _P, _P]),
     'gcc_reflect_pad': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -669,6 +669,8 @@ struct InFusedArgs {
     bf16_t* out; int ldout;            // fwd: == y ; bwd: dx (may alias the incoming gradient)
     int C, HW, act; float slope, eps;
     float *mean, *rstd, *scale, *shift;   // [N][C]
+    // BatchNorm backward through the grid kernel (gcc_bn_bwd_one_launch: N == 1, HW = all pixels of the batch)
+    const float* gamma; float *dgamma, *dbeta;
 };
 
 // LPP lanes share a pixel (each 8 channels = 16 bytes): the slab is 8 * LPP channels wide.  Sums of the lanes with the same
@@ -1192,12 +1194,23 @@ __global__ __launch_bounds__(256, 4) void inorm_grid_kernel(const InGridArgs ga)
         }
         IN_STAMP(5);
     } else {
+        if (s == 0 && (a.dgamma || a.dbeta)) {
+            // BatchNorm: d(gamma) += sum dz xhat, d(beta) += sum dz -- one workgroup per channel group, one writer per channel
+            for (int cl = t; cl < ga.CHg * 8; cl += 256) {
+                const int c = cg * ga.CHg * 8 + cl;
+                if (c < a.C) {
+                    if (a.dbeta) a.dbeta[c] += (float)tot[(cl >> 3) * 16 + (cl & 7)];
+                    if (a.dgamma) a.dgamma[c] += (float)tot[(cl >> 3) * 16 + 8 + (cl & 7)];
+                }
+            }
+        }
         if (!live) return;
         float A[8], B[8], K[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const float k0 = (float)(tot[ch * 16 + j] * inv_hw), k1 = (float)(tot[ch * 16 + 8 + j] * inv_hw);
-            A[j] = rs[j]; B[j] = -rs[j] * rs[j] * k1; K[j] = -rs[j] * k0 + rs[j] * rs[j] * k1 * mu[j];
+            const float gr = (a.gamma && c0 + j < a.C) ? a.gamma[c0 + j] * rs[j] : rs[j];      // dx = gamma rstd (dz - k0 - xhat k1)
+            A[j] = gr; B[j] = -gr * rs[j] * k1; K[j] = -gr * k0 + gr * rs[j] * k1 * mu[j];
         }
         auto emit = [&](int p, const i32x4& rx, const i32x4& rgr, const i32x4& ry) {
             float xv[8], yv[8], gv[8], o[8];
@@ -1247,6 +1260,7 @@ static bool inorm_grid_plan(int C, int HW, int N, int px, size_t ws_bytes, InGri
     // best of 2 / 4 / 8 -- more workgroups shorten the passes and lengthen the hand-off, ~40 ns per arrival on one counter)
     long S = (HW + px * PL - 1) / (px * PL);
     S = std::min<long>(S, 256 / (N * CG));                    // residency: <= 256 workgroups of <= 128 VGPRs per launch
+    S = std::min<long>(S, 8 * std::max(1, 4096 / V));         // two exchange levels: 8 groups of 4096 / V workgroups
     S = std::max<long>(S, 1);
     int rows = (int)((HW + S - 1) / S);
     rows = ((rows + PL - 1) / PL) * PL;
@@ -1469,6 +1483,30 @@ extern "C" int gcc_inorm_bwd(const void* x, int ldx, const void* y, int ldy, con
     a.out = (bf16_t*)dx; a.ldout = lddx; a.C = C; a.HW = HW; a.act = act; a.slope = slope;
     a.mean = (float*)mean; a.rstd = (float*)rstd;
     inorm_launch<true>(a, N, (hipStream_t)stream, workspace, workspace_bytes);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+// BatchNorm backward (training statistics, no gate / dropout / second gradient) in ONE launch: the grid InstanceNorm backward
+// with the whole batch as one plane and gamma folded into the coefficients.  The activation derivative comes from the saved
+// output y, or there is no activation (y NULL with an activation would need the affine output recomputed: not this route).
+extern "C" int gcc_bn_bwd_one_launch(const void* x, int ldx, const void* y, int ldy, const void* g, int ldg, void* dx, int lddx,
+                                     int C, size_t pixels, int act, float slope, const float* mean, const float* rstd,
+                                     const float* gamma, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                     gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!x || !g || !dx || !mean || !rstd || C <= 0 || pixels == 0 || pixels > (size_t)1 << 30 || (ldx & 7) || (ldg & 7) ||
+        (lddx & 7) || (y && (ldy & 7)))
+        return GCC_ERR_BAD_ARG;
+    if (!y && act != GCC_ACT_NONE) return GCC_ERR_UNSUPPORTED;
+    InFusedArgs a = {};
+    a.x = (const bf16_t*)x; a.ldx = ldx; a.y = (const bf16_t*)y; a.ldy = ldy; a.aux = (const bf16_t*)g; a.ldaux = ldg;
+    a.out = (bf16_t*)dx; a.ldout = lddx; a.C = C; a.HW = (int)pixels; a.act = act; a.slope = slope;
+    a.mean = (float*)mean; a.rstd = (float*)rstd; a.gamma = gamma; a.dgamma = dgamma; a.dbeta = dbeta;
+    InGridArgs ga;
+    if (!workspace || workspace_bytes < INORM_WS_HEADER + 16384 || !inorm_grid_plan(C, (int)pixels, 1, 4, workspace_bytes, &ga))
+        return GCC_ERR_UNSUPPORTED;
+    inorm_launch<true>(a, 1, (hipStream_t)stream, workspace, workspace_bytes);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

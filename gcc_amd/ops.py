@@ -771,6 +771,10 @@ def bnact_fwd(x, y, y2=None, scale=None, shift=None, gate=None, gate_after_act=F
     check(lib().gcc_bnact_fwd(C.byref(p), xp, ldx, 0, yp, ldy, 0, y2p, ldy2, 0, Cc, pixels, stream()), 'gcc_bnact_fwd')
 
 
+BN_BWD_GRID = os.environ.get('GCC_BN_BWD_GRID', '1') != '0'
+BN_BWD_GRID_MIN_PIXELS = 4096        # at or below: bnact_bwd_small_kernel (one workgroup per 8 channels) is the one-launch form
+
+
 def bnact_bwd(x, y, g1, dx, g2=None, bn=None, gamma=None, beta=None, bn_eval=False, gate=None, gate_after_act=False,
               act=ACT_NONE, slope=0.2, act2=ACT_NONE, drop_p=0.0, seed=0, dgamma=None, dbeta=None, dalpha=None,
               in_act=ACT_NONE, groups=1):
@@ -786,6 +790,17 @@ def bnact_bwd(x, y, g1, dx, g2=None, bn=None, gamma=None, beta=None, bn_eval=Fal
     dxp, _, _, _, _, lddx = geom(dx)
     pixels = N * H * W if groups <= 1 else H * W
     assert groups <= 1 or groups == N
+    if (BN_BWD_GRID and bn is not None and not bn_eval and g2 is None and gate is None and not gate_after_act and drop_p == 0.0
+            and dalpha is None and in_act == ACT_NONE and act2 == ACT_NONE and groups <= 1 and (y is not None or act == ACT_NONE)
+            and pixels > BN_BWD_GRID_MIN_PIXELS and not PROFILE.active):
+        # plain training-mode BatchNorm backward (SRResNet / SAGAN-generator blocks): one launch instead of reduce + finalize + apply
+        ws = inorm_workspace(x.device)
+        rc = lib().gcc_bn_bwd_one_launch(xp, ldx, yp, ldy, g1p, ldg1, dxp, lddx, Cc, pixels, act, slope, bn.mean.data_ptr(),
+                                         bn.rstd.data_ptr(), _p(gamma), _p(dgamma), _p(dbeta), ws.data_ptr(), ws.numel(), stream())
+        if rc == 0:
+            return
+        if rc != -2:                    # GCC_ERR_UNSUPPORTED: the geometry stays with the three-launch route below
+            check(rc, 'gcc_bn_bwd_one_launch')
     p = _lib.bnact_bwd_t(1 if bn is not None else 0, int(bn_eval), _p(bn.mean) if bn is not None else None,
                          _p(bn.rstd) if bn is not None else None, _p(gamma), _p(beta), _p(gate), int(gate_after_act),
                          act, slope, act2, drop_p, seed, _p(dgamma), _p(dbeta), _p(dalpha), groups, 0)

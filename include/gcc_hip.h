@@ -244,6 +244,14 @@ int gcc_inorm_fwd(const void* x, int ldx, void* y, int ldy, const void* residual
 int gcc_inorm_bwd(const void* x, int ldx, const void* y, int ldy, const void* g, int ldg, void* dx, int lddx, int C, int HW,
                   int N, int act, float slope, const float* mean, const float* rstd, void* workspace, size_t workspace_bytes,
                   gcc_stream_t stream);
+/* BatchNorm backward with training statistics and nothing else fused (no gate, dropout or second gradient) in ONE launch
+ * -- the SRResNet / SAGAN-generator blocks (models/SRGAN.py:19-66, models/SAGAN.py:77-140): dx = gamma rstd (dz - mean(dz) -
+ * xhat mean(dz xhat)), dz = g act'(y) (y NULL: no activation), dgamma += sum dz xhat, dbeta += sum dz (either may be NULL).
+ * workspace: as for gcc_inorm_fwd (the same one may be shared on a stream).  GCC_ERR_UNSUPPORTED when the geometry does not
+ * fit the grid form: call gcc_bnact_bwd instead. */
+int gcc_bn_bwd_one_launch(const void* x, int ldx, const void* y, int ldy, const void* g, int ldg, void* dx, int lddx, int C,
+                          size_t pixels, int act, float slope, const float* mean, const float* rstd, const float* gamma,
+                          float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, gcc_stream_t stream);
 int gcc_channel_stats_tiles(size_t pixels_per_group, int C);
 int gcc_channel_stats(const void* x, int ld, int off, int C, size_t pixels_per_group, int groups, float* stats,
                       gcc_stream_t stream);

@@ -915,6 +915,45 @@ def _instance_norm_one_launch_body(ops, C, H, W, relu, res):
         assert float(base[..., C:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('N,C,H,W,act,with_y', [(16, 64, 24, 24, 'none', False), (16, 24, 24, 24, 'none', False), (64, 96, 16, 16, 'relu', True),
+                                                 (2, 256, 96, 96, 'lrelu', True), (16, 520, 24, 24, 'none', False)])
+def test_batchnorm_backward_one_launch_vs_three_launches(N, C, H, W, act, with_y, monkeypatch):
+    """gcc_bn_bwd_one_launch (the grid InstanceNorm backward with the batch as one plane and gamma in the coefficients) against
+    the reduce + finalize + apply route and against fp32 torch autograd: dx, d(gamma) +=, d(beta) +="""
+    ops = _ops()
+    g = torch.Generator().manual_seed(C + N)
+    x = rb(torch.randn(N, C, H, W, generator=g) * 1.2 + 0.1)
+    gy = rb(torch.randn(N, C, H, W, generator=g))
+    gamma = (torch.rand(C, generator=g) + 0.5)
+    beta = torch.randn(C, generator=g) * 0.1
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = F.batch_norm(xr, None, None, gr, br, training=True, eps=1e-5)
+    yref = {'none': z, 'relu': F.relu(z), 'lrelu': F.leaky_relu(z, 0.2)}[act]
+    yref.backward(gy)
+    code = {'none': ops.ACT_NONE, 'relu': ops.ACT_RELU, 'lrelu': ops.ACT_LRELU}[act]
+    xd, gd = to_dev(x), to_dev(gy)
+    yd = to_dev(rb(yref.detach())) if with_y else None
+    st = ops.BNState(C, DEV)
+    st.mean.copy_(x.mean((0, 2, 3))); st.rstd.copy_(1.0 / torch.sqrt(x.var((0, 2, 3), unbiased=False) + 1e-5))
+    gam, bet = gamma.to(DEV), beta.to(DEV)
+    outs = []
+    for grid in (True, False):
+        monkeypatch.setattr(ops, 'BN_BWD_GRID', grid)
+        dx = ops.new_act(N, C, H, W, DEV)
+        dg, db = torch.full((C,), 0.25, device=DEV), torch.full((C,), -0.5, device=DEV)          # accumulated into
+        before = ops.lib().gcc_launch_count(1)
+        ops.bnact_bwd(xd, yd, gd, dx, bn=st, gamma=gam, beta=bet, act=code, dgamma=dg, dbeta=db)
+        launches = ops.lib().gcc_launch_count(1)
+        outs.append((to_cpu(dx), dg.cpu() - 0.25, db.cpu() + 0.5, launches))
+    assert outs[0][3] == 1 and outs[1][3] == 3, (outs[0][3], outs[1][3])
+    close(outs[0][0], xr.grad, tol=2e-2, what='BatchNorm dx (one launch)')
+    close(outs[0][1], gr.grad, tol=2e-2, what='d gamma')
+    close(outs[0][2], br.grad, tol=2e-2, what='d beta')
+    d = (outs[0][0] - outs[1][0]).abs().max()
+    assert float(d) <= 2e-2 * max(1.0, float(outs[1][0].abs().max())), float(d)
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-3) and torch.allclose(outs[0][2], outs[1][2], rtol=1e-4, atol=1e-3)
+
+
 def test_instance_norm_grid_form_on_concurrent_streams():
     """the grid form's in-launch barrier under the conditions of a training step: four streams launch it back to back on their
     own tensors (each stream has its own workspace) while a fifth keeps the chip busy with large copies -- every launch completes
