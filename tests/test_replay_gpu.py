@@ -119,3 +119,46 @@ def test_teacher_enqueue_thread_changes_nothing(monkeypatch):
     assert l0 == l1
     bad = [k for k in s0 if not torch.equal(s0[k], s1[k])]
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize('which', ['srgan', 'cyclegan'])
+def test_train_loop_with_replay_ends_on_the_same_weights(tmp_path, monkeypatch, which):
+    """python -m gcc_amd.train with GCC_REPLAY=1 (the iteration recorded, replayed, dropped at the epoch boundary with the new
+    learning rate and recorded again) against the eager loop: same seeds, same synthetic batches, three epochs -- every saved
+    tensor of the final checkpoint is bit-identical"""
+    import os
+    from gcc_amd import train
+    os.environ['GCC_VGG19_RANDOM'] = '1'
+    common = ['--dataroot', 'synthetic:4', '--gpu_ids', '0', '--online_distillation', '--darts_discriminator', '--n_epochs', '2',
+              '--n_epochs_decay', '1', '--print_freq', '100', '--ngf', '8', '--ndf', '8', '--teacher_ngf', '16']
+    if which == 'srgan':
+        argv = common + ['--model', 'srgan', '--image_size', '48', '--batch_size', '2']
+    else:
+        argv = common + ['--model', 'cyclegan', '--crop_size', '64', '--batch_size', '1']
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('GCC_REPLAY', mode)
+        random.seed(7)
+        torch.manual_seed(7)
+        model = train.main(argv + ['--checkpoints_dir', str(tmp_path / ('ck' + mode)), '--name', 'r'])
+        torch.cuda.synchronize()
+        ck = tmp_path / ('ck' + mode) / 'r' / 'checkpoints'
+        files = sorted(os.listdir(str(ck)))
+        assert files, 'no checkpoint written'
+        out[mode] = torch.load(str(ck / files[-1]), map_location='cpu')
+        del model
+
+    def flat(prefix, o, acc):
+        if torch.is_tensor(o):
+            acc[prefix] = o
+        elif isinstance(o, dict):
+            for k, v in o.items():
+                flat('%s.%s' % (prefix, k), v, acc)
+        elif isinstance(o, (list, tuple)):
+            for i, v in enumerate(o):
+                flat('%s[%d]' % (prefix, i), v, acc)
+        return acc
+    a, b = flat('', out['0'], {}), flat('', out['1'], {})
+    assert a.keys() == b.keys() and len(a) > 20
+    bad = [k for k in a if not torch.equal(a[k], b[k])]
+    assert not bad, bad[:8]
