@@ -920,7 +920,7 @@ __global__ __launch_bounds__(NTH) void inorm_bwd_fused_kernel(const InFusedArgs 
 struct InGridArgs {
     InFusedArgs a;
     float* partial;        // [N * CG][S][V] (value, tag) pairs
-    float* level2;         // [N * CG][G][V] (double, tag, -) quads: the groups' sums when S > S1
+    float* level2;         // [N * CG][G][V] (low half, tag, high half, tag) quads: the groups' sums (double) when S > S1
     int S1, G;             // workgroups whose partials one workgroup folds; groups of S1 per domain
     unsigned* cnt;         // [N * CG][4]: word 1 = the domain's epoch
     int S, rows;           // workgroups per (image, channel group), pixels per workgroup
@@ -1041,7 +1041,8 @@ __global__ __launch_bounds__(256, 4) void inorm_grid_kernel(const InGridArgs ga)
     // tags match and folds them itself, in index order (S * V <= 4 K values: one or two round trips with all loads in flight).
     // Two memory hops (store visible, load) instead of the five of a ticket / last-arriver-folds / totals / flag protocol.
     // The domain's epoch word is bumped by its workgroup 0 once it has seen all S partials -- by then every workgroup of the
-    // domain has read the old value (it read it before it wrote its partial).  The workspace starts zero-filled; tag 0 never occurs.
+    // domain has read the old value (it read it before it wrote its partial).  The workspace starts zero-filled; tag 0 never occurs;
+    // behind its header every odd 32-bit word is a tag word and every even one a value, in every layout (both exchange levels).
     const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(ga.partial + dom * ga.S * (size_t)ga.V * 2), 0, ga.S * ga.V * 8, 0x00020000);
     if (!alone) {
@@ -1103,14 +1104,16 @@ __global__ __launch_bounds__(256, 4) void inorm_grid_kernel(const InGridArgs ga)
         }
         if (ga.G > 1) {
             // level 2 (planes whose S partials are more than one workgroup should fold): the first workgroup of every group
-            // publishes the group's sums as (double, tag) in 16 bytes; everyone folds the G <= 8 of them
+            // publishes the group's sums (double) as two (half, tag) pairs; everyone folds the G <= 8 of them
             const __amdgpu_buffer_rsrc_t rs_l2 = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(ga.level2 + dom * ga.G * (size_t)ga.V * 4), 0, ga.G * ga.V * 16, 0x00020000);
             __syncthreads();
             if (s == g_lo) {
                 for (int k = t; k < ga.V; k += 256) {
+                    // (low half, tag), (high half, tag): every odd word of the workspace is a tag word in every layout that ever
+                    // used it, so a stale VALUE can never be taken for this launch's tag (layouts of different planes overlap)
                     const i32x2 bits = __builtin_bit_cast(i32x2, tot[k]);
-                    const i32x4 v4 = {bits[0], bits[1], (int)tag, 0};
+                    const i32x4 v4 = {bits[0], (int)tag, bits[1], (int)tag};
                     __builtin_amdgcn_raw_buffer_store_b128(v4, rs_l2, (grp * ga.V + k) * 16, 0, 16);
                 }
             }
@@ -1120,10 +1123,10 @@ __global__ __launch_bounds__(256, 4) void inorm_grid_kernel(const InGridArgs ga)
                     i32x4 v4 = {0, 0, 0, 0};
                     for (int spin = 0; spin < (1 << 20); spin++) {
                         v4 = __builtin_amdgcn_raw_buffer_load_b128(rs_l2, (q * ga.V + k) * 16, 0, 16);
-                        if ((unsigned)v4[2] == tag) break;
+                        if ((unsigned)v4[1] == tag && (unsigned)v4[3] == tag) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
-                    const i32x2 bits = {v4[0], v4[1]};
+                    const i32x2 bits = {v4[0], v4[2]};
                     tsum += __builtin_bit_cast(double, bits);
                 }
                 tot[k] = tsum;
