@@ -128,6 +128,10 @@ struct GccLaunchRec {
     int nargs; void* const* args; const unsigned* sizes;
 };
 bool gcc_replay_recording();
+unsigned gcc_replay_generation();          // recordings begun so far in this process (replay.hip)
+// pinned host word a waiting kernel stores a code into when a bounded spin expires (misc.hip; NULL if it could not be mapped)
+unsigned* gcc_device_error_word();
+extern "C" int gcc_device_error(int clear);
 void gcc_replay_record_kernel(const GccLaunchRec& rec);
 // the few non-kernel stream operations of the library, recorded the same way
 hipError_t gcc_memset_async(void* dst, int value, size_t bytes, hipStream_t st);
@@ -199,7 +203,7 @@ __host__ __device__ static inline int seg_to_logical(int p, int n, int split) { 
 // read is what orders the data.  M0 (the DMA's LDS base) is written in the same statement that uses it; nothing else in this
 // kernel depends on M0 (no LDS-DMA builtin is left).
 __device__ __forceinline__ void lds_dma16(const i32x4& rsrc, uint32_t lds_base, uint32_t voff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc) : "memory", "m0");
 }
 __device__ __forceinline__ i32x4 make_rsrc(const void* ptr, uint32_t bytes) {
     const uint64_t a = (uint64_t)ptr;

@@ -2,6 +2,7 @@
 #include <atomic>
 #include <mutex>
 #include <stdlib.h>
+#include <string.h>
 #include "common.hpp"
 #include <algorithm>
 
@@ -439,6 +440,34 @@ void opt_init() {
 int gcc_opt(int id) {
     std::call_once(g_opt_once, opt_init);
     return g_opt[id].load(std::memory_order_relaxed);
+}
+// ---- device-side error word ---------------------------------------------------------------------------------------
+// A kernel cannot return a code.  The few that wait inside a launch (inorm_grid_kernel's tagged exchange) bound every spin and,
+// should one expire, store a code into this word: pinned, mapped host memory the GPU writes directly and the host reads without
+// synchronising.  Every entry point of such a kernel returns GCC_ERR_LAUNCH while the word is set (sticky until gcc_device_error(1)).
+namespace {
+std::once_flag g_err_once;
+unsigned* g_err_host = nullptr;
+unsigned* g_err_dev = nullptr;
+void err_init() {
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return; }
+    memset(h, 0, 64);
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); d = h; }
+    g_err_host = (unsigned*)h; g_err_dev = (unsigned*)d;
+}
+}  // namespace
+unsigned* gcc_device_error_word() {
+    std::call_once(g_err_once, err_init);
+    return g_err_dev;
+}
+extern "C" int gcc_device_error(int clear) {
+    std::call_once(g_err_once, err_init);
+    if (!g_err_host) return 0;
+    const unsigned v = __atomic_load_n(g_err_host, __ATOMIC_RELAXED);
+    if (clear) __atomic_store_n(g_err_host, 0u, __ATOMIC_RELAXED);
+    return (int)v;
 }
 namespace { std::atomic<long long> g_launches{0}; }
 void gcc_count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }

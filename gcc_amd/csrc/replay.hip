@@ -118,6 +118,8 @@ void worker_loop(gcc_replay* r, int lane, int device) {
 }  // namespace
 
 bool gcc_replay_recording() { return t_rec != nullptr; }
+static std::atomic<unsigned> g_generation{0};
+unsigned gcc_replay_generation() { return g_generation.load(std::memory_order_relaxed); }
 
 void gcc_replay_record_kernel(const GccLaunchRec& k) {
     gcc_replay* r = t_rec;
@@ -195,6 +197,7 @@ extern "C" int gcc_replay_begin(gcc_replay_t** out) {
     gcc_replay* r = new (std::nothrow) gcc_replay;
     if (!r) return GCC_ERR_LAUNCH;
     r->recording = true;
+    g_generation.fetch_add(1, std::memory_order_relaxed);
     t_rec = r;
     *out = r;
     return GCC_OK;

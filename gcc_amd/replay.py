@@ -61,23 +61,39 @@ class IterationReplay:
 
     def _stage(self, which, batch):
         """the batch's tensors copied into persistent device buffers (allocated on first sight of a key / shape); returns the
-        batch dict the model sees: the same object every iteration"""
+        batch dict the model sees: the same object every iteration.
+
+        A device-resident batch may carry 'ready' (a torch.cuda.Event its producer -- gcc_amd.data's loader stream -- recorded
+        behind the last kernel that wrote it): the copies below wait for it on the current stream, and the source tensors are
+        marked as used on that stream so that the caching allocator does not hand their blocks back to the producer while a
+        copy is pending (without either the copy could read a half-written batch).  'ready' is NOT forwarded: the
+        staged buffers are produced by the copies on the current stream, so set_input records its own event behind them
+        (models/_streams._note_input) and the teacher's stream waits for THAT -- an ops.Event, hence part of the recording."""
         if batch is None:
             return None
         st = self.static[which]
         dev = self.model.device
+        cur = ops.current_stream()
+        ready = batch.get('ready') if hasattr(batch, 'get') else None
+        if ready is not None:
+            ops.wait_event(cur, ready)
         for k, v in batch.items():
+            if k == 'ready':
+                continue
             if torch.is_tensor(v):
                 t = st.get(k)
                 if t is None or t.shape != v.shape or t.dtype != v.dtype:
                     t = st[k] = torch.empty(v.shape, dtype=v.dtype, device=dev)
                 t.copy_(v, non_blocking=True)
+                if v.is_cuda:
+                    v.record_stream(cur)
             else:
                 st[k] = v
+        st.pop('ready', None)
         return st
 
     def _signature(self, a, b):
-        return tuple((k, tuple(v.shape)) for d in (a, b) if d is not None for k, v in sorted(d.items()) if torch.is_tensor(v))
+        return tuple((k, tuple(v.shape)) for d in (a, b) if d is not None for k, v in sorted(d.items(), key=lambda kv: kv[0]) if torch.is_tensor(v))
 
     def usable(self):
         if not self.enabled or not torch.cuda.is_available():
