@@ -21,7 +21,8 @@ class conv_t(C.Structure):
 
 class epilogue_t(C.Structure):
     _fields_ = [('bias', C.c_void_p), ('act', C.c_int), ('slope', C.c_float), ('stats_partial', C.c_void_p),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('bn', C.c_void_p),
+                ('y2', C.c_void_p), ('ldy2', C.c_int), ('y2off', C.c_int), ('y2_mode', C.c_int), ('y2_gate', C.c_void_p)]
 
 
 class bnact_t(C.Structure):
@@ -33,7 +34,7 @@ class bnact_t(C.Structure):
 class bn_t(C.Structure):
     _fields_ = [('gamma', C.c_void_p), ('beta', C.c_void_p), ('eps', C.c_float), ('momentum', C.c_float), ('count', C.c_double),
                 ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p),
-                ('scale', C.c_void_p), ('shift', C.c_void_p)]
+                ('scale', C.c_void_p), ('shift', C.c_void_p), ('tail_ws', C.c_void_p), ('tail_ws_bytes', C.c_size_t)]
 
 
 class bnact_bwd_t(C.Structure):
@@ -41,7 +42,7 @@ class bnact_bwd_t(C.Structure):
                 ('gamma', C.c_void_p), ('beta', C.c_void_p), ('gate', C.c_void_p), ('gate_after_act', C.c_int),
                 ('act', C.c_int), ('slope', C.c_float), ('act2', C.c_int), ('drop_p', C.c_float),
                 ('seed', C.c_uint64), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('dalpha', C.c_void_p),
-                ('groups', C.c_int), ('pad_', C.c_int)]
+                ('groups', C.c_int), ('flags', C.c_int)]
 
 
 class adam_tensor_t(C.Structure):
@@ -67,8 +68,8 @@ class adam_chunk_t(C.Structure):
 (OPT_IGEMM_BIG, OPT_IGEMM_BIG_MIN, OPT_IGEMM_BIG_NK, OPT_IGEMM_GLDS, OPT_IGEMM_HEAD, OPT_IGEMM_THIN, OPT_WGRAD_BIG,
  OPT_BN_SWEEPS, OPT_BN_MAXBLK, OPT_BN_REDUCE_THREADS, OPT_BN_REDUCE_CAP, OPT_INORM_LPP, OPT_WGRAD_WGS_BIG,
  OPT_WGRAD_WGS, OPT_IGEMM_FORCE_BC, OPT_IGEMM_FORCE_KSPLIT, OPT_IGEMM_NARROW, OPT_IGEMM_PAIR, OPT_WGRAD_BIG_MIN_TILES, OPT_FUSE_BN,
- OPT_BN_BWD_SMALL, OPT_WGRAD_ROW_TABLE, OPT_IGEMM_HALO, OPT_FUSE_BN_PARTIAL_KB, OPT_INORM_GRID,
- OPT_DEBUG) = range(26)
+ OPT_BN_BWD_SMALL, OPT_WGRAD_ROW_TABLE, OPT_IGEMM_HALO, OPT_FUSE_BN_PARTIAL_KB, OPT_INORM_GRID, OPT_HALO_HC,
+ OPT_DEBUG) = range(27)
 
 _P = C.c_void_p
 _I = C.c_int
@@ -80,12 +81,14 @@ PROTOTYPES = {
     'gcc_strerror': (C.c_char_p, [_I]),
     'gcc_version': (_I, []),
     'gcc_launch_count': (C.c_longlong, [_I]),
+    'gcc_device_error': (_I, [_I]),
     'gcc_set_option': (_I, [_I, _I]),
     'gcc_get_option': (_I, [_I]),
     'gcc_conv_set_plan': (_I, [_I, _I, _I]),
     'gcc_conv_tile': (_I, [C.POINTER(conv_t), _I]),
     'gcc_conv_stat_tiles': (_I, [C.POINTER(conv_t), _I]),
     'gcc_conv_route': (_I, [C.POINTER(conv_t), _I, C.POINTER(epilogue_t)]),
+    'gcc_conv_y2_supported': (_I, [C.POINTER(conv_t), _I, C.POINTER(epilogue_t)]),
     'gcc_conv_workspace': (_Z, [C.POINTER(conv_t), _I]),
     'gcc_conv_fprop': (_I, [C.POINTER(conv_t), _P, _P, _P, C.POINTER(epilogue_t), _P]),
     'gcc_conv_dgrad': (_I, [C.POINTER(conv_t), _P, _P, _P, C.POINTER(epilogue_t), _P]),

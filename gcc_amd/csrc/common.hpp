@@ -210,6 +210,39 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* ptr, uint32_t bytes) {
     return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
 }
 
+// ---- BatchNorm statistics: the canonical fold of the per-tile partial sums (round 4) ---------------------------------------
+// Every producer of training statistics (the conv epilogues, the split-K fold kernel, gcc_channel_stats) writes rows of fp32
+// partial sums [row][2][C].  Their fold has ONE order, whoever performs it -- bn_finalize_kernel (norm_act.hip) or the
+// last-arriving workgroups of the producing launch (stats_tail, igemm_common.hpp): rows are summed in double, ascending,
+// inside groups of FIN_GROUP consecutive rows; the group sums are summed in double, ascending.  Same bits either way, which is
+// what lets a pass that ran ahead of its place (the early D(real) pass) replay its finalize later with the running-statistics
+// update, and lets tests compare the two routes bit for bit.
+constexpr int FIN_GROUP = 16;
+__device__ __forceinline__ void bn_channel_finalize(double s, double ss, double count, float eps, float momentum, const float* gamma,
+                                                    const float* beta, int c, float* rmean, float* rvar, float* mean, float* rstd,
+                                                    float* scale, float* shift) {
+    const double m = s / count;
+    double var = ss / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float r = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    if (mean) mean[c] = (float)m;
+    if (rstd) rstd[c] = r;
+    scale[c] = g * r;
+    shift[c] = b - (float)m * g * r;
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+    if (rvar) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+// a partial sum another workgroup of the same launch may read (stats_tail, igemm_common.hpp; bwd_tail, norm_act.hip): sc1 = write-through
+__device__ __forceinline__ void st_stat(float* p, float v, bool sc1) {
+    if (sc1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 // XCD-aware remap of a linear workgroup id (8 XCDs, round-robin dispatch): logical tiles that are
 // adjacent end up on the same XCD (shared L2).  Bijective for any nwg.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -49,16 +49,20 @@ struct HaloParams {
     int ntiles;                    // column tiles
     int nchunks;                   // Ct / 64
     int PH, PW;                    // positions that exist (mode 3: Ho x Wo of the padded H x W grid; otherwise the whole grid)
+    TailFin fin;                   // BatchNorm finalize by the last-arriving workgroups (igemm_common.hpp); tickets NULL: off
 };
 
-constexpr int HB = 256, HC = 256;
-using HCfg = Cfg<HB, HC>;
-constexpr int HALO_W_BYTES = HC * BK * 2;          // one weight stage: [256][64] bf16
+constexpr int HB = 256;
 constexpr int HALO_MAX_PIECES = 48;                // 6 per wave
 
-template <bool S1>
+// HC: columns of the tile.  256: the round-3 form (8 waves of 64 pixels x 128 columns).  128 (round 4): 8 waves of 64 x 64 -- twice
+// the workgroups for the launches whose 256-column tiles cover half the chip (PatchGAN L3 forward, L4 data gradient: 128 of
+// 256 CUs) and for 128-column layers; half the weight stage (the pixel slices are staged by both column tiles of a pixel tile).
+template <bool S1, int HC>
 __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
-    using C = HCfg;
+    using C = Cfg<HB, HC>;
+    constexpr int HALO_W_BYTES = HC * BK * 2;        // one weight stage: [HC][64] bf16
+    constexpr int WPIECES = HC / 64;                 // 1-KiB weight pieces per wave and k-step
     constexpr int T = S1 ? 16 : 4;                   // k-steps (taps) a staged slice serves
     extern __shared__ __attribute__((aligned(128))) char smem[];
     char* sW = smem;                                 // weights [2][256][128 B]
@@ -126,9 +130,9 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
         }
     };
 
-    // ---- weights: wave w stages rows 32 w .. 32 w + 31 of the [256][64] tile, four 1-KiB pieces --------------------------------
+    // ---- weights: wave w stages rows (HC / 8) w .. of the [HC][64] tile, WPIECES 1-KiB pieces -----------------------------------
     // (the plan guarantees whole tiles: every row exists)
-    const int wr0 = wave * 32 + (lane >> 3);
+    const int wr0 = wave * (HC / 8) + (lane >> 3);
     const int w_row0 = (p.mode == 2 ? (wr0 & 127) : n0 + wr0) * p.ldw * 2 + chunk * 16;
     const int px_w = p.mode == 2 ? (wave >> 2) : pxz;      // column half of the rows this wave stages (mode 2)
     auto issue_w = [&](int kt, int buf) {
@@ -147,9 +151,9 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
         }
         const int tapoff = ((kh * 4 + kw) * p.Ct + ch * BK) * 2;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < WPIECES; i++) {
             const uint32_t off = (uint32_t)(w_row0 + tapoff + i * (16 * p.ldw));
-            lds_dma16(rs_wgt, lds0 + buf * HALO_W_BYTES + (wave * 4 + i) * 1024, off);
+            lds_dma16(rs_wgt, lds0 + buf * HALO_W_BYTES + (wave * WPIECES + i) * 1024, off);
         }
     };
 
@@ -215,21 +219,30 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
             for (int j = 0; j < C::PB; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[i], fa0[j], acc[i][j], 0, 0, 0);
             fw1[i] = wfrag(1, i);
-            if (i & 1) fa1[i >> 1] = afrag(1, i >> 1);
+            if constexpr (C::CB == 8) { if (i & 1) fa1[i >> 1] = afrag(1, i >> 1); }
+            else fa1[i] = afrag(1, i);
         }
 #pragma unroll
         for (int i = 0; i < C::CB; i++)
 #pragma unroll
             for (int j = 0; j < C::PB; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[i], fa1[j], acc[i][j], 0, 0, 0);
-        static_assert(C::CB == 8 && C::PB == 4, "schedule below is written for 128 x 64 per wave");
+        static_assert((C::CB == 8 || C::CB == 4) && C::PB == 4, "schedules below: 128 x 64 or 64 x 64 per wave");
         __builtin_amdgcn_sched_group_barrier(0x100, C::CB + C::PB, 0);
+        if constexpr (C::CB == 8) {
 #pragma unroll
-        for (int i = 0; i < C::CB / 2; i++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, C::PB, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, C::PB, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            for (int i = 0; i < C::CB / 2; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, C::PB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, C::PB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < C::CB; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, C::PB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
         }
         __builtin_amdgcn_sched_group_barrier(0x008, C::CB * C::PB, 0);
     };
@@ -342,9 +355,10 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
             float ts = 0.f, tss = 0.f;
 #pragma unroll
             for (int q = 0; q < PARTS; q++) { ts += sR[q * HC + tid]; tss += sR[C::NT + q * HC + tid]; }
-            p.stats[((size_t)mt * 2 + 0) * p.Cout + n0 + tid] = ts;
-            p.stats[((size_t)mt * 2 + 1) * p.Cout + n0 + tid] = tss;
+            st_stat(p.stats + ((size_t)mt * 2 + 0) * p.Cout + n0 + tid, ts, p.fin.tickets != nullptr);
+            st_stat(p.stats + ((size_t)mt * 2 + 1) * p.Cout + n0 + tid, tss, p.fin.tickets != nullptr);
         }
+        if (p.fin.tickets) stats_tail<C::NT>(p.fin, p.stats, p.Cout, mt, (int*)(smem + HB * C::OSTRIDE + 2 * C::NT * 4), tid);
     }
 }
 
@@ -359,9 +373,9 @@ HaloPlan halo_plan(const gcc_conv_t* c, int dgrad) {
     if (c->stride == 2) {
         if ((c->H & 1) || (c->W & 1)) return h;
         gh = c->H / 2; gw = c->W / 2;
-        if (!dgrad) { if (Cout % HC) return h; h.mode = 0; }
-        else if (Cout == 128) h.mode = 2;
-        else if (Cout % HC == 0) h.mode = 1;
+        if (!dgrad) { if (Cout % 128) return h; h.mode = 0; }
+        else if (Cout == 128 && gcc_opt(GCC_OPT_HALO_HC) != 128) h.mode = 2;
+        else if (Cout % 128 == 0) h.mode = 1;
         else return h;
         int tw = 256;
         while (tw > gw) tw >>= 1;
@@ -372,7 +386,7 @@ HaloPlan halo_plan(const gcc_conv_t* c, int dgrad) {
         h.phases = h.mode == 0 ? 1 : (h.mode == 1 ? 4 : 2);
     } else if (c->stride == 1) {
         if (gcc_opt(GCC_OPT_IGEMM_HALO) < 2) return h;            // 2 (default): the stride-1 form too
-        if (Cout % HC) return h;
+        if (Cout % 128) return h;
         gh = c->H; gw = c->W;                     // forward: the padded grid (Ho = H - 1 rows exist)
         h.mode = dgrad ? 4 : 3;
         h.TW = 16; h.TR = 16;
@@ -385,19 +399,34 @@ HaloPlan halo_plan(const gcc_conv_t* c, int dgrad) {
     h.npieces = (h.HR * h.HWp + 7) / 8;
     if (h.npieces > HALO_MAX_PIECES) return h;
     h.tiles_x = gw / h.TW; h.tiles_y = gh / h.TR;
-    h.ntiles = h.mode == 2 ? 1 : Cout / HC;
-    const size_t loop = 2 * (size_t)HALO_W_BYTES + 2 * (size_t)h.npieces * 1024;
-    const size_t epi = (size_t)HCfg::LDS_BYTES_EPI;
+    // columns per tile: 256 (one workgroup per CU, the least CU time per FLOP), or 128 -- twice the workgroups -- where the layer
+    // has no 256-column tiling, where 256-column tiles are too few to be routed here at all, or (GCC_OPT_HALO_HC 1; the models'
+    // single-stream plan sets it like GCC_OPT_IGEMM_PAIR) where they would cover only half the chip
+    const long pix_tiles = (long)c->N * h.tiles_x * h.tiles_y * h.phases;
+    const int pref = gcc_opt(GCC_OPT_HALO_HC);
+    h.hc = 256;
+    if (h.mode != 2) {
+        const bool can256 = Cout % 256 == 0, can128 = Cout % 128 == 0;
+        const long w256 = can256 ? pix_tiles * (Cout / 256) : 0;
+        if (pref == 128 && can128) h.hc = 128;
+        else if (pref == 256 && can256) h.hc = 256;
+        else if (!can256 || w256 < gcc_opt(GCC_OPT_IGEMM_BIG_MIN) || (pref == 1 && w256 < 192)) h.hc = can128 ? 128 : 256;
+        if (Cout % h.hc) return h;
+    }
+    h.ntiles = h.mode == 2 ? 1 : Cout / h.hc;
+    const size_t loop = 2 * (size_t)h.hc * BK * 2 + 2 * (size_t)h.npieces * 1024;
+    const size_t epi = h.hc == 256 ? (size_t)Cfg<HB, 256>::LDS_BYTES_EPI : (size_t)Cfg<HB, 128>::LDS_BYTES_EPI;
     h.lds = loop > epi ? loop : epi;
     if (h.lds > 160 * 1024) return h;
-    h.wgs = (long)c->N * h.tiles_x * h.tiles_y * h.ntiles * h.phases;
+    h.wgs = pix_tiles * h.ntiles;
     h.ok = 1;
     return h;
 }
 
 int launch_halo(const gcc_conv_t* c, int dgrad, const HaloPlan& h, const void* src, const void* w, void* dst, const gcc_epilogue_t* ep,
-                hipStream_t st) {
+                const TailFin* fin, hipStream_t st) {
     HaloParams p;
+    p.fin = fin ? *fin : TailFin{};
     const int Ho = gcc_conv_out(c->H, 4, c->stride, 1), Wo = gcc_conv_out(c->W, 4, c->stride, 1);
     p.src = (const bf16_t*)src; p.wgt = (const bf16_t*)w; p.dst = (bf16_t*)dst;
     p.bias = ep ? ep->bias : nullptr; p.stats = ep ? ep->stats_partial : nullptr;
@@ -420,12 +449,19 @@ int launch_halo(const gcc_conv_t* c, int dgrad, const HaloPlan& h, const void* s
     p.PH = h.mode == 3 ? Ho : h.tiles_y * h.TR; p.PW = h.mode == 3 ? Wo : h.tiles_x * h.TW;
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute((const void*)igemm_halo_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)igemm_halo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)igemm_halo_kernel<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)igemm_halo_kernel<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)igemm_halo_kernel<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)igemm_halo_kernel<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const dim3 grid((unsigned)(c->N * h.tiles_x * h.tiles_y * h.ntiles), 1, h.phases);
-    if (h.mode >= 3) hipLaunchKernelGGL(igemm_halo_kernel<true>, grid, dim3(512), h.lds, st, p);
-    else hipLaunchKernelGGL(igemm_halo_kernel<false>, grid, dim3(512), h.lds, st, p);
+    if (h.hc == 256) {
+        if (h.mode >= 3) hipLaunchKernelGGL((igemm_halo_kernel<true, 256>), grid, dim3(512), h.lds, st, p);
+        else hipLaunchKernelGGL((igemm_halo_kernel<false, 256>), grid, dim3(512), h.lds, st, p);
+    } else {
+        if (h.mode >= 3) hipLaunchKernelGGL((igemm_halo_kernel<true, 128>), grid, dim3(512), h.lds, st, p);
+        else hipLaunchKernelGGL((igemm_halo_kernel<false, 128>), grid, dim3(512), h.lds, st, p);
+    }
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

@@ -83,10 +83,13 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
     const int m0 = mt * BP;
     const int n0 = nt * BC;
     if (m0 >= M) {         // smaller phase (odd sizes): uniform exit, no barrier reached yet
-        if (p.stats && tid < BC && n0 + tid < p.Cout) {
+        if (p.stats) {
             const int trow = blockIdx.z * p.mtiles_max + mt;
-            p.stats[((size_t)trow * 2 + 0) * p.Cout + n0 + tid] = 0.f;
-            p.stats[((size_t)trow * 2 + 1) * p.Cout + n0 + tid] = 0.f;
+            if (tid < BC && n0 + tid < p.Cout) {
+                st_stat(p.stats + ((size_t)trow * 2 + 0) * p.Cout + n0 + tid, 0.f, p.fin.tickets != nullptr);
+                st_stat(p.stats + ((size_t)trow * 2 + 1) * p.Cout + n0 + tid, 0.f, p.fin.tickets != nullptr);
+            }
+            if (p.fin.tickets) stats_tail<NT>(p.fin, p.stats, p.Cout, trow, (int*)smem, tid);     // its row counts like any other
         }
         return;
     }
@@ -530,6 +533,97 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams 
     }
 }
 
+// finish a split-K launch whose output feeds a BatchNorm, in ONE kernel on the whole chip (round 4): a workgroup owns `rpw`
+// consecutive rows of a phase x all channels -- folds the K slices (+ bias, activation), stores the bf16-rounded rows, writes
+// the statistic row of ITS rows and, with p.fin, takes part in the finalize by the last arrivers (stats_tail).  Replaces
+// splitk_epilogue + channel_stats (+ bn_finalize), and splitk_bn_act_kernel's C / 8 workgroups that walked every row twice
+// (14-56 us on the U-Net's <= 16x16 layers, profiles/r3z_unet_student_chain.txt).  Statistic rows: phases x wpp.
+struct FoldStatsArgs { IgemmParams p; int rpw, wpp, CHP, sh; };
+__global__ __launch_bounds__(256) void splitk_fold_stats_kernel(const FoldStatsArgs a) {
+    __shared__ float red[256 * 16];
+    __shared__ int ticket;
+    const IgemmParams& p = a.p;
+    int py = 0, px = 0, Hg, Wg, ostr = 1;
+    if (!p.dgrad) { Hg = p.Hd; Wg = p.Wd; }
+    else {
+        const int s = p.stride;
+        py = blockIdx.z / s; px = blockIdx.z % s; ostr = s;
+        Hg = (p.Hd - py + s - 1) / s; Wg = (p.Wd - px + s - 1) / s;
+    }
+    const int M = p.N * Hg * Wg;
+    const int CH = ceil8(p.Cout) / 8;
+    const int tid = threadIdx.x;
+    const int chl = tid & (a.CHP - 1), pl = tid >> a.sh, PL = 256 >> a.sh;
+    const int m_lo = blockIdx.x * a.rpw, m_hi = min(m_lo + a.rpw, M);
+    const float* base = p.partial + (size_t)blockIdx.z * p.ksplit * p.rows_max * p.Cpad;
+    const size_t sstride = (size_t)p.rows_max * p.Cpad;
+    float s[8], ss[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] = ss[j] = 0.f;
+    if (chl < CH) {
+        const int c0 = chl * 8;
+        for (int m = m_lo + pl; m < m_hi; m += PL) {
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const float* r0 = base + (size_t)m * p.Cpad + c0;
+            int sl = 0;
+            for (; sl + 3 < p.ksplit; sl += 4) {            // four slices (8 loads) in flight, added in slice order
+                f32x4 u[4], w[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { u[q] = *(const f32x4*)(r0 + (sl + q) * sstride); w[q] = *(const f32x4*)(r0 + (sl + q) * sstride + 4); }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    v[0] += u[q][0]; v[1] += u[q][1]; v[2] += u[q][2]; v[3] += u[q][3];
+                    v[4] += w[q][0]; v[5] += w[q][1]; v[6] += w[q][2]; v[7] += w[q][3];
+                }
+            }
+            for (; sl < p.ksplit; sl++) {
+                const f32x4 u = *(const f32x4*)(r0 + sl * sstride), w = *(const f32x4*)(r0 + sl * sstride + 4);
+                v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+                v[4] += w[0]; v[5] += w[1]; v[6] += w[2]; v[7] += w[3];
+            }
+            if (p.bias) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] += c0 + j < p.Cout ? p.bias[c0 + j] : 0.f;
+            }
+            apply_act8(v, v, p.act, p.slope);
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (c0 + j >= p.Cout) v[j] = 0.f;          // pad channels stay exact zeros
+            const i32x4 pk = pack8(v);
+            float r[8];
+            unpack8(pk, r);
+#pragma unroll
+            for (int j = 0; j < 8; j++) { s[j] += r[j]; ss[j] += r[j] * r[j]; }
+            const int n = m / (Hg * Wg);
+            const int rr = m - n * (Hg * Wg);
+            const int oy = rr / Wg, ox = rr - oy * Wg;
+            const size_t o = ((size_t)(n * p.Hd + oy * ostr + py) * p.Wd + (ox * ostr + px)) * p.ldd + p.doff + c0;
+            *(i32x4*)(p.dst + o) = pk;
+        }
+    }
+    if (!p.stats) return;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { red[tid * 16 + j] = s[j]; red[tid * 16 + 8 + j] = ss[j]; }
+    __syncthreads();
+    const int trow = blockIdx.z * a.wpp + blockIdx.x;
+    const bool sc1 = p.fin.tickets != nullptr;
+    for (int idx = tid; idx < 2 * p.Cout; idx += 256) {      // row lanes folded in ascending order
+        const int w = idx >= p.Cout ? 1 : 0, c = idx - w * p.Cout;
+        float t = 0.f;
+        for (int q = 0; q < PL; q++) t += red[((q << a.sh) + (c >> 3)) * 16 + w * 8 + (c & 7)];
+        st_stat(p.stats + ((size_t)trow * 2 + w) * p.Cout + c, t, sc1);
+    }
+    if (p.fin.tickets) stats_tail<256>(p.fin, p.stats, p.Cout, trow, &ticket, tid);
+}
+// statistic rows of that kernel for a geometry: ~256 workgroups over all phases, never fewer per phase than the unsplit
+// launch's 128-row tiles (so that either route fits the rows gcc_conv_stat_tiles promised)
+static int fold_wpp(size_t max_rows, int phases) {
+    const long mt = (long)((max_rows + 127) / 128);
+    long w = 256 / phases;
+    if (w < mt) w = mt;
+    if (w > (long)max_rows) w = (long)max_rows;
+    return (int)(w < 1 ? 1 : w);
+}
+
 // per-channel sum / sum of squares of an NHWC bf16 tensor -> stats[0][2][C] (one 8-channel chunk per block)
 __global__ __launch_bounds__(256) void channel_stats_kernel(const bf16_t* __restrict__ x, int ld, int off, int C, size_t pixels,
                                                             float* __restrict__ stats, int tiles) {
@@ -816,6 +910,10 @@ struct ThinArgs {
     uint32_t x_bytes;
     int total;            // N * Ho * Wo
     FastDiv dHoWo, dWo;
+    // second output written by the same launch (round 4: gcc_epilogue_t.y2): f(y) of the rounded first output --
+    // mode 1: relu(y) (the U-Net's first skip: lin = lrelu(e0) for the next down conv, relu(e0) into the concat buffer; exact,
+    // relu(v) == max(lrelu(v), 0)); mode 2: y * gate[c] (the selective-activation PatchGAN's first gate, m in {0, .5, 1})
+    bf16_t* y2; int ldy2, y2off, mode2; const float* gate;
 };
 
 template <int NJ>      // 32-channel groups per workgroup column
@@ -924,7 +1022,21 @@ __global__ __launch_bounds__(256) void thin_fprop_kernel(const ThinArgs a) {
             const int pix = sidx * PPI + pl;
             const i32x4 v = *(const i32x4*)(stage + pix * ROWB + c * 16);
             const int q = tile * 16 + pix;
-            if (q < a.total && co < a.Co) *(i32x4*)(a.y + (size_t)q * a.ldy + a.yoff + co) = v;
+            if (q < a.total && co < a.Co) {
+                *(i32x4*)(a.y + (size_t)q * a.ldy + a.yoff + co) = v;
+                if (a.y2) {
+                    float f[8];
+                    unpack8(v, f);
+                    if (a.mode2 == 1) {
+#pragma unroll
+                        for (int e = 0; e < 8; e++) f[e] = fmaxf(f[e], 0.f);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; e++) f[e] *= (co + e < a.Co) ? a.gate[co + e] : 0.f;
+                    }
+                    *(i32x4*)(a.y2 + (size_t)q * a.ldy2 + a.y2off + co) = pack8(f);
+                }
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the image is rewritten by the next tile
     };
@@ -963,6 +1075,10 @@ static int launch_thin(const gcc_conv_t* c, const void* x, const void* w, void* 
     a.H = c->H; a.W = c->W; a.KW = c->KW; a.stride = c->stride; a.pad = c->pad; a.taps = c->KH * c->KW;
     a.Ho = gcc_conv_out(c->H, c->KH, c->stride, c->pad); a.Wo = gcc_conv_out(c->W, c->KW, c->stride, c->pad);
     a.ldx = c->ldx; a.xoff = c->xoff; a.ldy = c->ldy; a.yoff = c->yoff; a.Co = c->Co;
+    a.y2 = nullptr; a.ldy2 = a.y2off = a.mode2 = 0; a.gate = nullptr;
+    if (ep && ep->y2) {
+        a.y2 = (bf16_t*)ep->y2; a.ldy2 = ep->ldy2; a.y2off = ep->y2off; a.mode2 = ep->y2_mode; a.gate = ep->y2_gate;
+    }
     const size_t xb = (size_t)c->N * c->H * c->W * c->ldx * 2, outs = (size_t)c->N * a.Ho * a.Wo;
     if (xb >= OOB || outs >= (size_t)1 << 30) return -1;
     a.x_bytes = (uint32_t)xb; a.total = (int)outs;
@@ -1235,6 +1351,15 @@ static int launch_thin_dgrad(const gcc_conv_t* c, const void* dy, const void* wt
 }
 
 // internal entry (also used by distill.hip): `batch` independent problems, strides in elements
+extern "C" int gcc_conv_y2_supported(const gcc_conv_t* c, int dgrad, const gcc_epilogue_t* ep) {
+    if (check_conv(c) || dgrad || !ep || !thin_shape(c)) return 0;
+    if (ep->stats_partial || ep->act == GCC_ACT_TANH || (ep->act == GCC_ACT_LRELU && (ep->slope < 0.f || ep->slope > 1.f))) return 0;
+    if ((ep->ldy2 & 7) || (ep->y2off & 7)) return 0;
+    if (ep->y2_mode == 1) return ep->act == GCC_ACT_LRELU || ep->act == GCC_ACT_NONE;      // relu(y) == relu(pre-activation) for these
+    if (ep->y2_mode == 2) return ep->y2_gate != nullptr;
+    return 0;
+}
+
 int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const void* w, void* dst, const gcc_epilogue_t* ep,
                        int batch, long src_bstride, long wgt_bstride, long dst_bstride, hipStream_t st) {
     GCC_ENTER();
@@ -1284,11 +1409,15 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
         const int rc2 = launch_thin_dgrad(c, src, w, dst, ep, st);
         if (rc2 >= 0) return rc2;
     }
+    if (ep && ep->y2) {          // a second output: the thin forward route only (gcc_conv_y2_supported says so beforehand)
+        if (!gcc_conv_y2_supported(c, dgrad, ep)) return GCC_ERR_UNSUPPORTED;
+    }
     if (batch == 1 && !dgrad && thin_shape(c) &&
         !(ep && (ep->stats_partial || ep->act == GCC_ACT_TANH || (ep->act == GCC_ACT_LRELU && (ep->slope < 0.f || ep->slope > 1.f))))) {
         const int rc2 = launch_thin(c, src, w, dst, ep, st);
         if (rc2 >= 0) return rc2;
     }
+    if (ep && ep->y2) return GCC_ERR_UNSUPPORTED;
     IgemmParams p;
     p.src = (const bf16_t*)src; p.wgt = (const bf16_t*)w; p.dst = (bf16_t*)dst;
     p.bias = ep ? ep->bias : nullptr;
@@ -1322,13 +1451,36 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
     const int phases = dgrad ? c->stride * c->stride : 1;
     if (dgrad && (c->KH < c->stride || c->KW < c->stride)) return GCC_ERR_UNSUPPORTED;
     const TilePlan tp = select_tile(max_rows, p.Cout, phases, conv_nk(c, dgrad), batch);
+    // BatchNorm behind this conv (ep->bn): its coefficients are final when this call returns -- folded by the last-arriving
+    // workgroups of the launch that writes the statistic rows where the route can (stats_tail), by a gcc_bn_finalize launch
+    // otherwise.  Every route writes (or zero-fills) the gcc_conv_stat_tiles() rows the caller allocated.
+    const gcc_bn_t* bnf = (ep && ep->bn && p.stats && batch == 1) ? ep->bn : nullptr;
+    const int rows_alloc = p.stats ? gcc_conv_stat_tiles(c, dgrad) : 0;
+    auto make_tail = [&](int rows, int wgs_per_row, TailFin* f) -> bool {
+        *f = TailFin{};
+        if (!bnf || !bnf->tail_ws || (((uintptr_t)bnf->tail_ws) & 15) || rows != rows_alloc) return false;
+        if (tail_ws_bytes(rows, p.Cout) > bnf->tail_ws_bytes) return false;
+        f->tickets = (unsigned*)bnf->tail_ws; f->grp = (double*)((char*)bnf->tail_ws + TAIL_TICKET_BYTES);
+        f->rows = rows; f->wgs_per_row = wgs_per_row; f->count = bnf->count; f->eps = bnf->eps; f->momentum = bnf->momentum;
+        f->gamma = bnf->gamma; f->beta = bnf->beta; f->running_mean = bnf->running_mean; f->running_var = bnf->running_var;
+        f->mean = bnf->mean; f->rstd = bnf->rstd; f->scale = bnf->scale; f->shift = bnf->shift;
+        return true;
+    };
+    float* const stats_rows = p.stats;             // (p.stats itself is cleared on the split route)
+    auto finalize_after = [&]() -> int {          // the separate launch, over the same rows in the same order
+        if (!bnf) return GCC_OK;
+        return gcc_bn_finalize(stats_rows, rows_alloc, p.Cout, bnf->count, bnf->gamma, bnf->beta, bnf->eps, bnf->momentum,
+                               bnf->running_mean, bnf->running_var, bnf->mean, bnf->rstd, bnf->scale, bnf->shift, (gcc_stream_t)st);
+    };
     if (batch == 1) {
         // k4 s2 p1 layers whose geometry fits: the tile's input neighbourhood staged once per 64 channels (conv_halo.hip).  With
         // statistics the tile rows must be the ones gcc_conv_stat_tiles() promised (the 256-pixel plan's).
         const HaloPlan h = halo_plan(c, dgrad);
         if (halo_routed(h, dgrad, p.stats != nullptr, tp.BP)) {
-            const int rc2 = launch_halo(c, dgrad, h, src, w, dst, ep, st);
-            if (rc2 >= 0) return rc2;
+            TailFin fin;
+            const bool tail = p.stats && make_tail(c->N * h.tiles_x * h.tiles_y, h.ntiles, &fin);
+            const int rc2 = launch_halo(c, dgrad, h, src, w, dst, ep, tail ? &fin : nullptr, st);
+            if (rc2 >= 0) return (rc2 == GCC_OK && !tail) ? finalize_after() : rc2;
         }
     }
     const int BC = tp.BC;
@@ -1348,13 +1500,35 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
         }
     }
     float* stats_out = p.stats;
+    bool fold_stats = false;         // split launch + splitk_fold_stats_kernel (statistics rows: phases x fold_wpp)
     if (batch == 1 && tp.BP == 128 && ep && ep->workspace) {
-        const SplitPlan sp = plan_ksplit((long)p.mtiles_max * p.ntiles * phases, conv_nk(c, dgrad), tp.max_slices);
+        SplitPlan sp = plan_ksplit((long)p.mtiles_max * p.ntiles * phases, conv_nk(c, dgrad), tp.max_slices);
+        if (sp.ksplit > 4 && stats_out) {
+            // a BatchNorm layer's slices are all read back by the fold kernel: cap them at GCC_OPT_FUSE_BN_PARTIAL_KB of partial
+            // tiles, never below four (fewer leave the partial-tile launch with a handful of workgroups)
+            const size_t per_slice = (size_t)phases * max_rows * p.Cpad * sizeof(float);
+            const size_t cap = (size_t)gcc_opt(GCC_OPT_FUSE_BN_PARTIAL_KB) * 1024;
+            const int nk = conv_nk(c, dgrad);
+            int ks = sp.ksplit;
+            while (ks > 4 && per_slice * ks > cap) ks = (ks + 1) / 2;
+            if (ks != sp.ksplit) { sp.kper = cdiv(nk, ks); sp.ksplit = cdiv(nk, sp.kper); }
+        }
         const size_t need = (size_t)phases * sp.ksplit * max_rows * p.Cpad * sizeof(float);
         if (sp.ksplit > 1 && need <= ep->workspace_bytes && (((uintptr_t)ep->workspace) & 15) == 0) {
             p.ksplit = sp.ksplit; p.kper = sp.kper; p.partial = (float*)ep->workspace;
-            p.stats = nullptr;       // statistics are taken from the finished tensor below
+            p.stats = nullptr;       // statistics are taken while the slices are folded
+            fold_stats = stats_out && ceil8(p.Cout) / 8 <= 256 && rows_alloc == fold_wpp(max_rows, phases) * phases;
+            if (fold_stats) p.raw_partial = 1;
         }
+    }
+    TailFin fin_direct;
+    bool tail_direct = false;
+    if (p.stats) {                   // un-split launch writes mtiles x phases rows itself
+        const int rows = p.mtiles_max * phases;
+        if (rows != rows_alloc && gcc_memset_async(stats_out, 0, (size_t)rows_alloc * 2 * p.Cout * sizeof(float), st) != hipSuccess)
+            return GCC_ERR_LAUNCH;
+        tail_direct = make_tail(rows, p.ntiles, &fin_direct);
+        if (tail_direct) p.fin = fin_direct;
     }
     if (tp.BP == 256) {
         rc = BC == 256 ? launch<256, 256>(p, phases, batch, st) : launch<256, 128>(p, phases, batch, st);
@@ -1367,14 +1541,29 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
         }
     }
     if (rc) return rc;
+    if (fold_stats) {
+        FoldStatsArgs a;
+        a.p = p; a.p.stats = stats_out;
+        a.wpp = fold_wpp(max_rows, phases);
+        a.rpw = (int)((max_rows + a.wpp - 1) / a.wpp);
+        const int CH = ceil8(p.Cout) / 8;
+        a.CHP = 1; a.sh = 0;
+        while (a.CHP < CH) { a.CHP <<= 1; a.sh++; }
+        TailFin fin;
+        const bool tail = make_tail(a.wpp * phases, 1, &fin);
+        a.p.fin = tail ? fin : TailFin{};
+        hipLaunchKernelGGL(splitk_fold_stats_kernel, dim3(a.wpp, 1, phases), dim3(256), 0, st, a);
+        GCC_CHECK_LAUNCH();
+        return tail ? GCC_OK : finalize_after();
+    }
     if (p.ksplit > 1 && stats_out && !p.pair) {
-        const int tiles = p.mtiles_max * phases;
         const size_t pixels = (size_t)p.N * p.Hd * p.Wd;
         hipLaunchKernelGGL(channel_stats_kernel, dim3(ceil8(p.Cout) / 8), dim3(256), 0, st, p.dst, p.ldd, p.doff, p.Cout,
-                           pixels, stats_out, tiles);
+                           pixels, stats_out, rows_alloc);
         GCC_CHECK_LAUNCH();
+        return finalize_after();
     }
-    return GCC_OK;
+    return tail_direct ? GCC_OK : finalize_after();
 }
 
 #ifdef GCC_CLOCK_PROBE
@@ -1605,7 +1794,7 @@ extern "C" int gcc_conv_bn_act(const gcc_conv_t* c, int dgrad, const void* x, co
         if (ks != sp.ksplit) { sp.kper = cdiv(nk, ks); sp.ksplit = cdiv(nk, sp.kper); }
     }
     const bool routed = (dgrad && thin_dgrad_shape(c)) || (!dgrad && thin_shape(c)) || head_shape(c);
-    if (!routed && sp.ksplit > 1 && max_rows * phases <= FOLD_BN_MAX_ROWS && gcc_opt(GCC_OPT_FUSE_BN)) {
+    if (!routed && sp.ksplit > 1 && max_rows * phases <= FOLD_BN_MAX_ROWS && gcc_opt(GCC_OPT_FUSE_BN) == 1) {
         // split launch with raw partial tiles, then the fused fold + statistics + finalize + normalise kernel
         FoldBnArgs a;
         IgemmParams& p = a.p;
@@ -1642,12 +1831,14 @@ extern "C" int gcc_conv_bn_act(const gcc_conv_t* c, int dgrad, const void* x, co
         GCC_CHECK_LAUNCH();
         return GCC_OK;
     }
-    // ordinary path: conv with statistics in its epilogue, finalize, normalise -- one call, three to five launches
-    gcc_epilogue_t ep = {nullptr, GCC_ACT_NONE, 0.f, stats, split_bytes ? ws : nullptr, split_bytes};
+    // default (GCC_OPT_FUSE_BN 2, round 4): the conv with statistics in its epilogue -- a split layer: partial tiles, then
+    // splitk_fold_stats_kernel on the whole chip -- finalized by the last-arriving workgroups of the launch that wrote the rows
+    // (bn->tail_ws; else a gcc_bn_finalize launch), then the normalising pass: two launches per layer, three on split layers.
+    // GCC_OPT_FUSE_BN 0: the same without the in-launch finalize.
+    gcc_bn_t bnf = *bn;
+    if (!gcc_opt(GCC_OPT_FUSE_BN)) { bnf.tail_ws = nullptr; bnf.tail_ws_bytes = 0; }
+    gcc_epilogue_t ep = {nullptr, GCC_ACT_NONE, 0.f, stats, split_bytes ? ws : nullptr, split_bytes, &bnf, nullptr, 0, 0, 0, nullptr};
     rc = gcc_internal_igemm(c, dgrad, x, w, y_raw, &ep, 1, 0, 0, 0, st);
-    if (rc) return rc;
-    rc = gcc_bn_finalize(stats, gcc_conv_stat_tiles(c, dgrad), Cout, bn->count, bn->gamma, bn->beta, bn->eps, bn->momentum,
-                         bn->running_mean, bn->running_var, bn->mean, bn->rstd, bn->scale, bn->shift, stream);
     if (rc) return rc;
     gcc_bnact_t q = *act;
     q.scale = bn->scale; q.shift = bn->shift; q.gate = nullptr; q.gate_after_act = 0; q.groups = 1; q.residual = nullptr; q.ld_residual = 0;
@@ -1682,6 +1873,11 @@ extern "C" int gcc_conv_stat_tiles(const gcc_conv_t* c, int dgrad) {
     const TilePlan tp = select_tile(conv_max_rows(c, dgrad), dgrad ? c->Ci : c->Co, phases, conv_nk(c, dgrad), 1);
     const HaloPlan h = halo_plan(c, dgrad);
     if (halo_routed(h, dgrad, true, tp.BP)) return c->N * h.tiles_x * h.tiles_y;
+    if (tp.BP == 128 && ceil8(dgrad ? c->Ci : c->Co) / 8 <= 256) {
+        // layers whose K loop is split over workgroups: the rows of splitk_fold_stats_kernel (an un-split fallback zero-fills them)
+        const SplitPlan sp = plan_ksplit((long)tp.mtiles * tp.ntiles * phases, conv_nk(c, dgrad), tp.max_slices);
+        if (sp.ksplit > 1) return fold_wpp(conv_max_rows(c, dgrad), phases) * phases;
+    }
     return tp.mtiles * phases;
 }
 

@@ -7,6 +7,88 @@
 // linkage whose body holds lambdas inside an `if constexpr` branch
 namespace gcc_igemm {
 
+// BatchNorm finalize inside the producing launch (round 4): the workgroups that write the last row of a group of FIN_GROUP
+// statistic rows fold that group, the one that completes the last group folds the group sums and finalizes -- the canonical
+// order of common.hpp, so the coefficients are bit for bit those of a gcc_bn_finalize launch over the same rows, which this
+// replaces (120 launches of ~5 us per Pix2Pix iteration, each a dependent hop on a chain of small kernels).  No workgroup waits
+// for another: arrival is counted with returning agent-scope atomics (tickets), the workgroup told "you are last" does the
+// fold.  Hand-off as in MI355X_MICROARCH.md, 'Valid forms' table row 1: every handed-off value is stored sc1 (write-through),
+// every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane adds to the counter; the workgroup whose add
+// came last loads them sc1 behind a workgroup barrier.  The ticket words start zero (caller-provided workspace, zero-filled
+// once) and the last arriver leaves them zero; the workspace belongs to ONE stream (its launches are ordered).
+struct TailFin {
+    unsigned* tickets;      // NULL: off.  [groups + 1]
+    double* grp;            // [groups][2][Cout] group sums
+    int rows;               // statistic rows of the launch (tile rows x phases)
+    int wgs_per_row;        // workgroups that contribute to one row (column tiles)
+    double count;
+    float eps, momentum;
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var; float* mean; float* rstd; float* scale; float* shift;
+};
+constexpr size_t TAIL_TICKET_BYTES = 4096;                 // up to 1023 groups = 16368 statistic rows
+static inline size_t tail_ws_bytes(int rows, int Cout) {
+    const size_t G = (size_t)(rows + FIN_GROUP - 1) / FIN_GROUP;
+    return G + 1 > TAIL_TICKET_BYTES / 4 ? ~(size_t)0 : TAIL_TICKET_BYTES + G * 2 * (size_t)Cout * sizeof(double);
+}
+// called by EVERY thread of a workgroup after the workgroup's statistic row `trow` has been stored (sc1); sh: one LDS int
+// nobody else touches until the call returns.  NT threads.
+template <int NT>
+__device__ __forceinline__ void stats_tail(const TailFin& f, const float* stats, int Cout, int trow, int* sh, int tid) {
+    typedef __attribute__((address_space(1))) unsigned int gu32;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int g = trow / FIN_GROUP;
+    const int G = (f.rows + FIN_GROUP - 1) / FIN_GROUP;
+    const int nr = min(FIN_GROUP, f.rows - g * FIN_GROUP);
+    if (tid == 0) sh[0] = (int)__hip_atomic_fetch_add((gu32*)f.tickets + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool group_last = sh[0] == nr * f.wgs_per_row - 1;
+    __syncthreads();
+    if (!group_last) return;
+    // (sc1 loads through buffer intrinsics: the compiler keeps them in flight together; scoped atomic loads were waited for one
+    // by one -- a 16-deep chain of round trips per fold, 9-21 us per conv launch: profiles/r4c_*)
+    const __amdgpu_buffer_rsrc_t rs_st = __builtin_amdgcn_make_buffer_rsrc((void*)stats, 0, (unsigned)((size_t)f.rows * 2 * Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_gr = __builtin_amdgcn_make_buffer_rsrc((void*)f.grp, 0, (unsigned)((size_t)G * 2 * Cout * 8), 0x00020000);
+    for (int idx = tid; idx < 2 * Cout; idx += NT) {
+        const int w = idx >= Cout ? 1 : 0, c = idx - w * Cout;
+        float v[FIN_GROUP];
+#pragma unroll
+        for (int r = 0; r < FIN_GROUP; r++)
+            v[r] = r < nr ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_st, (((g * FIN_GROUP + r) * 2 + w) * Cout + c) * 4, 0, 16)) : 0.f;
+        double sum = 0.0;
+#pragma unroll
+        for (int r = 0; r < FIN_GROUP; r++)
+            if (r < nr) sum += (double)v[r];
+        __hip_atomic_store(f.grp + ((size_t)g * 2 + w) * Cout + c, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) sh[0] = (int)__hip_atomic_fetch_add((gu32*)f.tickets + G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool last = sh[0] == G - 1;
+    __syncthreads();
+    if (!last) return;
+    for (int c = tid; c < Cout; c += NT) {
+        double s = 0.0, ss = 0.0;
+        for (int q0 = 0; q0 < G; q0 += 16) {                // sixteen groups' loads in flight, added in ascending order
+            i32x2 a[16], b[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int q = q0 + u < G ? q0 + u : G - 1;
+                a[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_gr, ((q * 2 + 0) * Cout + c) * 8, 0, 16);
+                b[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_gr, ((q * 2 + 1) * Cout + c) * 8, 0, 16);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+                if (q0 + u < G) { s += __builtin_bit_cast(double, a[u]); ss += __builtin_bit_cast(double, b[u]); }
+        }
+        bn_channel_finalize(s, ss, f.count, f.eps, f.momentum, f.gamma, f.beta, c, f.running_mean, f.running_var, f.mean, f.rstd,
+                            f.scale, f.shift);
+    }
+    for (int i = tid; i <= G; i += NT) __hip_atomic_store((gu32*)f.tickets + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct IgemmParams {
     const bf16_t* src;   // gather source (x for fprop, dy for dgrad)
     const bf16_t* wgt;   // packed weights, rows = output channels of this GEMM
@@ -40,15 +122,17 @@ struct IgemmParams {
     float* pair_slab;            // [tiles][256 * 256] fp32
     unsigned int* pair_flags;    // [tiles][2]: ticket, ready -- zeroed by the launcher before every launch
     int debug = 0;               // GCC_OPT_DEBUG ablations (timing diagnostics only)
+    TailFin fin = {};            // BatchNorm finalize by the last-arriving workgroups (tickets NULL: a separate gcc_bn_finalize)
 };
 
 constexpr int BK = 64;   // k per step
 
 // conv_halo.hip: k4 s2 p1 convolutions with the tile's input neighbourhood resident in LDS
-struct HaloPlan { int ok, mode, TR, TW, lgTW, HR, HW, HWp, npieces, tiles_x, tiles_y, ntiles, phases; size_t lds; long wgs; };
+struct HaloPlan { int ok, mode, TR, TW, lgTW, HR, HW, HWp, npieces, tiles_x, tiles_y, ntiles, phases, hc; size_t lds; long wgs; };
 HaloPlan halo_plan(const gcc_conv_t* c, int dgrad);
+struct TailFin;
 int launch_halo(const gcc_conv_t* c, int dgrad, const HaloPlan& h, const void* src, const void* w, void* dst, const gcc_epilogue_t* ep,
-                hipStream_t st);
+                const TailFin* fin, hipStream_t st);
 constexpr uint32_t OOB = 0x7FFFFFF0u;
 
 // BP pixels x BC channels per workgroup.  BP = 128: 4 waves (2 workgroups per CU); BP = 256: 8 waves,
@@ -78,7 +162,7 @@ struct Cfg {
     static constexpr int W_CHUNKS = (BC * 8 + NT - 1) / NT;  // register path: 16-B weight chunks per thread
     static constexpr int LDS_BYTES_LOOP = 2 * (BP + BC) * BK * 2;
     static constexpr int OSTRIDE = BC * 2 + 16;            // epilogue tile row stride (bytes)
-    static constexpr int LDS_BYTES_EPI = BP * OSTRIDE + 2 * NT * 4;
+    static constexpr int LDS_BYTES_EPI = BP * OSTRIDE + 2 * NT * 4 + 16;      // + the ticket word of stats_tail
     static constexpr int LDS_BYTES = LDS_BYTES_LOOP > LDS_BYTES_EPI ? LDS_BYTES_LOOP : LDS_BYTES_EPI;
 };
 
@@ -175,9 +259,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
 #pragma unroll
             for (int q = 0; q < PARTS; q++) { ts += sR[q * BC + tid]; tss += sR[NT + q * BC + tid]; }
             const int trow = blockIdx.z * p.mtiles_max + mt;
-            p.stats[((size_t)trow * 2 + 0) * p.Cout + n0 + tid] = ts;
-            p.stats[((size_t)trow * 2 + 1) * p.Cout + n0 + tid] = tss;
+            st_stat(p.stats + ((size_t)trow * 2 + 0) * p.Cout + n0 + tid, ts, p.fin.tickets != nullptr);
+            st_stat(p.stats + ((size_t)trow * 2 + 1) * p.Cout + n0 + tid, tss, p.fin.tickets != nullptr);
         }
+        if (p.fin.tickets) stats_tail<NT>(p.fin, p.stats, p.Cout, blockIdx.z * p.mtiles_max + mt, (int*)(smem + BP * C::OSTRIDE + 2 * NT * 4), tid);
     }
 }
 }  // namespace gcc_igemm

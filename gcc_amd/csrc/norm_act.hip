@@ -41,6 +41,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            const float* gamma, const float* beta, float eps, float momentum,
                                                            float* rmean, float* rvar, float* mean, float* rstd,
                                                            float* scale, float* shift) {
+    // the canonical fold (common.hpp, FIN_GROUP): 32 channels x 32 group lanes; lane pl sums the rows of group g0 + pl, the
+    // channel's first lane adds the 32 group sums in ascending order, chunk of 32 groups after chunk
     __shared__ double sh[2][32][33];
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -51,51 +53,32 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         if (rstd) rstd += g * C;
         scale += g * C; shift += g * C;
     }
+    const int G = (tiles + FIN_GROUP - 1) / FIN_GROUP;
     double s = 0.0, ss = 0.0;
-    if (c < C) {
-        int t = pl;
-        for (; t + 96 < tiles; t += 128) {          // four tile rows (8 loads) in flight per thread
-            float a[4], b[4];
+    for (int g0 = 0; g0 < G; g0 += 32) {
+        const int g = g0 + pl;
+        double a = 0.0, b = 0.0;
+        if (c < C && g < G) {
+            const int r0 = g * FIN_GROUP, nr = min(FIN_GROUP, tiles - r0);
+            float va[FIN_GROUP], vb[FIN_GROUP];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                a[u] = part[((size_t)(t + 32 * u) * 2 + 0) * C + c];
-                b[u] = part[((size_t)(t + 32 * u) * 2 + 1) * C + c];
+            for (int r = 0; r < FIN_GROUP; r++) {
+                va[r] = r < nr ? part[((size_t)(r0 + r) * 2 + 0) * C + c] : 0.f;
+                vb[r] = r < nr ? part[((size_t)(r0 + r) * 2 + 1) * C + c] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) { s += (double)a[u]; ss += (double)b[u]; }
+            for (int r = 0; r < FIN_GROUP; r++)
+                if (r < nr) { a += (double)va[r]; b += (double)vb[r]; }
         }
-        for (; t < tiles; t += 32) {
-            s += (double)part[((size_t)t * 2 + 0) * C + c];
-            ss += (double)part[((size_t)t * 2 + 1) * C + c];
+        sh[0][pl][cl] = a; sh[1][pl][cl] = b;
+        __syncthreads();
+        if (pl == 0) {
+            const int nq = min(32, G - g0);
+            for (int q = 0; q < nq; q++) { s += sh[0][q][cl]; ss += sh[1][q][cl]; }
         }
+        __syncthreads();
     }
-    sh[0][pl][cl] = s; sh[1][pl][cl] = ss;
-    __syncthreads();
-    // two-level fold of the 32 tile lanes (a single thread walking 31 dependent LDS reads cost ~1 us per launch)
-    if (pl < 8) {
-        s = (s + sh[0][pl + 8][cl]) + (sh[0][pl + 16][cl] + sh[0][pl + 24][cl]);
-        ss = (ss + sh[1][pl + 8][cl]) + (sh[1][pl + 16][cl] + sh[1][pl + 24][cl]);
-    }
-    __syncthreads();
-    if (pl < 8) { sh[0][pl][cl] = s; sh[1][pl][cl] = ss; }
-    __syncthreads();
-    if (pl == 0 && c < C) {
-        for (int q = 1; q < 8; q++) { s += sh[0][q][cl]; ss += sh[1][q][cl]; }
-        const double m = s / count;
-        double var = ss / count - m * m;
-        if (var < 0.0) var = 0.0;
-        const float r = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-        if (mean) mean[c] = (float)m;
-        if (rstd) rstd[c] = r;
-        scale[c] = g * r;
-        shift[c] = b - (float)m * g * r;
-        if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
-        if (rvar) {
-            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
-        }
-    }
+    if (pl == 0 && c < C) bn_channel_finalize(s, ss, count, eps, momentum, gamma, beta, c, rmean, rvar, mean, rstd, scale, shift);
 }
 
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -245,6 +228,8 @@ struct BwdArgs {
     float in_slope;
     int groups;       // > 1: InstanceNorm -- blockIdx.y = image; mean/rstd/partial/totals are per group
     int nblocks;      // reduce-pass workgroups per group
+    unsigned* tickets;   // NULL: a bnact_bwd_finalize launch.  Else the reduce pass's last-arriving workgroups finalize (bwd_tail):
+    double* grp;         // [groups of FIN_GROUP rows + 1] ticket words (zero, self-resetting) and [G][3][C8] group sums
 };
 
 // per-group view of the arguments (group = blockIdx.y)
@@ -269,6 +254,88 @@ __device__ __forceinline__ BwdArgs group_view(const BwdArgs& a0) {
 // GATE: a gate mask and/or d(alpha) is involved (needs z = bn(x) and a third sum); DROP: dropout.
 // The plain BatchNorm+activation case (both false) keeps 32 fewer live registers -> higher occupancy
 // for what is a pure HBM-streaming kernel.
+// what bnact_bwd_finalize_kernel does per channel with the three totals
+__device__ __forceinline__ void bwd_channel_finalize(const BwdArgs& a, int c, const double (&t)[3]) {
+    if (c < a.C) {
+        if (a.p.dbeta) a.p.dbeta[c] += (float)t[0];
+        if (a.p.dgamma) a.p.dgamma[c] += (float)t[1];
+        if (a.p.dalpha) a.p.dalpha[c] += (float)t[2];
+    }
+    // coefficients of the apply pass, dx = A dz + B x + K  (= gamma rstd (dz - mean(dz) - xhat mean(dz xhat))):
+    // one row each in `totals`, read by the apply kernel as 16-byte loads
+    float A = 0.f, B = 0.f, K = 0.f;
+    if (c < a.C && a.p.bn && !a.p.bn_eval) {
+        const float inv = 1.f / (float)a.pixels;
+        const float rs = a.p.rstd[c], mu = a.p.mean[c];
+        const float gr = (a.p.gamma ? a.p.gamma[c] : 1.f) * rs;
+        const float k0 = (float)t[0] * inv, k1 = (float)t[1] * inv;
+        A = gr; B = -gr * rs * k1; K = -gr * k0 + gr * rs * k1 * mu;
+    }
+    a.totals[c] = A; a.totals[a.C8 + c] = B; a.totals[2 * a.C8 + c] = K;
+}
+
+// The finalize of the backward pass by the reduce pass's own last-arriving workgroups (round 4; protocol and hand-off rules as
+// stats_tail, igemm_common.hpp): the workgroup that writes the last of FIN_GROUP consecutive partial rows folds them (double,
+// ascending), the one that completes the last group folds the group sums and does bwd_channel_finalize -- one launch fewer per
+// BatchNorm backward (52 per Pix2Pix iteration).  Deterministic: the order of the additions does not depend on who arrives when.
+template <int NT>
+__device__ __forceinline__ void bwd_tail(const BwdArgs& a, int* sh) {
+    typedef __attribute__((address_space(1))) unsigned int gu32;
+    const int tid = threadIdx.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int g = blockIdx.x / FIN_GROUP;
+    const int G = (a.nblocks + FIN_GROUP - 1) / FIN_GROUP;
+    const int nr = min(FIN_GROUP, a.nblocks - g * FIN_GROUP);
+    const int W = 3 * a.C8;
+    if (tid == 0) sh[0] = (int)__hip_atomic_fetch_add((gu32*)a.tickets + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool group_last = sh[0] == nr - 1;
+    __syncthreads();
+    if (!group_last) return;
+    // (sc1 loads through buffer intrinsics, all in flight together: scoped atomic loads were waited for one by one)
+    const __amdgpu_buffer_rsrc_t rs_pt = __builtin_amdgcn_make_buffer_rsrc((void*)a.partial, 0, (unsigned)((size_t)a.nblocks * W * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_gr = __builtin_amdgcn_make_buffer_rsrc((void*)a.grp, 0, (unsigned)((size_t)G * W * 8), 0x00020000);
+    for (int idx = tid; idx < W; idx += NT) {
+        float v[FIN_GROUP];
+#pragma unroll
+        for (int r = 0; r < FIN_GROUP; r++)
+            v[r] = r < nr ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_pt, ((g * FIN_GROUP + r) * W + idx) * 4, 0, 16)) : 0.f;
+        double sum = 0.0;
+#pragma unroll
+        for (int r = 0; r < FIN_GROUP; r++)
+            if (r < nr) sum += (double)v[r];
+        __hip_atomic_store(a.grp + (size_t)g * W + idx, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) sh[0] = (int)__hip_atomic_fetch_add((gu32*)a.tickets + G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool last = sh[0] == G - 1;
+    __syncthreads();
+    if (!last) return;
+    for (int c = tid; c < a.C8; c += NT) {
+        double t[3] = {0.0, 0.0, 0.0};
+        for (int q0 = 0; q0 < G; q0 += 8) {
+            i32x2 v[8][3];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int q = q0 + u < G ? q0 + u : G - 1;
+#pragma unroll
+                for (int k = 0; k < 3; k++) v[u][k] = __builtin_amdgcn_raw_buffer_load_b64(rs_gr, (q * W + k * a.C8 + c) * 8, 0, 16);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (q0 + u < G) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) t[k] += __builtin_bit_cast(double, v[u][k]);
+                }
+        }
+        bwd_channel_finalize(a, c, t);
+    }
+    for (int i = tid; i <= G; i += NT) __hip_atomic_store((gu32*)a.tickets + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // V = channels per thread (4: 8-byte accesses, half the per-channel state -> twice the occupancy)
 // NTH = 256 (default): small workgroups with 5 KB of LDS, so that they can share a CU with the two 74 KB workgroups of the
 // weight-gradient kernel running on the side stream (with 1024-thread / 61 KB workgroups the two streams took turns:
@@ -418,12 +485,13 @@ __global__ __launch_bounds__(NTH) void bnact_bwd_reduce_kernel(const BwdArgs a0)
     }
     // fold the pixel lanes of this block, one statistic at a time through the same small LDS buffer
     float* o = a.partial + (size_t)blockIdx.x * 3 * a.C8;
+    const bool sc1 = a.tickets != nullptr;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         if (k == 2 && !GATE) {
             if (pl == 0 && active) {
 #pragma unroll
-                for (int j = 0; j < V; j++) o[2 * a.C8 + c0 + j] = 0.f;
+                for (int j = 0; j < V; j++) st_stat(o + 2 * a.C8 + c0 + j, 0.f, sc1);
             }
             break;
         }
@@ -435,11 +503,12 @@ __global__ __launch_bounds__(NTH) void bnact_bwd_reduce_kernel(const BwdArgs a0)
             for (int j = 0; j < V; j++) {
                 float t = 0.f;
                 for (int q = 0; q < a.L.PPB; q++) t += red[q * a.L.CHP + ch][j];
-                o[k * a.C8 + c0 + j] = t;
+                st_stat(o + k * a.C8 + c0 + j, t, sc1);
             }
         }
         __syncthreads();
     }
+    if (a.tickets) bwd_tail<NTH>(a, (int*)&red[0][0]);
 }
 
 // pass 2: totals over blocks; parameter gradients (+=)
@@ -482,22 +551,7 @@ __global__ __launch_bounds__(1024) void bnact_bwd_finalize_kernel(const BwdArgs 
     if (pl == 0 && c < a.C8) {
         for (int q = 1; q < 8; q++)
             for (int k = 0; k < 3; k++) t[k] += sh[k][q][cl];
-        if (c < a.C) {
-            if (a.p.dbeta) a.p.dbeta[c] += (float)t[0];
-            if (a.p.dgamma) a.p.dgamma[c] += (float)t[1];
-            if (a.p.dalpha) a.p.dalpha[c] += (float)t[2];
-        }
-        // coefficients of the apply pass, dx = A dz + B x + K  (= gamma rstd (dz - mean(dz) - xhat mean(dz xhat))):
-        // one row each in `totals`, read by the apply kernel as 16-byte loads
-        float A = 0.f, B = 0.f, K = 0.f;
-        if (c < a.C && a.p.bn && !a.p.bn_eval) {
-            const float inv = 1.f / (float)a.pixels;
-            const float rs = a.p.rstd[c], mu = a.p.mean[c];
-            const float gr = (a.p.gamma ? a.p.gamma[c] : 1.f) * rs;
-            const float k0 = (float)t[0] * inv, k1 = (float)t[1] * inv;
-            A = gr; B = -gr * rs * k1; K = -gr * k0 + gr * rs * k1 * mu;
-        }
-        a.totals[c] = A; a.totals[a.C8 + c] = B; a.totals[2 * a.C8 + c] = K;
+        bwd_channel_finalize(a, c, t);
     }
 }
 
@@ -1369,7 +1423,23 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const SumArgs a) {
     const bool active = ch < a.L.CH;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (active) {
-        for (size_t pix = (size_t)blockIdx.x * a.L.PPB + pl; pix < a.pixels; pix += (size_t)gridDim.x * a.L.PPB) {
+        // four pixels (16-byte loads) in flight per lane: one at a time the sweep was a chain of dependent round trips -- 33 us
+        // for the 16.8 MB of a [16, 3, 256, 256] gradient (the U-Net's last bias gradient) against ~5 us of HBM time
+        const size_t step = (size_t)gridDim.x * a.L.PPB;
+        size_t pix = (size_t)blockIdx.x * a.L.PPB + pl;
+        for (; pix + 3 * step < a.pixels; pix += 4 * step) {
+            i32x4 r[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) r[u] = *(const i32x4*)(a.x + (pix + u * step) * a.ld + a.off + c0);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                float v[8];
+                unpack8(r[u], v);
+#pragma unroll
+                for (int j = 0; j < 8; j++) s[j] += v[j];
+            }
+        }
+        for (; pix < a.pixels; pix += step) {
             float v[8];
             unpack8(*(const i32x4*)(a.x + pix * a.ld + a.off + c0), v);
 #pragma unroll
@@ -1634,11 +1704,14 @@ static int bwd_blocks(size_t pixels, const Layout& L) {
     return (int)b;
 }
 
+constexpr size_t BWD_TICKET_BYTES = 4096;
 extern "C" size_t gcc_bnact_bwd_workspace(int C, size_t pixels) {      // per group
     Layout L;
     if (C <= 0 || !make_layout(C, &L)) return 0;
     const int C8 = (C + 7) & ~7;
-    return ((size_t)bwd_blocks(pixels, L) + 1) * 3 * C8 * sizeof(float);
+    // [ticket words of the in-launch finalize: BWD_TICKET_BYTES][partial rows][totals][group sums (double)]
+    const size_t blocks = (size_t)bwd_blocks(pixels, L);
+    return BWD_TICKET_BYTES + (blocks + 1) * 3 * C8 * sizeof(float) + 64 + ((blocks + FIN_GROUP - 1) / FIN_GROUP) * 3 * C8 * sizeof(double);
 }
 
 // extended entry used by the library itself and by the python shim: `in_act` = activation the
@@ -1667,8 +1740,16 @@ extern "C" int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_s
     if (!make_layout(C, &a.L)) return GCC_ERR_UNSUPPORTED;
     const int blocks = bwd_blocks(pixels, a.L);
     a.groups = groups; a.nblocks = blocks;
-    a.partial = (float*)ws;
+    a.partial = (float*)((char*)ws + BWD_TICKET_BYTES);
     a.totals = a.partial + (size_t)groups * blocks * 3 * a.C8;
+    a.tickets = nullptr; a.grp = nullptr;
+    // the caller says its workspace was zero-filled when it was allocated and belongs to one stream (flags bit 0): the
+    // finalize is then done by the reduce pass's last-arriving workgroups (ticket words at the head of the workspace)
+    const int G = (blocks + FIN_GROUP - 1) / FIN_GROUP;
+    if ((p->flags & 1) && groups == 1 && (size_t)(G + 1) * 4 <= BWD_TICKET_BYTES) {
+        a.tickets = (unsigned*)ws;
+        a.grp = (double*)(((uintptr_t)(a.totals + (size_t)3 * a.C8) + 63) & ~(uintptr_t)63);
+    }
     hipStream_t st = (hipStream_t)stream;
     const bool gate = p->gate != nullptr || p->dalpha != nullptr || p->gate_after_act;
     const bool drop = p->drop_p > 0.f;
@@ -1696,8 +1777,10 @@ extern "C" int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_s
 #undef GCC_LAUNCH_REDUCE
     }
     GCC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3((a.C8 + 31) / 32, groups), dim3(1024), 0, st, a, blocks);
-    GCC_CHECK_LAUNCH();
+    if (!a.tickets) {
+        hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3((a.C8 + 31) / 32, groups), dim3(1024), 0, st, a, blocks);
+        GCC_CHECK_LAUNCH();
+    }
     if (p->bn && !p->bn_eval) {
         hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(stream_blocks(pixels, a.L, 2), groups), dim3(256), 0, st, a);
         GCC_CHECK_LAUNCH();

@@ -268,10 +268,12 @@ class _GpuFileLoader:
         from .. import dist as gdist
         order = self.order()
         w = gdist.world_size()
-        # only TRAINING loaders are dealt over the ranks: an evaluation loader (serial order, or a non-train phase) is walked
-        # whole by whoever iterates it -- no collective inside, so one rank may evaluate alone
-        shard = bool(getattr(self.opt, 'isTrain', False)) and not self.opt.serial_batches and \
-            getattr(self.opt, 'phase', 'train') == 'train'
+        # only TRAINING loaders are dealt over the ranks: an evaluation loader (a non-train phase, or `self.shard = False` set by
+        # whoever builds it) is walked whole by whoever iterates it -- no collective inside, so one rank may evaluate alone
+        # (ADVICE r2).  --serial_batches only fixes the ORDER (a data-parallel training run with it used to feed the
+        # whole dataset to every rank).
+        shard = bool(getattr(self.opt, 'isTrain', False)) and getattr(self.opt, 'phase', 'train') == 'train' and \
+            getattr(self, 'shard', True)
         if w > 1 and shard:
             import torch.distributed as dist
             box = [order]

@@ -114,14 +114,17 @@ class ConvOp:
         self._pack.run()
 
     # -- forward ---------------------------------------------------------------------------
-    def forward(self, x, out, act=ACT_NONE, want_stats=False, use_bias=True):
+    def forward(self, x, out, act=ACT_NONE, want_stats=False, use_bias=True, bn=None, y2=None, y2_mode=0, y2_gate=None):
+        """bn: gcc_bn_t (BNOp.desc) of the BatchNorm behind this conv -- finalized inside the call (with want_stats);
+        y2 / y2_mode / y2_gate: a second output (ops.conv_fprop; plain convs only)"""
         b = self.bias.data if (self.bias is not None and use_bias) else None
         if not self.transposed:
             return ops.conv_fprop(x, self.w, self.rows_k, self.k, self.stride, self.pad, out=out, bias=b, act=act,
-                                  slope=LRELU, want_stats=want_stats)
+                                  slope=LRELU, want_stats=want_stats, bn=bn, y2=y2, y2_mode=y2_mode, y2_gate=y2_gate)
+        assert y2 is None
         N, _, H, W = out.shape
         return ops.conv_dgrad(x, self.wt, self.cols_k, H, W, self.k, self.stride, self.pad, out=out, bias=b, act=act,
-                              slope=LRELU, want_stats=want_stats)
+                              slope=LRELU, want_stats=want_stats, bn=bn)
 
     def forward_bn_act(self, x, raw, bnop, st, count, y, y2=None, act=ACT_NONE, act2=ACT_NONE, drop_p=0.0, seed=0):
         """conv + BatchNorm (training statistics) + activation [+ dropout, + second activated copy] as one C call"""
@@ -177,6 +180,13 @@ class BNOp:
 
     def replay_update(self, rec, tag):
         self.pending_batches += 1          # one more training-mode application inside a replayed iteration
+
+    def desc(self, st, count, device, running=True):
+        """gcc_bn_t for a conv call that finalizes this (training-mode) BatchNorm itself -- ConvOp.forward(..., bn=...): no
+        gcc_bn_finalize launch on the chain.  Counts the application like finalize() does."""
+        self.pending_batches += 1
+        ops.note_host(self)
+        return ops.bn_desc(self.bn, st, count, device, running)
 
     def finalize(self, stats, count, st, train):
         bn = self.bn
@@ -397,8 +407,9 @@ class UnetEngine:
         self.seed += 1
         c.iter_seed = self.seed
         # ---- down path
-        self.down[0].forward(c.x_in, c.e[0])
-        ops.bnact_fwd(c.e[0], c.lin[1], ops.cslice(c.rcat[1], 0, wd[0]), act=ACT_LRELU, act2=ACT_RELU)
+        # outermost down conv (no norm): both activated copies of e[0] straight from the conv launch -- the LeakyReLU'd one for the
+        # next down conv, the ReLU'd one into the concat buffer (hazard H1); e[0] itself is never materialised
+        self.down[0].forward(c.x_in, c.lin[1], act=ACT_LRELU, y2=ops.cslice(c.rcat[1], 0, wd[0]), y2_mode=ops.Y2_RELU)
         # (bench.py's bracketed roofline step times every igemm launch on its own: the layers run as separate calls there)
         fused = train and FUSE_CONV_BN and not ops.PROFILE.active
         for d in range(1, D - 1):
@@ -407,8 +418,11 @@ class UnetEngine:
                 self.down[d].forward_bn_act(c.lin[d], c.e[d], self.down_bn[d], c.st_down[d], n, c.lin[d + 1],
                                             ops.cslice(c.rcat[d + 1], 0, wd[d]), act=ACT_LRELU, act2=ACT_RELU)
                 continue
-            _, stats = self.down[d].forward(c.lin[d], c.e[d], want_stats=True)
-            self.down_bn[d].finalize(stats, n, c.st_down[d], train)
+            if train:
+                self.down[d].forward(c.lin[d], c.e[d], want_stats=True, bn=self.down_bn[d].desc(c.st_down[d], n, self.device))
+            else:
+                _, stats = self.down[d].forward(c.lin[d], c.e[d], want_stats=True)
+                self.down_bn[d].finalize(stats, n, c.st_down[d], train)
             ops.bnact_fwd(c.e[d], c.lin[d + 1], ops.cslice(c.rcat[d + 1], 0, wd[d]), scale=c.st_down[d].scale,
                           shift=c.st_down[d].shift, act=ACT_LRELU, act2=ACT_RELU)
         self.down[D - 1].forward(c.lin[D - 1], c.e[D - 1], act=ACT_RELU)      # innermost: conv + ReLU fused
@@ -423,8 +437,11 @@ class UnetEngine:
                                           seed=c.iter_seed * 64 + d)
                 src = c.rcat[d]
                 continue
-            _, stats = self.up[d].forward(src, c.t[d], want_stats=True)
-            self.up_bn[d].finalize(stats, N * hh * ww, c.st_up[d], train)
+            if train:
+                self.up[d].forward(src, c.t[d], want_stats=True, bn=self.up_bn[d].desc(c.st_up[d], N * hh * ww, self.device))
+            else:
+                _, stats = self.up[d].forward(src, c.t[d], want_stats=True)
+                self.up_bn[d].finalize(stats, N * hh * ww, c.st_up[d], train)
             ops.bnact_fwd(c.t[d], ops.cslice(c.rcat[d], self.uoff[d], uw[d]), scale=c.st_up[d].scale,
                           shift=c.st_up[d].shift, act=ACT_RELU, drop_p=drop, seed=c.iter_seed * 64 + d)
             src = c.rcat[d]
@@ -490,7 +507,8 @@ class UnetEngine:
                               beta=bn.bias.data, bn_eval=not c.train, act=ACT_LRELU, act2=ACT_RELU,
                               dgamma=bn.weight.grad if wgrad else None, dbeta=bn.bias.grad if wgrad else None)
             else:
-                ops.bnact_bwd(c.e[0], c.lin[1], c.g_lin[1], c.g_e[0], g2=g2, act=ACT_LRELU, act2=ACT_RELU)
+                # (x is not read for its values here: the activation derivatives come from the saved output lin[1])
+                ops.bnact_bwd(c.lin[1], c.lin[1], c.g_lin[1], c.g_e[0], g2=g2, act=ACT_LRELU, act2=ACT_RELU)
             if wgrad:
                 self.down[d].backward_weight(c.lin[d] if d > 0 else c.x_in, c.g_e[d])
                 self._seg_done(2 * D - 1 - d)
@@ -628,9 +646,10 @@ class PatchGANEngine:
         if self.masked and refresh:
             self.refresh_masks()
         c.deferred = []
-        self.conv[0].forward(c.x_in, c.a0, act=ACT_LRELU)
-        if self.masked:
-            ops.bnact_fwd(c.a0, c.g0, gate=self.mask[0], gate_after_act=True)
+        if self.masked:         # the first gate (applied after the LeakyReLU, models/Pix2Pix.py:320-322) by the conv launch itself
+            self.conv[0].forward(c.x_in, c.a0, act=ACT_LRELU, y2=c.g0, y2_mode=ops.Y2_GATE, y2_gate=self.mask[0])
+        else:
+            self.conv[0].forward(c.x_in, c.a0, act=ACT_LRELU)
         src = c.g0
         for li in range(1, L - 1):
             if self.inorm[li]:
@@ -641,13 +660,16 @@ class PatchGANEngine:
                     ops.in_finalize(ops.channel_stats(c.c[li]), c.hs[li][0] * c.hs[li][1], c.st[li])
                     ops.bnact_fwd(c.c[li], c.y[li], scale=c.st[li].scale, shift=c.st[li].shift, act=ACT_LRELU, groups=c.N)
             else:
-                _, stats = self.conv[li].forward(src, c.c[li], want_stats=True)
                 n = c.N * c.hs[li][0] * c.hs[li][1]
                 if defer_running and train:
-                    bn = self.bn[li].bn
-                    ops.bn_finalize(stats, n, bn.weight.data, bn.bias.data, None, None, c.st[li], eps=bn.eps, momentum=bn.momentum)
+                    # coefficients now (by the conv launch itself), running statistics when the pass's place comes
+                    _, stats = self.conv[li].forward(src, c.c[li], want_stats=True,
+                                                     bn=ops.bn_desc(self.bn[li].bn, c.st[li], n, self.device, running=False))
                     c.deferred.append((li, stats, n))
+                elif train:
+                    self.conv[li].forward(src, c.c[li], want_stats=True, bn=self.bn[li].desc(c.st[li], n, self.device))
                 else:
+                    _, stats = self.conv[li].forward(src, c.c[li], want_stats=True)
                     self.bn[li].finalize(stats, n, c.st[li], train)
                 ops.bnact_fwd(c.c[li], c.y[li], scale=c.st[li].scale, shift=c.st[li].shift, gate=self.mask[li], act=ACT_LRELU)
             src = c.y[li]
@@ -999,16 +1021,16 @@ class SNConvOp:
     def new_state(self):
         return SNState(self)
 
-    def forward(self, st, x, out, act=ACT_NONE, slope=LRELU, want_stats=False):
+    def forward(self, st, x, out, act=ACT_NONE, slope=LRELU, want_stats=False, bn=None):
         ops.spectral_power_iteration(self.w_bar.data, self.u.data, self.v.data, st.t, st.sigma, self.w_eff)
         ops.pack_weights_into(self.w_eff, st.w, st.wt)
         b = self.bias.data if self.bias is not None else None
         if not self.transposed:
             return ops.conv_fprop(x, st.w, self.rows, self.k, self.stride, self.pad, out=out, bias=b, act=act, slope=slope,
-                                  want_stats=want_stats)
+                                  want_stats=want_stats, bn=bn)
         _, _, H, W = out.shape
         return ops.conv_dgrad(x, st.wt, self.cols, H, W, self.k, self.stride, self.pad, out=out, bias=b, act=act, slope=slope,
-                              want_stats=want_stats)
+                              want_stats=want_stats, bn=bn)
 
     def backward_data(self, st, dy, out):
         if not self.transposed:
@@ -1146,8 +1168,12 @@ class SaganGeneratorEngine:
         c.train = train
         src = c.z
         for i in range(4):
-            _, stats = self.sn[i].forward(c.sn[i], src, c.raw[i], want_stats=True)
-            self.bn[i].finalize(stats, c.N * c.size[i] * c.size[i], c.bn[i], train)
+            n = c.N * c.size[i] * c.size[i]
+            if train:
+                self.sn[i].forward(c.sn[i], src, c.raw[i], want_stats=True, bn=self.bn[i].desc(c.bn[i], n, self.device))
+            else:
+                _, stats = self.sn[i].forward(c.sn[i], src, c.raw[i], want_stats=True)
+                self.bn[i].finalize(stats, n, c.bn[i], train)
             ops.bnact_fwd(c.raw[i], c.act[i], scale=c.bn[i].scale, shift=c.bn[i].shift, act=ACT_RELU)
             src = c.act[i]
             if i >= 2:
@@ -1379,16 +1405,25 @@ class SRResNetEngine:
         ops.prelu_fwd(c.raw0, self.first_slope.data, c.h0)
         h = c.h0
         for b, t in zip(self.blocks, c.blk):
-            _, st = b.conv1.forward(h, t.r1, want_stats=True)
-            b.bn1.finalize(st, N * hw, t.st1, train)
+            if train:
+                b.conv1.forward(h, t.r1, want_stats=True, bn=b.bn1.desc(t.st1, N * hw, self.device))
+            else:
+                _, st = b.conv1.forward(h, t.r1, want_stats=True)
+                b.bn1.finalize(st, N * hw, t.st1, train)
             ops.bnact_fwd(t.r1, t.z1, scale=t.st1.scale, shift=t.st1.shift)
             ops.prelu_fwd(t.z1, b.slope.data, t.a1)
-            _, st = b.conv2.forward(t.a1, t.r2, want_stats=True)
-            b.bn2.finalize(st, N * hw, t.st2, train)
+            if train:
+                b.conv2.forward(t.a1, t.r2, want_stats=True, bn=b.bn2.desc(t.st2, N * hw, self.device))
+            else:
+                _, st = b.conv2.forward(t.a1, t.r2, want_stats=True)
+                b.bn2.finalize(st, N * hw, t.st2, train)
             ops.bnact_fwd(t.r2, t.out, scale=t.st2.scale, shift=t.st2.shift, residual=h)
             h = t.out
-        _, st = self.mid.forward(h, c.rm, want_stats=True)
-        self.mid_bn.finalize(st, N * hw, c.st_m, train)
+        if train:
+            self.mid.forward(h, c.rm, want_stats=True, bn=self.mid_bn.desc(c.st_m, N * hw, self.device))
+        else:
+            _, st = self.mid.forward(h, c.rm, want_stats=True)
+            self.mid_bn.finalize(st, N * hw, c.st_m, train)
         ops.bnact_fwd(c.rm, c.hm, scale=c.st_m.scale, shift=c.st_m.shift, residual=c.h0)
         h = c.hm
         for j, (conv, slope) in enumerate(self.sub):
@@ -1533,8 +1568,12 @@ class SRDiscriminatorEngine:
         src = c.x_in
         for i in range(self.L):
             if self.bn[i] is not None:
-                _, st = self.conv[i].forward(src, c.raw[i], want_stats=True)
-                self.bn[i].finalize(st, c.N * c.hs[i][0] * c.hs[i][1], c.st[i], train)
+                n = c.N * c.hs[i][0] * c.hs[i][1]
+                if train:
+                    self.conv[i].forward(src, c.raw[i], want_stats=True, bn=self.bn[i].desc(c.st[i], n, self.device))
+                else:
+                    _, st = self.conv[i].forward(src, c.raw[i], want_stats=True)
+                    self.bn[i].finalize(st, n, c.st[i], train)
                 ops.bnact_fwd(c.raw[i], c.act[i], scale=c.st[i].scale, shift=c.st[i].shift, gate=self.mask[i], act=ACT_LRELU)
             else:
                 self.conv[i].forward(src, c.raw[i])

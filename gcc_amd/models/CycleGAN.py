@@ -60,8 +60,8 @@ class ImagePool:
         self.pool_size = pool_size
         self.count = 0              # images held
         self.store = None           # [pool_size, 3, H, W] NHWC bf16
-        self.sel = None             # device int32 [N][2]
-        self._n = 0
+        self.sel = None             # device int32 [8][2]: the draws of the group of images in flight
+        self._groups = []
 
     def _draw(self, N):
         """(mode, slot) per image: 0 pass through, 1 store in `slot` and pass through, 2 swap with `slot`"""
@@ -79,22 +79,38 @@ class ImagePool:
         return sel
 
     def query(self, images, out):
-        """images: NHWC bf16 batch view [N,3,H,W]; out: batch buffer of the same geometry that receives the answer"""
+        """images: NHWC bf16 batch view [N,3,H,W]; out: batch buffer of the same geometry that receives the answer.
+        The draws of up to 8 images travel in one launch argument (16 ints): a larger batch goes group by group, draws in image
+        order as in utils/image_pool.py:23-52 (any --batch_size works, as in the reference)."""
         N, _, H, W = images.shape
-        assert N <= 8, 'the draws of a batch travel in one launch argument (16 ints)'
         if self.store is None:
             self.store = ops.new_act(max(self.pool_size, 1), 3, H, W, images.device)
             self.sel = torch.zeros(16, dtype=torch.int32, device=images.device)
-        self._n = N
-        ops.note_dynamic(self)
-        ops.write_i32(self.sel, self._draw(N))
-        ops.image_pool_query(images, out, self.store, self.sel)
+        elif tuple(self.store.shape[2:]) != (H, W):
+            # the reference's pool would fail in torch.cat on mixed sizes; here the history buffer has one geometry
+            raise GccError('ImagePool holds %dx%d images, queried with %dx%d' % (self.store.shape[2], self.store.shape[3], H, W))
+        for gi, lo in enumerate(range(0, N, 8)):
+            hi = min(lo + 8, N)
+            while len(self._groups) <= gi:
+                self._groups.append(_PoolGroup(self))
+            grp = self._groups[gi]
+            grp.n = hi - lo
+            ops.note_dynamic(grp)
+            ops.write_i32(self.sel, self._draw(hi - lo))
+            ops.image_pool_query(images[lo:hi], out[lo:hi], self.store, self.sel)
         return out
+
+
+class _PoolGroup:
+    """one group of <= 8 images of an ImagePool.query: the unit a recorded gcc_write_i32 launch is patched by"""
+
+    def __init__(self, pool):
+        self.pool, self.n = pool, 0
 
     def replay_update(self, rec, tag):
         """the draws of one more iteration into the recorded gcc_write_i32 launch (its by-value argument 1)"""
         import ctypes as C
-        vals = (C.c_int * 16)(*self._draw(self._n))
+        vals = (C.c_int * 16)(*(self.pool._draw(self.n) + [0] * (16 - 2 * self.n)))
         n = ops.lib().gcc_replay_patch(rec, tag, 1, vals, 64)
         if n != 1:
             raise RuntimeError('gcc_replay_patch(image pool tag %d): %d launches patched' % (tag, n))

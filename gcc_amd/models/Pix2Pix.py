@@ -231,7 +231,9 @@ class HipAdam(torch.optim.Optimizer):
 # teacher's iteration is the critical path (its end gates the student's backward_G) and both networks' discriminator passes
 # fill the chip, so work given to the student early only delays the teacher.
 INTERLEAVE = int(os.environ.get('GCC_INTERLEAVE', '0'))
-TEACHER_EARLY_DREAL = os.environ.get('GCC_TEACHER_EARLY_DREAL', '0') == '1'      # measured: -7 % (a fifth busy queue); off
+# the online teacher's D(real) pass started early too: 1 = on an auxiliary stream of its own (measured: -7 %, a fifth busy queue on
+# four hardware queues); 2 = on the STUDENT's auxiliary stream, in front of the student's pass (no extra queue: round 4 A/B)
+TEACHER_EARLY_DREAL = int(os.environ.get('GCC_TEACHER_EARLY_DREAL', '0'))
 # the student joins the teacher's stream where the teacher's features and discriminator are final (after the head of the
 # teacher's backward_G), not at the end of the teacher's iteration: the teacher's generator backward + Adam + repack
 # (small and HBM-bound kernels) then run beside the student's distillation passes instead of in front of them
@@ -279,7 +281,16 @@ def _alternate(tgen, ts, sgen):
 # ------------------------------------------------------------------------------------------------
 class Pix2PixModel(TeacherStreamMixin, nn.Module):
 
-    replay_supported = False      # gcc_amd.replay: the U-Net's dropout seeds are by-value launch arguments of every iteration
+    @property
+    def replay_supported(self):
+        """gcc_amd.replay: the U-Net's dropout seeds are by-value launch arguments that change every iteration and that nothing
+        patches, so an iteration with dropout in it stays on the eager host path (--no_dropout, or the resnet backbone whose
+        blocks have Dropout(0), can be recorded: tests/test_replay_gpu.py).  The same holds for the online teacher."""
+        def dropout(m):
+            return (not m.resnet) and bool(getattr(getattr(m, 'G', None), 'drop_depths', None))
+        t = getattr(self, 'teacher_model', None)
+        return not dropout(self) and not (t is not None and dropout(t))
+
 
     def __init__(self, opt, filter_cfgs=None, channel_cfgs=None):
         super().__init__()
@@ -486,6 +497,8 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         # the student always; the online teacher only with GCC_TEACHER_EARLY_DREAL=1 (measured: 833 against 893 images/s)
         is_teacher = self.teacher_model is None
         aux = self._aux_stream() if (not is_teacher or (TEACHER_EARLY_DREAL and getattr(self, '_is_online_teacher', False))) else False
+        if is_teacher and TEACHER_EARLY_DREAL == 2 and aux:
+            aux = getattr(self, '_shared_aux', None) or False
         if not aux:
             return
         main = ops.current_stream()
@@ -646,6 +659,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             T = self.teacher_model
             T._defer_G_update = True
             T._is_online_teacher = True
+            T._shared_aux = self._aux_stream() if TEACHER_EARLY_DREAL == 2 else None
             ts = self._teacher_stream()
             if ts:
                 self._release_teacher_stream(ts)                 # after the last launch that reads the teacher's buffers

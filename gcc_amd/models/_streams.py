@@ -36,8 +36,10 @@ class TeacherStreamMixin:
             return
         from .. import _lib
         lib = ops.lib()
-        pair, wgs_big, wgs = plan
+        pair, wgs_big, wgs = plan[:3]
         lib.gcc_set_option(_lib.OPT_IGEMM_PAIR, pair)
+        if 'GCC_HALO_HC' not in os.environ:      # 128-column halo tiles for half-chip launches go with the pair split (-1: default)
+            lib.gcc_set_option(_lib.OPT_HALO_HC, 1 if pair == 1 else (-1 if pair < 0 else 0))
         if 'GCC_WGRAD_WGS_BIG' not in os.environ:
             lib.gcc_set_option(_lib.OPT_WGRAD_WGS_BIG, wgs_big)
         if 'GCC_WGRAD_WGS' not in os.environ:

@@ -454,7 +454,7 @@ class PackPlan:
               'gcc_pack_weights_multi')
 
 
-def _epilogue(bias, act, slope, stats, d=None, dgrad=0, device=None):
+def _epilogue(bias, act, slope, stats, d=None, dgrad=0, device=None, bn=None):
     wsp, wsb = None, 0
     if d is not None:
         need = lib().gcc_conv_workspace(C.byref(d), dgrad)
@@ -462,10 +462,19 @@ def _epilogue(bias, act, slope, stats, d=None, dgrad=0, device=None):
             ws = workspace(need, device, 'splitk')
             wsp, wsb = ws.data_ptr(), ws.numel()
     return _lib.epilogue_t(bias.data_ptr() if bias is not None else None, act, slope,
-                           stats.data_ptr() if stats is not None else None, wsp, wsb)
+                           stats.data_ptr() if stats is not None else None, wsp, wsb,
+                           C.cast(C.pointer(bn), C.c_void_p) if bn is not None else None, None, 0, 0, 0, None)
 
 
-def conv_fprop(x, w, Co, k, stride, pad, out=None, bias=None, act=ACT_NONE, slope=0.2, want_stats=False):
+Y2_RELU, Y2_GATE = 1, 2        # gcc_epilogue_t.y2_mode
+CONV_Y2 = os.environ.get('GCC_CONV_Y2', '1') != '0'      # A/B hook: 0 = always the separate gcc_bnact_fwd launch
+
+
+def conv_fprop(x, w, Co, k, stride, pad, out=None, bias=None, act=ACT_NONE, slope=0.2, want_stats=False, bn=None,
+               y2=None, y2_mode=0, y2_gate=None):
+    """bn: a gcc_bn_t (bn_desc) -- the BatchNorm behind this conv is finalized inside the call (needs want_stats).
+    y2: a second output f(out) -- Y2_RELU: relu(out); Y2_GATE: out * y2_gate[c] -- written by the conv launch itself where the
+    library can (the thin image-layer route), by a gcc_bnact_fwd launch behind it otherwise."""
     xp, N, Ci, H, W, ldx = geom(x)
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     if out is None:
@@ -476,16 +485,28 @@ def conv_fprop(x, w, Co, k, stride, pad, out=None, bias=None, act=ACT_NONE, slop
     if want_stats:
         tiles = lib().gcc_conv_stat_tiles(C.byref(d), 0)
         stats = torch.empty((tiles, 2, Co), dtype=torch.float32, device=x.device)
-    ep = _epilogue(bias, act, slope, stats, d, 0, x.device)
+    ep = _epilogue(bias, act, slope, stats, d, 0, x.device, bn)
+    y2_after = False
+    if y2 is not None:
+        y2p, _, _, _, _, ldy2 = geom(y2)
+        ep.y2, ep.ldy2, ep.y2off, ep.y2_mode = y2p, ldy2, 0, y2_mode
+        ep.y2_gate = y2_gate.data_ptr() if y2_gate is not None else None
+        if not (CONV_Y2 and lib().gcc_conv_y2_supported(C.byref(d), 0, C.byref(ep))):
+            ep.y2, y2_after = None, True
     e0 = PROFILE.begin() if PROFILE.active else None
     check(lib().gcc_conv_fprop(C.byref(d), xp, w.data_ptr(), yp, C.byref(ep), stream()), 'gcc_conv_fprop')
+    if y2_after:
+        if y2_mode == Y2_RELU:
+            bnact_fwd(out, y2, act=ACT_RELU)
+        else:
+            bnact_fwd(out, y2, gate=y2_gate, gate_after_act=True)
     if e0 is not None:
         PROFILE.end(_ROUTE_KIND[lib().gcc_conv_route(C.byref(d), 0, C.byref(ep))], 2.0 * N * Ho * Wo * Co * k * k * Ci, e0,
                     shape=('fprop', N, Ho, Wo, Ci, Co, k, stride))
     return (out, stats) if want_stats else out
 
 
-def conv_dgrad(dy, wt, Ci, H, W, k, stride, pad, out=None, bias=None, act=ACT_NONE, slope=0.2, want_stats=False):
+def conv_dgrad(dy, wt, Ci, H, W, k, stride, pad, out=None, bias=None, act=ACT_NONE, slope=0.2, want_stats=False, bn=None):
     """dx [N,Ci,H,W] = conv_backward_data(dy) == ConvTranspose2d forward."""
     yp, N, Co, Ho, Wo, ldy = geom(dy)
     assert Ho == (H + 2 * pad - k) // stride + 1 and Wo == (W + 2 * pad - k) // stride + 1
@@ -497,7 +518,7 @@ def conv_dgrad(dy, wt, Ci, H, W, k, stride, pad, out=None, bias=None, act=ACT_NO
     if want_stats:
         tiles = lib().gcc_conv_stat_tiles(C.byref(d), 1)
         stats = torch.empty((tiles, 2, Ci), dtype=torch.float32, device=dy.device)
-    ep = _epilogue(bias, act, slope, stats, d, 1, dy.device)
+    ep = _epilogue(bias, act, slope, stats, d, 1, dy.device, bn)
     e0 = PROFILE.begin() if PROFILE.active else None
     check(lib().gcc_conv_dgrad(C.byref(d), yp, wt.data_ptr(), xp, C.byref(ep), stream()), 'gcc_conv_dgrad')
     if e0 is not None:
@@ -522,9 +543,7 @@ def conv_bn_act(dgrad, src, w, raw, k, stride, pad, bn_module, st, count, y, y2=
         flops = 2.0 * N * Hs * Ws * Cs * k * k * Cr
     need = lib().gcc_conv_bn_act_workspace(C.byref(d), int(dgrad))
     ws = workspace(need, src.device, 'convbn')
-    bn = _lib.bn_t(bn_module.weight.data_ptr(), bn_module.bias.data_ptr(), bn_module.eps, bn_module.momentum, float(count),
-                   bn_module.running_mean.data_ptr(), bn_module.running_var.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
-                   st.scale.data_ptr(), st.shift.data_ptr())
+    bn = bn_desc(bn_module, st, count, src.device)
     yp, ldy = (None, 0)
     if y is not None:
         yp, _, _, _, _, ldy = geom(y)
@@ -716,8 +735,36 @@ def zeroed_workspace(device, slot, nbytes):
     key = (device, slot, stream())
     ws = _zero_ws.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = _zero_ws[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        grow = max(int(nbytes), 2 * ws.numel() if ws is not None else 0)
+        ws = _zero_ws[key] = torch.zeros(grow, dtype=torch.uint8, device=device)
     return ws
+
+
+TAIL_WS_BYTES = 4096 + (4 << 20)      # include/gcc_hip.h: GCC_TAIL_WORKSPACE_BYTES
+_tail_ws = {}
+
+
+def tail_workspace(device):
+    """zero-filled once, one per stream (gcc_bn_t.tail_ws: the ticket words and group sums of the BatchNorm finalize that the
+    last-arriving workgroups of a conv launch perform; the launches of one stream are ordered, so its layers share it)"""
+    key = (device, stream())
+    ws = _tail_ws.get(key)
+    if ws is None:
+        ws = _tail_ws[key] = torch.zeros(TAIL_WS_BYTES, dtype=torch.uint8, device=device)
+    return ws
+
+
+IN_CONV_FINALIZE = os.environ.get('GCC_IN_CONV_FINALIZE', '0') == '1'      # 1: the conv launch's last-arriving workgroups finalize (measured: profiles/r4_summary.md)
+
+
+def bn_desc(bn_module, st, count, device, running=True):
+    """gcc_bn_t of a training-mode BatchNorm2d application: statistics of `count` pixels, coefficients into the BNState `st`;
+    running=False leaves running_mean / running_var alone (a pass that runs ahead of its place: engine.PatchGANEngine)"""
+    ws = tail_workspace(device) if IN_CONV_FINALIZE else None
+    return _lib.bn_t(bn_module.weight.data_ptr(), bn_module.bias.data_ptr(), bn_module.eps, bn_module.momentum, float(count),
+                     bn_module.running_mean.data_ptr() if running else None, bn_module.running_var.data_ptr() if running else None,
+                     st.mean.data_ptr(), st.rstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
+                     ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0)
 
 
 def inorm_workspace(device):
@@ -771,6 +818,7 @@ def bnact_fwd(x, y, y2=None, scale=None, shift=None, gate=None, gate_after_act=F
     check(lib().gcc_bnact_fwd(C.byref(p), xp, ldx, 0, yp, ldy, 0, y2p, ldy2, 0, Cc, pixels, stream()), 'gcc_bnact_fwd')
 
 
+BN_BWD_TAIL = os.environ.get('GCC_BN_BWD_TAIL', '0') == '1'      # 1: the reduce launch's last-arriving workgroups finalize (measured: profiles/r4_summary.md)
 BN_BWD_GRID = os.environ.get('GCC_BN_BWD_GRID', '1') != '0'
 BN_BWD_GRID_MIN_PIXELS = 4096        # at or below: bnact_bwd_small_kernel (one workgroup per 8 channels) is the one-launch form
 
@@ -803,9 +851,10 @@ def bnact_bwd(x, y, g1, dx, g2=None, bn=None, gamma=None, beta=None, bn_eval=Fal
             check(rc, 'gcc_bn_bwd_one_launch')
     p = _lib.bnact_bwd_t(1 if bn is not None else 0, int(bn_eval), _p(bn.mean) if bn is not None else None,
                          _p(bn.rstd) if bn is not None else None, _p(gamma), _p(beta), _p(gate), int(gate_after_act),
-                         act, slope, act2, drop_p, seed, _p(dgamma), _p(dbeta), _p(dalpha), groups, 0)
+                         act, slope, act2, drop_p, seed, _p(dgamma), _p(dbeta), _p(dalpha), groups, 1 if BN_BWD_TAIL else 0)
     need = lib().gcc_bnact_bwd_workspace(Cc, pixels) * max(1, groups)
-    ws = workspace(need, x.device, 'bnbwd')
+    # zero-filled once, one per stream (flags bit 0: the reduce launch's last-arriving workgroups do the finalize step)
+    ws = zeroed_workspace(x.device, 'bnbwd', need) if BN_BWD_TAIL else workspace(need, x.device, 'bnbwd')
     e0 = PROFILE.begin() if (PROFILE.active and PROFILE.streaming) else None
     check(lib().gcc_bnact_bwd_ex(C.byref(p), in_act, slope, xp, ldx, 0, yp, ldy, 0, g1p, ldg1, 0, g2p, ldg2, 0, dxp, lddx,
                                  0, Cc, pixels, ws.data_ptr(), ws.numel(), stream()), 'gcc_bnact_bwd')

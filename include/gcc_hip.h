@@ -45,6 +45,11 @@ const char* gcc_strerror(int code);
 int gcc_version(void);
 /* kernel launches the library has made in this process so far (reset != 0: return the count and start again from zero) */
 long long gcc_launch_count(int reset);
+/* Device-side error word.  The kernels that wait for other workgroups inside a launch (the grid InstanceNorm's tagged exchange,
+ * gcc_inorm_fwd / gcc_inorm_bwd / gcc_bn_bwd_one_launch) bound every spin; a spin that expires stores a non-zero code into a
+ * pinned host word, the launch's results are wrong, and every later call of those entry points returns GCC_ERR_LAUNCH.
+ * Returns the word (0: no error; 0x1401: InstanceNorm exchange timed out); clear != 0 resets it.  Never synchronises. */
+int gcc_device_error(int clear);
 
 /* ---------------------------------------------------------------------------------------------
  * Tuning options: which tile shape / kernel family a geometry is routed to.  Every option only selects
@@ -82,7 +87,9 @@ enum {
                                    less CU time per launch, the free CUs run the other streams' kernels (the multi-stream
                                    production schedule: +1 % on the step).  gcc_amd's models switch it with their schedule. */
     GCC_OPT_WGRAD_BIG_MIN_TILES,/* minimum number of 256x256 output tiles for the big weight-gradient tiling (default 32) */
-    GCC_OPT_FUSE_BN,            /* 1 (default): gcc_conv_bn_act folds split-K partials, statistics, finalize and normalise in one kernel */
+    GCC_OPT_FUSE_BN,            /* gcc_conv_bn_act: 2: BatchNorm finalized by the last-arriving workgroups of the launch that writes the
+                                   statistic rows (gcc_bn_t.tail_ws), split layers folded by one full-chip kernel; 1: the round-2 form (a split
+                                   layer's partials, statistics, finalize and normalise in one kernel of C / 8 workgroups; default: measured faster, profiles/r4_summary.md); 0: separate launches */
     GCC_OPT_BN_BWD_SMALL,       /* 1 (default): gcc_bnact_bwd of <= 4096 pixels (training BatchNorm, no gate) runs as one kernel instead of
                                    three, gcc_channel_sum of <= 16384 pixels as one instead of two */
     GCC_OPT_WGRAD_ROW_TABLE,    /* 1 (default): the weight-gradient kernel decomposes each pixel of a workgroup's range once, into an LDS table
@@ -95,8 +102,14 @@ enum {
     GCC_OPT_FUSE_BN_PARTIAL_KB, /* gcc_conv_bn_act: cap (KB of fp32 partial tiles, default 4096) on the K split of the layers whose fold + statistics +
                                    normalise run as one kernel: every slice is another copy of the output that kernel reads back */
     GCC_OPT_INORM_GRID,         /* 1 (default): gcc_inorm_fwd / _bwd with a workspace split an image's plane over workgroups (in-launch barrier); 0: slab kernels */
+    GCC_OPT_HALO_HC,            /* columns per tile of igemm_halo_kernel: 0 (default): 256 where the layer tiles by 256 and such tiles are enough
+                                   to be routed (GCC_OPT_IGEMM_BIG_MIN), else 128; 1: also 128 where 256-column tiles would cover less
+                                   than 3/4 of the chip (PatchGAN L3 forward, L4 data gradient: 128 workgroups) -- the plan for a launch
+                                   that has the chip to itself, set by the models with GCC_OPT_IGEMM_PAIR; 128 / 256: forced (tests, A/B) */
     GCC_OPT_DEBUG,              /* 0 (default).  Diagnostic ablations for timing only -- RESULTS ARE WRONG when set: bit 1 (2) the main loops issue
-                                   no staging loads after the first step, bit 2 (4) they re-load the first step's addresses */
+                                   no staging loads after the first step, bit 2 (4) they re-load the first step's addresses, bit 5 (32)
+                                   s_memrealtime stamps of the grid InstanceNorm, bit 6 (64) its exchange is made to time out (256 polls,
+                                   workgroup 1 of every domain publishes nothing): the test of gcc_device_error */
     GCC_OPT_COUNT_
 };
 int gcc_set_option(int id, int value);
@@ -124,6 +137,23 @@ typedef struct {
 
 static inline int gcc_conv_out(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
+/* A BatchNorm2d (training statistics) that follows a convolution: nn.BatchNorm2d at models/Pix2Pix.py:34, 44-64, 286-298,
+ * 320-341.  Handed to the conv (gcc_epilogue_t.bn, gcc_conv_bn_act) its coefficients are final when the call returns: where
+ * the launch that writes the statistic rows can, its last-arriving workgroups fold them (no gcc_bn_finalize launch on the
+ * chain; same bits as that launch: one canonical summation order) -- this needs `tail_ws`: GCC_TAIL_WORKSPACE_BYTES bytes,
+ * zero-filled ONCE by the caller when it is allocated, used by ONE stream (its calls are ordered) and by nothing else; the
+ * library leaves its counter words zero after every launch.  tail_ws NULL (or too small for the layer): a gcc_bn_finalize
+ * launch inside the call instead. */
+#define GCC_TAIL_WORKSPACE_BYTES ((size_t)4096 + ((size_t)4 << 20))
+typedef struct {
+    const float* gamma; const float* beta;          /* [C] */
+    float eps, momentum;
+    double count;                                   /* N * H * W of the conv output */
+    float* running_mean; float* running_var;        /* [C] or NULL */
+    float* mean; float* rstd; float* scale; float* shift;   /* [C] outputs (saved for the backward pass) */
+    void* tail_ws; size_t tail_ws_bytes;            /* see above; may be NULL / 0 */
+} gcc_bn_t;
+
 /* fused epilogue of fprop / dgrad: out = act(acc + bias[c]); optional per-tile BatchNorm partial
  * statistics (sum, sum of squares of the bf16-rounded outputs) for gcc_bn_finalize. */
 typedef struct {
@@ -134,18 +164,26 @@ typedef struct {
     void* workspace;      /* NULL, or gcc_conv_workspace() bytes: lets small-grid launches (U-Net bottleneck,
                              1-channel PatchGAN head) split their K loop over more workgroups */
     size_t workspace_bytes;
+    const gcc_bn_t* bn;   /* NULL, or (with stats_partial) the BatchNorm behind this conv: finalized inside the call */
+    /* NULL, or a second output written by the same launch: y2[.., y2off + c] = f(out) -- y2_mode 1: relu(out) (the in-place
+     * LeakyReLU / ReLU pair the first U-Net skip is read through, models/Pix2Pix.py:33, 50, 77); 2: out * y2_gate[c] (the first
+     * DifferentiableOP of the masked PatchGAN, models/Pix2Pix.py:320-322).  Served where gcc_conv_y2_supported() says 1 (the
+     * thin image-layer forward route); GCC_ERR_UNSUPPORTED otherwise -- callers keep a gcc_bnact_fwd for that case. */
+    void* y2; int ldy2, y2off, y2_mode; const float* y2_gate;
 } gcc_epilogue_t;
 
 /* scratch a fprop (dgrad=0) / dgrad (dgrad=1) launch can use: split-K partial tiles of small grids, or the hand-off slabs of a
  * pair-split 256x256-tile launch; 0 when the launch needs none.  Without it the launch simply runs un-split. */
 size_t gcc_conv_workspace(const gcc_conv_t* c, int dgrad);
 
-/* number of partial-statistics rows a fprop/dgrad launch writes (one per 128-pixel tile) */
+/* number of partial-statistics rows a fprop/dgrad call writes or zero-fills (one per pixel tile of the route the plan picks) */
 int gcc_conv_stat_tiles(const gcc_conv_t* c, int dgrad);
 
 /* kernel family a fprop / dgrad call runs on: 0 igemm_kernel, 1 the thin image-layer kernels (<= 8 channels on the
  * image side), 2 the single-output-channel head route; < 0 for an invalid geometry.  Introspection for profilers. */
 int gcc_conv_route(const gcc_conv_t* c, int dgrad, const gcc_epilogue_t* ep);
+/* 1 when a call with this geometry / epilogue can write ep->y2 (see gcc_epilogue_t) */
+int gcc_conv_y2_supported(const gcc_conv_t* c, int dgrad, const gcc_epilogue_t* ep);
 /* tile the current plan picks for a geometry on the igemm_kernel route: BP * 1000 + BC (e.g. 256256 = 256 pixels x
  * 256 channels); 0 for an invalid geometry.  Introspection for tests and profilers. */
 int gcc_conv_tile(const gcc_conv_t* c, int dgrad);
@@ -291,13 +329,6 @@ int gcc_bnact_fwd(const gcc_bnact_t* p, const void* x, int ldx, int xoff, void* 
  * the fp32 partial tiles, then one kernel that folds them, takes the statistics (f64), finalises and normalises: a workgroup
  * per 8 output channels owns every row of them -- instead of five (partials, fold, channel statistics, finalize, normalise);
  * every other layer runs the ordinary three kernels inside this one call.  ws: gcc_conv_bn_act_workspace() bytes. */
-typedef struct {
-    const float* gamma; const float* beta;          /* [C] */
-    float eps, momentum;
-    double count;                                   /* N * H * W of the conv output */
-    float* running_mean; float* running_var;        /* [C] or NULL */
-    float* mean; float* rstd; float* scale; float* shift;   /* [C] outputs (saved for the backward pass) */
-} gcc_bn_t;
 size_t gcc_conv_bn_act_workspace(const gcc_conv_t* c, int dgrad);
 int gcc_conv_bn_act(const gcc_conv_t* c, int dgrad, const void* x, const void* w, void* y_raw, const gcc_bn_t* bn,
                     const gcc_bnact_t* act, void* y, int ldy, int yoff, void* y2, int ldy2, int y2off, void* ws,
@@ -324,7 +355,10 @@ typedef struct {
     float* dgamma; float* dbeta; float* dalpha;  /* [C] fp32, accumulated into (+=) ; any may be NULL */
     int groups;              /* G > 1: InstanceNorm backward (mean/rstd [G][C], no parameter gradients); workspace is
                                 G * gcc_bnact_bwd_workspace() */
-    int pad_;
+    int flags;               /* bit 0: the workspace was zero-filled when it was allocated, is used by ONE stream and by nothing but
+                                gcc_bnact_bwd calls -- the finalize step then runs inside the reduce launch (its last-arriving
+                                workgroups fold the partial rows; the library leaves the head of the workspace zero): two launches
+                                instead of three */
 } gcc_bnact_bwd_t;
 
 size_t gcc_bnact_bwd_workspace(int C, size_t pixels);

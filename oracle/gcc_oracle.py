@@ -209,7 +209,9 @@ def unet_forward(sd: SD, x: Tensor, num_downs: int = 8, train: bool = True,
         return F.conv_transpose2d(t, _qw(sd[key + '.weight']), sd.get(key + '.bias'), stride=2, padding=1)
 
     e: List[Tensor] = [None] * D
-    e[0] = _q(conv(_q(x), 'model.model.0'))
+    # (bf16 emulation: the HIP path never stores e[0] -- the outermost conv's launch writes leaky_relu(e0) and relu(e0) straight
+    # from its fp32 accumulators, gcc_epilogue_t.y2 -- so the only roundings are those of the two activated copies below)
+    e[0] = conv(_q(x), 'model.model.0')
     for d in range(1, D):
         p = unet_block_prefix(d)
         z = _q(conv(_q(F.leaky_relu(e[d - 1], LRELU)), p + '.model.1'))

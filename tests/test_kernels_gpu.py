@@ -239,7 +239,7 @@ def _true_shape_case(ops, name):
     (16, 32, 32, 128, 256, False, 0.0),      # un-split layer: the ordinary three kernels inside the one call
     (2, 16, 16, 64, 128, True, 0.0),
 ])
-@pytest.mark.parametrize('fuse', [1, 0])
+@pytest.mark.parametrize('fuse', [2, 1, 0])
 def test_conv_bn_act_one_call(case, fuse):
     """gcc_conv_bn_act against conv -> BatchNorm2d(train) -> activation in fp32 torch on the bf16-rounded conv output: raw output,
     batch statistics, running statistics, both activated copies; dropout: the mask is the one gcc_bnact_bwd regenerates
@@ -310,6 +310,109 @@ def test_conv_bn_act_one_call(case, fuse):
             assert float(full[:, ref_raw.shape[1]:].float().abs().max()) == 0.0
     finally:
         lib.gcc_set_option(_lib.OPT_FUSE_BN, -1)
+
+
+FINALIZE_CASES = [
+    # N, H, W, Ci, Co, k, stride, dgrad        route of the launch that writes the statistic rows
+    (16, 64, 64, 128, 256, 4, 2, False),       # halo kernel, stride 2 (PatchGAN L2 at a quarter of its size): 64 rows, 4 groups
+    (16, 32, 32, 256, 512, 4, 1, False),       # halo kernel, stride 1 (L4-like, padded grid): 64 rows x 2 column tiles
+    (16, 64, 64, 32, 64, 4, 2, False),         # igemm 128-pixel tiles (student d1 at a quarter): 128 rows
+    (3, 10, 14, 40, 72, 4, 2, False),          # one ragged tile: a single group, the group's last is the launch's last
+    (16, 8, 8, 256, 256, 4, 2, False),         # split-K layer: partial tiles + splitk_fold_stats_kernel
+    (16, 4, 4, 512, 512, 4, 2, True),          # split-K, ConvTranspose form (4 phases)
+    (2, 32, 32, 64, 128, 4, 2, True),          # un-split ConvTranspose form: rows of four phases
+    (5, 9, 9, 24, 40, 4, 2, True),             # odd size: phases of different sizes, early-exit workgroups hold tickets too
+]
+
+
+@pytest.mark.parametrize('case', FINALIZE_CASES)
+def test_bn_finalize_in_conv_matches_separate_launch(case, monkeypatch):
+    """round 4: with gcc_epilogue_t.bn the BatchNorm behind a conv is finalized by the last-arriving workgroups of the launch
+    that writes the statistic rows (stats_tail).  Same canonical summation order as gcc_bn_finalize: coefficients, saved
+    statistics and running statistics must be BIT-identical with the separate launch over the same rows (GCC_IN_CONV_FINALIZE=0
+    hands the conv no tail workspace), on every route, launch after launch on one workspace (the ticket words reset themselves);
+    and right against torch's batch statistics of the conv output."""
+    import torch.nn as nn
+    ops = _ops()
+    N, H, W, Ci, Co, k, s, dgrad = case
+    g = torch.Generator().manual_seed(N + H + Ci)
+    Ho, Wo = (H + 2 - k) // s + 1, (W + 2 - k) // s + 1
+    wgt = rb(torch.randn(Co, Ci, k, k, generator=g) * 0.05)
+    wp, wtp = ops.pack_weights(master_cl(wgt))
+    if not dgrad:
+        x = to_dev(rb(torch.randn(N, Ci, H, W, generator=g)))
+        Cn, shape = Co, (N, Co, Ho, Wo)
+    else:
+        x = to_dev(rb(torch.randn(N, Co, Ho, Wo, generator=g)))
+        Cn, shape = Ci, (N, Ci, H, W)
+    count = shape[0] * shape[2] * shape[3]
+
+    def run(in_conv, reps):
+        monkeypatch.setattr(ops, 'IN_CONV_FINALIZE', in_conv)
+        bn = nn.BatchNorm2d(Cn).to(DEV)
+        with torch.no_grad():
+            bn.weight.copy_(1 + 0.1 * torch.randn(Cn, generator=torch.Generator().manual_seed(1)))
+            bn.bias.copy_(torch.randn(Cn, generator=torch.Generator().manual_seed(2)))
+        st = ops.BNState(Cn, DEV)
+        out = ops.new_act(*shape, DEV)
+        launches = []
+        for _ in range(reps):
+            ops.lib().gcc_launch_count(1)
+            d = ops.bn_desc(bn, st, count, DEV)
+            if not dgrad:
+                ops.conv_fprop(x, wp, Co, k, s, 1, out=out, want_stats=True, bn=d)
+            else:
+                ops.conv_dgrad(x, wtp, Ci, H, W, k, s, 1, out=out, want_stats=True, bn=d)
+            launches.append(int(ops.lib().gcc_launch_count(1)))
+        torch.cuda.synchronize()
+        return out, [t.clone() for t in (st.mean, st.rstd, st.scale, st.shift, bn.running_mean, bn.running_var)], launches
+    out1, a, la = run(True, 3)
+    out0, b, lb = run(False, 3)
+    assert la[0] == lb[0] - 1 and la == [la[0]] * 3, (la, lb)          # one launch fewer, every time
+    assert torch.equal(out1, out0)
+    for name, u, v in zip(('mean', 'rstd', 'scale', 'shift', 'running_mean', 'running_var'), a, b):
+        assert torch.equal(u, v), name
+    raw = to_cpu(out1)
+    close(a[0].cpu(), raw.mean((0, 2, 3)), tol=1e-4, floor=1e-5, what='batch mean')
+    close(a[1].cpu(), 1.0 / torch.sqrt(raw.var((0, 2, 3), unbiased=False) + 1e-5), tol=1e-4, floor=1e-5, what='rstd')
+
+
+@pytest.mark.parametrize('N,H,W,Ci,Co', [(3, 37, 29, 6, 72), (2, 32, 32, 3, 32), (1, 64, 64, 5, 200), (2, 16, 16, 64, 128)])
+@pytest.mark.parametrize('mode', ['relu', 'gate'])
+def test_conv_second_output(N, H, W, Ci, Co, mode, monkeypatch):
+    """gcc_epilogue_t.y2 (round 4): the image-layer convs write a second output from the same launch -- relu(out) (the U-Net's
+    first skip) or out * gate[c] (the masked PatchGAN's first DifferentiableOP) -- bit-identical with the separate gcc_bnact_fwd
+    launch it replaces; geometries the thin route does not take (last case) fall back to that launch inside ops.conv_fprop."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N * H + Co)
+    x = to_dev(rb(torch.randn(N, Ci, H, W, generator=g)))
+    wgt = rb(torch.randn(Co, Ci, 4, 4, generator=g) * 0.2)
+    b = torch.randn(Co, generator=g).to(DEV)
+    wp, _ = ops.pack_weights(master_cl(wgt))
+    gate = (torch.randint(0, 3, (Co,), generator=g).float() * 0.5).to(DEV)
+    Ho, Wo = (H + 2 - 4) // 2 + 1, (W + 2 - 4) // 2 + 1
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, 'CONV_Y2', fused)
+        y, y2 = ops.new_act(N, Co, Ho, Wo, DEV), ops.new_act(N, Co, Ho, Wo, DEV)
+        ops.lib().gcc_launch_count(1)
+        if mode == 'relu':
+            ops.conv_fprop(x, wp, Co, 4, 2, 1, out=y, bias=b, act=ops.ACT_LRELU, y2=y2, y2_mode=ops.Y2_RELU)
+        else:
+            ops.conv_fprop(x, wp, Co, 4, 2, 1, out=y, bias=b, act=ops.ACT_LRELU, y2=y2, y2_mode=ops.Y2_GATE, y2_gate=gate)
+        outs.append((y.clone(), y2.clone(), int(ops.lib().gcc_launch_count(1))))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    thin = Ci <= 8
+    if thin:
+        assert outs[0][2] == 1 and outs[1][2] == 2, (outs[0][2], outs[1][2])
+    else:                       # the library's own fallback: the conv's launches, then the gcc_bnact_fwd launch -- either way
+        assert outs[0][2] == outs[1][2] >= 2, (outs[0][2], outs[1][2])
+    yf = to_cpu(outs[0][0])
+    ref2 = torch.relu(yf) if mode == 'relu' else rb(yf * gate.cpu()[None, :, None, None])
+    assert torch.equal(to_cpu(outs[0][1]), ref2)
+    ref = F.leaky_relu(F.conv2d(to_cpu(x), wgt, b.cpu(), stride=2, padding=1), 0.2)
+    close(yf, ref, what='first output')
 
 
 def test_conv_transpose_as_dgrad_with_stats_and_tanh():
@@ -654,6 +757,43 @@ def test_bn_backward_small_tensor_one_launch(C, N, H, W, drop, noy, two):
         assert torch.equal(res[1][0], res[0][0])
 
 
+@pytest.mark.parametrize('N,C,H,W,gate,two', [(16, 64, 64, 64, False, True), (16, 256, 32, 32, True, False), (8, 40, 33, 17, False, False),
+                                              (16, 128, 128, 128, True, False)])
+def test_bn_backward_finalize_inside_the_reduce_launch(N, C, H, W, gate, two, monkeypatch):
+    """round 4: gcc_bnact_bwd with flags bit 0 (zero-filled, stream-private workspace) lets the reduce pass's last-arriving
+    workgroups do the finalize step (bwd_tail): two launches instead of three, the same gradients (fp32 sums in another order:
+    1e-5 relative), bit-identical from call to call on one workspace (the ticket words reset themselves)"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N + C)
+    x = to_dev(rb(torch.randn(N, C, H, W, generator=g) * 1.3 + 0.2))
+    g1 = to_dev(rb(torch.randn(N, C, H, W, generator=g)))
+    g2 = to_dev(rb(torch.randn(N, C, H, W, generator=g))) if two else None
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    mask = (torch.randint(0, 3, (C,), generator=g).float() * 0.5).to(DEV) if gate else None
+    st = ops.BNState(C, DEV)
+    xf = x.float()
+    st.mean.copy_(xf.mean((0, 2, 3))); st.rstd.copy_(1.0 / torch.sqrt(xf.var((0, 2, 3), unbiased=False) + 1e-5))
+    st.scale.copy_(gamma * st.rstd); st.shift.copy_(beta - st.mean * gamma * st.rstd)
+    outs = []
+    for tail in (True, True, False):
+        monkeypatch.setattr(ops, 'BN_BWD_TAIL', tail)
+        dx = ops.new_act(N, C, H, W, DEV)
+        dg, db, da = (torch.zeros(C, device=DEV) for _ in range(3))
+        ops.lib().gcc_launch_count(1)
+        ops.bnact_bwd(x, None, g1, dx, g2=g2, bn=st, gamma=gamma, beta=beta, gate=mask, act=ops.ACT_LRELU, act2=ops.ACT_RELU,
+                      dgamma=dg, dbeta=db, dalpha=da if gate else None)
+        outs.append((dx.clone(), dg.clone(), db.clone(), da.clone(), int(ops.lib().gcc_launch_count(1))))
+    torch.cuda.synchronize()
+    assert outs[0][4] == 2 and outs[2][4] == 3, (outs[0][4], outs[2][4])
+    for u, v in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(u, v)
+    for name, u, v in zip(('dgamma', 'dbeta', 'dalpha'), outs[0][1:4], outs[2][1:4]):
+        assert torch.allclose(u, v, rtol=1e-5, atol=1e-4 * max(1.0, float(v.abs().max()))), name
+    d = (outs[0][0].float() - outs[2][0].float()).abs().max()
+    assert float(d) <= 1e-2 * max(1.0, float(outs[2][0].float().abs().max())), float(d)
+
+
 @pytest.mark.parametrize('N,C,H,W', [(3, 40, 7, 5), (1, 24, 128, 128), (1, 64, 129, 128), (2, 8, 64, 100), (16, 256, 1, 1)])
 def test_channel_sum(N, C, H, W):
     """bias gradients: the one-launch kernel (<= 16384 pixels) and the two-launch pipeline, plain and accumulating"""
@@ -954,6 +1094,109 @@ def test_batchnorm_backward_one_launch_vs_three_launches(N, C, H, W, act, with_y
     assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-3) and torch.allclose(outs[0][2], outs[1][2], rtol=1e-4, atol=1e-3)
 
 
+def test_batchnorm_backward_one_launch_needs_the_grid_form(monkeypatch):
+    """with GCC_OPT_INORM_GRID = 0 gcc_bn_bwd_one_launch must refuse (GCC_ERR_UNSUPPORTED) instead of running the
+    InstanceNorm slab kernel, which knows no gamma / d gamma / d beta; ops.bnact_bwd then takes the three-launch route and the
+    gradients are the same as with the grid form"""
+    ops = _ops()
+    from gcc_amd import _lib
+    lib = _lib.load()
+    N, C, H, W = 16, 64, 24, 24
+    g = torch.Generator().manual_seed(5)
+    x = rb(torch.randn(N, C, H, W, generator=g) * 1.2 + 0.1)
+    gy = rb(torch.randn(N, C, H, W, generator=g))
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    xd, gd = to_dev(x), to_dev(gy)
+    st = ops.BNState(C, DEV)
+    st.mean.copy_(x.mean((0, 2, 3))); st.rstd.copy_(1.0 / torch.sqrt(x.var((0, 2, 3), unbiased=False) + 1e-5))
+    monkeypatch.setattr(ops, 'BN_BWD_GRID', True)
+    outs = []
+    for grid in (1, 0):
+        lib.gcc_set_option(_lib.OPT_INORM_GRID, grid)
+        try:
+            dx = ops.new_act(N, C, H, W, DEV)
+            dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+            lib.gcc_launch_count(1)
+            ops.bnact_bwd(xd, None, gd, dx, bn=st, gamma=gamma, beta=beta, act=ops.ACT_NONE, dgamma=dg, dbeta=db)
+            outs.append((to_cpu(dx), dg.cpu(), db.cpu(), lib.gcc_launch_count(1)))
+            if grid == 0:           # the entry point itself says so
+                ws = ops.inorm_workspace(DEV)
+                xp, _, _, _, _, ldx = ops.geom(xd)
+                gp, _, _, _, _, ldg = ops.geom(gd)
+                dxp, _, _, _, _, lddx = ops.geom(dx)
+                rc = lib.gcc_bn_bwd_one_launch(xp, ldx, None, 0, gp, ldg, dxp, lddx, C, N * H * W, ops.ACT_NONE, 0.2, st.mean.data_ptr(),
+                                               st.rstd.data_ptr(), gamma.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                               ws.numel(), ops.stream())
+                assert rc == -2, rc
+        finally:
+            lib.gcc_set_option(_lib.OPT_INORM_GRID, -1)
+    assert outs[0][3] == 1 and outs[1][3] == 3, (outs[0][3], outs[1][3])
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 2e-2 * max(1.0, float(outs[1][0].abs().max()))
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-3) and torch.allclose(outs[0][2], outs[1][2], rtol=1e-4, atol=1e-3)
+    assert float(outs[1][1].abs().max()) > 0.1          # d gamma was really computed
+
+
+def test_instance_norm_exchange_timeout_is_reported():
+    """a spin of the grid InstanceNorm's in-launch exchange that expires must not pass silently.
+    GCC_OPT_DEBUG bit 6 makes workgroup 1 of every domain publish nothing and cuts the polls to 256: the launch finishes (its
+    results are wrong), the device error word is set, and the next gcc_inorm_* call returns GCC_ERR_LAUNCH until it is cleared"""
+    ops = _ops()
+    from gcc_amd import _lib
+    lib = _lib.load()
+    assert lib.gcc_device_error(1) == 0
+    x = to_dev(rb(torch.randn(1, 64, 64, 64, generator=torch.Generator().manual_seed(2))))
+    y = ops.new_act(1, 64, 64, 64, DEV)
+    st = ops.INState(1, 64, DEV)
+    ops.inorm_fwd(x, y, st)
+    torch.cuda.synchronize()
+    good = y.clone()
+    assert lib.gcc_device_error(0) == 0
+    lib.gcc_set_option(_lib.OPT_DEBUG, 64)
+    try:
+        ops.inorm_fwd(x, y, st)                     # enqueued fine: the error only exists once the kernel has run
+        torch.cuda.synchronize()
+    finally:
+        lib.gcc_set_option(_lib.OPT_DEBUG, 0)
+    assert lib.gcc_device_error(0) == 0x1401
+    with pytest.raises(_lib.GccError):
+        ops.inorm_fwd(x, y, st)
+    assert lib.gcc_device_error(1) == 0x1401 and lib.gcc_device_error(0) == 0
+    ops.inorm_fwd(x, y, st)                         # and the path works again, on the same workspace
+    torch.cuda.synchronize()
+    assert torch.equal(y, good)
+
+
+def test_instance_norm_workspace_scrub_keeps_results():
+    """the launcher re-zeroes a grid InstanceNorm workspace at its first use inside every launch recording (and every 2^20
+    launches), so that the 24-bit epoch field of the exchange tag never wraps: a recorded + replayed sequence of launches gives
+    the bits of the eager one"""
+    import ctypes as C
+    ops = _ops()
+    lib = ops.lib()
+    x = to_dev(rb(torch.randn(2, 96, 64, 64, generator=torch.Generator().manual_seed(4))))
+    y, y2 = ops.new_act(2, 96, 64, 64, DEV), ops.new_act(2, 96, 64, 64, DEV)
+    st = ops.INState(2, 96, DEV)
+    for _ in range(3):
+        ops.inorm_fwd(x, y, st, act=ops.ACT_RELU)
+    torch.cuda.synchronize()
+    h = C.c_void_p()
+    assert lib.gcc_replay_begin(C.byref(h)) == 0
+    try:
+        for _ in range(3):
+            ops.inorm_fwd(x, y2, st, act=ops.ACT_RELU)
+    finally:
+        assert lib.gcc_replay_end(h, 1) == 0
+    entries = int(lib.gcc_replay_info(h, 0))
+    assert entries == 4, entries                    # one memset (the scrub) + three launches
+    for _ in range(5):
+        y2.zero_()
+        assert lib.gcc_replay_run(h) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2)
+    lib.gcc_replay_destroy(h)
+
+
 def test_instance_norm_grid_form_on_concurrent_streams():
     """the grid form's in-launch barrier under the conditions of a training step: four streams launch it back to back on their
     own tensors (each stream has its own workspace) while a fifth keeps the chip busy with large copies -- every launch completes
@@ -1030,8 +1273,9 @@ HALO_CASES = [  # N, H, W, Ci, Co, stride: the PatchGAN layers conv_halo.hip ser
     (4, 64, 64, 64, 512, 1)]
 
 
-@pytest.mark.parametrize('N,H,W,Ci,Co,stride', HALO_CASES)
-def test_halo_conv_vs_torch_and_gather_kernel(N, H, W, Ci, Co, stride):
+@pytest.mark.parametrize('hc', [0, 128])
+@pytest.mark.parametrize('N,H,W,Ci,Co,stride', HALO_CASES + [(16, 128, 128, 64, 128, 2)])
+def test_halo_conv_vs_torch_and_gather_kernel(N, H, W, Ci, Co, stride, hc):
     """igemm_halo_kernel (tile neighbourhood resident in LDS; k4 s2 p1 forward / data gradient per phase / both px phases of a
     128-channel data gradient, k4 s1 p1 forward on the padded grid / data gradient) against fp32 torch on the same bf16
     operands, against igemm_kernel (GCC_OPT_IGEMM_HALO = 0: same sums in another order), and its BatchNorm partial sums
@@ -1050,6 +1294,9 @@ def test_halo_conv_vs_torch_and_gather_kernel(N, H, W, Ci, Co, stride):
     ref_dx = torch.nn.grad.conv2d_input((N, Ci, H, W), m, dy, stride=stride, padding=p)
     res = {}
     prev = lib.gcc_get_option(_lib.OPT_IGEMM_HALO)
+    # hc = 128 (round 4): the 128-column tile form on every launch (GCC_OPT_HALO_HC; the last case -- the teacher U-Net's 64 -> 128
+    # down conv -- has no 256-column tiling and takes it under the default plan too)
+    lib.gcc_set_option(_lib.OPT_HALO_HC, hc)
     try:
         for halo in (0, 2):
             lib.gcc_set_option(_lib.OPT_IGEMM_HALO, halo)
@@ -1058,6 +1305,7 @@ def test_halo_conv_vs_torch_and_gather_kernel(N, H, W, Ci, Co, stride):
             res[halo] = (to_cpu(y), to_cpu(dx), st.double().sum(0).cpu())
     finally:
         lib.gcc_set_option(_lib.OPT_IGEMM_HALO, prev)
+        lib.gcc_set_option(_lib.OPT_HALO_HC, -1)
     y0, dx0, _ = res[0]
     y2, dx2, st2 = res[2]
     close(y2, ref_y, what='halo fprop vs torch')

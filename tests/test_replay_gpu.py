@@ -47,6 +47,19 @@ def _srgan():
     return model, teacher, opt, data
 
 
+def _pix2pix():
+    """Pix2Pix GCC with --no_dropout (dropout seeds are by-value arguments nothing patches: Pix2PixModel.replay_supported)"""
+    from tests.conftest import GOLDEN
+    from tests.test_pix2pix_gpu import load, _build_gcc
+    z = load(GOLDEN, 'pix2pix_gcc_d6.npz')
+    model, teacher, opt = _build_gcc(z)
+    assert model.replay_supported
+    g = torch.Generator().manual_seed(8)
+    data = [{'A': torch.rand(2, 3, 64, 64, generator=g) * 2 - 1, 'B': torch.rand(2, 3, 64, 64, generator=g) * 2 - 1,
+             'A_paths': ['a'] * 2, 'B_paths': ['b'] * 2} for _ in range(4)]
+    return model, teacher, opt, data
+
+
 def _state(model, teacher):
     out = {}
     for tag, m in (('s', model), ('t', teacher)):
@@ -81,9 +94,9 @@ def _run(build, threads, enabled, iters=7):
     return modes, losses, st, info
 
 
-@pytest.mark.parametrize('which', ['cyclegan', 'sagan', 'srgan'])
+@pytest.mark.parametrize('which', ['cyclegan', 'sagan', 'srgan', 'pix2pix'])
 def test_replay_is_bit_identical_to_the_eager_iteration(which):
-    build = {'cyclegan': _cyclegan, 'sagan': _sagan, 'srgan': _srgan}[which]
+    build = {'cyclegan': _cyclegan, 'sagan': _sagan, 'srgan': _srgan, 'pix2pix': _pix2pix}[which]
     m0, l0, s0, _ = _run(build, 1, False)
     assert set(m0) == {'eager'}
     for threads in (1, 4):
@@ -162,3 +175,45 @@ def test_train_loop_with_replay_ends_on_the_same_weights(tmp_path, monkeypatch, 
     assert a.keys() == b.keys() and len(a) > 20
     bad = [k for k in a if not torch.equal(a[k], b[k])]
     assert not bad, bad[:8]
+
+
+def test_replay_stages_loader_batches_behind_their_ready_event():
+    """batches that come from gcc_amd.data's GPU loaders are written on the LOADER's stream and carry a 'ready' event.
+    IterationReplay._stage must wait for it before copying them into its persistent buffers (and must not forward it: the
+    staged buffers are produced by the copies, set_input records its own event behind them).  The producer here is made slow
+    on purpose (large fills in front of the batch on its stream): a staging copy that did not wait would read the old bytes."""
+    from gcc_amd.data import _GpuFileLoader
+    from gcc_amd.replay import IterationReplay
+    random.seed(5)
+    torch.manual_seed(5)
+    model, teacher, opt, data = _srgan()
+    loader = _GpuFileLoader.__new__(_GpuFileLoader)
+    loader._stream = None
+    junk = torch.empty(128 << 20, dtype=torch.float32, device=DEV)
+
+    def produce(d):
+        def fn():
+            for i in range(6):
+                junk.fill_(float(i))                          # ~ms of work in front of the batch on the loader's stream
+            return {k: (v.to(DEV, non_blocking=True) if torch.is_tensor(v) else v) for k, v in d.items()}
+        return loader._produce(fn)
+    rp = IterationReplay(model, opt, warmup=1, threads=1, enabled=True)
+    modes, losses = [], []
+    for i in range(5):
+        b, vb = produce(data[i % 4]), produce(data[(i + 1) % 4])
+        assert 'ready' in b
+        modes.append(rp.step(b, vb))
+        assert 'ready' not in rp.static[0] and 'ready' not in rp.static[1]
+        for k in ('lr', 'hr'):                                # the staged copy holds the batch, not what was there before
+            assert torch.equal(rp.static[0][k].cpu(), data[i % 4][k])
+        losses.append(dict(model.get_current_losses()))
+    assert modes == ['eager', 'record', 'replay', 'replay', 'replay'], modes
+    # the same five iterations from host batches, eagerly: same losses
+    random.seed(5)
+    torch.manual_seed(5)
+    model2, teacher2, opt2, data2 = _srgan()
+    rp2 = IterationReplay(model2, opt2, warmup=1, threads=1, enabled=False)
+    for i in range(5):
+        rp2.step(data2[i % 4], data2[(i + 1) % 4])
+        assert dict(model2.get_current_losses()) == losses[i], i
+    rp.invalidate()
