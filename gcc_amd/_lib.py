@@ -176,6 +176,9 @@ PROTOTYPES = {
     'gcc_comm_unique_id': (_I, [_P]),
     'gcc_comm_init': (_I, [C.POINTER(C.c_void_p), _I, _I, _P]),
     'gcc_comm_allreduce_sum_f32': (_I, [_P, _P, _Z, _P]),
+    'gcc_comm_allreduce_sum_bf16': (_I, [_P, _P, _Z, _P]),
+    'gcc_cast_f32_bf16': (_I, [_P, _P, _Z, _P]),
+    'gcc_cast_bf16_f32': (_I, [_P, _P, _Z, _P]),
     'gcc_comm_rank': (_I, [_P]),
     'gcc_comm_world': (_I, [_P]),
     'gcc_comm_destroy': (_I, [_P]),

@@ -24,6 +24,7 @@ typedef int ncclDataType_t;    // ncclFloat32 == 7
 typedef int ncclRedOp_t;       // ncclSum == 0
 constexpr ncclResult_t ncclSuccess = 0;
 constexpr ncclDataType_t ncclFloat = 7;
+constexpr ncclDataType_t ncclBfloat16 = 9;
 constexpr ncclRedOp_t ncclSum = 0;
 
 namespace {
@@ -93,16 +94,30 @@ extern "C" int gcc_comm_init(gcc_comm_t** out, int rank, int world, const void* 
     return GCC_OK;
 }
 
-// in-place sum over ranks of `count` fp32 values, enqueued on `stream` (ordered like a kernel; never synchronises).  One call
-// per gradient bucket: the caller sizes the buckets (tens of MB keep every xGMI link busy) and applies 1/world in its
-// optimizer step (gcc_adam_tensor_t.grad_scale).
+// in-place sum over ranks of `count` values (dtype 0: fp32, 1: bf16), enqueued on `stream` (ordered like a kernel; never
+// synchronises).  One call per gradient bucket: the caller sizes the buckets (tens of MB keep every xGMI link busy) and applies
+// 1/world in its optimizer step (gcc_adam_tensor_t.grad_scale).  While the calling thread records a launch sequence
+// (gcc_replay_begin) the call is part of the recording.
+int gcc_internal_comm_allreduce(void* comm, void* buf, size_t count, int dtype, hipStream_t st) {
+    gcc_comm* c = (gcc_comm*)comm;
+    const RcclApi& r = rccl();
+    if (!r.ok) return GCC_ERR_UNSUPPORTED;
+    if (!rccl_ok(r.AllReduce(buf, buf, count, dtype ? ncclBfloat16 : ncclFloat, ncclSum, c->comm, st))) return GCC_ERR_LAUNCH;
+    return GCC_OK;
+}
 extern "C" int gcc_comm_allreduce_sum_f32(gcc_comm_t* c, float* buf, size_t count, gcc_stream_t stream) {
     GCC_ENTER();
     if (!c || !buf || count == 0) return GCC_ERR_BAD_ARG;
-    const RcclApi& r = rccl();
-    if (!r.ok) return GCC_ERR_UNSUPPORTED;
-    if (!rccl_ok(r.AllReduce(buf, buf, count, ncclFloat, ncclSum, c->comm, (hipStream_t)stream))) return GCC_ERR_LAUNCH;
-    return GCC_OK;
+    if (gcc_replay_recording()) gcc_replay_record_allreduce(c, buf, count, 0, (hipStream_t)stream);
+    return gcc_internal_comm_allreduce(c, buf, count, 0, (hipStream_t)stream);
+}
+// the same over bf16 values (gradient buckets cast by gcc_cast_f32_bf16: half the bytes over xGMI; every
+// rank receives the same sums, so replicas stay identical)
+extern "C" int gcc_comm_allreduce_sum_bf16(gcc_comm_t* c, void* buf, size_t count, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!c || !buf || count == 0) return GCC_ERR_BAD_ARG;
+    if (gcc_replay_recording()) gcc_replay_record_allreduce(c, buf, count, 1, (hipStream_t)stream);
+    return gcc_internal_comm_allreduce(c, buf, count, 1, (hipStream_t)stream);
 }
 
 extern "C" int gcc_comm_rank(const gcc_comm_t* c) { return c ? c->rank : GCC_ERR_BAD_ARG; }

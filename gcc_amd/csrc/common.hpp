@@ -136,6 +136,10 @@ void gcc_replay_record_kernel(const GccLaunchRec& rec);
 // the few non-kernel stream operations of the library, recorded the same way
 hipError_t gcc_memset_async(void* dst, int value, size_t bytes, hipStream_t st);
 hipError_t gcc_memcpy_d2d_async(void* dst, const void* src, size_t bytes, hipStream_t st);
+// the C ABI's own all-reduce (comm.hip) as a recordable stream operation: while the calling thread records, the call is written
+// down (communicator, buffer, count, element type 0 fp32 / 1 bf16, stream) and gcc_replay_run issues it again in recorded order
+void gcc_replay_record_allreduce(void* comm, void* buf, size_t count, int dtype, hipStream_t st);
+int gcc_internal_comm_allreduce(void* comm, void* buf, size_t count, int dtype, hipStream_t st);
 
 template <typename T> struct GccArgBox { T v; };
 template <typename Tuple, size_t... I>

@@ -380,6 +380,25 @@ __global__ __launch_bounds__(256) void adam_kernel(const gcc_adam_tensor_t* __re
     }
 }
 
+// gradient buckets in bf16 for the exchange over xGMI (dist.GradReducer, GCC_DP_BF16=1): four values per thread
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n4, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = ((const f32x4*)src)[i];
+        i32x2 o = {(int)pack2bf(v[0], v[1]), (int)pack2bf(v[2], v[3])};
+        ((i32x2*)dst)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] = f2bf(src[n4 * 4 + threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, size_t n4, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const i32x2 v = ((const i32x2*)src)[i];
+        f32x4 o = {__uint_as_float((uint32_t)v[0] << 16), __uint_as_float((uint32_t)v[0] & 0xffff0000u),
+                   __uint_as_float((uint32_t)v[1] << 16), __uint_as_float((uint32_t)v[1] & 0xffff0000u)};
+        ((f32x4*)dst)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] = bf2f(src[n4 * 4 + threadIdx.x]);
+}
+
 __global__ void fill_kernel(float* p, float v, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -854,6 +873,20 @@ extern "C" int gcc_fill_f32(float* p, float v, size_t n, gcc_stream_t stream) {
     GCC_ENTER();
     if (!p || n == 0) return GCC_ERR_BAD_ARG;
     hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, v, n);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+extern "C" int gcc_cast_f32_bf16(const float* src, void* dst, size_t n, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!src || !dst || n == 0 || (((uintptr_t)src) & 15) || (((uintptr_t)dst) & 7)) return GCC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n / 4, n);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+extern "C" int gcc_cast_bf16_f32(const void* src, float* dst, size_t n, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!src || !dst || n == 0 || (((uintptr_t)dst) & 15) || (((uintptr_t)src) & 7)) return GCC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, n / 4, n);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

@@ -22,7 +22,7 @@
 #include "common.hpp"
 
 namespace {
-enum { E_KERNEL = 0, E_MEMSET, E_MEMCPY, E_RECORD, E_WAIT };
+enum { E_KERNEL = 0, E_MEMSET, E_MEMCPY, E_RECORD, E_WAIT, E_ALLREDUCE };
 
 struct Entry {
     int type, tag;
@@ -77,6 +77,10 @@ int issue(gcc_replay* r, const Entry& x) {
         if (hipEventRecord(x.own, x.stream) != hipSuccess) return 1;
         return (x.last && hipEventRecord(x.ev, x.stream) != hipSuccess) ? 1 : 0;
     case E_WAIT: return hipStreamWaitEvent(x.stream, x.dep >= 0 ? x.own : x.ev, 0) == hipSuccess ? 0 : 1;
+    // a gradient all-reduce of the C ABI's communicator (comm.hip): dst = buffer, src = communicator, bytes = count, value = dtype.
+    // Collectives of one communicator must be issued in the same order on every rank: a recording that holds one is replayed
+    // from ONE thread (gcc_replay_end)
+    case E_ALLREDUCE: return gcc_internal_comm_allreduce((void*)x.src, x.dst, x.bytes, x.value, x.stream) == GCC_OK ? 0 : 1;
     }
     return 1;
 }
@@ -144,6 +148,12 @@ hipError_t gcc_memset_async(void* dst, int value, size_t bytes, hipStream_t st) 
         t_rec->e.push_back(x);
     }
     return hipMemsetAsync(dst, value, bytes, st);
+}
+void gcc_replay_record_allreduce(void* comm, void* buf, size_t count, int dtype, hipStream_t st) {
+    if (!t_rec) return;
+    Entry x = {};
+    x.type = E_ALLREDUCE; x.stream = st; x.dst = buf; x.src = comm; x.bytes = count; x.value = dtype; x.dep = -1;
+    t_rec->e.push_back(x);
 }
 hipError_t gcc_memcpy_d2d_async(void* dst, const void* src, size_t bytes, hipStream_t st) {
     if (t_rec) {
@@ -231,6 +241,8 @@ extern "C" int gcc_replay_end(gcc_replay_t* r, int threads) {
         for (size_t j = i + 1; j < order.size(); j++)
             if (count[order[j]] > count[order[i]]) std::swap(order[i], order[j]);
     int nl = threads > 1 ? threads : 1;
+    for (const Entry& x : r->e)
+        if (x.type == E_ALLREDUCE) { nl = 1; break; }       // collectives: one issuing thread, the recorded order on every rank
     if (nl > (int)streams.size()) nl = (int)streams.size() ? (int)streams.size() : 1;
     if (nl > 8) nl = 8;
     r->nlanes = nl;
@@ -288,7 +300,7 @@ extern "C" int gcc_replay_run(gcc_replay_t* r) {
     if (r->nlanes <= 1) {
         static const bool timing = getenv("GCC_REPLAY_TIMING") != nullptr;     // host time per entry kind, to stderr
         if (timing) {
-            double t[5] = {0, 0, 0, 0, 0}; long n[5] = {0, 0, 0, 0, 0};
+            double t[6] = {0, 0, 0, 0, 0, 0}; long n[6] = {0, 0, 0, 0, 0, 0};
             for (const Entry& x : r->e) {
                 timespec a, b;
                 clock_gettime(CLOCK_MONOTONIC, &a);

@@ -65,29 +65,74 @@ def broadcast_module(module, src=0):
 
 def all_reduce_flat(flat_grads):
     """sum the flat gradient buffer of one parameter group over ranks (scaled by 1/world inside the
-    Adam kernel via grad_scale)"""
-    if is_dist():
+    Adam kernel via grad_scale), on the current stream's order"""
+    if not is_dist():
+        return
+    if comm_route() == 'native' and flat_grads.is_cuda and flat_grads.dtype == torch.float32:
+        native_comm().all_reduce_sum_(flat_grads)            # enqueued on the current stream, recordable
+    else:
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
 
 
 def all_reduce_grads(optimizer, async_op=False):
-    """sum this optimizer's flat gradient bucket over ranks.  async_op: returns the work handle (the
-    collective runs on RCCL's stream behind everything enqueued so far); call .wait() before the
-    optimizer step."""
+    """sum this optimizer's flat gradient bucket over ranks.  async_op: returns a handle with .wait() (torch route: the
+    collective runs on RCCL's stream behind everything enqueued so far; native route: it is already ordered on the current
+    stream, the handle's wait is a no-op); call .wait() before the optimizer step."""
     if not is_dist():
         return None
     optimizer.set_grad_scale(1.0 / world_size())
     if async_op:
+        if comm_route() == 'native' and optimizer.flat.grads.is_cuda:
+            native_comm().all_reduce_sum_(optimizer.flat.grads)
+            return _Done()
         return dist.all_reduce(optimizer.flat.grads, op=dist.ReduceOp.SUM, async_op=True)
     all_reduce_flat(optimizer.flat.grads)
     return None
 
 
+class _Done:
+    def wait(self):
+        pass
+
+
+_route = None
+
+
 def comm_route():
-    """GCC_DP_COMM=native: the bucket all-reduces are enqueued through the C ABI's own communicator (gcc_comm_allreduce_sum_f32,
-    csrc/comm.hip: RCCL on the CALLER's stream -- the weight-gradient side stream -- so the step stays on its four hardware
-    queues); default 'torch': torch.distributed's all_reduce(async_op=True), which runs on ProcessGroupNCCL's own stream."""
-    return 'native' if os.environ.get('GCC_DP_COMM', 'torch') == 'native' else 'torch'
+    """Which library carries the gradient exchange of the iteration.
+    'native': the C ABI's own communicator (gcc_comm_allreduce_sum_*, csrc/comm.hip: RCCL on the CALLER's stream -- the
+    weight-gradient side stream -- so the step stays on its four hardware queues, and the call is part of a launch recording:
+    data parallelism and gcc_amd.replay compose).  'torch': torch.distributed's all_reduce(async_op=True) on
+    ProcessGroupNCCL's own stream (a fifth busy queue: profiles/r3_summary.md measures -36 % with five hardware queues).
+    GCC_DP_COMM=native / torch forces one.  Default (round 4): native wherever it can work -- an RCCL process group of more
+    than one rank whose communicator can be created and whose bucket self-check passes (bucket_selfcheck) -- else torch, with
+    a warning; never the other way round."""
+    global _route
+    env = os.environ.get('GCC_DP_COMM')
+    if env in ('native', 'torch'):
+        return env
+    if _route is None:
+        _route = 'torch'
+        if is_dist() and world_size() > 1 and torch.cuda.is_available() and dist.get_backend() == 'nccl':
+            try:
+                native_comm()
+                _route = 'native'
+            except Exception as e:          # RCCL missing from the process, communicator creation refused ...
+                _warn('native RCCL communicator unavailable (%s: %s): gradient exchange through torch.distributed' % (type(e).__name__, e))
+    return _route
+
+
+def _warn(msg):
+    if rank() == 0:
+        import sys
+        print('[gcc_amd.dist] ' + msg, file=sys.stderr, flush=True)
+
+
+def bf16_buckets():
+    """GCC_DP_BF16=1: gradient buckets travel as bf16 (cast, summed, cast back: half the bytes over xGMI).
+    Every rank receives the same sums, so replicas stay bit-identical; the sums themselves carry 8 significant bits per term.
+    Off by default: the reference has no gradient exchange to compare a precision with."""
+    return os.environ.get('GCC_DP_BF16', '0') == '1'
 
 
 _native = None
@@ -117,6 +162,7 @@ def bucket_selfcheck(device):
     and route on the real backend: a side stream runs ~ms of kernels and then writes rank + 1 into a zeroed buffer, the
     all-reduce follows at once; every element must come back as world * (world + 1) / 2.  False (with a warning) makes the
     model classes fall back to one flat all-reduce per optimizer on the main stream."""
+    global _route
     route = comm_route()
     key = (str(device), route)
     if key in _selfcheck:
@@ -146,10 +192,13 @@ def bucket_selfcheck(device):
         flag = torch.tensor([1.0 if bool((buf == want).all()) else 0.0], device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item() == 1.0)
-        if not ok and rank() == 0:
-            import sys
-            print('[gcc_amd.dist] bucketed all-reduce self-check FAILED on route %r: falling back to one flat all-reduce per '
-                  'optimizer' % route, file=sys.stderr, flush=True)
+        if not ok and route == 'native' and os.environ.get('GCC_DP_COMM') != 'native':
+            _warn('bucketed all-reduce self-check FAILED on the native route: gradient exchange through torch.distributed')
+            _selfcheck[key] = False
+            _route = 'torch'
+            return bucket_selfcheck(device)
+        if not ok:
+            _warn('bucketed all-reduce self-check FAILED on route %r: falling back to one flat all-reduce per optimizer' % route)
     _selfcheck[key] = ok
     return ok
 
@@ -193,22 +242,63 @@ class GradReducer:
         self.enabled = True
         self.route = comm_route()
         self.native = native_comm() if self.route == 'native' else None
+        self.bf16 = bf16_buckets()
+        self.stage = torch.empty(max(e - b for b, e, _ in self.buckets), dtype=torch.bfloat16, device=self.flat.grads.device) \
+            if self.bf16 else None
+        self._events = []          # ops.Event pool of the native route (library events: part of a launch recording)
+        self._pending_cast = []    # torch route + bf16: (handle, b, e) whose cast back waits for the collective
+
+    def _event(self, i):
+        from . import ops
+        while len(self._events) <= i:
+            self._events.append(ops.Event())
+        return self._events[i]
 
     def _reduce(self, b, e, stream=None):
         """enqueue the all-reduce of grads[b:e]: behind everything enqueued so far on `stream` (a torch.cuda.Stream; default:
-        the current stream).  torch route: a work handle; native route: an event recorded behind the collective."""
+        the current stream).  torch route: a work handle; native route: a library event recorded behind the collective.
+        With bf16 buckets the slice is cast into the staging buffer, summed there and cast back (one bucket in flight at a
+        time per reducer on the native route: the casts and the collective are ordered on one stream)."""
         from . import ops
+        g = self.flat.grads[b:e]
+        if not g.is_cuda:                      # host tensors (the gloo tests of the bucket logic): nothing to order
+            self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+            return
+        st = stream if stream is not None else ops.current_stream()
         if self.route == 'native':
-            st = stream if stream is not None else ops.current_stream()
-            self.native.all_reduce_sum_(self.flat.grads[b:e], stream=st.cuda_stream)
-            ev = torch.cuda.Event()
+            with ops.on_stream(st):
+                if self.bf16:
+                    if self.handles:                  # the staging buffer's previous user may sit on another stream
+                        self.handles[-1].wait(st)
+                    buf = self.stage[:e - b]
+                    _lib_check('gcc_cast_f32_bf16', g.data_ptr(), buf.data_ptr(), e - b, st.cuda_stream)
+                    self.native.all_reduce_sum_bf16_(buf, stream=st.cuda_stream)
+                    _lib_check('gcc_cast_bf16_f32', buf.data_ptr(), g.data_ptr(), e - b, st.cuda_stream)
+                else:
+                    self.native.all_reduce_sum_(g, stream=st.cuda_stream)
+            ev = self._event(len(self.handles))
             ev.record(st)
             self.handles.append(ev)
-        elif stream is not None:
-            with ops.on_stream(stream):
-                self.handles.append(dist.all_reduce(self.flat.grads[b:e], op=dist.ReduceOp.SUM, async_op=True))
-        else:
-            self.handles.append(dist.all_reduce(self.flat.grads[b:e], op=dist.ReduceOp.SUM, async_op=True))
+            return
+        with ops.on_stream(st):
+            if self.bf16:
+                # the staging buffer is shared: the previous bucket's collective must have been cast back first
+                self._drain_casts()
+                buf = self.stage[:e - b]
+                _lib_check('gcc_cast_f32_bf16', g.data_ptr(), buf.data_ptr(), e - b, st.cuda_stream)
+                h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+                self._pending_cast.append((h, b, e, st))
+                self.handles.append(h)
+            else:
+                self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+
+    def _drain_casts(self):
+        from . import ops
+        for h, b, e, st in self._pending_cast:
+            with ops.on_stream(st):
+                h.wait()                      # orders `st` behind the collective
+                _lib_check('gcc_cast_bf16_f32', self.stage[:e - b].data_ptr(), self.flat.grads[b:e].data_ptr(), e - b, st.cuda_stream)
+        self._pending_cast = []
 
     def begin(self):
         """a new backward pass starts writing these gradients"""
@@ -235,14 +325,24 @@ class GradReducer:
             if not self.launched[k]:
                 self.launched[k] = True
                 self._reduce(b, e)
-        if self.route == 'native':
-            from . import ops
-            cur = ops.current_stream()
-            for ev in self.handles:
-                cur.wait_event(ev)
-        else:
+        from . import ops
+        if not self.flat.grads.is_cuda:
             for h in self.handles:
                 h.wait()
+            self.handles = []
+            return
+        cur = ops.current_stream()
+        if self.route == 'native':
+            for ev in self.handles:
+                ev.wait(cur)
+        else:
+            casts = self._pending_cast
+            self._drain_casts()
+            for h in self.handles:
+                h.wait()
+            for _, _, _, st in casts:         # the casts back ran on the buckets' streams
+                if st.cuda_stream != cur.cuda_stream:
+                    ops.wait_stream(cur, st)
         self.handles = []
 
     def wait(self):                 # the handle protocol of all_reduce_grads(async_op=True)
@@ -282,6 +382,14 @@ class NativeComm:
                                                         ops.stream() if stream is None else stream), 'gcc_comm_allreduce_sum_f32')
         return flat
 
+    def all_reduce_sum_bf16_(self, buf, stream=None):
+        """in place over a bf16 tensor (a gradient bucket cast by gcc_cast_f32_bf16)"""
+        from . import _lib, ops
+        assert buf.dtype == torch.bfloat16 and buf.is_contiguous() and buf.is_cuda
+        _lib.check(self._lib.gcc_comm_allreduce_sum_bf16(self._h, buf.data_ptr(), buf.numel(),
+                                                         ops.stream() if stream is None else stream), 'gcc_comm_allreduce_sum_bf16')
+        return buf
+
     def close(self):
         if getattr(self, '_h', None):
             self._lib.gcc_comm_destroy(self._h)
@@ -298,8 +406,16 @@ def all_reduce_sum(t):
     """sum over ranks of a small fp32 device vector, in place (the teacher's arch-difference terms: every replica must
     feed the same value into its EMA; the caller folds 1/world into its next kernel)"""
     if is_dist():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if comm_route() == 'native' and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+            native_comm().all_reduce_sum_(t)          # on the current stream, part of a launch recording
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+def _lib_check(name, *args):
+    from . import _lib
+    _lib.check(getattr(_lib.load(), name)(*args), name)
 
 
 def mean_dict(d, device):

@@ -754,13 +754,14 @@ def tail_workspace(device):
     return ws
 
 
-IN_CONV_FINALIZE = os.environ.get('GCC_IN_CONV_FINALIZE', '0') == '1'      # 1: the conv launch's last-arriving workgroups finalize (measured: profiles/r4_summary.md)
+IN_CONV_FINALIZE = os.environ.get('GCC_IN_CONV_FINALIZE', '1') != '0'      # the conv launch's last-arriving workgroups finalize (0: a gcc_bn_finalize launch; profiles/r4_summary.md)
 
 
 def bn_desc(bn_module, st, count, device, running=True):
     """gcc_bn_t of a training-mode BatchNorm2d application: statistics of `count` pixels, coefficients into the BNState `st`;
     running=False leaves running_mean / running_var alone (a pass that runs ahead of its place: engine.PatchGANEngine)"""
-    ws = tail_workspace(device) if IN_CONV_FINALIZE else None
+    # (bench.py's bracketed roofline step times every conv launch on its own: no finalize tail inside it there)
+    ws = tail_workspace(device) if (IN_CONV_FINALIZE and not PROFILE.active) else None
     return _lib.bn_t(bn_module.weight.data_ptr(), bn_module.bias.data_ptr(), bn_module.eps, bn_module.momentum, float(count),
                      bn_module.running_mean.data_ptr() if running else None, bn_module.running_var.data_ptr() if running else None,
                      st.mean.data_ptr(), st.rstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),

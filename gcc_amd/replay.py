@@ -16,10 +16,11 @@ What makes the iteration replayable:
     the CycleGAN image pool's random draws);
   * anything else that changes a launch argument invalidates the recording: call invalidate() after update_learning_rate(),
     adaptive_ema_beta(), pruning, a changed batch shape (step() checks shapes itself); the next step() records again.
-Data parallelism (gradient all-reduce through torch.distributed inside the iteration) is not recorded: with world_size > 1
-step() stays eager.  So does a model class that says `replay_supported = False`: Pix2Pix with dropout on (the dropout seeds are
-by-value launch arguments that nothing patches -- and its iteration is bound by its convolutions, not by the host: replayed it
-measured 16.1 ms against 15.6 eager, `scratch/replay_pix2pix.py`).
+Data parallelism: the gradient all-reduces of the C ABI's own communicator (dist.comm_route() 'native', the default on an RCCL
+process group) are recorded like launches and replayed from ONE host thread in the recorded order (the same on every rank);
+with the exchange on torch.distributed step() stays eager.  So does a model class that says `replay_supported = False`:
+Pix2Pix with dropout on (the dropout seeds are by-value launch arguments that nothing patches -- and its iteration is bound by
+its convolutions, not by the host: replayed it measured 16.1 ms against 15.6 eager, `scratch/replay_pix2pix.py`).
 """
 import ctypes as C
 import os
@@ -100,8 +101,13 @@ class IterationReplay:
             return False
         if not getattr(self.model, 'replay_supported', True):
             return False
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            return False
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                (torch.distributed.get_world_size() > 1 or os.environ.get('GCC_DP_FORCE_BUCKETS') == '1'):
+            # data parallelism: the iteration holds gradient all-reduces.  Through the C ABI's communicator (dist.comm_route()
+            # 'native') they are launch-like calls of the library and part of the recording (replayed from one host thread, in the
+            # recorded order on every rank); through torch.distributed they are not: eager
+            from . import dist as gdist
+            return gdist.comm_route() == 'native'
         return True
 
     # ------------------------------------------------------------------------------------------------

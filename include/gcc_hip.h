@@ -580,6 +580,13 @@ int gcc_comm_init(gcc_comm_t** comm, int rank, int world, const void* id);   /* 
 /* in-place sum over ranks of count fp32 values, ordered on `stream` like a kernel; the caller applies 1 / world in its
  * optimizer step (gcc_adam_tensor_t.grad_scale) and picks the bucket size (one call per bucket) */
 int gcc_comm_allreduce_sum_f32(gcc_comm_t* comm, float* buf, size_t count, gcc_stream_t stream);
+/* the same over bf16 values: a gradient bucket cast by gcc_cast_f32_bf16, summed, cast back by gcc_cast_bf16_f32 moves half the
+ * bytes over xGMI; every rank receives the same sums, so replicas stay identical.  Both all-reduce entry
+ * points are part of a launch recording (gcc_replay_begin) made on the calling thread; a recording that holds one is replayed
+ * from one host thread, in the recorded order (collectives of a communicator must be issued in one order on every rank). */
+int gcc_comm_allreduce_sum_bf16(gcc_comm_t* comm, void* buf, size_t count, gcc_stream_t stream);
+int gcc_cast_f32_bf16(const float* src, void* dst, size_t n, gcc_stream_t stream);      /* src 16-byte, dst 8-byte aligned */
+int gcc_cast_bf16_f32(const void* src, float* dst, size_t n, gcc_stream_t stream);
 int gcc_comm_rank(const gcc_comm_t* comm);
 int gcc_comm_world(const gcc_comm_t* comm);
 int gcc_comm_destroy(gcc_comm_t* comm);

@@ -244,6 +244,66 @@ def test_rccl_single_rank_with_teacher_stream(route):
     assert res['same_weights']
 
 
+def _rccl_replay_worker(port, q, bf16):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', GCC_DP_FORCE_BUCKETS='1', GCC_DP_COMM='native', GCC_DP_BF16='1' if bf16 else '0')
+    import torch.distributed as dist
+    from gcc_amd.replay import IterationReplay
+    from tests.test_pix2pix_gpu import GCC_ARGV, build_model
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
+
+    def run(enabled):
+        torch.manual_seed(5)
+        model, teacher, opt = build_model(GCC_ARGV, teacher_ndf=16)        # --no_dropout: replayable
+        model._world = teacher._world = 2            # take the data-parallel code paths (async teacher-G bucket included)
+        model.model_train()
+        g = torch.Generator().manual_seed(11)
+        data = [{'A': torch.rand(2, 3, 64, 64, generator=g) * 2 - 1, 'B': torch.rand(2, 3, 64, 64, generator=g) * 2 - 1,
+                 'A_paths': [''], 'B_paths': ['']} for _ in range(3)]
+        rp = IterationReplay(model, opt, warmup=2, threads=4, enabled=enabled)
+        modes, losses = [], []
+        for i in range(6):
+            modes.append(rp.step(data[i % 3], data[(i + 1) % 3]))
+            losses.append(dict(model.get_current_losses()))
+        model.finish_G_update()
+        teacher.finish_G_update()
+        torch.cuda.synchronize()
+        info = rp.info()
+        w = torch.cat([p.detach().float().reshape(-1) for m in (model.netG, model.netD, teacher.netG, teacher.netD)
+                       for p in m.parameters()]).cpu()
+        rp.invalidate()
+        return modes, losses, w, info, (model.optimizer_D.reducer is not None and model.optimizer_D.reducer.route)
+    m0, l0, w0, _, route = run(False)
+    m1, l1, w1, info, _ = run(True)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put({'eager_modes': m0, 'modes': m1, 'same_losses': l0 == l1, 'same_weights': bool(torch.equal(w0, w1)), 'info': info,
+           'route': route, 'finite': bool(torch.isfinite(w1).all())})
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize('bf16', [False, True])
+def test_replay_composes_with_data_parallel_native_route(bf16):
+    """with the gradient exchange on the C ABI's own communicator (the default route on an RCCL process group)
+    the all-reduces are part of the launch recording -- bucketed reducer on the weight-gradient side streams, the
+    asynchronous teacher-generator bucket, the summed arch-difference terms -- and a replayed data-parallel iteration leaves
+    the bits of the eager one (one RCCL rank: what this box can give; issued from ONE host thread, whatever was asked for).
+    bf16: the same with the buckets cast to bf16 for the exchange (GCC_DP_BF16=1)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_replay_worker, args=(_free_port(), q, bf16))
+    p.start()
+    res = _collect(q, [p], 1)[0]
+    p.join(120)
+    assert p.exitcode == 0
+    assert res['route'] == 'native', res['route']
+    assert set(res['eager_modes']) == {'eager'} and res['modes'] == ['eager', 'eager', 'record', 'replay', 'replay', 'replay'], res
+    assert res['info']['threads'] == 1 and res['info']['launches'] > 100, res['info']
+    assert res['same_losses'] and res['same_weights'] and res['finite']
+
+
 @pytest.mark.timeout(1500)
 def test_bench_two_ranks_driver_command_line():
     """the driver's multi-GPU invocation of bench.py, rehearsed with two ranks on this box's one GPU (gloo in place of
