@@ -34,7 +34,8 @@ class bnact_t(C.Structure):
 class bn_t(C.Structure):
     _fields_ = [('gamma', C.c_void_p), ('beta', C.c_void_p), ('eps', C.c_float), ('momentum', C.c_float), ('count', C.c_double),
                 ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p),
-                ('scale', C.c_void_p), ('shift', C.c_void_p), ('tail_ws', C.c_void_p), ('tail_ws_bytes', C.c_size_t)]
+                ('scale', C.c_void_p), ('shift', C.c_void_p), ('tail_ws', C.c_void_p), ('tail_ws_bytes', C.c_size_t),
+                ('finalize_in_launch', C.c_int), ('pad_', C.c_int)]
 
 
 class bnact_bwd_t(C.Structure):
@@ -121,6 +122,8 @@ PROTOTYPES = {
     'gcc_inorm_fwd': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
     'gcc_inorm_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
     'gcc_bn_bwd_one_launch': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _Z, _I, _F, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    'gcc_bn_bwd_one_launch_ex': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _Z, _I, _I, _F, _F, C.c_uint64, _P, _P, _P, _P, _P, _P, _P,
+                                      _P, _Z, _P]),
     'gcc_channel_stats_tiles': (_I, [_Z, _I]),
     'gcc_channel_stats': (_I, [_P, _I, _I, _I, _Z, _I, _P, _P]),
     'gcc_reflect_pad': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -247,6 +247,18 @@ __device__ __forceinline__ void st_stat(float* p, float v, bool sc1) {
     else *p = v;
 }
 
+// gcc_conv_bn_act's split layers, second launch (norm_act.hip bn_fold_grid_kernel; GCC_OPT_FUSE_BN 3): the K slices of the
+// partial-tile launch folded, BatchNorm statistics exchanged inside the launch, every row normalised from registers
+struct BnFoldDesc {
+    const float* part; int ksplit, rows_max, Cpad, phases;        // [phase][slice][rows_max][Cpad] fp32
+    int N, Hd, Wd, stride, dgrad;                                  // output geometry; dgrad: rows of phase (py, px) are the sub-grid
+    void* raw; int ldraw, rawoff;                                  // bf16 raw output (kept for the backward pass)
+    void* y; int ldy, yoff; void* y2; int ldy2, y2off;
+    int C; gcc_bn_t bn; int act, act2; float slope, drop_p; unsigned long long seed;
+    void* ws; size_t ws_bytes;                                     // GCC_INORM_WORKSPACE_BYTES, zero-filled once, one stream
+};
+int gcc_internal_bn_fold_grid(const BnFoldDesc* d, hipStream_t st);      // GCC_ERR_UNSUPPORTED: geometry outside the plan
+
 // XCD-aware remap of a linear workgroup id (8 XCDs, round-robin dispatch): logical tiles that are
 // adjacent end up on the same XCD (shared L2).  Bijective for any nwg.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

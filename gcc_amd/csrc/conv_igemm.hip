@@ -1458,8 +1458,8 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
     const int rows_alloc = p.stats ? gcc_conv_stat_tiles(c, dgrad) : 0;
     auto make_tail = [&](int rows, int wgs_per_row, TailFin* f) -> bool {
         *f = TailFin{};
-        if (!bnf || !bnf->tail_ws || (((uintptr_t)bnf->tail_ws) & 15) || rows != rows_alloc) return false;
-        if (tail_ws_bytes(rows, p.Cout) > bnf->tail_ws_bytes) return false;
+        if (!bnf || !bnf->finalize_in_launch || !bnf->tail_ws || (((uintptr_t)bnf->tail_ws) & 15) || rows != rows_alloc) return false;
+        if (tail_ws_bytes(rows, p.Cout) > TAIL_TICKET_BYTES + TAIL_GROUP_BYTES || bnf->tail_ws_bytes < TAIL_TICKET_BYTES + TAIL_GROUP_BYTES) return false;
         f->tickets = (unsigned*)bnf->tail_ws; f->grp = (double*)((char*)bnf->tail_ws + TAIL_TICKET_BYTES);
         f->rows = rows; f->wgs_per_row = wgs_per_row; f->count = bnf->count; f->eps = bnf->eps; f->momentum = bnf->momentum;
         f->gamma = bnf->gamma; f->beta = bnf->beta; f->running_mean = bnf->running_mean; f->running_var = bnf->running_var;
@@ -1794,7 +1794,9 @@ extern "C" int gcc_conv_bn_act(const gcc_conv_t* c, int dgrad, const void* x, co
         if (ks != sp.ksplit) { sp.kper = cdiv(nk, ks); sp.ksplit = cdiv(nk, sp.kper); }
     }
     const bool routed = (dgrad && thin_dgrad_shape(c)) || (!dgrad && thin_shape(c)) || head_shape(c);
-    if (!routed && sp.ksplit > 1 && max_rows * phases <= FOLD_BN_MAX_ROWS && gcc_opt(GCC_OPT_FUSE_BN) == 1) {
+    const int fuse = gcc_opt(GCC_OPT_FUSE_BN);
+    const bool grid_ws = bn->tail_ws && bn->tail_ws_bytes >= GCC_TAIL_WORKSPACE_BYTES && (((uintptr_t)bn->tail_ws) & 15) == 0;
+    if (!routed && sp.ksplit > 1 && max_rows * phases <= FOLD_BN_MAX_ROWS && (fuse == 1 || fuse == 3)) {
         // split launch with raw partial tiles, then the fused fold + statistics + finalize + normalise kernel
         FoldBnArgs a;
         IgemmParams& p = a.p;
@@ -1825,6 +1827,18 @@ extern "C" int gcc_conv_bn_act(const gcc_conv_t* c, int dgrad, const void* x, co
             default: rc = launch<128, 16>(p, phases, 1, st); break;
         }
         if (rc) return rc;
+        if (fuse == 3 && grid_ws) {
+            // the slices folded, the statistics exchanged and the rows normalised by ONE kernel on the whole chip
+            BnFoldDesc d = {};
+            d.part = p.partial; d.ksplit = p.ksplit; d.rows_max = p.rows_max; d.Cpad = p.Cpad; d.phases = phases;
+            d.N = p.N; d.Hd = p.Hd; d.Wd = p.Wd; d.stride = c->stride; d.dgrad = dgrad;
+            d.raw = y_raw; d.ldraw = p.ldd; d.rawoff = p.doff;
+            d.y = y; d.ldy = ldy; d.yoff = yoff; d.y2 = y2; d.ldy2 = ldy2; d.y2off = y2off;
+            d.C = Cout; d.bn = *bn; d.act = act->act; d.act2 = act->act2; d.slope = act->slope; d.drop_p = act->drop_p; d.seed = act->seed;
+            d.ws = (char*)bn->tail_ws + TAIL_TICKET_BYTES + TAIL_GROUP_BYTES; d.ws_bytes = GCC_INORM_WORKSPACE_BYTES;
+            const int rc3 = gcc_internal_bn_fold_grid(&d, st);
+            if (rc3 != GCC_ERR_UNSUPPORTED) return rc3;
+        }
         a.bn = *bn; a.act = act->act; a.act2 = act->act2; a.slope = act->slope; a.drop_p = act->drop_p; a.seed = act->seed;
         a.y = (bf16_t*)y; a.ldy = ldy; a.yoff = yoff; a.y2 = (bf16_t*)y2; a.ldy2 = ldy2; a.y2off = y2off; a.phases = phases;
         hipLaunchKernelGGL(splitk_bn_act_kernel<1024>, dim3(ceil8(Cout) / 8), dim3(1024), 0, st, a);

@@ -27,6 +27,7 @@ struct TailFin {
     float* running_mean; float* running_var; float* mean; float* rstd; float* scale; float* shift;
 };
 constexpr size_t TAIL_TICKET_BYTES = 4096;                 // up to 1023 groups = 16368 statistic rows
+constexpr size_t TAIL_GROUP_BYTES = (size_t)4 << 20;         // group sums; behind them: the grid fold kernel's workspace (GCC_TAIL_WORKSPACE_BYTES)
 static inline size_t tail_ws_bytes(int rows, int Cout) {
     const size_t G = (size_t)(rows + FIN_GROUP - 1) / FIN_GROUP;
     return G + 1 > TAIL_TICKET_BYTES / 4 ? ~(size_t)0 : TAIL_TICKET_BYTES + G * 2 * (size_t)Cout * sizeof(double);

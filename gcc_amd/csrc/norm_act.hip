@@ -727,6 +727,11 @@ struct InFusedArgs {
     float *mean, *rstd, *scale, *shift;   // [N][C]
     // BatchNorm backward through the grid kernel (gcc_bn_bwd_one_launch: N == 1, HW = all pixels of the batch)
     const float* gamma; float *dgamma, *dbeta;
+    // ... its extended form (template EXT, round 4: the U-Net's layers): the activation input recomputed from the forward's affine
+    // (bscale / bshift; y NULL), a second incoming gradient through a second activation, the dropout mask regenerated
+    const float* bscale; const float* bshift;
+    const bf16_t* g2; int ldg2; int act2;
+    float drop_p; unsigned long long seed;
 };
 
 // LPP lanes share a pixel (each 8 channels = 16 bytes): the slab is 8 * LPP channels wide.  Sums of the lanes with the same
@@ -997,94 +1002,12 @@ struct InGridArgs {
 };
 constexpr unsigned GCC_DEVERR_INORM_SPIN = 0x1401u;
 
-// A lane keeps its first PPT pixels (16 bytes each, per tensor) in registers from the statistics pass to the normalising pass:
-// every load of a pass is in flight at once, and the second pass loads nothing but the residual.  (With four loads in flight
-// and a second read of x, s_memrealtime stamps of the 64 x 64 x 256 plane read: 2 us statistics, 4 us hand-off, 6 us
-// normalising; the backward 8 + 4 + 8.)  Rows beyond PPT * (256 / CHP) per workgroup stream through the loops behind.
-template <bool BWD>
-__global__ __launch_bounds__(256, 4) void inorm_grid_kernel(const InGridArgs ga) {   // <= 128 VGPRs: four workgroups per CU, the residency the barrier counts on
-    constexpr int PPT = BWD ? 4 : 8;
-    __shared__ double smem_d[2048 + 256 + 1];       // one array (a second __shared__ object costs a vmcnt(0), guide 5.4)
-    float* red = (float*)smem_d;                    // [4 waves][64 lanes][16] per-wave sums; later the forward's coefficients
-    double* tot = smem_d + 2048;                    // [V <= 256] totals of the (image, channel group)
-    const InFusedArgs& a = ga.a;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int ch = t & (ga.CHP - 1), pl = t >> ga.sh, PL = 256 >> ga.sh;      // ch: chunk inside the group
-    const int s = blockIdx.x, cg = blockIdx.y;
-    const size_t g = blockIdx.z;
-    const size_t dom = g * ga.CG + cg;              // the barrier domain: S workgroups
-    const bool live = ch < ga.CHg && cg * ga.CHg + ch < ga.CH;
-    const int c0 = (cg * ga.CHg + ch) * 8;
-    const int p0 = s * ga.rows, p1 = min(p0 + ga.rows, a.HW);
-    const bf16_t* xg = a.x + g * (size_t)a.HW * a.ldx + c0;
-    const bf16_t* yg = (BWD && a.y) ? a.y + g * (size_t)a.HW * a.ldy + c0 : nullptr;
-    const bf16_t* ag = a.aux ? a.aux + g * (size_t)a.HW * a.ldaux + c0 : nullptr;     // fwd: residual; bwd: incoming gradient
-    bf16_t* og = a.out + g * (size_t)a.HW * a.ldout + c0;
-    float mu[8], rs[8];
-    if (BWD) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const bool ok = live && c0 + j < a.C;
-            mu[j] = ok ? a.mean[g * a.C + c0 + j] : 0.f;
-            rs[j] = ok ? a.rstd[g * a.C + c0 + j] : 0.f;
-        }
-    }
-    // the domain's epoch word: stable until every workgroup of the domain has written its partial (all of them read it first)
-    typedef __attribute__((address_space(1))) unsigned int gu32;
-    gu32* cnt = (gu32*)ga.cnt + dom * 4;            // [1]: the domain's epoch (launches that used it)
+// The statistics hand-off of the grid kernels (inorm_grid_kernel, bn_fold_grid_kernel): this workgroup's per-lane sums v[2][8]
+// -> the (image, channel group) domain's totals tot[V] (double), identical in every workgroup of the domain.
 #define IN_STAMP(k) do { if (ga.clk && t == 0 && dom == 0) ga.clk[s * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-    IN_STAMP(0);
-    unsigned epoch = 0;
-    if (t == 0 && ga.S > 1) epoch = __hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float v[2][8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) v[0][j] = v[1][j] = 0.f;
-    auto accum = [&](const i32x4& rx, const i32x4& rgr, const i32x4& ry) {
-        float xv[8];
-        unpack8(rx, xv);
-        if (!BWD) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) { v[0][j] += xv[j]; v[1][j] += xv[j] * xv[j]; }
-        } else {
-            float gv[8], yv[8];
-            unpack8(rgr, gv);
-            if (yg) unpack8(ry, yv);
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float xh = (xv[j] - mu[j]) * rs[j];
-                const float yo = yg ? yv[j] : apply_act(xh, a.act, a.slope);
-                const float d = gv[j] * act_grad_from_out(yo, a.act, a.slope);
-                v[0][j] += d; v[1][j] += d * xh;
-            }
-        }
-    };
-    const i32x4 zero4 = {0, 0, 0, 0};
-    i32x4 cx[PPT], cgr[BWD ? PPT : 1];               // the saved output y is read again in the second pass: 128 VGPRs hold no more
-    const int pfirst = p0 + pl;                     // this lane's pixels: pfirst + u * PL
-    const int pstream = pfirst + PPT * PL;          // the first one that is not held in registers
-    if (live) {
-        i32x4 cy[BWD ? PPT : 1];
-#pragma unroll
-        for (int u = 0; u < PPT; u++) {
-            const int p = pfirst + u * PL;
-            const bool ok = p < p1;
-            cx[u] = ok ? *(const i32x4*)(xg + (size_t)p * a.ldx) : zero4;
-            if (BWD) {
-                cgr[u] = ok ? *(const i32x4*)(ag + (size_t)p * a.ldaux) : zero4;      // zero gradient: no contribution
-                cy[u] = (ok && yg) ? *(const i32x4*)(yg + (size_t)p * a.ldy) : zero4;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PPT; u++) accum(cx[u], cgr[BWD ? u : 0], cy[BWD ? u : 0]);
-        for (int p = pstream; p < p1; p += PL) {
-            i32x4 rx = *(const i32x4*)(xg + (size_t)p * a.ldx), rgr = rx, ry = rx;
-            if (BWD) {
-                rgr = *(const i32x4*)(ag + (size_t)p * a.ldaux);
-                if (yg) ry = *(const i32x4*)(yg + (size_t)p * a.ldy);
-            }
-            accum(rx, rgr, ry);
-        }
-    }
+__device__ __forceinline__ void grid_exchange(const InGridArgs& ga, float (&v)[2][8], double* smem_d, float* red, double* tot, int s,
+                                              size_t dom, __attribute__((address_space(1))) unsigned int* cnt, unsigned epoch, int t,
+                                              int lane, int wave, int ch) {
     // lanes of a wave that hold the same chunk (CHP < 64), then the waves through LDS
     for (int o = 32; o >= ga.CHP; o >>= 1) {
 #pragma unroll
@@ -1208,6 +1131,142 @@ __global__ __launch_bounds__(256, 4) void inorm_grid_kernel(const InGridArgs ga)
     } else {
         __syncthreads();
     }
+}
+#undef IN_STAMP
+
+// A lane keeps its first PPT pixels (16 bytes each, per tensor) in registers from the statistics pass to the normalising pass:
+// every load of a pass is in flight at once, and the second pass loads nothing but the residual.  (With four loads in flight
+// and a second read of x, s_memrealtime stamps of the 64 x 64 x 256 plane read: 2 us statistics, 4 us hand-off, 6 us
+// normalising; the backward 8 + 4 + 8.)  Rows beyond PPT * (256 / CHP) per workgroup stream through the loops behind.
+template <bool BWD, int EXT = 0>      // EXT (backward only): 1 recomputed activation input / second gradient, 2: + dropout
+__global__ __launch_bounds__(256, 4) void inorm_grid_kernel(const InGridArgs ga) {   // <= 128 VGPRs: four workgroups per CU, the residency the barrier counts on
+    static_assert(BWD || !EXT, "the extended form is a backward");
+    constexpr int PPT = BWD ? (EXT ? 2 : 4) : 8;
+    __shared__ double smem_d[2048 + 256 + 1];       // one array (a second __shared__ object costs a vmcnt(0), guide 5.4)
+    float* red = (float*)smem_d;                    // [4 waves][64 lanes][16] per-wave sums; later the forward's coefficients
+    double* tot = smem_d + 2048;                    // [V <= 256] totals of the (image, channel group)
+    const InFusedArgs& a = ga.a;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ch = t & (ga.CHP - 1), pl = t >> ga.sh, PL = 256 >> ga.sh;      // ch: chunk inside the group
+    const int s = blockIdx.x, cg = blockIdx.y;
+    const size_t g = blockIdx.z;
+    const size_t dom = g * ga.CG + cg;              // the barrier domain: S workgroups
+    const bool live = ch < ga.CHg && cg * ga.CHg + ch < ga.CH;
+    const int c0 = (cg * ga.CHg + ch) * 8;
+    const int p0 = s * ga.rows, p1 = min(p0 + ga.rows, a.HW);
+    const bf16_t* xg = a.x + g * (size_t)a.HW * a.ldx + c0;
+    const bf16_t* yg = (BWD && a.y) ? a.y + g * (size_t)a.HW * a.ldy + c0 : nullptr;
+    const bf16_t* ag = a.aux ? a.aux + g * (size_t)a.HW * a.ldaux + c0 : nullptr;     // fwd: residual; bwd: incoming gradient
+    bf16_t* og = a.out + g * (size_t)a.HW * a.ldout + c0;
+    float mu[8], rs[8];
+    float bsc[EXT ? 8 : 1], bsf[EXT ? 8 : 1];
+    const bf16_t* g2g = nullptr;
+    const float keep_scale = (EXT == 2 && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
+    if (BWD) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const bool ok = live && c0 + j < a.C;
+            mu[j] = ok ? a.mean[g * a.C + c0 + j] : 0.f;
+            rs[j] = ok ? a.rstd[g * a.C + c0 + j] : 0.f;
+            if constexpr (EXT) {
+                bsc[j] = (ok && a.bscale) ? a.bscale[c0 + j] : 0.f;
+                bsf[j] = (ok && a.bshift) ? a.bshift[c0 + j] : 0.f;
+            }
+        }
+        if constexpr (EXT) g2g = a.g2 ? a.g2 + c0 : nullptr;
+    }
+    // the gradient that reaches the normalisation's output at pixel p: g act'(y) [+ g2 act2'(y)], through the dropout mask
+    auto dz8 = [&](int p, const float* xv, const float* gv, const float* g2v, const float* yv, float* d, float* xh) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            xh[j] = (xv[j] - mu[j]) * rs[j];
+            float yo, df = 1.f;
+            if constexpr (EXT) {
+                float z = a.bscale ? xv[j] * bsc[j] + bsf[j] : xh[j];        // the forward's own affine form
+                if constexpr (EXT == 2) {
+                    const float uu = rng_uniform(a.seed, (size_t)p * (size_t)a.C + c0 + j);
+                    df = uu >= a.drop_p ? keep_scale : 0.f;
+                    z *= df;
+                }
+                yo = yg ? yv[j] : apply_act(z, a.act, a.slope);
+            } else {
+                yo = yg ? yv[j] : apply_act(xh[j], a.act, a.slope);
+            }
+            float dd = gv[j] * act_grad_from_out(yo, a.act, a.slope);
+            if constexpr (EXT) {
+                if (g2g) dd += g2v[j] * act_grad_from_out(yo, a.act2, a.slope);
+                dd *= df;
+            }
+            d[j] = dd;
+        }
+    };
+    // the domain's epoch word: stable until every workgroup of the domain has written its partial (all of them read it first)
+    typedef __attribute__((address_space(1))) unsigned int gu32;
+    gu32* cnt = (gu32*)ga.cnt + dom * 4;            // [1]: the domain's epoch (launches that used it)
+#define IN_STAMP(k) do { if (ga.clk && t == 0 && dom == 0) ga.clk[s * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    IN_STAMP(0);
+    unsigned epoch = 0;
+    if (t == 0 && ga.S > 1) epoch = __hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float v[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[0][j] = v[1][j] = 0.f;
+    auto accum = [&](int p, const i32x4& rx, const i32x4& rgr, const i32x4& ry, const i32x4& rg2) {
+        float xv[8];
+        unpack8(rx, xv);
+        if (!BWD) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { v[0][j] += xv[j]; v[1][j] += xv[j] * xv[j]; }
+        } else {
+            float gv[8], yv[8];
+            unpack8(rgr, gv);
+            if (yg) unpack8(ry, yv);
+            if constexpr (!EXT) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float xh = (xv[j] - mu[j]) * rs[j];
+                    const float yo = yg ? yv[j] : apply_act(xh, a.act, a.slope);
+                    const float d = gv[j] * act_grad_from_out(yo, a.act, a.slope);
+                    v[0][j] += d; v[1][j] += d * xh;
+                }
+            } else {
+                float g2v[8], d[8], xh[8];
+                if (g2g) unpack8(rg2, g2v);
+                dz8(p, xv, gv, g2v, yv, d, xh);
+#pragma unroll
+                for (int j = 0; j < 8; j++) { v[0][j] += d[j]; v[1][j] += d[j] * xh[j]; }
+            }
+        }
+    };
+    const i32x4 zero4 = {0, 0, 0, 0};
+    i32x4 cx[PPT], cgr[BWD ? PPT : 1];               // the saved output y is read again in the second pass: 128 VGPRs hold no more
+    const int pfirst = p0 + pl;                     // this lane's pixels: pfirst + u * PL
+    const int pstream = pfirst + PPT * PL;          // the first one that is not held in registers
+    if (live) {
+        i32x4 cy[BWD ? PPT : 1], cg2[EXT ? PPT : 1];
+#pragma unroll
+        for (int u = 0; u < PPT; u++) {
+            const int p = pfirst + u * PL;
+            const bool ok = p < p1;
+            cx[u] = ok ? *(const i32x4*)(xg + (size_t)p * a.ldx) : zero4;
+            if (BWD) {
+                cgr[u] = ok ? *(const i32x4*)(ag + (size_t)p * a.ldaux) : zero4;      // zero gradient: no contribution
+                cy[u] = (ok && yg) ? *(const i32x4*)(yg + (size_t)p * a.ldy) : zero4;
+                if constexpr (EXT) cg2[u] = (ok && g2g) ? *(const i32x4*)(g2g + (size_t)p * a.ldg2) : zero4;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PPT; u++) accum(pfirst + u * PL, cx[u], cgr[BWD ? u : 0], cy[BWD ? u : 0], cg2[EXT ? u : 0]);
+        for (int p = pstream; p < p1; p += PL) {
+            i32x4 rx = *(const i32x4*)(xg + (size_t)p * a.ldx), rgr = rx, ry = rx, rg2 = rx;
+            if (BWD) {
+                rgr = *(const i32x4*)(ag + (size_t)p * a.ldaux);
+                if (yg) ry = *(const i32x4*)(yg + (size_t)p * a.ldy);
+                if constexpr (EXT) { if (g2g) rg2 = *(const i32x4*)(g2g + (size_t)p * a.ldg2); }
+            }
+            accum(p, rx, rgr, ry, rg2);
+        }
+    }
+    grid_exchange(ga, v, smem_d, red, tot, s, dom, cnt, epoch, t, lane, wave, ch);
     IN_STAMP(4);
     const double inv_hw = 1.0 / (double)a.HW;
     if (!BWD) {
@@ -1285,36 +1344,186 @@ __global__ __launch_bounds__(256, 4) void inorm_grid_kernel(const InGridArgs ga)
             const float gr = (a.gamma && c0 + j < a.C) ? a.gamma[c0 + j] * rs[j] : rs[j];      // dx = gamma rstd (dz - k0 - xhat k1)
             A[j] = gr; B[j] = -gr * rs[j] * k1; K[j] = -gr * k0 + gr * rs[j] * k1 * mu[j];
         }
-        auto emit = [&](int p, const i32x4& rx, const i32x4& rgr, const i32x4& ry) {
+        auto emit = [&](int p, const i32x4& rx, const i32x4& rgr, const i32x4& ry, const i32x4& rg2) {
             float xv[8], yv[8], gv[8], o[8];
             unpack8(rx, xv); unpack8(rgr, gv);
             if (yg) unpack8(ry, yv);
+            if constexpr (!EXT) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float yo = yg ? yv[j] : apply_act((xv[j] - mu[j]) * rs[j], a.act, a.slope);
-                const float d = gv[j] * act_grad_from_out(yo, a.act, a.slope);
-                o[j] = A[j] * d + B[j] * xv[j] + K[j];
+                for (int j = 0; j < 8; j++) {
+                    const float yo = yg ? yv[j] : apply_act((xv[j] - mu[j]) * rs[j], a.act, a.slope);
+                    const float d = gv[j] * act_grad_from_out(yo, a.act, a.slope);
+                    o[j] = A[j] * d + B[j] * xv[j] + K[j];
+                }
+            } else {
+                float g2v[8], d[8], xh[8];
+                if (g2g) unpack8(rg2, g2v);
+                dz8(p, xv, gv, g2v, yv, d, xh);
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j] = A[j] * d[j] + B[j] * xv[j] + K[j];
             }
             *(i32x4*)(og + (size_t)p * a.ldout) = pack8(o);
         };
-        i32x4 cy[PPT];
+        i32x4 cy[PPT], cg2[EXT ? PPT : 1];
 #pragma unroll
         for (int u = 0; u < PPT; u++) {
             const int p = pfirst + u * PL;
             cy[u] = (p < p1 && yg) ? *(const i32x4*)(yg + (size_t)p * a.ldy) : zero4;
+            if constexpr (EXT) cg2[u] = (p < p1 && g2g) ? *(const i32x4*)(g2g + (size_t)p * a.ldg2) : zero4;
         }
 #pragma unroll
         for (int u = 0; u < PPT; u++)
-            if (pfirst + u * PL < p1) emit(pfirst + u * PL, cx[u], cgr[BWD ? u : 0], cy[u]);
+            if (pfirst + u * PL < p1) emit(pfirst + u * PL, cx[u], cgr[BWD ? u : 0], cy[u], cg2[EXT ? u : 0]);
         for (int p = pstream; p < p1; p += PL) {
             const i32x4 rx = *(const i32x4*)(xg + (size_t)p * a.ldx);
             const i32x4 rgr = *(const i32x4*)(ag + (size_t)p * a.ldaux);
             const i32x4 ry = yg ? *(const i32x4*)(yg + (size_t)p * a.ldy) : rx;
-            emit(p, rx, rgr, ry);
+            i32x4 rg2 = rx;
+            if constexpr (EXT) { if (g2g) rg2 = *(const i32x4*)(g2g + (size_t)p * a.ldg2); }
+            emit(p, rx, rgr, ry, rg2);
         }
         IN_STAMP(5);
     }
 #undef IN_STAMP
+}
+
+// ---- split-K fold + BatchNorm + activation on the whole chip, one launch (round 4) -----------------------------------------------
+// The U-Net's <= 16x16 layers run their conv as fp32 partial tiles of K slices (the weights streamed by every CU); what
+// followed was splitk_bn_act_kernel: C / 8 workgroups, each walking every row of its 8 channels twice (14-56 us per layer,
+// profiles/r3z_unet_student_chain.txt).  Here the rows are dealt over S x CG workgroups as in inorm_grid_kernel -- a lane owns
+// 8 channels of <= PPT rows: folds their K slices in slice order (every slice's two 16-byte loads in flight), rounds to bf16
+// (the raw output, kept for the backward pass), keeps the rounded values in registers, the per-channel sums go through
+// grid_exchange (tagged write-through partials; residency and workspace rules of inorm_grid_kernel), and the rows are
+// normalised from the registers: dropout by the (pixel, channel) counter of bnact_fwd_kernel, both activated copies.
+struct FoldGridArgs {
+    InGridArgs g;                          // exchange layout; g.a is not used
+    const float* part; int ksplit, rows_max, Cpad, phases, Mph, Rt;
+    int Hd, Wd, ostr, Hg, Wg; FastDiv dMph, dHgWg, dWg;
+    bf16_t* raw; int ldraw, rawoff;
+    bf16_t* y; int ldy, yoff; bf16_t* y2; int ldy2, y2off;
+    int C; double count;
+    const float* gamma; const float* beta; float eps, momentum;
+    float* running_mean; float* running_var; float* mean; float* rstd; float* scale; float* shift;
+    int act, act2; float slope, drop_p; unsigned long long seed;
+};
+template <int PPT>
+__global__ __launch_bounds__(256, 4) void bn_fold_grid_kernel(const FoldGridArgs fa) {
+    __shared__ double smem_d[2048 + 256 + 1];
+    float* red = (float*)smem_d;
+    double* tot = smem_d + 2048;
+    const InGridArgs& ga = fa.g;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ch = t & (ga.CHP - 1), pl = t >> ga.sh, PL = 256 >> ga.sh;
+    const int s = blockIdx.x, cg = blockIdx.y;
+    const size_t dom = cg;
+    const bool live = ch < ga.CHg && cg * ga.CHg + ch < ga.CH;
+    const int c0 = (cg * ga.CHg + ch) * 8;
+    const int p0 = s * ga.rows, p1 = min(p0 + ga.rows, fa.Rt);
+    typedef __attribute__((address_space(1))) unsigned int gu32;
+    gu32* cnt = (gu32*)ga.cnt + dom * 4;
+    unsigned epoch = 0;
+    if (t == 0 && ga.S > 1) epoch = __hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float v[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[0][j] = v[1][j] = 0.f;
+    i32x4 cx[PPT];
+    int pixv[PPT];
+    const size_t sstride = (size_t)fa.rows_max * fa.Cpad;
+#pragma unroll
+    for (int u = 0; u < PPT; u++) {
+        const int p = p0 + pl + u * PL;
+        cx[u] = i32x4{0, 0, 0, 0};
+        pixv[u] = -1;
+        if (live && p < p1) {
+            const int z = fdiv(p, fa.dMph), m = p - z * fa.Mph;
+            const float* r0 = fa.part + ((size_t)z * fa.ksplit * fa.rows_max + m) * fa.Cpad + c0;
+            float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int sl = 0;
+            for (; sl + 3 < fa.ksplit; sl += 4) {
+                f32x4 a[4], b[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { a[q] = *(const f32x4*)(r0 + (sl + q) * sstride); b[q] = *(const f32x4*)(r0 + (sl + q) * sstride + 4); }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    f[0] += a[q][0]; f[1] += a[q][1]; f[2] += a[q][2]; f[3] += a[q][3];
+                    f[4] += b[q][0]; f[5] += b[q][1]; f[6] += b[q][2]; f[7] += b[q][3];
+                }
+            }
+            for (; sl < fa.ksplit; sl++) {
+                const f32x4 a = *(const f32x4*)(r0 + sl * sstride), b = *(const f32x4*)(r0 + sl * sstride + 4);
+                f[0] += a[0]; f[1] += a[1]; f[2] += a[2]; f[3] += a[3];
+                f[4] += b[0]; f[5] += b[1]; f[6] += b[2]; f[7] += b[3];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (c0 + j >= fa.C) f[j] = 0.f;        // pad channels stay exact zeros
+            const i32x4 pk = pack8(f);
+            cx[u] = pk;
+            float r[8];
+            unpack8(pk, r);
+#pragma unroll
+            for (int j = 0; j < 8; j++) { v[0][j] += r[j]; v[1][j] += r[j] * r[j]; }
+            const int py = z / fa.ostr, px = z - py * fa.ostr;               // phase -> sub-grid origin (fprop: ostr 1, z 0)
+            const int n = fdiv(m, fa.dHgWg), rr = m - n * (fa.Hg * fa.Wg);
+            const int oy = fdiv(rr, fa.dWg), ox = rr - oy * fa.Wg;
+            const int pix = (n * fa.Hd + oy * fa.ostr + py) * fa.Wd + ox * fa.ostr + px;
+            pixv[u] = pix;
+            *(i32x4*)(fa.raw + (size_t)pix * fa.ldraw + fa.rawoff + c0) = pk;
+        }
+    }
+    grid_exchange(ga, v, smem_d, red, tot, s, dom, cnt, epoch, t, lane, wave, ch);
+    __syncthreads();              // `red` is read by other threads until here; it now receives the coefficients
+    for (int cl = t; cl < ga.CHg * 8; cl += 256) {
+        const int chunk = cl >> 3, j = cl & 7;
+        const int c = cg * ga.CHg * 8 + cl;
+        const double m = tot[chunk * 16 + j] / fa.count;
+        double var = tot[chunk * 16 + 8 + j] / fa.count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float r = (float)(1.0 / sqrt(var + (double)fa.eps));
+        const bool ok = c < fa.C;
+        const float gam = (ok && fa.gamma) ? fa.gamma[c] : 1.f, bet = (ok && fa.beta) ? fa.beta[c] : 0.f;
+        const float sc = gam * r, sf = bet - (float)m * gam * r;
+        red[chunk * 16 + j] = sc; red[chunk * 16 + 8 + j] = sf;
+        if (s == 0 && ok) {
+            if (fa.mean) fa.mean[c] = (float)m;
+            if (fa.rstd) fa.rstd[c] = r;
+            fa.scale[c] = sc; fa.shift[c] = sf;
+            if (fa.running_mean) fa.running_mean[c] = (1.f - fa.momentum) * fa.running_mean[c] + fa.momentum * (float)m;
+            if (fa.running_var) {
+                const double unb = fa.count > 1.0 ? var * fa.count / (fa.count - 1.0) : var;
+                fa.running_var[c] = (1.f - fa.momentum) * fa.running_var[c] + fa.momentum * (float)unb;
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    float sc[8], sf[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { sc[j] = red[ch * 16 + j]; sf[j] = red[ch * 16 + 8 + j]; }
+    const float keep_scale = fa.drop_p > 0.f ? 1.f / (1.f - fa.drop_p) : 1.f;
+#pragma unroll
+    for (int u = 0; u < PPT; u++) {
+        const int pix = pixv[u];
+        if (pix < 0) continue;
+        float f[8], o1[8], o2[8];
+        unpack8(cx[u], f);
+#pragma unroll
+        for (int j = 0; j < 8; j++) f[j] = f[j] * sc[j] + sf[j];
+        if (fa.drop_p > 0.f) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float uu = rng_uniform(fa.seed, (size_t)pix * (size_t)fa.C + c0 + j);
+                f[j] = uu >= fa.drop_p ? f[j] * keep_scale : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (c0 + j >= fa.C) f[j] = 0.f;
+        apply_act8(f, o1, fa.act, fa.slope);
+        if (fa.y) *(i32x4*)(fa.y + (size_t)pix * fa.ldy + fa.yoff + c0) = pack8(o1);
+        if (fa.y2) {
+            apply_act8(f, o2, fa.act2, fa.slope);
+            *(i32x4*)(fa.y2 + (size_t)pix * fa.ldy2 + fa.y2off + c0) = pack8(o2);
+        }
+    }
 }
 
 constexpr size_t INORM_WS_HEADER = 4096;           // [N * CG <= 256][4] counter words in front of the totals and the partials
@@ -1377,10 +1586,11 @@ static void inorm_ws_scrub(void* ws, size_t bytes, hipStream_t st) {
 }
 
 // returns true when the grid form ran (need_grid: the caller has no other route -- nothing is launched otherwise)
-template <bool BWD>
+template <bool BWD, int EXT = 0>
 bool inorm_launch(const InFusedArgs& a, int N, hipStream_t st, void* ws, size_t ws_bytes, bool need_grid = false) {
     InGridArgs ga;
-    if (ws && ws_bytes >= INORM_WS_HEADER + 16384 && gcc_opt(GCC_OPT_INORM_GRID) && inorm_grid_plan(a.C, a.HW, N, BWD ? 4 : 8, ws_bytes, &ga)) {
+    if (ws && ws_bytes >= INORM_WS_HEADER + 16384 && gcc_opt(GCC_OPT_INORM_GRID) &&
+        inorm_grid_plan(a.C, a.HW, N, BWD ? (EXT ? 2 : 4) : 8, ws_bytes, &ga)) {
         ga.a = a;
         ga.cnt = (unsigned*)ws;
         ga.partial = (float*)((char*)ws + INORM_WS_HEADER);
@@ -1391,10 +1601,10 @@ bool inorm_launch(const InFusedArgs& a, int N, hipStream_t st, void* ws, size_t 
         ga.spin_limit = (dbg & 64) ? 256 : (1 << 20);
         ga.mute = (dbg & 64) ? 1 : 0;
         if (ga.S > 1) inorm_ws_scrub(ws, ws_bytes - ((dbg & 32) ? 16384 : 0), st);
-        hipLaunchKernelGGL((inorm_grid_kernel<BWD>), dim3(ga.S, ga.CG, N), dim3(256), 0, st, ga);
+        hipLaunchKernelGGL((inorm_grid_kernel<BWD, EXT>), dim3(ga.S, ga.CG, N), dim3(256), 0, st, ga);
         return true;
     }
-    if (need_grid) return false;
+    if (need_grid || EXT) return false;
     const int lpp_env = gcc_opt(GCC_OPT_INORM_LPP);
     const int lpp = lpp_env ? lpp_env : 2;
     const int slabs = ((a.C + 7) / 8 + lpp - 1) / lpp;
@@ -1411,6 +1621,49 @@ bool inorm_launch(const InFusedArgs& a, int N, hipStream_t st, void* ws, size_t 
 #undef GCC_IN_LAUNCH
     return false;
 }
+
+}  // namespace
+int gcc_internal_bn_fold_grid(const BnFoldDesc* d, hipStream_t st) {
+    if (!d || !d->part || !d->raw || !d->ws || d->ws_bytes < INORM_WS_HEADER + 16384 || !d->bn.scale || !d->bn.shift) return GCC_ERR_BAD_ARG;
+    if (gcc_device_error(0)) return GCC_ERR_LAUNCH;
+    if (!gcc_opt(GCC_OPT_INORM_GRID)) return GCC_ERR_UNSUPPORTED;
+    FoldGridArgs fa = {};
+    const int st_ = d->dgrad ? d->stride : 1;
+    if (d->dgrad && ((d->Hd % st_) || (d->Wd % st_))) return GCC_ERR_UNSUPPORTED;        // phases of different sizes: the other route
+    fa.ostr = st_; fa.Hd = d->Hd; fa.Wd = d->Wd; fa.Hg = d->Hd / st_; fa.Wg = d->Wd / st_;
+    fa.phases = d->phases; fa.Mph = d->N * fa.Hg * fa.Wg; fa.Rt = fa.phases * fa.Mph;
+    if (fa.phases != st_ * st_ || fa.Mph > d->rows_max || (size_t)d->N * d->Hd * d->Wd >= ((size_t)1 << 31) / (size_t)(d->C > 0 ? d->C : 1))
+        return GCC_ERR_UNSUPPORTED;
+    InGridArgs& ga = fa.g;
+    if (!inorm_grid_plan(d->C, fa.Rt, 1, 1, d->ws_bytes, &ga)) return GCC_ERR_UNSUPPORTED;
+    const int PL = 256 / ga.CHP;
+    const int ppt = (ga.rows + PL - 1) / PL;
+    if (ppt > 4) return GCC_ERR_UNSUPPORTED;
+    ga.cnt = (unsigned*)d->ws;
+    ga.partial = (float*)((char*)d->ws + INORM_WS_HEADER);
+    ga.level2 = (float*)((char*)d->ws + INORM_WS_HEADER + (size_t)ga.CG * ga.S * ga.V * 8);
+    const int dbg = gcc_opt(GCC_OPT_DEBUG);
+    ga.clk = nullptr;
+    ga.err = gcc_device_error_word();
+    ga.spin_limit = (dbg & 64) ? 256 : (1 << 20);
+    ga.mute = (dbg & 64) ? 1 : 0;
+    fa.part = d->part; fa.ksplit = d->ksplit; fa.rows_max = d->rows_max; fa.Cpad = d->Cpad;
+    fa.dMph = make_fastdiv(fa.Mph); fa.dHgWg = make_fastdiv(fa.Hg * fa.Wg); fa.dWg = make_fastdiv(fa.Wg);
+    fa.raw = (bf16_t*)d->raw; fa.ldraw = d->ldraw; fa.rawoff = d->rawoff;
+    fa.y = (bf16_t*)d->y; fa.ldy = d->ldy; fa.yoff = d->yoff; fa.y2 = (bf16_t*)d->y2; fa.ldy2 = d->ldy2; fa.y2off = d->y2off;
+    fa.C = d->C; fa.count = d->bn.count; fa.gamma = d->bn.gamma; fa.beta = d->bn.beta; fa.eps = d->bn.eps; fa.momentum = d->bn.momentum;
+    fa.running_mean = d->bn.running_mean; fa.running_var = d->bn.running_var; fa.mean = d->bn.mean; fa.rstd = d->bn.rstd;
+    fa.scale = d->bn.scale; fa.shift = d->bn.shift;
+    fa.act = d->act; fa.act2 = d->act2; fa.slope = d->slope; fa.drop_p = d->drop_p; fa.seed = d->seed;
+    if (ga.S > 1) inorm_ws_scrub(d->ws, d->ws_bytes, st);
+    const dim3 grid(ga.S, ga.CG, 1);
+    if (ppt <= 1) hipLaunchKernelGGL((bn_fold_grid_kernel<1>), grid, dim3(256), 0, st, fa);
+    else if (ppt == 2) hipLaunchKernelGGL((bn_fold_grid_kernel<2>), grid, dim3(256), 0, st, fa);
+    else hipLaunchKernelGGL((bn_fold_grid_kernel<4>), grid, dim3(256), 0, st, fa);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+namespace {
 
 struct SumArgs {
     const bf16_t* x; int ld, off; int C, C8; size_t pixels; Layout L; float* partial;
@@ -1634,6 +1887,35 @@ extern "C" int gcc_bn_bwd_one_launch(const void* x, int ldx, const void* y, int 
     // only the grid form knows gamma / dgamma / dbeta: with GCC_OPT_INORM_GRID = 0, or a geometry its plan refuses, nothing is
     // launched and the caller keeps its three-launch route (the slab kernels would have ignored them silently)
     if (!inorm_launch<true>(a, 1, (hipStream_t)stream, workspace, workspace_bytes, true)) return GCC_ERR_UNSUPPORTED;
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+// The same with what the U-Net's layers need (round 4): y NULL with an activation -- its input is recomputed through the forward's
+// affine (scale / shift of the BNState) and the regenerated dropout mask --, a second incoming gradient g2 through act2 (the skip
+// path), dropout.  One launch instead of reduce + finalize + apply, also for small tensors (bnact_bwd_small_kernel's C / 8
+// workgroups took 10-38 us on the <= 16x16 layers).
+extern "C" int gcc_bn_bwd_one_launch_ex(const void* x, int ldx, const void* y, int ldy, const void* g, int ldg, const void* g2, int ldg2,
+                                        void* dx, int lddx, int C, size_t pixels, int act, int act2, float slope, float drop_p,
+                                        unsigned long long seed, const float* mean, const float* rstd, const float* scale,
+                                        const float* shift, const float* gamma, float* dgamma, float* dbeta, void* workspace,
+                                        size_t workspace_bytes, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (gcc_device_error(0)) return GCC_ERR_LAUNCH;
+    if (!x || !g || !dx || !mean || !rstd || C <= 0 || pixels == 0 || pixels > (size_t)1 << 30 || (ldx & 7) || (ldg & 7) ||
+        (lddx & 7) || (y && (ldy & 7)) || (g2 && (ldg2 & 7)))
+        return GCC_ERR_BAD_ARG;
+    if (!y && act != GCC_ACT_NONE && (!scale || !shift)) return GCC_ERR_BAD_ARG;
+    if (pixels * (size_t)C >= (size_t)1 << 40) return GCC_ERR_UNSUPPORTED;
+    InFusedArgs a = {};
+    a.x = (const bf16_t*)x; a.ldx = ldx; a.y = (const bf16_t*)y; a.ldy = ldy; a.aux = (const bf16_t*)g; a.ldaux = ldg;
+    a.out = (bf16_t*)dx; a.ldout = lddx; a.C = C; a.HW = (int)pixels; a.act = act; a.slope = slope;
+    a.mean = (float*)mean; a.rstd = (float*)rstd; a.gamma = gamma; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.bscale = y ? nullptr : scale; a.bshift = y ? nullptr : shift;
+    a.g2 = (const bf16_t*)g2; a.ldg2 = ldg2; a.act2 = act2; a.drop_p = drop_p; a.seed = seed;
+    const bool ran = drop_p > 0.f ? inorm_launch<true, 2>(a, 1, (hipStream_t)stream, workspace, workspace_bytes, true)
+                                  : inorm_launch<true, 1>(a, 1, (hipStream_t)stream, workspace, workspace_bytes, true);
+    if (!ran) return GCC_ERR_UNSUPPORTED;
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

@@ -740,7 +740,7 @@ def zeroed_workspace(device, slot, nbytes):
     return ws
 
 
-TAIL_WS_BYTES = 4096 + (4 << 20)      # include/gcc_hip.h: GCC_TAIL_WORKSPACE_BYTES
+TAIL_WS_BYTES = 4096 + (4 << 20) + 4096 + (3 << 19)      # include/gcc_hip.h: GCC_TAIL_WORKSPACE_BYTES
 _tail_ws = {}
 
 
@@ -754,6 +754,7 @@ def tail_workspace(device):
     return ws
 
 
+FOLD_GRID = os.environ.get('GCC_FOLD_GRID', '1') != '0'      # the U-Net's split layers: fold + BatchNorm + activation as one full-chip kernel (GCC_OPT_FUSE_BN 3)
 IN_CONV_FINALIZE = os.environ.get('GCC_IN_CONV_FINALIZE', '1') != '0'      # the conv launch's last-arriving workgroups finalize (0: a gcc_bn_finalize launch; profiles/r4_summary.md)
 
 
@@ -761,11 +762,12 @@ def bn_desc(bn_module, st, count, device, running=True):
     """gcc_bn_t of a training-mode BatchNorm2d application: statistics of `count` pixels, coefficients into the BNState `st`;
     running=False leaves running_mean / running_var alone (a pass that runs ahead of its place: engine.PatchGANEngine)"""
     # (bench.py's bracketed roofline step times every conv launch on its own: no finalize tail inside it there)
-    ws = tail_workspace(device) if (IN_CONV_FINALIZE and not PROFILE.active) else None
+    ws = tail_workspace(device) if ((IN_CONV_FINALIZE or FOLD_GRID) and not PROFILE.active) else None
     return _lib.bn_t(bn_module.weight.data_ptr(), bn_module.bias.data_ptr(), bn_module.eps, bn_module.momentum, float(count),
                      bn_module.running_mean.data_ptr() if running else None, bn_module.running_var.data_ptr() if running else None,
                      st.mean.data_ptr(), st.rstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
-                     ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0)
+                     ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                     1 if (IN_CONV_FINALIZE and ws is not None) else 0, 0)
 
 
 def inorm_workspace(device):
@@ -821,6 +823,9 @@ def bnact_fwd(x, y, y2=None, scale=None, shift=None, gate=None, gate_after_act=F
 
 BN_BWD_TAIL = os.environ.get('GCC_BN_BWD_TAIL', '0') == '1'      # 1: the reduce launch's last-arriving workgroups finalize (measured: profiles/r4_summary.md)
 BN_BWD_GRID = os.environ.get('GCC_BN_BWD_GRID', '1') != '0'
+# gcc_bn_bwd_one_launch_ex (the U-Net's layers): 0 off; 1 (default) tensors of <= BN_BWD_GRID_EX_MAX_PIXELS pixels; 2 every size
+BN_BWD_GRID_EX = int(os.environ.get('GCC_BN_BWD_GRID_EX', '1'))
+BN_BWD_GRID_EX_MAX_PIXELS = int(os.environ.get('GCC_BN_BWD_GRID_EX_MAX_PIXELS', '4096'))
 BN_BWD_GRID_MIN_PIXELS = 4096        # at or below: bnact_bwd_small_kernel (one workgroup per 8 channels) is the one-launch form
 
 
@@ -839,6 +844,20 @@ def bnact_bwd(x, y, g1, dx, g2=None, bn=None, gamma=None, beta=None, bn_eval=Fal
     dxp, _, _, _, _, lddx = geom(dx)
     pixels = N * H * W if groups <= 1 else H * W
     assert groups <= 1 or groups == N
+    if (BN_BWD_GRID_EX and bn is not None and not bn_eval and gate is None and not gate_after_act and dalpha is None
+            and in_act == ACT_NONE and groups <= 1 and not PROFILE.active
+            and (g2 is not None or drop_p > 0.0 or (y is None and act != ACT_NONE) or pixels <= BN_BWD_GRID_MIN_PIXELS)
+            and (BN_BWD_GRID_EX >= 2 or pixels <= BN_BWD_GRID_EX_MAX_PIXELS)):
+        # the U-Net's BatchNorm backward (second gradient of the skip path, dropout, activation input recomputed from the forward's
+        # affine) in ONE launch on the whole chip, small tensors included (round 4; gcc_bn_bwd_one_launch_ex)
+        ws = inorm_workspace(x.device)
+        rc = lib().gcc_bn_bwd_one_launch_ex(xp, ldx, yp, ldy, g1p, ldg1, g2p, ldg2, dxp, lddx, Cc, pixels, act, act2, slope, drop_p, seed,
+                                            bn.mean.data_ptr(), bn.rstd.data_ptr(), bn.scale.data_ptr(), bn.shift.data_ptr(),
+                                            _p(gamma), _p(dgamma), _p(dbeta), ws.data_ptr(), ws.numel(), stream())
+        if rc == 0:
+            return
+        if rc != -2:
+            check(rc, 'gcc_bn_bwd_one_launch_ex')
     if (BN_BWD_GRID and bn is not None and not bn_eval and g2 is None and gate is None and not gate_after_act and drop_p == 0.0
             and dalpha is None and in_act == ACT_NONE and act2 == ACT_NONE and groups <= 1 and (y is not None or act == ACT_NONE)
             and pixels > BN_BWD_GRID_MIN_PIXELS and not PROFILE.active):

@@ -87,7 +87,8 @@ enum {
                                    less CU time per launch, the free CUs run the other streams' kernels (the multi-stream
                                    production schedule: +1 % on the step).  gcc_amd's models switch it with their schedule. */
     GCC_OPT_WGRAD_BIG_MIN_TILES,/* minimum number of 256x256 output tiles for the big weight-gradient tiling (default 32) */
-    GCC_OPT_FUSE_BN,            /* gcc_conv_bn_act: 2: BatchNorm finalized by the last-arriving workgroups of the launch that writes the
+    GCC_OPT_FUSE_BN,            /* gcc_conv_bn_act: 3: a split layer's K slices folded, statistics exchanged inside the launch and rows normalised by
+                                   one kernel on the whole chip (bn_fold_grid_kernel; needs gcc_bn_t.tail_ws; other layers as 1); 2: BatchNorm finalized by the last-arriving workgroups of the launch that writes the
                                    statistic rows (gcc_bn_t.tail_ws), split layers folded by one full-chip kernel; 1: the round-2 form (a split
                                    layer's partials, statistics, finalize and normalise in one kernel of C / 8 workgroups; default: measured faster, profiles/r4_summary.md); 0: separate launches */
     GCC_OPT_BN_BWD_SMALL,       /* 1 (default): gcc_bnact_bwd of <= 4096 pixels (training BatchNorm, no gate) runs as one kernel instead of
@@ -137,6 +138,7 @@ typedef struct {
 
 static inline int gcc_conv_out(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
+#define GCC_INORM_WORKSPACE_BYTES ((size_t)4096 + ((size_t)3 << 19))      /* gcc_inorm_fwd / _bwd, see there */
 /* A BatchNorm2d (training statistics) that follows a convolution: nn.BatchNorm2d at models/Pix2Pix.py:34, 44-64, 286-298,
  * 320-341.  Handed to the conv (gcc_epilogue_t.bn, gcc_conv_bn_act) its coefficients are final when the call returns: where
  * the launch that writes the statistic rows can, its last-arriving workgroups fold them (no gcc_bn_finalize launch on the
@@ -144,7 +146,7 @@ static inline int gcc_conv_out(int in, int k, int stride, int pad) { return (in 
  * zero-filled ONCE by the caller when it is allocated, used by ONE stream (its calls are ordered) and by nothing else; the
  * library leaves its counter words zero after every launch.  tail_ws NULL (or too small for the layer): a gcc_bn_finalize
  * launch inside the call instead. */
-#define GCC_TAIL_WORKSPACE_BYTES ((size_t)4096 + ((size_t)4 << 20))
+#define GCC_TAIL_WORKSPACE_BYTES ((size_t)4096 + ((size_t)4 << 20) + GCC_INORM_WORKSPACE_BYTES)   /* the last part: gcc_conv_bn_act's grid fold kernel */
 typedef struct {
     const float* gamma; const float* beta;          /* [C] */
     float eps, momentum;
@@ -152,6 +154,9 @@ typedef struct {
     float* running_mean; float* running_var;        /* [C] or NULL */
     float* mean; float* rstd; float* scale; float* shift;   /* [C] outputs (saved for the backward pass) */
     void* tail_ws; size_t tail_ws_bytes;            /* see above; may be NULL / 0 */
+    int finalize_in_launch;                         /* 1: the launch that writes the statistic rows may finalize (needs tail_ws); 0: always a
+                                                       gcc_bn_finalize launch (tail_ws then only serves gcc_conv_bn_act's grid fold kernel) */
+    int pad_;
 } gcc_bn_t;
 
 /* fused epilogue of fprop / dgrad: out = act(acc + bias[c]); optional per-tile BatchNorm partial
@@ -273,7 +278,6 @@ int gcc_in_finalize(const float* stats_partial, int tiles_per_group, int groups,
  * plane of an image is split over up to 256 / N workgroups (pixel ranges x 64-channel groups) that meet at an in-launch barrier; without one (NULL) a workgroup
  * owns a whole (image, 16-channel slab).  Workspace contract: GCC_INORM_WORKSPACE_BYTES bytes, zero-filled once by the
  * caller when it is allocated, used by ONE stream (calls on it are ordered) and by nothing else. */
-#define GCC_INORM_WORKSPACE_BYTES ((size_t)4096 + ((size_t)3 << 19))
 int gcc_inorm_fwd(const void* x, int ldx, void* y, int ldy, const void* residual, int ld_residual, int C, int HW, int N,
                   int act, float slope, float eps, float* mean, float* rstd, float* scale, float* shift,
                   void* workspace, size_t workspace_bytes, gcc_stream_t stream);
@@ -290,6 +294,15 @@ int gcc_inorm_bwd(const void* x, int ldx, const void* y, int ldy, const void* g,
 int gcc_bn_bwd_one_launch(const void* x, int ldx, const void* y, int ldy, const void* g, int ldg, void* dx, int lddx, int C,
                           size_t pixels, int act, float slope, const float* mean, const float* rstd, const float* gamma,
                           float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, gcc_stream_t stream);
+/* ... with the pieces the U-Net's layers need (models/Pix2Pix.py:33-64): y NULL with an activation (its input is recomputed through
+ * the forward's affine form `scale` / `shift` and the regenerated dropout mask), a second incoming gradient g2 through act2 (the
+ * skip path: g act'(y) + g2 act2'(y)), Dropout(drop_p) with the (seed, pixel * C + channel) counter of gcc_bnact_fwd.  Any
+ * tensor size; GCC_ERR_UNSUPPORTED as above. */
+int gcc_bn_bwd_one_launch_ex(const void* x, int ldx, const void* y, int ldy, const void* g, int ldg, const void* g2, int ldg2,
+                             void* dx, int lddx, int C, size_t pixels, int act, int act2, float slope, float drop_p,
+                             unsigned long long seed, const float* mean, const float* rstd, const float* scale, const float* shift,
+                             const float* gamma, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                             gcc_stream_t stream);
 int gcc_channel_stats_tiles(size_t pixels_per_group, int C);
 int gcc_channel_stats(const void* x, int ld, int off, int C, size_t pixels_per_group, int groups, float* stats,
                       gcc_stream_t stream);

@@ -231,7 +231,7 @@ def test_struct_layouts_match_header():
     from gcc_amd import _lib
     assert ctypes.sizeof(_lib.conv_t) == 13 * 4
     assert ctypes.sizeof(_lib.epilogue_t) == 80
-    assert ctypes.sizeof(_lib.bn_t) == 96
+    assert ctypes.sizeof(_lib.bn_t) == 104
     assert ctypes.sizeof(_lib.adam_tensor_t) == 48
     assert ctypes.sizeof(_lib.adam_chunk_t) == 16
     assert ctypes.sizeof(_lib.bnact_t) == 72

@@ -239,7 +239,7 @@ def _true_shape_case(ops, name):
     (16, 32, 32, 128, 256, False, 0.0),      # un-split layer: the ordinary three kernels inside the one call
     (2, 16, 16, 64, 128, True, 0.0),
 ])
-@pytest.mark.parametrize('fuse', [2, 1, 0])
+@pytest.mark.parametrize('fuse', [3, 2, 1, 0])
 def test_conv_bn_act_one_call(case, fuse):
     """gcc_conv_bn_act against conv -> BatchNorm2d(train) -> activation in fp32 torch on the bf16-rounded conv output: raw output,
     batch statistics, running statistics, both activated copies; dropout: the mask is the one gcc_bnact_bwd regenerates
@@ -709,11 +709,12 @@ def test_bn_act_gate_forward_backward(C, gate, after, drop):
 @pytest.mark.parametrize('C,N,H,W,drop,noy,two', [(20, 3, 5, 7, 0.0, False, True), (256, 16, 16, 16, 0.0, True, True),
                                                   (64, 16, 8, 8, 0.5, True, False), (512, 16, 2, 2, 0.5, False, True),
                                                   (32, 5, 29, 29, 0.0, True, True)])
-def test_bn_backward_small_tensor_one_launch(C, N, H, W, drop, noy, two):
-    """gcc_bnact_bwd of <= 4096 pixels (the U-Net's <= 16x16 layers at N=16) runs as ONE kernel (GCC_OPT_BN_BWD_SMALL): against
-    fp32 torch autograd and against the three-launch pipeline on the same inputs (dropout mask regenerated from the same
-    counter; y given or recomputed from x; one or two incoming gradients).  The last case (4205 pixels) is above the limit and
-    must take the three-launch path under both settings."""
+def test_bn_backward_small_tensor_one_launch(C, N, H, W, drop, noy, two, monkeypatch):
+    """gcc_bnact_bwd of the U-Net's layers as ONE kernel -- gcc_bn_bwd_one_launch_ex (round 4: the grid kernel on the whole chip,
+    any size) or bnact_bwd_small_kernel (<= 4096 pixels, GCC_OPT_BN_BWD_SMALL) -- against fp32 torch autograd and against the
+    three-launch pipeline on the same inputs (dropout mask regenerated from the same counter; y given or recomputed from x
+    through the forward's affine; one or two incoming gradients).  The last case (4205 pixels) is above the small kernel's limit
+    and must take the three-launch path under both of its settings."""
     ops = _ops()
     from gcc_amd import _lib
     g = torch.Generator().manual_seed(C + H)
@@ -737,19 +738,26 @@ def test_bn_backward_small_tensor_one_launch(C, N, H, W, drop, noy, two):
     loss = (F.leaky_relu(z, 0.2) * g1).sum() + ((F.relu(z) * g2).sum() if two else 0.0)
     loss.backward()
     res = {}
-    for small in (1, 0):
-        prev = ops.lib().gcc_set_option(_lib.OPT_BN_BWD_SMALL, small)
+    for small in (2, 1, 0):         # 2: the extended grid kernel; 1: the small-tensor kernel; 0: three launches
+        monkeypatch.setattr(ops, 'BN_BWD_GRID_EX', 2 if small == 2 else 0)
+        prev = ops.lib().gcc_set_option(_lib.OPT_BN_BWD_SMALL, 1 if small else 0)
         try:
             dgamma, dbeta = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
             dx = ops.new_act(N, C, H, W, DEV)
+            ops.lib().gcc_launch_count(1)
             ops.bnact_bwd(xd, None if noy else y, to_dev(g1), dx, g2=to_dev(g2) if two else None, bn=st, gamma=gamma.to(DEV),
                           beta=beta.to(DEV), act=ops.ACT_LRELU, act2=ops.ACT_RELU, drop_p=drop, seed=77, dgamma=dgamma, dbeta=dbeta)
+            launches = int(ops.lib().gcc_launch_count(1))
             res[small] = (to_cpu(dx), dgamma.cpu(), dbeta.cpu())
         finally:
             ops.lib().gcc_set_option(_lib.OPT_BN_BWD_SMALL, prev)
-        close(res[small][0], xr.grad, tol=2e-2, what='dx (one launch: %d)' % small)
-        close(res[small][1], gr.grad, tol=1e-2, floor=1e-3, what='dgamma (one launch: %d)' % small)
-        close(res[small][2], br.grad, tol=1e-2, floor=1e-3, what='dbeta (one launch: %d)' % small)
+        if small == 2:
+            assert launches == 1, launches
+        close(res[small][0], xr.grad, tol=2e-2, what='dx (route %d)' % small)
+        close(res[small][1], gr.grad, tol=1e-2, floor=1e-3, what='dgamma (route %d)' % small)
+        close(res[small][2], br.grad, tol=1e-2, floor=1e-3, what='dbeta (route %d)' % small)
+    close(res[2][0], res[0][0], tol=1e-2, what='dx, grid kernel against three launches')
+    close(res[2][1], res[0][1], tol=1e-4, floor=1e-4, what='dgamma, grid kernel against three launches')
     # the two paths against each other: same sums up to their order, dz unrounded in the one-launch kernel
     close(res[1][0], res[0][0], tol=1e-2, what='dx, one launch against three')
     close(res[1][1], res[0][1], tol=1e-4, floor=1e-4, what='dgamma, one launch against three')
