@@ -40,14 +40,19 @@ namespace gcc_igemm {
 __device__ unsigned long long g_clock_probe[4096][4];
 #endif
 
-template <int BP, int BC, bool GLDS, bool UT>
+// NS: LDS stages of the k loop.  2: the round-1 loop (one k-step in flight behind the one being multiplied).  3 (round 4; 128-pixel
+// tiles of 32 / 64 columns on the uniform-tap path): two k-steps in flight.  The U-Net's mid layers run these tiles on 256-512
+// workgroups with 8-32 k-steps of 8-16 MFMAs per wave: a k-step was ~0.85 us of which ~0.06 us is matrix work -- the step waits
+// for the loads it issued one step earlier (profiles/r4f_unet_student_chain.txt: d3 27 us for 32 steps).
+template <int BP, int BC, bool GLDS, bool UT, int NS = 2>
 __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams p) {
     using C = Cfg<BP, BC>;
     static_assert(GLDS || BP == 128, "register staging is only kept for the 128-pixel tile");
+    static_assert(NS == 2 || (GLDS && UT && BP == 128 && (BC == 32 || BC == 64)), "deeper loops: uniform-tap 128 x {32, 64} tiles");
     constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                          // pixels  [2][BP][128 B]
-    char* sW = smem + 2 * BP * BK * 2;        // weights [2][BC][128 B]
+    char* sA = smem;                          // pixels  [NS][BP][128 B]
+    char* sW = smem + NS * BP * BK * 2;       // weights [NS][BC][128 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -310,6 +315,44 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
 #ifdef GCC_CLOCK_PROBE
         const unsigned long long pt0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();
 #endif
+        if constexpr (NS > 2) {
+            // NS - 1 k-steps in flight.  LDS-DMA from inline assembly (lds_dma16): through the builtin hipcc would put
+            // s_waitcnt vmcnt(0) in front of the fragment reads of the stage being multiplied (it counts a pending DMA as an LDS
+            // write it cannot prove disjoint) and drain the steps behind it; here the counted wait + barrier below order the data.
+            constexpr int PER_STEP = AI + W_N;                     // DMA instructions per wave and k-step (uniform for BC 32 / 64)
+            static_assert(C::WPW > 0, "every wave stages weights");
+            const i32x4 rsv_src = make_rsrc(srcp, p.src_bytes), rsv_wgt = make_rsrc(wgtp, p.wgt_bytes);
+            const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+            auto issue_n = [&](int stage) {
+#pragma unroll
+                for (int i = 0; i < AI; i++) {
+                    lds_dma16(rsv_src, lds0 + stage * (BP * BK * 2) + (wave * AI + i) * 1024, cur_a[i]);
+                    cur_a[i] += BK * 2;
+                }
+#pragma unroll
+                for (int i = 0; i < W_N; i++) {
+                    lds_dma16(rsv_wgt, lds0 + NS * BP * BK * 2 + stage * (BC * BK * 2) + (wave * WPW + i) * 1024, cur_w[i]);
+                    cur_w[i] += BK * 2;
+                }
+            };
+            load_tap();
+#pragma unroll
+            for (int st = 0; st < NS - 1; st++) { issue_n(st); next_step(); }
+            int stage = 0, fill = NS - 1;                          // stage of step kt; stage the next issue goes to
+            for (int kt = 0; kt < nk; kt++) {
+                // step kt has landed once at most the NS - 2 younger steps are outstanding (vmcnt counts in issue order)
+                if constexpr (NS == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_STEP) : "memory");
+                __syncthreads();                                     // ... for every wave, and everyone left the stage of step kt - 1
+                issue_n(fill);                                       // past the end of K: out-of-range offsets, zero fill, unused
+                next_step();
+                compute(stage);
+                stage = stage + 1 == NS ? 0 : stage + 1;
+                fill = fill + 1 == NS ? 0 : fill + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
         load_tap();
         issue(0);
         next_step();
@@ -395,6 +438,7 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #endif
+        }
 #ifdef GCC_CLOCK_PROBE
         {
             const unsigned long long pt1 = __builtin_amdgcn_s_memtime(), pr1 = __builtin_amdgcn_s_memrealtime();
@@ -695,6 +739,18 @@ int launch(const IgemmParams& p, int phases, int batch, hipStream_t st) {
     dim3 grid(p.mtiles_max * p.ntiles, p.ksplit > 1 ? p.ksplit : batch, phases);
     const bool ut = (p.Ct % BK) == 0;
     bool launched = false;
+    if constexpr (BP == 128 && (BC == 32 || BC == 64)) {
+        // three LDS stages (two k-steps in flight) for the short-tile layers: GCC_OPT_IGEMM_STAGES
+        if (ut && use_glds() && gcc_opt(GCC_OPT_IGEMM_STAGES) >= 3 && !(p.debug & 14)) {
+            constexpr int LDS3 = 3 * (BP + BC) * BK * 2 > C::LDS_BYTES_EPI ? 3 * (BP + BC) * BK * 2 : C::LDS_BYTES_EPI;
+            static std::once_flag attr3;
+            std::call_once(attr3, [] {
+                hipFuncSetAttribute((const void*)igemm_kernel<BP, BC, true, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
+            });
+            hipLaunchKernelGGL((igemm_kernel<BP, BC, true, true, 3>), grid, dim3(C::NT), LDS3, st, p);
+            launched = true;
+        }
+    }
     if constexpr (BP == 128) {
         if (!use_glds()) {
             hipLaunchKernelGGL((igemm_kernel<BP, BC, false, false>), grid, dim3(C::NT), C::LDS_BYTES, st, p);

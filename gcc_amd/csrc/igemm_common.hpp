@@ -54,9 +54,10 @@ __device__ __forceinline__ void stats_tail(const TailFin& f, const float* stats,
     for (int idx = tid; idx < 2 * Cout; idx += NT) {
         const int w = idx >= Cout ? 1 : 0, c = idx - w * Cout;
         float v[FIN_GROUP];
+        // (unconditional loads, rows past the group clamped: a `r < nr ? load : 0` compiles to sixteen branches with a wait each)
 #pragma unroll
         for (int r = 0; r < FIN_GROUP; r++)
-            v[r] = r < nr ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_st, (((g * FIN_GROUP + r) * 2 + w) * Cout + c) * 4, 0, 16)) : 0.f;
+            v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_st, (((g * FIN_GROUP + (r < nr ? r : nr - 1)) * 2 + w) * Cout + c) * 4, 0, 16));
         double sum = 0.0;
 #pragma unroll
         for (int r = 0; r < FIN_GROUP; r++)

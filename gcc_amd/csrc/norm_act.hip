@@ -299,8 +299,8 @@ __device__ __forceinline__ void bwd_tail(const BwdArgs& a, int* sh) {
     for (int idx = tid; idx < W; idx += NT) {
         float v[FIN_GROUP];
 #pragma unroll
-        for (int r = 0; r < FIN_GROUP; r++)
-            v[r] = r < nr ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_pt, ((g * FIN_GROUP + r) * W + idx) * 4, 0, 16)) : 0.f;
+        for (int r = 0; r < FIN_GROUP; r++)         // unconditional, clamped: conditional loads compile to a branch and a wait each
+            v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_pt, ((g * FIN_GROUP + (r < nr ? r : nr - 1)) * W + idx) * 4, 0, 16));
         double sum = 0.0;
 #pragma unroll
         for (int r = 0; r < FIN_GROUP; r++)
@@ -509,6 +509,50 @@ __global__ __launch_bounds__(NTH) void bnact_bwd_reduce_kernel(const BwdArgs a0)
         __syncthreads();
     }
     if (a.tickets) bwd_tail<NTH>(a, (int*)&red[0][0]);
+}
+
+// Plain activation backward (no normalisation, gate, dropout or parameter gradient): dx = (g1 act'(y) + g2 act2'(y)) in_act'(x),
+// one streaming launch -- the tanh of the generator's image, the ReLU fused into the innermost down conv, the U-Net's first skip
+// (LeakyReLU / ReLU pair).  These went through the reduce pass (per-block sums nobody reads) + the finalize launch: 27 + 5 us for
+// the 16.8 MB image gradient against ~8 us of HBM time (profiles/r4f_unet_student_chain.txt).
+__global__ __launch_bounds__(256) void act_bwd_kernel(const BwdArgs a) {
+    const int ch = threadIdx.x & (a.L.CHP - 1);
+    const int pl = threadIdx.x >> a.L.sh;
+    if (ch >= a.L.CH) return;
+    const int c0 = ch * 8;
+    const size_t pstep = (size_t)gridDim.x * a.L.PPB;
+    for (size_t pix = (size_t)blockIdx.x * a.L.PPB + pl; pix < a.pixels; pix += 2 * pstep) {
+        // two pixels (up to eight 16-byte loads) in flight per lane
+        const size_t p2 = pix + pstep;
+        const bool two = p2 < a.pixels;
+        i32x4 rx[2], ry[2], rg1[2], rg2[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const size_t q = u ? p2 : pix;
+            if (u && !two) break;
+            rx[u] = *(const i32x4*)(a.x + q * a.ldx + a.xoff + c0);
+            rg1[u] = *(const i32x4*)(a.g1 + q * a.ldg1 + a.g1off + c0);
+            if (a.y) ry[u] = *(const i32x4*)(a.y + q * a.ldy + a.yoff + c0);
+            if (a.g2) rg2[u] = *(const i32x4*)(a.g2 + q * a.ldg2 + a.g2off + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (u && !two) break;
+            const size_t q = u ? p2 : pix;
+            float xv[8], yv[8], g1v[8], g2v[8], o[8];
+            unpack8(rx[u], xv); unpack8(rg1[u], g1v);
+            if (a.y) unpack8(ry[u], yv);
+            if (a.g2) unpack8(rg2[u], g2v);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float yo = a.y ? yv[j] : xv[j];
+                float d = g1v[j] * act_grad_from_out(yo, a.p.act, a.p.slope);
+                if (a.g2) d += g2v[j] * act_grad_from_out(yo, a.p.act2, a.p.slope);
+                o[j] = d * act_grad_from_out(xv[j], a.in_act, a.in_slope);
+            }
+            *(i32x4*)(a.dx + q * a.lddx + a.dxoff + c0) = pack8(o);
+        }
+    }
 }
 
 // pass 2: totals over blocks; parameter gradients (+=)
@@ -1699,10 +1743,29 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const SumArgs a) {
             for (int j = 0; j < 8; j++) s[j] += v[j];
         }
     }
+    // fold the pixel lanes: first the lanes of a wave that hold the same chunk (shuffles), then the four waves through LDS.
+    // (One thread per chunk walking all PPB lanes was a chain of up to 256 x 8 dependent LDS reads: with 3 channels -- CHP 1,
+    // PPB 256 -- that fold was 25 of this kernel's 32 us on the generator's image gradient, profiles/r4h_unet_student_chain.txt.)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (a.L.CHP < 64) {
+        for (int o = 32; o >= a.L.CHP; o >>= 1) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) red[threadIdx.x][j] = s[j];
+            for (int j = 0; j < 8; j++) s[j] += __shfl_xor(s[j], o, 64);
+        }
+    }
+    const int per_wave = a.L.CHP < 64 ? a.L.CHP : 64;          // chunks a wave holds one sum of
+    if (lane < per_wave) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) red[wave * 64 + lane][j] = s[j];
+    }
     __syncthreads();
-    if (pl == 0 && active) {
+    if (a.L.CHP <= 64) {
+        if (threadIdx.x < a.L.CHP && active) {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                a.partial[(size_t)blockIdx.x * a.C8 + c0 + j] = (red[ch][j] + red[64 + ch][j]) + (red[128 + ch][j] + red[192 + ch][j]);
+        }
+    } else if (pl == 0 && active) {                            // 65 .. 256 chunks: PPB <= 2 pixel lanes, each wave holds other chunks
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             float t = 0.f;
@@ -2035,6 +2098,11 @@ extern "C" int gcc_bnact_bwd_ex(const gcc_bnact_bwd_t* p, int in_act, float in_s
     hipStream_t st = (hipStream_t)stream;
     const bool gate = p->gate != nullptr || p->dalpha != nullptr || p->gate_after_act;
     const bool drop = p->drop_p > 0.f;
+    if (!p->bn && !gate && !drop && !p->dgamma && !p->dbeta && groups == 1 && gcc_opt(GCC_OPT_BN_BWD_SMALL)) {
+        hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_blocks(pixels, a.L, 4)), dim3(256), 0, st, a);
+        GCC_CHECK_LAUNCH();
+        return GCC_OK;
+    }
     if (p->bn && !p->bn_eval && !gate && groups == 1 && pixels <= SMALL_MAX_PIXELS && gcc_opt(GCC_OPT_BN_BWD_SMALL)) {
         if (drop) hipLaunchKernelGGL(bnact_bwd_small_kernel<true>, dim3(a.C8 / 8), dim3(SMALL_NT), 0, st, a);
         else hipLaunchKernelGGL(bnact_bwd_small_kernel<false>, dim3(a.C8 / 8), dim3(SMALL_NT), 0, st, a);

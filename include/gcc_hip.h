@@ -107,6 +107,8 @@ enum {
                                    to be routed (GCC_OPT_IGEMM_BIG_MIN), else 128; 1: also 128 where 256-column tiles would cover less
                                    than 3/4 of the chip (PatchGAN L3 forward, L4 data gradient: 128 workgroups) -- the plan for a launch
                                    that has the chip to itself, set by the models with GCC_OPT_IGEMM_PAIR; 128 / 256: forced (tests, A/B) */
+    GCC_OPT_IGEMM_STAGES,       /* 3 (default): the 128-pixel x 32 / 64-column tiles (uniform taps) keep two k-steps of LDS-DMA in flight behind
+                                   the one being multiplied (three LDS stages); 2: one (the round-1 loop) */
     GCC_OPT_DEBUG,              /* 0 (default).  Diagnostic ablations for timing only -- RESULTS ARE WRONG when set: bit 1 (2) the main loops issue
                                    no staging loads after the first step, bit 2 (4) they re-load the first step's addresses, bit 5 (32)
                                    s_memrealtime stamps of the grid InstanceNorm, bit 6 (64) its exchange is made to time out (256 polls,

@@ -75,6 +75,10 @@ CONV_CASES = [
     (3, 20, 28, 5, 56, 4, 2, 1),       # thin-output data gradient: ragged pair tiles (Wo = 14), 56 channels in
     (2, 36, 36, 3, 40, 4, 2, 1),       # thin-output data gradient: two pair tiles per row, 40 channels in
     (4, 33, 33, 264, 520, 4, 1, 1),    # wgrad 256x256 tiles: ragged columns (4224) and output channels (520), 4 pixel splits
+    (4, 32, 32, 64, 64, 4, 2, 1),      # 128 x 64 tiles on the uniform-tap path: the three-stage k loop (fprop and dgrad), 16 / 4 k-steps
+    (4, 32, 32, 128, 32, 4, 2, 1),     # 128 x 32 tiles, three stages, 32 k-steps
+    (3, 20, 36, 64, 48, 4, 2, 1),      # ... with ragged pixel tiles and a channel tail
+    (2, 8, 8, 64, 64, 1, 1, 0),        # a single k-step under the three-stage loop (1x1)
 ]
 
 
