@@ -190,6 +190,31 @@ def allreduce_table(model, device, reps=5):
     return out
 
 
+def loss_check_step1(first, batch, world, rel=2e-2):
+    """The losses of the very first iteration (seeded weights, seeded synthetic batch, counter-RNG dropout: the same numbers on
+    every run of an unchanged tree) against the committed values of tests/golden/bench_step1_losses.json -- a changed
+    kernel that shifts the arithmetic shows up here, on the bench's own full-size workload.  World 1 only: with more
+    ranks the architecture step of iteration 1 already runs on all-reduced weights."""
+    if first is None:
+        return None
+    out = {'values': {k: round(v, 5) for k, v in first.items()}}
+    path = os.path.join(ROOT, 'tests', 'golden', 'bench_step1_losses.json')
+    if world != 1 or not os.path.exists(path):
+        out['reference'] = None
+        return out
+    with open(path) as fh:
+        ref = json.load(fh).get('batch%d' % batch)
+    if ref is None:
+        out['reference'] = None
+        return out
+    dev = {k: abs(first[k] - ref[k]) / max(abs(ref[k]), 1e-3) for k in ref if k in first}
+    out.update({'reference': 'tests/golden/bench_step1_losses.json', 'max_rel_dev': round(max(dev.values()), 6),
+                'tolerance': rel, 'ok': bool(max(dev.values()) <= rel and set(ref) <= set(first))})
+    if not out['ok']:
+        log('WARNING: first-iteration losses differ from the committed values: %s' % dev)
+    return out
+
+
 def generator_block(tag_stats, batch):
     """north_star's sub-figure: MFMA utilisation of the generator forward + backward at batch 16.  From the bracketed step:
     conv_* = the generator's fprop / dgrad / wgrad launches alone (algorithmic FLOP / sum of their durations); pass_* = the
@@ -222,6 +247,8 @@ OTHER_ARGV = {
     'sagan': (64, ['--dataroot', 'synthetic', '--model', 'sagan', '--ngf', '48', '--ndf', '64', '--teacher_ngf', '64',
                    '--crop_size', '64', '--gan_mode', 'hinge']),
     'srgan': (16, ['--dataroot', 'synthetic', '--model', 'srgan', '--ngf', '24', '--teacher_ngf', '64', '--image_size', '96']),
+    # BASELINE.json config 5 at its literal size: x4 96 x 96 -> 384 x 384 (16 times the pixels of the training crop above)
+    'srgan_96_to_384': (16, ['--dataroot', 'synthetic', '--model', 'srgan', '--ngf', '24', '--teacher_ngf', '64', '--image_size', '384']),
 }
 
 
@@ -267,6 +294,24 @@ def other_configs(warmup=10, steps=30):
             launches = ops.lib().gcc_launch_count(1) / steps
             out[which] = {'batch': batch, 'ms_per_step': round(ms, 3), 'images_per_s': round(batch / ms * 1e3, 1),
                           'launches_per_step': round(launches)}
+            # roofline of the iteration: the FLOP of its MFMA conv launches (counted by one bracketed step on one stream)
+            # over the eager and the replayed step time, against the dense bf16 peak; the conv roofline beside it
+            try:
+                torch.cuda.synchronize()
+                ops.PROFILE.start(steps=1)
+                step(0)
+                ops.PROFILE.step_done()
+                r = ops.PROFILE.stop()
+                if r is not None:
+                    fl = sum(v['gflop'] for v in r['per_kernel'].values()) * 1e9
+                    out[which]['roofline'] = {
+                        'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': PEAK_BF16 / 1e12,
+                        'conv_gflop_per_step': round(fl / 1e9, 2),
+                        'achieved': round(fl / (ms * 1e-3) / 1e12, 2), 'frac': round(fl / (ms * 1e-3) / PEAK_BF16, 4),
+                        'dominant_kernel': r['kernel'], 'dominant_kernel_frac': r['frac'],
+                        'conv_roofline': r.get('conv_roofline'), 'per_kernel': r['per_kernel']}
+            except Exception as e:
+                out[which]['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
             # the same iteration recorded once and re-issued from native code (gcc_amd.replay; bit-identical results:
             # tests/test_replay_gpu.py): the figure a launch-bound model trains at with GCC_REPLAY=1
             try:
@@ -285,6 +330,9 @@ def other_configs(warmup=10, steps=30):
                 torch.cuda.synchronize()
                 rms = (time.perf_counter() - t0) / steps * 1e3
                 info = rp.info() or {}
+                if 'conv_gflop_per_step' in out[which].get('roofline', {}):
+                    out[which]['roofline']['frac_replayed'] = round(
+                        out[which]['roofline']['conv_gflop_per_step'] * 1e9 / (rms * 1e-3) / PEAK_BF16, 4)
                 out[which]['replay'] = {'ms_per_step': round(rms, 3), 'images_per_s': round(batch / rms * 1e3, 1),
                                         'entries': info.get('entries'), 'host_threads': info.get('threads'),
                                         'streams': info.get('streams')}
@@ -328,11 +376,13 @@ def main():
     train, val = synthetic(args.batch, rank, device)
 
     log('model built on %s (world %d); warm-up %d steps' % (device, world, args.warmup))
+    first_losses = None
     for i in range(args.warmup):
         one_step(model, train, val)
         if i == 0:
             torch.cuda.synchronize()
             log('first step done')
+            first_losses = dict(model.get_current_losses())
     torch.cuda.synchronize()
     log('warm-up done; timing %d steps' % args.steps)
     if world > 1:
@@ -425,6 +475,7 @@ def main():
         'step_tflops': round(FLOP_PER_IMG * args.batch * args.steps / dt / 1e12, 2),
         'step_mfma_frac': round(FLOP_PER_IMG * args.batch * args.steps / dt / PEAK_BF16, 4),
         'loss_check': {k: round(v, 4) for k, v in losses.items()},
+        'loss_check_step1': loss_check_step1(first_losses, args.batch, world),
         'launches_per_step': launches_per_step,
     }
     if roof is not None:

@@ -109,7 +109,7 @@ class _Profile:
         per = {}
         for kind, (fl, sec, n) in agg.items():
             per[kind] = {'launches': n, 'avg_us': round(1e6 * sec / n, 2), 'tflops': round(fl / sec / 1e12, 2),
-                         'time_s': round(sec, 4)}
+                         'time_s': round(sec, 4), 'gflop': round(fl / 1e9, 3)}
             if kind == dom:
                 out = {'bound': 'mfma', 'kernel': kind, 'achieved': round(fl / sec / 1e12, 2), 'peak': peak / 1e12,
                        'unit': 'TFLOP/s', 'frac': round(fl / sec / peak, 4), 'traffic': None, 'launches': n,
