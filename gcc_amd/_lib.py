@@ -70,7 +70,7 @@ class adam_chunk_t(C.Structure):
  OPT_BN_SWEEPS, OPT_BN_MAXBLK, OPT_BN_REDUCE_THREADS, OPT_BN_REDUCE_CAP, OPT_INORM_LPP, OPT_WGRAD_WGS_BIG,
  OPT_WGRAD_WGS, OPT_IGEMM_FORCE_BC, OPT_IGEMM_FORCE_KSPLIT, OPT_IGEMM_NARROW, OPT_IGEMM_PAIR, OPT_WGRAD_BIG_MIN_TILES, OPT_FUSE_BN,
  OPT_BN_BWD_SMALL, OPT_WGRAD_ROW_TABLE, OPT_IGEMM_HALO, OPT_FUSE_BN_PARTIAL_KB, OPT_INORM_GRID, OPT_HALO_HC,
- OPT_IGEMM_STAGES, OPT_DEBUG) = range(28)
+ OPT_IGEMM_STAGES, OPT_WGRAD_TS, OPT_HALO_XCD_COLS, OPT_DEBUG) = range(30)
 
 _P = C.c_void_p
 _I = C.c_int

@@ -48,6 +48,7 @@ struct HaloParams {
     int tiles_x, tiles_y;          // tiles per image
     int ntiles;                    // column tiles
     int nchunks;                   // Ct / 64
+    int xcd_cols;                  // tile order: 1: every XCD owns one column tile (launcher: ntiles divides 8, whole groups of 8 workgroups)
     int PH, PW;                    // positions that exist (mode 3: Ho x Wo of the padded H x W grid; otherwise the whole grid)
     TailFin fin;                   // BatchNorm finalize by the last-arriving workgroups (igemm_common.hpp); tickets NULL: off
 };
@@ -75,8 +76,17 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
     const int lr = lane & 15, lq = lane >> 4;
 
     const int nwg = gridDim.x;
-    const int tile = xcd_remap(blockIdx.x, nwg);
-    const int mt = tile / p.ntiles, nt = tile % p.ntiles;
+    int mt, nt;
+    if (p.xcd_cols) {
+        // one column tile per XCD (GCC_OPT_HALO_XCD_COLS): workgroup b runs on XCD b & 7; the XCD's L2 then streams 1 / ntiles of the
+        // weights (once: its workgroups walk K in step) and the pixel slices are fetched by ntiles XCDs instead of one
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        nt = xcd % p.ntiles;
+        mt = xcd / p.ntiles + (8 / p.ntiles) * idx;
+    } else {
+        const int tile = xcd_remap(blockIdx.x, nwg);
+        mt = tile / p.ntiles; nt = tile % p.ntiles;
+    }
     const int n0 = nt * HC;
     const int tpi = p.tiles_x * p.tiles_y;
     const int img = mt / tpi, trem = mt - img * tpi;
@@ -455,6 +465,12 @@ int launch_halo(const gcc_conv_t* c, int dgrad, const HaloPlan& h, const void* s
         (void)hipFuncSetAttribute((const void*)igemm_halo_kernel<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const dim3 grid((unsigned)(c->N * h.tiles_x * h.tiles_y * h.ntiles), 1, h.phases);
+    {
+        const int mode = gcc_opt(GCC_OPT_HALO_XCD_COLS);       // 1: the stride-1 form (L4: 16.8 MB of weights); 2: every form
+        const unsigned pt = grid.x / h.ntiles;
+        p.xcd_cols = (mode >= 2 || (mode == 1 && h.mode >= 3)) && h.ntiles >= 2 && 8 % h.ntiles == 0 && grid.x % 8 == 0 &&
+                     pt % (8 / h.ntiles) == 0;
+    }
     if (h.hc == 256) {
         if (h.mode >= 3) hipLaunchKernelGGL((igemm_halo_kernel<true, 256>), grid, dim3(512), h.lds, st, p);
         else hipLaunchKernelGGL((igemm_halo_kernel<false, 256>), grid, dim3(512), h.lds, st, p);

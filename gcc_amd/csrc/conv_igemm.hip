@@ -37,7 +37,7 @@ namespace gcc_igemm {
 // Diagnostic build only (scratch/probe_clock.py; never part of libgcc_hip.so): the shader clock the chip holds inside the
 // main loop = d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, 'DVFS give-back' item 6), one stamp pair per
 // workgroup around the k loop.
-__device__ unsigned long long g_clock_probe[4096][4];
+__device__ unsigned long long g_clock_probe[4096][8];
 #endif
 
 // NS: LDS stages of the k loop.  2: the round-1 loop (one k-step in flight behind the one being multiplied).  3 (round 4; 128-pixel
@@ -59,6 +59,9 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA bases stay scalar
     const int wc = wave % C::WC;
     const int wp = wave / C::WC;
+#ifdef GCC_CLOCK_PROBE
+    const unsigned long long pe0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- per-phase geometry -----------------------------------------------------------------
     int py = 0, px = 0, Hg, Wg, sy, TA, TB, dy0, dx0, dstep, kh0, kw0, kstep, ostr;
@@ -446,12 +449,16 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
             if (tid == 0 && b < 4096) {
                 g_clock_probe[b][0] = pt1 - pt0; g_clock_probe[b][1] = pr1 - pr0; g_clock_probe[b][2] = (unsigned long long)nk;
                 g_clock_probe[b][3] = 1;
+                g_clock_probe[b][4] = pe0; g_clock_probe[b][5] = pr0; g_clock_probe[b][6] = pr1;
             }
         }
 #endif
     } else if constexpr (GLDS) {
         // one barrier per k-step: [tile kt landed for every wave AND everyone left tile kt-1] ->
         // issue tile kt+1 into the buffer tile kt-1 occupied -> compute tile kt while it flies
+#ifdef GCC_CLOCK_PROBE
+        const unsigned long long qr0 = __builtin_amdgcn_s_memrealtime();
+#endif
         issue_loads(0);
         for (int kt = 0; kt < nk; kt++) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -461,6 +468,17 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#ifdef GCC_CLOCK_PROBE
+        {
+            const unsigned long long qr1 = __builtin_amdgcn_s_memrealtime();
+            const unsigned b = blockIdx.z * gridDim.x + blockIdx.x;
+            if (tid == 0 && b < 4096) {
+                g_clock_probe[b][0] = 0; g_clock_probe[b][1] = qr1 - qr0; g_clock_probe[b][2] = (unsigned long long)nk;
+                g_clock_probe[b][3] = 1;
+                g_clock_probe[b][4] = pe0; g_clock_probe[b][5] = qr0; g_clock_probe[b][6] = qr1;
+            }
+        }
+#endif
     } else {
         // registers hold tile t+1 while LDS[t&1] is consumed
         issue_loads(0);
@@ -522,6 +540,13 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
         }
     }
     igemm_epilogue<C, BP, BC>(p, acc, smem, tid, lr, lq, wc, wp, m0, n0, M, Hg, Wg, ostr, py, px, mt, ks_idx, dstp);
+#ifdef GCC_CLOCK_PROBE
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned b = blockIdx.z * gridDim.x + blockIdx.x;
+        if (tid == 0 && b < 4096) g_clock_probe[b][7] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 
@@ -1624,10 +1649,10 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
 
 #ifdef GCC_CLOCK_PROBE
 extern "C" int gcc_probe_read(unsigned long long* dst, int clear) {
-    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(gcc_igemm::g_clock_probe), sizeof(unsigned long long) * 4096 * 4);
+    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(gcc_igemm::g_clock_probe), sizeof(unsigned long long) * 4096 * 8);
     if (e == hipSuccess && clear) {
         void* sym = nullptr;
-        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(gcc_igemm::g_clock_probe)) == hipSuccess) e = hipMemset(sym, 0, sizeof(unsigned long long) * 4096 * 4);
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(gcc_igemm::g_clock_probe)) == hipSuccess) e = hipMemset(sym, 0, sizeof(unsigned long long) * 4096 * 8);
     }
     return e == hipSuccess ? 0 : -1;
 }

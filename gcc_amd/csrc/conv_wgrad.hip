@@ -367,6 +367,232 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+
+// ---- tap-stationary weight gradient: k4 s1 p1, channels in multiples of 64 (round 4) ------------------------------------------
+// wgrad_kernel above stages, per 64 pixels, one [64][256] x image PER COLUMN TILE: the 16 taps of a 4x4 stride-1 filter read the
+// same input pixels shifted by (kh, kw), yet every (tap, ci) column block fetches its own copy, and a workgroup moves 64 KB
+// through L2 -> LDS per 512 MFMAs; the L4 weight gradient of the discriminators (512 -> 1024 at 32 x 32, 1.67 ms of the
+// production step) ran at the LDS-DMA rate, not the MFMA rate.  Here the output tile is 64 input channels x 64
+// output channels x ALL 16 taps, and the pixels arrive as 8 x 16 blocks of output positions: one [128][64] dy image and one
+// [11 x 19 halo][64] x image per block; a tap is a row shift (kh * pitch + kw) into the halo image, so the 16 taps share one
+// staged copy -- 49 KB per 1024 MFMAs, 2.6 times fewer bytes per MFMA.  8 waves: wave w owns taps {2w, 2w + 1} (one kh, two
+// kw) of the whole 64 x 64 channel tile.  Three LDS stages, two blocks in flight (counted vmcnt), one barrier per block.
+// Rows are 128 bytes (64 channels); the four 32-byte windows of a row are XOR-swizzled with bits 1-2 of the row number, so the
+// 8 consecutive rows a half-wave touches per transposing read fall on 8 distinct bank groups whatever the tap shift (the
+// halo pitch, 24 rows, is a multiple of 8: kh never changes those bits).
+namespace ts {
+constexpr int TR = 8, TW = 16, PX = TR * TW;       // output positions per block
+constexpr int HP = 24, HW = TW + 3, HR = TR + 3;   // halo pitch (rows of the LDS image per halo line), used width, lines
+constexpr int XROWS = HR * HP;                     // 264
+constexpr int XP = XROWS / 8, YP = PX / 8;         // 1-KiB LDS-DMA pieces: 33 + 16
+constexpr int RSB = 128;                           // bytes per LDS row
+constexpr int Y_BYTES = PX * RSB, X_BYTES = XROWS * RSB;
+constexpr int STAGE = Y_BYTES + X_BYTES;           // 50176
+constexpr int NS = 3;
+constexpr int LDS_BYTES = NS * STAGE;              // 150528: one workgroup per CU
+constexpr int NT = 512;
+}
+
+struct TsParams {
+    const bf16_t* x;
+    const bf16_t* dy;
+    float* out;          // slabs [splits][Co][16 * Ci]
+    float* dw;
+    int N, H, W, ldx, xoff, Ci;
+    int Ho, Wo, ldy, yoff, Co;
+    int ncols;           // 16 * Ci
+    int ci_tiles, co_tiles;
+    int TY, TX;          // blocks per image
+    int blocks, blocks_per_split;
+    uint32_t x_bytes, dy_bytes;
+    FastDiv dT, dTX;
+    int direct, accumulate;
+};
+
+__device__ __forceinline__ bf16x8 ts_frag(const char* a, int off1) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a + off1));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(ts::NT) void wgrad_ts_kernel(const TsParams p) {
+    using namespace ts;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = tile % p.ci_tiles, ot = tile / p.ci_tiles;       // input-channel tile fastest: neighbours share the dy panel
+    const int ci0 = ct * 64, co0 = ot * 64;
+    const int split = blockIdx.z;
+    const int b_begin = split * p.blocks_per_split;
+    int b_end = b_begin + p.blocks_per_split;
+    if (b_end > p.blocks) b_end = p.blocks;
+    const int nb = b_end - b_begin;
+
+    const i32x4 rs_x = make_rsrc(p.x, p.x_bytes);
+    const i32x4 rs_y = make_rsrc(p.dy, p.dy_bytes);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+
+    // LDS-DMA pieces of this wave: dy pieces wave + 8j (j < 2), x pieces wave + 8j (j < 5; piece 32 exists for wave 0 only).
+    // Lane (rsub, pch) of a piece lays down the physical 16-byte chunk pch of row 8 * piece + rsub: it fetches the logical chunk
+    // whose 32-byte window is XORed with bits 1-2 of the row.
+    const int rsub = lane >> 3, pch = lane & 7;
+    int yl[2], ypy[2], ypx[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int row = 8 * (wave + 8 * j) + rsub;
+        const int lch = (((pch >> 1) ^ ((row >> 1) & 3)) << 1) | (pch & 1);
+        ypy[j] = row >> 4; ypx[j] = row & 15;
+        yl[j] = ((ypy[j] * p.Wo + ypx[j]) * p.ldy + p.yoff + co0 + lch * 8) * 2;
+    }
+    int xl[5], xhy[5], xhx[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int row = 8 * (wave + 8 * j) + rsub;
+        const int lch = (((pch >> 1) ^ ((row >> 1) & 3)) << 1) | (pch & 1);
+        xhy[j] = row / HP; xhx[j] = row - xhy[j] * HP;
+        xl[j] = ((xhy[j] * p.W + xhx[j]) * p.ldx + p.xoff + ci0 + lch * 8) * 2;
+        if (xhx[j] >= HW) xhx[j] = 1 << 20;            // the 5 unused rows of a halo line: never inside the image
+    }
+    auto issue = [&](int b, int stage) {                // b: absolute block number (wave-uniform)
+        const int n = fdiv(b, p.dT);
+        const int t = b - n * (p.TY * p.TX);
+        const int ty = fdiv(t, p.dTX);
+        const int Y0 = ty * TR, X0 = (t - ty * p.TX) * TW;
+        const int ybase = ((n * p.Ho + Y0) * p.Wo + X0) * p.ldy * 2;
+        const int xbase = ((n * p.H + Y0 - 1) * p.W + X0 - 1) * p.ldx * 2;
+        const uint32_t d0 = lds0 + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const bool ok = Y0 + ypy[j] < p.Ho && X0 + ypx[j] < p.Wo;
+            lds_dma16(rs_y, d0 + (wave + 8 * j) * 1024, ok ? (uint32_t)(ybase + yl[j]) : OOB);
+        }
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            if (j < 4 || wave == 0) {
+                const bool ok = (unsigned)(Y0 - 1 + xhy[j]) < (unsigned)p.H && (unsigned)(X0 - 1 + xhx[j]) < (unsigned)p.W;
+                lds_dma16(rs_x, d0 + Y_BYTES + (wave + 8 * j) * 1024, ok ? (uint32_t)(xbase + xl[j]) : OOB);
+            }
+        }
+    };
+
+    // fragment addresses (tr_frag's lane pattern: lane (g, i) reads row 4g + (i >> 2) of a 16-row group, 8 bytes at channel
+    // 16t + 4 (i & 3)); the rows of a k-slice are positions (py = 2 ks [+ 1], px = 4g + (i >> 2)) of the block
+    const int g = lane >> 4, li = lane & 15;
+    const int px = 4 * g + (li >> 2);
+    const int kh = wave >> 1, kw0 = 2 * (wave & 1);
+    int ya[4], xa[2][4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        ya[t] = px * RSB + ((t ^ ((px >> 1) & 3)) << 5) + 8 * (li & 3);
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) {
+            const int hrow = kh * HP + px + kw0 + tj;
+            xa[tj][t] = Y_BYTES + hrow * RSB + ((t ^ ((hrow >> 1) & 3)) << 5) + 8 * (li & 3);
+        }
+    }
+
+    f32x4 acc[2][4][4];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nb > 0) {
+        issue(b_begin, 0);
+        if (nb > 1) issue(b_begin + 1, 1);
+        int cur = 0, fill = 2;
+        for (int b = 0; b < nb; b++) {
+            // block b landed (block b + 1 may still fly: 6 pieces of this wave, 7 of wave 0)
+            if (b + 1 < nb) {
+                if (wave == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();                     // ... for every wave, and every wave has left block b - 1: its stage takes b + 2
+            if (b + 2 < nb) issue(b_begin + b + 2, fill);
+            const char* st = smem + cur * STAGE;
+#pragma unroll
+            for (int pp = 0; pp < 2; pp++) {
+                bf16x8 fx[2][8], fy[2][4];
+#pragma unroll
+                for (int k2 = 0; k2 < 2; k2++) {
+                    const int ks = 2 * pp + k2;
+#pragma unroll
+                    for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+                        for (int t = 0; t < 4; t++)
+                            fx[k2][tj * 4 + t] = ts_frag(st + xa[tj][t] + 2 * ks * (HP * RSB), HP * RSB);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) fy[k2][t] = ts_frag(st + ya[t] + 2 * ks * (TW * RSB), TW * RSB);
+                }
+#pragma unroll
+                for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            acc[i >> 2][i & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[k2][i], fy[k2][j], acc[i >> 2][i & 3][j], 0, 0, 0);
+                // slice 1's transposing reads under slice 0's MFMAs (as in wgrad_kernel)
+                __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);
+#pragma unroll
+                for (int r = 0; r < 12; r++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 40, 0);
+            }
+            cur = cur == NS - 1 ? 0 : cur + 1;
+            fill = fill == NS - 1 ? 0 : fill + 1;
+        }
+    }
+
+    // acc[tj][i][j][r] = dW[co0 + 16 j + (lane & 15)][tap 2 wave + tj][ci0 + 16 i + 4 (lane >> 4) + r]
+    float* slab = p.direct ? p.dw : p.out + (size_t)split * p.Co * p.ncols;
+    const bool rmw = p.direct && p.accumulate;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int co = co0 + j * 16 + (lane & 15);
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int col = (2 * wave + tj) * p.Ci + ci0 + i * 16 + 4 * (lane >> 4);
+                f32x4* d = (f32x4*)(slab + (size_t)co * p.ncols + col);
+                f32x4 v = acc[tj][i][j];
+                if (rmw) { const f32x4 o = *d; v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+                *d = v;
+            }
+    }
+}
+
+// the split plan of the tap-stationary route; 0: the geometry (or GCC_OPT_WGRAD_TS) keeps the layer on wgrad_kernel
+int ts_plan(const gcc_conv_t* c, int batch, int* blocks_per_split) {
+    const int mode = gcc_opt(GCC_OPT_WGRAD_TS);
+    if (!mode || batch != 1 || c->KH != 4 || c->KW != 4 || c->stride != 1 || c->pad != 1) return 0;
+    if ((c->Ci & 63) || (c->Co & 63) || c->H < 2 || c->W < 2) return 0;
+    const int Ho = c->H - 1, Wo = c->W - 1;
+    const int blocks = c->N * cdiv(Ho, ts::TR) * cdiv(Wo, ts::TW);
+    const int tiles = (c->Ci / 64) * (c->Co / 64);
+    const int target = gcc_opt(GCC_OPT_WGRAD_WGS_BIG);
+    int splits = tiles >= (target * 25) / 32 ? 1 : cdiv(target, tiles);
+    if (mode == 1) {
+        // worth it where a workgroup streams enough blocks for the three-stage loop, and the tiles alone nearly fill the launch
+        const int max_splits = blocks / 16;
+        if (max_splits < 1 || tiles < 32) return 0;
+        if (splits > max_splits) splits = max_splits;
+    } else if (splits > blocks) {
+        splits = blocks;                                   // 2: forced wherever the geometry fits (tests)
+    }
+    const int per = cdiv(blocks, splits);
+    *blocks_per_split = per;
+    return cdiv(blocks, per);
+}
+
 int plan_splits(const gcc_conv_t* c, int batch, int* ksteps_per_split, bool* big_out = nullptr) {
     const int Ho = gcc_conv_out(c->H, c->KH, c->stride, c->pad), Wo = gcc_conv_out(c->W, c->KW, c->stride, c->pad);
     const long M = (long)c->N * Ho * Wo;
@@ -404,8 +630,10 @@ int plan_splits(const gcc_conv_t* c, int batch, int* ksteps_per_split, bool* big
 
 size_t gcc_internal_wgrad_workspace(const gcc_conv_t* c, int batch) {
     if (!c || c->Ci <= 0 || c->Co <= 0 || batch < 1) return 0;
-    int per;
-    const int splits = plan_splits(c, batch, &per);
+    int per, tper;
+    int splits = plan_splits(c, batch, &per);
+    const int tsplits = ts_plan(c, batch, &tper);          // the tap-stationary route's split count may differ
+    if (tsplits > splits) splits = tsplits;
     return (size_t)splits * batch * c->Co * c->KH * c->KW * ceil8(c->Ci) * sizeof(float);
 }
 
@@ -474,6 +702,40 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
     p.debug = gcc_opt(GCC_OPT_DEBUG);
     {
         p.rowmode = (gcc_opt(GCC_OPT_WGRAD_ROW_TABLE) && c->KH <= 15 && c->KW <= 15) ? 1 : 0;
+    }
+    int tper = 0;
+    const int tsplits = regular ? ts_plan(c, batch, &tper) : 0;
+    if (tsplits > 0) {
+        TsParams t;
+        t.x = p.x; t.dy = p.dy; t.out = (float*)ws; t.dw = dw;
+        t.N = c->N; t.H = c->H; t.W = c->W; t.ldx = c->ldx; t.xoff = c->xoff; t.Ci = c->Ci;
+        t.Ho = Ho; t.Wo = Wo; t.ldy = c->ldy; t.yoff = c->yoff; t.Co = c->Co;
+        t.ncols = p.ncols;
+        t.ci_tiles = c->Ci / 64; t.co_tiles = c->Co / 64;
+        t.TY = cdiv(Ho, ts::TR); t.TX = cdiv(Wo, ts::TW);
+        t.blocks = c->N * t.TY * t.TX; t.blocks_per_split = tper;
+        t.x_bytes = p.x_bytes; t.dy_bytes = p.dy_bytes;
+        t.dT = make_fastdiv(t.TY * t.TX); t.dTX = make_fastdiv(t.TX);
+        t.direct = tsplits == 1 ? 1 : 0; t.accumulate = accumulate;
+        static std::once_flag ts_once;
+        std::call_once(ts_once, [] {
+            hipFuncSetAttribute((const void*)wgrad_ts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ts::LDS_BYTES);
+        });
+        hipLaunchKernelGGL(wgrad_ts_kernel, dim3(t.ci_tiles * t.co_tiles, 1, tsplits), dim3(ts::NT), ts::LDS_BYTES, st, t);
+        GCC_CHECK_LAUNCH();
+        if (t.direct) return GCC_OK;
+        const size_t n4 = (size_t)c->Co * p.ncols / 4;
+        if (tsplits <= 8) {
+            int blocks = (int)((n4 + 255) / 256);
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, tsplits, n4, accumulate);
+        } else {
+            int blocks = (int)((n4 + 63) / 64);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, tsplits, n4, accumulate);
+        }
+        GCC_CHECK_LAUNCH();
+        return GCC_OK;
     }
     const int tcol = big ? 256 : 128;
     p.col_tiles = cdiv(p.ncols, tcol); p.co_tiles = cdiv(c->Co, tcol);

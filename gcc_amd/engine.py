@@ -389,7 +389,7 @@ class UnetEngine:
     def forward(self, N, H, W, train=True):
         """x must already sit in ctx.x_in (use ctx(N,H,W).x_in); returns ctx (ctx.out = tanh image)."""
         tag = getattr(self, 'profile_tag', None)
-        if tag and ops.PROFILE.active:             # bench.py's roofline.generator block
+        if tag and (ops.PROFILE.active or ops.PROFILE.spans_only):             # bench.py's roofline.generator block
             with ops.PROFILE.span(tag + '.fwd'):
                 return self._forward(N, H, W, train)
         return self._forward(N, H, W, train)
@@ -453,7 +453,7 @@ class UnetEngine:
         """c.g_out holds dL/d(out).  g_feat: optional list of 4 gradients w.r.t. features(c).
         Accumulates parameter gradients (wgrad) ; nothing is returned (the input image needs none)."""
         tag = getattr(self, 'profile_tag', None)
-        if tag and ops.PROFILE.active:
+        if tag and (ops.PROFILE.active or ops.PROFILE.spans_only):
             with ops.PROFILE.span(tag + '.bwd'):
                 return self._backward(c, g_feat, wgrad)
         return self._backward(c, g_feat, wgrad)

@@ -21,6 +21,7 @@ class _Profile:
 
     def __init__(self):
         self.active = False
+        self.spans_only = False         # time engine passes (span) of the production path; no launch is bracketed, no route changes
         self.records = []
         self.streaming = os.environ.get('GCC_PROFILE_STREAMING') == '1'     # also bracket the BN backward launches
 
@@ -33,6 +34,22 @@ class _Profile:
         self.active = True
         self.steps_left = steps
         self.steps_seen = 0
+
+    def start_spans(self):
+        """spans alone: the passes run exactly the launches the product path runs (`active` stays False, so no fused route is
+        replaced by its bracketable parts); stop_spans() returns {name: seconds}"""
+        self.spans = []
+        self.tag = None
+        self.spans_only = True
+
+    def stop_spans(self):
+        self.spans_only = False
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1 in self.spans:
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1) * 1e-3
+        self.spans = []
+        return out
 
     def step_done(self):
         if self.active:
@@ -132,7 +149,7 @@ class _Span:
         self.prof, self.name = prof, name
 
     def __enter__(self):
-        if self.prof.active:
+        if self.prof.active or self.prof.spans_only:
             self.prev = self.prof.tag
             self.prof.tag = self.name
             self.e0 = torch.cuda.Event(enable_timing=True)

@@ -109,6 +109,13 @@ enum {
                                    that has the chip to itself, set by the models with GCC_OPT_IGEMM_PAIR; 128 / 256: forced (tests, A/B) */
     GCC_OPT_IGEMM_STAGES,       /* 3 (default): the 128-pixel x 32 / 64-column tiles (uniform taps) keep two k-steps of LDS-DMA in flight behind
                                    the one being multiplied (three LDS stages); 2: one (the round-1 loop) */
+    GCC_OPT_WGRAD_TS,           /* 1 (default): k4 s1 p1 weight gradients with channels in multiples of 64, >= 32 channel tiles and >= 16 pixel
+                                   blocks per split run tap-stationary (wgrad_ts_kernel: the 16 taps share one staged halo image of the input);
+                                   2: wherever the geometry fits (tests); 0: wgrad_kernel only */
+    GCC_OPT_HALO_XCD_COLS,      /* tile order of igemm_halo_kernel: 0: a pixel tile's column tiles are neighbours on one XCD (its L2 fetches the pixel
+                                   slices once, every XCD streams all the weights); 1 (default): the stride-1 form gives every XCD one column tile
+                                   (1 / ntiles of the weights per L2, pixel slices fetched by ntiles XCDs: the L4 forward fetches 108 MB instead of
+                                   152 MB, same duration -- profiles/r4q_halo_xcd_cols.txt); 2: every form */
     GCC_OPT_DEBUG,              /* 0 (default).  Diagnostic ablations for timing only -- RESULTS ARE WRONG when set: bit 1 (2) the main loops issue
                                    no staging loads after the first step, bit 2 (4) they re-load the first step's addresses, bit 5 (32)
                                    s_memrealtime stamps of the grid InstanceNorm, bit 6 (64) its exchange is made to time out (256 polls,

@@ -33,7 +33,7 @@ def run(name, fn, seconds=2.5):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    buf = np.zeros((4096, 4), dtype=np.uint64)
+    buf = np.zeros((4096, 8), dtype=np.uint64)
     lib.gcc_probe_read(buf.ctypes.data, 1)
     t0 = time.time()
     n = 0

@@ -169,6 +169,57 @@ def test_conv_fprop_dgrad_wgrad(case, plan, conv_plan):
     close(dw.cpu(), 2 * wr.grad, tol=5e-3, floor=1e-4, what='wgrad accumulate')
 
 
+# wgrad_ts_kernel (conv_wgrad.hip): the tap-stationary k4 s1 p1 weight gradient.  GCC_OPT_WGRAD_TS = 2 routes every fitting
+# geometry to it; WGS_BIG sets the number of pixel splits (1 = direct write / accumulate into dW, more = slabs + fold).
+TS_CASES = [
+    # N, H, W, Ci, Co, workgroups aimed at
+    (2, 9, 21, 64, 64, 1),          # one channel tile, ragged 8 x 16 blocks (Ho = 8, Wo = 20), no split: direct write
+    (2, 9, 21, 64, 64, 4),          # ... 4 blocks over 4 splits: a single block per workgroup
+    (3, 32, 32, 128, 64, 2),        # 31 x 31 outputs on the 32 x 32 block grid: 24 blocks, one split
+    (3, 32, 32, 128, 64, 12),       # ... 6 splits of 4 blocks (the three-stage loop with its tail)
+    (1, 5, 40, 64, 192, 9),         # short image (one block row of 4 lines), 3 blocks per image
+    (2, 17, 17, 192, 128, 6),       # Ho = Wo = 16: exactly one block wide, two deep
+    (16, 32, 32, 512, 1024, 256),   # the discriminators' L4 at the headline batch (the layer the kernel exists for), 2 splits
+]
+
+
+@pytest.mark.parametrize('case', TS_CASES)
+def test_wgrad_tap_stationary(case):
+    ops = _ops()
+    from gcc_amd import _lib
+    lib = _lib.load()
+    N, H, W, Ci, Co, wgs = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = rb(torch.randn(N, Ci, H, W, generator=g))
+    dy = rb(torch.randn(N, Co, H - 1, W - 1, generator=g))
+    w = torch.zeros(Co, Ci, 4, 4, requires_grad=True)
+    F.conv2d(x, w, None, stride=1, padding=1).backward(dy)
+    xd, dyd = to_dev(x), to_dev(dy)
+    m = master_cl(w.detach())
+    try:
+        lib.gcc_set_option(_lib.OPT_WGRAD_WGS_BIG, wgs)
+        lib.gcc_set_option(_lib.OPT_WGRAD_TS, 2)
+        dw = torch.full_like(m, 7.0)                 # stale contents must not survive a fresh gradient
+        ops.lib().gcc_launch_count(1)
+        ops.conv_wgrad(xd, dyd, dw, 4, 1, 1, accumulate=False)
+        launches = int(ops.lib().gcc_launch_count(1))
+        ops.conv_wgrad(xd, dyd, dw, 4, 1, 1, accumulate=True)
+        torch.cuda.synchronize()
+        lib.gcc_set_option(_lib.OPT_WGRAD_TS, 0)
+        dw0 = torch.zeros_like(m)
+        ops.conv_wgrad(xd, dyd, dw0, 4, 1, 1, accumulate=False)
+        torch.cuda.synchronize()
+    finally:
+        lib.gcc_set_option(_lib.OPT_WGRAD_TS, -1)
+        lib.gcc_set_option(_lib.OPT_WGRAD_WGS_BIG, -1)
+    tiles = (Ci // 64) * (Co // 64)
+    assert launches == (1 if wgs <= tiles else 2), launches      # no split: the kernel alone
+    scale = float(w.grad.abs().max())
+    close(dw.cpu(), 2 * w.grad, tol=5e-3, floor=1e-4 * max(scale, 1.0), what='tap-stationary wgrad (fresh + accumulate)')
+    # against wgrad_kernel on the same operands: fp32 sums of the same bf16 products in another order
+    close(dw.cpu(), 2 * dw0.cpu(), tol=1e-4, floor=1e-5 * max(scale, 1.0), what='tap-stationary vs column-tiled wgrad')
+
+
 # True shapes of the headline configuration (BASELINE.json configs[1]: N = 16 per GPU, ndf 128, teacher ngf 64, 256 x 256) under
 # the DEFAULT plan: what bench.py actually launches (igemm 256x256 / 256x128 tiles, the 256x256 weight-gradient tiles).
 TRUE_SHAPES = {
@@ -1315,9 +1366,16 @@ def test_halo_conv_vs_torch_and_gather_kernel(N, H, W, Ci, Co, stride, hc):
             y, st = ops.conv_fprop(to_dev(x), w, Co, k, stride, p, want_stats=True)
             dx = ops.conv_dgrad(to_dev(dy), wt, Ci, H, W, k, stride, p)
             res[halo] = (to_cpu(y), to_cpu(dx), st.double().sum(0).cpu())
+            if halo:
+                # the other tile order (GCC_OPT_HALO_XCD_COLS: one column tile per XCD): the same tiles on other workgroups, same bits
+                lib.gcc_set_option(_lib.OPT_HALO_XCD_COLS, 2)
+                yb, stb = ops.conv_fprop(to_dev(x), w, Co, k, stride, p, want_stats=True)
+                dxb = ops.conv_dgrad(to_dev(dy), wt, Ci, H, W, k, stride, p)
+                assert torch.equal(yb, y) and torch.equal(dxb, dx) and torch.equal(stb.double().sum(0).cpu(), res[halo][2])
     finally:
         lib.gcc_set_option(_lib.OPT_IGEMM_HALO, prev)
         lib.gcc_set_option(_lib.OPT_HALO_HC, -1)
+        lib.gcc_set_option(_lib.OPT_HALO_XCD_COLS, -1)
     y0, dx0, _ = res[0]
     y2, dx2, st2 = res[2]
     close(y2, ref_y, what='halo fprop vs torch')
