@@ -176,6 +176,7 @@ def allreduce_table(model, device, reps=5):
             total_mb += mb
         return {'buckets': rows, 'total_MB_fp32': round(total_mb, 1), 'total_ms_unoverlapped': round(total_ms, 3)}
     out = {'route': gdist.comm_route(), 'bucketed': getattr(model.optimizer_D, 'reducer', None) is not None,
+           'bucket_dtype_in_step': 'bf16 (GCC_DP_BF16=1)' if gdist.bf16_buckets() else 'fp32',
            'note': 'each bucket alone after the timed region; in the step they overlap the backward pass (dist.GradReducer)',
            'torch': table(lambda buf: dist.all_reduce(buf))}
     # the second table needs the C ABI's communicator: its creation is one more collective (ncclCommInitRank) that has never run

@@ -114,12 +114,43 @@ def comm_route():
     if _route is None:
         _route = 'torch'
         if is_dist() and world_size() > 1 and torch.cuda.is_available() and dist.get_backend() == 'nccl':
+            # the choice is made by all ranks together (a rank that went its own way would leave the others inside a collective):
+            # first everything a rank can find out alone (library loads, RCCL resolves), then the communicator's creation
+            why = None
             try:
-                native_comm()
-                _route = 'native'
-            except Exception as e:          # RCCL missing from the process, communicator creation refused ...
-                _warn('native RCCL communicator unavailable (%s: %s): gradient exchange through torch.distributed' % (type(e).__name__, e))
+                NativeComm.unique_id()
+            except Exception as e:
+                why = '%s: %s' % (type(e).__name__, e)
+            if _all_ranks(why is None):
+                try:
+                    native_comm()
+                except Exception as e:      # communicator creation refused ...
+                    why = '%s: %s' % (type(e).__name__, e)
+                if _all_ranks(why is None):
+                    _route = 'native'
+                else:
+                    _drop_native()
+            if _route != 'native':
+                _warn('native RCCL communicator unavailable (%s): gradient exchange through torch.distributed' % (why or 'on another rank'))
     return _route
+
+
+def _all_ranks(ok):
+    """True when `ok` holds on every rank of the process group"""
+    dev = torch.device('cuda', torch.cuda.current_device()) if (torch.cuda.is_available() and dist.get_backend() == 'nccl') else 'cpu'
+    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item() == 1.0)
+
+
+def _drop_native():
+    global _native
+    if _native is not None:
+        try:
+            _native.close()
+        except Exception:
+            pass
+        _native = None
 
 
 def _warn(msg):
