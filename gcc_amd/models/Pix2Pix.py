@@ -238,6 +238,9 @@ TEACHER_EARLY_DREAL = int(os.environ.get('GCC_TEACHER_EARLY_DREAL', '0'))
 # teacher's backward_G), not at the end of the teacher's iteration: the teacher's generator backward + Adam + repack
 # (small and HBM-bound kernels) then run beside the student's distillation passes instead of in front of them
 EARLY_JOIN = os.environ.get('GCC_EARLY_JOIN', '1') != '0'
+# GCC_DISTILL_FORK (default 1): the distillation terms on the generator's features run on the auxiliary stream beside the
+# teacher discriminator's pass over the student's fake (backward_G's tail): +2.6 % (profiles/r4s_ab_distill_fork.txt)
+DISTILL_FORK = os.environ.get('GCC_DISTILL_FORK', '1') != '0'
 
 
 def _step(gen, stream):
@@ -600,39 +603,69 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             else:
                 ops.wait_stream(ops.current_stream(), ts)
         if self.distill:
-            T = self.teacher_model
-            # teacher D (train mode, frozen) on the student's fake: features for the last two terms (:531-533)
-            ct = T._d_forward('on_student', self._fake)
-            feats = self.G.features(gc) + T.D.features(ct)
-            N = feats[0].shape[0]
-            tf, dtf = [], []
-            for i in range(4):
-                f = feats[i]
-                buf = self._tbuf(i, N, self.T[i].rows, f.shape[2], f.shape[3])
-                self.T[i].forward(f, buf[0])
-                tf.append(buf[0])
-                dtf.append(buf[1])
-            tf += feats[4:]
-            dtf += [self._tbuf(4 + j, N, feats[4 + j].shape[1], feats[4 + j].shape[2], feats[4 + j].shape[3])[1]
-                    for j in range(2)]
-            for i in range(6):
-                f, t = tf[i], self.target_distillation_features[i]
-                ws = self._dws(i, N, f.shape[1], f.shape[2] * f.shape[3])
-                ops.distill_fwd(f, t, self._dist_out[i], ws)
-                ops.distill_bwd(f, t, opt.lambda_gram, opt.lambda_content, dtf[i], ws)
-            g_feat = []
-            for i in range(4):
-                self.T[i].backward_weight(feats[i], dtf[i])
-                gbuf = self._tbuf(10 + i, N, feats[i].shape[1], feats[i].shape[2], feats[i].shape[3])[0]
-                self.T[i].backward_data(dtf[i], gbuf)
-                g_feat.append(gbuf)
-            ops.SideStream.get(self.device).join()
-            if self.optimizer_G.reducer is not None:
-                self.optimizer_G.reducer.segment_done(0)          # the transform convs' gradients (main stream: joined)
-            dx2 = T.D.backward(ct, has_pred_grad=False, g_feat=[dtf[4], dtf[5]], wgrad=False, need_dx=True)
+            aux = self._aux_stream() if DISTILL_FORK else False
+            if aux:
+                # the generator's own terms on the auxiliary stream, beside the teacher discriminator's forward / backward over
+                # the student's fake: this stretch of the step has one busy queue otherwise (GCC_DISTILL_FORK=0: in line).
+                # Forking the whole block earlier -- beside the student's discriminator step -- loses 4.7 %: the step is
+                # chip-bound there (profiles/r4s_ab_distill_fork.txt)
+                ops.wait_stream(aux, ops.current_stream())
+                with ops.on_stream(aux):
+                    g_feat = self._distill_generator_terms(gc)
+            dx2 = self._distill_teacher_d_terms()
+            if not aux:
+                g_feat = self._distill_generator_terms(gc)
+            if aux:
+                ops.wait_stream(ops.current_stream(), aux)
             ops.nhwc_add(dx2, 3, gc.g_out, 0, 3)
             self._mark_teacher_free()
+            if self.optimizer_G.reducer is not None:
+                self.optimizer_G.reducer.segment_done(0)          # the transform convs' gradients (joined above)
         self.G.backward(gc, g_feat=g_feat, wgrad=True)
+
+    def _distill_generator_terms(self, gc):
+        """the four distillation terms on the generator's own features (transform conv, gram / content terms, their gradients
+        back through the transform; models/Pix2Pix.py:520-533): independent of the teacher discriminator's pass over the
+        student's fake.  Returns the gradients w.r.t. the hooked features; runs on the current stream."""
+        opt = self.opt
+        gfe = self.G.features(gc)
+        N = gfe[0].shape[0]
+        tf, dtf = [], []
+        for i in range(4):
+            f = gfe[i]
+            buf = self._tbuf(i, N, self.T[i].rows, f.shape[2], f.shape[3])
+            self.T[i].forward(f, buf[0])
+            tf.append(buf[0])
+            dtf.append(buf[1])
+        for i in range(4):
+            f, t = tf[i], self.target_distillation_features[i]
+            ws = self._dws(i, N, f.shape[1], f.shape[2] * f.shape[3])
+            ops.distill_fwd(f, t, self._dist_out[i], ws)
+            ops.distill_bwd(f, t, opt.lambda_gram, opt.lambda_content, dtf[i], ws)
+        out = []
+        for i in range(4):
+            self.T[i].backward_weight(gfe[i], dtf[i])
+            gbuf = self._tbuf(10 + i, N, gfe[i].shape[1], gfe[i].shape[2], gfe[i].shape[3])[0]
+            self.T[i].backward_data(dtf[i], gbuf)
+            out.append(gbuf)
+        ops.SideStream.get(self.device).join()
+        return out
+
+    def _distill_teacher_d_terms(self):
+        """teacher D (train mode, frozen) on the student's fake, the two terms on its features (:531-533) and their gradient
+        back to the image; returns that gradient's buffer (channels 3.. of the pair).  Runs on the current stream."""
+        opt = self.opt
+        T = self.teacher_model
+        ct = T._d_forward('on_student', self._fake)
+        dfe = T.D.features(ct)
+        N = dfe[0].shape[0]
+        dtd = [self._tbuf(4 + j, N, dfe[j].shape[1], dfe[j].shape[2], dfe[j].shape[3])[1] for j in range(2)]
+        for j in range(2):
+            f, t = dfe[j], self.target_distillation_features[4 + j]
+            ws = self._dws(4 + j, N, f.shape[1], f.shape[2] * f.shape[3])
+            ops.distill_fwd(f, t, self._dist_out[4 + j], ws)
+            ops.distill_bwd(f, t, opt.lambda_gram, opt.lambda_content, dtd[j], ws)
+        return T.D.backward(ct, has_pred_grad=False, g_feat=dtd, wgrad=False, need_dx=True)
 
     def _tbuf(self, i, N, C, H, W):
         key = ('t', i, N, C, H, W)

@@ -20,7 +20,9 @@ Data parallelism: the gradient all-reduces of the C ABI's own communicator (dist
 process group) are recorded like launches and replayed from ONE host thread in the recorded order (the same on every rank);
 with the exchange on torch.distributed step() stays eager.  So does a model class that says `replay_supported = False`:
 Pix2Pix with dropout on (the dropout seeds are by-value launch arguments that nothing patches -- and its iteration is bound by
-its convolutions, not by the host: replayed it measured 16.1 ms against 15.6 eager, `scratch/replay_pix2pix.py`).
+its convolutions, not by the host: the eager host enqueues a step in 5.8 ms and runs ahead of the 15.6 ms the device needs
+(`profiles/r4v_host_enqueue_unblocked.txt`); replayed -- GCC_REPLAY_FORCE=1, timing only -- it measured 17.9 ms,
+`profiles/r4u_replay_pix2pix.txt`).
 """
 import ctypes as C
 import os
@@ -99,8 +101,8 @@ class IterationReplay:
     def usable(self):
         if not self.enabled or not torch.cuda.is_available():
             return False
-        if not getattr(self.model, 'replay_supported', True):
-            return False
+        if not getattr(self.model, 'replay_supported', True) and os.environ.get('GCC_REPLAY_FORCE') != '1':
+            return False            # (GCC_REPLAY_FORCE=1: timing experiments only -- a recording repeats its dropout masks)
         if torch.distributed.is_available() and torch.distributed.is_initialized() and \
                 (torch.distributed.get_world_size() > 1 or os.environ.get('GCC_DP_FORCE_BUCKETS') == '1'):
             # data parallelism: the iteration holds gradient all-reduces.  Through the C ABI's communicator (dist.comm_route()

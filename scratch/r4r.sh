@@ -1,0 +1,5 @@
+#!/usr/bin/env bash
+out=gpurun_out/r4r; mkdir -p $out
+timeout 900 python -m pytest tests/test_pix2pix_gpu.py -q -m gpu -x -p no:cacheprovider 2>&1 | tail -4
+GCC_DISTILL_FORK=1 timeout 900 python -m pytest tests/test_pix2pix_gpu.py -q -m gpu -x -p no:cacheprovider 2>&1 | tail -4
+bash scratch/ab_quick.sh r4r "-" "GCC_DISTILL_FORK=1"

@@ -1,0 +1,4 @@
+#!/usr/bin/env bash
+out=gpurun_out/r4s; mkdir -p $out
+GCC_DISTILL_FORK=2 timeout 900 python -m pytest tests/test_pix2pix_gpu.py -q -m gpu -x -p no:cacheprovider 2>&1 | tail -4
+bash scratch/ab_quick.sh r4s "-" "GCC_DISTILL_FORK=1" "GCC_DISTILL_FORK=2"
