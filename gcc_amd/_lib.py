@@ -174,6 +174,7 @@ PROTOTYPES = {
     'gcc_distill_bwd': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _I, _I, _P, _Z, _P]),
     'gcc_adam_step': (_I, [_P, _P, _I, _I, _F, _F, _F, _F, _I, _P]),
     'gcc_fill_f32': (_I, [_P, _F, _Z, _P]),
+    'gcc_add_f32': (_I, [_P, _P, _Z, _P]),
     'gcc_clamp_f32': (_I, [_P, _F, _F, _Z, _P]),
     'gcc_scalar_op': (_I, [_I, _P, _P, _P, _F, _F, _P, _P]),
     'gcc_comm_unique_id': (_I, [_P]),

@@ -402,6 +402,9 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __rest
 __global__ void fill_kernel(float* p, float v, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
+__global__ void add_f32_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
 __global__ void clamp_kernel(float* p, float lo, float hi, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         p[i] = fminf(fmaxf(p[i], lo), hi);
@@ -873,6 +876,13 @@ extern "C" int gcc_fill_f32(float* p, float v, size_t n, gcc_stream_t stream) {
     GCC_ENTER();
     if (!p || n == 0) return GCC_ERR_BAD_ARG;
     hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, v, n);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+extern "C" int gcc_add_f32(float* dst, const float* src, size_t n, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!dst || !src || n == 0) return GCC_ERR_BAD_ARG;
+    hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

@@ -618,8 +618,8 @@ class PatchGANEngine:
         self.ctx[key] = c
         return c
 
-    def _gbufs(self, N, H, W):
-        key = (N, H, W)
+    def _gbufs(self, N, H, W, slot=0):
+        key = (N, H, W) if slot == 0 else (N, H, W, slot)       # slot: a second set for a backward pass that runs beside another
         if key not in self.gbuf:
             hs = self._sizes(H, W)
             dev = self.device
@@ -632,8 +632,8 @@ class PatchGANEngine:
     def features(self, c):
         return [c.y[1], c.y[3]]
 
-    def grad_pred_buffer(self, c):
-        return self._gbufs(c.N, c.H, c.W).layer[-1]
+    def grad_pred_buffer(self, c, slot=0):
+        return self._gbufs(c.N, c.H, c.W, slot).layer[-1]
 
     # ---------------------------------------------------------------------------------------
     def forward(self, c, train=True, defer_running=False, refresh=True):
@@ -685,12 +685,21 @@ class PatchGANEngine:
             self.bn[li].finalize(stats, n, c.st[li], True)
         c.deferred = []
 
-    def backward(self, c, has_pred_grad=True, g_feat=None, wgrad=True, agrad=False, need_dx=True):
+    def backward(self, c, has_pred_grad=True, g_feat=None, wgrad=True, agrad=False, need_dx=True, gslot=0, dalpha=None):
         """dL/dpred must be in grad_pred_buffer(c) when has_pred_grad; g_feat = optional [g(y1), g(y3)].
         wgrad: accumulate conv/BN parameter gradients; agrad: accumulate alpha gradients.
+        gslot / dalpha: a pass that runs beside another one of this discriminator (the architecture step's second pass, on the
+        auxiliary stream) works in its own gradient buffers and accumulates its alpha gradients into dalpha[layer] instead of
+        alpha.grad (the caller folds them in afterwards, in the reference's order).
         Returns dL/d(x_in) (NHWC bf16, same layout as c.x_in) when need_dx."""
         L = self.L
-        G = self._gbufs(c.N, c.H, c.W)
+        G = self._gbufs(c.N, c.H, c.W, gslot)
+        assert gslot == 0 or not wgrad
+
+        def agrad_of(li):
+            if not agrad or self.gate[li] is None:
+                return None
+            return dalpha[li] if dalpha is not None else self.gate[li].alpha.grad
         if g_feat is None:
             g_feat = [None, None]
         feat_of = {1: g_feat[0], 3: g_feat[1]}
@@ -715,7 +724,7 @@ class PatchGANEngine:
                 ops.bnact_bwd(c.c[li], None, g1, G.layer[li], g2=g2, bn=c.st[li], gamma=bn.weight.data, beta=bn.bias.data,
                               gate=self.mask[li], act=ACT_LRELU, act2=ACT_LRELU, dgamma=bn.weight.grad if wgrad else None,
                               dbeta=bn.bias.grad if wgrad else None,
-                              dalpha=gate.alpha.grad if (agrad and gate is not None) else None)
+                              dalpha=agrad_of(li))
             src = c.g0 if li == 1 else c.y[li - 1]
             if wgrad:
                 self.conv[li].backward_weight(src, G.layer[li])
@@ -726,7 +735,7 @@ class PatchGANEngine:
         # read of the [N, ndf, H/2, W/2] gradient by gcc_channel_sum (67 MB per discriminator pass at ndf 128, 256 x 256, N = 16)
         b0 = self.conv[0].bias
         ops.bnact_bwd(c.a0, None, G.layer[0], G.layer[0], gate=self.mask[0], gate_after_act=True, in_act=ACT_LRELU,
-                      dalpha=gate.alpha.grad if (agrad and gate is not None) else None,
+                      dalpha=agrad_of(0),
                       dbeta=b0.grad if (wgrad and b0 is not None) else None)
         if wgrad:
             self.conv[0].backward_weight(c.x_in, G.layer[0], bias_done=True)

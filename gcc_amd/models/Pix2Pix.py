@@ -241,6 +241,9 @@ EARLY_JOIN = os.environ.get('GCC_EARLY_JOIN', '1') != '0'
 # GCC_DISTILL_FORK (default 1): the distillation terms on the generator's features run on the auxiliary stream beside the
 # teacher discriminator's pass over the student's fake (backward_G's tail): +2.6 % (profiles/r4s_ab_distill_fork.txt)
 DISTILL_FORK = os.environ.get('GCC_DISTILL_FORK', '1') != '0'
+# GCC_ARCH_FORK (default 1): the architecture step's two discriminator backward passes (fake, real) side by side on two
+# streams: +1.9 % (profiles/r4y_ab_arch_fork.txt), same bits (tests/test_replay_gpu.py::test_pix2pix_stream_forks_change_nothing)
+ARCH_FORK = os.environ.get('GCC_ARCH_FORK', '1') != '0'
 
 
 def _step(gen, stream):
@@ -815,9 +818,42 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         ops.gan_loss(mode, cf.pred, True, False, self._l('scratch0'), dpred=gp, weight_dev=self._l('arch_c_fr'))
         ops.gan_loss(mode, cf.pred, False, True, self._l('scratch1'), dpred=gp, weight_dev=self._l('arch_c_f'),
                      dpred_accumulate=True)
+        flat = getattr(self.optimizer_arch, 'flat', None)
+        aux = self._aux_stream() if (ARCH_FORK and flat is not None and isinstance(self.D, engine.PatchGANEngine)) else False
+        if aux:
+            # the two passes are independent up to the sum of their alpha gradients: the pass over the real pair runs on the
+            # auxiliary stream in gradient buffers of its own and accumulates into a zeroed copy of the arch optimizer's flat
+            # gradient, which is added afterwards -- (0 + fake) + (0 + real), the bits of fake-then-real (each layer's sum
+            # arrives in one add: bnact_bwd_finalize)
+            side = self._arch_side_grads(flat)
+            ops.wait_stream(aux, ops.current_stream())
+            with ops.on_stream(aux):
+                ops.fill(side[0], 0.0)
+                gp1 = self.D.grad_pred_buffer(cr, slot=1)
+                ops.gan_loss(mode, cr.pred, True, True, self._l('scratch2'), dpred=gp1, grad_weight=0.5)
+                self.D.backward(cr, wgrad=False, agrad=True, need_dx=False, gslot=1, dalpha=side[1])
+            self.D.backward(cf, wgrad=False, agrad=True, need_dx=False)
+            ops.wait_stream(ops.current_stream(), aux)
+            ops.add_f32_(flat.grads, side[0])
+            return
         self.D.backward(cf, wgrad=False, agrad=True, need_dx=False)
         ops.gan_loss(mode, cr.pred, True, True, self._l('scratch2'), dpred=gp, grad_weight=0.5)
         self.D.backward(cr, wgrad=False, agrad=True, need_dx=False)
+
+    def _arch_side_grads(self, flat):
+        """(buffer shaped like the arch optimizer's flat gradient, {layer: view of it where that layer's alpha.grad sits})"""
+        got = getattr(self, '_arch_side', None)
+        if got is None or got[0].numel() != flat.grads.numel():
+            buf = torch.zeros_like(flat.grads)
+            views = {}
+            for li, gate in enumerate(self.D.gate):
+                if gate is not None:
+                    g = gate.alpha.grad
+                    off = (g.data_ptr() - flat.grads.data_ptr()) // 4
+                    assert 0 <= off and off + g.numel() <= buf.numel() and g.is_contiguous()
+                    views[li] = buf[off:off + g.numel()].view_as(g)
+            got = self._arch_side = (buf, views)
+        return got
 
     def optimizer_netD_arch(self):
         T = self.teacher_model

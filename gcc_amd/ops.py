@@ -1148,6 +1148,11 @@ def fill(t, v):
     check(lib().gcc_fill_f32(t.data_ptr(), float(v), t.numel(), stream()), 'gcc_fill_f32')
 
 
+def add_f32_(dst, src):
+    assert dst.dtype == src.dtype == torch.float32 and dst.numel() == src.numel() and dst.is_contiguous() and src.is_contiguous()
+    check(lib().gcc_add_f32(dst.data_ptr(), src.data_ptr(), dst.numel(), stream()), 'gcc_add_f32')
+
+
 def clamp_(t, lo, hi):
     check(lib().gcc_clamp_f32(t.data_ptr(), float(lo), float(hi), t.numel(), stream()), 'gcc_clamp_f32')
 

@@ -533,6 +533,9 @@ int gcc_scalar_op(int op, const float* a, const float* b, const float* c, float 
                   gcc_stream_t stream);
 int gcc_fill_f32(float* p, float v, size_t n, gcc_stream_t stream);
 int gcc_clamp_f32(float* p, float lo, float hi, size_t n, gcc_stream_t stream);
+/* dst[i] += src[i]: folds a gradient accumulated apart (the architecture step's second discriminator pass, run beside the first
+ * on another stream: models/Pix2Pix.py:496-511 accumulates both into DifferentiableOP.alpha.grad) in the reference's order */
+int gcc_add_f32(float* dst, const float* src, size_t n, gcc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Evaluation arithmetic.  The evaluator networks (Inception, DRN) stay external: these entry

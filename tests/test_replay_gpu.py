@@ -134,6 +134,25 @@ def test_teacher_enqueue_thread_changes_nothing(monkeypatch):
     assert not bad, bad[:8]
 
 
+def test_pix2pix_stream_forks_change_nothing(monkeypatch):
+    """the two stretches of the Pix2Pix step that run independent chains side by side on the auxiliary stream (round 4:
+    Pix2Pix.DISTILL_FORK -- the distillation terms on the generator's features beside the teacher discriminator's pass over
+    the student's fake; ARCH_FORK -- the architecture step's two discriminator backward passes, the second in gradient buffers
+    of its own, its alpha gradients added afterwards) against the in-line order: every weight, optimizer moment, BatchNorm
+    statistic and logged loss bit for bit after five iterations"""
+    from gcc_amd.models import Pix2Pix as P
+    monkeypatch.setattr(P, 'DISTILL_FORK', False)
+    monkeypatch.setattr(P, 'ARCH_FORK', False)
+    m0, l0, s0, _ = _run(_pix2pix, 1, False, iters=5)
+    for fork in ((True, False), (False, True), (True, True)):
+        monkeypatch.setattr(P, 'DISTILL_FORK', fork[0])
+        monkeypatch.setattr(P, 'ARCH_FORK', fork[1])
+        m1, l1, s1, _ = _run(_pix2pix, 1, False, iters=5)
+        assert l0 == l1, 'logged losses differ with forks %s' % (fork,)
+        bad = [k for k in s0 if not torch.equal(s0[k], s1[k])]
+        assert not bad, 'forks %s: %s' % (fork, bad[:8])
+
+
 @pytest.mark.parametrize('which', ['srgan', 'cyclegan'])
 def test_train_loop_with_replay_ends_on_the_same_weights(tmp_path, monkeypatch, which):
     """python -m gcc_amd.train with GCC_REPLAY=1 (the iteration recorded, replayed, dropped at the epoch boundary with the new
