@@ -332,9 +332,9 @@ class UnetEngine:
         self._pack.run()
 
     # ---------------------------------------------------------------------------------------
-    def _ctx(self, N, H, W):
-        key = (N, H, W)
-        if key in self.ctx:
+    def _ctx(self, N, H, W, slot=0):
+        key = (N, H, W) if slot == 0 else (N, H, W, slot)       # slot: a second set of activations (a forward that must not
+        if key in self.ctx:                                       # overwrite features another stream still reads)
             return self.ctx[key]
         D, dev, wd, uw = self.D, self.device, self.width, self.uwidth
         c = type('UnetCtx', (), {})()
@@ -386,22 +386,22 @@ class UnetEngine:
         return [c.lin[2], c.lin[4], c.rcat[4], c.rcat[2]]
 
     # ---------------------------------------------------------------------------------------
-    def forward(self, N, H, W, train=True):
-        """x must already sit in ctx.x_in (use ctx(N,H,W).x_in); returns ctx (ctx.out = tanh image)."""
+    def forward(self, N, H, W, train=True, slot=0):
+        """x must already sit in ctx.x_in (use _ctx(N,H,W,slot).x_in); returns ctx (ctx.out = tanh image)."""
         tag = getattr(self, 'profile_tag', None)
         if tag and (ops.PROFILE.active or ops.PROFILE.spans_only):             # bench.py's roofline.generator block
             with ops.PROFILE.span(tag + '.fwd'):
-                return self._forward(N, H, W, train)
-        return self._forward(N, H, W, train)
+                return self._forward(N, H, W, train, slot)
+        return self._forward(N, H, W, train, slot)
 
     # timing ablation only (scratch/ablate_generators.py): True = forward / backward enqueue nothing and the buffers keep the
     # values of the last real pass -- bounds what the U-Net passes cost the production schedule (results are stale by design)
     ablate_skip = False
 
-    def _forward(self, N, H, W, train=True):
+    def _forward(self, N, H, W, train=True, slot=0):
         if self.ablate_skip and (N, H, W) in self.ctx:
             return self.ctx[(N, H, W)]
-        c = self._ctx(N, H, W)
+        c = self._ctx(N, H, W, slot)
         D, wd, uw = self.D, self.width, self.uwidth
         c.train = train
         self.seed += 1

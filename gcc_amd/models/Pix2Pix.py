@@ -244,6 +244,9 @@ DISTILL_FORK = os.environ.get('GCC_DISTILL_FORK', '1') != '0'
 # GCC_ARCH_FORK (default 1): the architecture step's two discriminator backward passes (fake, real) side by side on two
 # streams: +1.9 % (profiles/r4y_ab_arch_fork.txt), same bits (tests/test_replay_gpu.py::test_pix2pix_stream_forks_change_nothing)
 ARCH_FORK = os.environ.get('GCC_ARCH_FORK', '1') != '0'
+# GCC_ARCH_EARLY=1: the online teacher's part of the architecture step (generator forward + two discriminator forwards over the
+# validation batch) starts when the teacher's iteration ends instead of when the student has finished reading the teacher
+ARCH_EARLY = os.environ.get('GCC_ARCH_EARLY', '0') == '1'
 
 
 def _step(gen, stream):
@@ -458,16 +461,20 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         ops.nchw_to_nhwc(self.real_A, self._A)
         ops.nchw_to_nhwc(self.real_B, self._B)
 
-    def forward(self):
-        """fake_B = G(real_A)  (models/Pix2Pix.py:460-462)"""
+    def forward(self, slot=0):
+        """fake_B = G(real_A)  (models/Pix2Pix.py:460-462).  slot 1: in a second set of activation buffers (the online teacher's
+        architecture-step forward, started while the student still reads the features of the training batch)"""
         self.finish_G_update()
         N, _, H, W = self._A.shape
-        c = self.G._ctx(N, H, W)
+        if self.resnet:
+            c = self.G._ctx(N, H, W, 'main' if slot == 0 else 'slot%d' % slot)
+        else:
+            c = self.G._ctx(N, H, W, slot)
         ops.nhwc_copy(self._A, 0, c.x_in, 0, 3, cfill=8)
         if self.resnet:
             self._gctx = self.G.forward(c, train=self.netG.training)
         else:
-            self._gctx = self.G.forward(N, H, W, train=self.netG.training)
+            self._gctx = self.G.forward(N, H, W, train=self.netG.training, slot=slot)
         self._fake = self._gctx.out
         self._fake_nchw = None
 
@@ -483,15 +490,17 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         return self.teacher_model.fake_B
 
     # -- helpers ------------------------------------------------------------------------------
-    def _pack_pair(self, ctx, second):
+    def _pack_pair(self, ctx, second, A=None):
         """ctx.x_in = cat(real_A, second) along channels (3 + 3, zero-filled to 8)"""
-        ops.nhwc_pack_pair(self._A, second, ctx.x_in, 3, 3)
+        ops.nhwc_pack_pair(self._A if A is None else A, second, ctx.x_in, 3, 3)
 
-    def _d_forward(self, tag, second, refresh=True):
-        N, _, H, W = self._A.shape
+    def _d_forward(self, tag, second, refresh=True, A=None, defer_running=False):
+        """A: the caller's own copy of real_A (the student's, when it runs the teacher's discriminator over its fake: the
+        teacher may already hold the next batch).  defer_running: see PatchGANEngine.forward"""
+        N, _, H, W = (self._A if A is None else A).shape
         ctx = self.D.new_ctx(N, H, W, tag)
-        self._pack_pair(ctx, second)
-        self.D.forward(ctx, train=True, refresh=refresh)
+        self._pack_pair(ctx, second, A)
+        self.D.forward(ctx, train=True, refresh=refresh, defer_running=defer_running)
         return ctx
 
     def _start_real_pass(self, tag):
@@ -659,7 +668,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         back to the image; returns that gradient's buffer (channels 3.. of the pair).  Runs on the current stream."""
         opt = self.opt
         T = self.teacher_model
-        ct = T._d_forward('on_student', self._fake)
+        ct = T._d_forward('on_student', self._fake, A=self._A)
         dfe = T.D.features(ct)
         N = dfe[0].shape[0]
         dtd = [self._tbuf(4 + j, N, dfe[j].shape[1], dfe[j].shape[2], dfe[j].shape[3])[1] for j in range(2)]
@@ -772,12 +781,18 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             self._apply_G_update()
 
     # -- architecture step (models/Pix2Pix.py:479-511, 585-593) -----------------------------------------
-    def get_D_arch_diff(self, isTeacher=False):
-        """three hinge terms on one fake / real pair; the |.| difference (EMA'd for the teacher)"""
+    def get_D_arch_diff(self, isTeacher=False, defer_running=False):
+        """three hinge terms on one fake / real pair; the |.| difference (EMA'd for the teacher).
+        defer_running: both passes leave the BatchNorm running statistics alone (the caller replays the updates where the
+        passes belong in the reference's order: PatchGANEngine.apply_deferred_running)"""
         mode = self.opt.gan_mode
         early = 'a_real' in getattr(self, '_early', {})
-        cf = self._d_forward('a_fake', self._fake, refresh=not early)
-        cr = self._take_real_pass('a_real')
+        if defer_running:
+            cf = self._d_forward('a_fake', self._fake, defer_running=True)
+            cr = self._d_forward('a_real', self._B, refresh=False, defer_running=True)
+        else:
+            cf = self._d_forward('a_fake', self._fake, refresh=not early)
+            cr = self._take_real_pass('a_real')
         ops.gan_loss(mode, cf.pred, False, True, self._l('D_arch_fake'))
         ops.gan_loss(mode, cf.pred, True, False, self._l('D_arch_fake_real'))
         ops.gan_loss(mode, cr.pred, True, True, self._l('D_arch_real'))
@@ -859,13 +874,29 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         T = self.teacher_model
         ts = self._teacher_stream()
 
+        free = getattr(self, '_teacher_free', None)
+        early = bool(ts) and ARCH_EARLY and free is not None and isinstance(T.D, engine.PatchGANEngine)
+
         def teacher_part():
             T.finish_G_update()
             T.set_input(self.input)
             yield
-            T.forward()
+            if not early:
+                T.forward()
+                yield
+                T.get_D_arch_diff(isTeacher=True)
+                return
+            # GCC_ARCH_EARLY: started when the teacher's own iteration ends, not when the student has finished reading the
+            # teacher (its stream idles ~2 ms there).  What the student still reads stays untouched: the generator's features
+            # (this forward runs in a second set of activation buffers), the discriminator contexts of the training batch
+            # (other tags), real_A (the student packs its own copy); the BatchNorm running statistics of the teacher's
+            # discriminator are updated where these two passes belong -- after the student's pass over it
+            T.forward(slot=1)
             yield
-            T.get_D_arch_diff(isTeacher=True)
+            cf, cr = T.get_D_arch_diff(isTeacher=True, defer_running=True)
+            ops.wait_event(ops.current_stream(), free)
+            T.D.apply_deferred_running(cf)
+            T.D.apply_deferred_running(cr)
 
         def student_part():
             if ts:
@@ -874,7 +905,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             self.forward()
 
         if ts:
-            self._release_teacher_stream(ts)
+            self._release_teacher_stream(ts, wait_free=not early)
             tgen = teacher_part()
             if not INTERLEAVE:
                 _drain(tgen, ts)

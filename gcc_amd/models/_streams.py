@@ -120,9 +120,12 @@ class TeacherStreamMixin:
                 t.record_stream(cur)
         self._input_ready = ev if dev else None
 
-    def _release_teacher_stream(self, ts):
+    def _release_teacher_stream(self, ts, wait_free=True):
+        """wait_free=False: the work about to be enqueued touches nothing the student still reads (Pix2Pix ARCH_EARLY)"""
         ev = getattr(self, '_teacher_free', None)
-        if ev is not None:
+        if not wait_free:
+            pass
+        elif ev is not None:
             ops.wait_event(ts, ev)
         else:
             ops.wait_stream(ts, ops.current_stream())

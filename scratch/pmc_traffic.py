@@ -9,7 +9,7 @@ import sys
 
 
 def family(name):
-    m = re.search(r'(igemm_halo_kernel<\w+>|igemm_kernel<[^>]*>)', name)
+    m = re.search(r'(igemm_halo_kernel<[^>]*>|igemm_kernel<[^>]*>)', name)
     return m.group(1) if m else None
 
 

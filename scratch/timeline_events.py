@@ -54,6 +54,17 @@ wrap_fn(model, '_backward_G_tail', 'S.tail (T.D on fake, distill, G backward)')
 wrap_fn(model, '_apply_G_update', 'S.adam G + repack')
 wrap_fn(model, 'optimizer_netD_arch', 'S.arch step')
 wrap_fn(model, 'backward_D_arch', 'S.arch backward (incl. its 2 D forwards)')
+wrap_fn(model, '_distill_teacher_d_terms', 'S.tail: teacher D over the fake + its terms')
+wrap_fn(model, '_distill_generator_terms', 'S.tail: generator-feature terms (aux stream when forked)')
+wrap_fn(model.G, 'backward', 'S.G backward')
+wrap_fn(T.G, 'backward', 'T.G backward (engine)')
+wrap_fn(model, 'forward', 'S.forward')
+wrap_fn(T, 'forward', 'T.forward')
+wrap_gen(model, '_backward_D_steps', 'S.D step')
+wrap_gen(T, '_backward_D_steps', 'T.D step')
+wrap_gen(model, '_backward_G_head_steps', 'S.head')
+wrap_gen(T, '_backward_G_head_steps', 'T.head')
+wrap_fn(model, 'get_D_arch_diff', 'S.arch D forwards + diff')
 orig_free = model._mark_teacher_free
 
 

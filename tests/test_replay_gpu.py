@@ -143,10 +143,14 @@ def test_pix2pix_stream_forks_change_nothing(monkeypatch):
     from gcc_amd.models import Pix2Pix as P
     monkeypatch.setattr(P, 'DISTILL_FORK', False)
     monkeypatch.setattr(P, 'ARCH_FORK', False)
+    monkeypatch.setattr(P, 'ARCH_EARLY', False)
     m0, l0, s0, _ = _run(_pix2pix, 1, False, iters=5)
-    for fork in ((True, False), (False, True), (True, True)):
+    # (ARCH_EARLY: the online teacher's architecture-step forward started before the student has finished reading the teacher:
+    # second set of generator activations, deferred BatchNorm running updates of the teacher's discriminator)
+    for fork in ((True, False, False), (False, True, False), (False, False, True), (True, True, True)):
         monkeypatch.setattr(P, 'DISTILL_FORK', fork[0])
         monkeypatch.setattr(P, 'ARCH_FORK', fork[1])
+        monkeypatch.setattr(P, 'ARCH_EARLY', fork[2])
         m1, l1, s1, _ = _run(_pix2pix, 1, False, iters=5)
         assert l0 == l1, 'logged losses differ with forks %s' % (fork,)
         bad = [k for k in s0 if not torch.equal(s0[k], s1[k])]
