@@ -316,11 +316,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __r
 #pragma unroll
         for (int z = 0; z < 8; z++)
             if (z < splits) v[z] = ((const f32x4*)slabs)[(size_t)z * n4 + i];
+        // the launch's own sum first, then ONE add to what the buffer holds: a gradient accumulated over several passes is then
+        // the same bits whether the passes add to one buffer in turn or to two buffers that are added afterwards
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (accumulate) o = ((const f32x4*)dw)[i];
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        if (accumulate) s = ((const f32x4*)dw)[i];
 #pragma unroll
         for (int z = 0; z < 8; z++)
             if (z < splits) { s[0] += v[z][0]; s[1] += v[z][1]; s[2] += v[z][2]; s[3] += v[z][3]; }
+        if (accumulate) { s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3]; }
         ((f32x4*)dw)[i] = s;
     }
 }

@@ -74,6 +74,36 @@ class FlatParams:
     def zero_grad(self):
         ops.fill(self.grads, 0.0)
 
+    # -- a second accumulator (two chains that add to the same gradients side by side on two streams) ---------------------------
+    def side_grads(self):
+        """(buffer shaped like `grads`, views of it shaped / strided like every parameter's .grad)"""
+        if getattr(self, '_side', None) is None:
+            buf = torch.zeros_like(self.grads)
+            base = self.grads.data_ptr()
+            views = [torch.as_strided(buf, g.shape, g.stride(), (g.data_ptr() - base) // 4) for g in self.grad_views]
+            self._side = (buf, views)
+        return self._side
+
+    class _Redirect:
+        def __init__(self, flat):
+            self.flat = flat
+
+        def __enter__(self):
+            for p, v in zip(self.flat.params, self.flat.side_grads()[1]):
+                p.grad = v
+            return self.flat.side_grads()[0]
+
+        def __exit__(self, *exc):
+            for p, g in zip(self.flat.params, self.flat.grad_views):
+                p.grad = g
+            return False
+
+    def redirect(self):
+        """with flat.redirect() as side: ... -- launches enqueued inside accumulate parameter gradients into `side` (which the
+        caller zeroes first and adds to `grads` afterwards: gcc_add_f32) instead of `grads`.  Host-side pointer swap: the
+        kernels take the address at enqueue time."""
+        return FlatParams._Redirect(self)
+
 
 def bn_buffers_to(module, device):
     for b in module.buffers():

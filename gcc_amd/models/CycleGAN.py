@@ -30,6 +30,11 @@ from .Pix2Pix import HipAdam, MobileResnetGenerator, _patchgan_tree, _portable
 from ._streams import TeacherStreamMixin
 
 HEAVY_SPARSITY = ('model.1', 'model.4', 'model.19', 'model.22')      # models/CycleGAN.py:243, 548-569
+# GCC_CYCLE_FORK=1: the two sides of the model (generator A -> B with its discriminator, generator B -> A with its) are
+# independent chains of small kernels inside forward, backward_G, backward_D and the architecture step: side B runs on the
+# auxiliary stream beside side A.  The host enqueues A then B as before, so everything that accumulates in launch order on the
+# weight-gradient side stream (both generators' parameter gradients) keeps the reference's order: same bits.
+CYCLE_FORK = int(os.environ.get('GCC_CYCLE_FORK', '1'))        # 2: the online teacher forks too (two more streams)
 
 
 class NLayerDiscriminator(nn.Module):
@@ -257,6 +262,35 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
         ops.nchw_to_nhwc(self.real_A, self._A)
         ops.nchw_to_nhwc(self.real_B, self._B)
 
+    def _forks(self):
+        return bool(CYCLE_FORK and not getattr(self, '_no_fork', False) and self._aux_stream())
+
+    def _two_sides(self, side_a, side_b, shared=None):
+        """side_a() on the current stream, side_b() on the auxiliary stream beside it (CYCLE_FORK; the online teacher, which
+        already runs on a stream of its own, and a single-stream schedule keep both in line); joined before returning.
+        shared: the optimizer whose parameter gradients BOTH sides add to (backward_G: each generator is differentiated by
+        both sides) -- side B then accumulates into a zeroed second buffer (engine.FlatParams.redirect) that is added
+        afterwards: (0 + A) + (0 + B), the bits of A-then-B, and no two launches ever add to one buffer at the same time"""
+        aux = self._aux_stream() if self._forks() else False
+        if not aux:
+            side_a()
+            side_b()
+            return
+        main = ops.current_stream()
+        flat = getattr(shared, 'flat', None) if shared is not None else None
+        ops.wait_stream(aux, main)
+        side_a()
+        with ops.on_stream(aux):
+            if flat is not None:
+                with flat.redirect() as side:
+                    ops.fill(side, 0.0)
+                    side_b()
+            else:
+                side_b()
+        ops.wait_stream(main, aux)
+        if flat is not None:
+            ops.add_f32_(flat.grads, flat.side_grads()[0])
+
     def _g(self, w, tag, src):
         """one generator pass: G_w on the NHWC image ``src``"""
         N, _, H, W = src.shape
@@ -272,15 +306,18 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
         of.  The contexts keep every activation for backward_G."""
         N, _, H, W = self._A.shape
         c, full = {}, {}
-        for w, first, second in (('A', self._A, self._B), ('B', self._B, self._A)):
+
+        def side(w, o, first, second, fake, idt, rec):
             cx = self.G[w]._ctx(2 * N, H, W, 'fake_idt')
             ops.nhwc_copy(first, 0, cx.x_in[:N], 0, 3)
             ops.nhwc_copy(second, 0, cx.x_in[N:], 0, 3)
             full[w] = self.G[w].forward(cx)
-        c['fake_B'], c['idt_A'] = _Half(full['A'], 0, N), _Half(full['A'], N, 2 * N)      # G_A(A), G_A(B)
-        c['fake_A'], c['idt_B'] = _Half(full['B'], 0, N), _Half(full['B'], N, 2 * N)      # G_B(B), G_B(A)
-        c['rec_A'] = self._g('B', 'rec', c['fake_B'].out)      # G_B(G_A(A))
-        c['rec_B'] = self._g('A', 'rec', c['fake_A'].out)      # G_A(G_B(B))
+            c[fake], c[idt] = _Half(full[w], 0, N), _Half(full[w], N, 2 * N)      # G_w(own domain), G_w(other domain)
+            c[rec] = self._g(o, 'rec', c[fake].out)                               # the cycle back through the other generator
+
+        # side A: G_A(A) | G_A(B), rec_A = G_B(G_A(A)); side B: G_B(B) | G_B(A), rec_B = G_A(G_B(B)) -- independent chains
+        self._two_sides(lambda: side('A', 'B', self._A, self._B, 'fake_B', 'idt_A', 'rec_A'),
+                        lambda: side('B', 'A', self._B, self._A, 'fake_A', 'idt_B', 'rec_B'))
         self._ctx = c
         self._nchw = {}
 
@@ -343,7 +380,7 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
             ci = c['idt_' + w]
             ops.l1_loss(ci.out, real[dom], self._l('idt_' + w), weight=lam[dom] * opt.lambda_identity, da=ci.g_out)
         # per side: fake = G_w(real), judged by D_w; the cycle through the other generator returns dL/d(fake)
-        for w, o, fake, rec in (('A', 'B', 'fake_B', 'rec_A'), ('B', 'A', 'fake_A', 'rec_B')):
+        def side(w, o, fake, rec):
             cf, cr = c[fake], c[rec]
             # the cycle that starts in G_w ends on G_w's input domain: rec_A = G_B(G_A(A)) against A, weight lambda_A
             ops.l1_loss(cr.out, real[w], self._l('cycle_' + w), weight=lam[w], da=cr.g_out)
@@ -356,11 +393,16 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
             ops.nhwc_add(dxd, 0, cf.g_out, 0, 3)
             g_feat = None
             if self.distill:
-                self._join(ts)              # first read of the teacher's features
+                self._join(ts)              # first read of the teacher's features (on this side's stream)
                 g_feat = self._distill_side(w, cf, T._ctx[fake])
-                if w == 'B':
+                if w == 'B' and not forked:
                     self._mark_teacher_free()
             self.G[w].backward(cf.full, g_feat=g_feat)
+
+        forked = self._forks()
+        self._two_sides(lambda: side('A', 'B', 'fake_B', 'rec_A'), lambda: side('B', 'A', 'fake_A', 'rec_B'), shared=self.optimizer_G)
+        if self.distill and forked:
+            self._mark_teacher_free()       # both sides have read the teacher (the sides ran on two streams: joined above)
 
     def _distill_side(self, w, cf, tcf):
         """distillation terms of one generator (:497-541): four transformed generator features carry gradients; the
@@ -399,7 +441,8 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
     # -- discriminators (:382-405): real first, then the pooled fake --------------------------------------
     def backward_D(self):
         mode = self.opt.gan_mode
-        for w, real, fake in (('A', self._B, 'fake_B'), ('B', self._A, 'fake_A')):
+
+        def side(w, real, fake):
             img = self._ctx[fake].out
             pooled = self.pool[w].query(img, self._buf(('pool', w), *img.shape))
             cr = self._d_forward(w, 'd_real', real)
@@ -411,11 +454,15 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
             self.D[w].backward(cf, wgrad=True, need_dx=False)
             self._dctx_last[w] = cf          # what the reference's D hooks hold after the iteration
 
+        self._two_sides(lambda: side('A', self._B, 'fake_B'), lambda: side('B', self._A, 'fake_A'))
+
     # -- one iteration (:571-590) -------------------------------------------------------------------------
     def optimize_parameters(self):
         ts = None
         if self.opt.online_distillation:
             T = self.teacher_model
+
+            T._no_fork = CYCLE_FORK < 2   # the online teacher already runs on a stream of its own
 
             def teacher_step():
                 T.set_input(self.input)
@@ -445,19 +492,23 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
     def get_D_arch_diff(self, isTeacher=False):
         mode = self.opt.gan_mode
         ctxs = {}
-        for w, fake, real in (('A', 'fake_B', self._B), ('B', 'fake_A', self._A)):
+        ema = isTeacher and self._ema_started          # one flag for both sides, as the reference tests side A only
+
+        def side(w, fake, real):
             cf = self._d_forward(w, 'a_fake', self._ctx[fake].out)
             cr = self._d_forward(w, 'a_real', real)
             ops.gan_loss(mode, cf.pred, False, True, self._l('arch_fake_' + w))
             ops.gan_loss(mode, cf.pred, True, False, self._l('arch_fake_real_' + w))
             ops.gan_loss(mode, cr.pred, True, True, self._l('arch_real_' + w))
             out = self._l('teacher_diff_' + w if isTeacher else 'D_arch_diff_' + w)
-            if isTeacher and self._ema_started:        # one flag for both sides, as the reference tests side A only
+            if ema:
                 b = float(self.opt.ema_beta)
                 ops.scalar_op(1, self._l('arch_fake_real_' + w), self._l('arch_fake_' + w), out, c=out, k0=b, k1=1.0 - b)
             else:
                 ops.scalar_op(0, self._l('arch_fake_real_' + w), self._l('arch_fake_' + w), out)
             ctxs[w] = (cf, cr)
+
+        self._two_sides(lambda: side('A', 'fake_B', self._B), lambda: side('B', 'fake_A', self._A))
         self._ema_started = True
         return ctxs
 
@@ -470,7 +521,7 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
         for w in 'AB':
             ops.scalar_op(2, T._l('teacher_diff_' + w), T._l('teacher_diff_' + w), self._l('teacher_diff_' + w), k0=0.0)
         self._mark_teacher_free()
-        for w in 'AB':
+        def side(w):
             cf, cr = ctxs[w]
             ops.arch_coeffs(self._l('arch_fake_real_' + w), self._l('arch_fake_' + w), self._l('arch_real_' + w),
                             self._l('teacher_diff_' + w), self._l('D_arch_' + w), self._l('arch_c_fr_' + w),
@@ -482,6 +533,8 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
             self.D[w].backward(cf, wgrad=False, agrad=True, need_dx=False)
             ops.gan_loss(mode, cr.pred, True, True, self._l('s2_' + w), dpred=gp, grad_weight=0.5)
             self.D[w].backward(cr, wgrad=False, agrad=True, need_dx=False)
+
+        self._two_sides(lambda: side('A'), lambda: side('B'))
 
     def optimizer_netD_arch(self):
         T = self.teacher_model

@@ -363,6 +363,23 @@ class SideStream:
             inst = cls._inst[key] = SideStream(device)
         return inst
 
+    @classmethod
+    def share(cls, device, user, owner):
+        """the stream `user` (raw handle) gets a SideStream object that launches on the SAME HIP stream as `owner`'s (own events,
+        own dirty flag): two chains that run side by side and accumulate into the same gradient buffers keep one launch order
+        for their weight-gradient kernels -- the host's enqueue order -- instead of racing on two side streams; and no further
+        HIP stream is created (the device has four hardware queues)"""
+        cur = cls._inst.get((device, user))
+        own = cls._inst.get((device, owner))
+        if own is None:
+            own = cls._inst[(device, owner)] = SideStream(device)
+        if cur is None or cur.raw != own.raw:
+            inst = cls.__new__(cls)
+            inst.stream, inst.raw, inst.dirty = own.stream, own.raw, False
+            inst.ev_fork, inst.ev_join = Event(), Event()
+            cls._inst[(device, user)] = inst
+        return cls._inst[(device, user)]
+
     def fork(self):
         """everything enqueued on the main stream so far happens-before later side-stream work"""
         self.ev_fork.record_raw(stream())

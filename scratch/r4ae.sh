@@ -1,0 +1,10 @@
+#!/usr/bin/env bash
+out=gpurun_out/r4ae; mkdir -p $out
+GCC_CYCLE_FORK=2 timeout 1200 python -m pytest tests/test_cyclegan_gpu.py tests/test_replay_gpu.py -q -m gpu -x -k "cyclegan or two_sides" -p no:cacheprovider 2>&1 | tail -3
+for v in 1 2; do
+  echo "== GCC_CYCLE_FORK=$v"
+  GCC_CYCLE_FORK=$v GCC_BENCH_OTHER=cyclegan timeout 600 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline 2> $out/cyc$v.err | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())['other_configs']['cyclegan']
+print({k: v for k, v in d.items() if k != 'roofline'})"
+done

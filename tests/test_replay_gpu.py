@@ -157,6 +157,22 @@ def test_pix2pix_stream_forks_change_nothing(monkeypatch):
         assert not bad, 'forks %s: %s' % (fork, bad[:8])
 
 
+def test_cyclegan_two_sides_fork_changes_nothing(monkeypatch):
+    """CycleGAN.CYCLE_FORK: side B of forward / backward_G / backward_D / the architecture step on the auxiliary stream beside
+    side A -- eager and replayed -- against the in-line order: every weight, optimizer moment and logged loss bit for bit"""
+    from gcc_amd.models import CycleGAN as Cg
+    monkeypatch.setattr(Cg, 'CYCLE_FORK', False)
+    m0, l0, s0, _ = _run(_cyclegan, 1, False, iters=5)
+    monkeypatch.setattr(Cg, 'CYCLE_FORK', True)
+    for enabled, threads in ((False, 1), (True, 4)):
+        m1, l1, s1, info = _run(_cyclegan, threads, enabled, iters=5)
+        if enabled:
+            assert m1[-1] == 'replay' and info['streams'] >= 3, (m1, info)
+        assert l0 == l1, 'logged losses differ (replay %s)' % enabled
+        bad = [k for k in s0 if not torch.equal(s0[k], s1[k])]
+        assert not bad, 'fork (replay %s): %s' % (enabled, bad[:8])
+
+
 @pytest.mark.parametrize('which', ['srgan', 'cyclegan'])
 def test_train_loop_with_replay_ends_on_the_same_weights(tmp_path, monkeypatch, which):
     """python -m gcc_amd.train with GCC_REPLAY=1 (the iteration recorded, replayed, dropped at the epoch boundary with the new
