@@ -34,6 +34,9 @@ IMAGENET_STD = (0.229, 0.224, 0.225)
 VGG19_CFG = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M')
 
 
+# GCC_SR_FORK (default 1): backward_G's VGG chain on the auxiliary stream beside the discriminator's pass over the fake
+SR_FORK = os.environ.get('GCC_SR_FORK', '1') != '0'
+
 class ConvolutionalBlock(nn.Module):
     """conv (padding k // 2) [+ BatchNorm] [+ DifferentiableOP] [+ PReLU | LeakyReLU(0.2) | Tanh]  (models/SRGAN.py:15-70)"""
 
@@ -360,20 +363,35 @@ class SRGAN(TeacherStreamMixin, nn.Module):
         ops.mse_loss(self._fake, self._hr, self._l('mse_content'), weight=opt.lambda_SR_content, da=g_img)
         self._normalise()
         g_n = self._buf('g_n', N, 3, H, W)                   # dL/d(normalised fake_hr)
+        def perceptual():
+            # perceptual term: MSE between VGG feature maps of the normalised fake and real images
+            vf, vr = self.V.new_ctx(N, H, W, 'fake'), self.V.new_ctx(N, H, W, 'real')
+            ops.nhwc_copy(self._fake_n, 0, vf.x_in, 0, 3)
+            ops.nhwc_copy(self._hr_n, 0, vr.x_in, 0, 3)
+            ff, fr = self.V.forward(vf), self.V.forward(vr)
+            g_ff = self._buf('g_ff', *ff.shape)
+            ops.mse_loss(ff, fr, self._l('perceptual'), weight=opt.lambda_SR_perceptual, da=g_ff)
+            return self.V.backward(vf, g_ff)
+
+        # the VGG chain (two forwards, one backward; frozen weights) and the discriminator's pass over the fake only meet in
+        # dL/d(fake_n): the VGG chain runs on the auxiliary stream beside the discriminator's (GCC_SR_FORK; the online teacher,
+        # already on a stream of its own, keeps it in line); the two gradients are added in the reference's order
+        aux = self._aux_stream() if (SR_FORK and not getattr(self, '_no_fork', False)) else False
+        if aux:
+            ops.wait_stream(aux, ops.current_stream())
+            with ops.on_stream(aux):
+                gv = perceptual()
         cg = self._d_forward('g_fake', self._fake_n)
         self._dctx_last = cg
         gp = self.D.grad_pred_buffer(cg)
         ops.gan_loss(mode, cg.pred, True, True, self._l('G_GAN'), dpred=gp, grad_weight=opt.lambda_SR_adversarial)
         dx = self.D.backward(cg, wgrad=False, need_dx=True)
         ops.nhwc_copy(dx, 0, g_n, 0, 3)
-        # perceptual term: MSE between VGG feature maps of the normalised fake and real images
-        vf, vr = self.V.new_ctx(N, H, W, 'fake'), self.V.new_ctx(N, H, W, 'real')
-        ops.nhwc_copy(self._fake_n, 0, vf.x_in, 0, 3)
-        ops.nhwc_copy(self._hr_n, 0, vr.x_in, 0, 3)
-        ff, fr = self.V.forward(vf), self.V.forward(vr)
-        g_ff = self._buf('g_ff', *ff.shape)
-        ops.mse_loss(ff, fr, self._l('perceptual'), weight=opt.lambda_SR_perceptual, da=g_ff)
-        ops.nhwc_add(self.V.backward(vf, g_ff), 0, g_n, 0, 3)
+        if aux:
+            ops.wait_stream(ops.current_stream(), aux)
+        else:
+            gv = perceptual()
+        ops.nhwc_add(gv, 0, g_n, 0, 3)
         g_feat = None
         if self.distill:
             T = self.teacher_model
@@ -428,6 +446,8 @@ class SRGAN(TeacherStreamMixin, nn.Module):
         ts = None
         if self.opt.online_distillation:
             T = self.teacher_model
+
+            T._no_fork = True            # the online teacher already runs on a stream of its own
 
             def teacher_step():
                 T.set_input(self.input)
