@@ -34,7 +34,26 @@ HEAVY_SPARSITY = ('model.1', 'model.4', 'model.19', 'model.22')      # models/Cy
 # independent chains of small kernels inside forward, backward_G, backward_D and the architecture step: side B runs on the
 # auxiliary stream beside side A.  The host enqueues A then B as before, so everything that accumulates in launch order on the
 # weight-gradient side stream (both generators' parameter gradients) keeps the reference's order: same bits.
-CYCLE_FORK = int(os.environ.get('GCC_CYCLE_FORK', '1'))        # 2: the online teacher forks too (two more streams)
+CYCLE_FORK = int(os.environ.get('GCC_CYCLE_FORK', '2'))
+# 2 (default): the online teacher's two sides fork as well, and the weight gradients stay on their chain's stream instead of a
+# side stream each: four chains on four HIP streams = the device's four hardware queues (with side streams the same forks
+# make eight streams and lose: profiles/r4ag_cyclegan_streams.txt -- eager 32.2 -> 23.3 ms, replayed 30.0 -> 24.7);
+# 1: the student's sides only, weight gradients on side streams (six streams: 25.6 ms replayed)
+
+
+class _ChainWgrad:
+    """with CYCLE_FORK >= 2: weight-gradient launches stay on the stream of the chain that needs them (engine.OVERLAP_WGRAD
+    off for the duration of the step; restored afterwards: other model families of the process keep their side streams)"""
+
+    def __enter__(self):
+        self.prev = engine.OVERLAP_WGRAD
+        if CYCLE_FORK >= 2 and os.environ.get('GCC_CYCLE_CHAIN_WGRAD', '1') != '0':
+            engine.OVERLAP_WGRAD = False
+        return self
+
+    def __exit__(self, *exc):
+        engine.OVERLAP_WGRAD = self.prev
+        return False
 
 
 class NLayerDiscriminator(nn.Module):
@@ -458,11 +477,15 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
 
     # -- one iteration (:571-590) -------------------------------------------------------------------------
     def optimize_parameters(self):
+        with _ChainWgrad():
+            return self._optimize_parameters()
+
+    def _optimize_parameters(self):
         ts = None
         if self.opt.online_distillation:
             T = self.teacher_model
 
-            T._no_fork = CYCLE_FORK < 2   # the online teacher already runs on a stream of its own
+            T._no_fork = CYCLE_FORK < 2   # 1: the online teacher, already on a stream of its own, keeps its sides in line
 
             def teacher_step():
                 T.set_input(self.input)
@@ -537,6 +560,10 @@ class MobileCycleGANModel(TeacherStreamMixin, nn.Module):
         self._two_sides(lambda: side('A'), lambda: side('B'))
 
     def optimizer_netD_arch(self):
+        with _ChainWgrad():
+            return self._optimizer_netD_arch()
+
+    def _optimizer_netD_arch(self):
         T = self.teacher_model
 
         def teacher_part():
