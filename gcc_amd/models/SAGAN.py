@@ -37,6 +37,24 @@ def l2normalize(v, eps=1e-12):
     return v / (v.norm() + eps)
 
 
+# GCC_SAGAN_CHAIN_WGRAD (default 1): the weight-gradient launches stay on the stream of the chain that needs them instead of a side
+# stream: at 64 x 64 every kernel is a few microseconds and the two event operations of a side-stream fork cost more than the
+# overlap returns (eager 10.6 -> 8.8 ms, replayed 9.3 -> 8.4: profiles/r4ak_chain_wgrad.txt; SRGAN measured the other way round)
+CHAIN_WGRAD = os.environ.get('GCC_SAGAN_CHAIN_WGRAD', '1') != '0'
+
+
+class _ChainWgrad:
+    def __enter__(self):
+        self.prev = engine.OVERLAP_WGRAD
+        if CHAIN_WGRAD:
+            engine.OVERLAP_WGRAD = False
+        return self
+
+    def __exit__(self, *exc):
+        engine.OVERLAP_WGRAD = self.prev
+        return False
+
+
 class SpectralNorm(nn.Module):
     """Parameter holder of the reference's wrapper (models/SAGAN.py:17-70): the wrapped conv loses ``weight`` and gains
     ``weight_u`` [rows], ``weight_v`` [cols*k*k] (requires_grad False) and ``weight_bar``; the arithmetic lives in
@@ -345,6 +363,10 @@ class SAGANModel(TeacherStreamMixin, nn.Module):
 
     # -- one iteration (:508-528) -----------------------------------------------------------------------------
     def optimize_parameters(self):
+        with _ChainWgrad():
+            return self._optimize_parameters()
+
+    def _optimize_parameters(self):
         ts = None
         if self.opt.online_distillation:
             T = self.teacher_model
@@ -405,6 +427,10 @@ class SAGANModel(TeacherStreamMixin, nn.Module):
         self.D.backward(cr, wgrad=False, agrad=True, need_dx=False)
 
     def optimizer_netD_arch(self):
+        with _ChainWgrad():
+            return self._optimizer_netD_arch()
+
+    def _optimizer_netD_arch(self):
         T = self.teacher_model
 
         def teacher_part():
