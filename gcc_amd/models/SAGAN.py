@@ -41,6 +41,9 @@ def l2normalize(v, eps=1e-12):
 # stream: at 64 x 64 every kernel is a few microseconds and the two event operations of a side-stream fork cost more than the
 # overlap returns (eager 10.6 -> 8.8 ms, replayed 9.3 -> 8.4: profiles/r4ak_chain_wgrad.txt; SRGAN measured the other way round)
 CHAIN_WGRAD = os.environ.get('GCC_SAGAN_CHAIN_WGRAD', '1') != '0'
+# GCC_SAGAN_FORK=1: backward_G's distillation block on the auxiliary stream beside the discriminator's pass -- same bits, measured
+# SLOWER (replayed 8.42 -> 9.0 ms, profiles/r4an_sagan_fork.txt: the chains are too short to pay for a third stream): off
+G_FORK = os.environ.get('GCC_SAGAN_FORK', '0') == '1'
 
 
 class _ChainWgrad:
@@ -321,16 +324,18 @@ class SAGANModel(TeacherStreamMixin, nn.Module):
     # -- G step (:460-494) ------------------------------------------------------------------------------------
     def backward_G(self, ts=None):
         opt, mode, gc = self.opt, self.opt.gan_mode, self._gctx
-        cg = self._d_forward('g_fake', self._fake)
-        self._dctx_g = cg
-        ops.gan_loss(mode, cg.pred, True, False, self._l('G_GAN'), dpred=self.D.grad_pred_buffer(cg))
-        dx = self.D.backward(cg, wgrad=False, need_dx=True)
-        ops.nhwc_copy(dx, 0, gc.g_out, 0, 3)
         g_feat = None
-        if self.distill:
+
+        def own_d():
+            cg = self._d_forward('g_fake', self._fake)
+            self._dctx_g = cg
+            ops.gan_loss(mode, cg.pred, True, False, self._l('G_GAN'), dpred=self.D.grad_pred_buffer(cg))
+            return self.D.backward(cg, wgrad=False, need_dx=True)
+
+        def distill_terms():
             T = self.teacher_model
             N = gc.N
-            self._join(ts)                                       # first read of the teacher's state
+            self._join(ts)                                       # first read of the teacher's state (on this chain's stream)
             ct = T._d_forward('on_student', self._fake)          # teacher D (frozen) on the student's fake: not detached
             feats = self.G.features(gc) + T.D.features(ct)
             tf, dtf = [], []
@@ -346,17 +351,34 @@ class SAGANModel(TeacherStreamMixin, nn.Module):
                 t = self.target_distillation_features[i]
                 ops.distill_fwd(tf[i], t, self._dist_out[i], ws)
                 ops.distill_bwd(tf[i], t, opt.lambda_gram, opt.lambda_content, dtf[i], ws)
-            g_feat = []
+            gf = []
             for i in range(2):
                 self.T[i].backward_weight(feats[i], dtf[i])
                 gbuf = self._buf(('gf', i), N, feats[i].shape[1], feats[i].shape[2], feats[i].shape[3])
                 self.T[i].backward_data(dtf[i], gbuf)
-                g_feat.append(gbuf)
+                gf.append(gbuf)
             ops.SideStream.get(self.device).join()
             dx2 = T.D.backward(ct, has_pred_grad=False, g_feat=[dtf[2], dtf[3]], wgrad=False, need_dx=True)
-            ops.nhwc_add(dx2, 0, gc.g_out, 0, 3)
             tmp = self._buf('l1', N, 3, 64, 64)
             ops.l1_loss(self._fake, T._fake, self._l('L1'), weight=opt.lambda_L1, da=tmp)
+            return gf, dx2, tmp
+
+        # the student discriminator's pass over the fake and the distillation block (teacher discriminator over the same fake,
+        # transform convs, gram / content terms) only meet in dL/d(fake): the block runs on the auxiliary stream beside the pass
+        # (GCC_SAGAN_FORK; the online teacher keeps everything in line); the gradients are added in the reference's order
+        aux = self._aux_stream() if (self.distill and G_FORK and not getattr(self, '_no_fork', False)) else False
+        if aux:
+            ops.wait_stream(aux, ops.current_stream())
+            with ops.on_stream(aux):
+                g_feat, dx2, tmp = distill_terms()
+        dx = own_d()
+        ops.nhwc_copy(dx, 0, gc.g_out, 0, 3)
+        if self.distill:
+            if aux:
+                ops.wait_stream(ops.current_stream(), aux)
+            else:
+                g_feat, dx2, tmp = distill_terms()
+            ops.nhwc_add(dx2, 0, gc.g_out, 0, 3)
             ops.nhwc_add(tmp, 0, gc.g_out, 0, 3)
             self._mark_teacher_free()
         self.G.backward(gc, g_feat=g_feat, wgrad=True)
@@ -370,6 +392,8 @@ class SAGANModel(TeacherStreamMixin, nn.Module):
         ts = None
         if self.opt.online_distillation:
             T = self.teacher_model
+
+            T._no_fork = True            # the online teacher already runs on a stream of its own
 
             def teacher_step():
                 T.set_input(self.input)

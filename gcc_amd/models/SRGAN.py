@@ -36,6 +36,7 @@ VGG19_CFG = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512,
 
 # GCC_SR_FORK (default 1): backward_G's VGG chain on the auxiliary stream beside the discriminator's pass over the fake
 SR_FORK = os.environ.get('GCC_SR_FORK', '1') != '0'
+TEACHER_CHAIN_WGRAD = os.environ.get('GCC_SR_TEACHER_CHAIN_WGRAD', '0') == '1'
 
 class ConvolutionalBlock(nn.Module):
     """conv (padding k // 2) [+ BatchNorm] [+ DifferentiableOP] [+ PReLU | LeakyReLU(0.2) | Tanh]  (models/SRGAN.py:15-70)"""
@@ -451,7 +452,13 @@ class SRGAN(TeacherStreamMixin, nn.Module):
 
             def teacher_step():
                 T.set_input(self.input)
-                T.optimize_parameters()
+                prev = engine.OVERLAP_WGRAD
+                if TEACHER_CHAIN_WGRAD:          # the teacher's weight gradients on its own stream: one HIP stream fewer
+                    engine.OVERLAP_WGRAD = False
+                try:
+                    T.optimize_parameters()
+                finally:
+                    engine.OVERLAP_WGRAD = prev
                 self.target_distillation_features = T.get_distillation_features()     # read after _join
             ts = self._run_teacher(teacher_step)
         self.forward()

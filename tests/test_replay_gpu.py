@@ -157,6 +157,20 @@ def test_pix2pix_stream_forks_change_nothing(monkeypatch):
         assert not bad, 'forks %s: %s' % (fork, bad[:8])
 
 
+def test_sagan_distill_fork_changes_nothing(monkeypatch):
+    """SAGAN.G_FORK: backward_G's distillation block on the auxiliary stream beside the discriminator's pass -- eager and
+    replayed -- against the in-line order: same bits"""
+    from gcc_amd.models import SAGAN as Sa
+    monkeypatch.setattr(Sa, 'G_FORK', False)
+    m0, l0, s0, _ = _run(_sagan, 1, False, iters=5)
+    monkeypatch.setattr(Sa, 'G_FORK', True)
+    for enabled, threads in ((False, 1), (True, 4)):
+        m1, l1, s1, info = _run(_sagan, threads, enabled, iters=5)
+        assert l0 == l1, 'logged losses differ (replay %s)' % enabled
+        bad = [k for k in s0 if not torch.equal(s0[k], s1[k])]
+        assert not bad, 'fork (replay %s): %s' % (enabled, bad[:8])
+
+
 def test_srgan_vgg_fork_changes_nothing(monkeypatch):
     """SRGAN.SR_FORK: backward_G's VGG chain on the auxiliary stream beside the discriminator's pass -- eager and replayed --
     against the in-line order: same bits"""
