@@ -21,6 +21,7 @@ import torch.nn as nn
 
 from .. import dist as gdist
 from .. import engine, ops
+from .. import _lib
 from .._lib import GccError
 from ..utils import util
 from .DifferentiableOp import DifferentiableOP
@@ -247,6 +248,9 @@ ARCH_FORK = os.environ.get('GCC_ARCH_FORK', '1') != '0'
 # GCC_ARCH_EARLY=1: the online teacher's part of the architecture step (generator forward + two discriminator forwards over the
 # validation batch) starts when the teacher's iteration ends instead of when the student has finished reading the teacher
 ARCH_EARLY = os.environ.get('GCC_ARCH_EARLY', '0') == '1'
+# GCC_TAIL_HALO_HC (default 1): the teacher discriminator's pass over the student's fake (the student's tail: one or two busy queues)
+# takes the 128-column halo tiles for its half-chip launches: +0.3-0.6 % (profiles/r4ao_ab_tail_halo_hc.txt)
+TAIL_HALO_HC = os.environ.get('GCC_TAIL_HALO_HC', '1') != '0'
 
 
 def _step(gen, stream):
@@ -668,6 +672,17 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         back to the image; returns that gradient's buffer (channels 3.. of the pair).  Runs on the current stream."""
         opt = self.opt
         T = self.teacher_model
+        # this pass runs where the step has one or two busy queues (the student's tail): its half-chip launches (L3 forward, L4
+        # data gradient: 128 workgroups of 256 x 256) take the 128-column halo tiles of the 'alone' plan (GCC_TAIL_HALO_HC)
+        lib = ops.lib()
+        hc_prev = lib.gcc_set_option(_lib.OPT_HALO_HC, 1) if (TAIL_HALO_HC and 'GCC_HALO_HC' not in os.environ) else None
+        try:
+            return self._distill_teacher_d_terms_body(T, opt)
+        finally:
+            if hc_prev is not None:
+                lib.gcc_set_option(_lib.OPT_HALO_HC, hc_prev)
+
+    def _distill_teacher_d_terms_body(self, T, opt):
         ct = T._d_forward('on_student', self._fake, A=self._A)
         dfe = T.D.features(ct)
         N = dfe[0].shape[0]
