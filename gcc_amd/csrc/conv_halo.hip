@@ -59,12 +59,15 @@ constexpr int HALO_MAX_PIECES = 48;                // 6 per wave
 // HC: columns of the tile.  256: the round-3 form (8 waves of 64 pixels x 128 columns).  128 (round 4): 8 waves of 64 x 64 -- twice
 // the workgroups for the launches whose 256-column tiles cover half the chip (PatchGAN L3 forward, L4 data gradient: 128 of
 // 256 CUs) and for 128-column layers; half the weight stage (the pixel slices are staged by both column tiles of a pixel tile).
-template <bool S1, int HC>
+// KS (stride-1 form): kernel size -- 4 (PatchGAN L4) or, round 4, 3 (k3 s1 p1: the VGG19 layers of SRGAN's perceptual loss at
+// 96 -> 384: 9 taps per staged slice, neighbourhood (16 + 2) x (16 + 2) at the same pitch of 20).
+template <bool S1, int HC, int KS = 4>
 __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
     using C = Cfg<HB, HC>;
+    static_assert(KS == 4 || (S1 && KS == 3), "kernel sizes: 4 (both strides), 3 (stride 1)");
     constexpr int HALO_W_BYTES = HC * BK * 2;        // one weight stage: [HC][64] bf16
     constexpr int WPIECES = HC / 64;                 // 1-KiB weight pieces per wave and k-step
-    constexpr int T = S1 ? 16 : 4;                   // k-steps (taps) a staged slice serves
+    constexpr int T = S1 ? KS * KS : 4;              // k-steps (taps) a staged slice serves
     extern __shared__ __attribute__((aligned(128))) char smem[];
     char* sW = smem;                                 // weights [2][256][128 B]
     char* sH = smem + 2 * HALO_W_BYTES;              // staged sub-grid slices [2][npieces * 8][128 B]
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
         int oy_s, ox_s, ch;
         if constexpr (S1) {
             ch = s;
-            oy_s = ox_s = p.mode == 3 ? -1 : -2;
+            oy_s = ox_s = p.mode == 3 ? -1 : -(KS - 2);          // forward: -pad; data gradient: -(KS - 1 - pad)
         } else if (p.mode == 0) {
             const int uv = s / p.nchunks;
             ch = s - uv * p.nchunks;
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
         int kh, kw, ch;
         if constexpr (S1) {
             ch = s;
-            kh = j >> 2; kw = j & 3;
+            kh = j / KS; kw = j - kh * KS;
         } else if (p.mode == 0) {
             const int uv = s / p.nchunks;
             ch = s - uv * p.nchunks;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
             ch = s;
             kh = 1 - py + 2 * ja; kw = 1 - px_w + 2 * jb;
         }
-        const int tapoff = ((kh * 4 + kw) * p.Ct + ch * BK) * 2;
+        const int tapoff = ((kh * KS + kw) * p.Ct + ch * BK) * 2;
 #pragma unroll
         for (int i = 0; i < WPIECES; i++) {
             const uint32_t off = (uint32_t)(w_row0 + tapoff + i * (16 * p.ldw));
@@ -273,14 +276,29 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
             __syncthreads();
             if (kt + 1 < nk) issue_w(kt + 1, wbuf ^ 1);
             if (j < 6 && s + 1 < nstages) issue_halo(s + 1, j, (s + 1) & 1);
-            const int kh = j >> 2, kw = j & 3;
-            compute(wbuf, s & 1, p.mode == 3 ? kh : 3 - kh, p.mode == 3 ? kw : 3 - kw);
+            const int kh = j / KS, kw = j - kh * KS;
+            compute(wbuf, s & 1, p.mode == 3 ? kh : KS - 1 - kh, p.mode == 3 ? kw : KS - 1 - kw);
         };
-        for (int s = 0; s < nstages; s++) {
+        if constexpr ((T & 1) == 0) {
+            for (int s = 0; s < nstages; s++) {
 #pragma unroll 1
-            for (int j = 0; j < T; j += 2) {
+                for (int j = 0; j < T; j += 2) {
+                    step(s, j, 0);
+                    step(s, j + 1, 1);
+                }
+            }
+        } else {
+            // an odd number of taps per slice: the weight stage alternates across slice boundaries -- pairs of k-steps over the
+            // flat index (s, j advance as scalars)
+            int s = 0, j = 0;
+#pragma unroll 1
+            for (int kt = 0; kt < nk; kt += 2) {
                 step(s, j, 0);
-                step(s, j + 1, 1);
+                if (++j == T) { j = 0; ++s; }
+                if (kt + 1 < nk) {
+                    step(s, j, 1);
+                    if (++j == T) { j = 0; ++s; }
+                }
             }
         }
     } else {
@@ -376,7 +394,8 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const HaloParams p) {
 HaloPlan halo_plan(const gcc_conv_t* c, int dgrad) {
     HaloPlan h = {};
     if (!gcc_opt(GCC_OPT_IGEMM_HALO)) return h;
-    if (c->KH != 4 || c->KW != 4 || c->pad != 1) return h;
+    const bool k3 = c->KH == 3 && c->KW == 3 && c->pad == 1 && c->stride == 1 && gcc_opt(GCC_OPT_IGEMM_HALO) >= 3;
+    if (!k3 && (c->KH != 4 || c->KW != 4 || c->pad != 1)) return h;
     const int Ct = dgrad ? c->Co : c->Ci, Cout = dgrad ? c->Ci : c->Co;
     if (Ct % BK || Ct < BK) return h;
     int gh, gw;                                   // position grid
@@ -395,12 +414,12 @@ HaloPlan halo_plan(const gcc_conv_t* c, int dgrad) {
         h.HWp = (h.HW + 7) & ~7;
         h.phases = h.mode == 0 ? 1 : (h.mode == 1 ? 4 : 2);
     } else if (c->stride == 1) {
-        if (gcc_opt(GCC_OPT_IGEMM_HALO) < 2) return h;            // 2 (default): the stride-1 form too
+        if (gcc_opt(GCC_OPT_IGEMM_HALO) < 2) return h;            // >= 2: the stride-1 form too (3, the default: also its 3 x 3 instantiation)
         if (Cout % 128) return h;
-        gh = c->H; gw = c->W;                     // forward: the padded grid (Ho = H - 1 rows exist)
+        gh = c->H; gw = c->W;                     // forward: the padded grid (k4: Ho = H - 1 rows exist; k3: all of them)
         h.mode = dgrad ? 4 : 3;
         h.TW = 16; h.TR = 16;
-        h.HR = 19; h.HW = 19; h.HWp = 20;
+        h.HR = h.HW = 16 + c->KH - 1; h.HWp = 20;
         h.phases = 1;
     } else return h;
     if (gw % h.TW || gh % h.TR) return h;
@@ -437,7 +456,7 @@ int launch_halo(const gcc_conv_t* c, int dgrad, const HaloPlan& h, const void* s
                 const TailFin* fin, hipStream_t st) {
     HaloParams p;
     p.fin = fin ? *fin : TailFin{};
-    const int Ho = gcc_conv_out(c->H, 4, c->stride, 1), Wo = gcc_conv_out(c->W, 4, c->stride, 1);
+    const int Ho = gcc_conv_out(c->H, c->KH, c->stride, 1), Wo = gcc_conv_out(c->W, c->KW, c->stride, 1);
     p.src = (const bf16_t*)src; p.wgt = (const bf16_t*)w; p.dst = (bf16_t*)dst;
     p.bias = ep ? ep->bias : nullptr; p.stats = ep ? ep->stats_partial : nullptr;
     p.act = ep ? ep->act : GCC_ACT_NONE; p.slope = ep ? ep->slope : 0.f;
@@ -449,7 +468,7 @@ int launch_halo(const gcc_conv_t* c, int dgrad, const HaloPlan& h, const void* s
         p.Hs = Ho; p.Ws = Wo; p.lds_ = c->ldy; p.soff = c->yoff; p.Hd = c->H; p.Wd = c->W; p.ldd = c->ldx; p.doff = c->xoff;
         p.Ct = c->Co; p.Cout = c->Ci;
     }
-    p.ldw = 16 * p.Ct;
+    p.ldw = c->KH * c->KW * p.Ct;
     const size_t sb = (size_t)p.N * p.Hs * p.Ws * p.lds_ * 2, wb = (size_t)p.Cout * p.ldw * 2;
     const size_t db = (size_t)p.N * p.Hd * p.Wd * p.ldd * 2;
     if (sb >= OOB || wb >= OOB || db >= (size_t)1 << 32) return -1;
@@ -463,6 +482,8 @@ int launch_halo(const gcc_conv_t* c, int dgrad, const HaloPlan& h, const void* s
         (void)hipFuncSetAttribute((const void*)igemm_halo_kernel<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)igemm_halo_kernel<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)igemm_halo_kernel<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)igemm_halo_kernel<true, 256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)igemm_halo_kernel<true, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const dim3 grid((unsigned)(c->N * h.tiles_x * h.tiles_y * h.ntiles), 1, h.phases);
     {
@@ -471,7 +492,10 @@ int launch_halo(const gcc_conv_t* c, int dgrad, const HaloPlan& h, const void* s
         p.xcd_cols = (mode >= 2 || (mode == 1 && h.mode >= 3)) && h.ntiles >= 2 && 8 % h.ntiles == 0 && grid.x % 8 == 0 &&
                      pt % (8 / h.ntiles) == 0;
     }
-    if (h.hc == 256) {
+    if (h.mode >= 3 && c->KH == 3) {
+        if (h.hc == 256) hipLaunchKernelGGL((igemm_halo_kernel<true, 256, 3>), grid, dim3(512), h.lds, st, p);
+        else hipLaunchKernelGGL((igemm_halo_kernel<true, 128, 3>), grid, dim3(512), h.lds, st, p);
+    } else if (h.hc == 256) {
         if (h.mode >= 3) hipLaunchKernelGGL((igemm_halo_kernel<true, 256>), grid, dim3(512), h.lds, st, p);
         else hipLaunchKernelGGL((igemm_halo_kernel<false, 256>), grid, dim3(512), h.lds, st, p);
     } else {

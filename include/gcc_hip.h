@@ -96,7 +96,8 @@ enum {
     GCC_OPT_WGRAD_ROW_TABLE,    /* 1 (default): the weight-gradient kernel decomposes each pixel of a workgroup's range once, into an LDS table
                                    (gather base + validity mask), instead of in every lane at every k-step (0: the round-2 form;
                                    kernels taller or wider than 15 taps always take that form) */
-    GCC_OPT_IGEMM_HALO,         /* 2 (default): also k4 s1 p1 convolutions on a 16-divisible grid (16 taps per staged slice); 1: k4 s2 p1 convolutions whose geometry fits (channels per tap a multiple of 64, 256 output channels
+    GCC_OPT_IGEMM_HALO,         /* 3 (default): also k3 s1 p1 convolutions on a 16-divisible grid (9 taps per staged slice: the VGG19 layers of SRGAN's
+                                   perceptual loss, 10-25 % per layer, profiles/r4as_halo_3x3.txt); 2: also k4 s1 p1 convolutions on a 16-divisible grid (16 taps per staged slice); 1: k4 s2 p1 convolutions whose geometry fits (channels per tap a multiple of 64, 256 output channels
                                    per tile, output rows that tile 256 pixels) stage each 64-channel slice of the input neighbourhood of a
                                    256-pixel tile ONCE in LDS and serve the taps that share it from there (conv_halo.hip); 0: the gather
                                    kernel re-stages the pixels for every tap */

@@ -20,6 +20,8 @@ cls = get_model_class(opt)
 model = cls(opt)
 attach_teacher(model, opt, cls)
 model.model_train()
+if os.environ.get('GCC_SERIALIZE') == '1' and hasattr(model, 'set_stream_schedule'):
+    model.set_stream_schedule(False)          # every launch on one stream: a kernel's duration is its own
 data = list(SyntheticPairs(opt, 4, 7))
 def step(i):
     model.set_input(data[i % 4]); model.optimize_parameters()
