@@ -408,7 +408,18 @@ def cslice(t, off, Cc):
 
 
 def geom(t):
-    """(ptr, N, C, H, W, ld) of an NHWC bf16 activation view."""
+    """(ptr, N, C, H, W, ld) of an NHWC bf16 activation view.  The iteration's activations are persistent buffers: the tuple is
+    kept on the tensor object (a view made per call is simply computed again; geometry and address of a tensor object never
+    change -- nothing in this package resizes or re-homes an activation in place)."""
+    d = t.__dict__
+    g = d.get('_gcc_geom')
+    if g is not None:
+        return g
+    g = d['_gcc_geom'] = _geom(t)
+    return g
+
+
+def _geom(t):
     N, Cc, H, W = t.shape
     s0, s1, s2, ld = t.stride()
     p = t.data_ptr()
