@@ -251,6 +251,9 @@ ARCH_EARLY = os.environ.get('GCC_ARCH_EARLY', '0') == '1'
 # GCC_TAIL_HALO_HC (default 1): the teacher discriminator's pass over the student's fake (the student's tail: one or two busy queues)
 # takes the 128-column halo tiles for its half-chip launches: +0.3-0.6 % (profiles/r4ao_ab_tail_halo_hc.txt)
 TAIL_HALO_HC = os.environ.get('GCC_TAIL_HALO_HC', '1') != '0'
+# GCC_ARCH_FREE_EARLY (default 1): in the architecture step the teacher's stream hands its difference scalar over itself and is
+# released behind its own part: +0.6 % (profiles/r4ay_ab_arch_free_early.txt), same bits
+ARCH_FREE_EARLY = os.environ.get('GCC_ARCH_FREE_EARLY', '1') != '0'
 
 
 def _step(gen, stream):
@@ -838,8 +841,10 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         cf, cr = self.get_D_arch_diff(isTeacher=False)
         if ts:
             ops.wait_stream(ops.current_stream(), ts)          # the teacher's difference was computed on its stream
-        ops.scalar_op(2, T._l('teacher_D_arch_diff'), T._l('teacher_D_arch_diff'), self._l('teacher_D_arch_diff'), k0=0.0)
-        self._mark_teacher_free()
+        if not (ts and ARCH_FREE_EARLY):
+            ops.scalar_op(2, T._l('teacher_D_arch_diff'), T._l('teacher_D_arch_diff'), self._l('teacher_D_arch_diff'), k0=0.0)
+            self._mark_teacher_free()
+        # (else: the teacher's own stream copied the scalar and released itself at the end of its part, optimizer_netD_arch)
         # loss_D_arch = |d_S - d_T| + (L_real + L_fake)/2 ; coefficients of the three hinge gradients
         ops.arch_coeffs(self._l('D_arch_fake_real'), self._l('D_arch_fake'), self._l('D_arch_real'),
                         self._l('teacher_D_arch_diff'), self._l('D_arch'), self._l('arch_c_fr'), self._l('arch_c_f'))
@@ -892,6 +897,14 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         free = getattr(self, '_teacher_free', None)
         early = bool(ts) and ARCH_EARLY and free is not None and isinstance(T.D, engine.PatchGANEngine)
 
+        def hand_over():
+            # GCC_ARCH_FREE_EARLY: the last thing the student reads of the teacher in this step is its difference scalar -- the
+            # teacher's stream copies it into the student's loss vector itself and is free from here (its next iteration then
+            # starts behind its own architecture-step part, not behind the student's two discriminator forwards)
+            if ts and ARCH_FREE_EARLY:
+                ops.scalar_op(2, T._l('teacher_D_arch_diff'), T._l('teacher_D_arch_diff'), self._l('teacher_D_arch_diff'), k0=0.0)
+                self._mark_teacher_free()
+
         def teacher_part():
             T.finish_G_update()
             T.set_input(self.input)
@@ -900,6 +913,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
                 T.forward()
                 yield
                 T.get_D_arch_diff(isTeacher=True)
+                hand_over()
                 return
             # GCC_ARCH_EARLY: started when the teacher's own iteration ends, not when the student has finished reading the
             # teacher (its stream idles ~2 ms there).  What the student still reads stays untouched: the generator's features
@@ -912,6 +926,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             ops.wait_event(ops.current_stream(), free)
             T.D.apply_deferred_running(cf)
             T.D.apply_deferred_running(cr)
+            hand_over()
 
         def student_part():
             if ts:

@@ -147,10 +147,15 @@ def test_pix2pix_stream_forks_change_nothing(monkeypatch):
     m0, l0, s0, _ = _run(_pix2pix, 1, False, iters=5)
     # (ARCH_EARLY: the online teacher's architecture-step forward started before the student has finished reading the teacher:
     # second set of generator activations, deferred BatchNorm running updates of the teacher's discriminator)
-    for fork in ((True, False, False), (False, True, False), (False, False, True), (True, True, True)):
+    monkeypatch.setattr(P, 'ARCH_FREE_EARLY', False)
+    for fork in ((True, False, False, False), (False, True, False, False), (False, False, True, False), (False, False, False, True),
+                 (True, True, True, True)):
+        # (fork[3], ARCH_FREE_EARLY: the teacher's stream copies its difference scalar itself and is released behind its own
+        # architecture-step part)
         monkeypatch.setattr(P, 'DISTILL_FORK', fork[0])
         monkeypatch.setattr(P, 'ARCH_FORK', fork[1])
         monkeypatch.setattr(P, 'ARCH_EARLY', fork[2])
+        monkeypatch.setattr(P, 'ARCH_FREE_EARLY', fork[3])
         m1, l1, s1, _ = _run(_pix2pix, 1, False, iters=5)
         assert l0 == l1, 'logged losses differ with forks %s' % (fork,)
         bad = [k for k in s0 if not torch.equal(s0[k], s1[k])]
