@@ -227,6 +227,40 @@ def test_gradient_layout_follows_backward_completion_order():
     assert [b[2] for b in red.buckets] == sorted(b[2] for b in red.buckets) and red.buckets[-1][2] == 15
 
 
+def test_flat_params_redirect_is_a_host_side_pointer_swap():
+    """engine.FlatParams.redirect (round 4: a second chain that adds to the same parameter gradients on another stream accumulates
+    into a second buffer, folded in afterwards): inside the context every parameter's .grad is the view of the SIDE buffer
+    with the shape, strides and offset of its view of `grads`; outside, the original views are back; (0 + a) + (0 + b) is what
+    a then b gives"""
+    from gcc_amd import engine
+    from gcc_amd.models.Pix2Pix import UnetGenertor
+    g = UnetGenertor(3, 3, 8, ngf=8)
+    params = list(g.parameters())
+    flat = engine.FlatParams(params, 'cpu')
+    base, views = flat.grads.data_ptr(), list(flat.grad_views)
+    gen = torch.Generator().manual_seed(1)
+    a = [torch.randn(p.shape, generator=gen) for p in params]
+    b = [torch.randn(p.shape, generator=gen) for p in params]
+    for p, x in zip(params, a):
+        p.grad.add_(x)                                    # the first chain: into `grads`
+    with flat.redirect() as side:
+        assert side.shape == flat.grads.shape and side.data_ptr() != base
+        side.zero_()
+        for p, v, x in zip(params, views, b):
+            assert p.grad.data_ptr() - side.data_ptr() == v.data_ptr() - base
+            assert p.grad.shape == v.shape and p.grad.stride() == v.stride()
+            p.grad.add_(x)                                # the second chain: into the side buffer
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, views)), 'the views of `grads` are restored'
+    flat.grads.add_(flat.side_grads()[0])
+    for p, x, y in zip(params, a, b):
+        want = torch.zeros_like(x).add_(x).add_(y)        # what accumulating a then b into one buffer gives
+        assert torch.equal(p.grad, want)
+    with pytest.raises(RuntimeError):                     # an exception inside the context still restores the views
+        with flat.redirect():
+            raise RuntimeError('boom')
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, views))
+
+
 def test_struct_layouts_match_header():
     from gcc_amd import _lib
     assert ctypes.sizeof(_lib.conv_t) == 13 * 4
