@@ -147,6 +147,7 @@ PROTOTYPES = {
     'gcc_arch_coeffs': (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _P]),
     'gcc_spectral_workspace': (_Z, [_I, _I, _I]),
     'gcc_spectral_power_iteration': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
+    'gcc_spectral_power_iteration_pack': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     'gcc_spectral_grad': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     'gcc_resample_u8': (_I, [_P, _I, _I, _Z, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P]),
     'gcc_crop_flip_normalize': (_I, [_P, _I, _I, _Z, _I, _I, _I, _I, _I, _P, _P, _I, _P]),

@@ -28,6 +28,7 @@ struct SnArgs {
     float* t;             // [R]  (kept per forward call)
     float* scal;          // [4]: 0 |vt|^2, 1 |t|^2, 2 sigma, 3 inner
     float* w_eff;         // [R*C*T]
+    float* sigma_out;     // the caller's copy of sigma (gcc_spectral_power_iteration_pack), or NULL (copied by the entry point)
 };
 
 __device__ __forceinline__ float block_sum(float v, float* sh) {
@@ -104,7 +105,35 @@ __global__ __launch_bounds__(256) void sn_finalize_kernel(SnArgs a) {
     }
     if (blockIdx.x == 0) {
         for (int r = threadIdx.x; r < a.R; r += 256) a.u[r] = a.t[r] * inv_t;
-        if (threadIdx.x == 0) { a.scal[1] = t2; a.scal[2] = t2 * inv_t; }      // u . t = |t|^2 / (|t| + eps)
+        if (threadIdx.x == 0) {
+            a.scal[1] = t2; a.scal[2] = t2 * inv_t;                            // u . t = |t|^2 / (|t| + eps)
+            if (a.sigma_out) a.sigma_out[0] = t2 * inv_t;
+        }
+    }
+}
+
+// W_eff = W_bar / sigma straight into the two bf16 packings the convolutions read (W [R][T][Cp], Wt [C][T][Rp], channel counts
+// padded to 8 with zeros): a 32 x 32 tile of one tap per workgroup, transposed through LDS -- the scale launch, the fp32 W_eff
+// round trip and the two pack launches of the separate route in one (round 4: the SAGAN iteration is a chain of ~5 us launches;
+// this is 3 of the 7 a spectrally normalised convolution's forward spent before its convolution).  Same bits: bf16(w * (1/sigma)).
+__global__ __launch_bounds__(256) void sn_scale_pack_kernel(const float* __restrict__ m, const float* scal, int rows, int taps,
+                                                            int cols, int colsp, int rowsp, unsigned short* __restrict__ w,
+                                                            unsigned short* __restrict__ wt) {
+    __shared__ float t[32][33];
+    const float inv = 1.f / scal[2];
+    const int tap = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        const float v = (r < rows && c < cols) ? m[((size_t)r * taps + tap) * cols + c] * inv : 0.f;
+        t[k][tx] = v;
+        if (r < rows && c < colsp) w[((size_t)r * taps + tap) * colsp + c] = f2bf(v);          // columns cols..colsp-1: zeros
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < cols && r < rowsp) wt[((size_t)c * taps + tap) * rowsp + r] = f2bf(t[tx][k]);   // rows rows..rowsp-1: zeros
     }
 }
 
@@ -189,12 +218,39 @@ extern "C" int gcc_spectral_power_iteration(const float* w_bar, float* u, float*
     GCC_CHECK_LAUNCH();
     SnArgs a;
     a.w = w_bar; a.u = u; a.v = v; a.R = R; a.C = C; a.T = T; a.vt = vt; a.t = t_out; a.scal = scal; a.w_eff = w_eff;
+    a.sigma_out = nullptr;
     hipLaunchKernelGGL(sn_finalize_kernel, dim3(nblocks(K, 64)), dim3(256), 0, st, a);
     GCC_CHECK_LAUNCH();
     const size_t n = (size_t)R * K;
     hipLaunchKernelGGL(sn_scale_kernel, dim3(nblocks(n)), dim3(256), 0, st, w_bar, (const float*)scal, w_eff, n);
     GCC_CHECK_LAUNCH();
     if (gcc_memcpy_d2d_async(sigma_out, scal + 2, sizeof(float), st) != hipSuccess) return GCC_ERR_LAUNCH;
+    return GCC_OK;
+}
+
+extern "C" int gcc_spectral_power_iteration_pack(const float* w_bar, float* u, float* v, int R, int C, int T, float* t_out,
+                                                 float* sigma_out, void* w, void* wt, void* ws, size_t ws_bytes,
+                                                 gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!w_bar || !u || !v || !t_out || !sigma_out || !w || !wt || !ws || R <= 0 || C <= 0 || T <= 0) return GCC_ERR_BAD_ARG;
+    if (ws_bytes < gcc_spectral_workspace(R, C, T)) return GCC_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int K = C * T;
+    float* scal = (float*)ws;
+    float* vt = scal + 64;
+    hipLaunchKernelGGL(sn_wtu_kernel, dim3((K + 63) / 64), dim3(1024), 0, st, w_bar, (const float*)u, R, K, vt, 1.f);
+    GCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sn_wv_kernel, dim3(R), dim3(256), 0, st, w_bar, (const float*)vt, K, scal, t_out);
+    GCC_CHECK_LAUNCH();
+    SnArgs a;
+    a.w = w_bar; a.u = u; a.v = v; a.R = R; a.C = C; a.T = T; a.vt = vt; a.t = t_out; a.scal = scal; a.w_eff = nullptr;
+    a.sigma_out = sigma_out;
+    hipLaunchKernelGGL(sn_finalize_kernel, dim3(nblocks(K, 64)), dim3(256), 0, st, a);
+    GCC_CHECK_LAUNCH();
+    const int colsp = (C + 7) & ~7, rowsp = (R + 7) & ~7;
+    hipLaunchKernelGGL(sn_scale_pack_kernel, dim3((colsp + 31) / 32, (rowsp + 31) / 32, T), dim3(256), 0, st, w_bar,
+                       (const float*)scal, R, T, C, colsp, rowsp, (unsigned short*)w, (unsigned short*)wt);
+    GCC_CHECK_LAUNCH();
     return GCC_OK;
 }
 

@@ -1061,8 +1061,11 @@ class SNConvOp:
         return SNState(self)
 
     def forward(self, st, x, out, act=ACT_NONE, slope=LRELU, want_stats=False, bn=None):
-        ops.spectral_power_iteration(self.w_bar.data, self.u.data, self.v.data, st.t, st.sigma, self.w_eff)
-        ops.pack_weights_into(self.w_eff, st.w, st.wt)
+        if ops.SN_FUSED_PACK and self.w_bar.data.is_contiguous(memory_format=torch.channels_last if self.k > 1 else torch.contiguous_format):
+            ops.spectral_power_iteration_pack(self.w_bar.data, self.u.data, self.v.data, st.t, st.sigma, st.w, st.wt)
+        else:
+            ops.spectral_power_iteration(self.w_bar.data, self.u.data, self.v.data, st.t, st.sigma, self.w_eff)
+            ops.pack_weights_into(self.w_eff, st.w, st.wt)
         b = self.bias.data if self.bias is not None else None
         if not self.transposed:
             return ops.conv_fprop(x, st.w, self.rows, self.k, self.stride, self.pad, out=out, bias=b, act=act, slope=slope,

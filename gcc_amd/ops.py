@@ -966,6 +966,18 @@ def spectral_power_iteration(w_bar, u, v, t_out, sigma_out, w_eff, slot='sn_fwd'
           'gcc_spectral_power_iteration')
 
 
+SN_FUSED_PACK = os.environ.get('GCC_SN_FUSED_PACK', '1') != '0'
+
+
+def spectral_power_iteration_pack(w_bar, u, v, t_out, sigma_out, w, wt, slot='sn_fwd'):
+    """the power iteration with W_bar / sigma written straight into the bf16 packings w / wt (4 launches instead of 7)"""
+    R, Cc, kh, kw = w_bar.shape
+    ws = workspace(lib().gcc_spectral_workspace(R, Cc, kh * kw), w_bar.device, slot)
+    check(lib().gcc_spectral_power_iteration_pack(w_bar.data_ptr(), u.data_ptr(), v.data_ptr(), R, Cc, kh * kw, t_out.data_ptr(),
+                                                  sigma_out.data_ptr(), w.data_ptr(), wt.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  stream()), 'gcc_spectral_power_iteration_pack')
+
+
 def spectral_grad(g_eff, w_bar, u, v, t_fwd, sigma_fwd, dw_bar, du=None, dv=None, slot='sn_bwd'):
     R, Cc, kh, kw = w_bar.shape
     ws = workspace(lib().gcc_spectral_workspace(R, Cc, kh * kw), w_bar.device, slot)

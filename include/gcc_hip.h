@@ -471,6 +471,11 @@ int gcc_distill_bwd(const void* f, int ldf, int foff, const void* t, int ldt, in
 size_t gcc_spectral_workspace(int R, int C, int T);
 int gcc_spectral_power_iteration(const float* w_bar, float* u, float* v, int R, int C, int T, float* t_out,
                                  float* sigma_out, float* w_eff, void* ws, size_t ws_bytes, gcc_stream_t stream);
+/* the same power iteration with W_eff written straight into the two bf16 packings of gcc_pack_weights (w: [R][T][C padded to 8],
+ * wt: [C][T][R padded to 8]) instead of an fp32 tensor: 4 launches instead of 7 for what a spectrally normalised convolution's
+ * forward does before its convolution (SpectralNorm.forward, models/SAGAN.py:56-70); same bits as the separate calls */
+int gcc_spectral_power_iteration_pack(const float* w_bar, float* u, float* v, int R, int C, int T, float* t_out,
+                                      float* sigma_out, void* w, void* wt, void* ws, size_t ws_bytes, gcc_stream_t stream);
 int gcc_spectral_grad(const float* g_eff, const float* w_bar, const float* u, const float* v, const float* t_fwd,
                       const float* sigma_fwd, int R, int C, int T, float* dw_bar, float* du, float* dv, void* ws,
                       size_t ws_bytes, gcc_stream_t stream);

@@ -60,6 +60,43 @@ def test_spectral_norm_power_iteration_and_gradient(shape, transposed):
     assert _rel(du.cpu(), u.grad) <= 1e-4 and _rel(dv.cpu(), vv.grad) <= 1e-4
 
 
+@pytest.mark.parametrize('shape', [(32, 16, 4, 4), (128, 24, 4, 4), (8, 3, 4, 4), (100, 52, 3, 3), (48, 48, 1, 1), (1, 384, 4, 4)])
+def test_spectral_power_iteration_fused_with_the_packings(shape):
+    """gcc_spectral_power_iteration_pack (W_bar / sigma straight into the two bf16 packings: 4 launches) against the separate route
+    (gcc_spectral_power_iteration + gcc_pack_weights: 7): u, v, t, sigma and both packings bit for bit, padding included"""
+    from gcc_amd import ops
+    R, Cc, k, _ = shape
+    g = torch.Generator().manual_seed(R + Cc)
+    w = (torch.randn(shape, generator=g) * 0.1).to(DEV)
+    wd = w.contiguous(memory_format=torch.channels_last) if k > 1 else w.contiguous()
+    u0, v0 = torch.randn(R, generator=g).to(DEV), torch.randn(Cc * k * k, generator=g).to(DEV)
+    outs = []
+    for fused in (False, True):
+        u, v = u0.clone(), v0.clone()
+        t, s = torch.zeros(R, device=DEV), torch.zeros(1, device=DEV)
+        pw = torch.full((ops.ceil8(R), k * k, ops.ceil8(Cc)), 7.0, dtype=torch.bfloat16, device=DEV)
+        pwt = torch.full((ops.ceil8(Cc), k * k, ops.ceil8(R)), 7.0, dtype=torch.bfloat16, device=DEV)
+        pw[R:] = 0                                   # rows beyond R are the allocation's zeros on both routes (never written)
+        ops.lib().gcc_launch_count(1)
+        if fused:
+            ops.spectral_power_iteration_pack(wd, u, v, t, s, pw, pwt)
+        else:
+            w_eff = torch.empty_like(wd)
+            ops.spectral_power_iteration(wd, u, v, t, s, w_eff)
+            ops.pack_weights_into(w_eff, pw, pwt)
+        n = int(ops.lib().gcc_launch_count(1))
+        torch.cuda.synchronize()
+        outs.append((u, v, t, s, pw, pwt, n))
+    a, b = outs
+    for x, y, what in zip(a[:6], b[:6], ('u', 'v', 't', 'sigma', 'W', 'Wt')):
+        assert torch.equal(x, y), what
+    if ops.ceil8(Cc) > Cc:
+        assert float(b[4][:R, :, Cc:].float().abs().max()) == 0.0      # padding columns of the rows that exist: zeros
+    if ops.ceil8(R) > R:
+        assert float(b[5][:Cc, :, R:].float().abs().max()) == 0.0
+    assert b[6] == 4 and a[6] >= 6, (a[6], b[6])
+
+
 @pytest.mark.parametrize('B,C,H', [(2, 64, 16), (3, 16, 8), (2, 512, 4), (1, 48, 32), (2, 96, 12), (2, 256, 8), (1, 64, 7),
                                    (2, 8, 32), (2, 32, 8), (1, 24, 9)])
 def test_self_attention_forward_backward(B, C, H):
