@@ -750,6 +750,7 @@ class INState:
         z = torch.zeros((4, N, Cc), dtype=torch.float32, device=device)
         self.mean, self.rstd, self.scale, self.shift = z[0], z[1], z[2], z[3]
         self.N = N
+        self.ptrs = (z[0].data_ptr(), z[1].data_ptr(), z[2].data_ptr(), z[3].data_ptr())       # (the host's hot path: one tuple, no tensor calls)
 
 
 def channel_stats(x):
@@ -824,6 +825,30 @@ def inorm_workspace(device):
     return ws
 
 
+_inorm_ws_raw = {}
+
+
+def _inorm_ws_ptr(device, raw):
+    """(pointer, bytes) of the stream's InstanceNorm workspace: the per-launch form of inorm_workspace"""
+    got = _inorm_ws_raw.get(raw)
+    if got is None:
+        ws = inorm_workspace(device)
+        got = _inorm_ws_raw[raw] = (ws.data_ptr(), ws.numel())
+    return got
+
+
+def _inorm_fwd_c(*a):
+    global _inorm_fwd_c
+    _inorm_fwd_c = lib().gcc_inorm_fwd           # bound once: the launch path then calls the ctypes function object directly
+    return _inorm_fwd_c(*a)
+
+
+def _inorm_bwd_c(*a):
+    global _inorm_bwd_c
+    _inorm_bwd_c = lib().gcc_inorm_bwd
+    return _inorm_bwd_c(*a)
+
+
 def inorm_fwd(x, y, st, act=ACT_NONE, slope=0.2, residual=None, eps=1e-5):
     """InstanceNorm2d(affine=False) + activation (+ residual) in one launch; st (INState) receives mean / rstd"""
     xp, N, Cc, H, W, ldx = geom(x)
@@ -831,9 +856,12 @@ def inorm_fwd(x, y, st, act=ACT_NONE, slope=0.2, residual=None, eps=1e-5):
     rp, ldr = (None, 0)
     if residual is not None:
         rp, _, _, _, _, ldr = geom(residual)
-    ws = inorm_workspace(x.device)
-    check(lib().gcc_inorm_fwd(xp, ldx, yp, ldy, rp, ldr, Cc, H * W, N, act, slope, eps, st.mean.data_ptr(), st.rstd.data_ptr(),
-                              st.scale.data_ptr(), st.shift.data_ptr(), ws.data_ptr(), ws.numel(), stream()), 'gcc_inorm_fwd')
+    raw = stream()
+    wsp, wsb = _inorm_ws_ptr(x.device, raw)
+    m, r, sc, sh = st.ptrs
+    rc = _inorm_fwd_c(xp, ldx, yp, ldy, rp, ldr, Cc, H * W, N, act, slope, eps, m, r, sc, sh, wsp, wsb, raw)
+    if rc:
+        check(rc, 'gcc_inorm_fwd')
 
 
 def inorm_bwd(x, y, g, dx, st, act=ACT_NONE, slope=0.2):
@@ -843,9 +871,11 @@ def inorm_bwd(x, y, g, dx, st, act=ACT_NONE, slope=0.2):
         yp, _, _, _, _, ldy = geom(y)
     gp, _, _, _, _, ldg = geom(g)
     dxp, _, _, _, _, lddx = geom(dx)
-    ws = inorm_workspace(x.device)
-    check(lib().gcc_inorm_bwd(xp, ldx, yp, ldy, gp, ldg, dxp, lddx, Cc, H * W, N, act, slope, st.mean.data_ptr(),
-                              st.rstd.data_ptr(), ws.data_ptr(), ws.numel(), stream()), 'gcc_inorm_bwd')
+    raw = stream()
+    wsp, wsb = _inorm_ws_ptr(x.device, raw)
+    rc = _inorm_bwd_c(xp, ldx, yp, ldy, gp, ldg, dxp, lddx, Cc, H * W, N, act, slope, st.ptrs[0], st.ptrs[1], wsp, wsb, raw)
+    if rc:
+        check(rc, 'gcc_inorm_bwd')
 
 
 def bnact_fwd(x, y, y2=None, scale=None, shift=None, gate=None, gate_after_act=False, act=ACT_NONE, slope=0.2,
