@@ -482,6 +482,8 @@ def main():
         dt = float(t.item())
     losses = model.get_current_losses()
     comm = allreduce_table(model, device) if world > 1 else None
+    from gcc_amd import dist as gdist
+    rccl_ranks = gdist.rccl_ranks() if world > 1 else 1          # collective: every rank calls it
     if rank != 0:
         return
     imgs = world * args.batch * args.steps
@@ -506,7 +508,7 @@ def main():
         if 'conv_roofline' in roof:       # north_star: throughput as a fraction of the conv roofline
             roof['conv_roofline']['frac_of_step'] = round(roof['conv_roofline']['bound_ms'] / (1000.0 * dt / args.steps), 4)
         out['roofline'] = roof
-    out['rccl_ranks'] = world
+    out['rccl_ranks'] = rccl_ranks
     if comm is not None:
         out['allreduce'] = comm
     if world == 1 and not args.no_cpu_baseline:

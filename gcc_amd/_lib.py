@@ -186,6 +186,7 @@ PROTOTYPES = {
     'gcc_cast_bf16_f32': (_I, [_P, _P, _Z, _P]),
     'gcc_comm_rank': (_I, [_P]),
     'gcc_comm_world': (_I, [_P]),
+    'gcc_comm_count': (_I, [_P]),
     'gcc_comm_destroy': (_I, [_P]),
     'gcc_comm_last_error': (C.c_char_p, []),
 }

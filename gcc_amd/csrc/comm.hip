@@ -33,6 +33,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*CommCount)(const ncclComm_t, int*);       // optional: gcc_comm_count answers GCC_ERR_UNSUPPORTED without it
     const char* (*GetErrorString)(ncclResult_t);
     bool ok;
 };
@@ -52,6 +53,7 @@ const RcclApi& rccl() {
         g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
         g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
         g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+        g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
         g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
         g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.AllReduce && g_rccl.CommDestroy;
     });
@@ -122,6 +124,18 @@ extern "C" int gcc_comm_allreduce_sum_bf16(gcc_comm_t* c, void* buf, size_t coun
 
 extern "C" int gcc_comm_rank(const gcc_comm_t* c) { return c ? c->rank : GCC_ERR_BAD_ARG; }
 extern "C" int gcc_comm_world(const gcc_comm_t* c) { return c ? c->world : GCC_ERR_BAD_ARG; }
+
+// the number of ranks RCCL itself reports for the communicator (ncclCommCount) -- what a scaling report should print, not the
+// launcher's WORLD_SIZE
+extern "C" int gcc_comm_count(const gcc_comm_t* c) {
+    GCC_ENTER();
+    if (!c) return GCC_ERR_BAD_ARG;
+    const RcclApi& r = rccl();
+    if (!r.ok || !r.CommCount) return GCC_ERR_UNSUPPORTED;
+    int n = 0;
+    if (!rccl_ok(r.CommCount(c->comm, &n))) return GCC_ERR_LAUNCH;
+    return n;
+}
 
 extern "C" int gcc_comm_destroy(gcc_comm_t* c) {
     GCC_ENTER();

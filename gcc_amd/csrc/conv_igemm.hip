@@ -91,7 +91,9 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
     const int m0 = mt * BP;
     const int n0 = nt * BC;
     if (m0 >= M) {         // smaller phase (odd sizes): uniform exit, no barrier reached yet
-        if (p.stats) {
+        // pair split: both K halves of an empty tile land here; only half 0 counts (a full tile reaches the epilogue once,
+        // through its second-arriving half, and make_tail's wgs_per_row = ntiles assumes one arrival per tile)
+        if (p.stats && (!p.pair || blockIdx.y == 0)) {
             const int trow = blockIdx.z * p.mtiles_max + mt;
             if (tid < BC && n0 + tid < p.Cout) {
                 st_stat(p.stats + ((size_t)trow * 2 + 0) * p.Cout + n0 + tid, 0.f, p.fin.tickets != nullptr);
@@ -1146,8 +1148,16 @@ __global__ __launch_bounds__(256) void thin_fprop_kernel(const ThinArgs a) {
 }
 
 static bool thin_enabled() { return gcc_opt(GCC_OPT_IGEMM_THIN) != 0; }
+// launch_thin's own size limits (32-bit buffer offsets of the input, the pixel counter) are part of the shape test: what
+// gcc_conv_y2_supported() promises is exactly what launch_thin() takes
+static bool thin_sizes_ok(const gcc_conv_t* c) {
+    const size_t xb = (size_t)c->N * c->H * c->W * c->ldx * 2;
+    const size_t outs = (size_t)c->N * gcc_conv_out(c->H, c->KH, c->stride, c->pad) * gcc_conv_out(c->W, c->KW, c->stride, c->pad);
+    return xb < OOB && outs < ((size_t)1 << 30);
+}
 static bool thin_shape(const gcc_conv_t* c) {
-    return ceil8(c->Ci) == 8 && c->KH * c->KW <= 16 && c->Co >= 16 && (size_t)c->Co * c->KH * c->KW * 16 < OOB && thin_enabled();
+    return ceil8(c->Ci) == 8 && c->KH * c->KW <= 16 && c->Co >= 16 && (size_t)c->Co * c->KH * c->KW * 16 < OOB && thin_enabled() &&
+           thin_sizes_ok(c);
 }
 static int launch_thin(const gcc_conv_t* c, const void* x, const void* w, void* y, const gcc_epilogue_t* ep, hipStream_t st) {
     ThinArgs a;

@@ -100,39 +100,67 @@ _route = None
 
 def comm_route():
     """Which library carries the gradient exchange of the iteration.
+    'torch' (default since round 5): torch.distributed's all_reduce on ProcessGroupNCCL (= RCCL) -- the one route that has
+    been rehearsed end to end: gloo world 2 on CPU (tests/test_dist_cpu.py), one-rank RCCL on the GPU box (tests/test_dp_gpu.py),
+    the driver's command line (test_bench_two_ranks_driver_command_line).
     'native': the C ABI's own communicator (gcc_comm_allreduce_sum_*, csrc/comm.hip: RCCL on the CALLER's stream -- the
     weight-gradient side stream -- so the step stays on its four hardware queues, and the call is part of a launch recording:
-    data parallelism and gcc_amd.replay compose).  'torch': torch.distributed's all_reduce(async_op=True) on
-    ProcessGroupNCCL's own stream (a fifth busy queue: profiles/r3_summary.md measures -36 % with five hardware queues).
-    GCC_DP_COMM=native / torch forces one.  Default (round 4): native wherever it can work -- an RCCL process group of more
-    than one rank whose communicator can be created and whose bucket self-check passes (bucket_selfcheck) -- else torch, with
-    a warning; never the other way round."""
+    data parallelism and gcc_amd.replay compose).  Opt-in with GCC_DP_COMM=native: its creation (ncclCommInitRank) has never
+    run on two devices of this pool, and a hang inside it cannot be recovered from in-process.  Even when
+    asked for it is latched only after every rank (i) resolved RCCL and made an id alone, (ii) created the communicator,
+    (iii) passed a one-element all-reduce probe through it, (iv) reports the communicator's own rank count (ncclCommCount) equal
+    to the process group's -- each stage voted on by all ranks BEFORE the next collective is entered, so a rank that fails
+    alone never leaves the others inside one; anything else falls back to 'torch' with a warning."""
     global _route
+    if _route is not None:
+        return _route
     env = os.environ.get('GCC_DP_COMM')
-    if env in ('native', 'torch'):
-        return env
-    if _route is None:
-        _route = 'torch'
-        if is_dist() and world_size() > 1 and torch.cuda.is_available() and dist.get_backend() == 'nccl':
-            # the choice is made by all ranks together (a rank that went its own way would leave the others inside a collective):
-            # first everything a rank can find out alone (library loads, RCCL resolves), then the communicator's creation
-            why = None
+    _route = 'torch'
+    if env == 'native' and not (is_dist() and world_size() > 1):
+        _route = 'native' if torch.cuda.is_available() else 'torch'      # one rank: nothing to vote on (tests, recordings)
+    elif env == 'native' and torch.cuda.is_available() and dist.get_backend() == 'nccl':
+        why = None
+        try:
+            NativeComm.unique_id()                        # (i) rank-local: the library loads, RCCL resolves
+        except Exception as e:
+            why = '%s: %s' % (type(e).__name__, e)
+        if _all_ranks(why is None):
             try:
-                NativeComm.unique_id()
+                native_comm()                             # (ii) collective: every rank enters it (voted above)
             except Exception as e:
                 why = '%s: %s' % (type(e).__name__, e)
             if _all_ranks(why is None):
-                try:
-                    native_comm()
-                except Exception as e:      # communicator creation refused ...
+                try:                                      # (iii) + (iv)
+                    probe = torch.full((1,), float(rank() + 1), dtype=torch.float32, device=torch.device('cuda', torch.cuda.current_device()))
+                    native_comm().all_reduce_sum_(probe)
+                    torch.cuda.synchronize()
+                    w = world_size()
+                    if float(probe.item()) != w * (w + 1) / 2.0:
+                        why = 'probe all-reduce returned %r' % float(probe.item())
+                    elif native_comm().count() != w:
+                        why = 'ncclCommCount %d != world %d' % (native_comm().count(), w)
+                except Exception as e:
                     why = '%s: %s' % (type(e).__name__, e)
                 if _all_ranks(why is None):
                     _route = 'native'
-                else:
-                    _drop_native()
-            if _route != 'native':
-                _warn('native RCCL communicator unavailable (%s): gradient exchange through torch.distributed' % (why or 'on another rank'))
+        if _route != 'native':
+            _drop_native()
+            _warn('native RCCL communicator unavailable (%s): gradient exchange through torch.distributed' % (why or 'on another rank'))
     return _route
+
+
+def rccl_ranks():
+    """how many ranks the communicator that carries the gradient exchange really spans: ncclCommCount of the C ABI's
+    communicator on the native route; on the torch route a sum of ones over the process group (what an all-reduce on that
+    backend actually reaches) -- never a copy of WORLD_SIZE"""
+    if not is_dist():
+        return 1
+    if comm_route() == 'native' and _native is not None:
+        return int(_native.count())
+    dev = torch.device('cuda', torch.cuda.current_device()) if (torch.cuda.is_available() and dist.get_backend() == 'nccl') else 'cpu'
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(round(float(one.item())))
 
 
 def _all_ranks(ok):
@@ -223,7 +251,7 @@ def bucket_selfcheck(device):
         flag = torch.tensor([1.0 if bool((buf == want).all()) else 0.0], device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item() == 1.0)
-        if not ok and route == 'native' and os.environ.get('GCC_DP_COMM') != 'native':
+        if not ok and route == 'native':
             _warn('bucketed all-reduce self-check FAILED on the native route: gradient exchange through torch.distributed')
             _selfcheck[key] = False
             _route = 'torch'
@@ -420,6 +448,14 @@ class NativeComm:
         _lib.check(self._lib.gcc_comm_allreduce_sum_bf16(self._h, buf.data_ptr(), buf.numel(),
                                                          ops.stream() if stream is None else stream), 'gcc_comm_allreduce_sum_bf16')
         return buf
+
+    def count(self):
+        """ncclCommCount of the communicator"""
+        n = int(self._lib.gcc_comm_count(self._h))
+        if n < 0:
+            from . import _lib
+            raise _lib.GccError('gcc_comm_count: %s' % self._lib.gcc_strerror(n).decode())
+        return n
 
     def close(self):
         if getattr(self, '_h', None):

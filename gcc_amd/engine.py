@@ -429,8 +429,8 @@ class UnetEngine:
     ablate_skip = False
 
     def _forward(self, N, H, W, train=True, slot=0):
-        if self.ablate_skip and (N, H, W) in self.ctx:
-            return self.ctx[(N, H, W)]
+        if self.ablate_skip and ((N, H, W) if slot == 0 else (N, H, W, slot)) in self.ctx:
+            return self._ctx(N, H, W, slot)
         c = self._ctx(N, H, W, slot)
         D, wd, uw = self.D, self.width, self.uwidth
         c.train = train

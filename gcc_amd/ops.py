@@ -414,9 +414,14 @@ def geom(t):
     d = t.__dict__
     g = d.get('_gcc_geom')
     if g is not None:
+        if GEOM_CHECK and g != _geom(t):       # GCC_DEBUG_GEOM=1 (tests/conftest.py sets it): the invariant above, enforced
+            raise AssertionError('activation re-homed or resized in place: cached %r, now %r' % (g, _geom(t)))
         return g
     g = d['_gcc_geom'] = _geom(t)
     return g
+
+
+GEOM_CHECK = os.environ.get('GCC_DEBUG_GEOM', '0') != '0'
 
 
 def _geom(t):

@@ -16,8 +16,8 @@ What makes the iteration replayable:
     the CycleGAN image pool's random draws);
   * anything else that changes a launch argument invalidates the recording: call invalidate() after update_learning_rate(),
     adaptive_ema_beta(), pruning, a changed batch shape (step() checks shapes itself); the next step() records again.
-Data parallelism: the gradient all-reduces of the C ABI's own communicator (dist.comm_route() 'native', the default on an RCCL
-process group) are recorded like launches and replayed from ONE host thread in the recorded order (the same on every rank);
+Data parallelism: the gradient all-reduces of the C ABI's own communicator (dist.comm_route() 'native': GCC_DP_COMM=native, opt-in
+since round 5) are recorded like launches and replayed from ONE host thread in the recorded order (the same on every rank);
 with the exchange on torch.distributed step() stays eager.  So does a model class that says `replay_supported = False`:
 Pix2Pix with dropout on (the dropout seeds are by-value launch arguments that nothing patches -- and its iteration is bound by
 its convolutions, not by the host: the eager host enqueues a step in 5.8 ms and runs ahead of the 15.6 ms the device needs

@@ -87,10 +87,11 @@ enum {
                                    less CU time per launch, the free CUs run the other streams' kernels (the multi-stream
                                    production schedule: +1 % on the step).  gcc_amd's models switch it with their schedule. */
     GCC_OPT_WGRAD_BIG_MIN_TILES,/* minimum number of 256x256 output tiles for the big weight-gradient tiling (default 32) */
-    GCC_OPT_FUSE_BN,            /* gcc_conv_bn_act: 3: a split layer's K slices folded, statistics exchanged inside the launch and rows normalised by
-                                   one kernel on the whole chip (bn_fold_grid_kernel; needs gcc_bn_t.tail_ws; other layers as 1); 2: BatchNorm finalized by the last-arriving workgroups of the launch that writes the
-                                   statistic rows (gcc_bn_t.tail_ws), split layers folded by one full-chip kernel; 1: the round-2 form (a split
-                                   layer's partials, statistics, finalize and normalise in one kernel of C / 8 workgroups; default: measured faster, profiles/r4_summary.md); 0: separate launches */
+    GCC_OPT_FUSE_BN,            /* gcc_conv_bn_act: 3 (default; profiles/r4_summary.md): a split layer's K slices folded, statistics exchanged inside the
+                                   launch and rows normalised by one kernel on the whole chip (bn_fold_grid_kernel; needs gcc_bn_t.tail_ws; other
+                                   layers as 1); 2: BatchNorm finalized by the last-arriving workgroups of the launch that writes the statistic
+                                   rows (gcc_bn_t.tail_ws), split layers folded by one full-chip kernel; 1: the round-2 form (a split layer's
+                                   partials, statistics, finalize and normalise in one kernel of C / 8 workgroups); 0: separate launches */
     GCC_OPT_BN_BWD_SMALL,       /* 1 (default): gcc_bnact_bwd of <= 4096 pixels (training BatchNorm, no gate) runs as one kernel instead of
                                    three, gcc_channel_sum of <= 16384 pixels as one instead of two */
     GCC_OPT_WGRAD_ROW_TABLE,    /* 1 (default): the weight-gradient kernel decomposes each pixel of a workgroup's range once, into an LDS table
@@ -620,6 +621,7 @@ int gcc_cast_f32_bf16(const float* src, void* dst, size_t n, gcc_stream_t stream
 int gcc_cast_bf16_f32(const void* src, float* dst, size_t n, gcc_stream_t stream);
 int gcc_comm_rank(const gcc_comm_t* comm);
 int gcc_comm_world(const gcc_comm_t* comm);
+int gcc_comm_count(const gcc_comm_t* comm);      /* ncclCommCount of the communicator (>= 1), or a negative error code */
 int gcc_comm_destroy(gcc_comm_t* comm);
 /* RCCL's own message for the calling thread's last failing gcc_comm_* call ("" if none failed): a GCC_ERR_LAUNCH from this
  * group otherwise hides which ncclResult it was */

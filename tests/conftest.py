@@ -8,6 +8,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+# the cached activation geometry of gcc_amd.ops.geom is re-derived and compared on every use under the tests
+os.environ.setdefault('GCC_DEBUG_GEOM', '1')
 
 
 def pytest_configure(config):

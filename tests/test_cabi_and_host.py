@@ -52,7 +52,7 @@ def test_comm_entry_points_without_a_gpu():
     assert lib.gcc_comm_init(None, 0, 1, bytes(buf)) == -1
     assert lib.gcc_comm_allreduce_sum_f32(None, None, 0, None) == -1
     assert lib.gcc_comm_destroy(None) == -1
-    assert lib.gcc_comm_rank(None) == -1 and lib.gcc_comm_world(None) == -1
+    assert lib.gcc_comm_rank(None) == -1 and lib.gcc_comm_world(None) == -1 and lib.gcc_comm_count(None) == -1
     import subprocess
     out = subprocess.run(['readelf', '-d', _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert 'rccl' not in out, 'libgcc_hip.so must not depend on RCCL at load time'

@@ -141,6 +141,7 @@ def _native_worker(rank, world, uid, q):
     th.cuda.set_device(rank)
     ops.set_device_index(rank)
     comm = gdist.NativeComm(rank, world, uid)
+    assert comm.count() == world, (comm.count(), world)          # ncclCommCount, not the launcher's word
     g = th.Generator().manual_seed(3 + rank)
     host = th.randn(1 << 20, generator=g)
     buf = host.to('cuda:%d' % rank)

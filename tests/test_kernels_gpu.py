@@ -382,6 +382,24 @@ FINALIZE_CASES = [
 
 @pytest.mark.parametrize('case', FINALIZE_CASES)
 def test_bn_finalize_in_conv_matches_separate_launch(case, monkeypatch):
+    _finalize_in_conv_case(case, monkeypatch)
+
+
+def test_bn_finalize_in_conv_pair_split_unequal_phases(monkeypatch, conv_plan):
+    """a data gradient with BatchNorm statistics on the pair-split 256x256 plan whose stride-2 phases hold different
+    numbers of tiles (23 x 23: phases of 2, 2, 2 and 1 row tiles) -- both K halves of the empty tile reach the early exit and only
+    one of them may take a ticket, else the finalize fires early and the ticket words stay non-zero for the next launch on the
+    same tail workspace (three launches in a row here)."""
+    from gcc_amd import _lib
+    case = (2, 23, 23, 256, 768, 4, 2, True)
+    conv_plan('tile256x256_pair')
+    assert _tiles(case[:7] + (1,))[1] == 256256, 'the case must run 256x256 tiles'
+    d = _lib.conv_t(2, 23, 23, 256, 768, 4, 4, 2, 1, 256, 0, 768, 0)
+    assert _lib.load().gcc_conv_workspace(C.byref(d), 1) > 256 * 256 * 4, 'pair split not planned for this geometry'
+    _finalize_in_conv_case(case, monkeypatch)
+
+
+def _finalize_in_conv_case(case, monkeypatch):
     """round 4: with gcc_epilogue_t.bn the BatchNorm behind a conv is finalized by the last-arriving workgroups of the launch
     that writes the statistic rows (stats_tail).  Same canonical summation order as gcc_bn_finalize: coefficients, saved
     statistics and running statistics must be BIT-identical with the separate launch over the same rows (GCC_IN_CONV_FINALIZE=0
