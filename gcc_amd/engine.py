@@ -286,9 +286,14 @@ class UnetEngine:
     multiples of 8 (pruned, irregular widths: see DESIGN.md 'next')."""
 
     def __init__(self, module, num_downs, device, use_dropout=False):
-        self.module, self.D, self.device = module, num_downs, device
-        D = num_downs
+        # D = number of blocks that are BUILT (a pruned generator may have lost inner blocks: UnetGenertor.present); everything
+        # below goes by nesting position, as the reference's module names do
+        D = len(getattr(module, 'present', range(num_downs)))
+        self.module, self.D, self.device = module, D, device
         self.use_dropout = use_dropout
+        # last block = a loop block around Identity (models/Pix2Pix.py:59-67) instead of the innermost kind: conv, BatchNorm, ReLU
+        self.inner_identity = bool(getattr(module, 'inner_identity', False))
+        ii = self.inner_identity
 
         def prefix(d):
             return 'model' if d == 0 else 'model.model.1' + '.model.3' * (d - 1)
@@ -299,14 +304,14 @@ class UnetEngine:
             cname = p + ('.model.0' if d == 0 else '.model.1')
             c = _get(module, cname)
             self.down[d] = ConvOp(c.weight, c.bias, 4, 2, 1, False)
-            if 0 < d < D - 1:
+            if 0 < d < D - 1 or (d == D - 1 and ii):
                 self.down_bn[d] = BNOp(_get(module, p + '.model.2'))
-            uname = p + ('.model.3' if d in (0, D - 1) else '.model.5')
+            uname = p + ('.model.3' if (d == 0 or (d == D - 1 and not ii)) else '.model.5')
             u = _get(module, uname)
             # the up conv at depth d < D-1 reads cat(skip e[d] | up output of depth d+1): rows are a concatenation
             self.up[d] = ConvOp(u.weight, u.bias, 4, 2, 1, True, row_split=(self.down[d].rows if d < D - 1 else 0))
             if d > 0:
-                self.up_bn[d] = BNOp(_get(module, p + ('.model.4' if d == D - 1 else '.model.6')))
+                self.up_bn[d] = BNOp(_get(module, p + ('.model.4' if (d == D - 1 and not ii) else '.model.6')))
         self.width = [self.down[d].rows for d in range(D)]          # channels of e[d]
         self.uwidth = [self.up[d].cols for d in range(D)]           # channels of the up-conv output at depth d
         # channel offset of the up-path part inside the concat buffer of depth d (skip part padded to 8)
@@ -316,7 +321,10 @@ class UnetEngine:
         # padded inside it, else the plain sum (same convention as ConvOp.rows_k / cols_k)
         self.catc = [0] + [self.catw[d] if self.width[d - 1] % 8 else self.width[d - 1] + self.uwidth[d]
                            for d in range(1, D)]
-        self.drop_depths = [D - 2 - i for i in range(D - 5)] if use_dropout else []
+        self.drop_depths = ([D - 2 - i for i in range(D - 5)] if not hasattr(module, 'dropout_positions')
+                            else list(module.dropout_positions)) if use_dropout else []
+        if D < 5 and not (D == 4 and ii):
+            raise NotImplementedError('U-Net of %d blocks' % D)
         self.hook_names = ['model.model.1.model.2', 'model.model.1.model.3.model.3.model.2',
                            'model.model.1.model.3.model.3.model.4', 'model.model.1.model.4']
         self.ctx = {}
@@ -329,20 +337,22 @@ class UnetEngine:
     def grad_segments(module, num_downs):
         """parameters grouped in the order _backward() completes their gradients (one segment per layer: conv weight / bias
         with the BatchNorm behind it): up[0], up[1] .. up[D-1], down[D-1] .. down[0].  Same name scheme as __init__."""
-        D = num_downs
+        D = len(getattr(module, 'present', range(num_downs)))
+        ii = bool(getattr(module, 'inner_identity', False))
         prefix = lambda d: 'model' if d == 0 else 'model.model.1' + '.model.3' * (d - 1)
         par = lambda name: [p for p in _get(module, name).parameters()]
         segs = []
         for d in range(D):
             p = prefix(d)
-            seg = par(p + ('.model.3' if d in (0, D - 1) else '.model.5'))
+            inner = d == D - 1 and not ii
+            seg = par(p + ('.model.3' if (d == 0 or inner) else '.model.5'))
             if d > 0:
-                seg = par(p + ('.model.4' if d == D - 1 else '.model.6')) + seg
+                seg = par(p + ('.model.4' if inner else '.model.6')) + seg
             segs.append(seg)
         for d in range(D - 1, -1, -1):
             p = prefix(d)
             seg = par(p + ('.model.0' if d == 0 else '.model.1'))
-            if 0 < d < D - 1:
+            if 0 < d < D - 1 or (d == D - 1 and ii):
                 seg = par(p + '.model.2') + seg
             segs.append(seg)
         return segs
@@ -384,12 +394,15 @@ class UnetEngine:
             if d < D - 1:
                 c.lin[d + 1] = ops.new_act(N, wd[d], h, w, dev)
                 c.rcat[d + 1] = ops.new_act(N, self.catc[d + 1], h, w, dev, ld=self.catw[d + 1])
-            if 0 < d < D - 1:
+            if 0 < d < D - 1 or (d == D - 1 and self.inner_identity):
                 c.st_down[d] = ops.BNState(wd[d], dev)
             if d >= 1:
                 hh, ww = hs[d - 1]
                 c.t[d] = ops.new_act(N, uw[d], hh, ww, dev)
                 c.st_up[d] = ops.BNState(uw[d], dev)
+        # last block around Identity: relu(bn(e[D-1])) is what its transposed conv reads (the innermost kind fuses the ReLU
+        # into the conv and reads e[D-1] itself)
+        c.e_act = ops.new_act(N, wd[D - 1], hs[D - 1][0], hs[D - 1][1], dev) if self.inner_identity else c.e[D - 1]
         c.out = ops.new_act(N, 3, H, W, dev)
         # gradient buffers
         c.g_out = ops.new_act(N, 3, H, W, dev)
@@ -405,6 +418,7 @@ class UnetEngine:
                 hh, ww = hs[d - 1]
                 c.g_t[d] = ops.new_act(N, uw[d], hh, ww, dev)
         c.g_e_last = ops.new_act(N, wd[D - 1], hs[D - 1][0], hs[D - 1][1], dev)
+        c.g_e_in = ops.new_act(N, wd[D - 1], hs[D - 1][0], hs[D - 1][1], dev) if self.inner_identity else None
         c.g_e = [ops.new_act(N, wd[d], hs[d][0], hs[d][1], dev) for d in range(D - 1)]
         c.train = True
         c.iter_seed = 0
@@ -412,7 +426,11 @@ class UnetEngine:
         return c
 
     def features(self, c):
-        """the four hooked tensors, in the reference's order"""
+        """the four hooked tensors, in the reference's order.  Four blocks only (everything below depth 3 pruned away): the
+        BatchNorm output of block 3 is overwritten in place by that block's own ReLU (Identity hands the same tensor on), so
+        both of its hooks see relu(bn(e[3])) (hazard H1)"""
+        if self.D == 4:
+            return [c.lin[2], c.e_act, c.e_act, c.rcat[2]]
         return [c.lin[2], c.lin[4], c.rcat[4], c.rcat[2]]
 
     # ---------------------------------------------------------------------------------------
@@ -455,9 +473,21 @@ class UnetEngine:
                 self.down_bn[d].finalize(stats, n, c.st_down[d], train)
             ops.bnact_fwd(c.e[d], c.lin[d + 1], ops.cslice(c.rcat[d + 1], 0, wd[d]), scale=c.st_down[d].scale,
                           shift=c.st_down[d].shift, act=ACT_LRELU, act2=ACT_RELU)
-        self.down[D - 1].forward(c.lin[D - 1], c.e[D - 1], act=ACT_RELU)      # innermost: conv + ReLU fused
+        if not self.inner_identity:
+            self.down[D - 1].forward(c.lin[D - 1], c.e[D - 1], act=ACT_RELU)      # innermost: conv + ReLU fused
+        else:                    # a loop block around Identity: conv, BatchNorm, (in-place) ReLU
+            d, n = D - 1, N * c.hs[D - 1][0] * c.hs[D - 1][1]
+            if fused and self.down[d].bias is None and not (self.down[d].row_split or self.down[d].col_split):
+                self.down[d].forward_bn_act(c.lin[d], c.e[d], self.down_bn[d], c.st_down[d], n, c.e_act, None, act=ACT_RELU)
+            else:
+                if train:
+                    self.down[d].forward(c.lin[d], c.e[d], want_stats=True, bn=self.down_bn[d].desc(c.st_down[d], n, self.device))
+                else:
+                    _, stats = self.down[d].forward(c.lin[d], c.e[d], want_stats=True)
+                    self.down_bn[d].finalize(stats, n, c.st_down[d], train)
+                ops.bnact_fwd(c.e[d], c.e_act, scale=c.st_down[d].scale, shift=c.st_down[d].shift, act=ACT_RELU)
         # ---- up path
-        src = c.e[D - 1]
+        src = c.e_act
         for d in range(D - 1, 0, -1):
             hh, ww = c.hs[d - 1]
             drop = 0.5 if (train and d in self.drop_depths) else 0.0
@@ -513,17 +543,29 @@ class UnetEngine:
                           gamma=bn.weight.data, beta=bn.bias.data, bn_eval=not c.train, act=ACT_RELU, drop_p=drop,
                           seed=c.iter_seed * 64 + d, dgamma=bn.weight.grad if wgrad else None,
                           dbeta=bn.bias.grad if wgrad else None)
-            src = c.e[D - 1] if d == D - 1 else c.rcat[d + 1]
+            src = c.e_act if d == D - 1 else c.rcat[d + 1]
             if wgrad:
                 self.up[d].backward_weight(src, c.g_t[d])
                 self._seg_done(d)
             self.up[d].backward_data(c.g_t[d], c.g_e_last if d == D - 1 else c.g_rcat[d + 1])
-        # innermost down conv (+ fused ReLU)
-        ops.bnact_bwd(c.e[D - 1], None, c.g_e_last, c.g_e_last, in_act=ACT_RELU)
+        if not self.inner_identity:
+            # innermost down conv (+ fused ReLU)
+            ops.bnact_bwd(c.e[D - 1], None, c.g_e_last, c.g_e_last, in_act=ACT_RELU)
+        else:
+            # loop block around Identity: ReLU + BatchNorm backward (four blocks: block 3's two hooked tensors are this ReLU's output)
+            if D == 4:
+                for gf in (g_feat[1], g_feat[2]):
+                    if gf is not None:
+                        ops.nhwc_add(gf, 0, c.g_e_last, 0, wd[D - 1])
+            bn = self.down_bn[D - 1].bn
+            ops.bnact_bwd(c.e[D - 1], None, c.g_e_last, c.g_e_in, bn=c.st_down[D - 1], gamma=bn.weight.data, beta=bn.bias.data,
+                          bn_eval=not c.train, act=ACT_RELU, dgamma=bn.weight.grad if wgrad else None,
+                          dbeta=bn.bias.grad if wgrad else None)
+        g_in = c.g_e_in if self.inner_identity else c.g_e_last
         if wgrad:
-            self.down[D - 1].backward_weight(c.lin[D - 1], c.g_e_last)
+            self.down[D - 1].backward_weight(c.lin[D - 1], g_in)
             self._seg_done(D)
-        self.down[D - 1].backward_data(c.g_e_last, c.g_lin[D - 1])
+        self.down[D - 1].backward_data(g_in, c.g_lin[D - 1])
         for d in range(D - 2, -1, -1):
             # e[d] feeds lin[d+1] (LeakyReLU) and rcat[d+1][:w] (ReLU)
             if d == 1 and g_feat[0] is not None:

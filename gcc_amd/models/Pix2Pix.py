@@ -47,13 +47,20 @@ def _bn(c):
 
 class UnetGenertor(nn.Module):
     """Parameter tree of the reference's UnetGenertor (models/Pix2Pix.py:79-130; spelling kept).
-    Depth d block prefix: 'model' (d=0) / 'model.model.1' + '.model.3'*(d-1)."""
+    Block at nesting position j: prefix 'model' (j=0) / 'model.model.1' + '.model.3'*(j-1).
+
+    Pruned cfgs may remove blocks (models/Pix2Pix.py:87, 97): the innermost block (depth 7) when filter_cfgs[7] or [8] is 0,
+    a loop block (depths 6, 5, 4) when filter_cfgs[6-i] or [9+i] is 0.  `present` lists the depths that are built, outermost
+    first; the nesting (and with it every state_dict key) goes by position in that list, as in the reference where a parent
+    simply wraps whatever block was built last.  When the innermost block is absent the last block is a loop block around
+    Identity (:59-67): conv, BatchNorm, ReLU, transposed conv, BatchNorm -- `inner_identity`."""
 
     def __init__(self, input_nc, output_nc, num_downs, ngf=64, norm_layer=None, use_dropout=False,
                  filter_cfgs=None, channel_cfgs=None):
         super().__init__()
         D = num_downs
         self.num_downs, self.use_dropout = D, use_dropout
+        present = list(range(D))
         if filter_cfgs is None:
             wd = [min(ngf * 2 ** d, ngf * 8) for d in range(D)]
             down_in = [input_nc] + wd[:-1]
@@ -62,31 +69,49 @@ class UnetGenertor(nn.Module):
         else:
             if D != 8:
                 raise NotImplementedError('filter_cfgs describe the num_downs=8 generator')
-            if any(int(v) == 0 for v in list(filter_cfgs)[:15]) or any(int(v) == 0 for v in list(channel_cfgs)[:15]):
-                raise NotImplementedError('pruned generators with removed blocks (zero widths) are not on the '
-                                          'MI355X path yet')
             f, c = [int(v) for v in filter_cfgs], [int(v) for v in channel_cfgs]
             wd = f[:8]
             down_in = [input_nc] + c[:7]
             up_in = [c[14 - d] for d in range(8)]
             up_out = [output_nc] + [f[15 - d] for d in range(1, 8)]
+            present = [0, 1, 2, 3] + [d for d in (4, 5, 6) if f[d] != 0 and f[15 - d] != 0] + \
+                      ([7] if f[7] != 0 and f[8] != 0 else [])
+            if any(wd[d] <= 0 or up_in[d] <= 0 or (d > 0 and up_out[d] <= 0) or (d > 0 and down_in[d] <= 0) for d in present):
+                raise ValueError('filter_cfgs / channel_cfgs give a built block a zero width: %r %r' % (f, c))
+        self.present = present
+        self.inner_identity = present[-1] != D - 1
+        # the blocks torch's Dropout sits in: the loop blocks (models/Pix2Pix.py:101-104: depths D-2 .. 4), by position
+        self.dropout_positions = [j for j, d in enumerate(present) if 4 <= d <= D - 2] if use_dropout else []
+        K = len(present)
 
-        def prefix(d):
-            return 'model' if d == 0 else 'model.model.1' + '.model.3' * (d - 1)
+        def prefix(j):
+            return 'model' if j == 0 else 'model.model.1' + '.model.3' * (j - 1)
         _attach(self, 'model.model.0', nn.Conv2d(down_in[0], wd[0], 4, 2, 1, bias=False))
-        for d in range(1, D):
-            p = prefix(d)
+        for j in range(1, K):
+            d, p = present[j], prefix(j)
             _attach(self, p + '.model.1', nn.Conv2d(down_in[d], wd[d], 4, 2, 1, bias=False))
             if d < D - 1:
                 _attach(self, p + '.model.2', _bn(wd[d]))
-        p = prefix(D - 1)
-        _attach(self, p + '.model.3', nn.ConvTranspose2d(up_in[D - 1], up_out[D - 1], 4, 2, 1, bias=False))
-        _attach(self, p + '.model.4', _bn(up_out[D - 1]))
-        for d in range(D - 2, 0, -1):
-            p = prefix(d)
-            _attach(self, p + '.model.5', nn.ConvTranspose2d(up_in[d], up_out[d], 4, 2, 1, bias=False))
-            _attach(self, p + '.model.6', _bn(up_out[d]))
+        for j in range(K - 1, 0, -1):
+            d, p = present[j], prefix(j)
+            if d == D - 1:
+                _attach(self, p + '.model.3', nn.ConvTranspose2d(up_in[d], up_out[d], 4, 2, 1, bias=False))
+                _attach(self, p + '.model.4', _bn(up_out[d]))
+            else:
+                _attach(self, p + '.model.5', nn.ConvTranspose2d(up_in[d], up_out[d], 4, 2, 1, bias=False))
+                _attach(self, p + '.model.6', _bn(up_out[d]))
         _attach(self, 'model.model.3', nn.ConvTranspose2d(up_in[0], up_out[0], 4, 2, 1, bias=True))
+        # what a block hands to the one inside it must be what that block's conv takes, and what comes back up must be what the
+        # transposed conv takes (the reference would fail in forward(); here the engine would read garbage)
+        for j in range(1, K):
+            d, o = present[j], present[j - 1]
+            if down_in[d] != wd[o]:
+                raise ValueError('block at depth %d takes %d channels but its parent (depth %d) produces %d' % (d, down_in[d], o, wd[o]))
+            inner = wd[d] if j == K - 1 else wd[d] + up_out[present[j + 1]]
+            if up_in[d] != inner:
+                raise ValueError('up conv at depth %d takes %d channels, its input has %d' % (d, up_in[d], inner))
+        if up_in[0] != wd[0] + up_out[present[1]]:
+            raise ValueError('outermost up conv takes %d channels, its input has %d' % (up_in[0], wd[0] + up_out[present[1]]))
 
     def forward(self, x):
         raise GccError('UnetGenertor owns parameters only; run it through Pix2PixModel (gcc_amd.engine.UnetEngine)')

@@ -12,29 +12,19 @@ import torch.nn as nn
 
 
 def unet_macs(netG, size=256):
-    """(MACs in G, params in M) of a UnetGenertor parameter tree for a 1 x 3 x size x size input."""
-    convs = [m for m in netG.modules() if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))]
-    downs = [m for m in convs if isinstance(m, nn.Conv2d)]
-    ups = [m for m in convs if isinstance(m, nn.ConvTranspose2d)]
-    total = 0
-    h = size
-    hs = []
-    for m in downs:                       # named_modules order: outermost -> innermost
-        h //= 2
-        hs.append(h)
-        total += h * h * m.out_channels * m.in_channels * m.kernel_size[0] * m.kernel_size[1]
-    for m in ups:                         # innermost -> outermost
-        h *= 2
-        total += h * h * m.out_channels * m.in_channels * m.kernel_size[0] * m.kernel_size[1]
-    # BatchNorm: 2 ops per element of the tensor it normalises
-    D = len(downs)
-    bns = [m for m in netG.modules() if isinstance(m, nn.BatchNorm2d)]
-    for i, m in enumerate(bns):
-        if i < D - 2:                     # down norms at depth 1..D-2
-            hh = hs[i + 1]
-        else:                             # up norms, innermost first: output of up conv at depth D-1, D-2, ...
-            hh = hs[D - 2 - (i - (D - 2))]
-        total += 2 * m.num_features * hh * hh
+    """(MACs in G, params in M) of a UnetGenertor parameter tree for a 1 x 3 x size x size input.  The tree's module order is
+    the data-flow order (conv, norm, [inner block], transposed conv, norm), so one walk with the running map size counts every
+    layer -- also when inner blocks were pruned away."""
+    total, h = 0, size
+    for m in netG.modules():
+        if isinstance(m, nn.Conv2d):
+            h //= 2
+            total += h * h * m.out_channels * m.in_channels * m.kernel_size[0] * m.kernel_size[1]
+        elif isinstance(m, nn.ConvTranspose2d):
+            h *= 2
+            total += h * h * m.out_channels * m.in_channels * m.kernel_size[0] * m.kernel_size[1]
+        elif isinstance(m, nn.BatchNorm2d):             # 2 ops per element of the tensor it normalises
+            total += 2 * m.num_features * h * h
     params = sum(p.numel() for p in netG.parameters())
     return total / 1000 ** 3, params / 1000 ** 2
 
@@ -450,22 +440,17 @@ def cfg_macs(opt, f, c):
     k2 = 16
     total = 0
     D = 8
-    h = [size >> (d + 1) for d in range(D)]
-    present = [True] * D
-    present[7] = f[7] != 0 and f[8] != 0
-    for i in range(3):
-        present[6 - i] = f[6 - i] != 0 and f[9 + i] != 0
+    present = [0, 1, 2, 3] + [d for d in (4, 5, 6) if f[d] != 0 and f[15 - d] != 0] + ([7] if f[7] != 0 and f[8] != 0 else [])
     down_in = [3] + list(c[:7])
     up_in = [c[14 - d] for d in range(D)]
     up_out = [3] + [f[15 - d] for d in range(1, D)]
-    for d in range(D):
-        if not present[d]:
-            continue
-        total += h[d] * h[d] * f[d] * down_in[d] * k2
-        hh = h[d] * 2
+    for j, d in enumerate(present):                 # the blocks that are built nest by position: block j works on size >> (j + 1)
+        h = size >> (j + 1)
+        total += h * h * f[d] * down_in[d] * k2
+        hh = h * 2
         total += hh * hh * up_out[d] * up_in[d] * k2
         if 0 < d < D - 1:
-            total += 2 * f[d] * h[d] * h[d]
+            total += 2 * f[d] * h * h
         if d > 0:
             total += 2 * up_out[d] * hh * hh
     return total / 1000 ** 3

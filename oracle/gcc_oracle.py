@@ -188,7 +188,7 @@ def rmse(a: Tensor, b: Tensor) -> Tensor:
 # ----------------------------------------------------------------------------------------------
 def unet_forward(sd: SD, x: Tensor, num_downs: int = 8, train: bool = True,
                  dropout: bool = False, dropout_masks: Optional[Dict[int, Tensor]] = None,
-                 features: Optional[OrderedDict] = None) -> Tensor:
+                 features: Optional[OrderedDict] = None, drop_depths: Optional[List[int]] = None) -> Tensor:
     """8-down / 8-up U-Net with forced BatchNorm (models/Pix2Pix.py:26), written depth by depth.
 
     e[d]  : pre-activation output of the down conv (+BN for 0<d<D-1) at depth d
@@ -198,9 +198,17 @@ def unet_forward(sd: SD, x: Tensor, num_downs: int = 8, train: bool = True,
     ``features`` (if given) receives the four hooked tensors under the reference's module names.
     ``dropout_masks[d]`` optionally injects the (already 1/(1-p)-scaled) mask for depth d.
     """
+    # A pruned generator may have lost inner blocks (models/Pix2Pix.py:87, 97): the state_dict says how many are built (nesting
+    # goes by position) and of what kind the last one is -- the innermost kind (conv, ReLU, convT, BN) or a loop block around
+    # Identity (:59-67: conv, BN, ReLU, convT, BN).  ``drop_depths`` then names the positions of the loop blocks that are left.
     D = num_downs
+    while D > 1 and (unet_block_prefix(D - 1) + '.model.1.weight') not in sd:
+        D -= 1
+    ident = (unet_block_prefix(D - 1) + '.model.5.weight') in sd
     hook = unet_hook_names(D)
-    drop_depths = unet_dropout_depths(D) if dropout else []
+    if drop_depths is None:
+        drop_depths = unet_dropout_depths(num_downs) if D == num_downs else [d for d in range(4, D - (0 if ident else 1))]
+    drop_depths = drop_depths if dropout else []
 
     def conv(t, key):
         return F.conv2d(t, _qw(sd[key + '.weight']), sd.get(key + '.bias'), stride=2, padding=1)
@@ -215,14 +223,24 @@ def unet_forward(sd: SD, x: Tensor, num_downs: int = 8, train: bool = True,
     for d in range(1, D):
         p = unet_block_prefix(d)
         z = _q(conv(_q(F.leaky_relu(e[d - 1], LRELU)), p + '.model.1'))
-        if d < D - 1:
+        if d < D - 1 or ident:
             z = batch_norm(sd, p + '.model.2', z, train)
             if features is not None and (p + '.model.2') in hook:
-                features[p + '.model.2'] = _q(F.leaky_relu(z, LRELU))       # hazard H1
+                # hazard H1: the hooked BatchNorm output is overwritten in place by the next block's LeakyReLU -- or, when the
+                # block wraps Identity, by its own ReLU
+                features[p + '.model.2'] = _q(F.leaky_relu(z, LRELU)) if d < D - 1 else _q(F.relu(z))
         e[d] = z
 
     p = unet_block_prefix(D - 1)
-    u = batch_norm(sd, p + '.model.4', _q(convT(_q(F.relu(e[D - 1])), p + '.model.3')), train)
+    if not ident:
+        u = batch_norm(sd, p + '.model.4', _q(convT(_q(F.relu(e[D - 1])), p + '.model.3')), train)
+    else:
+        r = _q(F.relu(e[D - 1]))
+        if features is not None and (p + '.model.4') in hook:
+            features[p + '.model.4'] = r
+        u = batch_norm(sd, p + '.model.6', _q(convT(r, p + '.model.5')), train)
+        if (D - 1) in drop_depths and train:
+            u = u * dropout_masks[D - 1] if (dropout_masks is not None and (D - 1) in dropout_masks) else F.dropout(u, 0.5, True)
     cat = torch.cat([F.leaky_relu(e[D - 2], LRELU), u], 1)
     for d in range(D - 2, 0, -1):
         p = unet_block_prefix(d)
@@ -474,10 +492,12 @@ def unet_shapes(ngf: int, num_downs: int = 8, in_nc: int = 3, out_nc: int = 3) -
 
 
 def unet_shapes_cfg(filter_cfgs: Sequence[int], channel_cfgs: Sequence[int], in_nc: int = 3, out_nc: int = 3):
-    """Shapes of UnetGenertor(filter_cfgs, channel_cfgs), num_downs = 8, no block removed
-    (models/Pix2Pix.py:85-127; index layout in SURVEY.md Appendix A.1)."""
+    """Shapes of UnetGenertor(filter_cfgs, channel_cfgs), num_downs = 8 (models/Pix2Pix.py:85-127; index layout in SURVEY.md
+    Appendix A.1).  A block whose widths are zero is not built (:87, :97); the blocks that are nest by position, and when the
+    innermost kind is gone the last one is a loop block around Identity (:59-67)."""
     f, c = [int(v) for v in filter_cfgs], [int(v) for v in channel_cfgs]
     D = 8
+    present = [0, 1, 2, 3] + [d for d in (4, 5, 6) if f[d] != 0 and f[15 - d] != 0] + ([7] if f[7] != 0 and f[8] != 0 else [])
     shp: Dict[str, Tuple[int, ...]] = OrderedDict()
 
     def bn(key, ch):
@@ -485,18 +505,19 @@ def unet_shapes_cfg(filter_cfgs: Sequence[int], channel_cfgs: Sequence[int], in_
                        ('num_batches_tracked', ())):
             shp[key + '.' + sfx] = v
     shp['model.model.0.weight'] = (f[0], in_nc, 4, 4)
-    for d in range(1, D):
-        p = unet_block_prefix(d)
+    for j in range(1, len(present)):
+        d, p = present[j], unet_block_prefix(j)
         shp[p + '.model.1.weight'] = (f[d], c[d - 1], 4, 4)
         if d < D - 1:
             bn(p + '.model.2', f[d])
-    p = unet_block_prefix(D - 1)
-    shp[p + '.model.3.weight'] = (c[7], f[8], 4, 4)
-    bn(p + '.model.4', f[8])
-    for d in range(D - 2, 0, -1):
-        p = unet_block_prefix(d)
-        shp[p + '.model.5.weight'] = (c[14 - d], f[15 - d], 4, 4)
-        bn(p + '.model.6', f[15 - d])
+    for j in range(len(present) - 1, 0, -1):
+        d, p = present[j], unet_block_prefix(j)
+        if d == D - 1:
+            shp[p + '.model.3.weight'] = (c[7], f[8], 4, 4)
+            bn(p + '.model.4', f[8])
+        else:
+            shp[p + '.model.5.weight'] = (c[14 - d], f[15 - d], 4, 4)
+            bn(p + '.model.6', f[15 - d])
     shp['model.model.3.weight'] = (c[14], out_nc, 4, 4)
     shp['model.model.3.bias'] = (out_nc,)
     return shp

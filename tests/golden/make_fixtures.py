@@ -42,7 +42,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from recipe import recipe_state_dict, recipe_transform, sample_idx, srgan_condition  # noqa: E402
+from recipe import recipe_state_dict, recipe_transform, sample_idx, srgan_condition, shape_bn_scales_for_removal  # noqa: E402
 REF = '/root/reference'
 
 
@@ -364,6 +364,111 @@ def fixture_pruned_d8():
     sd_np_sampled('final.G.', model.netG.state_dict(), out)
     np.savez_compressed(os.path.join(HERE, 'pix2pix_pruned_d8.npz'), **out)
     print('pix2pix_pruned_d8 ok: f =', f)
+
+
+def fixture_pruned_removed_d8():
+    """Pruned students that LOST inner blocks (models/Pix2Pix.py:87, 97, Identity submodule :59-67).  A full ngf-32 U-Net with
+    BatchNorm scales shaped by recipe.shape_bn_scales_for_removal is searched by the reference's binarysearch_threshold (thop
+    stand-in above) for two budgets -> block 7 gone / blocks 6 and 7 gone; a direct scale_prune(0.96) removes 5, 6 and 7.  Each
+    pruned student then gets recipe weights and runs an eval image and one plain training iteration; the 6-block student also
+    runs one full GCC iteration (distillation from an ngf-48 teacher + arch step) with its hooked features."""
+    import utils.prune_util as pu
+    pu.profile = thop_standin_profile
+    opt = parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '-1', '--ngf', '32', '--ndf', '4',
+                 '--scale_prune', '--no_dropout'])
+    from models import get_model_class
+    cls = get_model_class(opt)
+    model = cls(opt)
+    load_recipe(model.netG, 311)
+    shape_bn_scales_for_removal(model.netG.state_dict(), 312)       # state_dict tensors alias the parameters
+    full, _ = pu.get_flops_parms(model.netG, model.device, opt)
+    mx, mn = model.max_min_bn_scale()
+    out = {'full_macs': np.array(full), 'seeds': np.array([311, 312]), 'max_min': np.array([float(mx), float(mn)], dtype=np.float64),
+           'direction': np.array(opt.direction)}
+    # budgets = what the thresholds 0.58 (block 7 gone) and 0.88 (6 and 7 gone, depth 5 thinned) cost, so that the search has
+    # an answer there; it stops at the first mid point within 0.1 G of the budget
+    cfgs = {}
+    for tag, probe in (('k7', 0.58), ('k6', 0.88)):
+        pm = model.scale_prune(probe)
+        target, _ = pu.get_flops_parms(pm.netG, pm.device, opt)
+        target = round(target, 3)
+        thr = pu.binarysearch_threshold(model, target)
+        pm = model.prune(thr)
+        f, c = pm.get_cfg()
+        macs, _ = pu.get_flops_parms(pm.netG, pm.device, opt)
+        out[tag + '.target'], out[tag + '.threshold'] = np.array(target), np.array(float(thr), dtype=np.float32)
+        out[tag + '.f'], out[tag + '.c'], out[tag + '.macs'] = np.array(f), np.array(c), np.array(macs)
+        cfgs[tag] = (f, c)
+    pm = model.scale_prune(0.96)
+    f, c = pm.get_cfg()
+    out['k5.threshold'], out['k5.f'], out['k5.c'] = np.array(0.96, dtype=np.float32), np.array(f), np.array(c)
+    out['k5.macs'] = np.array(pu.get_flops_parms(pm.netG, pm.device, opt)[0])
+    cfgs['k5'] = (f, c)
+    g = torch.Generator().manual_seed(9)
+    A = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    B = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    out['A'], out['B'] = A.numpy(), B.numpy()
+    popt = parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '-1', '--ngf', '32', '--ndf', '8',
+                  '--no_dropout'])
+    for i, tag in enumerate(('k7', 'k6', 'k5')):
+        f, c = cfgs[tag]
+        pm = cls(popt, filter_cfgs=f, channel_cfgs=c)
+        load_recipe(pm.netG, 411 + 2 * i)
+        load_recipe(pm.netD, 412 + 2 * i)
+        out[tag + '.keys'] = np.array(list(pm.netG.state_dict().keys()))
+        pm.model_eval()
+        pm.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
+        with torch.no_grad():
+            pm.forward()
+        out[tag + '.eval.fake_B'] = pm.fake_B.numpy()[:, :, ::2, ::2].copy()
+        pm.model_train()
+        pm.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
+        pm.optimize_parameters()
+        out[tag + '.train.fake_B'] = pm.fake_B.detach().numpy()[:, :, ::2, ::2].copy()
+        for k, v in pm.get_current_losses().items():
+            out[tag + '.loss.%s' % k] = np.array(v, dtype=np.float64)
+        sd_np_sampled(tag + '.final.G.', pm.netG.state_dict(), out)
+    # one GCC iteration of the 6-block student
+    f, c = cfgs['k6']
+    gopt = parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '-1', '--ngf', '32', '--ndf', '8',
+                  '--teacher_ngf', '48', '--no_dropout', '--online_distillation', '--darts_discriminator', '--lambda_content', '50',
+                  '--lambda_gram', '1e4', '--arch_lr', '1e-4', '--arch_lr_step'])
+    gopt.teacher_ndf = 8
+    student = cls(gopt, filter_cfgs=f, channel_cfgs=c)
+    topt = copy.deepcopy(gopt)
+    topt.ngf, topt.ndf, topt.darts_discriminator, topt.online_distillation, topt.generator_only = 48, 8, False, False, False
+    teacher = cls(topt)
+    teacher.model_train()
+    student.teacher_model = teacher
+    student.init_distillation()
+    teacher.init_distillation()
+    student.model_train()
+    for m, sd in ((student.netG, 421), (student.netD, 422), (teacher.netG, 423), (teacher.netD, 424)):
+        load_recipe(m, sd)
+    with torch.no_grad():
+        for i, t in enumerate(student.transform_convs):
+            t.weight.copy_(recipe_transform(t.weight.shape[0], t.weight.shape[1], 425 + i))
+    vA = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    vB = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    out['vA'], out['vB'] = vA.numpy(), vB.numpy()
+    student.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
+    student.optimize_parameters()
+    out['gcc.fake_B'] = student.fake_B.detach().numpy()[:, :, ::2, ::2].copy()
+    for j, t in enumerate(student.get_distillation_features()):
+        t = t.detach().reshape(-1)
+        out['gcc.sfeat.%d' % j] = t[sample_idx(t.numel(), 8192)].numpy().copy()
+        out['gcc.sfeat_shape.%d' % j] = np.array(student.get_distillation_features()[j].shape)
+    student.set_input({'A': vA, 'B': vB, 'A_paths': ['a'], 'B_paths': ['b']})
+    student.clipping_mask_alpha()
+    student.optimizer_netD_arch()
+    for k, v in student.get_current_losses().items():
+        out['gcc.loss.%s' % k] = np.array(v, dtype=np.float64)
+    sd_np_sampled('gcc.final.sG.', student.netG.state_dict(), out)
+    for i, t in enumerate(student.transform_convs):
+        t = t.weight.detach().reshape(-1)
+        out['gcc.final.T.%d' % i] = t[sample_idx(t.numel())].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'pix2pix_pruned_removed_d8.npz'), **out)
+    print('pruned_removed_d8 ok:', {t: (float(out[t + '.threshold']), list(out[t + '.f'])) for t in ('k7', 'k6', 'k5')})
 
 
 def thop_standin_profile(model, inputs, verbose=False):
@@ -1160,6 +1265,6 @@ if __name__ == '__main__':
     only = sys.argv[1:]            # e.g. "make_fixtures.py cyclegan cyclegan_pretrain"; none = all
     import_reference()
     for fn in (fixture_options, fixture_ops, fixture_eval_d8, fixture_gcc_d6, fixture_pretrain_d6, fixture_prune_d8,
-               fixture_pruned_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan, fixture_srgan, fixture_prune_search_gan, fixture_checkpoint, fixture_checkpoint_other, fixture_metric, fixture_pipeline, fixture_srgan_content):
+               fixture_pruned_d8, fixture_pruned_removed_d8, fixture_prune_search, fixture_resnet_gcc, fixture_cyclegan, fixture_cyclegan_pretrain, fixture_prune_resnet, fixture_sagan, fixture_srgan, fixture_prune_search_gan, fixture_checkpoint, fixture_checkpoint_other, fixture_metric, fixture_pipeline, fixture_srgan_content):
         if not only or fn.__name__[len('fixture_'):] in only:
             fn()

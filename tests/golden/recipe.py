@@ -50,6 +50,23 @@ def srgan_condition(sd):
                 i += 1
 
 
+def shape_bn_scales_for_removal(sd, seed):
+    """In-place on a name -> tensor mapping of a full (num_downs 8) U-Net: BatchNorm scales laid out so that a magnitude
+    threshold removes whole inner blocks (models/Pix2Pix.py:87, 97) -- the innermost up norm in [.50, .55], the depth-6 norms
+    in [.60, .80], the depth-5 norms in [.75, .95], every other norm spread over [.30, 1.10] (so that the MAC budget falls steadily
+    with the threshold and a budget search has something to find).  Thresholds in (.55, .60) remove block 7, in (.80, .95) blocks 6
+    and 7, above .95 blocks 5, 6 and 7."""
+    p5 = 'model.model.1' + '.model.3' * 4
+    ranges = {p5 + '.model.3.model.3.model.4': (0.50, 0.55), p5 + '.model.3.model.2': (0.60, 0.80), p5 + '.model.3.model.6': (0.60, 0.80),
+              p5 + '.model.2': (0.75, 0.95), p5 + '.model.6': (0.75, 0.95)}
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for k, v in sd.items():
+            if v.dim() == 1 and k.endswith('.weight'):
+                lo, hi = ranges.get(k[:-len('.weight')], (0.30, 1.10))
+                v.copy_(lo + (hi - lo) * torch.rand(v.shape, generator=g))
+
+
 def recipe_transform(cout, cin, seed):
     g = torch.Generator().manual_seed(seed)
     return (torch.rand((cout, cin, 1, 1), generator=g) * 2 - 1) / (cin ** 0.5)

@@ -389,6 +389,40 @@ def test_prune_cfgs_and_budget_search_match_reference(golden_dir):
             assert abs(PU.cfg_macs(opt, f, c) - float(s['s%d.macs' % i])) < 1e-9
 
 
+def test_prune_search_that_removes_blocks(golden_dir):
+    """budget searches whose answer prunes whole inner blocks away (tests/golden/pix2pix_pruned_removed_d8.npz: the reference's
+    binarysearch_threshold on an ngf-32 U-Net with shaped BatchNorm scales): threshold (fp32), cfgs with their zero entries and
+    the MAC count of the smaller nest, bit for bit; the parameter tree built from such a cfg has the reference's keys"""
+    from oracle import gcc_oracle as O
+    from gcc_amd.utils import prune_util as PU
+    from tests.golden.recipe import recipe_state_dict, shape_bn_scales_for_removal
+    from gcc_amd.models.Pix2Pix import UnetGenertor
+    z = np.load(os.path.join(golden_dir, 'pix2pix_pruned_removed_d8.npz'))
+    G = recipe_state_dict(O.unet_shapes(32, 8), int(z['seeds'][0]))
+    shape_bn_scales_for_removal(G, int(z['seeds'][1]))
+    mx, mn = PU.max_min_bn_scale(G)
+    assert [float(mx), float(mn)] == [float(v) for v in z['max_min']]
+    opt = type('O', (), dict(scale_prune=True, num_downs=8, ngf=32, dataroot='./database/cityscapes/', load_size=256))()
+    assert abs(PU.unet_macs(UnetGenertor(3, 3, 8, ngf=32))[0] - float(z['full_macs'])) < 1e-9
+    for tag, blocks in (('k7', 7), ('k6', 6), ('k5', 5)):
+        if tag != 'k5':
+            thr = PU.binarysearch_threshold_sd(G, opt, float(z[tag + '.target']))
+            assert np.float32(float(thr)) == np.float32(z[tag + '.threshold']), tag
+        else:
+            thr = float(z['k5.threshold'])
+        f, c = PU.scale_prune_cfg(G, thr, 32)
+        assert f == [int(v) for v in z[tag + '.f']] and c == [int(v) for v in z[tag + '.c']], tag
+        assert abs(PU.cfg_macs(opt, f, c) - float(z[tag + '.macs'])) < 1e-9, tag
+        net = UnetGenertor(3, 3, 8, ngf=32, filter_cfgs=f, channel_cfgs=c)
+        assert len(net.present) == blocks and net.inner_identity
+        assert list(net.state_dict().keys()) == [str(k) for k in z[tag + '.keys']]
+        assert abs(PU.unet_macs(net)[0] - float(z[tag + '.macs'])) < 1e-9, tag
+    with pytest.raises(ValueError):         # a block removed from the middle with widths that do not meet: the reference would fail in forward()
+        f, c = [int(v) for v in z['k7.f']], [int(v) for v in z['k7.c']]
+        f[5] = 0
+        UnetGenertor(3, 3, 8, ngf=32, filter_cfgs=f, channel_cfgs=c)
+
+
 # ---------------------------------------------------------------------------------------------------
 # norm / resnet pruning cfgs (host logic on the parameter trees; golden: tests/golden/prune_resnet.npz, prune_d8.npz)
 # ---------------------------------------------------------------------------------------------------

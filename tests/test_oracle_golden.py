@@ -249,6 +249,77 @@ def test_pruned_student_irregular_widths(golden_dir):
     _compare_sd(m.G, z, 'final.G.', atol=2e-5)
 
 
+@pytest.mark.parametrize('tag', ['k7', 'k6', 'k5'])
+def test_pruned_student_removed_blocks(golden_dir, tag):
+    """students that lost inner blocks (filter_cfgs with zeros; models/Pix2Pix.py:87, 97 and the Identity submodule :59-67):
+    k7 = the innermost block gone (block 6 wraps Identity), k6 = 6 and 7 gone, k5 = 5, 6 and 7 gone.  state_dict keys, eval
+    image and one training iteration against the reference"""
+    z = load(golden_dir, 'pix2pix_pruned_removed_d8.npz')
+    f, c = [int(v) for v in z[tag + '.f']], [int(v) for v in z[tag + '.c']]
+    assert f[7] == 0 and f[8] == 0
+    i = ('k7', 'k6', 'k5').index(tag)
+    shapes = O.unet_shapes_cfg(f, c)
+    assert list(shapes.keys()) == [str(k) for k in z[tag + '.keys']]
+    G = recipe_state_dict(shapes, 411 + 2 * i)
+    D = recipe_state_dict(O.patchgan_shapes(8, 6, False), 412 + 2 * i)
+    A, B = torch.from_numpy(z['A']), torch.from_numpy(z['B'])
+    with torch.no_grad():
+        out = O.unet_forward(G, A if str(z['direction']) == 'AtoB' else B, 8, train=False)
+    np.testing.assert_allclose(out.numpy()[:, :, ::2, ::2], z[tag + '.eval.fake_B'], atol=2e-5)
+    opt = O.Opt(ngf=32, ndf=8, num_downs=8, no_dropout=True, darts_discriminator=False, online_distillation=False,
+                direction=str(z['direction']))
+    m = O.Pix2PixOracle(opt, G, D, masked=False)
+    m.set_input(A, B)
+    m.optimize_parameters()
+    np.testing.assert_allclose(m.fake_B.numpy()[:, :, ::2, ::2], z[tag + '.train.fake_B'], atol=2e-5)
+    for k in ('G_GAN', 'G_L1', 'D_real', 'D_fake'):
+        assert abs(m.losses[k] - float(z[tag + '.loss.' + k])) < 1e-4 * max(1, abs(m.losses[k]))
+    # (one sampled element of one deep conv has |gradient| ~ Adam's eps: its first-step update is not +-lr and flips with the
+    # summation order -- admitted as an outlier within 2 lr)
+    _compare_sd(m.G, z, tag + '.final.G.', atol=2e-5, outliers=0.001, hard=4.1e-4)
+
+
+def build_removed_gcc_oracle(z):
+    """the 6-block student (blocks 6 and 7 pruned away) under distillation from an ngf-48 teacher, recipe weights of
+    pix2pix_pruned_removed_d8.npz"""
+    f, c = [int(v) for v in z['k6.f']], [int(v) for v in z['k6.c']]
+    opt = O.Opt(ngf=32, ndf=8, teacher_ngf=48, teacher_ndf=8, num_downs=8, no_dropout=True, direction=str(z['direction']))
+    teacher = O.Pix2PixOracle(opt, recipe_state_dict(O.unet_shapes(48, 8), 423), recipe_state_dict(O.patchgan_shapes(8, 6, False), 424),
+                              masked=False)
+    sw, tw = [c[1], c[3], c[-4], c[-2]], [96, 384, 768, 192]
+    T = [recipe_transform(t, s_, 425 + i) for i, (s_, t) in enumerate(zip(sw, tw))]
+    m = O.Pix2PixOracle(opt, recipe_state_dict(O.unet_shapes_cfg(f, c), 421), recipe_state_dict(O.patchgan_shapes(8, 6, True), 422),
+                        T, masked=True, teacher=teacher)
+    return m, teacher, opt
+
+
+def test_pruned_student_removed_blocks_gcc_iteration(golden_dir):
+    """... and one full GCC iteration of it (teacher step, distillation through the four hooked tensors -- the deepest pair now
+    sits directly above the last block -- and the arch step)"""
+    z = load(golden_dir, 'pix2pix_pruned_removed_d8.npz')
+    m, teacher, opt = build_removed_gcc_oracle(z)
+    m.set_input(torch.from_numpy(z['A']), torch.from_numpy(z['B']))
+    m.optimize_parameters()
+    np.testing.assert_allclose(m.fake_B.numpy()[:, :, ::2, ::2], z['gcc.fake_B'], atol=2e-5)
+    for j in range(4):
+        t = list(m.g_feats.values())[j]
+        assert list(t.shape) == [int(v) for v in z['gcc.sfeat_shape.%d' % j]]
+        t = t.detach().reshape(-1)
+        ref = z['gcc.sfeat.%d' % j]
+        np.testing.assert_allclose(t[sample_idx(t.numel(), 8192)].numpy(), ref, atol=2e-5 + 1e-4 * np.abs(ref).max())
+    m.set_input(torch.from_numpy(z['vA']), torch.from_numpy(z['vB']))
+    m.clipping_mask_alpha()
+    m.optimizer_netD_arch()
+    for k in z.files:
+        if k.startswith('gcc.loss.'):
+            name, ref = k.split('.')[-1], float(z[k])
+            assert abs(m.losses[name] - ref) <= 2e-4 * max(1.0, abs(ref)), (name, m.losses[name], ref)
+    _compare_sd(m.G, z, 'gcc.final.sG.', atol=3e-5, outliers=0.001, hard=4.1e-4)
+    for i in range(4):
+        t = m.T[i].detach().reshape(-1)
+        np.testing.assert_allclose(t[sample_idx(t.numel())].numpy(), z['gcc.final.T.%d' % i], atol=3e-5)
+
+
 def build_resnet_gcc_oracle(z):
     """--backbone resnet student (ngf 8) + teacher (ngf 16) with the recipe weights of pix2pix_resnet_gcc.npz"""
     opt = O.Opt(ngf=8, ndf=8, teacher_ngf=16, teacher_ndf=16, direction=str(z['direction']), backbone='resnet')

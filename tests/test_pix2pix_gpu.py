@@ -707,6 +707,159 @@ def test_pruned_student_irregular_widths(golden_dir):
             assert float(np.abs(g - ref).max()) <= tol, (name, float(np.abs(g - ref).max()), tol)
 
 
+def _check_pruned_iteration(model, z, tag, opt):
+    """eval image, training-mode image, losses and post-step generator weights of a plain training iteration against the
+    reference golden (images stored at every second pixel)"""
+    from tests.golden.recipe import sample_idx
+    data = {'A': torch.from_numpy(z['A']), 'B': torch.from_numpy(z['B']), 'A_paths': ['a'], 'B_paths': ['b']}
+    model.model_eval()
+    model.set_input(data)
+    model.forward()
+    e = (model.fake_B.cpu()[:, :, ::2, ::2] - torch.from_numpy(z[tag + '.eval.fake_B'])).abs()
+    print('%s eval fake_B: max %.4g mean %.4g' % (tag, e.max(), e.mean()))
+    assert e.max() <= 2e-2 and e.mean() <= 3e-3
+    model.model_train()
+    model.set_input(data)
+    model.optimize_parameters()
+    e = (model.fake_B.cpu()[:, :, ::2, ::2] - torch.from_numpy(z[tag + '.train.fake_B'])).abs()
+    print('%s train fake_B: max %.4g mean %.4g' % (tag, e.max(), e.mean()))
+    assert e.max() <= 2e-2 and e.mean() <= 3e-3
+    losses = model.get_current_losses()
+    for k in ('G_GAN', 'G_L1', 'D_real', 'D_fake'):
+        ref = float(z[tag + '.loss.' + k])
+        assert abs(losses[k] - ref) <= 3e-2 * max(1.0, abs(ref)), (k, losses[k], ref)
+    sd = model.netG.state_dict()
+    pre = tag + '.final.G.'
+    for k in z.files:
+        if k.startswith(pre):
+            name = k[len(pre):]
+            g = sd[name].detach().float().cpu().reshape(-1)
+            g = g[sample_idx(g.numel())].numpy()
+            ref = z[k]
+            if name.endswith('num_batches_tracked'):
+                assert int(g[0]) == int(ref.reshape(-1)[0])
+                continue
+            tol = 3e-2 * max(1.0, float(np.abs(ref).max())) if 'running' in name else 2.2 * opt.lr + 1e-6
+            assert float(np.abs(g - ref).max()) <= tol, (name, float(np.abs(g - ref).max()), tol)
+
+
+@pytest.mark.parametrize('tag', ['k7', 'k6', 'k5'])
+def test_pruned_student_removed_blocks(golden_dir, tag):
+    """students whose cfgs hold zeros: the innermost block (k7), blocks 6 and 7 (k6), blocks 5, 6 and 7 (k5) are not built
+    (models/Pix2Pix.py:87, 97) and the last block wraps Identity (:59-67: conv, BatchNorm, ReLU, transposed conv, BatchNorm);
+    the widths that are left are irregular (45, 85, 163 ...).  state_dict keys, eval image, one training iteration."""
+    z = load(golden_dir, 'pix2pix_pruned_removed_d8.npz')
+    f, c = [int(v) for v in z[tag + '.f']], [int(v) for v in z[tag + '.c']]
+    from gcc_amd.options import options
+    from gcc_amd.models import get_model_class
+    opt = options.parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '0', '--ngf', '32',
+                         '--ndf', '8', '--no_dropout'])
+    opt.isTrain = True
+    model = get_model_class(opt)(opt, filter_cfgs=f, channel_cfgs=c)
+    assert list(model.netG.state_dict().keys()) == [str(k) for k in z[tag + '.keys']]
+    assert model.G.D == {'k7': 7, 'k6': 6, 'k5': 5}[tag] and model.G.inner_identity
+    i = ('k7', 'k6', 'k5').index(tag)
+    load_recipe(model.netG, 411 + 2 * i)
+    load_recipe(model.netD, 412 + 2 * i)
+    model.refresh_weights()
+    _check_pruned_iteration(model, z, tag, opt)
+
+
+def test_removed_blocks_dropout_positions():
+    """with dropout on, the loop blocks that are left (positions 4 .. last) keep their Dropout(0.5) -- the Identity-wrapping
+    last block included (models/Pix2Pix.py:60-64) -- and a training forward / backward runs"""
+    from gcc_amd.options import options
+    from gcc_amd.models import get_model_class
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'pix2pix_pruned_removed_d8.npz'))
+    opt = options.parse(['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '0', '--ngf', '32', '--ndf', '8'])
+    opt.isTrain = True
+    for tag, want in (('k7', [4, 5, 6]), ('k6', [4, 5]), ('k5', [4])):
+        f, c = [int(v) for v in z[tag + '.f']], [int(v) for v in z[tag + '.c']]
+        model = get_model_class(opt)(opt, filter_cfgs=f, channel_cfgs=c)
+        assert sorted(model.G.drop_depths) == want, (tag, model.G.drop_depths)
+        model.set_input({'A': torch.from_numpy(z['A']), 'B': torch.from_numpy(z['B']), 'A_paths': ['a'], 'B_paths': ['b']})
+        model.optimize_parameters()
+        assert all(np.isfinite(v) for v in model.get_current_losses().values())
+
+
+def test_prune_end_to_end_on_gpu(golden_dir, tmp_path):
+    """the reference's recipe from a pretrained checkpoint to a training student (train.py:86-105), on the GPU box: pretrained
+    weights resident on the device -> save_models -> prune_util.prune (load_models, budget search, model.prune: the
+    reference's own call passes a lottery_path its method does not take, hazard H7) -> cfgs BIT-EXACT with the reference's
+    search (blocks 6 and 7 pruned away) -> teacher attached -> one GCC iteration of the pruned student (distillation through
+    the hooked tensors, arch step) against the reference's golden."""
+    import logging
+    from tests.golden.recipe import recipe_state_dict, recipe_transform, shape_bn_scales_for_removal, sample_idx
+    from gcc_amd.options import options
+    from gcc_amd.models import get_model_class
+    from gcc_amd.train import attach_teacher
+    from gcc_amd.utils import prune_util
+    z = load(golden_dir, 'pix2pix_pruned_removed_d8.npz')
+    argv = ['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '0', '--ngf', '32', '--ndf', '8',
+            '--teacher_ngf', '48', '--no_dropout', '--online_distillation', '--darts_discriminator', '--lambda_content', '50',
+            '--lambda_gram', '1e4', '--arch_lr', '1e-4', '--arch_lr_step', '--scale_prune', '--target_budget', repr(float(z['k6.target']))]
+    opt = options.parse(argv)
+    opt.isTrain, opt.teacher_ndf = True, 8
+    cls = get_model_class(opt)
+    pre = cls(opt)                                      # the "pretrained" full model, weights on the device
+    sd = recipe_state_dict(OrderedDict((k, tuple(v.shape)) for k, v in pre.netG.state_dict().items()), int(z['seeds'][0]))
+    shape_bn_scales_for_removal(sd, int(z['seeds'][1]))
+    pre.netG.load_state_dict(sd)
+    pre.refresh_weights()
+    pre.save_models(0, str(tmp_path))
+    opt.pretrain_path = os.path.join(str(tmp_path), 'model_0.pth')
+    model = cls(opt)
+    model = prune_util.prune(model, opt, logging.getLogger('prune'))
+    f, c = model.get_cfg()
+    assert [int(v) for v in f] == [int(v) for v in z['k6.f']] and [int(v) for v in c] == [int(v) for v in z['k6.c']]
+    assert f[6] == 0 and f[7] == 0 and model.G.D == 6 and model.G.inner_identity
+    assert abs(prune_util.get_flops_parms(model.netG, model.device, opt)[0] - float(z['k6.macs'])) < 1e-9
+    teacher = attach_teacher(model, opt, cls)
+    model.model_train()
+    for m, seed in ((model.netG, 421), (model.netD, 422), (teacher.netG, 423), (teacher.netD, 424)):
+        load_recipe(m, seed)
+    with torch.no_grad():
+        for i, t in enumerate(model.transform_convs):
+            t.weight.copy_(recipe_transform(t.weight.shape[0], t.weight.shape[1], 425 + i).to(t.weight.device))
+    model.refresh_weights()
+    teacher.refresh_weights()
+    model.set_input({'A': torch.from_numpy(z['A']), 'B': torch.from_numpy(z['B']), 'A_paths': ['a'], 'B_paths': ['b']})
+    model.optimize_parameters()
+    e = (model.fake_B.cpu()[:, :, ::2, ::2] - torch.from_numpy(z['gcc.fake_B'])).abs()
+    print('pruned GCC student fake_B: max %.4g mean %.4g' % (e.max(), e.mean()))
+    assert e.max() <= 2e-2 and e.mean() <= 3e-3
+    feats = model.get_distillation_features()
+    G = model.G
+    for j in range(4):
+        t = feats[j].float().cpu()
+        if j >= 2:          # relu(cat(skip | up)): the concat buffer keeps its two parts in 8-aligned slices (DESIGN.md section 2)
+            d = 4 if j == 2 else 2
+            t = torch.cat([t[:, :G.width[d - 1]], t[:, G.uoff[d]:G.uoff[d] + G.uwidth[d]]], 1)
+        assert list(t.shape) == [int(v) for v in z['gcc.sfeat_shape.%d' % j]]
+        t = t.reshape(-1)
+        ref = z['gcc.sfeat.%d' % j]
+        err = float(np.abs(t[sample_idx(t.numel(), 8192)].numpy() - ref).max())
+        assert err <= 3e-2 * max(1.0, float(np.abs(ref).max())), (j, err)
+    model.set_input({'A': torch.from_numpy(z['vA']), 'B': torch.from_numpy(z['vB']), 'A_paths': ['a'], 'B_paths': ['b']})
+    model.clipping_mask_alpha()
+    model.optimizer_netD_arch()
+    losses = model.get_current_losses()
+    for k in z.files:
+        if k.startswith('gcc.loss.'):
+            name, ref = k.split('.')[-1], float(z[k])
+            assert abs(losses[name] - ref) <= 3e-2 * max(1.0, abs(ref)), (name, losses[name], ref)
+    sd = model.netG.state_dict()
+    for k in z.files:
+        if k.startswith('gcc.final.sG.'):
+            name = k[len('gcc.final.sG.'):]
+            if name.endswith('num_batches_tracked'):
+                continue
+            g = sd[name].detach().float().cpu().reshape(-1)
+            g = g[sample_idx(g.numel())].numpy()
+            tol = 3e-2 * max(1.0, float(np.abs(z[k]).max())) if 'running' in name else 2.2 * opt.lr + 1e-6
+            assert float(np.abs(g - z[k]).max()) <= tol, (name, float(np.abs(g - z[k]).max()), tol)
+
+
 @pytest.mark.parametrize('tag', ['a', 'b'])
 def test_pruned_resnet_generator(golden_dir, tag):
     """MobileResnet student built from a resnet_prune cfg: 'a' irregular block widths (17, 15, 18 ...), 'b' the same with
