@@ -4,9 +4,13 @@ A bound such as |w_hip - w_ref| <= 2.2 * lr * steps is satisfied by a path that 
 at most ~lr per step), so the model tests use these two instead:
 
 * MovementAgreement (golden trajectories): over the sampled elements the REFERENCE moved by a clear amount
-  (|w_ref_final - w_init| >= 0.5 * lr * steps, i.e. a gradient sign that did not flip between the steps), the HIP path
-  must have moved too (>= 99 % non-zero displacement) and in the same direction (>= min_agree; the remainder are elements
-  whose fp32 gradient is smaller than the bf16 pipeline's noise -- Adam turns even those into a full +-lr step).
+  (|w_ref_final - w_init| >= 0.5 * lr * steps, i.e. a gradient sign that did not flip between the steps) AND whose fp32
+  oracle gradient of the first iteration stands clear of the bf16 pipeline's noise in its tensor (floor_masks: |g32| >=
+  3 * rms(g_bf16_emulated - g32), the selection sign_check uses), the HIP path must have moved too (>= 99 % non-zero
+  displacement) and in the same direction (>= 0.98; measured 0.991-0.9999, profiles/r5_test_report.txt).  Without the floor selection the figure is reported, not judged: Adam
+  turns an element whose gradient is below the noise into a full +-lr step of arbitrary sign, and the bf16-EMULATING ORACLE
+  itself agrees with the reference on only 0.902-0.904 of the clearly moved generator weights of the CycleGAN fixture
+  (scratch/r5/emul_agreement.py, CPU; the HIP path: 0.901-0.906) against 0.9993 above the floor.
 * sign_check (oracle gradients): for elements whose fp32 oracle gradient exceeds the measured bf16 floor of its tensor
   (|g32| >= 3 * rms(g_bf16_emulated - g32)) the displacement of one real Adam step must be opposite to the gradient on
   >= 99 %.
@@ -38,30 +42,48 @@ def snapshot(nets):
     return {tag: {k: sampled(v) for k, v in net.state_dict().items() if v.dtype.is_floating_point} for tag, net in nets.items()}
 
 
+def floor_masks(g32, g16, k=3.0):
+    """{key: fp32 oracle gradient}, {key: bf16-emulated oracle gradient} -> {key: bool mask over the sampled elements}: those
+    whose gradient is at least k times the rms deviation bf16 storage alone causes in that tensor"""
+    out = {}
+    for key, a in g32.items():
+        a, b = a.detach().float().cpu().reshape(-1), g16[key].detach().float().cpu().reshape(-1)
+        floor = float((b - a).pow(2).mean().sqrt())
+        m = a.abs() >= max(k * floor, 1e-30)
+        out[key] = m[sample_idx(m.numel())].numpy()
+    return out
+
+
 class MovementAgreement:
     def __init__(self, min_move=0.5):
         self.min_move = min_move
         self.acc = {}
+        self.raw = {}
 
-    def add(self, tag, init, got, ref, unit):
-        """init / got / ref: sampled values (numpy); unit: lr * number of Adam updates of this tensor"""
+    def add(self, tag, init, got, ref, unit, mask=None):
+        """init / got / ref: sampled values (numpy); unit: lr * number of Adam updates of this tensor; mask: floor_masks()
+        entry of the tensor (None: every clearly moved element is judged)"""
         d_ref, d_hip = ref.reshape(-1) - init.reshape(-1), got.reshape(-1) - init.reshape(-1)
-        sel = np.abs(d_ref) >= self.min_move * unit
-        a = self.acc.setdefault(tag, [0, 0, 0, 0])
-        a[0] += int(sel.sum())
-        a[1] += int((np.sign(d_hip[sel]) == np.sign(d_ref[sel])).sum())
-        a[2] += int((d_hip[sel] != 0).sum())
-        a[3] += int(d_ref.size)
+        clear = np.abs(d_ref) >= self.min_move * unit
+        for acc, sel in ((self.raw, clear), (self.acc, clear if mask is None else (clear & mask.reshape(-1)))):
+            a = acc.setdefault(tag, [0, 0, 0, 0])
+            a[0] += int(sel.sum())
+            a[1] += int((np.sign(d_hip[sel]) == np.sign(d_ref[sel])).sum())
+            a[2] += int((d_hip[sel] != 0).sum())
+            a[3] += int(d_ref.size)
 
-    def check(self, min_agree=0.9, min_moved=0.99, min_selected=0.1):
+    def check(self, min_agree=0.98, min_moved=0.99, min_selected=0.04):
         assert self.acc, 'no tensors were compared'
         for tag, (n, agree, moved, total) in sorted(self.acc.items()):
-            _report('update agreement %-9s: %6d of %6d sampled elements moved clearly in the reference; same direction %.4f, '
-                    'moved at all %.4f' % (tag, n, total, agree / max(n, 1), moved / max(n, 1)))
+            rn, ragree = self.raw[tag][0], self.raw[tag][1]
+            _report('update agreement %-9s: %6d of %6d sampled elements moved clearly in the reference and stand above the bf16 '
+                    'gradient floor; same direction %.4f, moved at all %.4f  (all %d clearly moved ones: %.4f)' % (
+                        tag, n, total, agree / max(n, 1), moved / max(n, 1), rn, ragree / max(rn, 1)))
         for tag, (n, agree, moved, total) in self.acc.items():
-            assert n >= max(8, min_selected * total), (tag, 'too few clearly moved elements', n, total)
+            assert n >= max(8, min_selected * total), (tag, 'too few clearly moved elements above the floor', n, total)
             assert moved >= min_moved * n, (tag, 'weights did not move', moved, n)
             assert agree >= min_agree * n, (tag, 'update direction disagrees with the reference', agree, n)
+            assert self.raw[tag][1] >= 0.85 * self.raw[tag][0], (tag, 'update direction disagrees with the reference (all clearly moved)')
 
 
 def sign_check(tag, before, after, g32, g16, acc):
@@ -84,3 +106,16 @@ def sign_report(acc, min_frac=0.99, min_selected=0.02):
     for tag, (n, ok, total) in acc.items():
         assert n >= min_selected * total, (tag, 'too few elements above the floor', n, total)
         assert ok >= min_frac * n, (tag, 'update sign disagrees with the oracle gradient', ok, n)
+
+
+MAP_LOSSES = ('G_GAN', 'D_real', 'D_fake', 'D_arch', 'D_arch_diff', 'teacher_D_arch_diff', 'D_fake_arch', 'D_real_arch')
+
+
+def loss_tol(name, ref, n_map, rel=3e-2):
+    """Bar on |got - ref| of a logged loss scalar (no max(1, |ref|) denominator): `rel` of the reference's
+    value, but not below what ONE flipped decision costs.  The GAN / arch terms are means over the n_map outputs of a PatchGAN
+    map behind a hinge (or differences of two such means): an output that bf16 rounding carries across a kink, here or in a
+    LeakyReLU / gate below it, moves the mean by up to ~2 / n_map (72-value map of the 64 x 64 fixtures: 0.028; the 900 values
+    of a 256 x 256 image: 0.0022).  Every other term is a mean over >= 1e4 elements: floor 1e-3."""
+    floor = 2.0 / max(int(n_map), 1) if any(name == m or name.startswith(m) for m in MAP_LOSSES) else 1e-3
+    return max(rel * abs(ref), floor)

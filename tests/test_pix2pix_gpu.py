@@ -100,6 +100,17 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-12))
 
 
+def _loss_tol(name, ref, model):
+    """tests/_updates.loss_tol with the size of the PatchGAN map of the model's current batch"""
+    from tests import _updates
+    N, _, H, W = model.real_A.shape
+    h = ((H // 8) - 1) - 1                  # three stride-2 convs, two k4 s1 p1 convs
+    w = ((W // 8) - 1) - 1
+    tol = _updates.loss_tol(name, ref, N * h * w)
+    print('loss %-20s ref %.5g bar %.4g' % (name, ref, tol))
+    return tol
+
+
 def test_gcc_two_iterations_vs_reference_golden(golden_dir):
     from tests.golden.recipe import sample_idx
     z = load(golden_dir, 'pix2pix_gcc_d6.npz')
@@ -108,7 +119,11 @@ def test_gcc_two_iterations_vs_reference_golden(golden_dir):
     nets = {'final.sG.': model.netG, 'final.tG.': teacher.netG, 'final.sD.': model.netD, 'final.tD.': teacher.netD}
     init = _updates.snapshot(nets)
     agree = _updates.MovementAgreement()
+    from tests.test_oracle_golden import build_gcc_oracle as _bo
+    _in = [torch.from_numpy(z['it0.' + k]) for k in ('A', 'B', 'vA', 'vB')]
+    masks = _updates.floor_masks(_oracle_grads(lambda: _bo(z), *_in, False), _oracle_grads(lambda: _bo(z), *_in, True))
     worst = {}
+    worst_loss = 0.0
     # the same two iterations on the oracle with bf16 storage emulated at the points the HIP path rounds: the second bar a
     # logged scalar may meet (the bar the model tests of the other families use), instead of a looser tolerance
     from oracle import gcc_oracle as O
@@ -164,15 +179,17 @@ def test_gcc_two_iterations_vs_reference_golden(golden_dir):
                 name = k.split('.')[-1]
                 ref = float(z[k])
                 got = losses[name] if '.loss.' in k else tl[name]
-                err = abs(got - ref) / max(1.0, abs(ref))
+                err = abs(got - ref) / _updates.loss_tol(name, ref, n_map=72)         # 2 x 1 x 6 x 6 PatchGAN map
                 e16 = emu[it][0 if '.loss.' in k else 1].get(name)
-                err16 = abs(got - e16) / max(1.0, abs(e16)) if e16 is not None else float('inf')
+                err16 = abs(got - e16) / _updates.loss_tol(name, e16, n_map=72) if e16 is not None else float('inf')
                 print('it%d %s %s: got %.5g ref %.5g bf16-emulating oracle %s' % (it, 'S' if '.loss.' in k else 'T', name, got, ref,
                                                                                  '%.5g' % e16 if e16 is not None else '-'))
-                # 3e-2 of the reference's value, or of the bf16-emulating oracle's (the arch terms are differences of two O(1)
-                # hinge means over a 2x1x6x6 PatchGAN map: one of 72 values crossing the hinge moves a mean by 1.4 %, and behind
-                # the first Adam steps which side it falls on is a matter of bf16 storage, not of the arithmetic)
-                assert min(err, err16) <= 3e-2, (it, k, got, ref, e16)
+                # within the bar (_updates.loss_tol: 3e-2 relative, floor = one flipped decision of the 72-value map) of the
+                # reference's value, or of the bf16-emulating oracle's (the arch terms are differences of two O(1) hinge means:
+                # behind the first Adam steps which side of the hinge a value falls on is a matter of bf16 storage, not of the
+                # arithmetic)
+                worst_loss = max(worst_loss, min(err, err16))
+                assert min(err, err16) <= 1.0, (it, k, got, ref, e16)
     lr = opt.lr
     for prefix, mod, steps in (('final.sG.', model.netG, 2), ('final.tG.', teacher.netG, 2), ('final.sD.', model.netD, 2),
                                ('final.tD.', teacher.netD, 2)):
@@ -198,8 +215,10 @@ def test_gcc_two_iterations_vs_reference_golden(golden_dir):
             assert err <= tol, (prefix, name, err, tol)
             if not (name.endswith('running_mean') or name.endswith('running_var')):
                 agree.add(prefix + ('alpha' if name.endswith('alpha') else 'w'), init[prefix][name], g, ref.reshape(-1),
-                          (opt.arch_lr if name.endswith('alpha') else lr) * steps)
+                          (opt.arch_lr if name.endswith('alpha') else lr) * steps,
+                          mask=masks.get(('alpha', name) if name.endswith('alpha') else (prefix[6:8], name)))
     print('post-step weights: worst err/tol', worst)
+    _updates._report('logged losses: worst |err| / bar %.3f (bar: 3e-2 relative, floor 2 / 72 on the PatchGAN-map means)' % worst_loss)
     agree.check()
 
 
@@ -347,8 +366,37 @@ def test_dropout_iteration_vs_oracle_with_injected_masks():
     om.optimizer_netD_arch()
     got = model.get_current_losses()
     for k, v in om.losses.items():
-        assert abs(got[k] - v) <= 3e-2 * max(1.0, abs(v)), (k, got[k], v)
+        assert abs(got[k] - v) <= _loss_tol(k, v, model), (k, got[k], v)
     print('dropout on: %d loss scalars within 3e-2 of the oracle' % len(om.losses))
+
+
+def _oracle_grads(build_oracle, A, B, vA, vB, emulate, gan_mode=None):
+    """fp32 oracle, or the oracle with bf16 storage emulated at the points the HIP path rounds"""
+    from oracle import gcc_oracle as O
+    O.EMULATE_BF16 = emulate
+    try:
+        om, ot, oopt = build_oracle()
+        if gan_mode is not None:
+            oopt.gan_mode = gan_mode
+        for o in (om, ot):
+            o.lr_G = o.lr_D = o.lr_arch = 0.0
+        om.set_input(A, B)
+        om.optimize_parameters()
+        g = {}
+        for tag, sd, keys in (('tD', ot.D, ot.D_w_keys), ('tG', ot.G, ot.G_keys), ('sD', om.D, om.D_w_keys),
+                              ('sG', om.G, om.G_keys)):
+            for k in keys:
+                g[(tag, k)] = sd[k].grad.clone()
+        for i in range(4):
+            g[('T', i)] = om.T[i].grad.clone()
+        om.set_input(vA, vB)
+        om.clipping_mask_alpha()
+        om.optimizer_netD_arch()
+        for k in om.D_a_keys:
+            g[('alpha', k)] = om.D[k].grad.clone()
+        return g
+    finally:
+        O.EMULATE_BF16 = False
 
 
 def _gradient_check(model, teacher, build_oracle, A, B, vA, vB, skip=None, gan_mode='lsgan'):
@@ -359,34 +407,8 @@ def _gradient_check(model, teacher, build_oracle, A, B, vA, vB, skip=None, gan_m
             o.param_groups[0]['lr'] = 0.0
     model.optimizer_arch.param_groups[0]['lr'] = 0.0
 
-    def oracle_grads(emulate):
-        """fp32 oracle, or the oracle with bf16 storage emulated at the points the HIP path rounds"""
-        from oracle import gcc_oracle as O
-        O.EMULATE_BF16 = emulate
-        try:
-            om, ot, oopt = build_oracle()
-            oopt.gan_mode = gan_mode
-            for o in (om, ot):
-                o.lr_G = o.lr_D = o.lr_arch = 0.0
-            om.set_input(A, B)
-            om.optimize_parameters()
-            g = {}
-            for tag, sd, keys in (('tD', ot.D, ot.D_w_keys), ('tG', ot.G, ot.G_keys), ('sD', om.D, om.D_w_keys),
-                                  ('sG', om.G, om.G_keys)):
-                for k in keys:
-                    g[(tag, k)] = sd[k].grad.clone()
-            for i in range(4):
-                g[('T', i)] = om.T[i].grad.clone()
-            om.set_input(vA, vB)
-            om.clipping_mask_alpha()
-            om.optimizer_netD_arch()
-            for k in om.D_a_keys:
-                g[('alpha', k)] = om.D[k].grad.clone()
-            return g
-        finally:
-            O.EMULATE_BF16 = False
-    g32 = oracle_grads(False)
-    g16 = oracle_grads(True)
+    g32 = _oracle_grads(build_oracle, A, B, vA, vB, False, gan_mode)
+    g16 = _oracle_grads(build_oracle, A, B, vA, vB, True, gan_mode)
     model.set_input({'A': A, 'B': B, 'A_paths': ['a'], 'B_paths': ['b']})
     model.optimize_parameters()
     torch.cuda.synchronize()
@@ -548,10 +570,10 @@ def test_full_config_iteration_vs_oracle(plan, batch):
     assert len(om.losses) >= 9
     for k, v in om.losses.items():
         print('S %-22s got %.5g ref %.5g' % (k, got[k], v))
-        assert abs(got[k] - v) <= 3e-2 * max(1.0, abs(v)), (k, got[k], v)
+        assert abs(got[k] - v) <= _loss_tol(k, v, model), (k, got[k], v)
     for k in ('G_GAN', 'G_L1', 'D_real', 'D_fake'):
         print('T %-22s got %.5g ref %.5g' % (k, tgot[k], ot.losses[k]))
-        assert abs(tgot[k] - ot.losses[k]) <= 3e-2 * max(1.0, abs(ot.losses[k])), (k, tgot[k], ot.losses[k])
+        assert abs(tgot[k] - ot.losses[k]) <= _loss_tol(k, ot.losses[k], model), (k, tgot[k], ot.losses[k])
 
 
 RESNET_ARGV = ['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '0', '--backbone', 'resnet',
@@ -624,7 +646,7 @@ def test_resnet_backbone_vs_reference_golden(golden_dir):
         if k.startswith('loss.'):
             ref, got = float(z[k]), losses[k[5:]]
             print('%s: got %.5g ref %.5g' % (k, got, ref))
-            assert abs(got - ref) <= 3e-2 * max(1.0, abs(ref)), (k, got, ref)
+            assert abs(got - ref) <= _loss_tol(k[5:], ref, model), (k, got, ref)
     for prefix, mod in (('final.sG.', model.netG), ('final.tG.', teacher.netG), ('final.sD.', model.netD)):
         sd = mod.state_dict()
         for k in z.files:
@@ -692,7 +714,7 @@ def test_pruned_student_irregular_widths(golden_dir):
     losses = model.get_current_losses()
     for k in ('G_GAN', 'G_L1', 'D_real', 'D_fake'):
         ref = float(z['loss.' + k])
-        assert abs(losses[k] - ref) <= 3e-2 * max(1.0, abs(ref)), (k, losses[k], ref)
+        assert abs(losses[k] - ref) <= _loss_tol(k, ref, model), (k, losses[k], ref)
     sd = model.netG.state_dict()
     for k in z.files:
         if k.startswith('final.G.'):
@@ -727,7 +749,7 @@ def _check_pruned_iteration(model, z, tag, opt):
     losses = model.get_current_losses()
     for k in ('G_GAN', 'G_L1', 'D_real', 'D_fake'):
         ref = float(z[tag + '.loss.' + k])
-        assert abs(losses[k] - ref) <= 3e-2 * max(1.0, abs(ref)), (k, losses[k], ref)
+        assert abs(losses[k] - ref) <= _loss_tol(k, ref, model), (k, losses[k], ref)
     sd = model.netG.state_dict()
     pre = tag + '.final.G.'
     for k in z.files:
@@ -847,7 +869,7 @@ def test_prune_end_to_end_on_gpu(golden_dir, tmp_path):
     for k in z.files:
         if k.startswith('gcc.loss.'):
             name, ref = k.split('.')[-1], float(z[k])
-            assert abs(losses[name] - ref) <= 3e-2 * max(1.0, abs(ref)), (name, losses[name], ref)
+            assert abs(losses[name] - ref) <= _loss_tol(name, ref, model), (name, losses[name], ref)
     sd = model.netG.state_dict()
     for k in z.files:
         if k.startswith('gcc.final.sG.'):
@@ -891,7 +913,7 @@ def test_pruned_resnet_generator(golden_dir, tag):
     losses = model.get_current_losses()
     for k in ('G_GAN', 'G_L1', 'D_real', 'D_fake'):
         ref = float(z['pruned_%s.loss.%s' % (tag, k)])
-        assert abs(losses[k] - ref) <= 3e-2 * max(1.0, abs(ref)), (k, losses[k], ref)
+        assert abs(losses[k] - ref) <= _loss_tol(k, ref, model), (k, losses[k], ref)
     sd = model.netG.state_dict()
     pre = 'pruned_%s.final.G.' % tag
     last = [k for k in sd if k.endswith('.bias')][-1]

@@ -172,6 +172,7 @@ def test_srgan_two_iterations_vs_reference_golden(golden_dir):
     from tests import _updates
     init = _updates.snapshot({'sG': model.netG, 'sD': model.netD, 'tG': teacher.netG, 'tD': teacher.netD})
     agree = _updates.MovementAgreement()
+    masks = _updates.floor_masks(_oracle_grads(z, False), _oracle_grads(z, True))
     emu = []
     O.EMULATE_BF16 = True
     try:
@@ -240,8 +241,40 @@ def test_srgan_two_iterations_vs_reference_golden(golden_dir):
             assert err <= tol, (tag, name, err, tol)
             if not (name.endswith('running_mean') or name.endswith('running_var')):
                 agree.add(tag + ('.alpha' if name.endswith('alpha') else ''), init[tag][name], g, ref.reshape(-1),
-                          (opt.arch_lr if name.endswith('alpha') else opt.lr) * 2)
+                          (opt.arch_lr if name.endswith('alpha') else opt.lr) * 2,
+                          mask=masks.get(('alpha', name) if name.endswith('alpha') else (tag, name)))
     agree.check()
+
+
+def _oracle_grads(z, emulate):
+    """every parameter gradient of the first golden iteration + arch step on the oracle, learning rates 0 (fp32, or with bf16
+    storage emulated)"""
+    from oracle import gcc_oracle as O
+    from tests.test_oracle_golden import build_srgan_oracle
+    lr_, hr_, vlr, vhr = (torch.from_numpy(z['it0.' + k]) for k in ('lr', 'hr', 'vlr', 'vhr'))
+    O.EMULATE_BF16 = emulate
+    try:
+        om, ot, _ = build_srgan_oracle(z)
+        for o in (om, ot):
+            o.lr_G = o.lr_D = o.lr_arch = 0.0
+        om.set_input(lr_, hr_)
+        om.optimize_parameters()
+        g = {}
+        for tag, who in (('t', ot), ('s', om)):
+            for k in who.G_keys:
+                g[(tag + 'G', k)] = who.G[k].grad.clone()
+            for k in who.D_w_keys:
+                g[(tag + 'D', k)] = who.D[k].grad.clone()
+        for i in range(4):
+            g[('T', i)] = om.T[i].grad.clone()
+        om.set_input(vlr, vhr)
+        om.clipping_mask_alpha()
+        om.optimizer_netD_arch()
+        for k in om.D_a_keys:
+            g[('alpha', k)] = om.D[k].grad.clone()
+        return g
+    finally:
+        O.EMULATE_BF16 = False
 
 
 def test_srgan_gradients_vs_oracle(golden_dir):
@@ -260,31 +293,7 @@ def test_srgan_gradients_vs_oracle(golden_dir):
     model.optimizer_arch.param_groups[0]['lr'] = 0.0
     lr_, hr_, vlr, vhr = (torch.from_numpy(z['it0.' + k]) for k in ('lr', 'hr', 'vlr', 'vhr'))
 
-    def oracle_grads(emulate):
-        O.EMULATE_BF16 = emulate
-        try:
-            om, ot, _ = build_srgan_oracle(z)
-            for o in (om, ot):
-                o.lr_G = o.lr_D = o.lr_arch = 0.0
-            om.set_input(lr_, hr_)
-            om.optimize_parameters()
-            g = {}
-            for tag, who in (('t', ot), ('s', om)):
-                for k in who.G_keys:
-                    g[(tag + 'G', k)] = who.G[k].grad.clone()
-                for k in who.D_w_keys:
-                    g[(tag + 'D', k)] = who.D[k].grad.clone()
-            for i in range(4):
-                g[('T', i)] = om.T[i].grad.clone()
-            om.set_input(vlr, vhr)
-            om.clipping_mask_alpha()
-            om.optimizer_netD_arch()
-            for k in om.D_a_keys:
-                g[('alpha', k)] = om.D[k].grad.clone()
-            return g
-        finally:
-            O.EMULATE_BF16 = False
-    g32, g16 = oracle_grads(False), oracle_grads(True)
+    g32, g16 = _oracle_grads(z, False), _oracle_grads(z, True)
     model.set_input({'lr': lr_, 'hr': hr_, 'lr_names': ['a'] * 2, 'hr_names': ['b'] * 2})
     model.optimize_parameters()
     torch.cuda.synchronize()
