@@ -386,6 +386,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    # the measured path is the shipped library with every process-wide tuning hook at its built-in default (the tile plan is not
+    # among them: it travels with each call, ops.set_plan): a GCC_* override in the environment would make the line describe
+    # another configuration than the product's -- refuse (GCC_BENCH_ALLOW_OPTIONS=1: same-box A/B runs, flagged in the JSON)
+    from gcc_amd import _lib
+    lib = ops.lib()
+    option_vector = {n: int(lib.gcc_get_option(i)) for i, n in enumerate(_lib.OPT_NAMES)}
+    options_default = bool(lib.gcc_options_default())
+    if 'diag' in os.path.basename(_lib.LIB_PATH):
+        raise SystemExit('bench.py measures libgcc_hip.so, not the diagnostic build (%s)' % _lib.LIB_PATH)
+    if not options_default and os.environ.get('GCC_BENCH_ALLOW_OPTIONS') != '1':
+        raise SystemExit('tuning hooks differ from their defaults (%s): unset the GCC_* variables or pass GCC_BENCH_ALLOW_OPTIONS=1'
+                         % {k: v for k, v in option_vector.items()})
     model, opt = build(args.batch)
     model.G.profile_tag, model.teacher_model.G.profile_tag = 'student_G', 'teacher_G'
     device = model.device
@@ -505,6 +517,8 @@ def main():
         'loss_check': {k: round(v, 4) for k, v in losses.items()},
         'loss_check_step1': loss_check_step1(first_losses, args.batch, world),
         'launches_per_step': launches_per_step,
+        'library': {'so': os.path.basename(_lib.LIB_PATH), 'tuning_hooks_at_default': options_default, 'tuning_hooks': option_vector,
+                    'tile_plan_pinned_by_env': dict(ops._plan_pinned), 'tile_plan_of_the_step': ops.current_plan()},
     }
     if roof is not None:
         if 'conv_roofline' in roof:       # north_star: throughput as a fraction of the conv roofline

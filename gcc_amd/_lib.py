@@ -14,9 +14,17 @@ class GccError(RuntimeError):
     pass
 
 
+class conv_plan_t(C.Structure):
+    """include/gcc_hip.h gcc_conv_plan_t: the tile plan of a convolution call (every field 0 = the library's default)"""
+    _fields_ = [(n, C.c_int) for n in ('tile_families', 'big_min', 'big_nk', 'pair', 'halo_hc', 'wgrad_wgs_big', 'wgrad_wgs')]
+
+
+PLAN_FIELDS = tuple(n for n, _ in conv_plan_t._fields_)
+
+
 class conv_t(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('N', 'H', 'W', 'Ci', 'Co', 'KH', 'KW', 'stride', 'pad',
-                                       'ldx', 'xoff', 'ldy', 'yoff')]
+                                       'ldx', 'xoff', 'ldy', 'yoff')] + [('plan', conv_plan_t)]
 
 
 class epilogue_t(C.Structure):
@@ -66,11 +74,14 @@ class adam_chunk_t(C.Structure):
 
 
 # gcc_set_option ids (enum in include/gcc_hip.h)
-(OPT_IGEMM_BIG, OPT_IGEMM_BIG_MIN, OPT_IGEMM_BIG_NK, OPT_IGEMM_GLDS, OPT_IGEMM_HEAD, OPT_IGEMM_THIN, OPT_WGRAD_BIG,
- OPT_BN_SWEEPS, OPT_BN_MAXBLK, OPT_BN_REDUCE_THREADS, OPT_BN_REDUCE_CAP, OPT_INORM_LPP, OPT_WGRAD_WGS_BIG,
- OPT_WGRAD_WGS, OPT_IGEMM_FORCE_BC, OPT_IGEMM_FORCE_KSPLIT, OPT_IGEMM_NARROW, OPT_IGEMM_PAIR, OPT_WGRAD_BIG_MIN_TILES, OPT_FUSE_BN,
- OPT_BN_BWD_SMALL, OPT_WGRAD_ROW_TABLE, OPT_IGEMM_HALO, OPT_FUSE_BN_PARTIAL_KB, OPT_INORM_GRID, OPT_HALO_HC,
- OPT_IGEMM_STAGES, OPT_WGRAD_TS, OPT_HALO_XCD_COLS, OPT_DEBUG) = range(30)
+(OPT_IGEMM_GLDS, OPT_IGEMM_HEAD, OPT_IGEMM_THIN, OPT_WGRAD_BIG, OPT_BN_SWEEPS, OPT_BN_MAXBLK, OPT_BN_REDUCE_THREADS,
+ OPT_BN_REDUCE_CAP, OPT_INORM_LPP, OPT_IGEMM_FORCE_BC, OPT_IGEMM_FORCE_KSPLIT, OPT_IGEMM_NARROW, OPT_WGRAD_BIG_MIN_TILES,
+ OPT_FUSE_BN, OPT_BN_BWD_SMALL, OPT_WGRAD_ROW_TABLE, OPT_IGEMM_HALO, OPT_FUSE_BN_PARTIAL_KB, OPT_INORM_GRID, OPT_IGEMM_STAGES,
+ OPT_WGRAD_TS, OPT_HALO_XCD_COLS) = range(22)
+OPT_COUNT = 22
+OPT_NAMES = ('IGEMM_GLDS', 'IGEMM_HEAD', 'IGEMM_THIN', 'WGRAD_BIG', 'BN_SWEEPS', 'BN_MAXBLK', 'BN_REDUCE_THREADS', 'BN_REDUCE_CAP',
+             'INORM_LPP', 'IGEMM_FORCE_BC', 'IGEMM_FORCE_KSPLIT', 'IGEMM_NARROW', 'WGRAD_BIG_MIN_TILES', 'FUSE_BN', 'BN_BWD_SMALL',
+             'WGRAD_ROW_TABLE', 'IGEMM_HALO', 'FUSE_BN_PARTIAL_KB', 'INORM_GRID', 'IGEMM_STAGES', 'WGRAD_TS', 'HALO_XCD_COLS')
 
 _P = C.c_void_p
 _I = C.c_int
@@ -85,7 +96,7 @@ PROTOTYPES = {
     'gcc_device_error': (_I, [_I]),
     'gcc_set_option': (_I, [_I, _I]),
     'gcc_get_option': (_I, [_I]),
-    'gcc_conv_set_plan': (_I, [_I, _I, _I]),
+    'gcc_options_default': (_I, []),
     'gcc_conv_tile': (_I, [C.POINTER(conv_t), _I]),
     'gcc_conv_stat_tiles': (_I, [C.POINTER(conv_t), _I]),
     'gcc_conv_route': (_I, [C.POINTER(conv_t), _I, C.POINTER(epilogue_t)]),

@@ -116,8 +116,23 @@ __device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
     return f.d == 1 ? n : (int)(__umulhi((uint32_t)n, f.mul) >> f.shr);
 }
 
-// process-wide tuning options (include/gcc_hip.h: gcc_set_option); defined in misc.hip
+// process-wide tuning hooks (include/gcc_hip.h: gcc_set_option); defined in misc.hip
 int gcc_opt(int id);
+// per-call tile plan (gcc_conv_t.plan): a field that is 0 means the library's default
+static inline int plan_or(int v, int def) { return v ? v : def; }
+constexpr int PLAN_TILE_FAMILIES = 3, PLAN_BIG_MIN = 120, PLAN_BIG_NK = 24, PLAN_WGRAD_WGS_BIG = 256, PLAN_WGRAD_WGS = 512;
+// Diagnostic ablations (timing probes whose RESULTS ARE WRONG, the test of the device error word) are compiled only into the
+// GCC_DIAG_BUILD variant of the library (build.sh: libgcc_hip_diag.so); in the shipped one the bits are the constant 0 and the
+// branches on them do not exist.  Bits: 2 the main loops issue no staging loads after the first step, 4 they re-load the first
+// step's addresses, 8 weights every fourth step only, 32 s_memrealtime stamps of the grid InstanceNorm, 64 its exchange is made
+// to time out (256 polls, workgroup 1 of every domain publishes nothing).
+#ifdef GCC_DIAG_BUILD
+int gcc_diag_bits();
+#define GCC_DIAG(x) (x)
+#else
+static inline int gcc_diag_bits() { return 0; }
+#define GCC_DIAG(x) 0
+#endif
 // Every kernel launch of the library goes through gcc_launch: it is counted (gcc_launch_count: bench.py reports launches per
 // step) and, while the calling thread records (gcc_replay_begin, replay.hip), written down with its argument values so that
 // gcc_replay_run can issue it again without the host code in front of it.  The launch itself is hipLaunchKernel on the kernel's

@@ -403,7 +403,7 @@ HaloPlan halo_plan(const gcc_conv_t* c, int dgrad) {
         if ((c->H & 1) || (c->W & 1)) return h;
         gh = c->H / 2; gw = c->W / 2;
         if (!dgrad) { if (Cout % 128) return h; h.mode = 0; }
-        else if (Cout == 128 && gcc_opt(GCC_OPT_HALO_HC) != 128) h.mode = 2;
+        else if (Cout == 128 && c->plan.halo_hc != 128) h.mode = 2;
         else if (Cout % 128 == 0) h.mode = 1;
         else return h;
         int tw = 256;
@@ -429,17 +429,17 @@ HaloPlan halo_plan(const gcc_conv_t* c, int dgrad) {
     if (h.npieces > HALO_MAX_PIECES) return h;
     h.tiles_x = gw / h.TW; h.tiles_y = gh / h.TR;
     // columns per tile: 256 (one workgroup per CU, the least CU time per FLOP), or 128 -- twice the workgroups -- where the layer
-    // has no 256-column tiling, where 256-column tiles are too few to be routed here at all, or (GCC_OPT_HALO_HC 1; the models'
-    // single-stream plan sets it like GCC_OPT_IGEMM_PAIR) where they would cover only half the chip
+    // has no 256-column tiling, where 256-column tiles are too few to be routed here at all, or (gcc_conv_t.plan.halo_hc 1; the models'
+    // single-stream plan sets it together with plan.pair) where they would cover only half the chip
     const long pix_tiles = (long)c->N * h.tiles_x * h.tiles_y * h.phases;
-    const int pref = gcc_opt(GCC_OPT_HALO_HC);
+    const int pref = c->plan.halo_hc;
     h.hc = 256;
     if (h.mode != 2) {
         const bool can256 = Cout % 256 == 0, can128 = Cout % 128 == 0;
         const long w256 = can256 ? pix_tiles * (Cout / 256) : 0;
         if (pref == 128 && can128) h.hc = 128;
         else if (pref == 256 && can256) h.hc = 256;
-        else if (!can256 || w256 < gcc_opt(GCC_OPT_IGEMM_BIG_MIN) || (pref == 1 && w256 < 192)) h.hc = can128 ? 128 : 256;
+        else if (!can256 || w256 < plan_or(c->plan.big_min, PLAN_BIG_MIN) || (pref == 1 && w256 < 192)) h.hc = can128 ? 128 : 256;
         if (Cout % h.hc) return h;
     }
     h.ntiles = h.mode == 2 ? 1 : Cout / h.hc;

@@ -428,9 +428,9 @@ __global__ __launch_bounds__((BP / 32) * 64) void igemm_kernel(const IgemmParams
         for (int kt = 0; kt < nk; kt++) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (!(p.debug & 2)) {
-                issue((kt + 1) & 1, !(p.debug & 8) || (kt & 3) == 0);    // past the end of K the offsets are out of range: zero fill, unused
-                if (!(p.debug & 4)) next_step();    // (rare) tap change: its VALU work hides under the MFMAs below
+            if (!(GCC_DIAG(p.debug) & 2)) {
+                issue((kt + 1) & 1, !(GCC_DIAG(p.debug) & 8) || (kt & 3) == 0);    // past the end of K the offsets are out of range: zero fill, unused
+                if (!(GCC_DIAG(p.debug) & 4)) next_step();    // (rare) tap change: its VALU work hides under the MFMAs below
                 else {
 #pragma unroll
                     for (int i = 0; i < AI; i++) cur_a[i] -= BK * 2;
@@ -768,7 +768,7 @@ int launch(const IgemmParams& p, int phases, int batch, hipStream_t st) {
     bool launched = false;
     if constexpr (BP == 128 && (BC == 32 || BC == 64)) {
         // three LDS stages (two k-steps in flight) for the short-tile layers: GCC_OPT_IGEMM_STAGES
-        if (ut && use_glds() && gcc_opt(GCC_OPT_IGEMM_STAGES) >= 3 && !(p.debug & 14)) {
+        if (ut && use_glds() && gcc_opt(GCC_OPT_IGEMM_STAGES) >= 3 && !(GCC_DIAG(p.debug) & 14)) {
             constexpr int LDS3 = 3 * (BP + BC) * BK * 2 > C::LDS_BYTES_EPI ? 3 * (BP + BC) * BK * 2 : C::LDS_BYTES_EPI;
             static std::once_flag attr3;
             std::call_once(attr3, [] {
@@ -806,13 +806,13 @@ struct TilePlan { int BP, BC, ntiles, mtiles, max_slices, pair; };
 // does a launch take the LDS-resident-neighbourhood kernel (conv_halo.hip)?  With statistics its tile rows must be the ones
 // gcc_conv_stat_tiles() promised: the stride-2 form keeps the 256-pixel plan's rows, the stride-1 form has its own (and
 // gcc_conv_stat_tiles reports them).
-static bool halo_routed(const HaloPlan& h, int dgrad, bool with_stats, int plan_bp) {
-    if (!h.ok || h.wgs < gcc_opt(GCC_OPT_IGEMM_BIG_MIN)) return false;
+static bool halo_routed(const gcc_conv_plan_t& pl, const HaloPlan& h, int dgrad, bool with_stats, int plan_bp) {
+    if (!h.ok || h.wgs < plan_or(pl.big_min, PLAN_BIG_MIN)) return false;
     if (!with_stats) return true;
     if (dgrad) return false;
     return h.mode == 3 || plan_bp == 256;
 }
-static TilePlan select_tile(size_t max_rows, int Cout, int phases, int nk, int batch) {
+static TilePlan select_tile(const gcc_conv_plan_t& pl, size_t max_rows, int Cout, int phases, int nk, int batch) {
     TilePlan t;
     t.BP = 128;
     t.max_slices = 1 << 30;
@@ -840,9 +840,9 @@ static TilePlan select_tile(size_t max_rows, int Cout, int phases, int nk, int b
     if (const int f = gcc_opt(GCC_OPT_IGEMM_FORCE_BC)) {               // tuning hook
         if (f == 16 || f == 32 || f == 64 || f == 128) { t.BC = f; t.ntiles = cdiv(Cout, f); }
     }
-    // the plan (gcc_conv_set_plan): which tile families are allowed, minimum number of 256-pixel tiles, minimum K depth
-    const int g_big_tiles = gcc_opt(GCC_OPT_IGEMM_BIG), g_big_min = gcc_opt(GCC_OPT_IGEMM_BIG_MIN),
-              g_big_nk = gcc_opt(GCC_OPT_IGEMM_BIG_NK);
+    // the plan (gcc_conv_t.plan): which tile families are allowed, minimum number of 256-pixel tiles, minimum K depth
+    const int g_big_tiles = plan_or(pl.tile_families, PLAN_TILE_FAMILIES) - 1, g_big_min = plan_or(pl.big_min, PLAN_BIG_MIN),
+              g_big_nk = plan_or(pl.big_nk, PLAN_BIG_NK);
     // 256-pixel tiles (one 8-wave workgroup per CU) when they still fill the chip and the K loop is
     // long enough to amortise the un-overlapped prologue / epilogue of a lone workgroup
     if (g_big_tiles && use_glds() && batch == 1 && Cout >= 128 && nk >= g_big_nk) {
@@ -850,7 +850,7 @@ static TilePlan select_tile(size_t max_rows, int Cout, int phases, int nk, int b
         if (g_big_tiles >= 2 && Cout % 256 == 0 && m256 * (Cout / 256) * phases >= g_big_min) {
             t.BP = 256; t.BC = 256; t.ntiles = Cout / 256;
             // fewer than ~3/4 of a chip of one-per-CU workgroups and a long loop: two workgroups per tile, one per K half
-            t.pair = (gcc_opt(GCC_OPT_IGEMM_PAIR) && m256 * (Cout / 256) * phases < 192 && nk >= 48) ? 1 : 0;
+            t.pair = (pl.pair == 1 && m256 * (Cout / 256) * phases < 192 && nk >= 48) ? 1 : 0;
         } else if (m256 * cdiv(Cout, 128) * phases >= g_big_min) {
             t.BP = 256; t.BC = 128; t.ntiles = cdiv(Cout, 128);
         }
@@ -1541,7 +1541,7 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
     if (batch < 1 || (batch > 1 && p.stats)) return GCC_ERR_BAD_ARG;
     const int phases = dgrad ? c->stride * c->stride : 1;
     if (dgrad && (c->KH < c->stride || c->KW < c->stride)) return GCC_ERR_UNSUPPORTED;
-    const TilePlan tp = select_tile(max_rows, p.Cout, phases, conv_nk(c, dgrad), batch);
+    const TilePlan tp = select_tile(c->plan, max_rows, p.Cout, phases, conv_nk(c, dgrad), batch);
     // BatchNorm behind this conv (ep->bn): its coefficients are final when this call returns -- folded by the last-arriving
     // workgroups of the launch that writes the statistic rows where the route can (stats_tail), by a gcc_bn_finalize launch
     // otherwise.  Every route writes (or zero-fills) the gcc_conv_stat_tiles() rows the caller allocated.
@@ -1567,7 +1567,7 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
         // k4 s2 p1 layers whose geometry fits: the tile's input neighbourhood staged once per 64 channels (conv_halo.hip).  With
         // statistics the tile rows must be the ones gcc_conv_stat_tiles() promised (the 256-pixel plan's).
         const HaloPlan h = halo_plan(c, dgrad);
-        if (halo_routed(h, dgrad, p.stats != nullptr, tp.BP)) {
+        if (halo_routed(c->plan, h, dgrad, p.stats != nullptr, tp.BP)) {
             TailFin fin;
             const bool tail = p.stats && make_tail(c->N * h.tiles_x * h.tiles_y, h.ntiles, &fin);
             const int rc2 = launch_halo(c, dgrad, h, src, w, dst, ep, tail ? &fin : nullptr, st);
@@ -1580,7 +1580,7 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
     // ---- split-K decision (needs caller workspace; without it the launch simply is not split) ------
     p.ksplit = 1; p.kper = 0; p.partial = nullptr; p.rows_max = (int)max_rows; p.Cpad = p.ntiles * BC; p.raw_partial = 0;
     p.pair = 0; p.pair_slab = nullptr; p.pair_flags = nullptr;
-    p.debug = gcc_opt(GCC_OPT_DEBUG);
+    p.debug = gcc_diag_bits();
     if (tp.pair && batch == 1 && ep && ep->workspace && (((uintptr_t)ep->workspace) & 15) == 0) {
         const size_t tiles = (size_t)tp.mtiles * tp.ntiles * phases;
         if (pair_workspace(tiles) <= ep->workspace_bytes) {
@@ -1870,7 +1870,7 @@ extern "C" int gcc_conv_bn_act(const gcc_conv_t* c, int dgrad, const void* x, co
     // which plan would the conv take?  (same predicates as gcc_internal_igemm)
     const size_t max_rows = conv_max_rows(c, dgrad);
     const int nk = conv_nk(c, dgrad);
-    const TilePlan tp = select_tile(max_rows, Cout, phases, nk, 1);
+    const TilePlan tp = select_tile(c->plan, max_rows, Cout, phases, nk, 1);
     SplitPlan sp = tp.BP == 128 ? plan_ksplit((long)tp.mtiles * tp.ntiles * phases, nk, tp.max_slices) : SplitPlan{1, nk};
     // The K split is sized to fill the chip with the partial-tile launch, but every slice is one more fp32 copy of the output
     // that splitk_bn_act_kernel -- C / 8 workgroups -- has to read back: the student's 16x16 -> 8x8 layer wrote and folded 16
@@ -1956,7 +1956,7 @@ extern "C" size_t gcc_conv_workspace(const gcc_conv_t* c, int dgrad) {
     const int phases = dgrad ? c->stride * c->stride : 1;
     const size_t max_rows = conv_max_rows(c, dgrad);
     const int nk = conv_nk(c, dgrad);
-    const TilePlan tp = select_tile(max_rows, dgrad ? c->Ci : c->Co, phases, nk, 1);
+    const TilePlan tp = select_tile(c->plan, max_rows, dgrad ? c->Ci : c->Co, phases, nk, 1);
     if (tp.pair) return pair_workspace((size_t)tp.mtiles * tp.ntiles * phases);
     if (tp.BP != 128) return 0;
     const SplitPlan sp = plan_ksplit((long)tp.mtiles * tp.ntiles * phases, nk, tp.max_slices);
@@ -1967,7 +1967,7 @@ extern "C" size_t gcc_conv_workspace(const gcc_conv_t* c, int dgrad) {
 extern "C" int gcc_conv_tile(const gcc_conv_t* c, int dgrad) {
     if (check_conv(c)) return 0;
     const int phases = dgrad ? c->stride * c->stride : 1;
-    const TilePlan tp = select_tile(conv_max_rows(c, dgrad), dgrad ? c->Ci : c->Co, phases, conv_nk(c, dgrad), 1);
+    const TilePlan tp = select_tile(c->plan, conv_max_rows(c, dgrad), dgrad ? c->Ci : c->Co, phases, conv_nk(c, dgrad), 1);
     return tp.BP * 1000 + tp.BC;
 }
 
@@ -1975,9 +1975,9 @@ extern "C" int gcc_conv_stat_tiles(const gcc_conv_t* c, int dgrad) {
     GCC_ENTER();
     if (check_conv(c)) return 0;
     const int phases = dgrad ? c->stride * c->stride : 1;
-    const TilePlan tp = select_tile(conv_max_rows(c, dgrad), dgrad ? c->Ci : c->Co, phases, conv_nk(c, dgrad), 1);
+    const TilePlan tp = select_tile(c->plan, conv_max_rows(c, dgrad), dgrad ? c->Ci : c->Co, phases, conv_nk(c, dgrad), 1);
     const HaloPlan h = halo_plan(c, dgrad);
-    if (halo_routed(h, dgrad, true, tp.BP)) return c->N * h.tiles_x * h.tiles_y;
+    if (halo_routed(c->plan, h, dgrad, true, tp.BP)) return c->N * h.tiles_x * h.tiles_y;
     if (tp.BP == 128 && ceil8(dgrad ? c->Ci : c->Co) / 8 <= 256) {
         // layers whose K loop is split over workgroups: the rows of splitk_fold_stats_kernel (an un-split fallback zero-fills them)
         const SplitPlan sp = plan_ksplit((long)tp.mtiles * tp.ntiles * phases, conv_nk(c, dgrad), tp.max_slices);

@@ -34,7 +34,7 @@ struct WgradParams {
     int accumulate;
     float* dw;
     int rowmode;                     // how issue_loads finds a piece's pixels: 0 every lane decomposes its pixel every step, 1 LDS pixel table
-    int debug;                       // GCC_OPT_DEBUG ablations (timing diagnostics only; results are wrong)
+    int debug;                       // diagnostic-build ablations (common.hpp: GCC_DIAG) (timing diagnostics only; results are wrong)
 };
 
 constexpr int TP = 64;          // pixels per step
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(WCfg<BIG>::NT) void wgrad_kernel(const WgradParams 
             const int cur = kt & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (kt + 1 < nk && !(p.debug & 2)) issue_loads((p.debug & 4) ? 0 : kt + 1, cur ^ 1);
+            if (kt + 1 < nk && !(GCC_DIAG(p.debug) & 2)) issue_loads((GCC_DIAG(p.debug) & 4) ? 0 : kt + 1, cur ^ 1);
             // chunk (kt+1)/CH - 1 was last read a step ago (behind this step's barrier); its slot takes chunk (kt+1)/CH + 1
             if constexpr (TABLE) {
                 if (((kt + 1) & (C::CH - 1)) == 0) build_chunk(((kt + 1) / C::CH) + 1);
@@ -582,7 +582,7 @@ int ts_plan(const gcc_conv_t* c, int batch, int* blocks_per_split) {
     const int Ho = c->H - 1, Wo = c->W - 1;
     const int blocks = c->N * cdiv(Ho, ts::TR) * cdiv(Wo, ts::TW);
     const int tiles = (c->Ci / 64) * (c->Co / 64);
-    const int target = gcc_opt(GCC_OPT_WGRAD_WGS_BIG);
+    const int target = plan_or(c->plan.wgrad_wgs_big, PLAN_WGRAD_WGS_BIG);
     int splits = tiles >= (target * 25) / 32 ? 1 : cdiv(target, tiles);
     if (mode == 1) {
         // worth it where a workgroup streams enough blocks for the three-stage loop, and the tiles alone nearly fill the launch
@@ -609,7 +609,7 @@ int plan_splits(const gcc_conv_t* c, int batch, int* ksteps_per_split, bool* big
                ksteps >= 64;
     int splits;
     if (big) {
-        const int target = gcc_opt(GCC_OPT_WGRAD_WGS_BIG);
+        const int target = plan_or(c->plan.wgrad_wgs_big, PLAN_WGRAD_WGS_BIG);
         splits = tiles_big >= (target * 25) / 32 ? 1 : cdiv(target, tiles_big);
         const int max_splits = ksteps / 16 > 0 ? ksteps / 16 : 1;
         if (splits > max_splits) splits = max_splits;
@@ -617,7 +617,7 @@ int plan_splits(const gcc_conv_t* c, int batch, int* ksteps_per_split, bool* big
         const int tiles = cdiv(ncols, 128) * cdiv(c->Co, 128) * batch;
         // enough tiles to fill the chip (2 workgroups per CU resident): no split, dW written directly;
         // otherwise split the pixel range so that ~512 workgroups exist, >= 8 k-steps (512 pixels) each
-        const int target = gcc_opt(GCC_OPT_WGRAD_WGS);
+        const int target = plan_or(c->plan.wgrad_wgs, PLAN_WGRAD_WGS);
         splits = tiles >= (target * 3) / 8 ? 1 : cdiv(target, tiles);
         const int max_splits = ksteps / 8 > 0 ? ksteps / 8 : 1;
         if (splits > max_splits) splits = max_splits;
@@ -703,7 +703,7 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
     big = big && regular;              // concatenated / unaligned gradients keep the 128 x 128 tiling (same split plan)
     p.direct = (splits == 1 && regular) ? 1 : 0;
     p.accumulate = accumulate; p.dw = dw;
-    p.debug = gcc_opt(GCC_OPT_DEBUG);
+    p.debug = gcc_diag_bits();
     {
         p.rowmode = (gcc_opt(GCC_OPT_WGRAD_ROW_TABLE) && c->KH <= 15 && c->KW <= 15) ? 1 : 0;
     }

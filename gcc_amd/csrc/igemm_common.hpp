@@ -123,7 +123,7 @@ struct IgemmParams {
     int pair;
     float* pair_slab;            // [tiles][256 * 256] fp32
     unsigned int* pair_flags;    // [tiles][2]: ticket, ready -- zeroed by the launcher before every launch
-    int debug = 0;               // GCC_OPT_DEBUG ablations (timing diagnostics only)
+    int debug = 0;               // diagnostic-build ablations (common.hpp: GCC_DIAG) (timing diagnostics only)
     TailFin fin = {};            // BatchNorm finalize by the last-arriving workgroups (tickets NULL: a separate gcc_bn_finalize)
 };
 

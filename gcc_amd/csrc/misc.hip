@@ -439,12 +439,11 @@ extern "C" int gcc_version(void) {
 namespace {
 struct OptDef { const char* env; int def; };
 const OptDef kOptDef[GCC_OPT_COUNT_] = {
-    {"GCC_IGEMM_BIG", 2}, {"GCC_IGEMM_BIG_MIN", 120}, {"GCC_IGEMM_BIG_NK", 24}, {"GCC_IGEMM_GLDS", 1}, {"GCC_IGEMM_HEAD", 1},
-    {"GCC_IGEMM_THIN", 1}, {"GCC_WGRAD_BIG", 1}, {"GCC_BN_SWEEPS", 0}, {"GCC_BN_MAXBLK", 2048}, {"GCC_BN_REDUCE_THREADS", 256},
-    {"GCC_BN_REDUCE_CAP", 1024}, {"GCC_INORM_LPP", 0}, {"GCC_WGRAD_WGS_BIG", 256}, {"GCC_WGRAD_WGS", 512},
-    {"GCC_IGEMM_FORCE_BC", 0}, {"GCC_IGEMM_FORCE_KSPLIT", 0}, {"GCC_IGEMM_NARROW", 1}, {"GCC_IGEMM_PAIR", 0}, {"GCC_WGRAD_BIG_MIN_TILES", 32}, {"GCC_FUSE_BN", 3}, {"GCC_BN_BWD_SMALL", 1},
-    {"GCC_WGRAD_ROW_TABLE", 1}, {"GCC_IGEMM_HALO", 3}, {"GCC_FUSE_BN_PARTIAL_KB", 4096}, {"GCC_INORM_GRID", 1},
-    {"GCC_HALO_HC", 0}, {"GCC_IGEMM_STAGES", 3}, {"GCC_WGRAD_TS", 1}, {"GCC_HALO_XCD_COLS", 1}, {"GCC_DEBUG", 0},
+    {"GCC_IGEMM_GLDS", 1}, {"GCC_IGEMM_HEAD", 1}, {"GCC_IGEMM_THIN", 1}, {"GCC_WGRAD_BIG", 1}, {"GCC_BN_SWEEPS", 0},
+    {"GCC_BN_MAXBLK", 2048}, {"GCC_BN_REDUCE_THREADS", 256}, {"GCC_BN_REDUCE_CAP", 1024}, {"GCC_INORM_LPP", 0},
+    {"GCC_IGEMM_FORCE_BC", 0}, {"GCC_IGEMM_FORCE_KSPLIT", 0}, {"GCC_IGEMM_NARROW", 1}, {"GCC_WGRAD_BIG_MIN_TILES", 32},
+    {"GCC_FUSE_BN", 3}, {"GCC_BN_BWD_SMALL", 1}, {"GCC_WGRAD_ROW_TABLE", 1}, {"GCC_IGEMM_HALO", 3}, {"GCC_FUSE_BN_PARTIAL_KB", 4096},
+    {"GCC_INORM_GRID", 1}, {"GCC_IGEMM_STAGES", 3}, {"GCC_WGRAD_TS", 1}, {"GCC_HALO_XCD_COLS", 1},
 };
 std::atomic<int> g_opt[GCC_OPT_COUNT_];
 int g_opt_default[GCC_OPT_COUNT_];
@@ -505,12 +504,18 @@ extern "C" int gcc_set_option(int id, int value) {
     std::call_once(g_opt_once, opt_init);
     return g_opt[id].exchange(value < 0 ? g_opt_default[id] : value, std::memory_order_relaxed);
 }
-extern "C" int gcc_conv_set_plan(int big, int big_min, int big_nk) {
-    gcc_set_option(GCC_OPT_IGEMM_BIG, big);
-    gcc_set_option(GCC_OPT_IGEMM_BIG_MIN, big_min);
-    gcc_set_option(GCC_OPT_IGEMM_BIG_NK, big_nk);
-    return GCC_OK;
+// 1 while every tuning hook holds its built-in default (environment overrides count as changes): what bench.py asserts
+extern "C" int gcc_options_default(void) {
+    for (int i = 0; i < GCC_OPT_COUNT_; i++)
+        if (gcc_opt(i) != kOptDef[i].def) return 0;
+    return 1;
 }
+#ifdef GCC_DIAG_BUILD
+namespace { std::atomic<int> g_diag{0}; }
+int gcc_diag_bits() { return g_diag.load(std::memory_order_relaxed); }
+// diagnostic build only: set the ablation bits (common.hpp), returns the previous ones
+extern "C" int gcc_diag_set(int bits) { return g_diag.exchange(bits, std::memory_order_relaxed); }
+#endif
 
 extern "C" int gcc_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int N, int C, int H, int W, int ld, int off, int Cfill,
                                          gcc_stream_t stream) {

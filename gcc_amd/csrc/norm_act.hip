@@ -1039,16 +1039,16 @@ struct InGridArgs {
     int CG, CHg;           // channel groups per image, 16-byte chunks per group (all of them when the image has < 16)
     int CH, CHP, sh;       // chunks per pixel; the power of two above CHg, its log2
     int V;                 // CHg * 16 partial values per workgroup: [chunk][stat 0 / 1][8 channels]
-    unsigned long long* clk;   // GCC_OPT_DEBUG bit 5 (32): [S][8] s_memrealtime stamps of image 0, group 0 (100 MHz)
+    unsigned long long* clk;   // diagnostic build, bit 5 (32): [S][8] s_memrealtime stamps of image 0, group 0 (100 MHz)
     unsigned* err;         // the library's device error word (pinned host memory) or NULL
-    int spin_limit;        // polls before a wait gives up (1 << 20; GCC_OPT_DEBUG bit 6 (64): 256, and workgroup 1 of every domain
+    int spin_limit;        // polls before a wait gives up (1 << 20; diagnostic build, bit 6 (64): 256, and workgroup 1 of every domain
     int mute;              //   publishes nothing -- the test of the error path)
 };
 constexpr unsigned GCC_DEVERR_INORM_SPIN = 0x1401u;
 
 // The statistics hand-off of the grid kernels (inorm_grid_kernel, bn_fold_grid_kernel): this workgroup's per-lane sums v[2][8]
 // -> the (image, channel group) domain's totals tot[V] (double), identical in every workgroup of the domain.
-#define IN_STAMP(k) do { if (ga.clk && t == 0 && dom == 0) ga.clk[s * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define IN_STAMP(k) do { if (GCC_DIAG(ga.clk != nullptr) && t == 0 && dom == 0) ga.clk[s * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 __device__ __forceinline__ void grid_exchange(const InGridArgs& ga, float (&v)[2][8], double* smem_d, float* red, double* tot, int s,
                                               size_t dom, __attribute__((address_space(1))) unsigned int* cnt, unsigned epoch, int t,
                                               int lane, int wave, int ch) {
@@ -1092,7 +1092,7 @@ __device__ __forceinline__ void grid_exchange(const InGridArgs& ga, float (&v)[2
         for (int w = 0; w < 4; w++)
             if ((((w << 6) ^ chunk) & (ga.CHP - 1) & ~63) == 0) sum += red[(w * 64 + (chunk & 63)) * 16 + r];
         if (alone) tot[i] = (double)sum;
-        else if (!(ga.mute && s == 1)) {
+        else if (!(GCC_DIAG(ga.mute) && s == 1)) {
             const i32x2 pr = {(int)__float_as_uint(sum), (int)tag};
             __builtin_amdgcn_raw_buffer_store_b64(pr, rs_part, (s * ga.V + i) * 8, 0, 16);
         }
@@ -1247,7 +1247,7 @@ __global__ __launch_bounds__(256, 4) void inorm_grid_kernel(const InGridArgs ga)
     // the domain's epoch word: stable until every workgroup of the domain has written its partial (all of them read it first)
     typedef __attribute__((address_space(1))) unsigned int gu32;
     gu32* cnt = (gu32*)ga.cnt + dom * 4;            // [1]: the domain's epoch (launches that used it)
-#define IN_STAMP(k) do { if (ga.clk && t == 0 && dom == 0) ga.clk[s * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define IN_STAMP(k) do { if (GCC_DIAG(ga.clk != nullptr) && t == 0 && dom == 0) ga.clk[s * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     IN_STAMP(0);
     unsigned epoch = 0;
     if (t == 0 && ga.S > 1) epoch = __hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1583,9 +1583,27 @@ static int device_cus() {
     }();
     return cus;
 }
+// How many workgroups a launch of the grid kernels (inorm_grid_kernel, bn_fold_grid_kernel: they wait for their OWN workgroups
+// inside the launch) may have.  Progress argument: a launch of this family can only be stalled by
+// workgroups that themselves wait, i.e. by other launches of this family -- every other kernel drains.  At most Q launches run
+// at once, Q = hardware queues of the process (HIP's GPU_MAX_HW_QUEUES, default 4: a queue runs its kernels in order).  Every
+// kernel of the family is compiled for FOUR workgroups per CU (__launch_bounds__(256, 4): <= 128 VGPRs; 18 KB of LDS; <= 106
+// SGPRs admit 6) -- so the chip has 4 x CUs slots for them, and Q launches of <= 4 x CUs / Q workgroups each are ALL resident
+// whatever the placement: none can be kept waiting for a slot another waiting launch holds.  With the default Q = 4 that is one
+// workgroup per CU (the cap these kernels always had); a process that raises GPU_MAX_HW_QUEUES gets a proportionally smaller
+// grid.  A spin that expires anyway (a debugger, a hung partner) is reported through the device error word, never silent.
+static int grid_family_wgs() {
+    static const int v = [] {
+        int q = 4;
+        if (const char* e = getenv("GPU_MAX_HW_QUEUES")) { const int n = atoi(e); if (n > 0) q = n; }
+        const int cus = std::min(device_cus(), 256);      // the header holds 256 domains
+        return std::max(1, std::min(cus, 4 * cus / std::max(q, 4)));
+    }();
+    return v;
+}
 static bool inorm_grid_plan(int C, int HW, int N, int px, size_t ws_bytes, InGridArgs* ga) {
     const int CH = (C + 7) / 8;
-    const int cus = std::min(device_cus(), 256);          // the header holds 256 domains; one waiting workgroup per CU at most
+    const int cus = grid_family_wgs();
     if (CH > 256 || N > 64) return false;
     const int CHg = CH >= 16 ? 8 : CH;              // 64-channel groups (128-byte segments of a pixel) once an image has 128 channels
     const int CG = (CH + CHg - 1) / CHg;
@@ -1639,7 +1657,7 @@ bool inorm_launch(const InFusedArgs& a, int N, hipStream_t st, void* ws, size_t 
         ga.cnt = (unsigned*)ws;
         ga.partial = (float*)((char*)ws + INORM_WS_HEADER);
         ga.level2 = (float*)((char*)ws + INORM_WS_HEADER + (size_t)N * ga.CG * ga.S * ga.V * 8);
-        const int dbg = gcc_opt(GCC_OPT_DEBUG);
+        const int dbg = gcc_diag_bits();
         ga.clk = (dbg & 32) ? (unsigned long long*)((char*)ws + ws_bytes - 16384) : nullptr;
         ga.err = gcc_device_error_word();
         ga.spin_limit = (dbg & 64) ? 256 : (1 << 20);
@@ -1686,7 +1704,7 @@ int gcc_internal_bn_fold_grid(const BnFoldDesc* d, hipStream_t st) {
     ga.cnt = (unsigned*)d->ws;
     ga.partial = (float*)((char*)d->ws + INORM_WS_HEADER);
     ga.level2 = (float*)((char*)d->ws + INORM_WS_HEADER + (size_t)ga.CG * ga.S * ga.V * 8);
-    const int dbg = gcc_opt(GCC_OPT_DEBUG);
+    const int dbg = gcc_diag_bits();
     ga.clk = nullptr;
     ga.err = gcc_device_error_word();
     ga.spin_limit = (dbg & 64) ? 256 : (1 << 20);

@@ -702,13 +702,10 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         T = self.teacher_model
         # this pass runs where the step has one or two busy queues (the student's tail): its half-chip launches (L3 forward, L4
         # data gradient: 128 workgroups of 256 x 256) take the 128-column halo tiles of the 'alone' plan (GCC_TAIL_HALO_HC)
-        lib = ops.lib()
-        hc_prev = lib.gcc_set_option(_lib.OPT_HALO_HC, 1) if (TAIL_HALO_HC and 'GCC_HALO_HC' not in os.environ) else None
-        try:
+        if not TAIL_HALO_HC:
             return self._distill_teacher_d_terms_body(T, opt)
-        finally:
-            if hc_prev is not None:
-                lib.gcc_set_option(_lib.OPT_HALO_HC, hc_prev)
+        with ops.plan_override(halo_hc=1):
+            return self._distill_teacher_d_terms_body(T, opt)
 
     def _distill_teacher_d_terms_body(self, T, opt):
         ct = T._d_forward('on_student', self._fake, A=self._A)

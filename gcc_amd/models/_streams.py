@@ -21,44 +21,27 @@ import torch
 from .. import ops
 
 
-# the tile plan is process-wide state of libgcc_hip.so (gcc_set_option); every model instance keeps the plan it wants and
-# re-applies it at the head of its own phases when another instance (or a test) has changed the library's since
-_applied_plan = None
-
-
 class TeacherStreamMixin:
     def _ensure_plan(self):
-        """make the library's pair-split / weight-gradient split options the ones THIS model's schedule asked for (no-op when
-        they already are: a tuple compare per phase).  Explicit GCC_WGRAD_WGS* environment values win, as before."""
-        global _applied_plan
+        """state THIS model's tile plan (pair split, halo columns, weight-gradient split targets) for the launches the calling
+        thread is about to enqueue: ops.set_plan -- thread-local host state that travels with every convolution call
+        (gcc_conv_t.plan); the library itself holds no plan any more (round 5).  Explicit GCC_* environment values win (ops)."""
         plan = getattr(self, '_plan', None)
-        if plan is None or plan == _applied_plan:
+        if plan is None:
             return
-        from .. import _lib
-        lib = ops.lib()
         pair, wgs_big, wgs = plan[:3]
-        lib.gcc_set_option(_lib.OPT_IGEMM_PAIR, pair)
-        if 'GCC_HALO_HC' not in os.environ:      # 128-column halo tiles for half-chip launches go with the pair split (-1: default)
-            lib.gcc_set_option(_lib.OPT_HALO_HC, 1 if pair == 1 else (-1 if pair < 0 else 0))
-        if 'GCC_WGRAD_WGS_BIG' not in os.environ:
-            lib.gcc_set_option(_lib.OPT_WGRAD_WGS_BIG, wgs_big)
-        if 'GCC_WGRAD_WGS' not in os.environ:
-            lib.gcc_set_option(_lib.OPT_WGRAD_WGS, wgs)
-        _applied_plan = plan
+        ops.set_plan(pair=max(pair, 0), halo_hc=1 if pair == 1 else 0, wgrad_wgs_big=max(wgs_big, 0), wgrad_wgs=max(wgs, 0))
 
     def restore_library_plan(self):
-        """give the library its default plan back (model teardown / tests that go on to call the kernels directly)"""
-        global _applied_plan
-        self._plan = (-1, -1, -1)
-        self._ensure_plan()
+        """back to the library's default plan on this thread (model teardown / tests that go on to call the kernels directly)"""
         self._plan = None
-        _applied_plan = None
+        ops.set_plan()
 
     def set_stream_schedule(self, concurrent, plan=None):
         """concurrent=True: the production schedule (student, online teacher, auxiliary and weight-gradient streams).
         False: every launch on one stream.  plan: the library's tile plan -- 'production' (what the multi-stream schedule runs:
         no pair split, half-chip weight-gradient splits) or 'alone' (for launches that have the chip to themselves:
-        GCC_OPT_IGEMM_PAIR, full-chip weight-gradient splits); default: 'production' with concurrent streams, 'alone' without.
+        the pair split, full-chip weight-gradient splits); default: 'production' with concurrent streams, 'alone' without.
         bench.py times one single-stream step under each plan (a launch's duration is then the kernel's own)."""
         from .. import engine
         self.serialize_streams = not concurrent
@@ -204,8 +187,9 @@ class _EnqueueThread:
     def _loop(self):
         torch.cuda.set_device(self.device)
         while True:
-            fn, ts = self.q.get()
+            fn, ts, plan = self.q.get()
             try:
+                ops.set_plan(**plan)             # the submitting thread's tile plan (thread-local state of ops)
                 with ops.on_stream(ts):
                     fn()
             except BaseException as e:          # handed to the submitting thread at drain()
@@ -215,7 +199,7 @@ class _EnqueueThread:
     def submit(self, fn, ts):
         self._wait()                            # one step at a time: the steps of a model share its host state
         self.pending += 1
-        self.q.put((fn, ts))
+        self.q.put((fn, ts, ops.current_plan()))
 
     def _wait(self):
         while self.pending:

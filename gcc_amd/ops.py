@@ -6,6 +6,7 @@ HIP stream and (elsewhere) torch.distributed -- every computation below is a lib
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -434,8 +435,65 @@ def _geom(t):
     return p, N, Cc, H, W, ld
 
 
+# ---- the tile plan of the convolution calls (include/gcc_hip.h gcc_conv_plan_t) ------------------------------------------
+# It travels with every call (conv_desc) instead of living in the library as process-wide options (rounds 2-4).  A model class
+# states the plan of its schedule at the head of each phase (models/_streams.py _ensure_plan); the statement is THREAD-local, so
+# the teacher's enqueue thread and the main thread -- or two models of different schedules -- never see each other's.
+# GCC_IGEMM_TILES / GCC_IGEMM_BIG_MIN / GCC_IGEMM_BIG_NK / GCC_IGEMM_PAIR / GCC_HALO_HC / GCC_WGRAD_WGS_BIG / GCC_WGRAD_WGS in
+# the environment pin a field for A/B runs (an explicit value wins over what the schedule asks for, as before).
+_PLAN_ENV = {'tile_families': 'GCC_IGEMM_TILES', 'big_min': 'GCC_IGEMM_BIG_MIN', 'big_nk': 'GCC_IGEMM_BIG_NK', 'pair': 'GCC_IGEMM_PAIR',
+             'halo_hc': 'GCC_HALO_HC', 'wgrad_wgs_big': 'GCC_WGRAD_WGS_BIG', 'wgrad_wgs': 'GCC_WGRAD_WGS'}
+_plan_pinned = {f: int(os.environ[e]) for f, e in _PLAN_ENV.items() if os.environ.get(e, '') not in ('', '-1')}
+_plan_tls = threading.local()
+_PLAN_DEFAULT = (0,) * len(_lib.PLAN_FIELDS)
+
+
+def set_plan(**fields):
+    """state the calling thread's tile plan: named fields of gcc_conv_plan_t, everything else back to the library's default (0).
+    Returns the previous plan (a tuple for restore_plan)."""
+    prev = getattr(_plan_tls, 'plan', _PLAN_DEFAULT)
+    unknown = set(fields) - set(_lib.PLAN_FIELDS)
+    assert not unknown, unknown
+    fields.update(_plan_pinned)
+    _plan_tls.plan = tuple(int(fields.get(f, 0)) for f in _lib.PLAN_FIELDS)
+    return prev
+
+
+def restore_plan(prev):
+    _plan_tls.plan = prev
+
+
+def current_plan():
+    """{field: value} of the calling thread's plan"""
+    plan = getattr(_plan_tls, 'plan', None)
+    if plan is None:
+        set_plan()
+        plan = _plan_tls.plan
+    return dict(zip(_lib.PLAN_FIELDS, plan))
+
+
+class plan_override:
+    """with plan_override(halo_hc=1): ... -- the current plan with some fields changed, for the calls inside (environment pins win)"""
+
+    def __init__(self, **fields):
+        self.fields = fields
+
+    def __enter__(self):
+        cur = current_plan()
+        cur.update(self.fields)
+        self.prev = set_plan(**cur)
+
+    def __exit__(self, *exc):
+        restore_plan(self.prev)
+        return False
+
+
 def conv_desc(N, H, W, Ci, Co, k, stride, pad, ldx, ldy):
-    return _lib.conv_t(N, H, W, Ci, Co, k, k, stride, pad, ldx, 0, ldy, 0)
+    plan = getattr(_plan_tls, 'plan', None)
+    if plan is None:
+        set_plan()
+        plan = _plan_tls.plan
+    return _lib.conv_t(N, H, W, Ci, Co, k, k, stride, pad, ldx, 0, ldy, 0, plan)
 
 
 def pack_weights(master, want_w=True, want_wt=True):

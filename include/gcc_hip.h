@@ -5,9 +5,9 @@
  * models/Pix2Pix.py.  Each entry point below names the reference call site(s) whose ATen operator
  * it replaces (paths relative to the reference root).  Conventions:
  *   - plain C, no torch types; every pointer is a DEVICE pointer owned by the caller (activations,
- *     weights, workspaces); the library allocates nothing.  Its only process-wide state is the table of
- *     tuning options below (gcc_set_option / gcc_conv_set_plan: atomics, defaults read once from GCC_*
- *     environment variables), the one-time hipFuncSetAttribute of the kernels that use > 64 KB of LDS, and the RCCL entry
+ *     weights, workspaces); the library allocates nothing.  What a launch does is decided by its arguments
+ *     (the tile plan travels in gcc_conv_t.plan); the only process-wide state is the table of A/B tuning hooks below
+ *     (gcc_set_option: atomics, defaults read once from GCC_* environment variables; the product leaves them alone), the one-time hipFuncSetAttribute of the kernels that use > 64 KB of LDS, and the RCCL entry
  *     points resolved on the first gcc_comm_* call (communicators themselves are explicit objects the caller owns);
  *   - every kernel is enqueued on the caller's `stream` and never synchronises;
  *   - return value: 0 = GCC_OK, negative = error (see gcc_strerror); no exceptions, no abort;
@@ -52,20 +52,19 @@ long long gcc_launch_count(int reset);
 int gcc_device_error(int clear);
 
 /* ---------------------------------------------------------------------------------------------
- * Tuning options: which tile shape / kernel family a geometry is routed to.  Every option only selects
- * between kernels that compute the same result (the parity tests run each conv case under every plan).
- * Defaults come from the environment variable of the same name (GCC_<NAME>) when it is set at first use.
- * gcc_set_option(id, value): value < 0 restores the default; returns the previous value (>= 0) or
- * GCC_ERR_BAD_ARG.  Options are process-wide atomics: set them before launching, not concurrently with
- * launches whose workspace was sized under another plan (gcc_conv_workspace / gcc_conv_stat_tiles depend
- * on the plan).
+ * Tuning hooks: which kernel family a geometry is routed to.  Every option only selects between kernels that compute the same
+ * result (the parity tests run the cases under each).  These are A/B switches for measurements and tests -- NOT the way a host
+ * chooses its schedule: everything the model classes switch at run time (tile families, pair split, halo columns, weight-
+ * gradient split targets) travels with the call in gcc_conv_t.plan, and the product runs with every hook at its default
+ * (bench.py prints the vector and refuses to run otherwise).  Defaults come from the environment variable of the same name
+ * (GCC_<NAME>) when it is set at first use.  gcc_set_option(id, value): value < 0 restores the default; returns the previous
+ * value (>= 0) or GCC_ERR_BAD_ARG.  Process-wide atomics: set them while nothing is being launched.
+ * The shipped library holds no diagnostic ablation: the "results are wrong" switches of the earlier rounds (main loops without
+ * staging loads, a grid exchange made to time out) exist only in the GCC_DIAG_BUILD variant (csrc/build.sh: libgcc_hip_diag.so,
+ * same ABI plus gcc_diag_set(bits)), which tests and probes load explicitly through GCC_HIP_LIB.
  * ------------------------------------------------------------------------------------------- */
 enum {
-    GCC_OPT_IGEMM_BIG = 0,      /* 0: 128-pixel tiles only; 1: + 256x128; 2 (default): + 256x256 */
-    GCC_OPT_IGEMM_BIG_MIN,      /* minimum number of 256-pixel tiles of a launch (default 120: half a chip of one-per-CU workgroups; the rest of the
-                                   CUs run the other streams' kernels -- measured +2.7 % on the step against 200, profiles/r02_e) */
-    GCC_OPT_IGEMM_BIG_NK,       /* minimum K depth in 64-steps for 256-pixel tiles (default 24) */
-    GCC_OPT_IGEMM_GLDS,         /* 1 (default): LDS-DMA staging; 0: register-staged 128-pixel tiles */
+    GCC_OPT_IGEMM_GLDS = 0,       /* 1 (default): LDS-DMA staging; 0: register-staged 128-pixel tiles */
     GCC_OPT_IGEMM_HEAD,         /* 1 (default): single-output-channel head route */
     GCC_OPT_IGEMM_THIN,         /* 1 (default): thin image-layer kernels; 2: without the LDS-staged wide (65..128 channel) data-gradient form; 0: none */
     GCC_OPT_WGRAD_BIG,          /* 1 (default): 256x256 weight-gradient tiles on the large layers */
@@ -74,18 +73,10 @@ enum {
     GCC_OPT_BN_REDUCE_THREADS,  /* 256 (default) or 1024 threads per BatchNorm-backward reduce workgroup */
     GCC_OPT_BN_REDUCE_CAP,      /* cap on those workgroups (default 1024) */
     GCC_OPT_INORM_LPP,          /* 0 (default): automatic lanes per pixel of the one-launch InstanceNorm */
-    GCC_OPT_WGRAD_WGS_BIG,      /* workgroups a split 256x256 weight-gradient launch aims at (default 256) */
-    GCC_OPT_WGRAD_WGS,          /* ... a split 128x128 weight-gradient launch (default 512) */
     GCC_OPT_IGEMM_FORCE_BC,     /* tuning: 0 (default) automatic; 16 / 32 / 64 / 128: channel width of the 128-pixel tiles */
     GCC_OPT_IGEMM_FORCE_KSPLIT, /* tuning: 0 (default) automatic; n >= 1: K slices of a 128-pixel-tile launch (1 = never split) */
     GCC_OPT_IGEMM_NARROW,       /* 1 (default): 128-pixel tiles narrow to 64 / 32 channels until the launch has >= 256 workgroups, and
                                    K is split only for loops of >= 48 steps (0: the round-1 plan) */
-    GCC_OPT_IGEMM_PAIR,         /* 1: a 256x256-tile launch of < 192 tiles with >= 48 K steps runs two workgroups per tile (one per K
-                                   half, combined inside the launch through the caller's workspace) and fills the chip by itself: the
-                                   plan for a launch that has the chip to itself (single-stream schedules; measured 0.317 against
-                                   0.281 of the bf16 peak over the step's igemm launches).  0 (default): one workgroup per tile --
-                                   less CU time per launch, the free CUs run the other streams' kernels (the multi-stream
-                                   production schedule: +1 % on the step).  gcc_amd's models switch it with their schedule. */
     GCC_OPT_WGRAD_BIG_MIN_TILES,/* minimum number of 256x256 output tiles for the big weight-gradient tiling (default 32) */
     GCC_OPT_FUSE_BN,            /* gcc_conv_bn_act: 3 (default; profiles/r4_summary.md): a split layer's K slices folded, statistics exchanged inside the
                                    launch and rows normalised by one kernel on the whole chip (bn_fold_grid_kernel; needs gcc_bn_t.tail_ws; other
@@ -105,10 +96,6 @@ enum {
     GCC_OPT_FUSE_BN_PARTIAL_KB, /* gcc_conv_bn_act: cap (KB of fp32 partial tiles, default 4096) on the K split of the layers whose fold + statistics +
                                    normalise run as one kernel: every slice is another copy of the output that kernel reads back */
     GCC_OPT_INORM_GRID,         /* 1 (default): gcc_inorm_fwd / _bwd with a workspace split an image's plane over workgroups (in-launch barrier); 0: slab kernels */
-    GCC_OPT_HALO_HC,            /* columns per tile of igemm_halo_kernel: 0 (default): 256 where the layer tiles by 256 and such tiles are enough
-                                   to be routed (GCC_OPT_IGEMM_BIG_MIN), else 128; 1: also 128 where 256-column tiles would cover less
-                                   than 3/4 of the chip (PatchGAN L3 forward, L4 data gradient: 128 workgroups) -- the plan for a launch
-                                   that has the chip to itself, set by the models with GCC_OPT_IGEMM_PAIR; 128 / 256: forced (tests, A/B) */
     GCC_OPT_IGEMM_STAGES,       /* 3 (default): the 128-pixel x 32 / 64-column tiles (uniform taps) keep two k-steps of LDS-DMA in flight behind
                                    the one being multiplied (three LDS stages); 2: one (the round-1 loop) */
     GCC_OPT_WGRAD_TS,           /* 1 (default): k4 s1 p1 weight gradients with channels in multiples of 64, >= 32 channel tiles and >= 16 pixel
@@ -118,18 +105,12 @@ enum {
                                    slices once, every XCD streams all the weights); 1 (default): the stride-1 form gives every XCD one column tile
                                    (1 / ntiles of the weights per L2, pixel slices fetched by ntiles XCDs: the L4 forward fetches 108 MB instead of
                                    152 MB, same duration -- profiles/r4q_halo_xcd_cols.txt); 2: every form */
-    GCC_OPT_DEBUG,              /* 0 (default).  Diagnostic ablations for timing only -- RESULTS ARE WRONG when set: bit 1 (2) the main loops issue
-                                   no staging loads after the first step, bit 2 (4) they re-load the first step's addresses, bit 5 (32)
-                                   s_memrealtime stamps of the grid InstanceNorm, bit 6 (64) its exchange is made to time out (256 polls,
-                                   workgroup 1 of every domain publishes nothing): the test of gcc_device_error */
     GCC_OPT_COUNT_
 };
 int gcc_set_option(int id, int value);
 int gcc_get_option(int id);
-/* the fprop / dgrad tile plan in one call (each argument < 0: restore that default).  Tests select
- * {big=0}, {big=1, big_min=1, big_nk=1} and {big=2, big_min=1, big_nk=1} to run every geometry on the
- * 128xBC, 256x128 and 256x256 tiles. */
-int gcc_conv_set_plan(int big, int big_min, int big_nk);
+int gcc_options_default(void);      /* 1: every hook holds its built-in default */
+
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution geometry.  One descriptor serves Conv2d and ConvTranspose2d: a ConvTranspose2d
@@ -138,6 +119,28 @@ int gcc_conv_set_plan(int big, int big_min, int big_nk);
  * input-gradient = gcc_conv_fprop, its weight-gradient = gcc_conv_wgrad with x := grad of its
  * output and dy := its input).
  * ------------------------------------------------------------------------------------------- */
+/* The tile plan of a convolution call travels WITH the call (round 5: it used to be process-wide option state, which two
+ * models -- or two host threads -- with different schedules had to re-apply in turns).  Every field: 0 = the library's default.
+ * The functions that size workspaces or statistic rows (gcc_conv_workspace, gcc_conv_stat_tiles, gcc_conv_bn_act_workspace,
+ * gcc_conv_wgrad_workspace ...) read the plan of the descriptor they are given: pass them the descriptor the launch gets. */
+typedef struct {
+    int tile_families;  /* fprop / dgrad: 1: 128-pixel tiles only; 2: + 256x128; 3 (default): + 256x256 */
+    int big_min;        /* minimum number of 256-pixel tiles of a launch (default 120: half a chip of one-per-CU workgroups; the rest of
+                           the CUs run the other streams' kernels -- measured +2.7 % on the step against 200, profiles/r02_e) */
+    int big_nk;         /* minimum K depth in 64-steps for 256-pixel tiles (default 24) */
+    int pair;           /* 1: a 256x256-tile launch of < 192 tiles with >= 48 K steps runs two workgroups per tile (one per K half,
+                           combined inside the launch through the caller's workspace) and fills the chip by itself: the plan for a
+                           launch that has the chip to itself (single-stream schedules: 0.317 against 0.281 of the bf16 peak over the
+                           step's igemm launches).  0 (default): one workgroup per tile -- less CU time per launch, the free CUs run
+                           the other streams' kernels (the multi-stream production schedule: +1 % on the step) */
+    int halo_hc;        /* columns per tile of igemm_halo_kernel: 0 (default): 256 where the layer tiles by 256 and such tiles are
+                           enough to be routed (big_min), else 128; 1: also 128 where 256-column tiles would cover less than 3/4 of the
+                           chip (PatchGAN L3 forward, L4 data gradient: 128 workgroups) -- the plan for a launch that has the chip to
+                           itself, chosen together with `pair`; 128 / 256: forced (tests, A/B) */
+    int wgrad_wgs_big;  /* workgroups a split 256x256 weight-gradient launch aims at (default 256) */
+    int wgrad_wgs;      /* ... a split 128x128 weight-gradient launch (default 512) */
+} gcc_conv_plan_t;
+
 typedef struct {
     int N;            /* batch */
     int H, W;         /* conv INPUT spatial size */
@@ -145,6 +148,7 @@ typedef struct {
     int KH, KW, stride, pad;
     int ldx, xoff;    /* conv-input tensor pixel stride / channel offset (elements) */
     int ldy, yoff;    /* conv-output tensor pixel stride / channel offset */
+    gcc_conv_plan_t plan;   /* zero-filled: the library's defaults */
 } gcc_conv_t;
 
 static inline int gcc_conv_out(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }

@@ -13,7 +13,7 @@ for (N, H, W, Ci, Co) in CASES:
     dw = torch.zeros(Co, Ci, 4, 4, device=dev).contiguous(memory_format=torch.channels_last)
     fl = 2.0 * N * (H - 1) * (W - 1) * Co * Ci * 16
     for wgs in (256, 128):
-        lib.gcc_set_option(_lib.OPT_WGRAD_WGS_BIG, wgs)
+        ops.set_plan(wgrad_wgs_big=wgs)
         for ts in (0, 1):
             lib.gcc_set_option(_lib.OPT_WGRAD_TS, ts)
             for _ in range(3):

@@ -27,7 +27,8 @@ def med(fn, n=15):
     ts.sort()
     return ts[len(ts) // 2], ts[0]
 g = torch.Generator().manual_seed(0)
-CFGS = [('default', {}), ('stages2', {_lib.OPT_IGEMM_STAGES: 2}), ('noloads', {_lib.OPT_DEBUG: 2}),
+CFGS = [('default', {}), ('stages2', {_lib.OPT_IGEMM_STAGES: 2}), ('noloads', {'diag': 2}),      # diagnostic build only (GCC_HIP_LIB=gcc_amd/libgcc_hip_diag.so): skipped on the shipped library
+        
         ('bc32', {_lib.OPT_IGEMM_FORCE_BC: 32}), ('bc64', {_lib.OPT_IGEMM_FORCE_BC: 64}), ('bc128', {_lib.OPT_IGEMM_FORCE_BC: 128}),
         ('nohalo', {_lib.OPT_IGEMM_HALO: 0})]
 print('%-26s' % 'shape' + ''.join('%16s' % c[0] for c in CFGS) + '   roofline us (bytes @ 4 TB/s | flop @ 2.5 PF)')
@@ -41,13 +42,16 @@ for name, N, H, W, Ci, Co, mode in SHAPES:
     fn = (lambda: ops.conv_fprop(x, w, Co, 4, 2, 1, out=y)) if mode == 'f' else (lambda: ops.conv_dgrad(dy, wt, Ci, H, W, 4, 2, 1, out=dx))
     row = '%-26s' % name
     for cname, opts in CFGS:
-        for k, v in opts.items(): lib.gcc_set_option(k, v)
+        if 'diag' in opts and not hasattr(lib, 'gcc_diag_set'):
+            row += '%16s' % 'n/a'
+            continue
+        for k, v in opts.items(): (lib.gcc_diag_set(v) if k == 'diag' else lib.gcc_set_option(k, v))
         try:
             a, b = med(fn)
             row += '%9.1f/%6.1f' % (a, b)
         except Exception as e:
             row += '%16s' % 'err'
-        for k in opts: lib.gcc_set_option(k, -1)
+        for k in opts: (lib.gcc_diag_set(0) if k == 'diag' else lib.gcc_set_option(k, -1))
     nbytes = 2.0 * (N * H * W * Ci + N * Ho * Wo * Co + 16 * Ci * Co)
     fl = 2.0 * N * Ho * Wo * Co * 16 * Ci
     print(row + '   %5.1f | %5.1f' % (nbytes / 4e12 * 1e6, fl / 2.5e15 * 1e6), flush=True)

@@ -9,7 +9,7 @@ DEV = 'cuda:0'
 SHAPES = [('vgg 512->512 @48', 16, 48, 48, 512, 512), ('vgg 256->256 @96', 16, 96, 96, 256, 256), ('vgg 128->256 @192', 16, 192, 192, 128, 256),
           ('vgg 128->128 @192', 16, 192, 192, 128, 128), ('vgg 64->128 @192', 16, 192, 192, 64, 128), ('vgg 64->64 @384', 16, 384, 384, 64, 64),
           ('vgg 512->512 @24', 16, 24, 24, 512, 512), ('res 64->64 @96', 16, 96, 96, 64, 64), ('res 24->24 @96', 16, 96, 96, 24, 24)]
-PLANS = [('default', (-1, -1, -1)), ('t128', (0, -1, -1)), ('t256x128', (1, 1, 1)), ('t256x256', (2, 1, 1))]
+PLANS = [('default', {}), ('t128', dict(tile_families=1)), ('t256x128', dict(tile_families=2, big_min=1, big_nk=1)), ('t256x256', dict(tile_families=3, big_min=1, big_nk=1))]
 def rate(fn, reps=10):
     for _ in range(2): fn()
     torch.cuda.synchronize()
@@ -30,10 +30,11 @@ for name, N, H, W, Ci, Co in SHAPES:
     fl = 2.0 * N * H * W * Co * 9 * Ci
     row = '%-20s' % name
     for pname, plan in PLANS:
-        lib.gcc_conv_set_plan(*plan)
+        ops.set_plan(**plan)
+        d = ops.conv_desc(N, H, W, Ci, Co, 3, 1, 1, (Ci + 7) & ~7, (Co + 7) & ~7)
         tf, td = lib.gcc_conv_tile(C.byref(d), 0), lib.gcc_conv_tile(C.byref(d), 1)
         a = rate(lambda: ops.conv_fprop(x, w, Co, 3, 1, 1, out=y))
         b = rate(lambda: ops.conv_dgrad(dy, wt, Ci, H, W, 3, 1, 1, out=dx))
         row += '  %6.0f[%6d]/%6.0f[%6d]' % (a, tf, b, td)
-    lib.gcc_conv_set_plan(-1, -1, -1)
+    ops.set_plan()
     print(row + '   ideal %5.0f us @2.5PF' % (fl / 2.5e15 * 1e6), flush=True)

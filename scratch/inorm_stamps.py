@@ -4,7 +4,7 @@ import torch
 from gcc_amd import ops, _lib
 lib = _lib.load()
 dev = torch.device('cuda:0')
-lib.gcc_set_option(_lib.OPT_DEBUG, 32)
+lib.gcc_diag_set(32)      # diagnostic build only: run with GCC_HIP_LIB=gcc_amd/libgcc_hip_diag.so
 for N, C, H, W in [(1, 256, 64, 64), (1, 512, 32, 32), (1, 64, 256, 256)]:
     x = ops.new_act(N, C, H, W, dev); x.normal_()
     y = ops.new_act(N, C, H, W, dev); st = ops.INState(N, C, dev)

@@ -77,9 +77,9 @@ y2 = ops.new_act(N, 256, 64, 64, dev)
 
 run('L4 fprop (244 workgroups of 256x256)', lambda: ops.conv_fprop(x4, w4, 1024, 4, 1, 1, out=y4))
 run('L4 dgrad (128 workgroups of 256x256)', lambda: ops.conv_dgrad(dy4, wt4, 512, 32, 32, 4, 1, 1, out=dx4))
-lib.gcc_set_option(_lib.OPT_IGEMM_PAIR, 1)
+ops.set_plan(pair=1)
 run('L4 dgrad, pair split (256 workgroups, K/2)', lambda: ops.conv_dgrad(dy4, wt4, 512, 32, 32, 4, 1, 1, out=dx4))
-lib.gcc_set_option(_lib.OPT_IGEMM_PAIR, 0)
+ops.set_plan(pair=0)
 run('L3 fprop (128 workgroups of 256x256)', lambda: ops.conv_fprop(x3, w3, 512, 4, 2, 1, out=y3))
 run('L2 fprop (256 workgroups of 256x256)', lambda: ops.conv_fprop(x2, w2, 256, 4, 2, 1, out=y2))
 # zero-filled operands: the clock the chip holds when the MFMAs toggle nothing

@@ -38,7 +38,7 @@ bigs['L2 forward as 128x128 tiles, 1024 workgroups'] = (lambda: ops.conv_fprop(x
 sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
 ev = lambda: torch.cuda.Event(enable_timing=True)
 for name, (big, reps) in bigs.items():
-  ops.lib().gcc_set_option(_lib.OPT_IGEMM_BIG, 1 if '256x128' in name else (0 if '128x128' in name else 2))
+  ops.set_plan(tile_families=2 if '256x128' in name else (1 if '128x128' in name else 3))
   for nwg, small in smalls.items():
     for _ in range(2):
           torch.cuda.synchronize()

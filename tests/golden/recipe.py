@@ -37,7 +37,8 @@ def srgan_condition(sd):
     """In-place re-scaling of recipe values for the SRGAN nets (a name -> tensor mapping, e.g. a state_dict): the
     un-normalised VGG stack gets He-scaled conv weights (N(0, .02) through 16 plain convs underflows to zero features),
     the discriminator's Linear head N(0, .1) instead of the BatchNorm rule's ~1, and the PReLU slopes distinct positive
-    values in [0.1, 0.4) (the HIP path differentiates activations on their output, which needs a positive slope)."""
+    values in [0.1, 0.4) (distinct, so that a swapped slope shows; gcc_prelu itself differentiates on the sign of its input and takes
+    any slope: tests/test_srgan_gpu.py::test_prelu_and_pixel_shuffle runs 0 and -0.2)."""
     i = 0
     with torch.no_grad():
         for k, v in sd.items():

@@ -515,7 +515,7 @@ FULL_ARGV = ['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gp
 
 
 @pytest.mark.parametrize('plan,batch', [('default', 2), ('tile256', 2), ('default', 16)])
-def test_full_config_iteration_vs_oracle(plan, batch):
+def test_full_config_iteration_vs_oracle(plan, batch, monkeypatch):
     """BASELINE.json configs[1] at its real widths (student ngf 32 / masked PatchGAN ndf 128, teacher ngf 64 / ndf 128, 8 downs,
     256 x 256): one whole GCC iteration + arch step of the HIP path against the oracle on the same recipe weights.  N = 2 keeps
     the CPU oracle to seconds; 'tile256' forces every eligible conv onto the 256-pixel igemm tiles the N = 16 bench grid selects
@@ -526,8 +526,9 @@ def test_full_config_iteration_vs_oracle(plan, batch):
     from gcc_amd import _lib
     from oracle import gcc_oracle as O
     from tests.golden.recipe import recipe_state_dict, recipe_transform
-    lib = _lib.load()
-    lib.gcc_conv_set_plan(*((2, 1, 1) if plan == 'tile256' else (-1, -1, -1)))
+    from gcc_amd import ops
+    # (pinned like a GCC_IGEMM_* environment value: the model classes state their own plan at the head of every phase)
+    monkeypatch.setattr(ops, '_plan_pinned', dict(tile_families=3, big_min=1, big_nk=1) if plan == 'tile256' else {})
     try:
         model, teacher, opt = build_model(FULL_ARGV)
         assert (opt.teacher_ngf, opt.teacher_ndf, opt.num_downs) == (64, 128, 8)
@@ -562,7 +563,8 @@ def test_full_config_iteration_vs_oracle(plan, batch):
         om.clipping_mask_alpha()
         om.optimizer_netD_arch()
     finally:
-        lib.gcc_conv_set_plan(-1, -1, -1)
+        monkeypatch.setattr(ops, '_plan_pinned', {})
+        ops.set_plan()
     for what, a, b in (('fake_B', fake, ref_fake), ('Tfake_B', tfake, ref_tfake)):
         e = (a - b).abs()
         print('%s (%s plan): max %.4g mean %.4g' % (what, plan, e.max(), e.mean()))

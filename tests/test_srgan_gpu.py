@@ -25,13 +25,16 @@ def _to_nhwc(ops, x):
     return buf
 
 
+@pytest.mark.parametrize('slope', [0.3, 0.0, -0.2])
 @pytest.mark.parametrize('C,shuffle', [(16, 1), (20, 1), (8, 2), (64, 2)])
-def test_prelu_and_pixel_shuffle(C, shuffle):
+def test_prelu_and_pixel_shuffle(C, shuffle, slope):
+    """slope 0 and < 0: a learnable slope may train through zero (models/SRGAN.py:39-56 puts no bound on
+    it); gcc_prelu differentiates on the sign of its INPUT, which it reads, so forward and both gradients stay right"""
     from gcc_amd import ops
     g = torch.Generator().manual_seed(C + shuffle)
     N, H, W = 2, 5, 6
     x = _rb(torch.randn(N, C * shuffle * shuffle, H, W, generator=g))
-    a = torch.tensor([0.3])
+    a = torch.tensor([slope])
     xr, ar = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
     y_ref = F.prelu(F.pixel_shuffle(xr, shuffle) if shuffle > 1 else xr, ar)
     dy = _rb(torch.randn(y_ref.shape, generator=g))
