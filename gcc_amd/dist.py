@@ -63,30 +63,56 @@ def broadcast_module(module, src=0):
         dist.broadcast(t.data, src)
 
 
-def all_reduce_flat(flat_grads):
+_chain_groups = {}
+
+
+def chain_group(tag):
+    """A communicator of its own for a chain of the iteration that runs CONCURRENTLY with the main one (tag 'teacher': the online
+    teacher's iteration on its stream).  One communicator executes its collectives in issue order -- ProcessGroupNCCL on its
+    single stream, RCCL itself by chaining the user streams of consecutive operations -- and the host issues the teacher's whole
+    iteration first: with one communicator the student's discriminator buckets queue behind the teacher generator's, which
+    complete ~1.4 ms later, and the student's main stream stalls for exactly that at its D step's finish()
+    (profiles/r5_dp_one_rank.txt: 8.09 -> 9.44 ms on the phase timeline; gone with two communicators).  Created by
+    dist.new_group on first use: a collective, reached by every rank at the same point (the first optimize_parameters).
+    Returns the tag itself on the native route (native_comm(tag)).
+    OFF by default (GCC_DP_CHAIN_GROUPS=1 turns it on): on the one-rank rig the second communicator's stream is a SIXTH stream on
+    four hardware queues and lands on the main stream's queue, where its pending wait for the teacher's backward holds the
+    student's kernels back by 5.6 ms (17.0 -> 19.0 ms per step) -- a trade that only a box with real peers can settle."""
+    if not is_dist() or os.environ.get('GCC_DP_CHAIN_GROUPS', '0') != '1':
+        return None
+    if comm_route() == 'native':
+        native_comm(tag)
+        return tag
+    g = _chain_groups.get(tag)
+    if g is None:
+        g = _chain_groups[tag] = dist.new_group(ranks=list(range(world_size())))
+    return g
+
+
+def all_reduce_flat(flat_grads, group=None):
     """sum the flat gradient buffer of one parameter group over ranks (scaled by 1/world inside the
     Adam kernel via grad_scale), on the current stream's order"""
     if not is_dist():
         return
     if comm_route() == 'native' and flat_grads.is_cuda and flat_grads.dtype == torch.float32:
-        native_comm().all_reduce_sum_(flat_grads)            # enqueued on the current stream, recordable
+        native_comm(group or 'default').all_reduce_sum_(flat_grads)            # enqueued on the current stream, recordable
     else:
-        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
 
 
-def all_reduce_grads(optimizer, async_op=False):
+def all_reduce_grads(optimizer, async_op=False, group=None):
     """sum this optimizer's flat gradient bucket over ranks.  async_op: returns a handle with .wait() (torch route: the
     collective runs on RCCL's stream behind everything enqueued so far; native route: it is already ordered on the current
-    stream, the handle's wait is a no-op); call .wait() before the optimizer step."""
+    stream, the handle's wait is a no-op); call .wait() before the optimizer step.  group: chain_group()'s answer."""
     if not is_dist():
         return None
     optimizer.set_grad_scale(1.0 / world_size())
     if async_op:
         if comm_route() == 'native' and optimizer.flat.grads.is_cuda:
-            native_comm().all_reduce_sum_(optimizer.flat.grads)
+            native_comm(group or 'default').all_reduce_sum_(optimizer.flat.grads)
             return _Done()
-        return dist.all_reduce(optimizer.flat.grads, op=dist.ReduceOp.SUM, async_op=True)
-    all_reduce_flat(optimizer.flat.grads)
+        return dist.all_reduce(optimizer.flat.grads, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    all_reduce_flat(optimizer.flat.grads, group)
     return None
 
 
@@ -173,12 +199,14 @@ def _all_ranks(ok):
 
 def _drop_native():
     global _native
-    if _native is not None:
-        try:
-            _native.close()
-        except Exception:
-            pass
-        _native = None
+    for c in [_native] + list(_native_tagged.values()):
+        if c is not None:
+            try:
+                c.close()
+            except Exception:
+                pass
+    _native = None
+    _native_tagged.clear()
 
 
 def _warn(msg):
@@ -195,20 +223,29 @@ def bf16_buckets():
 
 
 _native = None
+_native_tagged = {}
 
 
-def native_comm():
-    """one gcc_comm communicator per process over the ranks of the process group (or of one rank without a group): the
-    RCCL id is made by rank 0 and handed round through the group"""
+def native_comm(tag='default'):
+    """a gcc_comm communicator over the ranks of the process group (or of one rank without a group): the RCCL id is made by
+    rank 0 and handed round through the group.  One per tag: 'default', and one per concurrently running chain (chain_group)."""
     global _native
+    if tag != 'default':
+        c = _native_tagged.get(tag)
+        if c is None:
+            c = _native_tagged[tag] = _new_native_comm()
+        return c
     if _native is None:
-        if is_dist() and world_size() > 1:
-            box = [NativeComm.unique_id() if rank() == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            _native = NativeComm(rank(), world_size(), box[0])
-        else:
-            _native = NativeComm(0, 1, NativeComm.unique_id())
+        _native = _new_native_comm()
     return _native
+
+
+def _new_native_comm():
+    if is_dist() and world_size() > 1:
+        box = [NativeComm.unique_id() if rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return NativeComm(rank(), world_size(), box[0])
+    return NativeComm(0, 1, NativeComm.unique_id())
 
 
 _selfcheck = {}
@@ -301,11 +338,17 @@ class GradReducer:
         self.enabled = True
         self.route = comm_route()
         self.native = native_comm() if self.route == 'native' else None
+        self.group = None          # set_group(): chain_group()'s answer for the chain this optimizer's backward pass runs in
         self.bf16 = bf16_buckets()
         self.stage = torch.empty(max(e - b for b, e, _ in self.buckets), dtype=torch.bfloat16, device=self.flat.grads.device) \
             if self.bf16 else None
         self._events = []          # ops.Event pool of the native route (library events: part of a launch recording)
         self._pending_cast = []    # torch route + bf16: (handle, b, e) whose cast back waits for the collective
+
+    def set_group(self, group):
+        self.group = group
+        if self.route == 'native':
+            self.native = native_comm(group or 'default')
 
     def _event(self, i):
         from . import ops
@@ -321,7 +364,7 @@ class GradReducer:
         from . import ops
         g = self.flat.grads[b:e]
         if not g.is_cuda:                      # host tensors (the gloo tests of the bucket logic): nothing to order
-            self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+            self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             return
         st = stream if stream is not None else ops.current_stream()
         if self.route == 'native':
@@ -345,11 +388,11 @@ class GradReducer:
                 self._drain_casts()
                 buf = self.stage[:e - b]
                 _lib_check('gcc_cast_f32_bf16', g.data_ptr(), buf.data_ptr(), e - b, st.cuda_stream)
-                h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+                h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self._pending_cast.append((h, b, e, st))
                 self.handles.append(h)
             else:
-                self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+                self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _drain_casts(self):
         from . import ops
@@ -469,14 +512,14 @@ class NativeComm:
             pass
 
 
-def all_reduce_sum(t):
+def all_reduce_sum(t, group=None):
     """sum over ranks of a small fp32 device vector, in place (the teacher's arch-difference terms: every replica must
     feed the same value into its EMA; the caller folds 1/world into its next kernel)"""
     if is_dist():
         if comm_route() == 'native' and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
-            native_comm().all_reduce_sum_(t)          # on the current stream, part of a launch recording
+            native_comm(group or 'default').all_reduce_sum_(t)          # on the current stream, part of a launch recording
         else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 

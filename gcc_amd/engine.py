@@ -21,6 +21,17 @@ from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH
 LRELU = 0.2
 # run weight-gradient kernels on a side stream, concurrently with the data-gradient / BN chain
 OVERLAP_WGRAD = os.environ.get('GCC_OVERLAP_WGRAD', '1') != '0'
+
+
+def overlap_wgrad_default(world):
+    """Weight gradients on the side stream?  Yes on one GPU (+1.2 %); no under data parallelism unless GCC_OVERLAP_WGRAD=1 asks:
+    the communication library's stream is one more busy stream on four hardware queues, and with the gradient buckets issued
+    from the chains' own streams a data-parallel rank steps in 16.45 ms instead of 17.04-17.30 (one-rank RCCL rig,
+    profiles/r5_dp_one_rank.txt; 15.1-15.4 without a process group)"""
+    env = os.environ.get('GCC_OVERLAP_WGRAD')
+    if env is not None:
+        return env != '0'
+    return world <= 1
 # U-Net layers as one C call (gcc_conv_bn_act): conv + BatchNorm statistics + finalize + normalise / activation
 FUSE_CONV_BN = os.environ.get('GCC_FUSE_CONV_BN', '1') != '0'
 

@@ -279,6 +279,10 @@ TAIL_HALO_HC = os.environ.get('GCC_TAIL_HALO_HC', '1') != '0'
 # GCC_ARCH_FREE_EARLY (default 1): in the architecture step the teacher's stream hands its difference scalar over itself and is
 # released behind its own part: +0.6 % (profiles/r4ay_ab_arch_free_early.txt), same bits
 ARCH_FREE_EARLY = os.environ.get('GCC_ARCH_FREE_EARLY', '1') != '0'
+# GCC_DP_TEACHER_UPDATE_EARLY (default 1; data parallelism only): the online teacher's generator update -- wait for its gradient
+# buckets, Adam, repack -- is enqueued on the teacher's own stream right behind its backward pass instead of in front of the
+# architecture step's teacher forward
+DP_TEACHER_UPDATE_EARLY = os.environ.get('GCC_DP_TEACHER_UPDATE_EARLY', '1') != '0'
 
 
 def _step(gen, stream):
@@ -451,8 +455,11 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         self._fake_nchw = None
         self._ema_started = False
         self._world = gdist.world_size()
+        if self._world > 1:
+            engine.OVERLAP_WGRAD = engine.overlap_wgrad_default(self._world)
         self._defer_G_update = False
         self._pending_G = None
+        self._comm_group = None        # gdist.chain_group('teacher') once this model runs as an online teacher on its own stream
 
     # ---------------------------------------------------------------------------------------
     def _l(self, name):
@@ -586,7 +593,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         if getattr(optimizer, 'reducer', None) is not None:
             optimizer.reducer.finish()
         else:
-            gdist.all_reduce_grads(optimizer)
+            gdist.all_reduce_grads(optimizer, group=self._comm_group)
 
     # -- D step (models/Pix2Pix.py:464-477) --------------------------------------------------------
     def backward_D(self):
@@ -746,6 +753,14 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             T._is_online_teacher = True
             T._shared_aux = self._aux_stream() if TEACHER_EARLY_DREAL == 2 else None
             ts = self._teacher_stream()
+            T._own_stream = bool(ts)
+            if ts and self._world > 1 and T._comm_group is None and not getattr(T, '_comm_group_set', False):
+                # the teacher's chain runs beside this one: its gradient buckets travel on a communicator of their own
+                T._comm_group_set = True
+                T._comm_group = gdist.chain_group('teacher')
+                for o in (T.optimizer_G, T.optimizer_D):
+                    if getattr(o, 'reducer', None) is not None:
+                        o.reducer.set_group(T._comm_group)
             if ts:
                 self._release_teacher_stream(ts)                 # after the last launch that reads the teacher's buffers
             tgen = T._iteration_steps(self.input)
@@ -763,7 +778,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             # online teacher under data parallelism: its generator is not read again before the arch
             # step, so its (largest, 218 MB) gradient bucket is reduced while the student's whole
             # iteration runs; finish_G_update() applies it.  Same arithmetic, later in stream order.
-            self._pending_G = self.optimizer_G.reducer or gdist.all_reduce_grads(self.optimizer_G, async_op=True)
+            self._pending_G = self.optimizer_G.reducer or gdist.all_reduce_grads(self.optimizer_G, async_op=True, group=self._comm_group)
             return
         self._allreduce(self.optimizer_G)
         self._apply_G_update()
@@ -798,7 +813,13 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
         yield
         self._backward_G_tail(None)
         if self._defer_G_update and self._world > 1:
-            self._pending_G = self.optimizer_G.reducer or gdist.all_reduce_grads(self.optimizer_G, async_op=True)
+            self._pending_G = self.optimizer_G.reducer or gdist.all_reduce_grads(self.optimizer_G, async_op=True, group=self._comm_group)
+            if DP_TEACHER_UPDATE_EARLY and getattr(self, '_own_stream', False):
+                # On a stream of its own (the online teacher's) nothing else is queued behind this iteration until the
+                # architecture step: the wait for the buckets, Adam and the repack go here, where the stream idles, and not in
+                # front of the arch step's forward, where the student's arch backward waits for them (round 5: +0.5 ms on the
+                # critical chain of a data-parallel rank, profiles/r5_dp_one_rank.txt).  The main stream never waits for this.
+                self.finish_G_update()
             return
         self._allreduce(self.optimizer_G)
         self._apply_G_update()
@@ -843,7 +864,7 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             # means are summed over ranks (in place: the teacher logs neither) and the 1/world goes into the scalar op
             i = self._slot['D_arch_fake']
             assert self._slot['D_arch_fake_real'] == i + 1
-            gdist.all_reduce_sum(self._lossvec[i:i + 2])
+            gdist.all_reduce_sum(self._lossvec[i:i + 2], group=self._comm_group)
             w = 1.0 / gdist.world_size()
         if isTeacher and self._ema_started:
             b = float(self.opt.ema_beta)

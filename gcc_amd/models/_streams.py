@@ -47,7 +47,7 @@ class TeacherStreamMixin:
         self.serialize_streams = not concurrent
         if getattr(self, 'teacher_model', None) is not None:
             self.teacher_model.serialize_streams = not concurrent
-        engine.OVERLAP_WGRAD = bool(concurrent) and os.environ.get('GCC_OVERLAP_WGRAD', '1') != '0'
+        engine.OVERLAP_WGRAD = bool(concurrent) and engine.overlap_wgrad_default(getattr(self, '_world', 1))
         if plan is None:
             plan = 'production' if concurrent else 'alone'
         assert plan in ('production', 'alone')

@@ -11,7 +11,16 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from gcc_amd.models import Pix2Pix as P  # noqa: E402
 
+DP = os.environ.get('GCC_TL_DP', '')          # 'torch' / 'native': one rank of an RCCL process group, the model on its world > 1 code paths
+if DP:
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29578', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', GCC_DP_FORCE_BUCKETS='1', GCC_DP_COMM=DP)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
 model, opt = bench.build(16)
+if DP:
+    model._world = model.teacher_model._world = 2
 dev = model.device
 torch.cuda.set_device(dev)
 train, val = bench.synthetic(16, 0, dev)
@@ -65,6 +74,11 @@ wrap_gen(T, '_backward_D_steps', 'T.D step')
 wrap_gen(model, '_backward_G_head_steps', 'S.head')
 wrap_gen(T, '_backward_G_head_steps', 'T.head')
 wrap_fn(model, 'get_D_arch_diff', 'S.arch D forwards + diff')
+if DP:
+    wrap_fn(model, 'finish_G_update', 'S.finish_G_update')
+    wrap_fn(T, 'finish_G_update', 'T.finish_G_update (deferred Adam G + repack)')
+    wrap_fn(model, '_allreduce', 'S._allreduce (finish buckets)')
+    wrap_fn(T, '_allreduce', 'T._allreduce (finish buckets)')
 orig_free = model._mark_teacher_free
 
 
@@ -75,8 +89,8 @@ model._mark_teacher_free = free_
 orig_rel = model._release_teacher_stream
 
 
-def rel_(ts):
-    orig_rel(ts)
+def rel_(ts, *a, **k):
+    orig_rel(ts, *a, **k)
     with torch.cuda.stream(ts):
         mark('T stream released (after its waits)')
 model._release_teacher_stream = rel_
