@@ -121,6 +121,17 @@ class _Done:
         pass
 
 
+class Deferred:
+    """all_reduce_grads(optimizer) that has not been issued yet: wait() issues it on the current stream (and, like every handle
+    here, leaves that stream ordered behind it)"""
+
+    def __init__(self, optimizer, group=None):
+        self.optimizer, self.group = optimizer, group
+
+    def wait(self):
+        all_reduce_grads(self.optimizer, group=self.group)
+
+
 _route = None
 
 

@@ -283,6 +283,7 @@ ARCH_FREE_EARLY = os.environ.get('GCC_ARCH_FREE_EARLY', '1') != '0'
 # buckets, Adam, repack -- is enqueued on the teacher's own stream right behind its backward pass instead of in front of the
 # architecture step's teacher forward
 DP_TEACHER_UPDATE_EARLY = os.environ.get('GCC_DP_TEACHER_UPDATE_EARLY', '1') != '0'
+DP_TEACHER_BUCKETS_LATE = os.environ.get('GCC_DP_TEACHER_BUCKETS_LATE', '1') != '0'
 
 
 def _step(gen, stream):
@@ -769,6 +770,11 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
                 tgen = None
         sgen = self._pre_join_steps()
         _alternate(tgen, ts, sgen)
+        if ts and getattr(self.teacher_model, '_held_G', False):
+            # the student's discriminator buckets are issued: now the teacher generator's, and its update, on the teacher's stream
+            self.teacher_model._held_G = False
+            with ops.on_stream(ts):
+                self.teacher_model.finish_G_update()
         if self.opt.online_distillation:
             # the reference clones; here the teacher's activation buffers of this iteration are
             # simply not overwritten before the student consumes them (separate contexts)
@@ -811,7 +817,25 @@ class Pix2PixModel(TeacherStreamMixin, nn.Module):
             self._head_done = ops.Event()
         self._head_done.record()
         yield
-        self._backward_G_tail(None)
+        # GCC_DP_TEACHER_BUCKETS_LATE (default 1; data parallelism, teacher on its own stream): the teacher generator's gradient
+        # buckets are NOT issued during its backward pass.  A communicator runs its collectives in issue order and the host
+        # issues this whole iteration before the student's: buckets issued here would sit in front of the student's discriminator
+        # buckets and make the student's main stream wait for the END of this backward pass at its D step's finish() (1.6 ms,
+        # profiles/r5_dp_one_rank.txt).  The student issues them -- and the update behind them -- on this stream once its own
+        # discriminator buckets are out (optimize_parameters); nothing reads this generator's weights before the arch step.
+        red = self.optimizer_G.reducer
+        hold = bool(DP_TEACHER_BUCKETS_LATE and self._defer_G_update and self._world > 1 and getattr(self, '_own_stream', False))
+        if hold and red is not None:
+            red.enabled = False
+        try:
+            self._backward_G_tail(None)
+        finally:
+            if red is not None:
+                red.enabled = True
+        if hold:
+            self._pending_G = red or gdist.Deferred(self.optimizer_G, self._comm_group)
+            self._held_G = True
+            return
         if self._defer_G_update and self._world > 1:
             self._pending_G = self.optimizer_G.reducer or gdist.all_reduce_grads(self.optimizer_G, async_op=True, group=self._comm_group)
             if DP_TEACHER_UPDATE_EARLY and getattr(self, '_own_stream', False):
