@@ -666,9 +666,16 @@ __global__ void head_rows_fold_kernel(const float* __restrict__ big, float* __re
     }
 }
 
+// conv_thinout.hip: wide kernels with <= 3 output channels (SRGAN's last 9 x 9 layer)
+size_t gcc_internal_thinout_wgrad_workspace(const gcc_conv_t* c);
+int gcc_internal_thinout_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                               hipStream_t st);
+
 extern "C" size_t gcc_conv_wgrad_workspace(const gcc_conv_t* c) {
     const size_t h = c ? head_wgrad_workspace(c) : 0;
-    return h ? h : gcc_internal_wgrad_workspace(c, 1);
+    if (h) return h;
+    const size_t t = c ? gcc_internal_thinout_wgrad_workspace(c) : 0, g = gcc_internal_wgrad_workspace(c, 1);
+    return t > g ? t : g;
 }
 
 // batched form: problem b reads x + b*x_bstride, dy + b*dy_bstride (elements; c->N images each) and
@@ -814,6 +821,10 @@ extern "C" int gcc_conv_wgrad(const gcc_conv_t* c, const void* x, const void* dy
                            accumulate);
         GCC_CHECK_LAUNCH();
         return GCC_OK;
+    }
+    if (c && x && dy && dw && ws && (((uintptr_t)dw) & 3) == 0) {
+        const int rc = gcc_internal_thinout_wgrad(c, x, dy, dw, accumulate, ws, ws_bytes, (hipStream_t)stream);
+        if (rc != GCC_ERR_UNSUPPORTED) return rc;
     }
     return gcc_internal_wgrad(c, x, dy, dw, accumulate, ws, ws_bytes, 1, 0, 0, (hipStream_t)stream, 0, 0, 0, 0);
 }

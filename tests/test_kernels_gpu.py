@@ -1304,6 +1304,42 @@ def test_grid_kernels_on_four_streams_make_progress():
                 assert torch.equal(y, ry) and torch.equal(dx, rdx)
 
 
+@pytest.mark.parametrize('case', [
+    # N, H, W, Ci, Co, k          wide kernels with <= 3 output channels: conv_thinout.hip
+    (2, 40, 80, 64, 3, 9),        # SRGAN teacher's last layer shape (64 -> 3, 9 x 9), a strip and a quarter wide, two row bands
+    (1, 33, 70, 24, 3, 9),        # student (24 channels: padded to 32 in LDS only), ragged width and height
+    (2, 24, 64, 32, 3, 5),        # 5 x 5
+    (1, 20, 48, 16, 4, 7),        # k * Co = 28 columns
+    (3, 9, 16, 8, 1, 3),          # smallest
+    (1, 96, 200, 64, 3, 9),       # many rows: several bands, the ring wraps many times
+])
+def test_thin_output_wide_kernel_wgrad(case):
+    """gcc_conv_wgrad's thin-output route (round 5; the horizontal taps in the MFMA's free dimension, the rows of x through an LDS
+    ring, dY expanded along x in LDS) against torch's conv2d_weight on the same bf16-rounded inputs, fresh and accumulating; the
+    launch count shows the route was taken (kernel + fold)"""
+    ops = _ops()
+    N, H, W, Ci, Co, k = case
+    pad = (k - 1) // 2
+    g = torch.Generator().manual_seed(sum(case))
+    x = rb(torch.randn(N, Ci, H, W, generator=g))
+    dy = rb(torch.randn(N, Co, H, W, generator=g))
+    dw_ref = torch.nn.grad.conv2d_weight(x, (Co, Ci, k, k), dy, stride=1, padding=pad)
+    xd, dyd = to_dev(x), to_dev(dy)
+    dw = torch.full((Co, Ci, k, k), 5.0, device=DEV).contiguous(memory_format=torch.channels_last)        # stale contents must go
+    ops.lib().gcc_launch_count(1)
+    ops.conv_wgrad(xd, dyd, dw, k, 1, pad, accumulate=False)
+    assert int(ops.lib().gcc_launch_count(1)) == 2, 'the thin-output route is a kernel + its fold'
+    close(dw.cpu(), dw_ref, tol=5e-3, floor=1e-3 * float(dw_ref.abs().max()), what='thin-output wgrad')
+    ops.conv_wgrad(xd, dyd, dw, k, 1, pad, accumulate=True)
+    close(dw.cpu(), 2 * dw_ref, tol=5e-3, floor=2e-3 * float(dw_ref.abs().max()), what='thin-output wgrad, accumulated')
+    # same bits run after run (fixed fold order)
+    dw2 = torch.zeros_like(dw)
+    ops.conv_wgrad(xd, dyd, dw2, k, 1, pad, accumulate=False)
+    dw3 = torch.zeros_like(dw)
+    ops.conv_wgrad(xd, dyd, dw3, k, 1, pad, accumulate=False)
+    assert torch.equal(dw2, dw3)
+
+
 def test_instance_norm_workspace_scrub_keeps_results():
     """the launcher re-zeroes a grid InstanceNorm workspace at its first use inside every launch recording (and every 2^20
     launches), so that the 24-bit epoch field of the exchange tag never wraps: a recorded + replayed sequence of launches gives
