@@ -1451,6 +1451,7 @@ extern "C" int gcc_conv_y2_supported(const gcc_conv_t* c, int dgrad, const gcc_e
     return 0;
 }
 
+int gcc_internal_thinout_fprop(const gcc_conv_t* c, const void* x, const void* w, void* y, const gcc_epilogue_t* ep, hipStream_t st);
 int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const void* w, void* dst, const gcc_epilogue_t* ep,
                        int batch, long src_bstride, long wgt_bstride, long dst_bstride, hipStream_t st) {
     GCC_ENTER();
@@ -1499,6 +1500,10 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
     if (batch == 1 && dgrad && thin_dgrad_shape(c) && !(ep && ep->stats_partial)) {
         const int rc2 = launch_thin_dgrad(c, src, w, dst, ep, st);
         if (rc2 >= 0) return rc2;
+    }
+    if (batch == 1 && !dgrad) {      // wide kernel, <= 3 output channels (SRGAN's last layer): conv_thinout.hip
+        const int rc3 = gcc_internal_thinout_fprop(c, src, w, dst, ep, st);
+        if (rc3 != GCC_ERR_UNSUPPORTED) return rc3;
     }
     if (ep && ep->y2) {          // a second output: the thin forward route only (gcc_conv_y2_supported says so beforehand)
         if (!gcc_conv_y2_supported(c, dgrad, ep)) return GCC_ERR_UNSUPPORTED;

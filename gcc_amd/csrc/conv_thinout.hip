@@ -205,6 +205,143 @@ __global__ __launch_bounds__(256) void thinout_wgrad_kernel(const ThinOutWgradAr
     }
 }
 
+// ---- forward --------------------------------------------------------------------------------------------------------------
+//   U_y[x_in][(tx, co)] = sum_{ty, ci} X[y + ty - P][x_in][ci] * W[co][ty][tx][ci]        one [32 x K C] x [K C x 64 pixels] product per row
+//   Y[y][x][co]         = act(bias[co] + sum_tx U_y[x + tx - P][(tx, co)])                   a shift-and-add over the k horizontal taps
+// Same walk as the weight gradient (64 input columns per strip = 64 - 2 P output columns, the rows of X through the LDS ring);
+// the weight operands -- 2 x K x C / 32 fragments -- stay in registers for the whole launch, the pixel operand is a plain
+// ds_read_b128 of the staged row (K = channels is contiguous), U goes through an 8 KB LDS image for the shift.
+struct ThinOutFpropArgs {
+    const bf16_t* x; const bf16_t* w; bf16_t* y; const float* bias;
+    int N, H, W, ldx, xoff, ldy, yoff, Ci, Co;
+    int Cip8;               // channels per tap of the packed weights (Ci rounded up to 8)
+    int strips, bands, band_h, units, act;
+    float slope;
+    uint32_t x_bytes, w_bytes;
+};
+
+template <int RS, int KK>
+__global__ __launch_bounds__(256) void thinout_fprop_kernel(const ThinOutFpropArgs a) {
+    constexpr int K = KK, P = (KK - 1) / 2, SWO = TO_SW - 2 * P;
+    constexpr int XROW = TO_SW * RS, PIECES = XROW / 1024, PPW = PIECES / 4;
+    constexpr int CC = RS / 64;                               // 32-channel k-steps per vertical tap (2 or 1)
+    constexpr int U_BASE = TO_RING * XROW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sX = smem;                                          // [TO_RING][64 px][RS]
+    float* sU = (float*)(smem + U_BASE);                      // [64 px][32 m] fp32 (+ 4 floats of row padding: 144-byte rows)
+    constexpr int UROW = 36;
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const i32x4 rs_x = make_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+    const int KC = K * a.Co;
+
+    // weight operands: fragment (mb, ty, cc): lane (i, g) holds row m = 16 mb + i = (tx, co), k = (ty, channels 32 cc + 8 g .. + 7)
+    bf16x8 wf[2][K][CC];
+#pragma unroll
+    for (int mb = 0; mb < 2; mb++) {
+        const int m = mb * 16 + i;
+        const int tx = m / a.Co, co = m - tx * a.Co;
+#pragma unroll
+        for (int ty = 0; ty < K; ty++)
+#pragma unroll
+            for (int cc = 0; cc < CC; cc++) {
+                const int ci = cc * 32 + g * 8;
+                const bool ok = m < KC && ci < a.Cip8;
+                const uint32_t off = ok ? (uint32_t)((((co * K + ty) * K + tx) * a.Cip8 + ci) * 2) : OOB;
+                wf[mb][ty][cc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));
+            }
+    }
+    // the shift-and-add: thread -> (pixel px = tid >> 2, taps tx = j, j + 4, j + 8 with j = tid & 3); partial sums meet by shuffles
+    const int spx = tid >> 2, sj = tid & 3;
+    float bv[3] = {0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) bv[c] = c < a.Co ? a.bias[c] : 0.f;
+    }
+
+    for (int unit = blockIdx.x; unit < a.units; unit += gridDim.x) {
+        int b = unit;
+        const int band = b % a.bands; b /= a.bands;
+        const int strip = b % a.strips;
+        const int n = b / a.strips;
+        const int xo = strip * SWO, xs = xo - P;              // first output column, first input column (may be negative: zeros)
+        const int y0 = band * a.band_h, y1 = min(a.H, y0 + a.band_h);
+        auto stage_x = [&](int yy) {
+            const bool row_ok = yy >= 0 && yy < a.H;
+            const int slot = ((yy % TO_RING) + TO_RING) % TO_RING;
+#pragma unroll
+            for (int q = 0; q < PPW; q++) {
+                const int piece = wave * PPW + q;
+                constexpr int CPR = RS / 16;
+                const int r = piece * (1024 / RS) + lane / CPR;
+                const int pc = lane % CPR;
+                const int pw = pc >> 1, sub = pc & 1;
+                const int lw = RS == 128 ? (pw ^ ((r >> 1) & 3)) : (pw ^ ((r >> 2) & 1));
+                const int ch = lw * 2 + sub;
+                const int col = xs + r;
+                const bool ok = row_ok && col >= 0 && col < a.W && ch * 8 < a.Ci;
+                const uint32_t off = ok ? (uint32_t)((((size_t)(n * a.H + yy) * a.W + col) * a.ldx + a.xoff + ch * 8) * 2) : OOB;
+                lds_dma16(rs_x, lds0 + slot * XROW + piece * 1024, off);
+            }
+        };
+        __syncthreads();
+        for (int yy = y0 - P; yy < y0 + P + TO_D; yy++) stage_x(yy);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int y = y0; y < y1; y++) {
+            if (y > y0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((TO_D - 1) * PPW) : "memory");
+            __syncthreads();                                  // row y + P landed everywhere; the previous row's shift-and-add has read sU
+            stage_x(y + P + TO_D);
+            int s0 = (y - P) % TO_RING;
+            s0 = s0 < 0 ? s0 + TO_RING : s0;
+            f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ty = 0; ty < K; ty++) {
+                const int slot = s0 + ty >= TO_RING ? s0 + ty - TO_RING : s0 + ty;
+                const char* row = sX + slot * XROW;
+#pragma unroll
+                for (int cc = 0; cc < CC; cc++) {
+                    // pixel operand: lane (i, g) -> pixel 16 wave + i, channels 32 cc + 8 g .. + 7 = 16-byte chunk 4 cc + g
+                    const bf16x8 xb = *(const bf16x8*)(row + img_off<RS>(wave * 16 + i, cc * 4 + g));
+                    u0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ty][cc], xb, u0, 0, 0, 0);
+                    u1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ty][cc], xb, u1, 0, 0, 0);
+                }
+            }
+            // lane (i, g) holds U[pixel 16 wave + i][m = 4 g + r] (u0) and [16 + 4 g + r] (u1)
+            *(f32x4*)(sU + (wave * 16 + i) * UROW + 4 * g) = u0;
+            *(f32x4*)(sU + (wave * 16 + i) * UROW + 16 + 4 * g) = u1;
+            __syncthreads();
+            float o[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int tx = sj + 4 * q;
+                const int src = spx + tx;                     // U pixel of output pixel P + spx' ... (output local x = spx: input local spx + tx)
+                if (tx < K && src < TO_SW) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+                        if (c < a.Co) o[c] += sU[src * UROW + tx * a.Co + c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                o[c] += __shfl_xor(o[c], 1, 64);
+                o[c] += __shfl_xor(o[c], 2, 64);
+            }
+            // output local x = spx (0 .. SWO - 1) sits at input local x = spx + P: y[x] = sum_tx U[x + tx]  (x + tx - P + P)
+            if (sj == 0 && spx < SWO && xo + spx < a.W) {
+                float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    if (c < a.Co) f[c] = apply_act(o[c] + bv[c], a.act, a.slope);
+                *(i32x4*)(a.y + ((size_t)(n * a.H + y) * a.W + xo + spx) * a.ldy + a.yoff) = pack8(f);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
 // dw[co][ty * K + tx][ci] (+)= sum over workgroups of part[wg][ty][tx * Co + co][ci]   (fixed order: reproducible)
 __global__ __launch_bounds__(256) void thinout_wgrad_fold_kernel(const float* part, float* dw, int wgs, int K, int Co, int Ci, int Cip,
                                                                  int accumulate) {
@@ -309,6 +446,54 @@ int gcc_internal_thinout_wgrad(const gcc_conv_t* c, const void* x, const void* d
     const int total = c->KH * c->KW * c->Co * c->Ci;
     hipLaunchKernelGGL(thinout_wgrad_fold_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)ws, dw, p.wgs, c->KH, c->Co, c->Ci,
                        p.Cip, accumulate);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+// forward route of gcc_conv_fprop (conv_igemm.hip): GCC_ERR_UNSUPPORTED = not this route's geometry / epilogue
+int gcc_internal_thinout_fprop(const gcc_conv_t* c, const void* x, const void* w, void* y, const gcc_epilogue_t* ep, hipStream_t st) {
+    ThinOutPlan p = thinout_plan(c);
+    if (!p.ok || c->Co > 3) return GCC_ERR_UNSUPPORTED;
+    if (ep && (ep->stats_partial || ep->y2 || ep->bn)) return GCC_ERR_UNSUPPORTED;
+    const int K = c->KH, SWO = TO_SW - 2 * c->pad;
+    // strips tile the OUTPUT columns here (64 input columns give 64 - 2 P outputs); same band search as the weight gradient
+    p.strips = cdiv(c->W, SWO);
+    const int cus = thinout_cus(), cols = c->N * p.strips;
+    const int max_bands = c->H / (2 * K) > 0 ? c->H / (2 * K) : 1;
+    long best = -1;
+    for (int b = 1; b <= max_bands && b <= 64; b++) {
+        const int bh = cdiv(c->H, b), nb = cdiv(c->H, bh);
+        const long cost = (long)cdiv(cols * nb, cus) * (bh + 2 * c->pad + TO_D);
+        if (best < 0 || cost < best) { best = cost; p.band_h = bh; p.bands = nb; }
+    }
+    p.units = cols * p.bands;
+    p.wgs = p.units < cus ? p.units : cus;
+    ThinOutFpropArgs a;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.y = (bf16_t*)y; a.bias = ep ? ep->bias : nullptr;
+    a.N = c->N; a.H = c->H; a.W = c->W; a.ldx = c->ldx; a.xoff = c->xoff; a.ldy = c->ldy; a.yoff = c->yoff; a.Ci = c->Ci; a.Co = c->Co;
+    a.Cip8 = ceil8(c->Ci);
+    a.strips = p.strips; a.bands = p.bands; a.band_h = p.band_h; a.units = p.units;
+    a.act = ep ? ep->act : GCC_ACT_NONE; a.slope = ep ? ep->slope : 0.f;
+    a.x_bytes = (uint32_t)((size_t)c->N * c->H * c->W * c->ldx * 2);
+    a.w_bytes = (uint32_t)((size_t)c->Co * K * K * a.Cip8 * 2);
+    const size_t lds = (size_t)TO_RING * TO_SW * p.Cip * 2 + (size_t)TO_SW * 36 * 4;
+#define GCC_TO_LAUNCH(RS_, K_)                                                                                                   \
+    do {                                                                                                                          \
+        static bool attr_done = false;                                                                                            \
+        if (!attr_done) {                                                                                                         \
+            (void)hipFuncSetAttribute((const void*)thinout_fprop_kernel<RS_, K_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_done = true;                                                                                                     \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((thinout_fprop_kernel<RS_, K_>), dim3(p.wgs), dim3(256), lds, st, a);                                  \
+    } while (0)
+    const bool wide = p.Cip == 64;
+    switch (K) {
+        case 9: if (wide) GCC_TO_LAUNCH(128, 9); else GCC_TO_LAUNCH(64, 9); break;
+        case 7: if (wide) GCC_TO_LAUNCH(128, 7); else GCC_TO_LAUNCH(64, 7); break;
+        case 5: if (wide) GCC_TO_LAUNCH(128, 5); else GCC_TO_LAUNCH(64, 5); break;
+        default: if (wide) GCC_TO_LAUNCH(128, 3); else GCC_TO_LAUNCH(64, 3); break;
+    }
+#undef GCC_TO_LAUNCH
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

@@ -1340,6 +1340,34 @@ def test_thin_output_wide_kernel_wgrad(case):
     assert torch.equal(dw2, dw3)
 
 
+@pytest.mark.parametrize('act', ['tanh', 'none'])
+@pytest.mark.parametrize('case', [
+    (2, 40, 80, 64, 3, 9), (1, 33, 70, 24, 3, 9), (2, 24, 64, 32, 3, 5), (1, 20, 130, 16, 2, 7), (3, 9, 16, 8, 1, 3), (1, 96, 200, 64, 3, 9)])
+def test_thin_output_wide_kernel_fprop(case, act):
+    """gcc_conv_fprop's thin-output route (conv_thinout.hip: U = W x row per 64 input columns, then the shift-and-add over the
+    horizontal taps, bias + activation, 8-channel padded store) against torch conv2d on the same bf16-rounded inputs; one launch;
+    the padding channels of the output stay zero"""
+    ops = _ops()
+    N, H, W, Ci, Co, k = case
+    pad = (k - 1) // 2
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = rb(torch.randn(N, Ci, H, W, generator=g))
+    w = rb(torch.randn(Co, Ci, k, k, generator=g) * (1.0 / (k * Ci ** 0.5)))
+    b = torch.randn(Co, generator=g) * 0.1
+    ref = F.conv2d(x, w, b, stride=1, padding=pad)
+    ref = torch.tanh(ref) if act == 'tanh' else ref
+    wp, _ = ops.pack_weights(master_cl(w))
+    y = ops.new_act(N, Co, H, W, DEV)
+    y.fill_(3.0)                                               # stale contents must go
+    ops.lib().gcc_launch_count(1)
+    ops.conv_fprop(to_dev(x), wp, Co, k, 1, pad, out=y, bias=b.to(DEV), act=ops.ACT_TANH if act == 'tanh' else ops.ACT_NONE)
+    assert int(ops.lib().gcc_launch_count(1)) == 1
+    close(to_cpu(y), ref, what='thin-output fprop')
+    full = y.permute(0, 2, 3, 1)
+    phys = torch.as_strided(full, (N, H, W, 8), (H * W * 8, W * 8, 8, 1))
+    assert float(phys[..., Co:].abs().max()) == 0.0, 'padding channels must be zero'
+
+
 def test_instance_norm_workspace_scrub_keeps_results():
     """the launcher re-zeroes a grid InstanceNorm workspace at its first use inside every launch recording (and every 2^20
     launches), so that the 24-bit epoch field of the exchange tag never wraps: a recorded + replayed sequence of launches gives
