@@ -1452,6 +1452,7 @@ extern "C" int gcc_conv_y2_supported(const gcc_conv_t* c, int dgrad, const gcc_e
 }
 
 int gcc_internal_thinout_fprop(const gcc_conv_t* c, const void* x, const void* w, void* y, const gcc_epilogue_t* ep, hipStream_t st);
+int gcc_internal_thinout_dgrad(const gcc_conv_t* c, const void* dy, const void* wt, void* dx, const gcc_epilogue_t* ep, hipStream_t st);
 int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const void* w, void* dst, const gcc_epilogue_t* ep,
                        int batch, long src_bstride, long wgt_bstride, long dst_bstride, hipStream_t st) {
     GCC_ENTER();
@@ -1501,8 +1502,8 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
         const int rc2 = launch_thin_dgrad(c, src, w, dst, ep, st);
         if (rc2 >= 0) return rc2;
     }
-    if (batch == 1 && !dgrad) {      // wide kernel, <= 3 output channels (SRGAN's last layer): conv_thinout.hip
-        const int rc3 = gcc_internal_thinout_fprop(c, src, w, dst, ep, st);
+    if (batch == 1) {      // wide kernel, <= 3 output channels (SRGAN's last layer): conv_thinout.hip
+        const int rc3 = dgrad ? gcc_internal_thinout_dgrad(c, src, w, dst, ep, st) : gcc_internal_thinout_fprop(c, src, w, dst, ep, st);
         if (rc3 != GCC_ERR_UNSUPPORTED) return rc3;
     }
     if (ep && ep->y2) {          // a second output: the thin forward route only (gcc_conv_y2_supported says so beforehand)

@@ -342,6 +342,141 @@ __global__ __launch_bounds__(256) void thinout_fprop_kernel(const ThinOutFpropAr
     }
 }
 
+// ---- data gradient ------------------------------------------------------------------------------------------------------------
+//   dX[y][x][ci] = sum_ty sum_{(tx, co)} E_{y - ty + P}[x][(tx, co)] * W[co][ty][tx][ci]     E: the expanded rows of dY (see the weight gradient)
+// One 32-deep k-step per vertical tap: [16 channels x 32] x [32 x 16 pixels]; the expanded rows of the last k rows of dY sit in an
+// LDS ring (4 KB each), the weight operands (k fragments per wave = 16 channels) in registers; a wave owns 16 channels of the 64
+// pixels of a strip.  dX is written once (the 302 MB of the teacher's layer), dY read ~1.1 times.
+struct ThinOutDgradArgs {
+    const bf16_t* dy; const bf16_t* wt; bf16_t* dx;
+    int N, H, W, ldx, xoff, ldy, yoff, Ci, Co;
+    int Cop8;               // output channels per tap of the packed dgrad weights (Co rounded up to 8)
+    int strips, bands, band_h, units, nblk;
+    uint32_t dy_bytes, wt_bytes;
+};
+
+template <int KK>
+__global__ __launch_bounds__(256) void thinout_dgrad_kernel(const ThinOutDgradArgs a) {
+    constexpr int K = KK, P = (KK - 1) / 2;
+    constexpr int ERING = K + 1, EIMG = TO_SW * 64;
+    constexpr int D_BASE = ERING * EIMG;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sE = smem;                                          // [ERING][64 px][64 B]
+    const bf16_t* sD = (const bf16_t*)(smem + D_BASE);        // [TO_DRING][128 px][8] raw rows of dY
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const i32x4 rs_dy = make_rsrc(a.dy, a.dy_bytes);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+    const int KC = K * a.Co;
+    const bool wave_on = wave < a.nblk;                       // 16-channel blocks: 4 (<= 64 channels) or fewer
+
+    // weight operands: A[ci = 16 wave + i][k = (tx, co) = 8 g .. 8 g + 7] for every vertical tap, from the dgrad packing
+    // Wt[ci][ty * K + tx][Cop8]: eight 2-byte gathers per fragment, once per launch
+    bf16x8 wf[K];
+    {
+        const int ci = wave * 16 + i;
+#pragma unroll
+        for (int ty = 0; ty < K; ty++) {
+            s16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int m = g * 8 + e;
+                const int tx = m / a.Co, co = m - tx * a.Co;
+                const bool ok = m < KC && ci < a.Ci;
+                v[e] = ok ? (short)a.wt[((size_t)ci * K * K + ty * K + tx) * a.Cop8 + co] : (short)0;
+            }
+            wf[ty] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+    int eoff[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int m = (tid & 3) * 8 + e;
+        const int tx = m / a.Co, co = m - tx * a.Co;
+        eoff[e] = m < KC ? (2 * P - tx) * 8 + co : -1;
+    }
+
+    for (int unit = blockIdx.x; unit < a.units; unit += gridDim.x) {
+        int b = unit;
+        const int band = b % a.bands; b /= a.bands;
+        const int strip = b % a.strips;
+        const int n = b / a.strips;
+        const int xs = strip * TO_SW;
+        const int y0 = band * a.band_h, y1 = min(a.H, y0 + a.band_h);
+        auto stage_dy = [&](int yy) {                         // wave 0: the raw row (zeros outside the image) into slot yy mod TO_DRING
+            if (wave != 0) return;
+            const int slot = ((yy % TO_DRING) + TO_DRING) % TO_DRING;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int j = q * 64 + lane, col = xs - P + j;
+                const bool ok = j < TO_SW + 2 * P && yy >= 0 && yy < a.H && col >= 0 && col < a.W;
+                const uint32_t off = ok ? (uint32_t)((((size_t)(n * a.H + yy) * a.W + col) * a.ldy + a.yoff) * 2) : OOB;
+                lds_dma16(rs_dy, lds0 + D_BASE + slot * 2048 + q * 1024, off);
+            }
+        };
+        auto expand = [&](int yy) {                           // raw row yy -> its expanded image in slot yy mod ERING
+            const int px = tid >> 2, c = tid & 3;
+            const bf16_t* d = sD + (size_t)(((yy % TO_DRING) + TO_DRING) % TO_DRING) * 1024 + px * 8;
+            uint32_t pk[4];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const bf16_t v0 = eoff[e] >= 0 ? d[eoff[e]] : (bf16_t)0, v1 = eoff[e + 1] >= 0 ? d[eoff[e + 1]] : (bf16_t)0;
+                pk[e >> 1] = (uint32_t)v0 | ((uint32_t)v1 << 16);
+            }
+            const int slot = ((yy % ERING) + ERING) % ERING;
+            *(i32x4*)(sE + slot * EIMG + img_off<64>(px, c)) = i32x4{(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
+        };
+        // ---- prologue: raw rows y0 - P .. y0 + P + D - 1; the images of rows y0 - P .. y0 + P - 1 ------------------------------
+        __syncthreads();
+        for (int yy = y0 - P; yy < y0 + P + TO_D; yy++) {
+            // the raw ring holds D + 1 rows: stage, wait, expand in turn for the first 2 P rows, then leave D rows in flight
+            stage_dy(yy);
+            if (yy < y0 + P) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                expand(yy);
+                __syncthreads();
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int y = y0; y < y1; y++) {
+            if (y > y0 && wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((TO_D - 1) * 2) : "memory");
+            __syncthreads();                                  // raw row y + P landed; the previous row's products are done with the image slot it replaces
+            stage_dy(y + P + TO_D);
+            expand(y + P);
+            __syncthreads();
+            if (wave_on) {
+                int s0 = (y + P) % ERING;                     // ty = 0 reads the image of row y + P, ty = k - 1 that of row y - P
+                f32x4 acc[4];
+#pragma unroll
+                for (int nb = 0; nb < 4; nb++) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ty = 0; ty < K; ty++) {
+                    const int slot = s0 - ty < 0 ? s0 - ty + ERING : s0 - ty;
+                    const char* E = sE + slot * EIMG;
+#pragma unroll
+                    for (int nb = 0; nb < 4; nb++) {
+                        const bf16x8 eb = *(const bf16x8*)(E + img_off<64>(nb * 16 + i, g));
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ty], eb, acc[nb], 0, 0, 0);
+                    }
+                }
+                // lane (i, g): pixel 16 nb + i, channels 16 wave + 4 g + r
+                const int c0 = wave * 16 + 4 * g;
+#pragma unroll
+                for (int nb = 0; nb < 4; nb++) {
+                    const int col = xs + nb * 16 + i;
+                    if (col < a.W && c0 < a.Ci) {
+                        const uint32_t lo = pack2bf(acc[nb][0], acc[nb][1]), hi = pack2bf(acc[nb][2], acc[nb][3]);
+                        *(i32x2*)(a.dx + ((size_t)(n * a.H + y) * a.W + col) * a.ldx + a.xoff + c0) = i32x2{(int)lo, (int)hi};
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
 // dw[co][ty * K + tx][ci] (+)= sum over workgroups of part[wg][ty][tx * Co + co][ci]   (fixed order: reproducible)
 __global__ __launch_bounds__(256) void thinout_wgrad_fold_kernel(const float* part, float* dw, int wgs, int K, int Co, int Ci, int Cip,
                                                                  int accumulate) {
@@ -494,6 +629,41 @@ int gcc_internal_thinout_fprop(const gcc_conv_t* c, const void* x, const void* w
         default: if (wide) GCC_TO_LAUNCH(128, 3); else GCC_TO_LAUNCH(64, 3); break;
     }
 #undef GCC_TO_LAUNCH
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+// data-gradient route of gcc_conv_dgrad (conv_igemm.hip): plain dX = conv_backward_data(dY) only (no bias / activation / statistics)
+int gcc_internal_thinout_dgrad(const gcc_conv_t* c, const void* dy, const void* wt, void* dx, const gcc_epilogue_t* ep, hipStream_t st) {
+    ThinOutPlan p = thinout_plan(c);
+    if (!p.ok || (c->Ci & 3)) return GCC_ERR_UNSUPPORTED;
+    if (ep && (ep->stats_partial || ep->y2 || ep->bn || ep->bias || ep->act != GCC_ACT_NONE)) return GCC_ERR_UNSUPPORTED;
+    const int K = c->KH, cus = thinout_cus();
+    // small LDS footprint (k + 1 expanded rows): two workgroups per CU
+    const int cols = c->N * p.strips, slots = 2 * cus;
+    const int max_bands = c->H / (2 * K) > 0 ? c->H / (2 * K) : 1;
+    long best = -1;
+    for (int b = 1; b <= max_bands && b <= 64; b++) {
+        const int bh = cdiv(c->H, b), nb = cdiv(c->H, bh);
+        const long cost = (long)cdiv(cols * nb, slots) * (bh + 2 * c->pad + TO_D);
+        if (best < 0 || cost < best) { best = cost; p.band_h = bh; p.bands = nb; }
+    }
+    p.units = cols * p.bands;
+    p.wgs = p.units < slots ? p.units : slots;
+    ThinOutDgradArgs a;
+    a.dy = (const bf16_t*)dy; a.wt = (const bf16_t*)wt; a.dx = (bf16_t*)dx;
+    a.N = c->N; a.H = c->H; a.W = c->W; a.ldx = c->ldx; a.xoff = c->xoff; a.ldy = c->ldy; a.yoff = c->yoff; a.Ci = c->Ci; a.Co = c->Co;
+    a.Cop8 = ceil8(c->Co);
+    a.strips = p.strips; a.bands = p.bands; a.band_h = p.band_h; a.units = p.units; a.nblk = cdiv(c->Ci, 16);
+    a.dy_bytes = (uint32_t)((size_t)c->N * c->H * c->W * c->ldy * 2);
+    a.wt_bytes = (uint32_t)((size_t)c->Ci * K * K * a.Cop8 * 2);
+    const size_t lds = (size_t)(K + 1) * TO_SW * 64 + TO_DRING * 2048;
+    switch (K) {
+        case 9: hipLaunchKernelGGL(thinout_dgrad_kernel<9>, dim3(p.wgs), dim3(256), lds, st, a); break;
+        case 7: hipLaunchKernelGGL(thinout_dgrad_kernel<7>, dim3(p.wgs), dim3(256), lds, st, a); break;
+        case 5: hipLaunchKernelGGL(thinout_dgrad_kernel<5>, dim3(p.wgs), dim3(256), lds, st, a); break;
+        default: hipLaunchKernelGGL(thinout_dgrad_kernel<3>, dim3(p.wgs), dim3(256), lds, st, a); break;
+    }
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

@@ -1368,6 +1368,27 @@ def test_thin_output_wide_kernel_fprop(case, act):
     assert float(phys[..., Co:].abs().max()) == 0.0, 'padding channels must be zero'
 
 
+@pytest.mark.parametrize('case', [
+    (2, 40, 80, 64, 3, 9), (1, 33, 70, 24, 3, 9), (2, 24, 64, 32, 3, 5), (1, 20, 130, 16, 2, 7), (3, 9, 16, 8, 1, 3), (1, 96, 200, 64, 3, 9)])
+def test_thin_output_wide_kernel_dgrad(case):
+    """gcc_conv_dgrad's thin-output route (conv_thinout.hip: one 32-deep k-step per vertical tap over the expanded rows of dY)
+    against torch's conv2d_input on the same bf16-rounded inputs; one launch"""
+    ops = _ops()
+    N, H, W, Ci, Co, k = case
+    pad = (k - 1) // 2
+    g = torch.Generator().manual_seed(sum(case) + 2)
+    dy = rb(torch.randn(N, Co, H, W, generator=g))
+    w = rb(torch.randn(Co, Ci, k, k, generator=g) * (1.0 / (k * Co ** 0.5)))
+    ref = torch.nn.grad.conv2d_input((N, Ci, H, W), w, dy, stride=1, padding=pad)
+    _, wtp = ops.pack_weights(master_cl(w))
+    dx = ops.new_act(N, Ci, H, W, DEV)
+    dx.fill_(3.0)
+    ops.lib().gcc_launch_count(1)
+    ops.conv_dgrad(to_dev(dy), wtp, Ci, H, W, k, 1, pad, out=dx)
+    assert int(ops.lib().gcc_launch_count(1)) == 1
+    close(to_cpu(dx), ref, what='thin-output dgrad')
+
+
 def test_instance_norm_workspace_scrub_keeps_results():
     """the launcher re-zeroes a grid InstanceNorm workspace at its first use inside every launch recording (and every 2^20
     launches), so that the 24-bit epoch field of the exchange tag never wraps: a recorded + replayed sequence of launches gives
