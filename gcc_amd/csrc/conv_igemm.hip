@@ -1676,8 +1676,10 @@ extern "C" int gcc_probe_read(unsigned long long* dst, int clear) {
 
 // which kernel family a fprop / dgrad call with this geometry and epilogue runs on (same predicates as the dispatch in
 // gcc_internal_igemm): 0 igemm_kernel, 1 thin_fprop / thin_dgrad, 2 the single-output-channel head route
+bool gcc_internal_thinout_routed(const gcc_conv_t* c, int dgrad, const gcc_epilogue_t* ep);
 extern "C" int gcc_conv_route(const gcc_conv_t* c, int dgrad, const gcc_epilogue_t* ep) {
     if (check_conv(c)) return -1;
+    if (gcc_internal_thinout_routed(c, dgrad, ep) && !(!dgrad && head_shape(c))) return 3;
     if (dgrad && thin_dgrad_shape(c) && !(ep && ep->stats_partial)) return 1;
     if (!dgrad && thin_shape(c) &&
         !(ep && (ep->stats_partial || ep->act == GCC_ACT_TANH || (ep->act == GCC_ACT_LRELU && (ep->slope < 0.f || ep->slope > 1.f)))))

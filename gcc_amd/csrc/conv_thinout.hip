@@ -585,6 +585,15 @@ int gcc_internal_thinout_wgrad(const gcc_conv_t* c, const void* x, const void* d
     return GCC_OK;
 }
 
+// does a fprop / dgrad call with this geometry and epilogue take the thin-output route?  (gcc_conv_route: 3)
+bool gcc_internal_thinout_routed(const gcc_conv_t* c, int dgrad, const gcc_epilogue_t* ep) {
+    const ThinOutPlan p = thinout_plan(c);
+    if (!p.ok) return false;
+    if (ep && (ep->stats_partial || ep->y2 || ep->bn)) return false;
+    if (dgrad) return (c->Ci & 3) == 0 && !(ep && (ep->bias || ep->act != GCC_ACT_NONE));
+    return c->Co <= 3;
+}
+
 // forward route of gcc_conv_fprop (conv_igemm.hip): GCC_ERR_UNSUPPORTED = not this route's geometry / epilogue
 int gcc_internal_thinout_fprop(const gcc_conv_t* c, const void* x, const void* w, void* y, const gcc_epilogue_t* ep, hipStream_t st) {
     ThinOutPlan p = thinout_plan(c);

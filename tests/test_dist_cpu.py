@@ -91,6 +91,39 @@ def _worker(rank, world, port, q):
     t2 = torch.tensor([1.0 + rank, 2.0], dtype=torch.float32)
     gdist.all_reduce_sum(t2)
     ok_buckets = ok_buckets and t2.tolist() == [3.0, 4.0]
+    # round 5: held buckets -- a reducer that is disabled during the backward pass issues nothing (the online teacher's generator:
+    # its buckets go out later, behind the student's discriminator buckets) and finish() reduces everything; the Deferred handle of
+    # the un-bucketed form; a communicator of its own for a concurrent chain (off unless GCC_DP_CHAIN_GROUPS=1)
+    flatp.grads.copy_(torch.randn(flatp.grads.shape, generator=gen))
+    want = flatp.grads.clone()
+    dist.all_reduce(want)
+    red.begin()
+    red.enabled = False
+    for i in range(len(segs)):
+        red.segment_done(i)
+    held = sum(red.launched) == 0
+    red.enabled = True
+    red.finish()
+    ok_buckets = ok_buckets and held and torch.equal(flatp.grads, want) and all(red.launched)
+    flatp.grads.copy_(torch.randn(flatp.grads.shape, generator=gen))
+    want = flatp.grads.clone()
+    dist.all_reduce(want)
+    h = gdist.Deferred(opt_)
+    still = not torch.equal(flatp.grads, want)
+    h.wait()
+    ok_buckets = ok_buckets and still and torch.equal(flatp.grads, want)
+    assert gdist.chain_group('teacher') is None
+    os.environ['GCC_DP_CHAIN_GROUPS'] = '1'
+    grp = gdist.chain_group('teacher')
+    ok_buckets = ok_buckets and grp is not None and gdist.chain_group('teacher') is grp
+    red.set_group(grp)
+    flatp.grads.copy_(torch.randn(flatp.grads.shape, generator=gen))
+    want = flatp.grads.clone()
+    dist.all_reduce(want)
+    red.begin()
+    red.finish()
+    ok_buckets = ok_buckets and torch.equal(flatp.grads, want)
+    ok_buckets = ok_buckets and gdist.rccl_ranks() == world
     q.put((rank, ok_grad, ok_bcast, ok_mean and ok_buckets, (b, e)))
     dist.barrier()
     dist.destroy_process_group()
