@@ -9,7 +9,7 @@ OUT=../libgcc_hip.so
 OUT_DIAG=../libgcc_hip_diag.so
 # -Wno-inline-asm: lds_dma16 (common.hpp) names m0 in its clobber list on purpose (the statement writes it); hipcc warns about any reserved register there
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -Wno-unused-value -Wno-inline-asm"
-SRCS="conv_igemm conv_halo conv_wgrad conv_thinout norm_act misc dwconv spectral attention srgan metric comm replay"
+SRCS="conv_igemm conv_halo conv_wgrad conv_thinout conv_ring3 norm_act misc dwconv spectral attention srgan metric comm replay"
 DIAG_SRCS="conv_igemm conv_wgrad norm_act misc"
 mkdir -p build
 # GCC_BUILD_FORCE=1 (set by __graft_entry__.build()): recompile every source, whatever the timestamps of shipped objects say

@@ -1453,6 +1453,10 @@ extern "C" int gcc_conv_y2_supported(const gcc_conv_t* c, int dgrad, const gcc_e
 
 int gcc_internal_thinout_fprop(const gcc_conv_t* c, const void* x, const void* w, void* y, const gcc_epilogue_t* ep, hipStream_t st);
 int gcc_internal_thinout_dgrad(const gcc_conv_t* c, const void* dy, const void* wt, void* dx, const gcc_epilogue_t* ep, hipStream_t st);
+// conv_ring3.hip: 3 x 3 stride-1 layers between <= 64-channel tensors at a large spatial size (SRGAN's trunk, VGG19 conv1_2)
+int gcc_internal_ring3(const gcc_conv_t* c, int dgrad, const void* src, const void* w, void* dst, const gcc_epilogue_t* ep, hipStream_t st);
+int gcc_internal_ring3_rows(const gcc_conv_t* c, int dgrad);
+bool gcc_internal_ring3_routed(const gcc_conv_t* c, int dgrad, const gcc_epilogue_t* ep);
 int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const void* w, void* dst, const gcc_epilogue_t* ep,
                        int batch, long src_bstride, long wgt_bstride, long dst_bstride, hipStream_t st) {
     GCC_ENTER();
@@ -1505,6 +1509,8 @@ int gcc_internal_igemm(const gcc_conv_t* c, int dgrad, const void* src, const vo
     if (batch == 1) {      // wide kernel, <= 3 output channels (SRGAN's last layer): conv_thinout.hip
         const int rc3 = dgrad ? gcc_internal_thinout_dgrad(c, src, w, dst, ep, st) : gcc_internal_thinout_fprop(c, src, w, dst, ep, st);
         if (rc3 != GCC_ERR_UNSUPPORTED) return rc3;
+        const int rc4 = gcc_internal_ring3(c, dgrad, src, w, dst, ep, st);      // its own statistics rows + finalize (gcc_conv_stat_tiles agrees)
+        if (rc4 != GCC_ERR_UNSUPPORTED) return rc4;
     }
     if (ep && ep->y2) {          // a second output: the thin forward route only (gcc_conv_y2_supported says so beforehand)
         if (!gcc_conv_y2_supported(c, dgrad, ep)) return GCC_ERR_UNSUPPORTED;
@@ -1680,6 +1686,8 @@ bool gcc_internal_thinout_routed(const gcc_conv_t* c, int dgrad, const gcc_epilo
 extern "C" int gcc_conv_route(const gcc_conv_t* c, int dgrad, const gcc_epilogue_t* ep) {
     if (check_conv(c)) return -1;
     if (gcc_internal_thinout_routed(c, dgrad, ep) && !(!dgrad && head_shape(c))) return 3;
+    if (gcc_internal_ring3_routed(c, dgrad, ep) && !(!dgrad && head_shape(c)) && !(dgrad && thin_dgrad_shape(c) && !(ep && ep->stats_partial)))
+        return 4;
     if (dgrad && thin_dgrad_shape(c) && !(ep && ep->stats_partial)) return 1;
     if (!dgrad && thin_shape(c) &&
         !(ep && (ep->stats_partial || ep->act == GCC_ACT_TANH || (ep->act == GCC_ACT_LRELU && (ep->slope < 0.f || ep->slope > 1.f)))))
@@ -1982,6 +1990,7 @@ extern "C" int gcc_conv_tile(const gcc_conv_t* c, int dgrad) {
 extern "C" int gcc_conv_stat_tiles(const gcc_conv_t* c, int dgrad) {
     GCC_ENTER();
     if (check_conv(c)) return 0;
+    if (const int r3 = gcc_internal_ring3_rows(c, dgrad)) return r3;      // one row per workgroup of the ring-walk route (conv_ring3.hip)
     const int phases = dgrad ? c->stride * c->stride : 1;
     const TilePlan tp = select_tile(c->plan, conv_max_rows(c, dgrad), dgrad ? c->Ci : c->Co, phases, conv_nk(c, dgrad), 1);
     const HaloPlan h = halo_plan(c, dgrad);

@@ -169,7 +169,8 @@ class _Span:
 PROFILE = _Profile()
 # gcc_conv_route() -> label of the bracketed launch
 _ROUTE_KIND = {0: 'igemm_kernel (conv fprop/dgrad)', 1: 'thin_fprop / thin_dgrad (image layers)', 2: 'head route (igemm 128x16 + tap sum)',
-               3: 'thinout_fprop / thinout_dgrad (wide filters, <= 3 output channels)', -1: 'igemm_kernel (conv fprop/dgrad)'}
+               3: 'thinout_fprop / thinout_dgrad (wide filters, <= 3 output channels)',
+               4: 'ring3_kernel (3 x 3 stride 1, <= 64 channels both sides)', -1: 'igemm_kernel (conv fprop/dgrad)'}
 
 
 def lib():

@@ -201,7 +201,8 @@ int gcc_conv_stat_tiles(const gcc_conv_t* c, int dgrad);
 
 /* kernel family a fprop / dgrad call runs on: 0 igemm_kernel, 1 the thin image-layer kernels (<= 8 channels on the
  * image side), 2 the single-output-channel head route, 3 the thin-output kernels for wide filters with <= 3 output channels
- * (conv_thinout.hip, round 5); < 0 for an invalid geometry.  Introspection for profilers. */
+ * (conv_thinout.hip, round 5), 4 the ring-walk kernel for 3 x 3 stride-1 layers between <= 64-channel tensors (conv_ring3.hip,
+ * round 5); < 0 for an invalid geometry.  Introspection for profilers. */
 int gcc_conv_route(const gcc_conv_t* c, int dgrad, const gcc_epilogue_t* ep);
 /* 1 when a call with this geometry / epilogue can write ep->y2 (see gcc_epilogue_t) */
 int gcc_conv_y2_supported(const gcc_conv_t* c, int dgrad, const gcc_epilogue_t* ep);

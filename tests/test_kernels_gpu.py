@@ -1389,6 +1389,153 @@ def test_thin_output_wide_kernel_dgrad(case):
     close(to_cpu(dx), ref, what='thin-output dgrad')
 
 
+RING3_CASES = [
+    # N, H, W, Ci, Co               3 x 3 stride-1 layers between <= 64-channel tensors: conv_ring3.hip
+    (2, 96, 96, 64, 64),            # SRGAN teacher's trunk layer at two images: three strips of 32 columns, several row bands
+    (1, 90, 120, 64, 64),           # two 64-column strips, the second ragged
+    (2, 70, 96, 24, 24),            # student widths: 32-channel LDS rows, one 32-channel destination half
+    (1, 128, 80, 40, 64),           # 40 -> 64
+    (1, 96, 128, 64, 24),           # 64 -> 24
+    (1, 96, 128, 16, 48),           # 16 -> 48
+    (3, 64, 48, 32, 32),            # one strip of 64 columns three quarters used
+    (1, 256, 33, 8, 8),             # narrowest: 8 channels, 33 columns
+    (1, 96, 96, 24, 20),            # destination width not a multiple of 8: the padding lanes of the output stay zero
+]
+
+
+def _ring3_route(case, dgrad):
+    import ctypes as C
+    ops = _ops()
+    N, H, W, Ci, Co = case
+    d = ops.conv_desc(N, H, W, Ci, Co, 3, 1, 1, (Ci + 7) & ~7, (Co + 7) & ~7)
+    return int(ops.lib().gcc_conv_route(C.byref(d), dgrad, None))
+
+
+@pytest.mark.parametrize('act', ['none', 'relu', 'lrelu'])
+@pytest.mark.parametrize('case', RING3_CASES)
+def test_ring_walk_3x3_fprop(case, act):
+    """gcc_conv_fprop's ring-walk route (conv_ring3.hip: rows of x once through an LDS ring, the nine taps of a wave's output
+    channels in registers, a horizontal tap = a shifted operand address) with bias + activation against fp32 torch on the same
+    bf16 operands and against igemm_kernel (GCC_OPT_IGEMM_THIN 0); one launch; stale output and padding lanes overwritten"""
+    from gcc_amd import _lib
+    ops = _ops()
+    N, H, W, Ci, Co = case
+    assert _ring3_route(case, 0) == 4
+    g = torch.Generator().manual_seed(sum(case) + 11)
+    x = rb(torch.randn(N, Ci, H, W, generator=g))
+    w = rb(torch.randn(Co, Ci, 3, 3, generator=g) * (1.0 / (3 * Ci ** 0.5)))
+    b = torch.randn(Co, generator=g) * 0.1
+    ref = F.conv2d(x, w, b, stride=1, padding=1)
+    ref = {'none': ref, 'relu': F.relu(ref), 'lrelu': F.leaky_relu(ref, 0.2)}[act]
+    a = {'none': ops.ACT_NONE, 'relu': ops.ACT_RELU, 'lrelu': ops.ACT_LRELU}[act]
+    wp, _ = ops.pack_weights(master_cl(w))
+    xd = to_dev(x)
+    y = ops.new_act(N, Co, H, W, DEV)
+    y.fill_(3.0)
+    ops.lib().gcc_launch_count(1)
+    ops.conv_fprop(xd, wp, Co, 3, 1, 1, out=y, bias=b.to(DEV), act=a, slope=0.2)
+    assert int(ops.lib().gcc_launch_count(1)) == 1
+    close(to_cpu(y), ref, what='ring-walk fprop')
+    ld = (Co + 7) & ~7
+    if ld > Co:
+        phys = torch.as_strided(y, (N, H, W, ld), (H * W * ld, W * ld, ld, 1))
+        assert float(phys[..., Co:].float().abs().max()) == 0.0, 'padding channels must be zero'
+    lib = ops.lib()
+    prev = lib.gcc_get_option(_lib.OPT_IGEMM_THIN)
+    try:
+        lib.gcc_set_option(_lib.OPT_IGEMM_THIN, 0)
+        y0 = ops.conv_fprop(xd, wp, Co, 3, 1, 1, bias=b.to(DEV), act=a, slope=0.2)
+    finally:
+        lib.gcc_set_option(_lib.OPT_IGEMM_THIN, prev)
+    close(to_cpu(y), to_cpu(y0), what='ring-walk fprop vs igemm_kernel')
+    y2 = ops.conv_fprop(xd, wp, Co, 3, 1, 1, bias=b.to(DEV), act=a, slope=0.2)
+    assert torch.equal(y, y2), 'same bits run after run'
+
+
+@pytest.mark.parametrize('case', RING3_CASES)
+def test_ring_walk_3x3_statistics_and_batchnorm(case, monkeypatch):
+    """the route's BatchNorm partial sums (one row per workgroup, of the ROUNDED outputs) and the finalize inside the call: rows sum to
+    the statistics of the output tensor; mean / rstd / running statistics against torch's batch statistics of the conv output"""
+    import torch.nn as nn
+    ops = _ops()
+    N, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(sum(case) + 12)
+    x = rb(torch.randn(N, Ci, H, W, generator=g) + 0.3)
+    w = rb(torch.randn(Co, Ci, 3, 3, generator=g) * (1.0 / (3 * Ci ** 0.5)))
+    wp, _ = ops.pack_weights(master_cl(w))
+    xd = to_dev(x)
+    raw, st = ops.conv_fprop(xd, wp, Co, 3, 1, 1, want_stats=True)
+    yd = to_cpu(raw).double()
+    want = torch.stack([yd.sum((0, 2, 3)), (yd * yd).sum((0, 2, 3))])
+    got = st.double().sum(0).cpu()
+    assert float((got - want).abs().max() / want.abs().max()) <= 1e-5
+    close(to_cpu(raw), F.conv2d(x, w, None, stride=1, padding=1), what='ring-walk fprop (statistics launch)')
+    gam, bet = 1 + 0.1 * torch.randn(Co, generator=g), torch.randn(Co, generator=g)
+
+    def run(in_conv):
+        monkeypatch.setattr(ops, 'IN_CONV_FINALIZE', in_conv)
+        bn = nn.BatchNorm2d(Co).to(DEV)
+        with torch.no_grad():
+            bn.weight.copy_(gam)
+            bn.bias.copy_(bet)
+        state = ops.BNState(Co, DEV)
+        out = ops.new_act(N, Co, H, W, DEV)
+        launches = []
+        for _ in range(2):                     # twice on one tail workspace: the ticket words reset themselves
+            ops.lib().gcc_launch_count(1)
+            ops.conv_fprop(xd, wp, Co, 3, 1, 1, out=out, want_stats=True, bn=ops.bn_desc(bn, state, N * H * W, DEV))
+            launches.append(int(ops.lib().gcc_launch_count(1)))
+        torch.cuda.synchronize()
+        return out, bn, [t.clone() for t in (state.mean, state.rstd, state.scale, state.shift, bn.running_mean, bn.running_var)], launches
+    out, bn, a, la = run(True)
+    out0, _, b, lb = run(False)
+    assert la == [1, 1] and lb == [2, 2], (la, lb)        # folded by the launch's last-arriving workgroups / by a gcc_bn_finalize launch
+    assert torch.equal(out, raw) and torch.equal(out0, raw)
+    for name, u, v in zip(('mean', 'rstd', 'scale', 'shift', 'running_mean', 'running_var'), a, b):
+        assert torch.equal(u, v), name
+    r = to_cpu(out)
+    m, v = r.mean((0, 2, 3)), r.var((0, 2, 3), unbiased=False)
+    vu = r.var((0, 2, 3), unbiased=True)
+    close(a[0].cpu(), m, tol=1e-4, floor=1e-5, what='batch mean')
+    close(a[1].cpu(), 1.0 / torch.sqrt(v + bn.eps), tol=1e-4, floor=1e-5, what='rstd')
+    close(a[4].cpu(), 0.1 * m + 0.9 * 0.1 * m, tol=1e-4, floor=1e-5, what='running mean after two updates')
+    close(a[5].cpu(), 0.81 + 0.19 * vu, tol=1e-4, floor=1e-5, what='running var after two updates')
+
+
+@pytest.mark.parametrize('case', RING3_CASES)
+def test_ring_walk_3x3_dgrad(case):
+    """gcc_conv_dgrad's ring-walk route (the same kernel over dY, taps mirrored, dgrad packing) against torch's conv2d_input on the
+    same bf16 operands and against igemm_kernel; one launch"""
+    from gcc_amd import _lib
+    ops = _ops()
+    N, H, W, Ci, Co = case
+    Ci, Co = Co, Ci                        # the cases name (source, destination) widths: here dY has the source's
+    if Co % 8:
+        pytest.skip('source width must be a multiple of 8')
+    # (8 -> 8: 3 x 8 = 24 <= 32 columns, the thin-output data gradient of conv_thinout.hip comes first)
+    assert _ring3_route((N, H, W, Ci, Co), 1) == (3 if Co * 3 <= 32 else 4)
+    g = torch.Generator().manual_seed(sum(case) + 13)
+    dy = rb(torch.randn(N, Co, H, W, generator=g))
+    w = rb(torch.randn(Co, Ci, 3, 3, generator=g) * (1.0 / (3 * Co ** 0.5)))
+    ref = torch.nn.grad.conv2d_input((N, Ci, H, W), w, dy, stride=1, padding=1)
+    _, wtp = ops.pack_weights(master_cl(w))
+    dyd = to_dev(dy)
+    dx = ops.new_act(N, Ci, H, W, DEV)
+    dx.fill_(3.0)
+    ops.lib().gcc_launch_count(1)
+    ops.conv_dgrad(dyd, wtp, Ci, H, W, 3, 1, 1, out=dx)
+    assert int(ops.lib().gcc_launch_count(1)) == 1
+    close(to_cpu(dx), ref, what='ring-walk dgrad')
+    lib = ops.lib()
+    prev = lib.gcc_get_option(_lib.OPT_IGEMM_THIN)
+    try:
+        lib.gcc_set_option(_lib.OPT_IGEMM_THIN, 0)
+        dx0 = ops.conv_dgrad(dyd, wtp, Ci, H, W, 3, 1, 1)
+    finally:
+        lib.gcc_set_option(_lib.OPT_IGEMM_THIN, prev)
+    close(to_cpu(dx), to_cpu(dx0), what='ring-walk dgrad vs igemm_kernel')
+
+
 def test_instance_norm_workspace_scrub_keeps_results():
     """the launcher re-zeroes a grid InstanceNorm workspace at its first use inside every launch recording (and every 2^20
     launches), so that the 24-bit epoch field of the exchange tag never wraps: a recorded + replayed sequence of launches gives
