@@ -150,24 +150,32 @@ __global__ __launch_bounds__(256, 2) void ring3_kernel(const Ring3Args a) {
 #pragma unroll
                 for (int nb = 0; nb < NBW; nb++) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int s0 = ((y - 1) % R3_RING + R3_RING) % R3_RING;
+            const char* rowp[3];
 #pragma unroll
-            for (int ty = 0; ty < 3; ty++) {
-                const int slot = s0 + ty >= R3_RING ? s0 + ty - R3_RING : s0 + ty;
-                const char* row = sX + slot * ROWB;
+            for (int ty = 0; ty < 3; ty++) rowp[ty] = sX + (s0 + ty >= R3_RING ? s0 + ty - R3_RING : s0 + ty) * ROWB;
+            // the 9 x CC x NBW pixel operands of the row in one software pipeline: operand k + PF is read while the products of
+            // operand k issue (a 16-byte LDS read returns after ~100 cycles, two products cover 32: with one read ahead -- the
+            // compiler's own schedule -- a wave multiplied a third of the time, profiles/r5_ring3.txt)
+            // pixel operand k = ((ty * 3 + tx) * CC + cc) * NBW + nb: lane (i, g) -> staged pixel 16 (NBW wn + nb) + i + tx,
+            // channels 32 cc + 8 g .. + 7
+            constexpr int NI = 9 * CC * NBW, PF = NI < 6 ? NI : 6;
+            auto rd = [&](int k) {
+                const int nb = k % NBW, cc = (k / NBW) % CC, tap = k / (NBW * CC), ty = tap / 3, tx = tap - 3 * ty;
+                return *(const bf16x8*)(rowp[ty] + r3_off<RS>((wn * NBW + nb) * 16 + i + tx, cc * 4 + g));
+            };
+            bf16x8 xb[NI];
 #pragma unroll
-                for (int tx = 0; tx < 3; tx++) {
+            for (int k = 0; k < PF; k++) xb[k] = rd(k);
+            __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
 #pragma unroll
-                    for (int cc = 0; cc < CC; cc++) {
+            for (int k = 0; k < NI; k++) {
+                if (k + PF < NI) xb[k + PF] = rd(k + PF);
+                const int nb = k % NBW, cc = (k / NBW) % CC, tap = k / (NBW * CC);
 #pragma unroll
-                        for (int nb = 0; nb < NBW; nb++) {
-                            // pixel operand: lane (i, g) -> staged pixel 16 (NBW wn + nb) + i + tx, channels 32 cc + 8 g .. + 7
-                            const bf16x8 xb = *(const bf16x8*)(row + r3_off<RS>((wn * NBW + nb) * 16 + i + tx, cc * 4 + g));
-#pragma unroll
-                            for (int mb = 0; mb < MBW; mb++)
-                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mb][ty * 3 + tx][cc], xb, acc[mb][nb], 0, 0, 0);
-                        }
-                    }
-                }
+                for (int mb = 0; mb < MBW; mb++)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mb][tap][cc], xb[k], acc[mb][nb], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MBW, 0);
+                if (k + PF < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             // lane (i, g): pixel 16 (NBW wn + nb) + i, channels 16 (MBW wm + mb) + 4 g + r
 #pragma unroll
