@@ -297,17 +297,27 @@ __global__ __launch_bounds__(256) void thinout_fprop_kernel(const ThinOutFpropAr
             int s0 = (y - P) % TO_RING;
             s0 = s0 < 0 ? s0 + TO_RING : s0;
             f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ty = 0; ty < K; ty++) {
+            // the K x CC pixel operands of the row as one software pipeline, six LDS reads ahead of the products they feed (the
+            // compiler's own schedule keeps one ahead: conv_ring3.hip, profiles/r5_ring3.txt)
+            // pixel operand k = ty * CC + cc: lane (i, g) -> pixel 16 wave + i, channels 32 cc + 8 g .. + 7 = 16-byte chunk 4 cc + g
+            constexpr int NI = K * CC, PF = NI < 6 ? NI : 6;
+            auto rd = [&](int k) {
+                const int ty = k / CC, cc = k - ty * CC;
                 const int slot = s0 + ty >= TO_RING ? s0 + ty - TO_RING : s0 + ty;
-                const char* row = sX + slot * XROW;
+                return *(const bf16x8*)(sX + slot * XROW + img_off<RS>(wave * 16 + i, cc * 4 + g));
+            };
+            bf16x8 xbv[NI];
 #pragma unroll
-                for (int cc = 0; cc < CC; cc++) {
-                    // pixel operand: lane (i, g) -> pixel 16 wave + i, channels 32 cc + 8 g .. + 7 = 16-byte chunk 4 cc + g
-                    const bf16x8 xb = *(const bf16x8*)(row + img_off<RS>(wave * 16 + i, cc * 4 + g));
-                    u0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ty][cc], xb, u0, 0, 0, 0);
-                    u1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ty][cc], xb, u1, 0, 0, 0);
-                }
+            for (int k = 0; k < PF; k++) xbv[k] = rd(k);
+            __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+            for (int k = 0; k < NI; k++) {
+                if (k + PF < NI) xbv[k + PF] = rd(k + PF);
+                const int ty = k / CC, cc = k - ty * CC;
+                u0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ty][cc], xbv[k], u0, 0, 0, 0);
+                u1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ty][cc], xbv[k], u1, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if (k + PF < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             // lane (i, g) holds U[pixel 16 wave + i][m = 4 g + r] (u0) and [16 + 4 g + r] (u1)
             *(f32x4*)(sU + (wave * 16 + i) * UROW + 4 * g) = u0;
@@ -451,15 +461,23 @@ __global__ __launch_bounds__(256) void thinout_dgrad_kernel(const ThinOutDgradAr
                 f32x4 acc[4];
 #pragma unroll
                 for (int nb = 0; nb < 4; nb++) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ty = 0; ty < K; ty++) {
+                // the 4 K pixel operands as one software pipeline, six LDS reads ahead of their products (conv_ring3.hip)
+                constexpr int NI = 4 * K, PF = 6;
+                auto rd = [&](int k) {
+                    const int ty = k >> 2, nb = k & 3;
                     const int slot = s0 - ty < 0 ? s0 - ty + ERING : s0 - ty;
-                    const char* E = sE + slot * EIMG;
+                    return *(const bf16x8*)(sE + slot * EIMG + img_off<64>(nb * 16 + i, g));
+                };
+                bf16x8 ebv[NI];
 #pragma unroll
-                    for (int nb = 0; nb < 4; nb++) {
-                        const bf16x8 eb = *(const bf16x8*)(E + img_off<64>(nb * 16 + i, g));
-                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ty], eb, acc[nb], 0, 0, 0);
-                    }
+                for (int k = 0; k < PF; k++) ebv[k] = rd(k);
+                __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+                for (int k = 0; k < NI; k++) {
+                    if (k + PF < NI) ebv[k + PF] = rd(k + PF);
+                    acc[k & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k >> 2], ebv[k], acc[k & 3], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (k + PF < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
                 // lane (i, g): pixel 16 nb + i, channels 16 wave + 4 g + r
                 const int c0 = wave * 16 + 4 * g;
