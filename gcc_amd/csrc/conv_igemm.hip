@@ -1067,14 +1067,21 @@ __global__ __launch_bounds__(256) void thin_fprop_kernel(const ThinArgs a) {
 #pragma unroll
         for (int t = 0; t < NJ; t++)
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                acc[t][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int h = 0; h < 2; h++) acc[t][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // weight operand k = (t * 2 + h) * 4 + kc, one per product: a software pipeline with six LDS reads ahead of their products
+        // (round 5, as conv_ring3.hip: left alone the compiler keeps one read ahead and every product waits for its operand)
+        constexpr int NI = NJ * 8, PF = 6;
+        bf16x8 wv[NI];
 #pragma unroll
-                for (int kc = 0; kc < 4; kc++)
-                    acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        *(const bf16x8*)(wlds + (((t * 2 + h) * 4 + kc) * 64 + lane) * 16), __builtin_bit_cast(bf16x8, xb[kc]),
-                        acc[t][h], 0, 0, 0);
-            }
+        for (int k = 0; k < PF; k++) wv[k] = *(const bf16x8*)(wlds + (k * 64 + lane) * 16);
+        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            if (k + PF < NI) wv[k + PF] = *(const bf16x8*)(wlds + ((k + PF) * 64 + lane) * 16);
+            acc[k >> 3][(k >> 2) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[k], __builtin_bit_cast(bf16x8, xb[k & 3]), acc[k >> 3][(k >> 2) & 1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (k + PF < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
         // lane (i, g) holds pixel tile*16 + i, channels co_base + 32t + 8g + {0..7} (h = 0: first four, h = 1: last four):
         // a store from here would touch 16 rows x 64 bytes.  The wave's [16 pixels][NJ*64 bytes] block goes through a
         // wave-private LDS image (row stride padded by 16 bytes: conflict-free both ways) so that each store instruction
@@ -1253,6 +1260,8 @@ __global__ __launch_bounds__(256) void thin_dgrad_k4s2_kernel(const ThinDgradArg
             yb[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
         }
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};       // two chains: MFMA back-to-back dependency
+        // (round 5: pipelining these weight reads six deep, as in thin_fprop_kernel, made the 64-channel layer SLOWER, 51 -> 58 us:
+        // the twelve global loads of the tile are what the wave waits for, and more live registers cut the waves that hide them)
 #pragma unroll
         for (int f = 0; f < NK; f += 2) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(wlds + (f * 64 + lane) * 16),
@@ -1362,17 +1371,23 @@ __global__ __launch_bounds__(THIN_WIDE_NT) void thin_dgrad_wide_kernel(const Thi
                 const char* t0 = row_u0 + jt * (16 * THIN_WIDE_RB);
                 const char* t1 = row_u1 + jt * (16 * THIN_WIDE_RB);
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                // both operands of a product come from LDS: a software pipeline with four pairs of reads ahead of their products (round 5)
+                constexpr int PF = 4;
+                bf16x8 yv[NK], wv[NK];
+                auto rdy = [&](int ff) {
+                    const int u = ff / (3 * NCC), bb = (ff / NCC) % 3, cc = ff % NCC;
+                    return *(const bf16x8*)((u == 0 ? t0 : t1) + yoffs[bb][cc]);
+                };
 #pragma unroll
-                for (int f = 0; f < NK; f += 2) {
-                    bf16x8 yb[2];
+                for (int f = 0; f < PF; f++) { yv[f] = rdy(f); wv[f] = *(const bf16x8*)(wp + f * 1024); }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * PF, 0);
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const int ff = f + h;
-                        const int u = ff / (3 * NCC), bb = (ff / NCC) % 3, cc = ff % NCC;
-                        yb[h] = *(const bf16x8*)((u == 0 ? t0 : t1) + yoffs[bb][cc]);
-                    }
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(wp + f * 1024), yb[0], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(wp + (f + 1) * 1024), yb[1], acc1, 0, 0, 0);
+                for (int f = 0; f < NK; f++) {
+                    if (f + PF < NK) { yv[f + PF] = rdy(f + PF); wv[f + PF] = *(const bf16x8*)(wp + (f + PF) * 1024); }
+                    if (f & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[f], yv[f], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[f], yv[f], acc0, 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (f + PF < NK) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 }
                 const int ix = 2 * (jt * 16 + i) + pxo;
                 if (ix < a.W) {

@@ -1,0 +1,27 @@
+"""image-side data gradients (the generators' last ConvTranspose, the first PatchGAN layer's dgrad): k4 s2 p1, N = 16, output 256 x 256"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from gcc_amd import ops
+DEV = torch.device('cuda:0')
+def med(fn, n=21):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+g = torch.Generator().manual_seed(0)
+for rep in range(2):
+    for Ci, Co in ((3, 64), (3, 128), (6, 128), (3, 32)):
+        N, H, W = 16, 256, 256
+        dy = ops.new_act(N, Co, H // 2, W // 2, DEV); dy.normal_()
+        m = (torch.randn(Co, Ci, 4, 4, generator=g) * 0.05).to(DEV).contiguous(memory_format=torch.channels_last)
+        w, wt = ops.pack_weights(m)
+        dx = ops.new_act(N, Ci, H, W, DEV)
+        t = med(lambda: ops.conv_dgrad(dy, wt, Ci, H, W, 4, 2, 1, out=dx, act=ops.ACT_TANH))
+        t2 = med(lambda: ops.conv_dgrad(dy, wt, Ci, H, W, 4, 2, 1, out=dx))
+        print('%d <- %3d: tanh %6.1f / %6.1f us   plain %6.1f / %6.1f' % ((Ci, Co) + t + t2), flush=True)
