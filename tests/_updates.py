@@ -7,7 +7,7 @@ at most ~lr per step), so the model tests use these two instead:
   (|w_ref_final - w_init| >= 0.5 * lr * steps, i.e. a gradient sign that did not flip between the steps) AND whose fp32
   oracle gradient of the first iteration stands clear of the bf16 pipeline's noise in its tensor (floor_masks: |g32| >=
   3 * rms(g_bf16_emulated - g32), the selection sign_check uses), the HIP path must have moved too (>= 99 % non-zero
-  displacement) and in the same direction (>= 0.98; measured 0.991-0.9999, profiles/r5_test_report.txt).  Without the floor selection the figure is reported, not judged: Adam
+  displacement) and in the same direction (>= 0.98; measured 0.991-0.9999, profiles/r5end_test_report.txt).  Without the floor selection the figure is reported, not judged: Adam
   turns an element whose gradient is below the noise into a full +-lr step of arbitrary sign, and the bf16-EMULATING ORACLE
   itself agrees with the reference on only 0.902-0.904 of the clearly moved generator weights of the CycleGAN fixture
   (scratch/r5/emul_agreement.py, CPU; the HIP path: 0.901-0.906) against 0.9993 above the floor.
