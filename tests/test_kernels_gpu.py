@@ -1400,6 +1400,8 @@ RING3_CASES = [
     (3, 64, 48, 32, 32),            # one strip of 64 columns three quarters used
     (1, 256, 33, 8, 8),             # narrowest: 8 channels, 33 columns
     (1, 96, 96, 24, 20),            # destination width not a multiple of 8: the padding lanes of the output stay zero
+    (1, 520, 16, 16, 16),           # narrowest image (one half-used strip of 32), a long walk: the ring wraps many times
+    (4, 33, 65, 64, 64),            # 65 columns: three strips of 32, the last one pixel wide; odd height
 ]
 
 
