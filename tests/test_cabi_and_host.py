@@ -168,6 +168,34 @@ def test_conv_route_predicates():
     assert lib.gcc_conv_route(ctypes.byref(bad), 0, ctypes.byref(none)) < 0
 
 
+def test_ring_walk_route_predicates():
+    """the ring-walk route of conv_ring3.hip (round 5) is chosen by geometry alone, and gcc_conv_stat_tiles promises its rows: 3 x 3
+    stride 1 pad 1, 8..64 channels on both sides (source width a multiple of 8), >= 8192 pixels; one statistics row per workgroup"""
+    from gcc_amd import _lib
+    lib = _lib.load()
+    conv = lambda N, H, W, Ci, Co, k, s, p: _lib.conv_t(N, H, W, Ci, Co, k, k, s, p, (Ci + 7) // 8 * 8, 0, (Co + 7) // 8 * 8, 0)
+    none = _lib.epilogue_t(None, 0, 0.2, None, None, 0)
+    with_stats = _lib.epilogue_t(None, 0, 0.2, ctypes.c_void_p(4096), None, 0)
+    route = lambda d, dgrad=0, ep=none: lib.gcc_conv_route(ctypes.byref(d), dgrad, ctypes.byref(ep))
+    trunk = conv(16, 96, 96, 64, 64, 3, 1, 1)                  # SRGAN's residual blocks at 96 x 96 (models/SRGAN.py:59-81)
+    assert route(trunk) == 4 and route(trunk, 1) == 4 and route(trunk, 0, with_stats) == 4
+    rows = lib.gcc_conv_stat_tiles(ctypes.byref(trunk), 0)
+    assert 0 < rows <= 512                                       # workgroups: at most two per CU
+    assert route(conv(16, 384, 384, 64, 64, 3, 1, 1)) == 4       # VGG19 conv1_2 at the high resolution
+    assert route(conv(16, 96, 96, 24, 24, 3, 1, 1)) == 4         # the student's pruned widths
+    assert route(conv(16, 96, 96, 24, 20, 3, 1, 1)) == 4 and route(conv(16, 96, 96, 24, 20, 3, 1, 1), 1) == 0   # dY of 20 channels: not a multiple of 8
+    assert route(conv(16, 96, 96, 64, 128, 3, 1, 1)) == 0        # wider than 64: igemm_kernel / the halo kernel
+    assert route(conv(16, 96, 96, 128, 64, 3, 1, 1)) == 0
+    assert route(conv(16, 192, 192, 64, 64, 3, 2, 1)) == 0       # stride 2
+    assert route(conv(2, 24, 24, 64, 64, 3, 1, 1)) == 0          # 1152 pixels: a launch-latency layer either way
+    prev = lib.gcc_set_option(_lib.OPT_IGEMM_THIN, 0)
+    try:
+        assert route(trunk) == 0
+        assert lib.gcc_conv_stat_tiles(ctypes.byref(trunk), 0) > 0          # igemm_kernel's pixel-tile rows
+    finally:
+        lib.gcc_set_option(_lib.OPT_IGEMM_THIN, prev)
+
+
 def test_tile_plan_travels_with_the_call():
     """gcc_conv_t.plan (round 5): the tile plan is an argument of the call -- the same geometry lands on different tile families
     under different plans with NO library state in between; the headline shapes land on the 256-pixel tiles under the default
