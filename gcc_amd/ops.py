@@ -966,6 +966,10 @@ BN_BWD_GRID = os.environ.get('GCC_BN_BWD_GRID', '1') != '0'
 BN_BWD_GRID_EX = int(os.environ.get('GCC_BN_BWD_GRID_EX', '1'))
 BN_BWD_GRID_EX_MAX_PIXELS = int(os.environ.get('GCC_BN_BWD_GRID_EX_MAX_PIXELS', '4096'))
 BN_BWD_GRID_MIN_PIXELS = 4096        # at or below: bnact_bwd_small_kernel (one workgroup per 8 channels) is the one-launch form
+# above: reduce + finalize + apply.  The one-launch kernel runs on the grid family's 4 x CUs / Q workgroups (one wave per SIMD): it wins
+# while the tensor is a few launches' worth of latency and loses once it is bandwidth (profiles/r5_bn_bwd_paths.txt: 9.4 MB 23.7 against
+# 25.7 us, 18.9 MB 44.4 against 36.6, 151 MB 388 against 204)
+BN_BWD_GRID_MAX_BYTES = int(os.environ.get('GCC_BN_BWD_GRID_MAX_BYTES', str(12 << 20)))
 
 
 def bnact_bwd(x, y, g1, dx, g2=None, bn=None, gamma=None, beta=None, bn_eval=False, gate=None, gate_after_act=False,
@@ -999,7 +1003,7 @@ def bnact_bwd(x, y, g1, dx, g2=None, bn=None, gamma=None, beta=None, bn_eval=Fal
             check(rc, 'gcc_bn_bwd_one_launch_ex')
     if (BN_BWD_GRID and bn is not None and not bn_eval and g2 is None and gate is None and not gate_after_act and drop_p == 0.0
             and dalpha is None and in_act == ACT_NONE and act2 == ACT_NONE and groups <= 1 and (y is not None or act == ACT_NONE)
-            and pixels > BN_BWD_GRID_MIN_PIXELS and not PROFILE.active):
+            and pixels > BN_BWD_GRID_MIN_PIXELS and pixels * ceil8(Cc) * 2 <= BN_BWD_GRID_MAX_BYTES and not PROFILE.active):
         # plain training-mode BatchNorm backward (SRResNet / SAGAN-generator blocks): one launch instead of reduce + finalize + apply
         ws = inorm_workspace(x.device)
         rc = lib().gcc_bn_bwd_one_launch(xp, ldx, yp, ldy, g1p, ldg1, dxp, lddx, Cc, pixels, act, slope, bn.mean.data_ptr(),

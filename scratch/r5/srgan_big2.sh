@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # SRGAN 96 -> 384: step time with / without the ring-walk + thin-output routes, then serialized kernel statistics of the current tree
-out=gpurun_out/r5_srgan3; mkdir -p $out
+out=gpurun_out/r5_srgan4; mkdir -p $out
 export TMPDIR=/tmp
 python scratch/other_one.py srgan_96_to_384 12 > $out/step_default.txt 2>&1; tail -1 $out/step_default.txt
 GCC_IGEMM_THIN=0 python scratch/other_one.py srgan_96_to_384 12 > $out/step_nothin.txt 2>&1; tail -1 $out/step_nothin.txt

@@ -1304,6 +1304,24 @@ def test_grid_kernels_on_four_streams_make_progress():
                 assert torch.equal(y, ry) and torch.equal(dx, rdx)
 
 
+def test_batchnorm_backward_route_by_size(monkeypatch):
+    """the one-launch BatchNorm backward is for tensors that are a few launches' worth of latency (<= GCC_BN_BWD_GRID_MAX_BYTES, 12 MB);
+    larger ones take reduce + finalize + apply, which runs at the memory system's rate (profiles/r5_bn_bwd_paths.txt)"""
+    ops = _ops()
+    monkeypatch.setattr(ops, 'BN_BWD_GRID', True)
+    for (N, C, H, W), want in (((2, 256, 96, 96), 1), ((4, 256, 96, 96), 3), ((16, 64, 96, 96), 3)):
+        x = ops.new_act(N, C, H, W, DEV); x.normal_()
+        gy = ops.new_act(N, C, H, W, DEV); gy.normal_()
+        y = ops.new_act(N, C, H, W, DEV); y.normal_()
+        dx = ops.new_act(N, C, H, W, DEV)
+        st = ops.BNState(C, DEV); st.rstd.fill_(1.0)
+        gam, bet = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        ops.lib().gcc_launch_count(1)
+        ops.bnact_bwd(x, y, gy, dx, bn=st, gamma=gam, beta=bet, act=ops.ACT_LRELU, dgamma=dg, dbeta=db)
+        assert int(ops.lib().gcc_launch_count(1)) == want, (N, C, H, W)
+
+
 @pytest.mark.parametrize('case', [
     # N, H, W, Ci, Co, k          wide kernels with <= 3 output channels: conv_thinout.hip
     (2, 40, 80, 64, 3, 9),        # SRGAN teacher's last layer shape (64 -> 3, 9 x 9), a strip and a quarter wide, two row bands
