@@ -16,7 +16,7 @@ def med(fn, n=15):
     ts.sort()
     return ts[len(ts) // 2]
 shapes = [('L2 256 @64', 16, 256, 64, 64), ('L3 512 @32', 16, 512, 32, 32), ('L4 1024 @31', 16, 1024, 31, 31), ('L1 128 @128 (gate only)', 16, 128, 128, 128),
-          ('SR-D 128 @192', 16, 128, 192, 192), ('SR-D 64 @192', 16, 64, 192, 192), ('SR-D 256 @96', 16, 256, 96, 96)]
+          ('SR-D 128 @192', 16, 128, 192, 192), ('SR-D 64 @192', 16, 64, 192, 192), ('SR-D 256 @96', 16, 256, 96, 96), ('SR-D 64 @384', 16, 64, 384, 384), ('SR-D 128 @384', 16, 128, 384, 384)]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if sys.argv[1] in s[0]]
 print('%-26s %8s | %18s %18s | %22s %22s %22s' % ('tensor', 'MB', 'fwd plain', 'fwd gate', 'bwd plain (5T)', 'bwd gate+dalpha (5T)', 'bwd eval-less apply'))
