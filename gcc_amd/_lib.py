@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GCC_HIP_LIB') or os.path.join(_HERE, 'libgcc_hip.so')     # GCC_HIP_LIB: another build of the same ABI (A/B runs)
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+GCC_HIP_ABI = 600     # include/gcc_hip.h GCC_HIP_ABI: the generation of struct layouts / option ids these bindings were written for
 
 
 class GccError(RuntimeError):
@@ -222,6 +223,11 @@ def load():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
+    got = lib.gcc_version()
+    if got != GCC_HIP_ABI:
+        raise GccError('%s was built from another generation of include/gcc_hip.h (gcc_version() = %d, these bindings are '
+                       'for GCC_HIP_ABI %d): struct layouts and option ids differ -- rebuild with gcc_amd/csrc/build.sh'
+                       % (LIB_PATH, got, GCC_HIP_ABI))
     _lib = lib
     return lib
 

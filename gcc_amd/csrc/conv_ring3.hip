@@ -13,6 +13,7 @@
 // written as full 128-byte lines; BatchNorm partial sums (of the rounded values) are kept per thread over the whole walk and
 // leave as ONE row per workgroup.  The data gradient is the same kernel over dY with the taps mirrored (flip) and the dgrad packing.
 #include <stdlib.h>
+#include <mutex>
 #include "common.hpp"
 #include "igemm_common.hpp"
 
@@ -323,11 +324,12 @@ int gcc_internal_ring3(const gcc_conv_t* c, int dgrad, const void* src, const vo
     }
 #define GCC_R3_LAUNCH(RS_, NBW_, DB_)                                                                                            \
     do {                                                                                                                          \
-        static bool attr_done = false;                                                                                            \
-        if (!attr_done) {                                                                                                         \
-            (void)hipFuncSetAttribute((const void*)ring3_kernel<RS_, NBW_, DB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr_done = true;                                                                                                     \
-        }                                                                                                                         \
+        static std::once_flag once;                                                                                               \
+        static hipError_t attr_err = hipSuccess;                                                                                  \
+        std::call_once(once, [] {                                                                                                 \
+            attr_err = hipFuncSetAttribute((const void*)ring3_kernel<RS_, NBW_, DB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        });                                                                                                                       \
+        if (attr_err != hipSuccess) return GCC_ERR_LAUNCH;                                                                        \
         hipLaunchKernelGGL((ring3_kernel<RS_, NBW_, DB_>), dim3(p.wgs), dim3(256), p.lds, st, a);                                 \
     } while (0)
     const int key = (p.rs == 128 ? 4 : 0) + (p.nbw == 2 ? 2 : 0) + (p.db == 2 ? 1 : 0);

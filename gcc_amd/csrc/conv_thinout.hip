@@ -15,6 +15,7 @@
 // registers for the whole walk, and the per-workgroup partial dW (k x 32 x C floats) is folded by a second small kernel.
 // MFMA-bound: 2 k / 16 products per pixel row and wave; 302 MB of X in ~0.1 ms instead of 5 ms.
 #include <stdlib.h>
+#include <mutex>
 #include "common.hpp"
 #include "igemm_common.hpp"
 
@@ -534,7 +535,9 @@ ThinOutPlan thinout_plan(const gcc_conv_t* c) {
     ThinOutPlan p = {};
     if (!gcc_opt(GCC_OPT_IGEMM_THIN)) return p;
     if (c->KH != c->KW || (c->KH & 1) == 0 || c->KH < 3 || c->KH > TO_MAXK || c->stride != 1 || c->pad != (c->KH - 1) / 2) return p;
-    if (c->Co < 1 || c->Co * c->KW > 32 || c->Ci < 8 || c->Ci > 64 || (c->Ci & 7)) return p;
+    // Co <= 8: the weight- and data-gradient kernels stage dY as ONE 16-byte chunk per pixel (channels 0..7 of the padded row,
+    // `sD[..][px][8]`); a 3 x 3 layer with 9 or 10 output channels (Co * KW <= 32) must take the generic kernels
+    if (c->Co < 1 || c->Co > 8 || c->Co * c->KW > 32 || c->Ci < 8 || c->Ci > 64 || (c->Ci & 7)) return p;
     if (c->W < 16 || c->H < 1) return p;
     p.Cip = c->Ci > 32 ? 64 : 32;
     p.strips = cdiv(c->W, TO_SW);
@@ -580,11 +583,12 @@ int gcc_internal_thinout_wgrad(const gcc_conv_t* c, const void* x, const void* d
     // one instantiation per (row bytes, kernel side): the vertical taps are unrolled
 #define GCC_TO_LAUNCH(RS_, K_)                                                                                                   \
     do {                                                                                                                          \
-        static bool attr_done = false;                                                                                            \
-        if (!attr_done) {                                                                                                         \
-            (void)hipFuncSetAttribute((const void*)thinout_wgrad_kernel<RS_, K_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr_done = true;                                                                                                     \
-        }                                                                                                                         \
+        static std::once_flag once;                                                                                               \
+        static hipError_t attr_err = hipSuccess;                                                                                  \
+        std::call_once(once, [] {                                                                                                 \
+            attr_err = hipFuncSetAttribute((const void*)thinout_wgrad_kernel<RS_, K_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        });                                                                                                                       \
+        if (attr_err != hipSuccess) return GCC_ERR_LAUNCH;                                                                        \
         hipLaunchKernelGGL((thinout_wgrad_kernel<RS_, K_>), dim3(p.wgs), dim3(256), p.lds, st, a);                                \
     } while (0)
     const bool wide = p.Cip == 64;
@@ -641,11 +645,12 @@ int gcc_internal_thinout_fprop(const gcc_conv_t* c, const void* x, const void* w
     const size_t lds = (size_t)TO_RING * TO_SW * p.Cip * 2 + (size_t)TO_SW * 36 * 4;
 #define GCC_TO_LAUNCH(RS_, K_)                                                                                                   \
     do {                                                                                                                          \
-        static bool attr_done = false;                                                                                            \
-        if (!attr_done) {                                                                                                         \
-            (void)hipFuncSetAttribute((const void*)thinout_fprop_kernel<RS_, K_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr_done = true;                                                                                                     \
-        }                                                                                                                         \
+        static std::once_flag once;                                                                                               \
+        static hipError_t attr_err = hipSuccess;                                                                                  \
+        std::call_once(once, [] {                                                                                                 \
+            attr_err = hipFuncSetAttribute((const void*)thinout_fprop_kernel<RS_, K_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        });                                                                                                                       \
+        if (attr_err != hipSuccess) return GCC_ERR_LAUNCH;                                                                        \
         hipLaunchKernelGGL((thinout_fprop_kernel<RS_, K_>), dim3(p.wgs), dim3(256), lds, st, a);                                  \
     } while (0)
     const bool wide = p.Cip == 64;

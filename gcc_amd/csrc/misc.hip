@@ -433,7 +433,7 @@ extern "C" const char* gcc_strerror(int code) {
     }
 }
 extern "C" int gcc_version(void) {
-    GCC_ENTER(); return 200; }
+    GCC_ENTER(); return GCC_HIP_ABI; }
 
 // ---- tuning options (the library's only process-wide state) --------------------------------------------------------
 namespace {

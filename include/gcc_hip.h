@@ -41,8 +41,13 @@ enum {
 
 enum { GCC_ACT_NONE = 0, GCC_ACT_LRELU = 1, GCC_ACT_RELU = 2, GCC_ACT_TANH = 3 };
 
+/* ABI generation of this header: bumped whenever a struct layout, an enum numbering or a prototype below changes.  gcc_version()
+ * of the library a host loads must return exactly this number (gcc_amd/_lib.py refuses any other; an external host should check it
+ * the same way): a stale .so reads gcc_conv_t.plan past its struct and sets the wrong option ids without any error. */
+#define GCC_HIP_ABI 600
+
 const char* gcc_strerror(int code);
-int gcc_version(void);
+int gcc_version(void); /* == GCC_HIP_ABI of the header the library was built from */
 /* kernel launches the library has made in this process so far (reset != 0: return the count and start again from zero) */
 long long gcc_launch_count(int reset);
 /* Device-side error word.  The kernels that wait for other workgroups inside a launch (the grid InstanceNorm's tagged exchange,

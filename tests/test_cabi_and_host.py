@@ -34,8 +34,37 @@ def test_library_exports_every_declared_symbol():
     for name in _lib.PROTOTYPES:
         assert name in decl, '%s bound but not declared in include/gcc_hip.h' % name
     _lib.load()
-    assert _lib.load().gcc_version() >= 100
+    hdr = open(os.path.join(ROOT, 'include', 'gcc_hip.h')).read()
+    abi = int(re.search(r'#define\s+GCC_HIP_ABI\s+(\d+)', hdr).group(1))
+    assert _lib.load().gcc_version() == abi == _lib.GCC_HIP_ABI
     assert b'workspace' in _lib.load().gcc_strerror(-3)
+
+
+def test_loader_refuses_a_library_of_another_abi_generation(monkeypatch):
+    """a stale libgcc_hip.so (or one named by GCC_HIP_LIB) whose struct layouts / option ids differ must not load"""
+    from gcc_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'GCC_HIP_ABI', _lib.GCC_HIP_ABI + 1)
+    with pytest.raises(_lib.GccError, match='GCC_HIP_ABI'):
+        _lib.load()
+    monkeypatch.undo()
+    _lib.load()
+
+
+def test_thin_output_route_rejects_more_than_eight_output_channels():
+    """Co * KW <= 32 admits 3 x 3 layers with 9 or 10 output channels (SRGAN's pruned residual blocks, 24 -> 9 /
+    64 -> 10), but the thin-output weight- and data-gradient kernels stage ONE 8-channel chunk of dY per pixel: such layers must take
+    the generic kernels (route 0 / the ring walk), and the weight gradient must ask for no thin-output workspace"""
+    from gcc_amd import _lib
+    lib = _lib.load()
+    conv = lambda N, H, W, Ci, Co, k, s, p: _lib.conv_t(N, H, W, Ci, Co, k, k, s, p, (Ci + 7) // 8 * 8, 0, (Co + 7) // 8 * 8, 0)
+    none = _lib.epilogue_t(None, 0, 0.2, None, None, 0)
+    route = lambda d, dgrad=0: lib.gcc_conv_route(ctypes.byref(d), dgrad, ctypes.byref(none))
+    assert route(conv(2, 48, 48, 64, 3, 9, 1, 4)) == 3 and route(conv(2, 48, 48, 64, 3, 9, 1, 4), 1) == 3
+    assert route(conv(2, 48, 48, 24, 8, 3, 1, 1), 1) == 3                        # 8 channels of dY: one chunk, still thin-output
+    for ci, co in ((24, 9), (64, 10), (24, 10), (64, 9)):
+        d = conv(2, 48, 48, ci, co, 3, 1, 1)
+        assert route(d, 0) != 3 and route(d, 1) != 3, (ci, co)
 
 
 def test_comm_entry_points_without_a_gpu():

@@ -1407,6 +1407,35 @@ def test_thin_output_wide_kernel_dgrad(case):
     close(to_cpu(dx), ref, what='thin-output dgrad')
 
 
+@pytest.mark.parametrize('case', [(2, 48, 48, 24, 9, 3), (1, 40, 64, 64, 10, 3), (2, 24, 32, 24, 10, 3), (1, 32, 48, 64, 9, 3)])
+def test_pruned_3x3_layers_with_nine_or_ten_output_channels(case):
+    """SRGAN's pruned residual blocks (inner_channels = int(sum(mask)): 24 -> 9, 64 -> 10 at 3 x 3 s1 p1) satisfied
+    the thin-output plan's Co * KW <= 32, but its gradient kernels stage only channels 0..7 of dY: weight and data gradient of such a
+    layer against torch, whichever kernel the geometry is routed to now (not the thin-output one: tests/test_cabi_and_host.py)"""
+    ops = _ops()
+    N, H, W, Ci, Co, k = case
+    g = torch.Generator().manual_seed(sum(case) + 7)
+    x = rb(torch.randn(N, Ci, H, W, generator=g))
+    dy = rb(torch.randn(N, Co, H, W, generator=g))
+    w = rb(torch.randn(Co, Ci, k, k, generator=g) * (1.0 / (k * Co ** 0.5)))
+    dw_ref = torch.nn.grad.conv2d_weight(x, (Co, Ci, k, k), dy, stride=1, padding=1)
+    dx_ref = torch.nn.grad.conv2d_input((N, Ci, H, W), w, dy, stride=1, padding=1)
+    xd, dyd = to_dev(x), to_dev(dy)
+    dw = torch.full((Co, Ci, k, k), 5.0, device=DEV).contiguous(memory_format=torch.channels_last)
+    ops.conv_wgrad(xd, dyd, dw, k, 1, 1, accumulate=False)
+    close(dw.cpu(), dw_ref, tol=5e-3, floor=1e-3 * float(dw_ref.abs().max()), what='wgrad, Co = %d' % Co)
+    _, wtp = ops.pack_weights(master_cl(w))
+    dx = ops.new_act(N, Ci, H, W, DEV)
+    dx.fill_(3.0)
+    ops.conv_dgrad(dyd, wtp, Ci, H, W, k, 1, 1, out=dx)
+    close(to_cpu(dx), dx_ref, what='dgrad, Co = %d' % Co)
+    y_ref = F.conv2d(x, w, None, stride=1, padding=1)
+    wp, _ = ops.pack_weights(master_cl(w))
+    y = ops.new_act(N, Co, H, W, DEV)
+    ops.conv_fprop(xd, wp, Co, k, 1, 1, out=y)
+    close(to_cpu(y), y_ref, what='fprop, Co = %d' % Co)
+
+
 RING3_CASES = [
     # N, H, W, Ci, Co               3 x 3 stride-1 layers between <= 64-channel tensors: conv_ring3.hip
     (2, 96, 96, 64, 64),            # SRGAN teacher's trunk layer at two images: three strips of 32 columns, several row bands
