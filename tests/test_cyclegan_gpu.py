@@ -82,6 +82,24 @@ def test_cyclegan_two_iterations_vs_reference_golden(golden_dir):
                               'tG_A': teacher.netG_A, 'tG_B': teacher.netG_B, 'tD_A': teacher.netD_A, 'tD_B': teacher.netD_B})
     agree = _updates.MovementAgreement()
     masks = _updates.floor_masks(_oracle_grads(z, False), _oracle_grads(z, True))
+    # the same two iterations on the bf16-emulating oracle: every logged scalar is reported against both (tests/_updates.LossBars);
+    # the assert below is against the REFERENCE alone, as before
+    from oracle import gcc_oracle as O
+    from tests.test_oracle_golden import build_cyclegan_oracle
+    emu = []
+    bars = _updates.LossBars('cyclegan', n_map=36)
+    O.EMULATE_BF16 = True
+    try:
+        om, ot, _ = build_cyclegan_oracle(z)
+        for it in range(2):
+            om.set_input(torch.from_numpy(z['it%d.A' % it]), torch.from_numpy(z['it%d.B' % it]))
+            om.optimize_parameters()
+            om.set_input(torch.from_numpy(z['it%d.vA' % it]), torch.from_numpy(z['it%d.vB' % it]))
+            om.clipping_mask_alpha()
+            om.optimizer_netD_arch()
+            emu.append((dict(om.losses), dict(ot.losses)))
+    finally:
+        O.EMULATE_BF16 = False
     for it in range(2):
         model.set_input(_data(z, 'it%d.A' % it, 'it%d.B' % it))
         model.optimize_parameters()
@@ -114,10 +132,11 @@ def test_cyclegan_two_iterations_vs_reference_golden(golden_dir):
         model.optimizer_netD_arch()
         losses, tl = model.get_current_losses(), teacher.get_current_losses()
         for k in z.files:
-            for pre, got in (('it%d.loss.' % it, losses), ('it%d.tloss.' % it, tl)):
+            for pre, got, em in (('it%d.loss.' % it, losses, emu[it][0]), ('it%d.tloss.' % it, tl, emu[it][1])):
                 if k.startswith(pre):
                     name, ref = k[len(pre):], float(z[k])
-                    print('it%d %s %s: got %.5g ref %.5g' % (it, pre[-6], name, got[name], ref))
+                    print('it%d %s %s: got %.5g ref %.5g bf16-emulating oracle %.5g' % (it, pre[-6], name, got[name], ref, em[name]))
+                    bars.add('it%d %s %s' % (it, pre[-6].replace('.', 'S'), name), name, got[name], ref, em[name])
                     assert abs(got[name] - ref) <= 3e-2 * max(1.0, abs(ref)), (it, k, got[name], ref)
     nets = {'sG_A': model.netG_A, 'sG_B': model.netG_B, 'sD_A': model.netD_A, 'sD_B': model.netD_B,
             'tG_A': teacher.netG_A, 'tG_B': teacher.netG_B, 'tD_A': teacher.netD_A, 'tD_B': teacher.netD_B}
@@ -147,7 +166,9 @@ def test_cyclegan_two_iterations_vs_reference_golden(golden_dir):
             if not (name.endswith('running_mean') or name.endswith('running_var')):
                 agree.add(tag[:2] + ('.alpha' if name.endswith('alpha') else ''), init[tag][name], g, ref.reshape(-1),
                           (opt.arch_lr if name.endswith('alpha') else opt.lr) * 2,
-                          mask=masks[('alpha_' + tag[-1], name) if name.endswith('alpha') else (tag, name)])
+                          mask=masks[('alpha_' + tag[-1], name) if name.endswith('alpha') else (tag, name)],
+                          emul=_updates.sampled((om if tag[0] == 's' else ot).__dict__[tag[1]][tag[-1]][name]))
+    bars.check(max_emul_only=0.10, require=False)
     agree.check()
 
 

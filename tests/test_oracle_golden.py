@@ -588,3 +588,52 @@ def test_srgan_two_iterations(golden_dir):
     _compare_sd(teacher.D, z, 'final.tD.', skip=zero_d, **kw)
     for i in range(4):
         np.testing.assert_allclose(m.T[i].detach().numpy(), z['final.T.%d' % i], atol=1e-4)
+
+
+# ---- the bf16-EMULATING mode of the oracle, pinned ---------------------------------------------------
+# oracle.EMULATE_BF16 is the one oracle mode no reference fixture exercises by itself: its rounding points were chosen to follow the
+# HIP path, and the GPU tests accept a logged loss that sits within the bar of EITHER the reference or this mode.  This test holds
+# the mode itself inside a stated band of the reference's own fixtures, on the CPU, for all four families -- so "within the bar of
+# the emulating oracle" can never mean more than "within bar + band of the reference".  Bands (scratch/r6/emul_loss_band.py prints
+# the measured values): Pix2Pix, CycleGAN, SRGAN -- the GPU tests' own bar (tests/_updates.loss_tol: 3e-2 relative, floor one flipped
+# decision of the fixture's PatchGAN map / 1e-3), measured <= 0.62 bars; SAGAN (Adam with beta1 = 0: every step is a sign step of the
+# whole weight, so behind the first update bf16 storage alone moves the hinge terms) -- 5e-2 relative in iteration 0 (measured 3.6e-2),
+# 0.25 relative in iteration 1 (measured 0.204 on D_real = 0.194, 0.108 on the others).
+_EMUL_FAMILIES = {
+    # family: (fixture, builder, input keys, n_map of the fixture's discriminator output, {iteration: relative bar})
+    'pix2pix': ('pix2pix_gcc_d6.npz', lambda z: build_gcc_oracle(z), ('A', 'B', 'vA', 'vB'), 72, {0: 3e-2, 1: 3e-2}),
+    'cyclegan': ('cyclegan_gcc.npz', lambda z: build_cyclegan_oracle(z), ('A', 'B', 'vA', 'vB'), 36, {0: 3e-2, 1: 3e-2}),
+    'sagan': ('sagan_gcc.npz', lambda z: build_sagan_oracle(z), ('z', 'real', 'vz', 'vreal'), 10 ** 9, {0: 5e-2, 1: 0.25}),
+    'srgan': ('srgan_gcc.npz', lambda z: build_srgan_oracle(z), ('lr', 'hr', 'vlr', 'vhr'), 10 ** 9, {0: 3e-2, 1: 3e-2}),
+}
+
+
+@pytest.mark.parametrize('family', sorted(_EMUL_FAMILIES))
+def test_emulating_oracle_losses_stay_in_a_band_of_the_reference(golden_dir, family):
+    from tests import _updates
+    fixture, build, ins, n_map, rel = _EMUL_FAMILIES[family]
+    z = load(golden_dir, fixture)
+    O.EMULATE_BF16 = True
+    try:
+        m, teacher, _ = build(z)
+        worst, n = (0.0, ''), 0
+        for it in range(2):
+            m.set_input(torch.from_numpy(z['it%d.%s' % (it, ins[0])]), torch.from_numpy(z['it%d.%s' % (it, ins[1])]))
+            m.optimize_parameters()
+            m.set_input(torch.from_numpy(z['it%d.%s' % (it, ins[2])]), torch.from_numpy(z['it%d.%s' % (it, ins[3])]))
+            m.clipping_mask_alpha()
+            m.optimizer_netD_arch()
+            for k in z.files:
+                for pre, who in (('it%d.loss.' % it, m), ('it%d.tloss.' % it, teacher)):
+                    if k.startswith(pre):
+                        name, ref = k[len(pre):], float(z[k])
+                        err = abs(float(who.losses[name]) - ref) / _updates.loss_tol(name, ref, n_map, rel[it])
+                        n += 1
+                        if err > worst[0]:
+                            worst = (err, '%s%s' % (pre, name))
+                        assert err <= 1.0, (family, k, float(who.losses[name]), ref, err)
+    finally:
+        O.EMULATE_BF16 = False
+    assert n >= 24
+    _updates._report('bf16-emulating oracle vs the reference fixture [%s]: %d logged losses over two iterations, worst |err| / band '
+                     '%.3f (%s)' % (family, n, worst[0], worst[1]))

@@ -123,7 +123,7 @@ def test_gcc_two_iterations_vs_reference_golden(golden_dir):
     _in = [torch.from_numpy(z['it0.' + k]) for k in ('A', 'B', 'vA', 'vB')]
     masks = _updates.floor_masks(_oracle_grads(lambda: _bo(z), *_in, False), _oracle_grads(lambda: _bo(z), *_in, True))
     worst = {}
-    worst_loss = 0.0
+    bars = _updates.LossBars('pix2pix', n_map=72)          # 2 x 1 x 6 x 6 PatchGAN map
     # the same two iterations on the oracle with bf16 storage emulated at the points the HIP path rounds: the second bar a
     # logged scalar may meet (the bar the model tests of the other families use), instead of a looser tolerance
     from oracle import gcc_oracle as O
@@ -179,18 +179,17 @@ def test_gcc_two_iterations_vs_reference_golden(golden_dir):
                 name = k.split('.')[-1]
                 ref = float(z[k])
                 got = losses[name] if '.loss.' in k else tl[name]
-                err = abs(got - ref) / _updates.loss_tol(name, ref, n_map=72)         # 2 x 1 x 6 x 6 PatchGAN map
                 e16 = emu[it][0 if '.loss.' in k else 1].get(name)
-                err16 = abs(got - e16) / _updates.loss_tol(name, e16, n_map=72) if e16 is not None else float('inf')
                 print('it%d %s %s: got %.5g ref %.5g bf16-emulating oracle %s' % (it, 'S' if '.loss.' in k else 'T', name, got, ref,
                                                                                  '%.5g' % e16 if e16 is not None else '-'))
                 # within the bar (_updates.loss_tol: 3e-2 relative, floor = one flipped decision of the 72-value map) of the
                 # reference's value, or of the bf16-emulating oracle's (the arch terms are differences of two O(1) hinge means:
                 # behind the first Adam steps which side of the hinge a value falls on is a matter of bf16 storage, not of the
-                # arithmetic)
-                worst_loss = max(worst_loss, min(err, err16))
-                assert min(err, err16) <= 1.0, (it, k, got, ref, e16)
+                # arithmetic).  The two errors are kept apart: bars.check() names every scalar that passes through the emulating
+                # oracle alone (itself held within 0.62 bars of this fixture on the CPU: tests/test_oracle_golden.py) and allows 10 %
+                bars.add('it%d %s %s' % (it, 'S' if '.loss.' in k else 'T', name), name, got, ref, e16)
     lr = opt.lr
+    emu_sd = {'final.sG.': om.G, 'final.tG.': ot.G, 'final.sD.': om.D, 'final.tD.': ot.D}     # the emulating oracle after the same two iterations
     for prefix, mod, steps in (('final.sG.', model.netG, 2), ('final.tG.', teacher.netG, 2), ('final.sD.', model.netD, 2),
                                ('final.tD.', teacher.netD, 2)):
         sd = mod.state_dict()
@@ -216,9 +215,10 @@ def test_gcc_two_iterations_vs_reference_golden(golden_dir):
             if not (name.endswith('running_mean') or name.endswith('running_var')):
                 agree.add(prefix + ('alpha' if name.endswith('alpha') else 'w'), init[prefix][name], g, ref.reshape(-1),
                           (opt.arch_lr if name.endswith('alpha') else lr) * steps,
-                          mask=masks.get(('alpha', name) if name.endswith('alpha') else (prefix[6:8], name)))
+                          mask=masks.get(('alpha', name) if name.endswith('alpha') else (prefix[6:8], name)),
+                          emul=_updates.sampled(emu_sd[prefix][name]))
     print('post-step weights: worst err/tol', worst)
-    _updates._report('logged losses: worst |err| / bar %.3f (bar: 3e-2 relative, floor 2 / 72 on the PatchGAN-map means)' % worst_loss)
+    bars.check(max_emul_only=0.10)
     agree.check()
 
 

@@ -222,6 +222,10 @@ def test_sagan_two_iterations_vs_reference_golden(golden_dir):
     from oracle import gcc_oracle as O
     from tests.test_oracle_golden import build_sagan_oracle
     emu = []
+    # both errors of every scalar, apart (tests/_updates.LossBars): this family's asserts below are two-sided already (emulated
+    # trajectory AND reference, each with its stated bar); the report names the scalars that sit within 3e-2 of the emulating oracle
+    # only -- with beta1 = 0 the fixture's own emulation leaves the reference by up to 20 % in iteration 1 (tests/test_oracle_golden.py)
+    bars = _updates.LossBars('sagan', n_map=10 ** 9)
     O.EMULATE_BF16 = True
     try:
         om, ot, _ = build_sagan_oracle(z)
@@ -271,9 +275,11 @@ def test_sagan_two_iterations_vs_reference_golden(golden_dir):
                     # before the first Adam step has acted (iteration 0: D_real, D_fake, content, gram, L1), else the
                     # measured drift 0.25
                     bar = 3e-2 if it == 0 else 5e-2
+                    bars.add('it%d %s %s' % (it, pre[-6].replace('.', 'S'), name), name, got[name], ref, em[name])
                     assert abs(got[name] - em[name]) <= bar * max(1.0, abs(em[name])), (it, k, got[name], em[name])
                     pre_step = it == 0 and name in ('D_real', 'D_fake', 'content', 'gram', 'L1')
                     assert abs(got[name] - ref) <= (3e-2 if pre_step else 0.25) * max(1.0, abs(ref)), (it, k, got[name], ref)
+    emu_sd = {'sG': om.G, 'sD': om.D, 'tG': ot.G, 'tD': ot.D}         # the emulating oracle after the same two iterations
     for tag, net, zero in (('sG', model.netG, _ZERO_G), ('sD', model.netD, _ZERO_D), ('tG', teacher.netG, _ZERO_G),
                            ('tD', teacher.netD, _ZERO_D)):
         sd = net.state_dict()
@@ -307,10 +313,13 @@ def test_sagan_two_iterations_vs_reference_golden(golden_dir):
             err = float(np.abs(g - ref).max())
             assert err <= tol, (tag, name, err, tol)
             if name.endswith('alpha'):
-                agree.add(tag + '.alpha', init[tag][name], g, ref.reshape(-1), opt.arch_lr * 2, mask=masks.get(('alpha', name)))
+                agree.add(tag + '.alpha', init[tag][name], g, ref.reshape(-1), opt.arch_lr * 2, mask=masks.get(('alpha', name)),
+                          emul=_updates.sampled(emu_sd[tag][name]))
             elif not (name.endswith('running_mean') or name.endswith('running_var') or name.endswith('weight_u')
                       or name.endswith('weight_v')):
-                agree.add(tag, init[tag][name], g, ref.reshape(-1), lr * n_upd, mask=masks.get((tag, name)))
+                agree.add(tag, init[tag][name], g, ref.reshape(-1), lr * n_upd, mask=masks.get((tag, name)),
+                          emul=_updates.sampled(emu_sd[tag][name]))
+    bars.check(max_emul_only=0.35, require=False)     # measured on the CPU: 7 of this fixture's 24 emulated scalars sit > 3e-2 from the reference
     agree.check()
 
 
@@ -403,7 +412,8 @@ def test_sagan_full_width_iteration_vs_oracle():
     """BASELINE.json configs[3] at its real widths (student ngf 48 / masked D ndf 64, teacher ngf 64 / ndf 64, 64 x 64, batch
     64, z 128): one iteration + arch step of the HIP path against the oracle on the same recipe weights.  The generated
     images against the fp32 oracle (before any update acts); the loss scalars against the bf16-emulating oracle, the
-    trajectory the HIP path must stay on behind the sign-like Adam steps (beta1 = 0) -- the fp32 values are printed beside."""
+    trajectory the HIP path must stay on behind the sign-like Adam steps (beta1 = 0), AND against the fp32 oracle (3e-2 before the
+    first Adam step has acted, the measured drift bar 0.25 behind it); the report says which scalars only the emulation explains."""
     from collections import OrderedDict
     from gcc_amd.options import options
     from gcc_amd.models import get_model_class
@@ -471,11 +481,20 @@ def test_sagan_full_width_iteration_vs_oracle():
         if not (e.max() <= max(2e-2, 1.5 * float(floor.max())) and e.mean() <= max(3e-3, 1.5 * float(floor.mean()))):
             bad.append((what, float(e.max()), float(e.mean())))
     assert len(set(emu_l) & set(got)) >= 8, (sorted(emu_l), sorted(got))
+    from tests import _updates
+    bars = _updates.LossBars('sagan-full-width', n_map=10 ** 9)
     for tag, gl, el, rl in (('S', got, emu_l, ref_l), ('T', tgot, emu_tl, ref_tl)):
         for k, v in el.items():
             if k not in gl:
                 continue
             print('%s %-24s got %.5g  bf16-emulating oracle %.5g  fp32 oracle %.5g' % (tag, k, gl[k], v, rl[k]))
+            bars.add('%s %s' % (tag, k), k, gl[k], rl[k], v)
             if not abs(gl[k] - v) <= 3e-2 * max(1.0, abs(v)):
                 bad.append((tag, k, gl[k], v))
+            # ... and against the fp32 oracle (this test judged against the emulating mode alone): 3e-2 for
+            # the terms no Adam step has acted on yet, the golden-trajectory test's measured drift bar (0.25) behind one
+            pre_step = k in ('D_real', 'D_fake', 'content', 'gram', 'L1')
+            if not abs(gl[k] - rl[k]) <= (3e-2 if pre_step else 0.25) * max(1.0, abs(rl[k])):
+                bad.append((tag, k, gl[k], 'fp32 oracle', rl[k]))
+    bars.check(max_emul_only=0.35, require=False)
     assert not bad, bad

@@ -177,6 +177,7 @@ def test_srgan_two_iterations_vs_reference_golden(golden_dir):
     agree = _updates.MovementAgreement()
     masks = _updates.floor_masks(_oracle_grads(z, False), _oracle_grads(z, True))
     emu = []
+    bars = _updates.LossBars('srgan', n_map=10 ** 9)     # both errors of every scalar, apart (the asserts below stay two-sided)
     O.EMULATE_BF16 = True
     try:
         om, ot, _ = build_srgan_oracle(z)
@@ -216,8 +217,10 @@ def test_srgan_two_iterations_vs_reference_golden(golden_dir):
                 if k.startswith(pre):
                     name, ref = k[len(pre):], float(z[k])
                     print('it%d %s %s: got %.5g  reference %.5g  bf16-emulating oracle %.5g' % (it, pre[-6], name, got[name], ref, em[name]))
+                    bars.add('it%d %s %s' % (it, pre[-6].replace('.', 'S'), name), name, got[name], ref, em[name])
                     assert abs(got[name] - em[name]) <= 4e-2 * max(1.0, abs(em[name])), (it, k, got[name], em[name])
                     assert abs(got[name] - ref) <= (4e-2 if it == 0 else 0.15) * max(1.0, abs(ref)), (it, k, got[name], ref)
+    emu_sd = {'sG': om.G, 'sD': om.D, 'tG': ot.G, 'tD': ot.D}         # the emulating oracle after the same two iterations
     for tag, net, zero in (('sG', model.netG, _ZERO_G), ('sD', model.netD, _ZERO_D), ('tG', teacher.netG, _ZERO_G),
                            ('tD', teacher.netD, _ZERO_D)):
         sd = net.state_dict()
@@ -245,7 +248,9 @@ def test_srgan_two_iterations_vs_reference_golden(golden_dir):
             if not (name.endswith('running_mean') or name.endswith('running_var')):
                 agree.add(tag + ('.alpha' if name.endswith('alpha') else ''), init[tag][name], g, ref.reshape(-1),
                           (opt.arch_lr if name.endswith('alpha') else opt.lr) * 2,
-                          mask=masks.get(('alpha', name) if name.endswith('alpha') else (tag, name)))
+                          mask=masks.get(('alpha', name) if name.endswith('alpha') else (tag, name)),
+                          emul=_updates.sampled(emu_sd[tag][name]))
+    bars.check(max_emul_only=0.10, require=False)
     agree.check()
 
 
@@ -481,14 +486,16 @@ FULL_SRGAN_ARGV = ['--dataroot', './database/sr/', '--model', 'srgan', '--gpu_id
                    '--image_size', '96', '--batch_size', '16']
 
 
-@pytest.mark.parametrize('hr_size,N', [(96, 16), (384, 2)])
+@pytest.mark.parametrize('hr_size,N', [(96, 16), (384, 2), (384, 16)])
 def test_srgan_full_width_iteration_vs_oracle(hr_size, N):
     """BASELINE.json configs[4] at its real widths (SRResNet ngf 24, teacher 64, D ndf 64, the real VGG19[:36] widths with
     conditioned random weights): one iteration + arch step of the HIP path against the oracle on the same weights -- every
     logged loss (content = MSE of the super-resolved image, perceptual = VGG feature MSE, the GAN, distillation and arch terms)
     within 3e-2 of the fp32 or the bf16-emulating oracle.  (96, 16): the reference's training crop, 24 x 24 -> 96 x 96, batch 16
     (options/options.py:196-203); (384, 2): BASELINE.json's literal size, x4 96 -> 384 (models/SRGAN.py:139-245), N = 2 so
-    that the CPU oracle finishes in seconds."""
+    that the CPU oracle finishes in seconds; (384, 16): the batch `bench.py`'s `other_configs.srgan_96_384` times -- the halo /
+    ring-walk / thin-output routes key on workgroup counts, so the benched launch set is its own parity case;
+    its CPU oracle takes 1-3 minutes on the host, the emulating run is made only when a scalar misses the fp32 bar."""
     from collections import OrderedDict
     from gcc_amd.options import options
     from gcc_amd.models import get_model_class
@@ -555,14 +562,23 @@ def test_srgan_full_width_iteration_vs_oracle(hr_size, N):
         finally:
             O.EMULATE_BF16 = False
     ref_l, ref_tl = run_oracle(False)
-    emu_l, emu_tl = run_oracle(True)
+    within = lambda a, b: abs(a - b) <= 3e-2 * max(1.0, abs(b))
+    lazy = N * hr_size * hr_size > 4 * 384 * 384          # the big case: emulate only if the fp32 oracle does not explain a scalar
+    if lazy and all(within(gl[k], v) for gl, rl in ((got, ref_l), (tgot, ref_tl)) for k, v in rl.items() if k in gl):
+        emu_l, emu_tl = {}, {}
+    else:
+        emu_l, emu_tl = run_oracle(True)
     bad = []
     assert len(set(ref_l) & set(got)) >= 8, (sorted(ref_l), sorted(got))
+    from tests import _updates
+    bars = _updates.LossBars('srgan-full-width-%d-%d' % (hr_size, N), n_map=10 ** 9)
     for tag, gl, rl, el in (('S', got, ref_l, emu_l), ('T', tgot, ref_tl, emu_tl)):
         for k, v in rl.items():
             if k not in gl:
                 continue
-            print('%s %-24s got %.5g  fp32 oracle %.5g  bf16-emulating oracle %.5g' % (tag, k, gl[k], v, el[k]))
-            if not (abs(gl[k] - v) <= 3e-2 * max(1.0, abs(v)) or abs(gl[k] - el[k]) <= 3e-2 * max(1.0, abs(el[k]))):
-                bad.append((tag, k, gl[k], v, el[k]))
+            print('%s %-24s got %.5g  fp32 oracle %.5g  bf16-emulating oracle %s' % (tag, k, gl[k], v, '%.5g' % el[k] if k in el else '(not run)'))
+            bars.add('%s %s' % (tag, k), k, gl[k], v, el.get(k))
+            if not (within(gl[k], v) or (k in el and within(gl[k], el[k]))):
+                bad.append((tag, k, gl[k], v, el.get(k)))
+    bars.check(max_emul_only=0.20, require=False)
     assert not bad, bad
