@@ -32,6 +32,27 @@ def get_params(opt, size):
     return {'crop_pos': (x, y), 'flip': flip}
 
 
+PREPROCESS_MODES = ('resize_and_crop', 'crop', 'scale_width', 'scale_width_and_crop', 'resize', 'none', 'none_exact')
+
+
+def resize_target(opt, h, w):
+    """The (height, width) the resizing stage of get_transform (data/base_dataset.py:81-131) gives an h x w image, or None when it
+    leaves the image alone: 'resize*' -> load_size x load_size (:85-87); 'scale_width*' -> width load_size, height
+    int(max(load_size * h / w, crop_size)) unless the width already fits and the height covers the crop (__scale_width, :123-129);
+    'none' -> both sides rounded to a multiple of 4 with Python's round (__make_power_2, :112-120); 'crop' -> nothing."""
+    pre = getattr(opt, 'preprocess', 'resize_and_crop')
+    if 'resize' in pre:
+        return (opt.load_size, opt.load_size) if (h, w) != (opt.load_size, opt.load_size) else None
+    if 'scale_width' in pre:
+        if w == opt.load_size and h >= opt.crop_size:
+            return None
+        return int(max(opt.load_size * h / w, opt.crop_size)), opt.load_size
+    if pre == 'none':
+        nh, nw = int(round(h / 4) * 4), int(round(w / 4) * 4)
+        return None if (nh, nw) == (h, w) else (nh, nw)
+    return None
+
+
 def _bicubic(x):
     a = -0.5
     if x < 0.0:
@@ -100,8 +121,13 @@ class AlignedGpuPipeline:
         self.opt = opt
         self.device = device or torch.device('cuda', torch.cuda.current_device())
         self._tables = {}
-        if getattr(opt, 'preprocess', 'resize_and_crop') not in ('resize_and_crop', 'crop', 'none_exact'):
-            raise NotImplementedError('preprocess %s: the MI355X pipeline covers resize_and_crop and crop' % opt.preprocess)
+        if getattr(opt, 'preprocess', 'resize_and_crop') not in PREPROCESS_MODES:
+            raise ValueError('unknown --preprocess %s (data/base_dataset.py:81-112 knows %s)' % (opt.preprocess, ', '.join(PREPROCESS_MODES[:6])))
+
+    def pre_resize(self, img):
+        """the resizing stage of get_transform for every --preprocess mode (resize_target), BICUBIC"""
+        t = resize_target(self.opt, img.shape[0], img.shape[1])
+        return img if t is None else self.resize(img, t[0], t[1])
 
     def _dev_tables(self, n_in, n_out, filter='bicubic'):
         key = (n_in, n_out, filter)
@@ -150,8 +176,7 @@ class AlignedGpuPipeline:
             params = get_params(opt, (w2, h))
         out = {}
         for name, img in zip(('A', 'B'), halves):
-            if 'resize' in opt.preprocess:
-                img = self.resize(img, opt.load_size, opt.load_size)
+            img = self.pre_resize(img)
             flip = (not opt.no_flip) and params['flip']
             if 'crop' in opt.preprocess:
                 out[name] = self.finish(img, params['crop_pos'], opt.crop_size, flip)
@@ -181,8 +206,7 @@ class UnalignedGpuPipeline(AlignedGpuPipeline):
         img = img.to(self.device, non_blocking=True).contiguous()
         if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
             raise GccError('expected a decoded RGB image, uint8 [h, w, 3]')
-        if 'resize' in opt.preprocess:
-            img = self.resize(img, opt.load_size, opt.load_size)
+        img = self.pre_resize(img)
         x = y = 0
         crop = opt.crop_size
         h, w = img.shape[0], img.shape[1]

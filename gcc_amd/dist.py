@@ -63,6 +63,30 @@ def broadcast_module(module, src=0):
         dist.broadcast(t.data, src)
 
 
+def experimental():
+    """GCC_DP_EXPERIMENTAL=1: the ONE switch in front of the data-parallel variants that have never met a second device (VERDICT r5
+    item 8) -- a communicator of its own for the teacher's chain (GCC_DP_CHAIN_GROUPS=1), bf16 bucket transport (GCC_DP_BF16=1),
+    launch replay of an iteration that holds collectives (gcc_amd.replay on the native route).  Without it those requests are
+    ignored, with a warning on rank 0: the supported surface is the torch.distributed route (default) and the C ABI's own
+    communicator behind its votes (GCC_DP_COMM=native)."""
+    return os.environ.get('GCC_DP_EXPERIMENTAL', '0') == '1'
+
+
+_warned = set()
+
+
+def _experimental_request(env_name):
+    """True when the variant `env_name`=1 is asked for AND the experimental switch is on"""
+    if os.environ.get(env_name, '0') != '1':
+        return False
+    if experimental():
+        return True
+    if env_name not in _warned:
+        _warned.add(env_name)
+        _warn('%s=1 ignored: an experimental data-parallel variant (never run on two devices) -- set GCC_DP_EXPERIMENTAL=1 as well' % env_name)
+    return False
+
+
 _chain_groups = {}
 
 
@@ -75,10 +99,10 @@ def chain_group(tag):
     (profiles/r5_dp_one_rank.txt: 8.09 -> 9.44 ms on the phase timeline; gone with two communicators).  Created by
     dist.new_group on first use: a collective, reached by every rank at the same point (the first optimize_parameters).
     Returns the tag itself on the native route (native_comm(tag)).
-    OFF by default (GCC_DP_CHAIN_GROUPS=1 turns it on): on the one-rank rig the second communicator's stream is a SIXTH stream on
+    EXPERIMENTAL, off by default (GCC_DP_EXPERIMENTAL=1 GCC_DP_CHAIN_GROUPS=1 turns it on): on the one-rank rig the second communicator's stream is a SIXTH stream on
     four hardware queues and lands on the main stream's queue, where its pending wait for the teacher's backward holds the
     student's kernels back by 5.6 ms (17.0 -> 19.0 ms per step) -- a trade that only a box with real peers can settle."""
-    if not is_dist() or os.environ.get('GCC_DP_CHAIN_GROUPS', '0') != '1':
+    if not is_dist() or not _experimental_request('GCC_DP_CHAIN_GROUPS'):
         return None
     if comm_route() == 'native':
         native_comm(tag)
@@ -227,10 +251,10 @@ def _warn(msg):
 
 
 def bf16_buckets():
-    """GCC_DP_BF16=1: gradient buckets travel as bf16 (cast, summed, cast back: half the bytes over xGMI).
+    """EXPERIMENTAL (GCC_DP_EXPERIMENTAL=1 GCC_DP_BF16=1): gradient buckets travel as bf16 (cast, summed, cast back: half the bytes over xGMI).
     Every rank receives the same sums, so replicas stay bit-identical; the sums themselves carry 8 significant bits per term.
     Off by default: the reference has no gradient exchange to compare a precision with."""
-    return os.environ.get('GCC_DP_BF16', '0') == '1'
+    return _experimental_request('GCC_DP_BF16')
 
 
 _native = None

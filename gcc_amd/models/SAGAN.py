@@ -585,7 +585,17 @@ class SAGANModel(TeacherStreamMixin, nn.Module):
                 cfg[name.split('.')[0]] = int((m.weight.detach().float().cpu() > threshold).sum())
         return SAGANModel(self.opt, filter_cfgs=list(cfg.values()))
 
+    def max_min_conv_norm(self):
+        """models/SAGAN.py:719-721: an empty method in the reference (`pass`): kept for the surface, returns None as there"""
+        return None
+
+    def norm_prune(self, threshold, lottery_path=None):
+        """models/SAGAN.py:752-754: an empty method in the reference (`pass`): `--norm_prune` on SAGAN yields None there too"""
+        return None
+
     def prune(self, threshold, lottery_path=None):
         if self.opt.scale_prune:
             return self.scale_prune(threshold)
+        if getattr(self.opt, 'norm_prune', False):
+            return self.norm_prune(threshold, lottery_path)           # :699-700
         raise NotImplementedError('only scale and norm pruning are supported!!!')

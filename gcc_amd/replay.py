@@ -108,8 +108,10 @@ class IterationReplay:
             # data parallelism: the iteration holds gradient all-reduces.  Through the C ABI's communicator (dist.comm_route()
             # 'native') they are launch-like calls of the library and part of the recording (replayed from one host thread, in the
             # recorded order on every rank); through torch.distributed they are not: eager
+            # -- an EXPERIMENTAL composition (dist.experimental(), GCC_DP_EXPERIMENTAL=1): no recording with collectives has ever
+            # been replayed against a real peer
             from . import dist as gdist
-            return gdist.comm_route() == 'native'
+            return gdist.experimental() and gdist.comm_route() == 'native'
         return True
 
     # ------------------------------------------------------------------------------------------------

@@ -114,6 +114,12 @@ def _worker(rank, world, port, q):
     ok_buckets = ok_buckets and still and torch.equal(flatp.grads, want)
     assert gdist.chain_group('teacher') is None
     os.environ['GCC_DP_CHAIN_GROUPS'] = '1'
+    os.environ['GCC_DP_BF16'] = '1'
+    # experimental variants are ignored (with a warning) unless the ONE experimental switch is on as well
+    assert gdist.chain_group('teacher') is None and not gdist.bf16_buckets() and not gdist.experimental()
+    os.environ['GCC_DP_EXPERIMENTAL'] = '1'
+    assert gdist.bf16_buckets()
+    os.environ['GCC_DP_BF16'] = '0'
     grp = gdist.chain_group('teacher')
     ok_buckets = ok_buckets and grp is not None and gdist.chain_group('teacher') is grp
     red.set_group(grp)

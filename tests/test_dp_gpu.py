@@ -248,7 +248,8 @@ def test_rccl_single_rank_with_teacher_stream(route):
 def _rccl_replay_worker(port, q, bf16):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
-                      HSA_ENABLE_IPC_MODE_LEGACY='0', GCC_DP_FORCE_BUCKETS='1', GCC_DP_COMM='native', GCC_DP_BF16='1' if bf16 else '0')
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', GCC_DP_FORCE_BUCKETS='1', GCC_DP_COMM='native', GCC_DP_BF16='1' if bf16 else '0',
+                      GCC_DP_EXPERIMENTAL='1')          # replay with collectives and bf16 buckets: experimental variants (dist.experimental)
     import torch.distributed as dist
     from gcc_amd.replay import IterationReplay
     from tests.test_pix2pix_gpu import GCC_ARGV, build_model
