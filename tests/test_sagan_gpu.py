@@ -413,7 +413,7 @@ def test_sagan_full_width_iteration_vs_oracle():
     64, z 128): one iteration + arch step of the HIP path against the oracle on the same recipe weights.  The generated
     images against the fp32 oracle (before any update acts); the loss scalars against the bf16-emulating oracle, the
     trajectory the HIP path must stay on behind the sign-like Adam steps (beta1 = 0), AND against the fp32 oracle (3e-2 before the
-    first Adam step has acted, the measured drift bar 0.25 behind it); the report says which scalars only the emulation explains."""
+    first Adam step has acted, 6e-2 behind it); the report says which scalars only the emulation explains."""
     from collections import OrderedDict
     from gcc_amd.options import options
     from gcc_amd.models import get_model_class
@@ -492,9 +492,10 @@ def test_sagan_full_width_iteration_vs_oracle():
             if not abs(gl[k] - v) <= 3e-2 * max(1.0, abs(v)):
                 bad.append((tag, k, gl[k], v))
             # ... and against the fp32 oracle (this test judged against the emulating mode alone): 3e-2 for
-            # the terms no Adam step has acted on yet, the golden-trajectory test's measured drift bar (0.25) behind one
+            # the terms no Adam step has acted on yet, 6e-2 behind one (batch 64 averages the hinge flips that the 4-image fixture
+            # shows as 10-20 %: measured worst 0.4 % of |ref|, profiles/r6a_test_report.txt)
             pre_step = k in ('D_real', 'D_fake', 'content', 'gram', 'L1')
-            if not abs(gl[k] - rl[k]) <= (3e-2 if pre_step else 0.25) * max(1.0, abs(rl[k])):
+            if not abs(gl[k] - rl[k]) <= (3e-2 if pre_step else 6e-2) * max(1.0, abs(rl[k])):
                 bad.append((tag, k, gl[k], 'fp32 oracle', rl[k]))
     bars.check(max_emul_only=0.35, require=False)
     assert not bad, bad
