@@ -8,7 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GCC_HIP_LIB') or os.path.join(_HERE, 'libgcc_hip.so')     # GCC_HIP_LIB: another build of the same ABI (A/B runs)
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
-GCC_HIP_ABI = 600     # include/gcc_hip.h GCC_HIP_ABI: the generation of struct layouts / option ids these bindings were written for
+GCC_HIP_ABI = 601
+WGRAD_GROUP_MAX = 32     # include/gcc_hip.h GCC_WGRAD_GROUP_MAX     # include/gcc_hip.h GCC_HIP_ABI: the generation of struct layouts / option ids these bindings were written for
 
 
 class GccError(RuntimeError):
@@ -26,6 +27,11 @@ PLAN_FIELDS = tuple(n for n, _ in conv_plan_t._fields_)
 class conv_t(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('N', 'H', 'W', 'Ci', 'Co', 'KH', 'KW', 'stride', 'pad',
                                        'ldx', 'xoff', 'ldy', 'yoff')] + [('plan', conv_plan_t)]
+
+
+class wgrad_item_t(C.Structure):
+    """include/gcc_hip.h gcc_wgrad_item_t: one entry of a grouped weight gradient"""
+    _fields_ = [('c', conv_t), ('x', C.c_void_p), ('dy', C.c_void_p), ('dw', C.c_void_p), ('accumulate', C.c_int)]
 
 
 class epilogue_t(C.Structure):
@@ -108,6 +114,10 @@ PROTOTYPES = {
     'gcc_conv_wgrad_workspace': (_Z, [C.POINTER(conv_t)]),
     'gcc_conv_wgrad': (_I, [C.POINTER(conv_t), _P, _P, _P, _I, _P, _Z, _P]),
     'gcc_conv_wgrad_seg': (_I, [C.POINTER(conv_t), _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    'gcc_conv_wgrad_group_table_bytes': (_Z, []),
+    'gcc_conv_wgrad_group_workspace': (_Z, [C.POINTER(wgrad_item_t), _I]),
+    'gcc_conv_wgrad_group_prepare': (_I, [C.POINTER(wgrad_item_t), _I, _P, _Z, _P]),
+    'gcc_conv_wgrad_group_run': (_I, [_P, _P, _P]),
     'gcc_pack_weights': (_I, [_P, _I, _I, _I, _P, _P, _P]),
     'gcc_pack_weights_multi': (_I, [_P, _P, _I, _P]),
     'gcc_nchw_f32_to_nhwc_bf16': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

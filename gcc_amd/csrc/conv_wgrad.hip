@@ -11,6 +11,7 @@
 // Split-K over pixels: every split writes an fp32 slab, gcc_wgrad_reduce folds the slabs into the
 // fp32 master-layout gradient (deterministic; no float atomics).
 #include <mutex>
+#include <string.h>
 #include "common.hpp"
 
 namespace {
@@ -83,11 +84,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int ks, int colbase,
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// One workgroup's share of a weight gradient: output tile `tile` (column tile fastest), pixel split `split`, problem `bidx` of a
+// batched call.  wgrad_kernel hands it its own block indices; wgrad_group_kernel (below) the ones of a table entry.
 template <bool BIG, bool TABLE>
-__global__ __launch_bounds__(WCfg<BIG>::NT) void wgrad_kernel(const WgradParams p) {
+__device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile, const int split, const int bidx, char* smem) {
     using C = WCfg<BIG>;
     constexpr int RS = C::RS, TILE_BYTES = C::TILE_BYTES, FI = C::FI, FJ = C::FJ;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sX = smem;                       // [2][64][RS]
     char* sY = smem + 2 * TILE_BYTES;      // [2][64][RS]
 
@@ -95,17 +97,14 @@ __global__ __launch_bounds__(WCfg<BIG>::NT) void wgrad_kernel(const WgradParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave & 1, wb = wave >> 1;               // 2 column groups x (2 or 4) output-channel groups
 
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int ct = tile % p.col_tiles;     // column tile fastest: neighbours share the dY panel
     const int ot = tile / p.col_tiles;
     const int col0 = ct * C::TCOL, co0 = ot * C::TCO;
-    const int split = blockIdx.z;
     const int k_begin = split * p.ksteps_per_split;
     int k_end = k_begin + p.ksteps_per_split;
     const int ksteps_total = (p.M + TP - 1) / TP;
     if (k_end > ksteps_total) k_end = ksteps_total;
 
-    const int bidx = blockIdx.y;
     const i32x4 rs_x = make_rsrc(p.x + (size_t)bidx * p.x_bstride, p.x_bytes);
     const i32x4 rs_y = make_rsrc(p.dy + (size_t)bidx * p.dy_bstride, p.dy_bytes);
     const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
@@ -278,6 +277,68 @@ __global__ __launch_bounds__(WCfg<BIG>::NT) void wgrad_kernel(const WgradParams 
             }
         }
     }
+}
+
+template <bool BIG, bool TABLE>
+__global__ __launch_bounds__(WCfg<BIG>::NT) void wgrad_kernel(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wgrad_body<BIG, TABLE>(p, xcd_remap(blockIdx.x, gridDim.x), blockIdx.z, blockIdx.y, smem);
+}
+
+// ---- grouped weight gradients (round 6) -------------------------------------------------------------------------------------------
+// The backward pass of a generator is a chain of small layers: 14 regular weight gradients per U-Net pass (the headline step runs
+// the student's and the teacher's), each a launch of 4-128 tiles x a few pixel splits plus a fold launch -- 58 + ~45 launches per
+// iteration at 13 % matrix-pipe utilisation, none of which fills the chip.  A GROUP runs them as ONE launch
+// over a table: workgroup b finds its entry by the table's prefix sums (<= GCC_WGRAD_GROUP_MAX entries, a uniform scan), takes the
+// entry's WgradParams and runs wgrad_body on its (tile, split).  Pixel splits are chosen for the group as a whole (equal k-steps per
+// workgroup over all entries, longest workgroups first), split entries write fp32 slabs, and ONE fold launch (wgrad_group_reduce_kernel)
+// adds each entry's slabs in slab order into its master-layout gradient: no float atomics, same bits run after run.
+constexpr int GROUP_MAX = GCC_WGRAD_GROUP_MAX;
+struct GroupReduce { const float* slabs; float* dw; unsigned n4; int splits; int accumulate; int blk0; };
+struct WgradGroupTable {
+    int magic, n_items, total_wgs, n_reduce, reduce_blocks, pad_[3];
+    int wg_prefix[GROUP_MAX + 1];
+    int tiles[GROUP_MAX];
+    GroupReduce red[GROUP_MAX];
+    WgradParams items[GROUP_MAX];
+};
+constexpr int GROUP_MAGIC = 0x47525036;
+
+__global__ __launch_bounds__(WCfg<false>::NT) void wgrad_group_kernel(const WgradGroupTable* __restrict__ t) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x, n = t->n_items;
+    int it = 0;
+    for (int i = 1; i < n; i++) it = b >= t->wg_prefix[i] ? i : it;        // uniform: every operand is a scalar load
+    it = __builtin_amdgcn_readfirstlane(it);
+    const int li = b - t->wg_prefix[it], tiles = t->tiles[it];
+    const int split = li / tiles, tile = li - split * tiles;
+    const WgradParams p = t->items[it];
+    wgrad_body<false, true>(p, tile, split, 0, smem);
+}
+
+__global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(const WgradGroupTable* __restrict__ t) {
+    const int b = blockIdx.x, n = t->n_reduce;
+    int it = 0;
+    for (int i = 1; i < n; i++) it = b >= t->red[i].blk0 ? i : it;
+    it = __builtin_amdgcn_readfirstlane(it);
+    const GroupReduce r = t->red[it];
+    const size_t i = (size_t)(b - r.blk0) * 256 + threadIdx.x;
+    if (i >= r.n4) return;
+    const f32x4* src = (const f32x4*)r.slabs + i;
+    // the launch's own sum first (slabs in order, eight loads in flight), then ONE add to what the buffer holds (as wgrad_reduce_flat_kernel)
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 8 <= r.splits; z += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[(size_t)(z + u) * r.n4];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { s[0] += v[u][0]; s[1] += v[u][1]; s[2] += v[u][2]; s[3] += v[u][3]; }
+    }
+    for (; z < r.splits; z++) { const f32x4 v = src[(size_t)z * r.n4]; s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3]; }
+    f32x4* d = (f32x4*)r.dw + i;
+    if (r.accumulate) { const f32x4 o = *d; s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3]; }
+    *d = s;
 }
 
 // regular widths (Ci % 8 == 0: slab layout == dW layout): 16-byte fold.  256 threads = 64 outputs
@@ -837,4 +898,152 @@ extern "C" int gcc_conv_wgrad_seg(const gcc_conv_t* c, const void* x, const void
     if (c->Co != seg_phys_size(rows, row_split) || c->Ci != seg_phys_size(cols, col_split)) return GCC_ERR_BAD_ARG;
     return gcc_internal_wgrad(c, x, dy, dw, accumulate, ws, ws_bytes, 1, 0, 0, (hipStream_t)stream, rows, cols, row_split,
                               col_split);
+}
+
+// ---- grouped weight gradients: host side ------------------------------------------------------------------------------------------
+namespace {
+struct GroupPlan {
+    int n, total_wgs;
+    int per[GROUP_MAX], splits[GROUP_MAX], tiles[GROUP_MAX], order[GROUP_MAX];
+    size_t slab_off[GROUP_MAX], ws_bytes;
+};
+int group_cus() {
+    static const int v = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            n = 256;
+        }
+        return n;
+    }();
+    return v;
+}
+bool group_item_ok(const gcc_wgrad_item_t* it) {
+    const gcc_conv_t* c = &it->c;
+    if (c->N <= 0 || c->H <= 0 || c->W <= 0 || c->Ci <= 0 || c->Co <= 0 || c->KH <= 0 || c->KW <= 0 || c->stride <= 0 || c->pad < 0) return false;
+    if ((c->Ci & 7) || (c->ldx & 7) || (c->xoff & 7) || (c->ldy & 7) || (c->yoff & 7)) return false;      // regular widths only
+    if (c->KH > 15 || c->KW > 15) return false;                       // the pixel table's tap masks
+    const int Ho = gcc_conv_out(c->H, c->KH, c->stride, c->pad), Wo = gcc_conv_out(c->W, c->KW, c->stride, c->pad);
+    if (Ho <= 0 || Wo <= 0) return false;
+    const size_t M = (size_t)c->N * Ho * Wo;
+    if ((size_t)c->N * c->H * c->W * c->ldx * 2 >= OOB || M * c->ldy * 2 >= OOB || M >= (1u << 30)) return false;
+    if (head_wgrad_workspace(c) || gcc_internal_thinout_wgrad_workspace(c)) return false;      // routes of their own
+    return true;
+}
+// Pixel splits for the group as a whole: every workgroup gets about S k-steps, S such that the group is ~2 rounds of the chip's
+// two-per-CU slots (16 <= S <= 64: below, a workgroup is all prologue; above, the tail of the launch is one long workgroup)
+int group_plan(const gcc_wgrad_item_t* items, int n, GroupPlan* g) {
+    if (!items || n < 1 || n > GROUP_MAX) return GCC_ERR_BAD_ARG;
+    long work = 0;
+    int ksteps[GROUP_MAX];
+    for (int i = 0; i < n; i++) {
+        if (!group_item_ok(&items[i])) return GCC_ERR_UNSUPPORTED;
+        const gcc_conv_t* c = &items[i].c;
+        const long M = (long)c->N * gcc_conv_out(c->H, c->KH, c->stride, c->pad) * gcc_conv_out(c->W, c->KW, c->stride, c->pad);
+        ksteps[i] = (int)((M + TP - 1) / TP);
+        g->tiles[i] = cdiv(c->KH * c->KW * c->Ci, 128) * cdiv(c->Co, 128);
+        work += (long)g->tiles[i] * ksteps[i];
+    }
+    long S = cdiv(work, (long)4 * group_cus());
+    S = S < 16 ? 16 : (S > 64 ? 64 : S);
+    g->n = n; g->total_wgs = 0; g->ws_bytes = 0;
+    for (int i = 0; i < n; i++) {
+        int splits = cdiv(ksteps[i], (int)S);
+        const int per = cdiv(ksteps[i], splits);
+        splits = cdiv(ksteps[i], per);
+        g->per[i] = per; g->splits[i] = splits;
+        g->total_wgs += g->tiles[i] * splits;
+        g->slab_off[i] = g->ws_bytes;
+        if (splits > 1) {
+            const gcc_conv_t* c = &items[i].c;
+            g->ws_bytes += al256((size_t)splits * c->Co * c->KH * c->KW * c->Ci * sizeof(float));
+        }
+        g->order[i] = i;
+    }
+    // longest workgroups first (insertion sort, stable: ties keep the caller's order)
+    for (int a = 1; a < n; a++) {
+        const int v = g->order[a];
+        int b = a;
+        while (b > 0 && g->per[g->order[b - 1]] < g->per[v]) { g->order[b] = g->order[b - 1]; b--; }
+        g->order[b] = v;
+    }
+    if (g->ws_bytes == 0) g->ws_bytes = 256;          // (a group without a split entry still gets a non-null workspace)
+    return GCC_OK;
+}
+}  // namespace
+
+extern "C" size_t gcc_conv_wgrad_group_table_bytes(void) { return sizeof(WgradGroupTable); }
+
+extern "C" size_t gcc_conv_wgrad_group_workspace(const gcc_wgrad_item_t* items, int n) {
+    GroupPlan g;
+    return group_plan(items, n, &g) == GCC_OK ? g.ws_bytes : 0;
+}
+
+extern "C" int gcc_conv_wgrad_group_prepare(const gcc_wgrad_item_t* items, int n, void* ws, size_t ws_bytes, void* table_host) {
+    GroupPlan g;
+    const int rc = group_plan(items, n, &g);
+    if (rc) return rc;
+    if (!table_host || !ws || (((uintptr_t)ws) & 15)) return GCC_ERR_BAD_ARG;
+    if (ws_bytes < g.ws_bytes) return GCC_ERR_WORKSPACE;
+    WgradGroupTable* t = (WgradGroupTable*)table_host;
+    memset(t, 0, sizeof(*t));
+    t->magic = GROUP_MAGIC; t->n_items = n; t->total_wgs = g.total_wgs;
+    int wg = 0, nred = 0, rblk = 0;
+    for (int k = 0; k < n; k++) {
+        const int i = g.order[k];
+        const gcc_wgrad_item_t* it = &items[i];
+        if (!it->x || !it->dy || !it->dw || (((uintptr_t)it->dw) & 15)) return GCC_ERR_BAD_ARG;
+        const gcc_conv_t* c = &it->c;
+        const int Ho = gcc_conv_out(c->H, c->KH, c->stride, c->pad), Wo = gcc_conv_out(c->W, c->KW, c->stride, c->pad);
+        WgradParams& p = t->items[k];
+        p.x = (const bf16_t*)it->x; p.dy = (const bf16_t*)it->dy;
+        p.out = (float*)((char*)ws + g.slab_off[i]);
+        p.N = c->N; p.H = c->H; p.W = c->W; p.ldx = c->ldx; p.xoff = c->xoff; p.Ci = c->Ci; p.Cip = c->Ci;
+        p.Ho = Ho; p.Wo = Wo; p.ldy = c->ldy; p.yoff = c->yoff; p.Co = c->Co;
+        p.KH = c->KH; p.KW = c->KW; p.stride = c->stride; p.pad = c->pad;
+        p.ncols = c->KH * c->KW * c->Ci;
+        const size_t M = (size_t)c->N * Ho * Wo;
+        p.M = (int)M;
+        p.x_bytes = (uint32_t)((size_t)c->N * c->H * c->W * c->ldx * 2); p.dy_bytes = (uint32_t)(M * c->ldy * 2);
+        p.ksteps_per_split = g.per[i];
+        p.col_tiles = cdiv(p.ncols, 128); p.co_tiles = cdiv(c->Co, 128);
+        p.dHW = make_fastdiv(Ho * Wo); p.dW = make_fastdiv(Wo); p.dCip = make_fastdiv(p.Cip); p.dKW = make_fastdiv(c->KW);
+        p.batch = 1; p.x_bstride = 0; p.dy_bstride = 0;
+        p.direct = g.splits[i] == 1 ? 1 : 0;
+        p.accumulate = it->accumulate; p.dw = it->dw;
+        p.rowmode = 1; p.debug = 0;
+        t->wg_prefix[k] = wg;
+        t->tiles[k] = g.tiles[i];
+        wg += g.tiles[i] * g.splits[i];
+        if (g.splits[i] > 1) {
+            GroupReduce& r = t->red[nred++];
+            r.slabs = p.out; r.dw = it->dw; r.splits = g.splits[i]; r.accumulate = it->accumulate;
+            r.n4 = (unsigned)((size_t)c->Co * p.ncols / 4);
+            r.blk0 = rblk;
+            rblk += (int)((r.n4 + 255) / 256);
+        }
+    }
+    t->wg_prefix[n] = wg;
+    t->n_reduce = nred; t->reduce_blocks = rblk;
+    return GCC_OK;
+}
+
+extern "C" int gcc_conv_wgrad_group_run(const void* table_dev, const void* table_host, gcc_stream_t stream) {
+    GCC_ENTER();
+    const WgradGroupTable* t = (const WgradGroupTable*)table_host;
+    if (!table_dev || !t || t->magic != GROUP_MAGIC || t->n_items < 1 || t->n_items > GROUP_MAX || t->total_wgs < 1) return GCC_ERR_BAD_ARG;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute((const void*)wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WCfg<false>::LDS_BYTES);
+    });
+    if (attr_err != hipSuccess) return GCC_ERR_LAUNCH;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wgrad_group_kernel, dim3(t->total_wgs), dim3(WCfg<false>::NT), WCfg<false>::LDS_BYTES, st, (const WgradGroupTable*)table_dev);
+    GCC_CHECK_LAUNCH();
+    if (t->reduce_blocks > 0) {
+        hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(t->reduce_blocks), dim3(256), 0, st, (const WgradGroupTable*)table_dev);
+        GCC_CHECK_LAUNCH();
+    }
+    return GCC_OK;
 }

@@ -34,6 +34,10 @@ def overlap_wgrad_default(world):
     return world <= 1
 # U-Net layers as one C call (gcc_conv_bn_act): conv + BatchNorm statistics + finalize + normalise / activation
 FUSE_CONV_BN = os.environ.get('GCC_FUSE_CONV_BN', '1') != '0'
+# GCC_WGRAD_GROUP (default 1): the regular weight gradients of a generator's backward pass run as grouped launches (ops.WgradGroup:
+# one launch + one fold per group) instead of one launch + fold per layer -- the U-Net's up path when its last data gradient is
+# enqueued, its down path at the end of the pass.  0: per layer, as before round 6.
+WGRAD_GROUP = os.environ.get('GCC_WGRAD_GROUP', '1') != '0'
 
 
 # ------------------------------------------------------------------------------------------------
@@ -192,6 +196,14 @@ class ConvOp:
                 self._backward_weight(x, dy, bias_done)
         else:
             self._backward_weight(x, dy, bias_done)
+
+    def group_entry(self, x, dy):
+        """this layer's weight gradient as an entry of ops.WgradGroup, or None when it has to run on its own (a padded channel
+        concatenation, an irregular width, a bias whose gradient rides on the same call)"""
+        if self.row_split or self.col_split or self.bias is not None or (self.cols & 7) or self.weight.grad is None:
+            return None
+        cx, cdy = (x, dy) if not self.transposed else (dy, x)
+        return (cx, cdy, self.weight.grad, self.k, self.stride, self.pad, True)
 
     def _backward_weight(self, x, dy, bias_done=False):
         cx, cdy = (x, dy) if not self.transposed else (dy, x)      # (conv input, conv output-gradient) of the adjoint pair
@@ -529,17 +541,55 @@ class UnetEngine:
                 return self._backward(c, g_feat, wgrad)
         return self._backward(c, g_feat, wgrad)
 
+    def _run_wgrad_group(self, c, which, entries, segs):
+        """the collected weight gradients of one half of the pass (ops.WgradGroup) on the weight-gradient side stream; the
+        segments they complete are reported behind them"""
+        if not entries:
+            return
+        groups = c.__dict__.setdefault('wgrad_groups', {})
+        g = groups.get(which)
+        if g is None:
+            g = groups[which] = ops.WgradGroup()
+
+        def launch():
+            if g.groupable(entries):
+                g.run()
+            else:
+                for (x, dy, dw, k, stride, pad, acc) in entries:
+                    ops.conv_wgrad(x, dy, dw, k, stride, pad, accumulate=acc)
+        if OVERLAP_WGRAD:
+            side = ops.SideStream.get(self.device)
+            side.fork()
+            with ops.on_stream(side.stream):
+                launch()
+        else:
+            launch()
+        for seg in segs:
+            self._seg_done(seg)
+
     def _backward(self, c, g_feat=None, wgrad=True):
         if self.ablate_skip:
             return
         D, wd, uw, N = self.D, self.width, self.uwidth, c.N
         if g_feat is None:
             g_feat = [None] * 4
+        # weight gradients: the regular layers are collected and run as two grouped launches (WGRAD_GROUP; bench.py's bracketed
+        # roofline step times every launch on its own: per layer there)
+        grouped = wgrad and WGRAD_GROUP and not ops.PROFILE.active
+        entries, segs = [], []
+
+        def weight_gradient(conv, x, dy, seg):
+            e = conv.group_entry(x, dy) if grouped else None
+            if e is not None:
+                entries.append(e)
+                segs.append(seg)
+                return
+            conv.backward_weight(x, dy)
+            self._seg_done(seg)
         # outermost: tanh' then the transposed conv
         ops.bnact_bwd(c.out, None, c.g_out, c.g_out, in_act=ACT_TANH)
         if wgrad:
-            self.up[0].backward_weight(c.rcat[1], c.g_out)
-            self._seg_done(0)
+            weight_gradient(self.up[0], c.rcat[1], c.g_out, 0)
         self.up[0].backward_data(c.g_out, c.g_rcat[1])
         for d in range(1, D):
             if d == 2 and g_feat[3] is not None:
@@ -556,9 +606,11 @@ class UnetEngine:
                           dbeta=bn.bias.grad if wgrad else None)
             src = c.e_act if d == D - 1 else c.rcat[d + 1]
             if wgrad:
-                self.up[d].backward_weight(src, c.g_t[d])
-                self._seg_done(d)
+                weight_gradient(self.up[d], src, c.g_t[d], d)
             self.up[d].backward_data(c.g_t[d], c.g_e_last if d == D - 1 else c.g_rcat[d + 1])
+        # the up path's gradients are all there: its group runs beside the down path's chain
+        self._run_wgrad_group(c, 'up', entries, segs)
+        entries, segs = [], []
         if not self.inner_identity:
             # innermost down conv (+ fused ReLU)
             ops.bnact_bwd(c.e[D - 1], None, c.g_e_last, c.g_e_last, in_act=ACT_RELU)
@@ -574,8 +626,7 @@ class UnetEngine:
                           dbeta=bn.bias.grad if wgrad else None)
         g_in = c.g_e_in if self.inner_identity else c.g_e_last
         if wgrad:
-            self.down[D - 1].backward_weight(c.lin[D - 1], g_in)
-            self._seg_done(D)
+            weight_gradient(self.down[D - 1], c.lin[D - 1], g_in, D)
         self.down[D - 1].backward_data(g_in, c.g_lin[D - 1])
         for d in range(D - 2, -1, -1):
             # e[d] feeds lin[d+1] (LeakyReLU) and rcat[d+1][:w] (ReLU)
@@ -593,10 +644,10 @@ class UnetEngine:
                 # (x is not read for its values here: the activation derivatives come from the saved output lin[1])
                 ops.bnact_bwd(c.lin[1], c.lin[1], c.g_lin[1], c.g_e[0], g2=g2, act=ACT_LRELU, act2=ACT_RELU)
             if wgrad:
-                self.down[d].backward_weight(c.lin[d] if d > 0 else c.x_in, c.g_e[d])
-                self._seg_done(2 * D - 1 - d)
+                weight_gradient(self.down[d], c.lin[d] if d > 0 else c.x_in, c.g_e[d], 2 * D - 1 - d)
             if d > 0:
                 self.down[d].backward_data(c.g_e[d], c.g_lin[d])
+        self._run_wgrad_group(c, 'down', entries, segs)
         ops.SideStream.get(self.device).join()
 
 

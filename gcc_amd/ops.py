@@ -686,6 +686,56 @@ def conv_wgrad(x, dy, dw, k, stride, pad, accumulate=False):
     return dw
 
 
+class WgradGroup:
+    """gcc_conv_wgrad_group_*: the weight gradients of several layers as ONE launch + one fold launch (include/gcc_hip.h).
+    entries: [(x, dy, dw, k, stride, pad, accumulate)] with the operands of conv_wgrad.  The table is prepared on first use from the
+    tensors' addresses and geometries and re-prepared whenever one of them changes (persistent activation / gradient buffers: never
+    in steady state); the slab workspace and the device copy of the table belong to the object.  groupable(): False when the
+    library refuses the set (an irregular width, a head / thin-output geometry) -- the caller then runs conv_wgrad per layer."""
+
+    def __init__(self):
+        self.key = None
+        self.ok = False
+
+    def _prepare(self, entries, key):
+        n = len(entries)
+        items = (_lib.wgrad_item_t * n)()
+        flops = 0.0
+        dev = entries[0][0].device
+        for it, (x, dy, dw, k, stride, pad, acc) in zip(items, entries):
+            xp, N, Ci, H, W, ldx = geom(x)
+            yp, _, Co, Ho, Wo, ldy = geom(dy)
+            assert tuple(dw.shape) == (Co, Ci, k, k) and dw.dtype == torch.float32
+            assert k == 1 or dw.is_contiguous(memory_format=torch.channels_last)
+            it.c = conv_desc(N, H, W, Ci, Co, k, stride, pad, ldx, ldy)
+            it.x, it.dy, it.dw, it.accumulate = xp, yp, dw.data_ptr(), int(acc)
+            flops += 2.0 * N * Ho * Wo * Co * k * k * Ci
+        self.key, self.flops, self.n = key, flops, n
+        need = lib().gcc_conv_wgrad_group_workspace(items, n) if n <= _lib.WGRAD_GROUP_MAX else 0
+        self.ok = need > 0
+        if not self.ok:
+            return
+        self.ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+        tb = int(lib().gcc_conv_wgrad_group_table_bytes())
+        self.table_host = torch.zeros(tb, dtype=torch.uint8)
+        check(lib().gcc_conv_wgrad_group_prepare(items, n, self.ws.data_ptr(), self.ws.numel(), self.table_host.data_ptr()),
+              'gcc_conv_wgrad_group_prepare')
+        self.table_dev = self.table_host.to(dev)          # (a synchronous copy, once per table)
+
+    def groupable(self, entries):
+        key = tuple((x.data_ptr(), dy.data_ptr(), dw.data_ptr(), tuple(x.shape), tuple(dy.shape), x.stride(), dy.stride(), k, s_, p_, bool(a))
+                    for (x, dy, dw, k, s_, p_, a) in entries) + (tuple(sorted(current_plan().items())),)
+        if key != self.key:
+            self._prepare(entries, key)
+        return self.ok
+
+    def run(self):
+        e0 = PROFILE.begin() if PROFILE.active else None
+        check(lib().gcc_conv_wgrad_group_run(self.table_dev.data_ptr(), self.table_host.data_ptr(), stream()), 'gcc_conv_wgrad_group_run')
+        if e0 is not None:
+            PROFILE.end('wgrad_group_kernel (+ fold)', self.flops, e0, shape=('wgrad_group', self.n))
+
+
 def seg_phys(n, split):
     """physical channel count of an n-channel dimension made of two 8-padded parts (split = first part)"""
     return ceil8(split) + ceil8(n - split) if 0 < split < n else ceil8(n)

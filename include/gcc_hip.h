@@ -44,7 +44,7 @@ enum { GCC_ACT_NONE = 0, GCC_ACT_LRELU = 1, GCC_ACT_RELU = 2, GCC_ACT_TANH = 3 }
 /* ABI generation of this header: bumped whenever a struct layout, an enum numbering or a prototype below changes.  gcc_version()
  * of the library a host loads must return exactly this number (gcc_amd/_lib.py refuses any other; an external host should check it
  * the same way): a stale .so reads gcc_conv_t.plan past its struct and sets the wrong option ids without any error. */
-#define GCC_HIP_ABI 600
+#define GCC_HIP_ABI 601
 
 const char* gcc_strerror(int code);
 int gcc_version(void); /* == GCC_HIP_ABI of the header the library was built from */
@@ -232,6 +232,31 @@ int gcc_conv_dgrad(const gcc_conv_t* c, const void* dy, const void* wt, void* dx
 size_t gcc_conv_wgrad_workspace(const gcc_conv_t* c);
 int gcc_conv_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float* dw, int accumulate,
                    void* ws, size_t ws_bytes, gcc_stream_t stream);
+
+/* A GROUP of weight gradients as one launch (+ one fold launch): the backward pass of a generator yields a dozen small layers whose
+ * weight gradients each fill a fraction of the chip (models/Pix2Pix.py:20-130: 14 regular ones per U-Net pass; aten runs one
+ * convolution_backward per layer at :576 loss_G.backward()).  Entry i is what gcc_conv_wgrad(&c, x, dy, dw, accumulate, ..) would
+ * compute; the pixel splits are planned for the group as a whole.  Only regular entries (Ci % 8 == 0, dw 16-byte aligned, no head /
+ * thin-output geometry): gcc_conv_wgrad_group_workspace returns 0 for a group that holds any other, and the caller keeps such layers
+ * on gcc_conv_wgrad.  Protocol (the library allocates nothing and copies nothing to the device):
+ *   bytes = gcc_conv_wgrad_group_workspace(items, n)                      -- DEVICE workspace for the slabs (persistent: its address
+ *                                                                            is part of the table)
+ *   gcc_conv_wgrad_group_prepare(items, n, ws, bytes, table_host)         -- fills gcc_conv_wgrad_group_table_bytes() bytes of HOST
+ *                                                                            memory; the caller copies them to device memory ONCE
+ *   gcc_conv_wgrad_group_run(table_dev, table_host, stream)               -- every iteration: two launches
+ * A table stays valid while the pointers and geometries it was prepared from do.  Fixed summation order: same bits run after run. */
+#define GCC_WGRAD_GROUP_MAX 32
+typedef struct {
+    gcc_conv_t c;
+    const void* x;
+    const void* dy;
+    float* dw;
+    int accumulate;
+} gcc_wgrad_item_t;
+size_t gcc_conv_wgrad_group_table_bytes(void);
+size_t gcc_conv_wgrad_group_workspace(const gcc_wgrad_item_t* items, int n);
+int gcc_conv_wgrad_group_prepare(const gcc_wgrad_item_t* items, int n, void* ws, size_t ws_bytes, void* table_host);
+int gcc_conv_wgrad_group_run(const void* table_dev, const void* table_host, gcc_stream_t stream);
 
 /* weight gradient when channel dimensions are concatenations (see gcc_pack_desc_t): `c` describes the
  * PHYSICAL problem (c->Co = padded rows, c->Ci = padded cols); dw is the logical master-layout gradient

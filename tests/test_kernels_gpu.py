@@ -1436,6 +1436,55 @@ def test_pruned_3x3_layers_with_nine_or_ten_output_channels(case):
     close(to_cpu(y), y_ref, what='fprop, Co = %d' % Co)
 
 
+def test_grouped_weight_gradients_vs_per_layer_and_torch():
+    """gcc_conv_wgrad_group_* (round 6): the weight gradients of a U-Net-like set of layers -- stride-2 4 x 4 convolutions between
+    8..256 channels from 64 x 64 down to 1 x 1, a ConvTranspose's adjoint pair, a 1 x 1 and a 3 x 3 layer, ragged pixel counts -- as
+    ONE launch + one fold, against torch's conv2d_weight on the same bf16-rounded operands and against gcc_conv_wgrad layer by layer
+    (same tolerance: the two differ in their pixel-split plans, i.e. in fp32 summation order); fresh and accumulating; the launch
+    count shows the grouping (2 launches for 9 layers); same bits run after run; a group that holds an irregular width is refused."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    # (N, Ci, H, W, Co, k, stride, pad)
+    layers = [(3, 8, 64, 64, 16, 4, 2, 1), (3, 16, 32, 32, 32, 4, 2, 1), (3, 32, 16, 16, 64, 4, 2, 1), (3, 64, 8, 8, 256, 4, 2, 1),
+              (3, 256, 4, 4, 256, 4, 2, 1), (3, 256, 2, 2, 128, 4, 2, 1), (2, 24, 33, 47, 40, 3, 1, 1), (3, 48, 20, 20, 16, 1, 1, 0),
+              (3, 128, 2, 2, 128, 4, 2, 1)]
+    entries, refs = [], []
+    for (N, Ci, H, W, Co, k, st, pd) in layers:
+        Ho, Wo = (H + 2 * pd - k) // st + 1, (W + 2 * pd - k) // st + 1
+        x = rb(torch.randn(N, Ci, H, W, generator=g))
+        dy = rb(torch.randn(N, Co, Ho, Wo, generator=g))
+        refs.append(torch.nn.grad.conv2d_weight(x, (Co, Ci, k, k), dy, stride=st, padding=pd))
+        dw = torch.full((Co, Ci, k, k), 5.0, device=DEV).contiguous(memory_format=torch.channels_last)      # stale contents must go
+        entries.append((to_dev(x), to_dev(dy), dw, k, st, pd, False))
+    grp = ops.WgradGroup()
+    assert grp.groupable(entries)
+    ops.lib().gcc_launch_count(1)
+    grp.run()
+    assert int(ops.lib().gcc_launch_count(1)) == 2, 'one grouped launch + one fold'
+    for (x, dy, dw, k, st, pd, _), ref, lay in zip(entries, refs, layers):
+        close(dw.cpu(), ref, tol=5e-3, floor=1e-3 * float(ref.abs().max()), what='grouped wgrad %s' % (lay,))
+        single = torch.zeros_like(dw)
+        ops.conv_wgrad(x, dy, single, k, st, pd, accumulate=False)
+        close(dw.cpu(), single.cpu(), tol=5e-4, floor=1e-4 * float(ref.abs().max()), what='grouped vs per-layer %s' % (lay,))
+    first = [e[2].clone() for e in entries]
+    # accumulating into what the buffers hold (a second group object over the same buffers), twice the gradient
+    acc = [(x, dy, dw, k, st, pd, True) for (x, dy, dw, k, st, pd, _) in entries]
+    grp2 = ops.WgradGroup()
+    assert grp2.groupable(acc)
+    grp2.run()
+    for (x, dy, dw, k, st, pd, _), ref in zip(acc, refs):
+        close(dw.cpu(), 2 * ref, tol=5e-3, floor=2e-3 * float(ref.abs().max()), what='grouped wgrad, accumulated')
+    # same bits run after run
+    grp.run()
+    for e, f in zip(entries, first):
+        assert torch.equal(e[2], f)
+    # a 3-channel image layer is not groupable: the caller keeps it on gcc_conv_wgrad
+    x = to_dev(rb(torch.randn(2, 3, 32, 32, generator=g)))
+    dy = to_dev(rb(torch.randn(2, 16, 16, 16, generator=g)))
+    dw = torch.zeros((16, 3, 4, 4), device=DEV).contiguous(memory_format=torch.channels_last)
+    assert not ops.WgradGroup().groupable(entries[:2] + [(x, dy, dw, 4, 2, 1, False)])
+
+
 RING3_CASES = [
     # N, H, W, Ci, Co               3 x 3 stride-1 layers between <= 64-channel tensors: conv_ring3.hip
     (2, 96, 96, 64, 64),            # SRGAN teacher's trunk layer at two images: three strips of 32 columns, several row bands
