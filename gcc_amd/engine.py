@@ -15,7 +15,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH
 
 LRELU = 0.2
@@ -38,6 +38,7 @@ FUSE_CONV_BN = os.environ.get('GCC_FUSE_CONV_BN', '1') != '0'
 # one launch + one fold per group) instead of one launch + fold per layer -- the U-Net's up path when its last data gradient is
 # enqueued, its down path at the end of the pass.  0: per layer, as before round 6.
 WGRAD_GROUP = os.environ.get('GCC_WGRAD_GROUP', '1') != '0'
+WGRAD_GROUP_MAX_UNITS = int(os.environ.get('GCC_WGRAD_GROUP_MAX_UNITS', '20000'))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -152,6 +153,7 @@ class ConvOp:
         self.w = torch.zeros((self.rows_p, taps, self.cols_p), dtype=torch.bfloat16, device=dev)
         self.wt = torch.zeros((self.cols_p, taps, self.rows_p), dtype=torch.bfloat16, device=dev)
         self._pack = None
+        self._groupable = {}
 
     def repack(self):
         if self._pack is None:
@@ -199,11 +201,22 @@ class ConvOp:
 
     def group_entry(self, x, dy):
         """this layer's weight gradient as an entry of ops.WgradGroup, or None when it has to run on its own (a padded channel
-        concatenation, an irregular width, a bias whose gradient rides on the same call)"""
-        if self.row_split or self.col_split or self.bias is not None or (self.cols & 7) or self.weight.grad is None:
+        concatenation, an irregular width); a bias gradient stays a launch of its own (WgradCollector)"""
+        if self.row_split or self.col_split or (self.cols & 7) or self.weight.grad is None:
             return None
         cx, cdy = (x, dy) if not self.transposed else (dy, x)
-        return (cx, cdy, self.weight.grad, self.k, self.stride, self.pad, True)
+        e = (cx, cdy, self.weight.grad, self.k, self.stride, self.pad, True)
+        # only layers whose own launch cannot fill the chip: (128 x 128 output tiles) x (64-pixel steps) of work.  A larger layer's
+        # launch is efficient by itself and overlaps the chain; grouped it waits for the flush (SRGAN's trunk at 96 x 96 x 16
+        # images, 11.5 k units per layer: +1.1 % on the 96 -> 384 step when grouped, profiles/r6_wgrad_group.txt)
+        units = -(-cdy.shape[0] * cdy.shape[2] * cdy.shape[3] // 64) * -(-self.k * self.k * cx.shape[1] // 128) * -(-cdy.shape[1] // 128)
+        if units > WGRAD_GROUP_MAX_UNITS:
+            return None
+        # the library's own answer for this geometry (a thin-output or head layer has a route of its own), asked once per shape
+        ok = self._groupable.get((tuple(cx.shape), tuple(cdy.shape), self.weight.grad.data_ptr() & 15))
+        if ok is None:
+            ok = self._groupable[(tuple(cx.shape), tuple(cdy.shape), self.weight.grad.data_ptr() & 15)] = bool(ops.wgrad_groupable(*e[:6]))
+        return e if ok else None
 
     def _backward_weight(self, x, dy, bias_done=False):
         cx, cdy = (x, dy) if not self.transposed else (dy, x)      # (conv input, conv output-gradient) of the adjoint pair
@@ -299,6 +312,64 @@ def refresh_gate_masks(obj):
     else:
         for (i, _), a in zip(gates, alphas):
             ops.gate_mask(a, obj.tau, obj.mask[i])
+
+
+class WgradCollector:
+    """The weight gradients of one backward pass, collected and run as grouped launches (ops.WgradGroup: one launch + one fold for
+    all regular layers added since the last flush) on the stream the per-layer launches would have taken (the weight-gradient side
+    stream when engine.OVERLAP_WGRAD).  A layer the group cannot take (ConvOp.group_entry) runs at once, as before; bias gradients
+    stay channel sums of their own, issued with the group.  The tables live on the pass's context object (one per context and
+    flush point: the operands' addresses are part of a table).  owner._seg_done(seg), where given, reports the segment to the
+    data-parallel reducer behind the launch that completes it."""
+
+    def __init__(self, owner, ctx, enabled=True):
+        self.owner, self.ctx = owner, ctx
+        self.on = bool(enabled) and WGRAD_GROUP and not ops.PROFILE.active      # (bench.py's bracketed step times every launch on its own)
+        self.entries, self.bias, self.segs = [], [], []
+
+    def add(self, conv, x, dy, seg=None):
+        e = conv.group_entry(x, dy) if self.on else None
+        if e is None:
+            conv.backward_weight(x, dy)
+            if seg is not None:
+                self.owner._seg_done(seg)
+            return
+        self.entries.append(e)
+        if conv.bias is not None:
+            self.bias.append((dy, conv.bias.grad))
+        if seg is not None:
+            self.segs.append(seg)
+
+    def flush(self, name):
+        entries, bias, segs = self.entries, self.bias, self.segs
+        self.entries, self.bias, self.segs = [], [], []
+        if not entries:
+            return
+        groups = self.ctx.__dict__.setdefault('wgrad_groups', {})
+
+        def launch():
+            for i in range(0, len(entries), _lib.WGRAD_GROUP_MAX):
+                part = entries[i:i + _lib.WGRAD_GROUP_MAX]
+                key = (name, i)
+                g = groups.get(key)
+                if g is None:
+                    g = groups[key] = ops.WgradGroup()
+                if len(part) > 1 and g.groupable(part):
+                    g.run()
+                else:
+                    for (x, dy, dw, k, stride, pad, acc) in part:
+                        ops.conv_wgrad(x, dy, dw, k, stride, pad, accumulate=acc)
+            for dy, bg in bias:
+                ops.channel_sum(dy, bg, accumulate=True)
+        if OVERLAP_WGRAD:
+            side = ops.SideStream.get(self.owner.device)
+            side.fork()
+            with ops.on_stream(side.stream):
+                launch()
+        else:
+            launch()
+        for seg in segs:
+            self.owner._seg_done(seg)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -541,32 +612,6 @@ class UnetEngine:
                 return self._backward(c, g_feat, wgrad)
         return self._backward(c, g_feat, wgrad)
 
-    def _run_wgrad_group(self, c, which, entries, segs):
-        """the collected weight gradients of one half of the pass (ops.WgradGroup) on the weight-gradient side stream; the
-        segments they complete are reported behind them"""
-        if not entries:
-            return
-        groups = c.__dict__.setdefault('wgrad_groups', {})
-        g = groups.get(which)
-        if g is None:
-            g = groups[which] = ops.WgradGroup()
-
-        def launch():
-            if g.groupable(entries):
-                g.run()
-            else:
-                for (x, dy, dw, k, stride, pad, acc) in entries:
-                    ops.conv_wgrad(x, dy, dw, k, stride, pad, accumulate=acc)
-        if OVERLAP_WGRAD:
-            side = ops.SideStream.get(self.device)
-            side.fork()
-            with ops.on_stream(side.stream):
-                launch()
-        else:
-            launch()
-        for seg in segs:
-            self._seg_done(seg)
-
     def _backward(self, c, g_feat=None, wgrad=True):
         if self.ablate_skip:
             return
@@ -575,17 +620,8 @@ class UnetEngine:
             g_feat = [None] * 4
         # weight gradients: the regular layers are collected and run as two grouped launches (WGRAD_GROUP; bench.py's bracketed
         # roofline step times every launch on its own: per layer there)
-        grouped = wgrad and WGRAD_GROUP and not ops.PROFILE.active
-        entries, segs = [], []
-
-        def weight_gradient(conv, x, dy, seg):
-            e = conv.group_entry(x, dy) if grouped else None
-            if e is not None:
-                entries.append(e)
-                segs.append(seg)
-                return
-            conv.backward_weight(x, dy)
-            self._seg_done(seg)
+        wg = WgradCollector(self, c)
+        weight_gradient = wg.add
         # outermost: tanh' then the transposed conv
         ops.bnact_bwd(c.out, None, c.g_out, c.g_out, in_act=ACT_TANH)
         if wgrad:
@@ -609,8 +645,7 @@ class UnetEngine:
                 weight_gradient(self.up[d], src, c.g_t[d], d)
             self.up[d].backward_data(c.g_t[d], c.g_e_last if d == D - 1 else c.g_rcat[d + 1])
         # the up path's gradients are all there: its group runs beside the down path's chain
-        self._run_wgrad_group(c, 'up', entries, segs)
-        entries, segs = [], []
+        wg.flush('up')
         if not self.inner_identity:
             # innermost down conv (+ fused ReLU)
             ops.bnact_bwd(c.e[D - 1], None, c.g_e_last, c.g_e_last, in_act=ACT_RELU)
@@ -647,7 +682,7 @@ class UnetEngine:
                 weight_gradient(self.down[d], c.lin[d] if d > 0 else c.x_in, c.g_e[d], 2 * D - 1 - d)
             if d > 0:
                 self.down[d].backward_data(c.g_e[d], c.g_lin[d])
-        self._run_wgrad_group(c, 'down', entries, segs)
+        wg.flush('down')
         ops.SideStream.get(self.device).join()
 
 
@@ -1078,8 +1113,11 @@ class MobileResnetEngine:
                 if g is not None:
                     gf[int(name.split('.')[1])] = g
         ops.bnact_bwd(c.out, None, c.g_out, c.g_out, in_act=ACT_TANH)
+        # the ConvOp layers' weight gradients (k7 / k3 s2 / ConvTranspose / the 18 pointwise convs) are collected and run as one
+        # grouped launch at the end of the pass (WgradCollector); the depthwise layers keep their own kernel
+        wg = WgradCollector(self, c)
         if wgrad:
-            self.last.backward_weight(c.ypad, c.g_out)
+            wg.add(self.last, c.ypad, c.g_out)
         self.last.backward_data(c.g_out, G.ypad)
         ops.reflect_pad(G.ypad, G.t[1], 3, backward=True)
         n_blk = len(self.blocks)
@@ -1087,7 +1125,7 @@ class MobileResnetEngine:
             self._inorm_bwd(c.t_raw[i], c.t_act[i], G.t[i], G.t[i], c.t_st[i], act=ACT_RELU)
             src = c.t_act[0] if i == 1 else (c.blk[-1].o if n_blk else c.s_act[2])
             if wgrad:
-                self.ups[i].backward_weight(src, G.t[i])
+                wg.add(self.ups[i], src, G.t[i])
             self.ups[i].backward_data(G.t[i], G.t[0] if i == 1 else G.h)
         for bi in range(n_blk - 1, -1, -1):
             b, t = self.blocks[bi], c.blk[bi]
@@ -1097,7 +1135,7 @@ class MobileResnetEngine:
                 ops.nhwc_add(gf[b.index], 0, G.h, 0, G.h.shape[1])
             self._inorm_bwd(t.p2, None, G.h, gp2, t.st[3])
             if wgrad:
-                b.pw2.backward_weight(t.n2, gp2)
+                wg.add(b.pw2, t.n2, gp2)
             b.pw2.backward_data(gp2, gn2)
             self._inorm_bwd(t.d2, None, gn2, gn2, t.st[2])
             if wgrad:
@@ -1105,20 +1143,22 @@ class MobileResnetEngine:
             b.dw2.backward_data(gn2, gr1)
             self._inorm_bwd(t.p1, t.r1, gr1, gr1, t.st[1], act=ACT_RELU)
             if wgrad:
-                b.pw1.backward_weight(t.n1, gr1)
+                wg.add(b.pw1, t.n1, gr1)
             b.pw1.backward_data(gr1, gn1)
             self._inorm_bwd(t.d1, None, gn1, gn1, t.st[0])
             if wgrad:
                 b.dw1.backward_weight(x_in, gn1)
             b.dw1.backward_data(gn1, G.tmp)
             ops.nhwc_add(G.tmp, 0, G.h, 0, G.h.shape[1])
+            if (n_blk - bi) % 3 == 0:
+                wg.flush('blk%d' % bi)             # a group per three blocks, beside the next blocks' chain
         if self.relu_index in gf:
             ops.nhwc_add(gf[self.relu_index], 0, G.h, 0, G.h.shape[1])
         g = G.h
         for i in (2, 1, 0):
             self._inorm_bwd(c.s_raw[i], c.s_act[i], g, g, c.s_st[i], act=ACT_RELU)
             if wgrad:
-                self.stem[i].backward_weight(c.s_act[i - 1] if i > 0 else c.xpad, g)
+                wg.add(self.stem[i], c.s_act[i - 1] if i > 0 else c.xpad, g)
             if i > 0:
                 self.stem[i].backward_data(g, G.s[i - 1])
                 g = G.s[i - 1]
@@ -1127,6 +1167,7 @@ class MobileResnetEngine:
             self.stem[0].backward_data(g, G.xpad)
             ops.reflect_pad(G.xpad, G.x_in, 3, backward=True)
             dx = G.x_in
+        wg.flush('all')
         ops.SideStream.get(self.device).join()
         return dx
 
@@ -1585,15 +1626,16 @@ class SRResNetEngine:
         gf = dict(zip(self.hook_blocks, g_feat)) if g_feat is not None else {}
         ds = lambda p: p.grad if (wgrad and self.train_prelu) else None
         ops.bnact_bwd(c.out, None, c.g_out, c.g_out, in_act=ACT_TANH)
+        wg = WgradCollector(self, c)       # the 3 x 3 / 9 x 9 layers' weight gradients as grouped launches: tail + mid, then the trunk
         if wgrad:
-            self.last.backward_weight(c.s_act[1], c.g_out)
+            wg.add(self.last, c.s_act[1], c.g_out)
         self.last.backward_data(c.g_out, G.s_act[1])
         for j in (1, 0):
             conv, slope = self.sub[j]
             ops.prelu_bwd(c.s_raw[j], slope.data, G.s_act[j], G.s_raw[j], dslope=ds(slope), shuffle=2)
             src = c.s_act[0] if j == 1 else c.hm
             if wgrad:
-                conv.backward_weight(src, G.s_raw[j])
+                wg.add(conv, src, G.s_raw[j])
             conv.backward_data(G.s_raw[j], G.s_act[0] if j == 1 else G.hm)
         # hm = BN(mid(h_last)) + h0
         bn = self.mid_bn.bn
@@ -1602,8 +1644,9 @@ class SRResNetEngine:
                       dgamma=bn.weight.grad if wgrad else None, dbeta=bn.bias.grad if wgrad else None)
         h_last = c.blk[-1].out if self.blocks else c.h0
         if wgrad:
-            self.mid.backward_weight(h_last, G.rm)
+            wg.add(self.mid, h_last, G.rm)
         self.mid.backward_data(G.rm, G.h)
+        wg.flush('tail')
         for bi in range(len(self.blocks) - 1, -1, -1):
             b, t = self.blocks[bi], c.blk[bi]
             g_r2, g_a1, g_z1, g_r1 = G.blk[bi]
@@ -1614,19 +1657,24 @@ class SRResNetEngine:
             ops.bnact_bwd(t.r2, None, G.h, g_r2, bn=t.st2, gamma=bn2.weight.data, beta=bn2.bias.data, bn_eval=not c.train,
                           dgamma=bn2.weight.grad if wgrad else None, dbeta=bn2.bias.grad if wgrad else None)
             if wgrad:
-                b.conv2.backward_weight(t.a1, g_r2)
+                wg.add(b.conv2, t.a1, g_r2)
             b.conv2.backward_data(g_r2, g_a1)
             ops.prelu_bwd(t.z1, b.slope.data, g_a1, g_z1, dslope=ds(b.slope))
             ops.bnact_bwd(t.r1, None, g_z1, g_r1, bn=t.st1, gamma=bn1.weight.data, beta=bn1.bias.data, bn_eval=not c.train,
                           dgamma=bn1.weight.grad if wgrad else None, dbeta=bn1.bias.grad if wgrad else None)
             if wgrad:
-                b.conv1.backward_weight(h_in, g_r1)
+                wg.add(b.conv1, h_in, g_r1)
             b.conv1.backward_data(g_r1, G.tmp)
             ops.nhwc_add(G.tmp, 0, G.h, 0, self.C)
+            # a group per four blocks: its launch runs beside the next blocks' chain, as the per-layer launches did (one group for
+            # the whole trunk runs behind the pass: +1.4 ms on the 96 -> 384 step, profiles/r6_wgrad_group.txt)
+            if (len(self.blocks) - bi) % 4 == 0:
+                wg.flush('trunk%d' % bi)
         ops.nhwc_add(G.h, 0, G.h0, 0, self.C)
         ops.prelu_bwd(c.raw0, self.first_slope.data, G.h0, G.raw0, dslope=ds(self.first_slope))
         if wgrad:
-            self.first.backward_weight(c.x_in, G.raw0)
+            wg.add(self.first, c.x_in, G.raw0)
+        wg.flush('trunk')
         ops.SideStream.get(self.device).join()
 
 

@@ -686,6 +686,17 @@ def conv_wgrad(x, dy, dw, k, stride, pad, accumulate=False):
     return dw
 
 
+def wgrad_groupable(x, dy, dw, k, stride, pad):
+    """would the library take this layer into a grouped weight gradient?  (gcc_conv_wgrad_group_workspace of the one-entry group:
+    regular widths, no head / thin-output geometry)"""
+    item = (_lib.wgrad_item_t * 1)()
+    xp, N, Ci, H, W, ldx = geom(x)
+    yp, _, Co, Ho, Wo, ldy = geom(dy)
+    item[0].c = conv_desc(N, H, W, Ci, Co, k, stride, pad, ldx, ldy)
+    item[0].x, item[0].dy, item[0].dw, item[0].accumulate = xp, yp, dw.data_ptr(), 1
+    return (dw.data_ptr() & 15) == 0 and lib().gcc_conv_wgrad_group_workspace(item, 1) > 0
+
+
 class WgradGroup:
     """gcc_conv_wgrad_group_*: the weight gradients of several layers as ONE launch + one fold launch (include/gcc_hip.h).
     entries: [(x, dy, dw, k, stride, pad, accumulate)] with the operands of conv_wgrad.  The table is prepared on first use from the
