@@ -8,8 +8,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GCC_HIP_LIB') or os.path.join(_HERE, 'libgcc_hip.so')     # GCC_HIP_LIB: another build of the same ABI (A/B runs)
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
-GCC_HIP_ABI = 601
-WGRAD_GROUP_MAX = 32     # include/gcc_hip.h GCC_WGRAD_GROUP_MAX     # include/gcc_hip.h GCC_HIP_ABI: the generation of struct layouts / option ids these bindings were written for
+GCC_HIP_ABI = 602
+WGRAD_GROUP_MAX = 32     # include/gcc_hip.h GCC_WGRAD_GROUP_MAX
+CHANSUM_GROUP_MAX = 24   # include/gcc_hip.h GCC_CHANSUM_GROUP_MAX
+CHANSUM_SMALL_MAX_PIXELS = 16384     # include/gcc_hip.h GCC_HIP_ABI: the generation of struct layouts / option ids these bindings were written for
 
 
 class GccError(RuntimeError):
@@ -32,6 +34,12 @@ class conv_t(C.Structure):
 class wgrad_item_t(C.Structure):
     """include/gcc_hip.h gcc_wgrad_item_t: one entry of a grouped weight gradient"""
     _fields_ = [('c', conv_t), ('x', C.c_void_p), ('dy', C.c_void_p), ('dw', C.c_void_p), ('accumulate', C.c_int)]
+
+
+class chansum_item_t(C.Structure):
+    """include/gcc_hip.h gcc_chansum_item_t"""
+    _fields_ = [('x', C.c_void_p), ('ld', C.c_int), ('off', C.c_int), ('C', C.c_int), ('pixels', C.c_size_t), ('out', C.c_void_p),
+                ('accumulate', C.c_int)]
 
 
 class epilogue_t(C.Structure):
@@ -163,6 +171,7 @@ PROTOTYPES = {
                               _I, _I, _I, _Z, _P, _Z, _P]),
     'gcc_channel_sum': (_I, [_P, _I, _I, _I, _Z, _P, _I, _P, _Z, _P]),
     'gcc_channel_sum_workspace': (_Z, [_I, _Z]),
+    'gcc_channel_sum_group': (_I, [C.POINTER(chansum_item_t), _I, _P]),
     'gcc_gate_mask': (_I, [_P, _F, _P, _I, _P]),
     'gcc_gan_loss': (_I, [_I, _I, _I, _P, _I, _I, _Z, _F, _P, _I, _P, _P, _Z, _P]),
     'gcc_gan_loss_ex': (_I, [_I, _I, _I, _P, _I, _I, _Z, _P, _P, _F, _P, _I, _P]),

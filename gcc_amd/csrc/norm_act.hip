@@ -1813,10 +1813,10 @@ __global__ __launch_bounds__(1024) void channel_sum_finalize_kernel(const float*
 // launch-bound models two host enqueues and two dependent launches per convolution bias.
 constexpr int SUM_SMALL_NT = 512;
 constexpr size_t SUM_SMALL_MAX_PIXELS = 16384;
-__global__ __launch_bounds__(SUM_SMALL_NT) void channel_sum_small_kernel(const SumArgs a, float* out, int accumulate) {
+__device__ __forceinline__ void channel_sum_small_body(const bf16_t* x, const int ld, const int off, const int C, const int pixels,
+                                                       float* out, const int accumulate, const int c0) {
     __shared__ double red[SUM_SMALL_NT / 64][8];
-    const int c0 = blockIdx.x * 8;
-    const int pixels = (int)a.pixels;
+    struct { const bf16_t* x; int ld, off, C; } a = {x, ld, off, C};
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int pix = threadIdx.x;
     for (; pix + 3 * SUM_SMALL_NT < pixels; pix += 4 * SUM_SMALL_NT) {
@@ -1852,6 +1852,22 @@ __global__ __launch_bounds__(SUM_SMALL_NT) void channel_sum_small_kernel(const S
         const int c = c0 + threadIdx.x;
         out[c] = accumulate ? out[c] + (float)t : (float)t;
     }
+}
+__global__ __launch_bounds__(SUM_SMALL_NT) void channel_sum_small_kernel(const SumArgs a, float* out, int accumulate) {
+    channel_sum_small_body(a.x, a.ld, a.off, a.C, (int)a.pixels, out, accumulate, blockIdx.x * 8);
+}
+// several of them as ONE launch (round 6: the bias gradients of the layers of a grouped weight gradient, engine.WgradCollector --
+// CycleGAN's 180 per iteration): the table travels by value in the kernel arguments, a workgroup finds its entry by the prefix
+// sums; the arithmetic of an entry is channel_sum_small_kernel's (same bits)
+struct SumGroupItem { const bf16_t* x; float* out; int ld, off, C, pixels, accumulate, blk0; };
+struct SumGroupArgs { int n, pad_; SumGroupItem it[GCC_CHANSUM_GROUP_MAX]; };
+__global__ __launch_bounds__(SUM_SMALL_NT) void channel_sum_group_kernel(const SumGroupArgs g) {
+    const int b = blockIdx.x;
+    int k = 0;
+    for (int i = 1; i < g.n; i++) k = b >= g.it[i].blk0 ? i : k;
+    k = __builtin_amdgcn_readfirstlane(k);
+    const SumGroupItem& it = g.it[k];
+    channel_sum_small_body(it.x, it.ld, it.off, it.C, it.pixels, it.out, it.accumulate, (b - it.blk0) * 8);
 }
 
 // per-channel sum / sum of squares in the conv-epilogue partial format: out[group][block][2][C]
@@ -2190,6 +2206,24 @@ extern "C" int gcc_channel_sum(const void* x, int ld, int off, int C, size_t pix
     GCC_CHECK_LAUNCH();
     hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, (const float*)ws, blocks, C,
                        a.C8, out, accumulate);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+extern "C" int gcc_channel_sum_group(const gcc_chansum_item_t* items, int n, gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!items || n < 1 || n > GCC_CHANSUM_GROUP_MAX) return GCC_ERR_BAD_ARG;
+    SumGroupArgs g;
+    g.n = n; g.pad_ = 0;
+    int blk = 0;
+    for (int i = 0; i < n; i++) {
+        const gcc_chansum_item_t& s = items[i];
+        if (!s.x || !s.out || s.C <= 0 || s.pixels == 0 || !aligned8(s.ld, s.off)) return GCC_ERR_BAD_ARG;
+        if (s.pixels > SUM_SMALL_MAX_PIXELS) return GCC_ERR_UNSUPPORTED;          // larger tensors: gcc_channel_sum's two-launch form
+        g.it[i] = SumGroupItem{(const bf16_t*)s.x, s.out, s.ld, s.off, s.C, (int)s.pixels, s.accumulate, blk};
+        blk += ((s.C + 7) & ~7) / 8;
+    }
+    hipLaunchKernelGGL(channel_sum_group_kernel, dim3(blk), dim3(SUM_SMALL_NT), 0, (hipStream_t)stream, g);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

@@ -359,8 +359,11 @@ class WgradCollector:
                 else:
                     for (x, dy, dw, k, stride, pad, acc) in part:
                         ops.conv_wgrad(x, dy, dw, k, stride, pad, accumulate=acc)
-            for dy, bg in bias:
-                ops.channel_sum(dy, bg, accumulate=True)
+            if len(bias) > 1:
+                ops.channel_sum_group(bias, accumulate=True)
+            else:
+                for dy, bg in bias:
+                    ops.channel_sum(dy, bg, accumulate=True)
         if OVERLAP_WGRAD:
             side = ops.SideStream.get(self.owner.device)
             side.fork()

@@ -1095,6 +1095,24 @@ def channel_sum(x, out, accumulate=False):
                                 stream()), 'gcc_channel_sum')
 
 
+def channel_sum_group(pairs, accumulate=True):
+    """[(x, out)]: out (+)= per-channel sums of x, every tensor of <= 16384 pixels in ONE launch per 24 (gcc_channel_sum_group);
+    larger ones through channel_sum"""
+    small = []
+    for x, out in pairs:
+        xp, N, Cc, H, W, ld = geom(x)
+        if N * H * W <= _lib.CHANSUM_SMALL_MAX_PIXELS:
+            small.append((xp, ld, Cc, N * H * W, out.data_ptr()))
+        else:
+            channel_sum(x, out, accumulate=accumulate)
+    for i in range(0, len(small), _lib.CHANSUM_GROUP_MAX):
+        part = small[i:i + _lib.CHANSUM_GROUP_MAX]
+        items = (_lib.chansum_item_t * len(part))()
+        for it, (xp, ld, Cc, px, op) in zip(items, part):
+            it.x, it.ld, it.off, it.C, it.pixels, it.out, it.accumulate = xp, ld, 0, Cc, px, op, int(accumulate)
+        check(lib().gcc_channel_sum_group(items, len(part), stream()), 'gcc_channel_sum_group')
+
+
 def gate_mask(alpha, tau, mask):
     check(lib().gcc_gate_mask(alpha.data_ptr(), float(tau), mask.data_ptr(), alpha.numel(), stream()), 'gcc_gate_mask')
 

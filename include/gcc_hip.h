@@ -44,7 +44,7 @@ enum { GCC_ACT_NONE = 0, GCC_ACT_LRELU = 1, GCC_ACT_RELU = 2, GCC_ACT_TANH = 3 }
 /* ABI generation of this header: bumped whenever a struct layout, an enum numbering or a prototype below changes.  gcc_version()
  * of the library a host loads must return exactly this number (gcc_amd/_lib.py refuses any other; an external host should check it
  * the same way): a stale .so reads gcc_conv_t.plan past its struct and sets the wrong option ids without any error. */
-#define GCC_HIP_ABI 601
+#define GCC_HIP_ABI 602
 
 const char* gcc_strerror(int code);
 int gcc_version(void); /* == GCC_HIP_ABI of the header the library was built from */
@@ -448,6 +448,18 @@ int gcc_dwconv3x3_reflect_wgrad(const void* x, int ldx, const void* dy, int lddy
 int gcc_channel_sum(const void* x, int ld, int off, int C, size_t pixels, float* out, int accumulate,
                     void* ws, size_t ws_bytes, gcc_stream_t stream);
 size_t gcc_channel_sum_workspace(int C, size_t pixels);
+/* several channel sums of <= 16384 pixels each (the bias gradients of the layers of one grouped weight gradient) as ONE launch;
+ * entry i is gcc_channel_sum(x, ld, off, C, pixels, out, accumulate, ..) bit for bit.  n <= GCC_CHANSUM_GROUP_MAX;
+ * GCC_ERR_UNSUPPORTED when an entry has more pixels (the caller keeps it on gcc_channel_sum). */
+#define GCC_CHANSUM_GROUP_MAX 24
+typedef struct {
+    const void* x;
+    int ld, off, C;
+    size_t pixels;
+    float* out;
+    int accumulate;
+} gcc_chansum_item_t;
+int gcc_channel_sum_group(const gcc_chansum_item_t* items, int n, gcc_stream_t stream);
 
 /* gate mask m = (sign(alpha - tau) + 1) / 2.  models/DifferentiableOp.py:25-26,58-59 */
 int gcc_gate_mask(const float* alpha, float tau, float* mask, int C, gcc_stream_t stream);

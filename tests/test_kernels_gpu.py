@@ -1485,6 +1485,30 @@ def test_grouped_weight_gradients_vs_per_layer_and_torch():
     assert not ops.WgradGroup().groupable(entries[:2] + [(x, dy, dw, 4, 2, 1, False)])
 
 
+def test_grouped_channel_sums_are_the_single_launches_bit_for_bit():
+    """gcc_channel_sum_group (round 6): the bias gradients of a grouped weight gradient's layers as one launch -- every entry the bits
+    of gcc_channel_sum on the same tensor (same per-thread order, same double fold), fresh and accumulating; a tensor of more than
+    16384 pixels goes through gcc_channel_sum itself"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(1, 24, 64, 64), (2, 96, 16, 16), (1, 3, 128, 128), (4, 40, 9, 7), (1, 256, 1, 1), (2, 64, 96, 96)]      # the last: 18432 pixels
+    xs = [to_dev(rb(torch.randn(*sh, generator=g))) for sh in shapes]
+    for accumulate in (False, True):
+        ref, got = [], []
+        for x in xs:
+            r = torch.full((x.shape[1],), 0.25, device=DEV)
+            ops.channel_sum(x, r, accumulate=accumulate)
+            ref.append(r)
+            got.append(torch.full((x.shape[1],), 0.25, device=DEV))
+        ops.lib().gcc_launch_count(1)
+        ops.channel_sum_group(list(zip(xs, got)), accumulate=accumulate)
+        assert int(ops.lib().gcc_launch_count(1)) == 3, 'five small tensors in one launch, the large one in its two'
+        for x, a, b in zip(xs, ref, got):
+            assert torch.equal(a, b), tuple(x.shape)
+        want = xs[0].float().sum(dim=(0, 2, 3)) + (0.25 if accumulate else 0.0)
+        close(got[0].cpu(), want.cpu(), tol=1e-5, floor=1e-4, what='channel sums')
+
+
 RING3_CASES = [
     # N, H, W, Ci, Co               3 x 3 stride-1 layers between <= 64-channel tensors: conv_ring3.hip
     (2, 96, 96, 64, 64),            # SRGAN teacher's trunk layer at two images: three strips of 32 columns, several row bands
