@@ -327,15 +327,20 @@ class WgradCollector:
         self.on = bool(enabled) and WGRAD_GROUP and not ops.PROFILE.active      # (bench.py's bracketed step times every launch on its own)
         self.entries, self.bias, self.segs = [], [], []
 
-    def add(self, conv, x, dy, seg=None):
+    def add(self, conv, x, dy, seg=None, bias_done=False):
         e = conv.group_entry(x, dy) if self.on else None
         if e is None:
-            conv.backward_weight(x, dy)
+            conv.backward_weight(x, dy, bias_done) if bias_done else conv.backward_weight(x, dy)
             if seg is not None:
-                self.owner._seg_done(seg)
+                # segments are reported in completion order (dist.GradReducer sends a bucket when its LAST segment is reported):
+                # behind collected layers that have not been launched yet, this one's report waits for their flush
+                if self.entries:
+                    self.segs.append(seg)
+                else:
+                    self.owner._seg_done(seg)
             return
         self.entries.append(e)
-        if conv.bias is not None:
+        if conv.bias is not None and not bias_done:
             self.bias.append((dy, conv.bias.grad))
         if seg is not None:
             self.segs.append(seg)
@@ -875,10 +880,12 @@ class PatchGANEngine:
         if g_feat is None:
             g_feat = [None, None]
         feat_of = {1: g_feat[0], 3: g_feat[1]}
+        # (layers small enough for a grouped weight gradient -- the batch-1 models' discriminators -- are collected and run at the
+        # end of the pass; the headline configuration's layers are far above ConvOp.group_entry's size rule and launch at once)
+        wg = WgradCollector(self, c)
         if has_pred_grad:
             if wgrad:
-                self.conv[L - 1].backward_weight(c.y[L - 2], G.layer[L - 1])
-                self._seg_done(0)
+                wg.add(self.conv[L - 1], c.y[L - 2], G.layer[L - 1], seg=0)
             self.conv[L - 1].backward_data(G.layer[L - 1], G.layer[L - 2])
         for li in range(L - 2, 0, -1):
             g1, g2 = G.layer[li], feat_of.get(li)
@@ -899,8 +906,7 @@ class PatchGANEngine:
                               dalpha=agrad_of(li))
             src = c.g0 if li == 1 else c.y[li - 1]
             if wgrad:
-                self.conv[li].backward_weight(src, G.layer[li])
-                self._seg_done(L - 1 - li)
+                wg.add(self.conv[li], src, G.layer[li], seg=L - 1 - li)
             self.conv[li].backward_data(G.layer[li], G.layer[li - 1])
         gate = self.gate[0]
         # the first conv's bias gradient is the channel sum of dz, which this pass forms anyway (its 'dbeta' sum): no separate
@@ -910,12 +916,12 @@ class PatchGANEngine:
                       dalpha=agrad_of(0),
                       dbeta=b0.grad if (wgrad and b0 is not None) else None)
         if wgrad:
-            self.conv[0].backward_weight(c.x_in, G.layer[0], bias_done=True)
-            self._seg_done(L - 1)
+            wg.add(self.conv[0], c.x_in, G.layer[0], seg=L - 1, bias_done=True)
         dx = None
         if need_dx:
             self.conv[0].backward_data(G.layer[0], G.x_in)
             dx = G.x_in
+        wg.flush('all')
         ops.SideStream.get(self.device).join()
         return dx
 

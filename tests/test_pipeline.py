@@ -152,14 +152,17 @@ def test_every_preprocess_mode_vs_pil(pre):
     for (h, w2), load, crop in (((101, 150), 96, 64), ((70, 96), 96, 64), ((130, 90), 80, 80)):
         ab = (rng.rand(h, 2 * w2, 3) * 255).astype(np.uint8)
         opt = types.SimpleNamespace(preprocess=pre, load_size=load, crop_size=crop, no_flip=False)
-        params = {'crop_pos': (3, 2), 'flip': True}
+        t = resize_target(opt, h, w2)
+        nh, nw = t if t is not None else (h, w2)
+        # a crop position get_params (data/base_dataset.py:63-78) can draw: inside the resized image
+        cx, cy = min(3, max(0, nw - crop)), min(2, max(0, nh - crop))
+        params = {'crop_pos': (cx, cy), 'flip': True}
         item = AlignedGpuPipeline(opt)(torch.from_numpy(ab), params)
         for name, img in (('A', ab[:, :w2]), ('B', ab[:, w2:])):
-            t = resize_target(opt, h, w2)
             if t is not None:
                 img = np.array(Image.fromarray(img).resize((t[1], t[0]), Image.BICUBIC))
             if 'crop' in pre and (img.shape[1] > crop or img.shape[0] > crop):
-                img = img[2:2 + crop, 3:3 + crop]
+                img = img[cy:cy + crop, cx:cx + crop]
             img = img[:, ::-1]
             ref = (np.transpose(img.astype(np.float32) / np.float32(255.), (2, 0, 1)) - np.float32(0.5)) / np.float32(0.5)
             got = item[name].cpu().numpy()
