@@ -441,7 +441,7 @@ struct OptDef { const char* env; int def; };
 const OptDef kOptDef[GCC_OPT_COUNT_] = {
     {"GCC_IGEMM_GLDS", 1}, {"GCC_IGEMM_HEAD", 1}, {"GCC_IGEMM_THIN", 1}, {"GCC_WGRAD_BIG", 1}, {"GCC_BN_SWEEPS", 0},
     {"GCC_BN_MAXBLK", 2048}, {"GCC_BN_REDUCE_THREADS", 256}, {"GCC_BN_REDUCE_CAP", 1024}, {"GCC_INORM_LPP", 0},
-    {"GCC_IGEMM_FORCE_BC", 0}, {"GCC_IGEMM_FORCE_KSPLIT", 0}, {"GCC_IGEMM_NARROW", 1}, {"GCC_WGRAD_BIG_MIN_TILES", 32},
+    {"GCC_IGEMM_FORCE_BC", 0}, {"GCC_IGEMM_FORCE_KSPLIT", 0}, {"GCC_IGEMM_NARROW", 1}, {"GCC_WGRAD_BIG_MIN_TILES", 8},
     {"GCC_FUSE_BN", 3}, {"GCC_BN_BWD_SMALL", 1}, {"GCC_WGRAD_ROW_TABLE", 1}, {"GCC_IGEMM_HALO", 3}, {"GCC_FUSE_BN_PARTIAL_KB", 4096},
     {"GCC_INORM_GRID", 1}, {"GCC_IGEMM_STAGES", 3}, {"GCC_WGRAD_TS", 1}, {"GCC_HALO_XCD_COLS", 1},
 };

@@ -82,7 +82,7 @@ enum {
     GCC_OPT_IGEMM_FORCE_KSPLIT, /* tuning: 0 (default) automatic; n >= 1: K slices of a 128-pixel-tile launch (1 = never split) */
     GCC_OPT_IGEMM_NARROW,       /* 1 (default): 128-pixel tiles narrow to 64 / 32 channels until the launch has >= 256 workgroups, and
                                    K is split only for loops of >= 48 steps (0: the round-1 plan) */
-    GCC_OPT_WGRAD_BIG_MIN_TILES,/* minimum number of 256x256 output tiles for the big weight-gradient tiling (default 32) */
+    GCC_OPT_WGRAD_BIG_MIN_TILES,/* minimum number of 256x256 output tiles for the big weight-gradient tiling (default 8: from the PatchGAN's 128 -> 256 layer up; 32 until round 6: +0.3 % on the step, profiles/r6_ab_wgrad_big_min_tiles.txt) */
     GCC_OPT_FUSE_BN,            /* gcc_conv_bn_act: 3 (default; profiles/r4_summary.md): a split layer's K slices folded, statistics exchanged inside the
                                    launch and rows normalised by one kernel on the whole chip (bn_fold_grid_kernel; needs gcc_bn_t.tail_ws; other
                                    layers as 1); 2: BatchNorm finalized by the last-arriving workgroups of the launch that writes the statistic
