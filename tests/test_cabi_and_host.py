@@ -166,6 +166,46 @@ def test_weight_gradient_plan_follows_the_schedule(monkeypatch):
     assert state() == (0, 0, 0, 0)
 
 
+def test_grouped_weight_gradient_host_logic():
+    """gcc_conv_wgrad_group_* (round 6) without a GPU: which entries the library takes into a group, the workspace / table sizes,
+    argument errors.  (prepare only writes host memory; the device pointers are addresses here)"""
+    from gcc_amd import _lib
+    lib = _lib.load()
+    conv = lambda N, H, W, Ci, Co, k, s, p: _lib.conv_t(N, H, W, Ci, Co, k, k, s, p, (Ci + 7) // 8 * 8, 0, (Co + 7) // 8 * 8, 0)
+
+    def items(descs, dw=0x40000000):
+        arr = (_lib.wgrad_item_t * len(descs))()
+        for it, d in zip(arr, descs):
+            it.c, it.x, it.dy, it.dw, it.accumulate = d, 0x10000000, 0x20000000, dw, 1
+        return arr
+    unet = [conv(16, 128, 128, 32, 64, 4, 2, 1), conv(16, 64, 64, 64, 128, 4, 2, 1), conv(16, 2, 2, 256, 256, 4, 2, 1),
+            conv(16, 16, 16, 128, 512, 4, 2, 1)]
+    tb = lib.gcc_conv_wgrad_group_table_bytes()
+    assert tb > 1024
+    ws = lib.gcc_conv_wgrad_group_workspace(items(unet), len(unet))
+    assert ws > 0
+    table = ctypes.create_string_buffer(tb)
+    assert lib.gcc_conv_wgrad_group_prepare(items(unet), len(unet), ctypes.c_void_p(0x50000000), ws, table) == 0
+    assert any(bytes(table))
+    assert lib.gcc_conv_wgrad_group_prepare(items(unet), len(unet), ctypes.c_void_p(0x50000000), ws - 1, table) == -3      # workspace
+    assert lib.gcc_conv_wgrad_group_prepare(items(unet), len(unet), None, ws, table) == -1
+    assert lib.gcc_conv_wgrad_group_prepare(items(unet, dw=0x40000004), len(unet), ctypes.c_void_p(0x50000000), ws, table) == -1   # dw not 16-byte aligned
+    # entries that keep their own route: a 3-channel image layer, the single-output-channel head, a thin-output 9 x 9 layer
+    for bad in (conv(16, 256, 256, 3, 32, 4, 2, 1), conv(16, 31, 31, 1024, 1, 4, 1, 1), conv(2, 96, 96, 64, 3, 9, 1, 4)):
+        assert lib.gcc_conv_wgrad_group_workspace(items(unet + [bad]), len(unet) + 1) == 0
+        assert lib.gcc_conv_wgrad_group_prepare(items(unet + [bad]), len(unet) + 1, ctypes.c_void_p(0x50000000), 1 << 30, table) == -2
+    assert lib.gcc_conv_wgrad_group_workspace(items(unet), 0) == 0
+    assert lib.gcc_conv_wgrad_group_workspace(items(unet * 9), 36) == 0                      # more than GCC_WGRAD_GROUP_MAX entries
+    assert lib.gcc_conv_wgrad_group_run(None, table, None) == -1
+    empty = ctypes.create_string_buffer(tb)
+    assert lib.gcc_conv_wgrad_group_run(ctypes.c_void_p(0x60000000), empty, None) == -1     # not a prepared table
+    # gcc_channel_sum_group: argument errors are codes
+    cs = (_lib.chansum_item_t * 1)()
+    assert lib.gcc_channel_sum_group(cs, 0, None) == -1 and lib.gcc_channel_sum_group(None, 1, None) == -1
+    cs[0].x, cs[0].ld, cs[0].off, cs[0].C, cs[0].pixels, cs[0].out, cs[0].accumulate = 0x10000000, 64, 0, 64, 1 << 20, 0x20000000, 1
+    assert lib.gcc_channel_sum_group(cs, 1, None) == -2                                       # more than 16384 pixels: gcc_channel_sum's job
+
+
 def test_conv_route_predicates():
     """gcc_conv_route is host logic only: which kernel family each layer shape of the headline config runs on"""
     from gcc_amd import _lib
