@@ -1061,6 +1061,16 @@ __global__ __launch_bounds__(256) void thin_fprop_kernel(const ThinArgs a) {
     constexpr int ROWB = NJ * 64 + 16;
     __shared__ __attribute__((aligned(16))) char stage_all[4][16 * ROWB];
     char* stage = stage_all[wave];
+    // the gate of the second output (Y2_GATE: the masked PatchGAN's first layer): a lane stores the same eight channels of every
+    // pixel it stores, so their mask values are read ONCE -- read per stored chunk inside the loop (eight dependent global loads
+    // in front of every second store) they made the two-output launch take 84 us against 36 for one output (N = 16, 6 -> 128 at
+    // 256 x 256: 67 MB more to write; scratch/r6/bench_d_l1.py)
+    float gatev[8];
+    {
+        const int cg = co_base + (lane % (NJ * 4)) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e++) gatev[e] = (a.y2 && a.mode2 != 1 && cg + e < a.Co) ? a.gate[cg + e] : 0.f;
+    }
 
     auto compute = [&](int tile, const i32x4* xb) {
         f32x4 acc[NJ][2];
@@ -1122,7 +1132,7 @@ __global__ __launch_bounds__(256) void thin_fprop_kernel(const ThinArgs a) {
                         for (int e = 0; e < 8; e++) f[e] = fmaxf(f[e], 0.f);
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 8; e++) f[e] *= (co + e < a.Co) ? a.gate[co + e] : 0.f;
+                        for (int e = 0; e < 8; e++) f[e] *= gatev[e];
                     }
                     *(i32x4*)(a.y2 + (size_t)q * a.ldy2 + a.y2off + co) = pack8(f);
                 }

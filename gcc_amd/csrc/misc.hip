@@ -254,19 +254,22 @@ __global__ __launch_bounds__(1024) void gan_loss_kernel(int mode, int real, int 
             *(i32x4*)(dpred + i * ld + off) = pack8(o);
         }
     };
-    // single workgroup (the map is ~10^4 values): four elements per thread in flight, the trip is a latency chain otherwise
+    // single workgroup (the map is ~10^4 values): sixteen elements per thread in flight -- the 16 x 30 x 30 map of the headline
+    // configuration in ONE round trip per thread (four in flight made it four dependent trips: 10.8 us per launch, fifteen launches
+    // per iteration on the chains between a discriminator's forward and its backward pass)
     const size_t bd = blockDim.x;
     const bool rd = dpred && dpred_accumulate;
-    for (size_t i0 = threadIdx.x; i0 < pixels; i0 += 4 * bd) {
-        float x[4], pv[4];
+    constexpr int U = 16;
+    for (size_t i0 = threadIdx.x; i0 < pixels; i0 += U * bd) {
+        float x[U], pv[U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < U; u++) {
             const size_t i = i0 + u * bd;
             x[u] = i < pixels ? bf2f(pred[i * ld + off]) : 0.f;
             pv[u] = (rd && i < pixels) ? bf2f(dpred[i * ld + off]) : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < U; u++)
             if (i0 + u * bd < pixels) one(i0 + u * bd, x[u], pv[u]);
     }
     const float t = block_sum256(acc, sh);
