@@ -726,6 +726,10 @@ class WgradGroup:
         self.ok = need > 0
         if not self.ok:
             return
+        # a launch of the previous table may still be in flight on a stream the caching allocator does not track: the buffers it
+        # reads stay alive for a few generations (re-preparing is rare: the operands are persistent buffers)
+        if getattr(self, 'table_dev', None) is not None:
+            self._retired = (getattr(self, '_retired', []) + [(self.ws, self.table_dev)])[-4:]
         self.ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
         tb = int(lib().gcc_conv_wgrad_group_table_bytes())
         self.table_host = torch.zeros(tb, dtype=torch.uint8)
