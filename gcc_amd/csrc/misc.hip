@@ -254,12 +254,12 @@ __global__ __launch_bounds__(1024) void gan_loss_kernel(int mode, int real, int 
             *(i32x4*)(dpred + i * ld + off) = pack8(o);
         }
     };
-    // single workgroup (the map is ~10^4 values): sixteen elements per thread in flight -- the 16 x 30 x 30 map of the headline
-    // configuration in ONE round trip per thread (four in flight made it four dependent trips: 10.8 us per launch, fifteen launches
+    // single workgroup (the map is ~10^4 values): eight elements per thread in flight -- the 16 x 30 x 30 map of the headline
+    // configuration in two round trips per thread (four in flight: four dependent trips, 10.8 us per launch; sixteen spill under __launch_bounds__(1024) and take 19 us; fifteen launches
     // per iteration on the chains between a discriminator's forward and its backward pass)
     const size_t bd = blockDim.x;
     const bool rd = dpred && dpred_accumulate;
-    constexpr int U = 16;
+    constexpr int U = 8;
     for (size_t i0 = threadIdx.x; i0 < pixels; i0 += U * bd) {
         float x[U], pv[U];
 #pragma unroll
