@@ -450,6 +450,21 @@ def _gradient_check(model, teacher, build_oracle, A, B, vA, vB, skip=None, gan_m
     # the same iteration once more with the real learning rates (weights are unchanged so far: every lr was 0; Adam's
     # moments hold this very gradient): each weight must step against the oracle's gradient
     from tests import _updates
+    acc = {}
+    # the architecture step first, alone, with its real learning rate: the weights have not moved, so its gradient is still the
+    # oracle's (after the weight step below it is not: at full width one Adam step of every PatchGAN weight turns a fifth of
+    # the gate gradients around)
+    model.optimizer_arch.param_groups[0]['lr'] = lrs[-1][1]
+    ab = {k: model.netD.state_dict()[k].detach().clone() for (t, k) in g32 if t == 'alpha'}
+    model.set_input({'A': vA, 'B': vB, 'A_paths': ['a'], 'B_paths': ['b']})
+    model.clipping_mask_alpha()
+    model.optimizer_netD_arch()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        for k, v in ab.items():
+            _updates.sign_check('alpha', v, model.netD.state_dict()[k], g32[('alpha', k)], g16[('alpha', k)], acc)
+            model.netD.state_dict()[k].copy_(v)          # (a gate at its threshold must not flip under the weight step's check)
+    model.refresh_weights()
     for o, lr in lrs:
         o.param_groups[0]['lr'] = lr
     mods = {'tD': teacher.netD, 'tG': teacher.netG, 'sD': model.netD, 'sG': model.netG}
@@ -463,14 +478,11 @@ def _gradient_check(model, teacher, build_oracle, A, B, vA, vB, skip=None, gan_m
     model.finish_G_update()
     teacher.finish_G_update()
     torch.cuda.synchronize()
-    acc = {}
     for (t, k) in g32:
         if skip is not None and skip((t, k)):
             continue
         if t in mods:
             _updates.sign_check(t, before[t][k], mods[t].state_dict()[k], g32[(t, k)], g16[(t, k)], acc)
-        elif t == 'alpha':
-            _updates.sign_check('alpha', before['sD'][k], model.netD.state_dict()[k], g32[(t, k)], g16[(t, k)], acc)
         elif t == 'T':
             _updates.sign_check('T', tb[k], model.transform_convs[k].weight, g32[(t, k)], g16[(t, k)], acc)
     _updates.sign_report(acc)
@@ -576,6 +588,46 @@ def test_full_config_iteration_vs_oracle(plan, batch, monkeypatch):
     for k in ('G_GAN', 'G_L1', 'D_real', 'D_fake'):
         print('T %-22s got %.5g ref %.5g' % (k, tgot[k], ot.losses[k]))
         assert abs(tgot[k] - ot.losses[k]) <= _loss_tol(k, ot.losses[k], model), (k, tgot[k], ot.losses[k])
+
+
+@pytest.mark.parametrize('batch', [2, 16])
+def test_full_config_gradients_vs_oracle(batch):
+    """every parameter gradient of one whole GCC iteration + arch step at BASELINE.json configs[1]'s REAL widths
+    (student ngf 32 / masked PatchGAN ndf 128, teacher ngf 64 / ndf 128, 8 downs, 256 x 256, hinge), all learning rates 0, against
+    the oracle's autograd gradient -- the check of test_gradients_vs_oracle (relative L2 per tensor against the fp32 oracle and the
+    bf16-emulating oracle, same bars), no longer only at ngf 8 / 64 x 64.  batch 16 is the bench's own launch set (LDS-resident
+    halo kernels, 256-pixel tiles, grouped weight gradients); batch 2 the small-grid routes of the same layers.  A quarter of the
+    first gate is closed (alpha < threshold), so the masked channels' zero gradients are part of the comparison."""
+    import copy
+    from oracle import gcc_oracle as O
+    from tests.golden.recipe import recipe_state_dict, recipe_transform
+    model, teacher, opt = build_model(FULL_ARGV)
+    assert opt.gan_mode == 'hinge'
+    sds = {}
+    for name, mod, seed in (('sG', model.netG, 41), ('sD', model.netD, 42), ('tG', teacher.netG, 43), ('tD', teacher.netD, 44)):
+        sds[name] = recipe_state_dict(OrderedDict((k, tuple(v.shape)) for k, v in mod.state_dict().items()), seed)
+        mod.load_state_dict(sds[name])
+    Ts = [recipe_transform(t.weight.shape[0], t.weight.shape[1], 45 + i) for i, t in enumerate(model.transform_convs)]
+    with torch.no_grad():
+        for t, v in zip(model.transform_convs, Ts):
+            t.weight.copy_(v.to(DEV))
+        a = model.netD.state_dict()['model.2.alpha']
+        a[: a.numel() // 4] = 0.3
+    sds['sD'] = OrderedDict((k, v.detach().float().cpu().clone()) for k, v in model.netD.state_dict().items())
+    model.refresh_weights()
+    teacher.refresh_weights()
+    model.model_train()
+
+    def build_oracle():
+        oopt = O.Opt(ngf=32, ndf=128, teacher_ngf=64, teacher_ndf=128, num_downs=8, no_dropout=True, direction=opt.direction,
+                     threshold=opt.threshold)
+        ot = O.Pix2PixOracle(oopt, copy.deepcopy(sds['tG']), copy.deepcopy(sds['tD']), masked=False)
+        om = O.Pix2PixOracle(oopt, copy.deepcopy(sds['sG']), copy.deepcopy(sds['sD']), [t.clone() for t in Ts], masked=True,
+                             teacher=ot)
+        return om, ot, oopt
+    g = torch.Generator().manual_seed(78)
+    A, B, vA, vB = (torch.rand(batch, 3, 256, 256, generator=g) * 2 - 1 for _ in range(4))
+    _gradient_check(model, teacher, build_oracle, A, B, vA, vB, gan_mode='hinge')
 
 
 RESNET_ARGV = ['--dataroot', './database/cityscapes/', '--model', 'pix2pix', '--gpu_ids', '0', '--backbone', 'resnet',
