@@ -210,7 +210,8 @@ def loss_check_step1(first, batch, world, rel=2e-2):
         return out
     dev = {k: abs(first[k] - ref[k]) / max(abs(ref[k]), 1e-3) for k in ref if k in first}
     out.update({'kind': 'self: a regression guard against values this HIP path produced at an earlier tree, NOT parity -- parity at this '
-                        'size is tests/test_pix2pix_gpu.py::test_full_config_iteration_vs_oracle[default-16] (CPU oracle, dropout masks injected)',
+                        'size, dropout on, is tests/test_pix2pix_gpu.py::test_full_config_dropout_iteration_vs_oracle (CPU oracle handed the kernels\' masks) '
+                        'and ::test_full_config_gradients_vs_oracle[16] (every parameter gradient)',
                 'reference': 'tests/golden/bench_step1_losses.json', 'max_rel_dev': round(max(dev.values()), 6),
                 'tolerance': rel, 'ok': bool(max(dev.values()) <= rel and set(ref) <= set(first))})
     if not out['ok']:

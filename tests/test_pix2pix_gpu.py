@@ -293,6 +293,24 @@ def test_gradients_vs_oracle_hinge():
     _gradient_check(model, teacher, build_oracle, A, B, vA, vB, gan_mode='hinge')
 
 
+def _dropout_masks(engine, nth, N, S):
+    """the (1 / (1 - p))-scaled dropout masks of the engine's nth forward pass from now, regenerated from the kernels' counter RNG by
+    a bare dropout backward of ones (the route gcc_bnact_bwd itself takes)"""
+    from gcc_amd import ops
+    out = {}
+    for d in engine.drop_depths:
+        hh, C = S >> d, engine.uwidth[d]
+        raw = ops.new_act(N, C, hh, hh, DEV)
+        ones = ops.new_act(N, C, hh, hh, DEV)
+        ones.fill_(1.0)
+        dx = ops.new_act(N, C, hh, hh, DEV)
+        ops.bnact_bwd(raw, None, ones, dx, bn=None, act=ops.ACT_NONE, drop_p=0.5, seed=(engine.seed + nth) * 64 + d)
+        out[d] = dx.float().cpu()
+        keep = float((out[d] != 0).float().mean())
+        assert set(out[d].unique().tolist()) <= {0.0, 2.0} and abs(keep - 0.5) < 0.05, keep
+    return out
+
+
 def test_dropout_iteration_vs_oracle_with_injected_masks():
     """SURVEY 8c hazard H4 / VERDICT r3 weak 1b: an iteration with Dropout(0.5) ON against the oracle.  The HIP path draws its
     masks from a counter RNG (splitmix64(seed, element)), not torch's Philox stream, so the oracle is handed the very masks the
@@ -324,19 +342,7 @@ def test_dropout_iteration_vs_oracle_with_injected_masks():
     A, B, vA, vB = (torch.rand(N, 3, S, S, generator=g) * 2 - 1 for _ in range(4))
 
     def masks(engine, nth):
-        """the (1 / (1 - p))-scaled masks of the engine's nth forward pass from now"""
-        out = {}
-        for d in engine.drop_depths:
-            hh, C = S >> d, engine.uwidth[d]
-            raw = ops.new_act(N, C, hh, hh, DEV)
-            ones = ops.new_act(N, C, hh, hh, DEV)
-            ones.fill_(1.0)
-            dx = ops.new_act(N, C, hh, hh, DEV)
-            ops.bnact_bwd(raw, None, ones, dx, bn=None, act=ops.ACT_NONE, drop_p=0.5, seed=(engine.seed + nth) * 64 + d)
-            out[d] = dx.float().cpu()
-            keep = float((out[d] != 0).float().mean())
-            assert set(out[d].unique().tolist()) <= {0.0, 2.0} and abs(keep - 0.5) < 0.05, keep
-        return out
+        return _dropout_masks(engine, nth, N, S)
     oopt = O.Opt(ngf=8, ndf=8, teacher_ngf=16, teacher_ndf=16, num_downs=6, no_dropout=False, direction=opt.direction,
                  threshold=opt.threshold, gan_mode=opt.gan_mode)
     ot = O.Pix2PixOracle(oopt, recipe_state_dict(O.unet_shapes(16, 6), seeds['tG']),
@@ -581,6 +587,60 @@ def test_full_config_iteration_vs_oracle(plan, batch, monkeypatch):
         e = (a - b).abs()
         print('%s (%s plan): max %.4g mean %.4g' % (what, plan, e.max(), e.mean()))
         assert e.max().item() <= 2e-2 and e.mean().item() <= 3e-3, (what, e.max().item(), e.mean().item())
+    assert len(om.losses) >= 9
+    for k, v in om.losses.items():
+        print('S %-22s got %.5g ref %.5g' % (k, got[k], v))
+        assert abs(got[k] - v) <= _loss_tol(k, v, model), (k, got[k], v)
+    for k in ('G_GAN', 'G_L1', 'D_real', 'D_fake'):
+        print('T %-22s got %.5g ref %.5g' % (k, tgot[k], ot.losses[k]))
+        assert abs(tgot[k] - ot.losses[k]) <= _loss_tol(k, ot.losses[k], model), (k, tgot[k], ot.losses[k])
+
+
+def test_full_config_dropout_iteration_vs_oracle():
+    """the bench's own workload -- BASELINE.json configs[1] at its real widths, N = 16, Dropout(0.5) ON in the three
+    inner up-blocks of both generators (bench.py runs without --no_dropout) -- one whole GCC iteration + arch step against the
+    oracle, which is handed the very masks the kernels draw (test_dropout_iteration_vs_oracle_with_injected_masks, there at
+    ngf 8 / 128 x 128).  Image max-abs 2e-2 / mean-abs 3e-3, loss scalars 3e-2, as in the --no_dropout tests."""
+    import copy
+    from oracle import gcc_oracle as O
+    from tests.golden.recipe import recipe_state_dict, recipe_transform
+    N, S = 16, 256
+    model, teacher, opt = build_model([a for a in FULL_ARGV if a != '--no_dropout'])
+    assert model.G.drop_depths and teacher.G.drop_depths == model.G.drop_depths and not opt.no_dropout
+    sds = {}
+    for name, mod, seed in (('sG', model.netG, 51), ('sD', model.netD, 52), ('tG', teacher.netG, 53), ('tD', teacher.netD, 54)):
+        sds[name] = recipe_state_dict(OrderedDict((k, tuple(v.shape)) for k, v in mod.state_dict().items()), seed)
+        mod.load_state_dict(sds[name])
+    Ts = [recipe_transform(t.weight.shape[0], t.weight.shape[1], 55 + i) for i, t in enumerate(model.transform_convs)]
+    with torch.no_grad():
+        for t, v in zip(model.transform_convs, Ts):
+            t.weight.copy_(v.to(DEV))
+    model.refresh_weights()
+    teacher.refresh_weights()
+    model.model_train()
+    oopt = O.Opt(ngf=32, ndf=128, teacher_ngf=64, teacher_ndf=128, num_downs=8, no_dropout=False, direction=opt.direction)
+    ot = O.Pix2PixOracle(oopt, copy.deepcopy(sds['tG']), copy.deepcopy(sds['tD']), masked=False)
+    om = O.Pix2PixOracle(oopt, copy.deepcopy(sds['sG']), copy.deepcopy(sds['sD']), [t.clone() for t in Ts], masked=True, teacher=ot)
+    g = torch.Generator().manual_seed(79)
+    A, B, vA, vB = (torch.rand(N, 3, S, S, generator=g) * 2 - 1 for _ in range(4))
+    om.dropout_masks, ot.dropout_masks = _dropout_masks(model.G, 1, N, S), _dropout_masks(teacher.G, 1, N, S)
+    model.set_input({'A': A, 'B': B, 'A_paths': ['a'] * N, 'B_paths': ['b'] * N})
+    model.optimize_parameters()
+    fake, tfake = model.fake_B.float().cpu(), teacher.fake_B.float().cpu()
+    om.set_input(A, B)
+    om.optimize_parameters()
+    for what, a, b in (('fake_B', fake, om.fake_B.detach()), ('Tfake_B', tfake, ot.fake_B.detach())):
+        e = (a - b).abs()
+        print('dropout on, full width, N = 16: %s max %.4g mean %.4g' % (what, e.max(), e.mean()))
+        assert e.max().item() <= 2e-2 and e.mean().item() <= 3e-3, (what, e.max().item(), e.mean().item())
+    om.dropout_masks, ot.dropout_masks = _dropout_masks(model.G, 1, N, S), _dropout_masks(teacher.G, 1, N, S)
+    model.set_input({'A': vA, 'B': vB, 'A_paths': ['a'] * N, 'B_paths': ['b'] * N})
+    model.clipping_mask_alpha()
+    model.optimizer_netD_arch()
+    om.set_input(vA, vB)
+    om.clipping_mask_alpha()
+    om.optimizer_netD_arch()
+    got, tgot = model.get_current_losses(), teacher.get_current_losses()
     assert len(om.losses) >= 9
     for k, v in om.losses.items():
         print('S %-22s got %.5g ref %.5g' % (k, got[k], v))
