@@ -445,17 +445,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // Rows are 128 bytes (64 channels); the four 32-byte windows of a row are XOR-swizzled with bits 1-2 of the row number, so the
 // 8 consecutive rows a half-wave touches per transposing read fall on 8 distinct bank groups whatever the tap shift (the
 // halo pitch, 24 rows, is a multiple of 8: kh never changes those bits).
+// KS = 3 (round 6: k3 s1 p1, the 33 Conv2d(64, 64, 3, 1, 1) of SRGAN's SRResNet trunk at 96 x 96 x 16 images and the stride-1 layers
+// of its discriminator): nine taps share the [10 x 18 halo][64] x image; nine waves, one tap each (64 x 64 channels: 16 MFMA tiles).
+template <int KS>
+struct TsCfg {
+    static constexpr int TR = 8, TW = 16, PX = TR * TW;           // output positions per block
+    static constexpr int HP = 24, HW = TW + KS - 1, HR = TR + KS - 1;   // halo pitch (rows of the LDS image per halo line), used width, lines
+    static constexpr int XROWS = HR * HP;                         // 264 / 240
+    static constexpr int XP = XROWS / 8, YP = PX / 8;             // 1-KiB LDS-DMA pieces: 33 / 30 + 16
+    static constexpr int RSB = 128;                               // bytes per LDS row
+    static constexpr int Y_BYTES = PX * RSB, X_BYTES = XROWS * RSB;
+    static constexpr int STAGE = Y_BYTES + X_BYTES;               // 50176 / 47104
+    static constexpr int NS = 3;
+    static constexpr int LDS_BYTES = NS * STAGE;                  // 150528 / 141312: one workgroup per CU
+    static constexpr int NW = KS == 4 ? 8 : 9;                    // waves
+    static constexpr int TPW = KS == 4 ? 2 : 1;                   // taps per wave
+    static constexpr int NT = NW * 64;
+    static constexpr int YJ = (YP + NW - 1) / NW, XJ = (XP + NW - 1) / NW;      // pieces per wave: 2 + 5 / 2 + 4 (the last ones partly)
+};
 namespace ts {
-constexpr int TR = 8, TW = 16, PX = TR * TW;       // output positions per block
-constexpr int HP = 24, HW = TW + 3, HR = TR + 3;   // halo pitch (rows of the LDS image per halo line), used width, lines
-constexpr int XROWS = HR * HP;                     // 264
-constexpr int XP = XROWS / 8, YP = PX / 8;         // 1-KiB LDS-DMA pieces: 33 + 16
-constexpr int RSB = 128;                           // bytes per LDS row
-constexpr int Y_BYTES = PX * RSB, X_BYTES = XROWS * RSB;
-constexpr int STAGE = Y_BYTES + X_BYTES;           // 50176
-constexpr int NS = 3;
-constexpr int LDS_BYTES = NS * STAGE;              // 150528: one workgroup per CU
-constexpr int NT = 512;
+constexpr int TR = 8, TW = 16;
 }
 
 struct TsParams {
@@ -481,8 +490,11 @@ __device__ __forceinline__ bf16x8 ts_frag(const char* a, int off1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(ts::NT) void wgrad_ts_kernel(const TsParams p) {
-    using namespace ts;
+template <int KS>
+__global__ __launch_bounds__(TsCfg<KS>::NT) void wgrad_ts_kernel(const TsParams p) {
+    using C = TsCfg<KS>;
+    constexpr int TR = C::TR, TW = C::TW, HP = C::HP, HW = C::HW, RSB = C::RSB, Y_BYTES = C::Y_BYTES, STAGE = C::STAGE, NS = C::NS;
+    constexpr int NW = C::NW, TPW = C::TPW, YJ = C::YJ, XJ = C::XJ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -499,27 +511,29 @@ __global__ __launch_bounds__(ts::NT) void wgrad_ts_kernel(const TsParams p) {
     const i32x4 rs_y = make_rsrc(p.dy, p.dy_bytes);
     const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
 
-    // LDS-DMA pieces of this wave: dy pieces wave + 8j (j < 2), x pieces wave + 8j (j < 5; piece 32 exists for wave 0 only).
+    // LDS-DMA pieces of this wave: dy pieces wave + NW j (< 16), x pieces wave + NW j (< 33 / 30).
     // Lane (rsub, pch) of a piece lays down the physical 16-byte chunk pch of row 8 * piece + rsub: it fetches the logical chunk
     // whose 32-byte window is XORed with bits 1-2 of the row.
     const int rsub = lane >> 3, pch = lane & 7;
-    int yl[2], ypy[2], ypx[2];
+    int yl[YJ], ypy[YJ], ypx[YJ];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int row = 8 * (wave + 8 * j) + rsub;
+    for (int j = 0; j < YJ; j++) {
+        const int row = 8 * (wave + NW * j) + rsub;
         const int lch = (((pch >> 1) ^ ((row >> 1) & 3)) << 1) | (pch & 1);
         ypy[j] = row >> 4; ypx[j] = row & 15;
         yl[j] = ((ypy[j] * p.Wo + ypx[j]) * p.ldy + p.yoff + co0 + lch * 8) * 2;
     }
-    int xl[5], xhy[5], xhx[5];
+    int xl[XJ], xhy[XJ], xhx[XJ];
 #pragma unroll
-    for (int j = 0; j < 5; j++) {
-        const int row = 8 * (wave + 8 * j) + rsub;
+    for (int j = 0; j < XJ; j++) {
+        const int row = 8 * (wave + NW * j) + rsub;
         const int lch = (((pch >> 1) ^ ((row >> 1) & 3)) << 1) | (pch & 1);
         xhy[j] = row / HP; xhx[j] = row - xhy[j] * HP;
         xl[j] = ((xhy[j] * p.W + xhx[j]) * p.ldx + p.xoff + ci0 + lch * 8) * 2;
-        if (xhx[j] >= HW) xhx[j] = 1 << 20;            // the 5 unused rows of a halo line: never inside the image
+        if (xhx[j] >= HW) xhx[j] = 1 << 20;            // the unused rows of a halo line: never inside the image
     }
+    // pieces this wave issues per block (wave-uniform): what "one block may still fly" means to its vmcnt
+    const int mine = ((C::YP - 1 - wave) / NW + 1) + ((C::XP - 1 - wave) / NW + 1);
     auto issue = [&](int b, int stage) {                // b: absolute block number (wave-uniform)
         const int n = fdiv(b, p.dT);
         const int t = b - n * (p.TY * p.TX);
@@ -529,15 +543,17 @@ __global__ __launch_bounds__(ts::NT) void wgrad_ts_kernel(const TsParams p) {
         const int xbase = ((n * p.H + Y0 - 1) * p.W + X0 - 1) * p.ldx * 2;
         const uint32_t d0 = lds0 + stage * STAGE;
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const bool ok = Y0 + ypy[j] < p.Ho && X0 + ypx[j] < p.Wo;
-            lds_dma16(rs_y, d0 + (wave + 8 * j) * 1024, ok ? (uint32_t)(ybase + yl[j]) : OOB);
+        for (int j = 0; j < YJ; j++) {
+            if ((j + 1) * NW <= C::YP || wave + NW * j < C::YP) {
+                const bool ok = Y0 + ypy[j] < p.Ho && X0 + ypx[j] < p.Wo;
+                lds_dma16(rs_y, d0 + (wave + NW * j) * 1024, ok ? (uint32_t)(ybase + yl[j]) : OOB);
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
-            if (j < 4 || wave == 0) {
+        for (int j = 0; j < XJ; j++) {
+            if ((j + 1) * NW <= C::XP || wave + NW * j < C::XP) {
                 const bool ok = (unsigned)(Y0 - 1 + xhy[j]) < (unsigned)p.H && (unsigned)(X0 - 1 + xhx[j]) < (unsigned)p.W;
-                lds_dma16(rs_x, d0 + Y_BYTES + (wave + 8 * j) * 1024, ok ? (uint32_t)(xbase + xl[j]) : OOB);
+                lds_dma16(rs_x, d0 + Y_BYTES + (wave + NW * j) * 1024, ok ? (uint32_t)(xbase + xl[j]) : OOB);
             }
         }
     };
@@ -546,21 +562,21 @@ __global__ __launch_bounds__(ts::NT) void wgrad_ts_kernel(const TsParams p) {
     // 16t + 4 (i & 3)); the rows of a k-slice are positions (py = 2 ks [+ 1], px = 4g + (i >> 2)) of the block
     const int g = lane >> 4, li = lane & 15;
     const int px = 4 * g + (li >> 2);
-    const int kh = wave >> 1, kw0 = 2 * (wave & 1);
-    int ya[4], xa[2][4];
+    const int kh = KS == 4 ? wave >> 1 : wave / 3, kw0 = KS == 4 ? 2 * (wave & 1) : wave - 3 * (wave / 3);
+    int ya[4], xa[TPW][4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         ya[t] = px * RSB + ((t ^ ((px >> 1) & 3)) << 5) + 8 * (li & 3);
 #pragma unroll
-        for (int tj = 0; tj < 2; tj++) {
+        for (int tj = 0; tj < TPW; tj++) {
             const int hrow = kh * HP + px + kw0 + tj;
             xa[tj][t] = Y_BYTES + hrow * RSB + ((t ^ ((hrow >> 1) & 3)) << 5) + 8 * (li & 3);
         }
     }
 
-    f32x4 acc[2][4][4];
+    f32x4 acc[TPW][4][4];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < TPW; a++)
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -571,10 +587,12 @@ __global__ __launch_bounds__(ts::NT) void wgrad_ts_kernel(const TsParams p) {
         if (nb > 1) issue(b_begin + 1, 1);
         int cur = 0, fill = 2;
         for (int b = 0; b < nb; b++) {
-            // block b landed (block b + 1 may still fly: 6 pieces of this wave, 7 of wave 0)
+            // block b landed (block b + 1 may still fly: `mine` pieces of this wave)
             if (b + 1 < nb) {
-                if (wave == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                if (mine == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                else if (mine == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (mine == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -583,12 +601,12 @@ __global__ __launch_bounds__(ts::NT) void wgrad_ts_kernel(const TsParams p) {
             const char* st = smem + cur * STAGE;
 #pragma unroll
             for (int pp = 0; pp < 2; pp++) {
-                bf16x8 fx[2][8], fy[2][4];
+                bf16x8 fx[2][TPW * 4], fy[2][4];
 #pragma unroll
                 for (int k2 = 0; k2 < 2; k2++) {
                     const int ks = 2 * pp + k2;
 #pragma unroll
-                    for (int tj = 0; tj < 2; tj++)
+                    for (int tj = 0; tj < TPW; tj++)
 #pragma unroll
                         for (int t = 0; t < 4; t++)
                             fx[k2][tj * 4 + t] = ts_frag(st + xa[tj][t] + 2 * ks * (HP * RSB), HP * RSB);
@@ -598,35 +616,46 @@ __global__ __launch_bounds__(ts::NT) void wgrad_ts_kernel(const TsParams p) {
 #pragma unroll
                 for (int k2 = 0; k2 < 2; k2++)
 #pragma unroll
-                    for (int i = 0; i < 8; i++)
+                    for (int i = 0; i < TPW * 4; i++)
 #pragma unroll
                         for (int j = 0; j < 4; j++)
                             acc[i >> 2][i & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[k2][i], fy[k2][j], acc[i >> 2][i & 3][j], 0, 0, 0);
-                // slice 1's transposing reads under slice 0's MFMAs (as in wgrad_kernel)
-                __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);
+                if constexpr (KS == 4) {
+                    // slice 1's transposing reads under slice 0's MFMAs (as in wgrad_kernel)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);
 #pragma unroll
-                for (int r = 0; r < 12; r++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    for (int r = 0; r < 12; r++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 40, 0);
+                } else {
+                    // 32 transposing reads, 32 MFMAs: slice 0's reads first, slice 1's under slice 0's MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 40, 0);
             }
             cur = cur == NS - 1 ? 0 : cur + 1;
             fill = fill == NS - 1 ? 0 : fill + 1;
         }
     }
 
-    // acc[tj][i][j][r] = dW[co0 + 16 j + (lane & 15)][tap 2 wave + tj][ci0 + 16 i + 4 (lane >> 4) + r]
+    // acc[tj][i][j][r] = dW[co0 + 16 j + (lane & 15)][tap TPW wave + tj][ci0 + 16 i + 4 (lane >> 4) + r]
     float* slab = p.direct ? p.dw : p.out + (size_t)split * p.Co * p.ncols;
     const bool rmw = p.direct && p.accumulate;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int co = co0 + j * 16 + (lane & 15);
 #pragma unroll
-        for (int tj = 0; tj < 2; tj++)
+        for (int tj = 0; tj < TPW; tj++)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int col = (2 * wave + tj) * p.Ci + ci0 + i * 16 + 4 * (lane >> 4);
+                const int col = (TPW * wave + tj) * p.Ci + ci0 + i * 16 + 4 * (lane >> 4);
                 f32x4* d = (f32x4*)(slab + (size_t)co * p.ncols + col);
                 f32x4 v = acc[tj][i][j];
                 if (rmw) { const f32x4 o = *d; v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
@@ -638,18 +667,29 @@ __global__ __launch_bounds__(ts::NT) void wgrad_ts_kernel(const TsParams p) {
 // the split plan of the tap-stationary route; 0: the geometry (or GCC_OPT_WGRAD_TS) keeps the layer on wgrad_kernel
 int ts_plan(const gcc_conv_t* c, int batch, int* blocks_per_split) {
     const int mode = gcc_opt(GCC_OPT_WGRAD_TS);
-    if (!mode || batch != 1 || c->KH != 4 || c->KW != 4 || c->stride != 1 || c->pad != 1) return 0;
+    const bool k4 = c->KH == 4 && c->KW == 4, k3 = c->KH == 3 && c->KW == 3;
+    if (!mode || batch != 1 || !(k4 || k3) || c->stride != 1 || c->pad != 1) return 0;
     if ((c->Ci & 63) || (c->Co & 63) || c->H < 2 || c->W < 2) return 0;
-    const int Ho = c->H - 1, Wo = c->W - 1;
+    const int Ho = k4 ? c->H - 1 : c->H, Wo = k4 ? c->W - 1 : c->W;
     const int blocks = c->N * cdiv(Ho, ts::TR) * cdiv(Wo, ts::TW);
     const int tiles = (c->Ci / 64) * (c->Co / 64);
     const int target = plan_or(c->plan.wgrad_wgs_big, PLAN_WGRAD_WGS_BIG);
     int splits = tiles >= (target * 25) / 32 ? 1 : cdiv(target, tiles);
     if (mode == 1) {
-        // worth it where a workgroup streams enough blocks for the three-stage loop, and the tiles alone nearly fill the launch
-        const int max_splits = blocks / 16;
-        if (max_splits < 1 || tiles < 32) return 0;
-        if (splits > max_splits) splits = max_splits;
+        if (k4) {
+            // worth it where a workgroup streams enough blocks for the three-stage loop, and the tiles alone nearly fill the launch
+            const int max_splits = blocks / 16;
+            if (max_splits < 1 || tiles < 32) return 0;
+            if (splits > max_splits) splits = max_splits;
+        } else {
+            // k3: a layer of few tiles (SRGAN's trunk: ONE 64 x 64 tile, 1152 blocks) fills the launch with pixel splits -- at least 8
+            // blocks each: every split is a [Co][9 Ci] fp32 slab to write and fold, and the launch runs beside the pass's chain
+            // (and at least 128 workgroups: at SRGAN's 24 x 24 training crop the trunk layer has 96 blocks -- 12 workgroups of 8 -- and
+            // the column-tiled kernel's ~100 workgroups are faster: 24 -> 96 step 12.3 -> 12.8 ms with this route, profiles/r6_wgrad_ts3.txt)
+            const int max_splits = blocks / 8;
+            if (splits > max_splits) splits = max_splits;
+            if (splits < 1 || (long)tiles * splits < 128) return 0;
+        }
     } else if (splits > blocks) {
         splits = blocks;                                   // 2: forced wherever the geometry fits (tests)
     }
@@ -790,10 +830,16 @@ int gcc_internal_wgrad(const gcc_conv_t* c, const void* x, const void* dy, float
         t.dT = make_fastdiv(t.TY * t.TX); t.dTX = make_fastdiv(t.TX);
         t.direct = tsplits == 1 ? 1 : 0; t.accumulate = accumulate;
         static std::once_flag ts_once;
+        static bool ts_attr_ok = false;
         std::call_once(ts_once, [] {
-            hipFuncSetAttribute((const void*)wgrad_ts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ts::LDS_BYTES);
+            ts_attr_ok = hipFuncSetAttribute((const void*)wgrad_ts_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, TsCfg<4>::LDS_BYTES) == hipSuccess &&
+                         hipFuncSetAttribute((const void*)wgrad_ts_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, TsCfg<3>::LDS_BYTES) == hipSuccess;
         });
-        hipLaunchKernelGGL(wgrad_ts_kernel, dim3(t.ci_tiles * t.co_tiles, 1, tsplits), dim3(ts::NT), ts::LDS_BYTES, st, t);
+        if (!ts_attr_ok) return GCC_ERR_LAUNCH;
+        if (c->KH == 4)
+            hipLaunchKernelGGL(wgrad_ts_kernel<4>, dim3(t.ci_tiles * t.co_tiles, 1, tsplits), dim3(TsCfg<4>::NT), TsCfg<4>::LDS_BYTES, st, t);
+        else
+            hipLaunchKernelGGL(wgrad_ts_kernel<3>, dim3(t.ci_tiles * t.co_tiles, 1, tsplits), dim3(TsCfg<3>::NT), TsCfg<3>::LDS_BYTES, st, t);
         GCC_CHECK_LAUNCH();
         if (t.direct) return GCC_OK;
         const size_t n4 = (size_t)c->Co * p.ncols / 4;
@@ -928,6 +974,8 @@ bool group_item_ok(const gcc_wgrad_item_t* it) {
     const size_t M = (size_t)c->N * Ho * Wo;
     if ((size_t)c->N * c->H * c->W * c->ldx * 2 >= OOB || M * c->ldy * 2 >= OOB || M >= (1u << 30)) return false;
     if (head_wgrad_workspace(c) || gcc_internal_thinout_wgrad_workspace(c)) return false;      // routes of their own
+    int tper = 0;
+    if (ts_plan(c, 1, &tper) > 0) return false;                       // the tap-stationary route: a launch of its own
     return true;
 }
 // Pixel splits for the group as a whole: every workgroup gets about S k-steps, S such that the group is ~2 rounds of the chip's

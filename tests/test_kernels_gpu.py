@@ -169,17 +169,26 @@ def test_conv_fprop_dgrad_wgrad(case, plan, conv_plan):
     close(dw.cpu(), 2 * wr.grad, tol=5e-3, floor=1e-4, what='wgrad accumulate')
 
 
-# wgrad_ts_kernel (conv_wgrad.hip): the tap-stationary k4 s1 p1 weight gradient.  GCC_OPT_WGRAD_TS = 2 routes every fitting
+# wgrad_ts_kernel (conv_wgrad.hip): the tap-stationary k4 s1 p1 / k3 s1 p1 weight gradient.  GCC_OPT_WGRAD_TS = 2 routes every fitting
 # geometry to it; WGS_BIG sets the number of pixel splits (1 = direct write / accumulate into dW, more = slabs + fold).
 TS_CASES = [
-    # N, H, W, Ci, Co, workgroups aimed at
-    (2, 9, 21, 64, 64, 1),          # one channel tile, ragged 8 x 16 blocks (Ho = 8, Wo = 20), no split: direct write
-    (2, 9, 21, 64, 64, 4),          # ... 4 blocks over 4 splits: a single block per workgroup
-    (3, 32, 32, 128, 64, 2),        # 31 x 31 outputs on the 32 x 32 block grid: 24 blocks, one split
-    (3, 32, 32, 128, 64, 12),       # ... 6 splits of 4 blocks (the three-stage loop with its tail)
-    (1, 5, 40, 64, 192, 9),         # short image (one block row of 4 lines), 3 blocks per image
-    (2, 17, 17, 192, 128, 6),       # Ho = Wo = 16: exactly one block wide, two deep
-    (16, 32, 32, 512, 1024, 256),   # the discriminators' L4 at the headline batch (the layer the kernel exists for), 2 splits
+    # k, N, H, W, Ci, Co, workgroups aimed at
+    (4, 2, 9, 21, 64, 64, 1),          # one channel tile, ragged 8 x 16 blocks (Ho = 8, Wo = 20), no split: direct write
+    (4, 2, 9, 21, 64, 64, 4),          # ... 4 blocks over 4 splits: a single block per workgroup
+    (4, 3, 32, 32, 128, 64, 2),        # 31 x 31 outputs on the 32 x 32 block grid: 24 blocks, one split
+    (4, 3, 32, 32, 128, 64, 12),       # ... 6 splits of 4 blocks (the three-stage loop with its tail)
+    (4, 1, 5, 40, 64, 192, 9),         # short image (one block row of 4 lines), 3 blocks per image
+    (4, 2, 17, 17, 192, 128, 6),       # Ho = Wo = 16: exactly one block wide, two deep
+    (4, 16, 32, 32, 512, 1024, 256),   # the discriminators' L4 at the headline batch (the layer the kernel exists for), 2 splits
+    # k3 s1 p1 (round 6): nine waves, one tap each
+    (3, 2, 9, 21, 64, 64, 1),          # ragged blocks (9 x 21 outputs on 8 x 16 blocks), no split: direct write
+    (3, 2, 9, 21, 64, 64, 8),          # ... 8 blocks over 8 splits: a single block per workgroup
+    (3, 3, 32, 32, 128, 64, 2),        # 24 blocks, one split per tile
+    (3, 3, 32, 32, 128, 64, 12),       # ... 6 splits of 4 blocks
+    (3, 1, 5, 40, 64, 192, 9),         # short image, three channel tiles
+    (3, 2, 16, 16, 192, 128, 6),       # exactly one block wide, two deep
+    (3, 16, 96, 96, 64, 64, 144),      # SRGAN's trunk layer at the 96 -> 384 size (the layer this form exists for): 144 splits of 8 blocks
+    (3, 4, 192, 192, 64, 128, 64),     # a stride-1 layer of its discriminator (N = 4 of 16)
 ]
 
 
@@ -188,11 +197,12 @@ def test_wgrad_tap_stationary(case):
     ops = _ops()
     from gcc_amd import _lib
     lib = _lib.load()
-    N, H, W, Ci, Co, wgs = case
+    k, N, H, W, Ci, Co, wgs = case
     g = torch.Generator().manual_seed(sum(case))
     x = rb(torch.randn(N, Ci, H, W, generator=g))
-    dy = rb(torch.randn(N, Co, H - 1, W - 1, generator=g))
-    w = torch.zeros(Co, Ci, 4, 4, requires_grad=True)
+    Ho, Wo = (H - 1, W - 1) if k == 4 else (H, W)
+    dy = rb(torch.randn(N, Co, Ho, Wo, generator=g))
+    w = torch.zeros(Co, Ci, k, k, requires_grad=True)
     F.conv2d(x, w, None, stride=1, padding=1).backward(dy)
     xd, dyd = to_dev(x), to_dev(dy)
     m = master_cl(w.detach())
@@ -201,13 +211,13 @@ def test_wgrad_tap_stationary(case):
         lib.gcc_set_option(_lib.OPT_WGRAD_TS, 2)
         dw = torch.full_like(m, 7.0)                 # stale contents must not survive a fresh gradient
         ops.lib().gcc_launch_count(1)
-        ops.conv_wgrad(xd, dyd, dw, 4, 1, 1, accumulate=False)
+        ops.conv_wgrad(xd, dyd, dw, k, 1, 1, accumulate=False)
         launches = int(ops.lib().gcc_launch_count(1))
-        ops.conv_wgrad(xd, dyd, dw, 4, 1, 1, accumulate=True)
+        ops.conv_wgrad(xd, dyd, dw, k, 1, 1, accumulate=True)
         torch.cuda.synchronize()
         lib.gcc_set_option(_lib.OPT_WGRAD_TS, 0)
         dw0 = torch.zeros_like(m)
-        ops.conv_wgrad(xd, dyd, dw0, 4, 1, 1, accumulate=False)
+        ops.conv_wgrad(xd, dyd, dw0, k, 1, 1, accumulate=False)
         torch.cuda.synchronize()
     finally:
         lib.gcc_set_option(_lib.OPT_WGRAD_TS, -1)
