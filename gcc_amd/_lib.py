@@ -8,9 +8,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GCC_HIP_LIB') or os.path.join(_HERE, 'libgcc_hip.so')     # GCC_HIP_LIB: another build of the same ABI (A/B runs)
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
-GCC_HIP_ABI = 602
+GCC_HIP_ABI = 603
 WGRAD_GROUP_MAX = 32     # include/gcc_hip.h GCC_WGRAD_GROUP_MAX
 CHANSUM_GROUP_MAX = 24   # include/gcc_hip.h GCC_CHANSUM_GROUP_MAX
+SPECTRAL_GROUP_MAX = 8    # include/gcc_hip.h GCC_SPECTRAL_GROUP_MAX
 CHANSUM_SMALL_MAX_PIXELS = 16384     # include/gcc_hip.h GCC_HIP_ABI: the generation of struct layouts / option ids these bindings were written for
 
 
@@ -40,6 +41,12 @@ class chansum_item_t(C.Structure):
     """include/gcc_hip.h gcc_chansum_item_t"""
     _fields_ = [('x', C.c_void_p), ('ld', C.c_int), ('off', C.c_int), ('C', C.c_int), ('pixels', C.c_size_t), ('out', C.c_void_p),
                 ('accumulate', C.c_int)]
+
+
+class sn_item_t(C.Structure):
+    """include/gcc_hip.h gcc_sn_item_t: one layer of a grouped spectral-norm power iteration"""
+    _fields_ = [('w_bar', C.c_void_p), ('u', C.c_void_p), ('v', C.c_void_p), ('R', C.c_int), ('C', C.c_int), ('T', C.c_int),
+                ('t_out', C.c_void_p), ('sigma_out', C.c_void_p), ('w', C.c_void_p), ('wt', C.c_void_p)]
 
 
 class epilogue_t(C.Structure):
@@ -179,6 +186,8 @@ PROTOTYPES = {
     'gcc_spectral_workspace': (_Z, [_I, _I, _I]),
     'gcc_spectral_power_iteration': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     'gcc_spectral_power_iteration_pack': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    'gcc_spectral_group_workspace': (_Z, [C.POINTER(sn_item_t), _I]),
+    'gcc_spectral_power_iteration_pack_group': (_I, [C.POINTER(sn_item_t), _I, _P, _Z, _P]),
     'gcc_spectral_grad': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     'gcc_resample_u8': (_I, [_P, _I, _I, _Z, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P]),
     'gcc_crop_flip_normalize': (_I, [_P, _I, _I, _Z, _I, _I, _I, _I, _I, _P, _P, _I, _P]),

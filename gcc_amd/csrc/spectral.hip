@@ -45,11 +45,10 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 // vt[p] = sum_r W[r][p] * u[r] * scale_by   (p physical column).
 // A workgroup owns 64 columns; its 16 waves split the rows (a wave reads 256 contiguous bytes of one row), so the serial
 // depth is R / 16 and the sum order is fixed.
-__global__ __launch_bounds__(1024) void sn_wtu_kernel(const float* __restrict__ w, const float* __restrict__ u, int R, int K,
-                                                      float* __restrict__ vt, float scale_by) {
-    __shared__ float red[16][65];
+__device__ __forceinline__ void sn_wtu_body(const float* __restrict__ w, const float* __restrict__ u, int R, int K,
+                                            float* __restrict__ vt, float scale_by, int block, float (*red)[65]) {
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int p = blockIdx.x * 64 + cl;
+    const int p = block * 64 + cl;
     float a0 = 0.f, a1 = 0.f;
     if (p < K) {
         int r = rg;
@@ -69,13 +68,16 @@ __global__ __launch_bounds__(1024) void sn_wtu_kernel(const float* __restrict__ 
         if (p < K) vt[p] = acc;
     }
 }
+__global__ __launch_bounds__(1024) void sn_wtu_kernel(const float* __restrict__ w, const float* __restrict__ u, int R, int K,
+                                                      float* __restrict__ vt, float scale_by) {
+    __shared__ float red[16][65];
+    sn_wtu_body(w, u, R, K, vt, scale_by, blockIdx.x, red);
+}
 
 // t[r] = sum_p W[r][p] * vt[p] / (|vt| + eps).  Every row's workgroup sums |vt|^2 itself, in the same fixed order: no
 // atomics anywhere in the power iteration, so sigma -- and every weight divided by it -- is reproducible bit for bit.
-__global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w, const float* __restrict__ vt, int K,
-                                                    float* scal, float* __restrict__ t) {
-    __shared__ float sh[4];
-    const int r = blockIdx.x;
+__device__ __forceinline__ void sn_wv_body(const float* __restrict__ w, const float* __restrict__ vt, int K, float* scal,
+                                           float* __restrict__ t, int r, float* sh) {
     float acc = 0.f, n2 = 0.f;
     for (int p = threadIdx.x; p < K; p += 256) {
         const float x = vt[p];
@@ -89,21 +91,25 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w,
         if (r == 0) scal[0] = n2;
     }
 }
+__global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w, const float* __restrict__ vt, int K,
+                                                    float* scal, float* __restrict__ t) {
+    __shared__ float sh[4];
+    sn_wv_body(w, vt, K, scal, t, blockIdx.x, sh);
+}
 
 // u, v, sigma
-__global__ __launch_bounds__(256) void sn_finalize_kernel(SnArgs a) {
-    __shared__ float sh[4];
+__device__ __forceinline__ void sn_finalize_body(const SnArgs& a, int block, int nblk, float* sh) {
     const int K = a.C * a.T;
     float t2 = 0.f;
     for (int r = threadIdx.x; r < a.R; r += 256) t2 += a.t[r] * a.t[r];
     t2 = block_sum(t2, sh);                      // |t|^2, the same bits in every workgroup
     const float inv_v = 1.f / (sqrtf(a.scal[0]) + 1e-12f);
     const float inv_t = 1.f / (sqrtf(t2) + 1e-12f);
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < K; p += gridDim.x * 256) {
+    for (int p = block * 256 + threadIdx.x; p < K; p += nblk * 256) {
         const int tt = p / a.C, c = p - tt * a.C;
         a.v[c * a.T + tt] = a.vt[p] * inv_v;
     }
-    if (blockIdx.x == 0) {
+    if (block == 0) {
         for (int r = threadIdx.x; r < a.R; r += 256) a.u[r] = a.t[r] * inv_t;
         if (threadIdx.x == 0) {
             a.scal[1] = t2; a.scal[2] = t2 * inv_t;                            // u . t = |t|^2 / (|t| + eps)
@@ -111,18 +117,20 @@ __global__ __launch_bounds__(256) void sn_finalize_kernel(SnArgs a) {
         }
     }
 }
+__global__ __launch_bounds__(256) void sn_finalize_kernel(SnArgs a) {
+    __shared__ float sh[4];
+    sn_finalize_body(a, blockIdx.x, gridDim.x, sh);
+}
 
 // W_eff = W_bar / sigma straight into the two bf16 packings the convolutions read (W [R][T][Cp], Wt [C][T][Rp], channel counts
 // padded to 8 with zeros): a 32 x 32 tile of one tap per workgroup, transposed through LDS -- the scale launch, the fp32 W_eff
 // round trip and the two pack launches of the separate route in one (round 4: the SAGAN iteration is a chain of ~5 us launches;
 // this is 3 of the 7 a spectrally normalised convolution's forward spent before its convolution).  Same bits: bf16(w * (1/sigma)).
-__global__ __launch_bounds__(256) void sn_scale_pack_kernel(const float* __restrict__ m, const float* scal, int rows, int taps,
-                                                            int cols, int colsp, int rowsp, unsigned short* __restrict__ w,
-                                                            unsigned short* __restrict__ wt) {
-    __shared__ float t[32][33];
+__device__ __forceinline__ void sn_scale_pack_body(const float* __restrict__ m, const float* scal, int rows, int taps, int cols,
+                                                   int colsp, int rowsp, unsigned short* __restrict__ w,
+                                                   unsigned short* __restrict__ wt, int bx, int by, int tap, float (*t)[33]) {
     const float inv = 1.f / scal[2];
-    const int tap = blockIdx.z;
-    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int r0 = by * 32, c0 = bx * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int k = ty; k < 32; k += 8) {
         const int r = r0 + k, c = c0 + tx;
@@ -135,6 +143,59 @@ __global__ __launch_bounds__(256) void sn_scale_pack_kernel(const float* __restr
         const int c = c0 + k, r = r0 + tx;
         if (c < cols && r < rowsp) wt[((size_t)c * taps + tap) * rowsp + r] = f2bf(t[tx][k]);   // rows rows..rowsp-1: zeros
     }
+}
+__global__ __launch_bounds__(256) void sn_scale_pack_kernel(const float* __restrict__ m, const float* scal, int rows, int taps,
+                                                            int cols, int colsp, int rowsp, unsigned short* __restrict__ w,
+                                                            unsigned short* __restrict__ wt) {
+    __shared__ float t[32][33];
+    sn_scale_pack_body(m, scal, rows, taps, cols, colsp, rowsp, w, wt, blockIdx.x, blockIdx.y, blockIdx.z, t);
+}
+
+// ---- the power iterations of several layers (every spectrally normalised convolution of one network's forward pass) as FOUR
+// launches instead of four per layer (round 6): a workgroup finds its layer by its block number; per layer the arithmetic, its
+// order and the workgroup shapes are those of the kernels above, so the results are the same bits.
+struct SnGroupItem {
+    SnArgs a;
+    unsigned short* pw; unsigned short* pwt;
+    int K, colsp, rowsp, gx, gy;
+    int b1, b2, b3, b4;            // this layer's first block in the four launches
+    int n3;                        // its blocks in the third one
+};
+struct SnGroupArgs { int n; int pad; SnGroupItem it[GCC_SPECTRAL_GROUP_MAX]; };
+__device__ __forceinline__ int sn_group_find(const SnGroupArgs& g, int b, int phase) {
+    int i = 0;
+    for (int q = 1; q < g.n; q++) {
+        const int first = phase == 1 ? g.it[q].b1 : (phase == 2 ? g.it[q].b2 : (phase == 3 ? g.it[q].b3 : g.it[q].b4));
+        if (b >= first) i = q;
+    }
+    return i;
+}
+__global__ __launch_bounds__(1024) void sn_wtu_group_kernel(const SnGroupArgs g) {
+    __shared__ float red[16][65];
+    const int i = sn_group_find(g, blockIdx.x, 1);
+    const SnGroupItem& it = g.it[i];
+    sn_wtu_body(it.a.w, it.a.u, it.a.R, it.K, it.a.vt, 1.f, blockIdx.x - it.b1, red);
+}
+__global__ __launch_bounds__(256) void sn_wv_group_kernel(const SnGroupArgs g) {
+    __shared__ float sh[4];
+    const int i = sn_group_find(g, blockIdx.x, 2);
+    const SnGroupItem& it = g.it[i];
+    sn_wv_body(it.a.w, it.a.vt, it.K, it.a.scal, it.a.t, blockIdx.x - it.b2, sh);
+}
+__global__ __launch_bounds__(256) void sn_finalize_group_kernel(const SnGroupArgs g) {
+    __shared__ float sh[4];
+    const int i = sn_group_find(g, blockIdx.x, 3);
+    const SnGroupItem& it = g.it[i];
+    sn_finalize_body(it.a, blockIdx.x - it.b3, it.n3, sh);
+}
+__global__ __launch_bounds__(256) void sn_scale_pack_group_kernel(const SnGroupArgs g) {
+    __shared__ float t[32][33];
+    const int i = sn_group_find(g, blockIdx.x, 4);
+    const SnGroupItem& it = g.it[i];
+    int b = blockIdx.x - it.b4;
+    const int bx = b % it.gx; b /= it.gx;
+    const int by = b % it.gy, tap = b / it.gy;
+    sn_scale_pack_body(it.a.w, it.a.scal, it.a.R, it.a.T, it.a.C, it.colsp, it.rowsp, it.pw, it.pwt, bx, by, tap, t);
 }
 
 __global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__ w, const float* scal, float* __restrict__ w_eff,
@@ -250,6 +311,55 @@ extern "C" int gcc_spectral_power_iteration_pack(const float* w_bar, float* u, f
     const int colsp = (C + 7) & ~7, rowsp = (R + 7) & ~7;
     hipLaunchKernelGGL(sn_scale_pack_kernel, dim3((colsp + 31) / 32, (rowsp + 31) / 32, T), dim3(256), 0, st, w_bar,
                        (const float*)scal, R, T, C, colsp, rowsp, (unsigned short*)w, (unsigned short*)wt);
+    GCC_CHECK_LAUNCH();
+    return GCC_OK;
+}
+
+static size_t sn_item_ws(const gcc_sn_item_t& it) { return (gcc_spectral_workspace(it.R, it.C, it.T) + 255) & ~(size_t)255; }
+extern "C" size_t gcc_spectral_group_workspace(const gcc_sn_item_t* items, int n) {
+    if (!items || n < 1 || n > GCC_SPECTRAL_GROUP_MAX) return 0;
+    size_t total = 0;
+    for (int i = 0; i < n; i++) {
+        if (items[i].R <= 0 || items[i].C <= 0 || items[i].T <= 0) return 0;
+        total += sn_item_ws(items[i]);
+    }
+    return total;
+}
+
+extern "C" int gcc_spectral_power_iteration_pack_group(const gcc_sn_item_t* items, int n, void* ws, size_t ws_bytes,
+                                                       gcc_stream_t stream) {
+    GCC_ENTER();
+    if (!items || n < 1 || n > GCC_SPECTRAL_GROUP_MAX || !ws || (((uintptr_t)ws) & 15)) return GCC_ERR_BAD_ARG;
+    const size_t need = gcc_spectral_group_workspace(items, n);
+    if (!need) return GCC_ERR_BAD_ARG;
+    if (ws_bytes < need) return GCC_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    SnGroupArgs g;
+    g.n = n; g.pad = 0;
+    int b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+    char* wsp = (char*)ws;
+    for (int i = 0; i < n; i++) {
+        const gcc_sn_item_t& q = items[i];
+        if (!q.w_bar || !q.u || !q.v || !q.t_out || !q.sigma_out || !q.w || !q.wt) return GCC_ERR_BAD_ARG;
+        SnGroupItem& it = g.it[i];
+        float* scal = (float*)wsp;
+        it.a.w = q.w_bar; it.a.u = q.u; it.a.v = q.v; it.a.R = q.R; it.a.C = q.C; it.a.T = q.T;
+        it.a.vt = scal + 64; it.a.t = q.t_out; it.a.scal = scal; it.a.w_eff = nullptr; it.a.sigma_out = q.sigma_out;
+        it.pw = (unsigned short*)q.w; it.pwt = (unsigned short*)q.wt;
+        it.K = q.C * q.T; it.colsp = (q.C + 7) & ~7; it.rowsp = (q.R + 7) & ~7;
+        it.gx = (it.colsp + 31) / 32; it.gy = (it.rowsp + 31) / 32;
+        it.b1 = b1; it.b2 = b2; it.b3 = b3; it.b4 = b4;
+        it.n3 = nblocks(it.K, 64);
+        b1 += (it.K + 63) / 64; b2 += q.R; b3 += it.n3; b4 += it.gx * it.gy * q.T;
+        wsp += sn_item_ws(q);
+    }
+    hipLaunchKernelGGL(sn_wtu_group_kernel, dim3(b1), dim3(1024), 0, st, g);
+    GCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sn_wv_group_kernel, dim3(b2), dim3(256), 0, st, g);
+    GCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sn_finalize_group_kernel, dim3(b3), dim3(256), 0, st, g);
+    GCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sn_scale_pack_group_kernel, dim3(b4), dim3(256), 0, st, g);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

@@ -38,6 +38,8 @@ FUSE_CONV_BN = os.environ.get('GCC_FUSE_CONV_BN', '1') != '0'
 # one launch + one fold per group) instead of one launch + fold per layer -- the U-Net's up path when its last data gradient is
 # enqueued, its down path at the end of the pass.  0: per layer, as before round 6.
 WGRAD_GROUP = os.environ.get('GCC_WGRAD_GROUP', '1') != '0'
+# the power iterations of a SAGAN pass's spectrally normalised layers as four grouped launches (SNConvOp.iterate_all); 0: four per layer
+SN_GROUP = os.environ.get('GCC_SN_GROUP', '1') != '0'
 WGRAD_GROUP_MAX_UNITS = int(os.environ.get('GCC_WGRAD_GROUP_MAX_UNITS', '20000'))
 
 
@@ -1214,8 +1216,22 @@ class SNConvOp:
     def new_state(self):
         return SNState(self)
 
-    def forward(self, st, x, out, act=ACT_NONE, slope=LRELU, want_stats=False, bn=None):
-        if ops.SN_FUSED_PACK and self.w_bar.data.is_contiguous(memory_format=torch.channels_last if self.k > 1 else torch.contiguous_format):
+    def fused_pack_ok(self):
+        return ops.SN_FUSED_PACK and self.w_bar.data.is_contiguous(memory_format=torch.channels_last if self.k > 1 else torch.contiguous_format)
+
+    @staticmethod
+    def iterate_all(pairs):
+        """the power iterations of a forward pass's layers [(SNConvOp, SNState)] up front, grouped (they depend on the weights alone):
+        four launches instead of four per layer; True when done -- the layers' forward(..., iterated=True) then skip their own"""
+        if not SN_GROUP or len(pairs) < 2 or not all(op.fused_pack_ok() for op, _ in pairs):
+            return False
+        ops.spectral_power_iteration_pack_group([(op.w_bar.data, op.u.data, op.v.data, st.t, st.sigma, st.w, st.wt) for op, st in pairs])
+        return True
+
+    def forward(self, st, x, out, act=ACT_NONE, slope=LRELU, want_stats=False, bn=None, iterated=False):
+        if iterated:
+            pass
+        elif self.fused_pack_ok():
             ops.spectral_power_iteration_pack(self.w_bar.data, self.u.data, self.v.data, st.t, st.sigma, st.w, st.wt)
         else:
             ops.spectral_power_iteration(self.w_bar.data, self.u.data, self.v.data, st.t, st.sigma, self.w_eff)
@@ -1363,12 +1379,13 @@ class SaganGeneratorEngine:
         """z already in c.z (NHWC [N,1,1,z_dim]); returns c (c.out = tanh image)"""
         c.train = train
         src = c.z
+        it = SNConvOp.iterate_all([(self.sn[i], c.sn[i]) for i in range(4)])
         for i in range(4):
             n = c.N * c.size[i] * c.size[i]
             if train:
-                self.sn[i].forward(c.sn[i], src, c.raw[i], want_stats=True, bn=self.bn[i].desc(c.bn[i], n, self.device))
+                self.sn[i].forward(c.sn[i], src, c.raw[i], want_stats=True, bn=self.bn[i].desc(c.bn[i], n, self.device), iterated=it)
             else:
-                _, stats = self.sn[i].forward(c.sn[i], src, c.raw[i], want_stats=True)
+                _, stats = self.sn[i].forward(c.sn[i], src, c.raw[i], want_stats=True, iterated=it)
                 self.bn[i].finalize(stats, n, c.bn[i], train)
             ops.bnact_fwd(c.raw[i], c.act[i], scale=c.bn[i].scale, shift=c.bn[i].shift, act=ACT_RELU)
             src = c.act[i]
@@ -1471,8 +1488,9 @@ class SaganDiscriminatorEngine:
         if self.masked:
             self.refresh_masks()
         src = c.x_in
+        it = SNConvOp.iterate_all([(self.sn[i], c.sn[i]) for i in range(4)])
         for i in range(4):
-            self.sn[i].forward(c.sn[i], src, c.raw[i])
+            self.sn[i].forward(c.sn[i], src, c.raw[i], iterated=it)
             ops.bnact_fwd(c.raw[i], c.act[i], gate=self.mask[i], act=ACT_LRELU, slope=self.SLOPE)
             src = c.act[i]
             if i >= 2:

@@ -1159,6 +1159,21 @@ def spectral_power_iteration_pack(w_bar, u, v, t_out, sigma_out, w, wt, slot='sn
                                                   stream()), 'gcc_spectral_power_iteration_pack')
 
 
+def spectral_power_iteration_pack_group(entries, slot='sn_group'):
+    """[(w_bar, u, v, t_out, sigma_out, w, wt)]: spectral_power_iteration_pack of every entry, all of them in four launches per
+    SPECTRAL_GROUP_MAX layers (gcc_spectral_power_iteration_pack_group: the same bits)"""
+    for i in range(0, len(entries), _lib.SPECTRAL_GROUP_MAX):
+        part = entries[i:i + _lib.SPECTRAL_GROUP_MAX]
+        items = (_lib.sn_item_t * len(part))()
+        for it, (w_bar, u, v, t_out, sigma_out, w, wt) in zip(items, part):
+            R, Cc, kh, kw = w_bar.shape
+            it.w_bar, it.u, it.v, it.R, it.C, it.T = w_bar.data_ptr(), u.data_ptr(), v.data_ptr(), R, Cc, kh * kw
+            it.t_out, it.sigma_out, it.w, it.wt = t_out.data_ptr(), sigma_out.data_ptr(), w.data_ptr(), wt.data_ptr()
+        ws = workspace(lib().gcc_spectral_group_workspace(items, len(part)), part[0][0].device, slot)
+        check(lib().gcc_spectral_power_iteration_pack_group(items, len(part), ws.data_ptr(), ws.numel(), stream()),
+              'gcc_spectral_power_iteration_pack_group')
+
+
 def spectral_grad(g_eff, w_bar, u, v, t_fwd, sigma_fwd, dw_bar, du=None, dv=None, slot='sn_bwd'):
     R, Cc, kh, kw = w_bar.shape
     ws = workspace(lib().gcc_spectral_workspace(R, Cc, kh * kw), w_bar.device, slot)

@@ -44,7 +44,7 @@ enum { GCC_ACT_NONE = 0, GCC_ACT_LRELU = 1, GCC_ACT_RELU = 2, GCC_ACT_TANH = 3 }
 /* ABI generation of this header: bumped whenever a struct layout, an enum numbering or a prototype below changes.  gcc_version()
  * of the library a host loads must return exactly this number (gcc_amd/_lib.py refuses any other; an external host should check it
  * the same way): a stale .so reads gcc_conv_t.plan past its struct and sets the wrong option ids without any error. */
-#define GCC_HIP_ABI 602
+#define GCC_HIP_ABI 603
 
 const char* gcc_strerror(int code);
 int gcc_version(void); /* == GCC_HIP_ABI of the header the library was built from */
@@ -525,6 +525,23 @@ int gcc_spectral_power_iteration(const float* w_bar, float* u, float* v, int R, 
  * forward does before its convolution (SpectralNorm.forward, models/SAGAN.py:56-70); same bits as the separate calls */
 int gcc_spectral_power_iteration_pack(const float* w_bar, float* u, float* v, int R, int C, int T, float* t_out,
                                       float* sigma_out, void* w, void* wt, void* ws, size_t ws_bytes, gcc_stream_t stream);
+/* the power iterations + packings of several layers (every spectrally normalised convolution of one network's forward pass:
+ * the iterations depend on the weights alone, not on the activations) as FOUR launches instead of four per layer; entry i is
+ * gcc_spectral_power_iteration_pack(w_bar, u, v, R, C, T, t_out, sigma_out, w, wt, ..) bit for bit.  n <= GCC_SPECTRAL_GROUP_MAX;
+ * ws: gcc_spectral_group_workspace(items, n) bytes (every layer its own scratch), 16-byte aligned. */
+#define GCC_SPECTRAL_GROUP_MAX 8
+typedef struct {
+    const float* w_bar;
+    float* u;
+    float* v;
+    int R, C, T;
+    float* t_out;
+    float* sigma_out;
+    void* w;
+    void* wt;
+} gcc_sn_item_t;
+size_t gcc_spectral_group_workspace(const gcc_sn_item_t* items, int n);
+int gcc_spectral_power_iteration_pack_group(const gcc_sn_item_t* items, int n, void* ws, size_t ws_bytes, gcc_stream_t stream);
 int gcc_spectral_grad(const float* g_eff, const float* w_bar, const float* u, const float* v, const float* t_fwd,
                       const float* sigma_fwd, int R, int C, int T, float* dw_bar, float* du, float* dv, void* ws,
                       size_t ws_bytes, gcc_stream_t stream);

@@ -380,7 +380,8 @@ def test_struct_layouts_match_header(tmp_path):
     from gcc_amd import _lib
     pairs = [('gcc_conv_plan_t', _lib.conv_plan_t, 'wgrad_wgs'), ('gcc_conv_t', _lib.conv_t, 'plan'), ('gcc_epilogue_t', _lib.epilogue_t, 'y2_gate'),
              ('gcc_bn_t', _lib.bn_t, None), ('gcc_adam_tensor_t', _lib.adam_tensor_t, None), ('gcc_adam_chunk_t', _lib.adam_chunk_t, 'offset'),
-             ('gcc_bnact_t', _lib.bnact_t, None)]
+             ('gcc_bnact_t', _lib.bnact_t, None), ('gcc_sn_item_t', _lib.sn_item_t, 'wt'), ('gcc_chansum_item_t', _lib.chansum_item_t, 'accumulate'),
+             ('gcc_wgrad_item_t', _lib.wgrad_item_t, 'accumulate')]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "gcc_hip.h"\nint main(void) {\n'
     for cname, _, last in pairs:
         src += '  printf("%s %%zu %%zu\\n", sizeof(%s), %s);\n' % (cname, cname, 'offsetof(%s, %s)' % (cname, last) if last else '(size_t)0')

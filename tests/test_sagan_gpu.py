@@ -97,6 +97,49 @@ def test_spectral_power_iteration_fused_with_the_packings(shape):
     assert b[6] == 4 and a[6] >= 6, (a[6], b[6])
 
 
+def test_grouped_spectral_power_iterations_are_the_single_calls_bit_for_bit():
+    """gcc_spectral_power_iteration_pack_group (the power iterations of all spectrally normalised layers of a forward pass: four
+    launches) against one gcc_spectral_power_iteration_pack per layer: u, v, t, sigma and both packings of every layer bit for
+    bit -- eleven layers (two groups of <= 8), the shapes of the single-call test plus SAGAN's own"""
+    from gcc_amd import ops, _lib
+    shapes = [(32, 16, 4, 4), (128, 24, 4, 4), (8, 3, 4, 4), (100, 52, 3, 3), (48, 48, 1, 1), (1, 384, 4, 4),
+              (128, 512, 4, 4), (512, 256, 4, 4), (256, 128, 4, 4), (64, 3, 4, 4), (128, 64, 4, 4)]
+    assert len(shapes) > _lib.SPECTRAL_GROUP_MAX
+    g = torch.Generator().manual_seed(5)
+    layers = []
+    for shape in shapes:
+        R, Cc, k, _ = shape
+        w = (torch.randn(shape, generator=g) * 0.1).to(DEV)
+        wd = w.contiguous(memory_format=torch.channels_last) if k > 1 else w.contiguous()
+        layers.append((wd, torch.randn(R, generator=g).to(DEV), torch.randn(Cc * k * k, generator=g).to(DEV)))
+
+    def fresh():
+        out = []
+        for wd, u0, v0 in layers:
+            R, Cc, k, _ = wd.shape
+            pw = torch.full((ops.ceil8(R), k * k, ops.ceil8(Cc)), 7.0, dtype=torch.bfloat16, device=DEV)
+            pwt = torch.full((ops.ceil8(Cc), k * k, ops.ceil8(R)), 7.0, dtype=torch.bfloat16, device=DEV)
+            pw[R:] = 0
+            out.append((wd, u0.clone(), v0.clone(), torch.zeros(R, device=DEV), torch.zeros(1, device=DEV), pw, pwt))
+        return out
+    single, grouped = fresh(), fresh()
+    for e in single:
+        ops.spectral_power_iteration_pack(*e)
+    ops.lib().gcc_launch_count(1)
+    for rep in range(2):                             # (a second iteration on the moved u, v: the scratch of a group is reused)
+        if rep:
+            for e in single:
+                ops.spectral_power_iteration_pack(*e)
+            ops.lib().gcc_launch_count(1)
+        ops.spectral_power_iteration_pack_group(grouped)
+        n = int(ops.lib().gcc_launch_count(1))
+        torch.cuda.synchronize()
+        assert n == 8, n
+        for a, b, shape in zip(single, grouped, shapes):
+            for x, y, what in zip(a[1:], b[1:], ('u', 'v', 't', 'sigma', 'W', 'Wt')):
+                assert torch.equal(x, y), (shape, what, rep)
+
+
 @pytest.mark.parametrize('B,C,H', [(2, 64, 16), (3, 16, 8), (2, 512, 4), (1, 48, 32), (2, 96, 12), (2, 256, 8), (1, 64, 7),
                                    (2, 8, 32), (2, 32, 8), (1, 24, 9)])
 def test_self_attention_forward_backward(B, C, H):
