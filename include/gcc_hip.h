@@ -104,7 +104,8 @@ enum {
     GCC_OPT_IGEMM_STAGES,       /* 3 (default): the 128-pixel x 32 / 64-column tiles (uniform taps) keep two k-steps of LDS-DMA in flight behind
                                    the one being multiplied (three LDS stages); 2: one (the round-1 loop) */
     GCC_OPT_WGRAD_TS,           /* 1 (default): k4 s1 p1 weight gradients with channels in multiples of 64, >= 32 channel tiles and >= 16 pixel
-                                   blocks per split run tap-stationary (wgrad_ts_kernel: the 16 taps share one staged halo image of the input);
+                                   blocks per split, and k3 s1 p1 ones with channels in multiples of 64 and >= 128 workgroups of >= 8 blocks, run
+                                   tap-stationary (wgrad_ts_kernel<4 / 3>: the 16 / 9 taps share one staged halo image of the input);
                                    2: wherever the geometry fits (tests); 0: wgrad_kernel only */
     GCC_OPT_HALO_XCD_COLS,      /* tile order of igemm_halo_kernel: 0: a pixel tile's column tiles are neighbours on one XCD (its L2 fetches the pixel
                                    slices once, every XCD streams all the weights); 1 (default): the stride-1 form gives every XCD one column tile

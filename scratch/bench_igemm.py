@@ -38,6 +38,22 @@ SHAPES = [
     ('Kscan 128->256 k4s2 @128', 16, 128, 128, 128, 256, 4, 2, 1),
     ('Kscan 256->256 k4s2 @128', 16, 128, 128, 256, 256, 4, 2, 1),
     ('Kscan 512->256 k4s2 @128', 16, 128, 128, 512, 256, 4, 2, 1),
+    # SRGAN 96 -> 384 (N = 16): the discriminator's and VGG19's 3 x 3 layers  (python scratch/bench_igemm.py 10 SR)
+    ('SR D 64->64 k3s2 @384', 16, 384, 384, 64, 64, 3, 2, 1),
+    ('SR D 64->128 k3s1 @192', 16, 192, 192, 64, 128, 3, 1, 1),
+    ('SR D 128->128 k3s2 @192', 16, 192, 192, 128, 128, 3, 2, 1),
+    ('SR D 128->256 k3s1 @96', 16, 96, 96, 128, 256, 3, 1, 1),
+    ('SR D 256->256 k3s2 @96', 16, 96, 96, 256, 256, 3, 2, 1),
+    ('SR D 256->512 k3s1 @48', 16, 48, 48, 256, 512, 3, 1, 1),
+    ('SR D 512->512 k3s2 @48', 16, 48, 48, 512, 512, 3, 2, 1),
+    ('SR VGG 64->64 k3s1 @384', 16, 384, 384, 64, 64, 3, 1, 1),
+    ('SR VGG 128->128 k3s1 @192', 16, 192, 192, 128, 128, 3, 1, 1),
+    ('SR VGG 256->256 k3s1 @96', 16, 96, 96, 256, 256, 3, 1, 1),
+    ('SR VGG 512->512 k3s1 @48', 16, 48, 48, 512, 512, 3, 1, 1),
+    ('SR G 64->64 k3s1 @96', 16, 96, 96, 64, 64, 3, 1, 1),
+    ('SR G 24->24 k3s1 @96', 16, 96, 96, 24, 24, 3, 1, 1),
+    ('SR G 64->256 k3s1 @96', 16, 96, 96, 64, 256, 3, 1, 1),
+    ('SR G 64->256 k3s1 @192', 16, 192, 192, 64, 256, 3, 1, 1),
 ]
 
 
