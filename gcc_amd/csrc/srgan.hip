@@ -32,6 +32,35 @@ __global__ __launch_bounds__(256) void prelu_kernel(const PreluArgs a) {
     const size_t pixels = (size_t)a.N * a.H * a.W;
     const size_t total = pixels * CH;
     float ds = 0.f;
+    if (BWD && a.r == 1) {
+        // the backward of the plain form: two items per trip, all four loads issued before any is used (the launch is capped at
+        // PRELU_BWD_BLOCKS workgroups -- every one of them ends in an atomic on ONE counter, ~10 ns each: 4096 of them were 40 of the
+        // 56 us this kernel took on SRGAN's 19 MB trunk tensors -- so a thread walks several items)
+        const size_t step = (size_t)gridDim.x * 256;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += 2 * step) {
+            const size_t i1 = i + step;
+            const bool has1 = i1 < total;
+            const size_t pix0 = i / CH, pix1 = has1 ? i1 / CH : pix0;
+            const int c00 = (int)(i - pix0 * CH) * 8, c01 = has1 ? (int)(i1 - pix1 * CH) * 8 : c00;
+            const i32x4 rx0 = *(const i32x4*)(a.x + pix0 * a.ldx + c00), rg0 = *(const i32x4*)(a.dy + pix0 * a.lddy + c00);
+            const i32x4 rx1 = *(const i32x4*)(a.x + pix1 * a.ldx + c01), rg1 = *(const i32x4*)(a.dy + pix1 * a.lddy + c01);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (u == 1 && !has1) break;
+                float xv[8], gv[8], ov[8];
+                unpack8(u ? rx1 : rx0, xv);
+                unpack8(u ? rg1 : rg0, gv);
+                const int c0 = u ? c01 : c00;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const bool live = c0 + j < a.C;
+                    ov[j] = live ? (xv[j] > 0.f ? gv[j] : s * gv[j]) : 0.f;
+                    if (live && xv[j] <= 0.f) ds += gv[j] * xv[j];
+                }
+                *(i32x4*)(a.dx + (u ? pix1 : pix0) * a.lddx + c0) = pack8(ov);
+            }
+        }
+    } else
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t pix = i / CH;
         const int c0 = (int)(i - pix * CH) * 8;
@@ -104,13 +133,23 @@ __global__ __launch_bounds__(256) void prelu_kernel(const PreluArgs a) {
         typedef __attribute__((address_space(1))) unsigned int gu32;
         gu32* cnt = (gu32*)a.counter;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.partial, 0, gridDim.x * 4, 0x00020000);
+        // arrivals in two levels (an atomic on one address costs ~10 ns per arrival whatever the workgroup count: 1024 arrivals on
+        // one word were 10 of this kernel's 24 us): 32 counters, one per blockIdx.x & 31, and the last arrival of each moves on
+        // to the top word.  Words 0 (top) and 1..32 of the workspace head; all of them zero before and after the launch.
         if (threadIdx.x == 0) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), rs, blockIdx.x * 4, 0, 16);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            sh[0] = __uint_as_float(__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const unsigned sub = blockIdx.x & 31u;
+            const unsigned nsub = (gridDim.x - sub + 31u) / 32u, ntop = gridDim.x < 32u ? gridDim.x : 32u;
+            unsigned lastf = 0;
+            if (__hip_atomic_fetch_add(cnt + 1 + sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsub - 1) {
+                __hip_atomic_store(cnt + 1 + sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lastf = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ntop - 1 ? 1u : 0u;
+            }
+            sh[0] = __uint_as_float(lastf);
         }
         __syncthreads();
-        const bool last = __float_as_uint(sh[0]) == gridDim.x - 1;
+        const bool last = __float_as_uint(sh[0]) == 1u;
         __syncthreads();
         if (!last) return;
         float acc = 0.f;
@@ -237,6 +276,7 @@ __global__ __launch_bounds__(256) void linear_head_wgrad_kernel(const bf16_t* __
     }
 }
 
+constexpr int PRELU_BWD_BLOCKS = 1024;
 int grid_for(size_t items, int cap = 4096) {
     size_t b = (items + 255) / 256;
     return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
@@ -261,7 +301,7 @@ extern "C" int gcc_prelu(int backward, const void* x, int ldx, const float* slop
         a.counter = (unsigned*)workspace;
         a.partial = (float*)((char*)workspace + 256);
     }
-    if (backward) hipLaunchKernelGGL(prelu_kernel<true>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, a);
+    if (backward) hipLaunchKernelGGL(prelu_kernel<true>, dim3(grid_for(items, shuffle == 1 ? PRELU_BWD_BLOCKS : 4096)), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(prelu_kernel<false>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, a);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
