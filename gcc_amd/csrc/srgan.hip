@@ -165,10 +165,12 @@ __global__ __launch_bounds__(256) void prelu_kernel(const PreluArgs a) {
 
 // ---- MaxPool2d(2, 2) ------------------------------------------------------------------------------
 // backward routes dy to the first maximum of the window in (h, w) scan order, as ATen's max_pool2d_with_indices does
+// relu_mask (backward): x is the output of a ReLU -- the gradient that reaches a position whose x is not positive is dropped here, so
+// that the ReLU's own backward pass over the (four times larger) input map is not needed
 template <bool BWD>
 __global__ __launch_bounds__(256) void maxpool_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
                                                       const bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict__ dx, int lddx,
-                                                      int N, int Ho, int Wo, int C) {
+                                                      int N, int Ho, int Wo, int C, int relu_mask) {
     const int CH = (C + 7) / 8;
     const size_t total = (size_t)N * Ho * Wo * CH;
     const int Hi = 2 * Ho, Wi = 2 * Wo;
@@ -200,8 +202,9 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const bf16_t* __restrict__
 #pragma unroll
                 for (int q = 1; q < 4; q++)
                     if (v[q][j] > v[best][j]) best = q;
+                const float gj = (relu_mask && !(v[best][j] > 0.f)) ? 0.f : g[j];
 #pragma unroll
-                for (int q = 0; q < 4; q++) o[q][j] = (q == best) ? g[j] : 0.f;
+                for (int q = 0; q < 4; q++) o[q][j] = (q == best) ? gj : 0.f;
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) *(i32x4*)(dx + ip[q] * lddx + c0) = pack8(o[q]);
@@ -315,10 +318,10 @@ extern "C" int gcc_maxpool2x2(int backward, const void* x, int ldx, void* y, int
     const size_t items = (size_t)N * Ho * Wo * ((C + 7) / 8);
     if (backward)
         hipLaunchKernelGGL(maxpool_kernel<true>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                           (bf16_t*)nullptr, 0, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, N, Ho, Wo, C);
+                           (bf16_t*)nullptr, 0, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, N, Ho, Wo, C, backward == 2 ? 1 : 0);
     else
         hipLaunchKernelGGL(maxpool_kernel<false>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                           (bf16_t*)y, ldy, (const bf16_t*)nullptr, 0, (bf16_t*)nullptr, 0, N, Ho, Wo, C);
+                           (bf16_t*)y, ldy, (const bf16_t*)nullptr, 0, (bf16_t*)nullptr, 0, N, Ho, Wo, C, 0);
     GCC_CHECK_LAUNCH();
     return GCC_OK;
 }

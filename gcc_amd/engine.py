@@ -1901,9 +1901,12 @@ class VGGEngine:
             src = c.act[i - 1] if i > 0 else c.x_in
             dst = gact[i - 1] if i > 0 else gx
             if kind == 'conv':
-                ops.bnact_bwd(c.act[i], None, g, g, in_act=ACT_RELU)
+                # (behind a max pool the ReLU's backward was applied by the pool's: maxpool_bwd(relu_mask=True) below)
+                if not (i + 1 < len(self.layers) and self.layers[i + 1][0] == 'pool'):
+                    ops.bnact_bwd(c.act[i], None, g, g, in_act=ACT_RELU)
                 conv.backward_data(g, dst)
             else:
-                ops.maxpool_bwd(src, g, dst)
+                # src = the ReLU'd output of the conv in front of the pool (always a conv in VGG19): its mask rides along
+                ops.maxpool_bwd(src, g, dst, relu_mask=i > 0 and self.layers[i - 1][0] == 'conv')
             g = dst
         return gx

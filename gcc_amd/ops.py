@@ -1255,11 +1255,12 @@ def maxpool_fwd(x, y):
     check(lib().gcc_maxpool2x2(0, xp, ldx, yp, ldy, None, 0, None, 0, N, Ho, Wo, Cc, stream()), 'gcc_maxpool2x2')
 
 
-def maxpool_bwd(x, dy, dx):
+def maxpool_bwd(x, dy, dx, relu_mask=False):
+    """relu_mask: x is a ReLU's output and dx is to be the gradient w.r.t. the ReLU's INPUT (its mask applied on the way)"""
     xp, N, Cc, H, W, ldx = geom(x)
     dyp, _, _, Ho, Wo, lddy = geom(dy)
     dxp, _, _, _, _, lddx = geom(dx)
-    check(lib().gcc_maxpool2x2(1, xp, ldx, None, 0, dyp, lddy, dxp, lddx, N, Ho, Wo, Cc, stream()), 'gcc_maxpool2x2')
+    check(lib().gcc_maxpool2x2(2 if relu_mask else 1, xp, ldx, None, 0, dyp, lddy, dxp, lddx, N, Ho, Wo, Cc, stream()), 'gcc_maxpool2x2')
 
 
 def pool_linear_fwd(x, w, b, pooled, logit):

@@ -567,9 +567,10 @@ int gcc_attention_bwd(const void* qkv, int ldq, int qoff, int koff, int voff, co
  * in front of it (SubPixelConvolutionalBlock, :68-99): shuffle == 2 reads x [N][H][W][4C] and writes y [N][2H][2W][C],
  * y[n][2h+i][2w+j][c] = prelu(x[n][h][w][4c+2i+j]).  backward != 0: dx (layout of x) from dy (layout of y), and
  * dslope (+=, may be NULL: the distillation optimizer of the reference leaves the PReLU slopes out, :349-352); with a
- * workspace (GCC_PRELU_WORKSPACE_BYTES, zero-filled once by the caller, one per stream; its first word is zero again after
+ * workspace (GCC_PRELU_WORKSPACE_BYTES, zero-filled once by the caller, one per stream; its first 33 words -- the arrival counters -- are zero again after
  * every call) the sum behind dslope is formed in a fixed order -- bit-reproducible; without one (NULL) by atomic adds.
- * gcc_maxpool2x2: nn.MaxPool2d(2, 2) of the VGG stack; backward routes to the first maximum in scan order.
+ * gcc_maxpool2x2: nn.MaxPool2d(2, 2) of the VGG stack; backward (1) routes to the first maximum in scan order; backward == 2: x is
+ * the output of a ReLU and the ReLU's backward is applied on the way (a gradient whose maximum is not positive is dropped).
  * gcc_pool_linear_*: AdaptiveAvgPool2d((1,1)) + Linear(C, 1) of the discriminators (:245-262): pooled [N][C] fp32 is
  * kept for the backward pass, logit is bf16 [N][ldl] (one pixel per image, as gcc_gan_loss reads it). */
 int gcc_prelu(int backward, const void* x, int ldx, const float* slope, int C, int N, int H, int W, int shuffle,

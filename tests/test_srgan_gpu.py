@@ -67,6 +67,15 @@ def test_maxpool_pool_linear_mse():
     dx = ops.new_act(N, C, H, W, DEV)
     ops.maxpool_bwd(xd, _to_nhwc(ops, dy), dx)
     assert torch.equal(ops.nhwc_to_nchw(dx, C).cpu(), xr.grad)
+    # the pool's backward with the ReLU in front of it folded in (VGGEngine.backward): x = relu(z), the gradient w.r.t. z
+    z = _rb(torch.randn(N, C, H, W, generator=g))
+    z[0, :, :2, :2] = -1.0                                   # a whole window without a positive value
+    zr = z.clone().requires_grad_(True)
+    (F.max_pool2d(F.relu(zr), 2, 2) * dy).sum().backward()
+    ad = _to_nhwc(ops, F.relu(z))
+    dz = ops.new_act(N, C, H, W, DEV)
+    ops.maxpool_bwd(ad, _to_nhwc(ops, dy), dz, relu_mask=True)
+    assert torch.equal(ops.nhwc_to_nchw(dz, C).cpu(), zr.grad)
     # global average pool + Linear(C, 1)
     w, b = torch.randn(1, C, generator=g) * 0.2, torch.randn(1, generator=g)
     xr2, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
